@@ -1,0 +1,243 @@
+/*
+ * tilespmv.h — C ABI of the MI355X-native TileSpMV engine (libtilespmv_f64.so / libtilespmv_f32.so).
+ *
+ * Drop-in boundary for the y = A*x hot path of SuperScientificSoftwareLaboratory/TileSpMV.
+ * The reference has no FFI layer: "the API" is the set of C functions its driver calls
+ * (reference src/main.cu:63,87,142,165) plus the CLI.  Every entry point below names the
+ * reference interface it replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Value type is a build-time choice exactly like the reference (src/common.h:12-14,
+ * src/Makefile:5,23):  libtilespmv_f64.so  <=>  -D MAT_VAL_TYPE=double
+ *                      libtilespmv_f32.so  <=>  -D MAT_VAL_TYPE=float
+ * Both libraries export the same symbol names.
+ */
+#ifndef TILESPMV_H_
+#define TILESPMV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef MAT_VAL_TYPE
+#define MAT_VAL_TYPE double /* reference src/common.h:12-14 */
+#endif
+#ifndef MAT_PTR_TYPE
+#define MAT_PTR_TYPE int /* reference src/common.h:25-27 */
+#endif
+
+/* Compile-time constants the tile format is defined by (reference src/common.h:37-63). */
+#define TILESPMV_BLOCK_SIZE 16       /* BLOCK_SIZE */
+#define TILESPMV_COO_NNZ_TH 12       /* COO_NNZ_TH */
+#define TILESPMV_PREFETCH_SMEM_TH 4  /* PREFETCH_SMEM_TH: tiles per row-block chunk */
+
+/* Per-tile format tags stored in Tile_matrix.Format (reference src/csr2tile.h:154-319). */
+enum {
+    TILESPMV_FMT_CSR = 0,
+    TILESPMV_FMT_COO = 1,
+    TILESPMV_FMT_ELL = 2,
+    TILESPMV_FMT_HYB = 3,
+    TILESPMV_FMT_DNS = 4,
+    TILESPMV_FMT_DNSROW = 5,
+    TILESPMV_FMT_DNSCOL = 6
+};
+
+/*
+ * Tile_matrix — field names, order and types are those of reference src/format.h:3-56
+ * (tests and callers read the fields by name).  Semantics after Tile_create are listed in
+ * arrays of length tilenum+1 are exclusive prefixes.
+ */
+typedef struct {
+    int tilem;
+    int tilen;
+    int tilenum;
+    MAT_PTR_TYPE *tile_ptr;
+    int *tile_columnidx;
+    int *tile_nnz;
+    char *Format;
+    int *blknnz;
+    unsigned char *blknnznnz;
+    int *dnsrowptr;
+    int *dnscolptr;
+    char *tilewidth;
+    int *csr_offset;
+    int *csrptr_offset;
+    int *coo_offset;
+    int *ell_offset;
+    int *hyb_offset;
+    int *hyb_coocount;
+    int *dns_offset;
+    int *dnsrow_offset;
+    int *dnscol_offset;
+    int *new_coocount;
+    MAT_VAL_TYPE *Blockcsr_Val;
+    unsigned char *Blockcsr_Ptr;
+    unsigned char *csr_compressedIdx;
+    int csrsize;
+    int csrptrlen;
+    MAT_VAL_TYPE *Blockcoo_Val;
+    unsigned char *coo_compressed_Idx;
+    int coosize;
+    MAT_VAL_TYPE *Blockell_Val;
+    unsigned char *ell_compressedIdx;
+    int ellsize;
+    MAT_VAL_TYPE *Blockhyb_Val;
+    unsigned char *hybIdx;
+    int hybsize;
+    int hybellsize;
+    int hybcoosize;
+    MAT_VAL_TYPE *Blockdense_Val;
+    int dnssize;
+    MAT_VAL_TYPE *Blockdenserow_Val;
+    char *denserowid;
+    int dnsrowsize;
+    MAT_VAL_TYPE *Blockdensecol_Val;
+    char *densecolid;
+    int dnscolsize;
+    int coototal;
+    MAT_VAL_TYPE *deferredcoo_val;
+    int *deferredcoo_colidx;
+    MAT_PTR_TYPE *deferredcoo_ptr;
+} Tile_matrix;
+
+/* ------------------------------------------------------------------------------------------
+ * Host preprocessing (kept API).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces reference src/csr2tile.h:629-635.  Caller owns the struct, callee mallocs every
+ * member array; inputs are borrowed and not modified.  Prints "\n  The number of tile = %i\n"
+ * (reference src/csr2tile.h:661).  Output is byte-identical to the reference's. */
+void Tile_create(Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA,
+                 MAT_PTR_TYPE *csrRowPtrA, int *csrColIdxA, MAT_VAL_TYPE *csrValA);
+
+/* Same as Tile_create with option bits.  TILESPMV_CREATE_HYB enables the HYB selection rule
+ * that is commented out in the shipped reference (src/csr2tile.h:308-316);
+ * TILESPMV_CREATE_QUIET suppresses the stdout line. */
+#define TILESPMV_CREATE_HYB 1u
+#define TILESPMV_CREATE_QUIET 2u
+void Tile_create_ex(Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA,
+                    const MAT_PTR_TYPE *csrRowPtrA, const int *csrColIdxA,
+                    const MAT_VAL_TYPE *csrValA, unsigned flags);
+
+/* Replaces reference src/format.h:58-94: frees the member arrays (all of them, including the
+ * four the reference leaks), not the struct. */
+void Tile_destroy(Tile_matrix *matrix);
+
+/* Replaces reference src/tilespmv_cpu.h:3-18: builds the row-block schedule
+ * (ptroffset1/2[tilenum] caller-allocated; rowblkblock and the three chunk arrays are
+ * malloc'd here and owned by the caller), computes y = A*x serially on the host in tile
+ * order, compares with y_golden (exact) and prints " Run CPU TileSpMV, errcount = %i\n".
+ * Host-side schedule builder + host check only — the GPU path never calls it. */
+void tilespmv_cpu(Tile_matrix *matrix, int *ptroffset1, int *ptroffset2, int *rowblkblock,
+                  unsigned int **blkcoostylerowidx, int **blkcoostylerowidx_colstart,
+                  int **blkcoostylerowidx_colstop, int rowA, int colA, MAT_PTR_TYPE nnzA,
+                  MAT_PTR_TYPE *csrRowPtrA, int *csrColIdxA, MAT_VAL_TYPE *csrValA,
+                  MAT_VAL_TYPE *x, MAT_VAL_TYPE *y, MAT_VAL_TYPE *y_golden);
+
+/* Replaces reference src/mmio_highlevel.h:593-759.  Returns 0, -1 (open), -2 (banner),
+ * -4 (size line).  Entries land in file order; symmetric/hermitian files are mirrored,
+ * skew-symmetric are not; pattern -> 1.0; complex keeps the real part. */
+int mmio_allinone(int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric, MAT_PTR_TYPE **csrRowPtr,
+                  int **csrColIdx, MAT_VAL_TYPE **csrVal, char *filename);
+
+/* ------------------------------------------------------------------------------------------
+ * GPU hot path.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces call_tilespmv_cuda, reference src/tilespmv_cuda.h:794-809 (same argument list and
+ * meaning; all pointers are HOST pointers; alpha is accepted and ignored like the reference).
+ * Uploads the tiled matrix to the current HIP device, runs WARMUP_NUM warm-up and
+ * BENCH_REPEAT timed SpMVs (env TILESPMV_WARMUP / TILESPMV_BENCH_REPEAT override 200 / 1000),
+ * prints "  CUDA SpMV runtime %4.2f ms, %4.2f GFlops\n\n" (kept verbatim for log parsers,
+ * reference :1139) plus one added "  HIP ..." line, appends "file,rowA,colA,nnzA,ms,gflops"
+ * to ./results.csv (reference :1142-1147) and copies y back.  Aborts with a message and a
+ * non-zero exit status on any HIP error (the reference checks nothing). */
+void call_tilespmv_hip(char *filename, Tile_matrix *matrix, int *ptroffset1, int *ptroffset2,
+                       int rowblkblock, unsigned int *blkcoostylerowidx,
+                       int *blkcoostylerowidx_colstart, int *blkcoostylerowidx_colstop, int rowA,
+                       int colA, MAT_PTR_TYPE nnzA, MAT_PTR_TYPE *csrRowPtrA, int *csrColIdxA,
+                       MAT_VAL_TYPE *csrValA, MAT_VAL_TYPE alpha, MAT_VAL_TYPE *x,
+                       MAT_VAL_TYPE *y, MAT_VAL_TYPE *y_golden);
+
+/*
+ * Resident-plan API (new; what call_tilespmv_hip is built from).  A plan owns the device
+ * copy of one Tile_matrix (or of one contiguous block of its tile-rows: the multi-GPU shard),
+ * re-laid-out for CDNA4.  x / y are DEVICE pointers; stream is a hipStream_t passed as void*.
+ */
+typedef struct tilespmv_plan tilespmv_plan;
+
+/* How COO tiles (and HYB remainders) are executed — reference has both paths
+ * (in-kernel deferred COO: src/tilespmv_cuda.h:462-488; extracted CSR + CSR5: :1011-1029,:1080). */
+#define TILESPMV_COO_AUTO 0      /* pick by modelled bytes */
+#define TILESPMV_COO_IN_TILE 1   /* COO tile kernel inside the fused launch */
+#define TILESPMV_COO_FALLBACK 2  /* very-sparse CSR fallback kernel (y += A_coo x) */
+
+/* Dense-tile arithmetic. */
+#define TILESPMV_DENSE_AUTO 0
+#define TILESPMV_DENSE_MFMA 1  /* v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 */
+#define TILESPMV_DENSE_VALU 2
+
+/* Fused-kernel generation. */
+#define TILESPMV_KERNEL_AUTO 0
+#define TILESPMV_KERNEL_DIRECT 1  /* strip-per-16-lanes, direct global loads */
+#define TILESPMV_KERNEL_STAGED 2  /* wave-private LDS staging of the payload stream */
+
+typedef struct {
+    int coo_mode;       /* TILESPMV_COO_*    */
+    int dense_mode;     /* TILESPMV_DENSE_*  */
+    int kernel;         /* TILESPMV_KERNEL_* */
+    int tilerow_begin;  /* shard: first tile-row (0 for the whole matrix) */
+    int tilerow_end;    /* shard: one past the last tile-row (<=0 means tilem) */
+    int reserved[3];
+} tilespmv_plan_options;
+
+/* Returns 0 on success, non-zero (message on stderr) when no HIP device / extension is
+ * usable — there is no CPU fallback behind this entry point. */
+int tilespmv_plan_create(tilespmv_plan **plan, const Tile_matrix *matrix, int rowA, int colA,
+                         MAT_PTR_TYPE nnzA, const tilespmv_plan_options *opts);
+void tilespmv_plan_destroy(tilespmv_plan *plan);
+
+/* y[16*tilerow_begin .. 16*tilerow_end) = A_shard * x.  d_x has colA elements, d_y points at
+ * element 0 of the FULL-length y (the shard writes only its own rows).  Asynchronous on
+ * `stream`.  Returns a hipError_t value (0 = success). */
+int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y,
+                       void *stream);
+
+/* Plan facts for reports: index into `out` by TILESPMV_INFO_*. */
+enum {
+    TILESPMV_INFO_DEVICE_BYTES = 0,   /* bytes of the resident plan */
+    TILESPMV_INFO_STREAM_BYTES = 1,   /* bytes one SpMV must read/write at least (plan model) */
+    TILESPMV_INFO_NNZ = 2,            /* true nonzeros covered by the shard */
+    TILESPMV_INFO_ROWS = 3,
+    TILESPMV_INFO_TILES = 4,
+    TILESPMV_INFO_COO_MODE = 5,       /* resolved mode */
+    TILESPMV_INFO_DENSE_MODE = 6,
+    TILESPMV_INFO_KERNEL = 7,
+    TILESPMV_INFO_NUM_TASKS = 8,
+    TILESPMV_INFO_NUM_SPLIT_ROWS = 9,
+    TILESPMV_INFO_FALLBACK_NNZ = 10,  /* nonzeros executed by the CSR fallback kernel */
+    TILESPMV_INFO_COUNT = 16
+};
+void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
+
+/* Times `reps` back-to-back SpMVs on `stream` with hipEvents recorded on that stream (after
+ * `warmup` untimed ones) and returns the mean milliseconds per SpMV, or a negative value on
+ * error.  Used by bench.py for the live per-launch figure. */
+double tilespmv_plan_time(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y,
+                          void *stream, int warmup, int reps);
+
+/* Multi-GPU helper: nnz-balanced contiguous tile-row partition (new; the reference is
+ * single-GPU, src/main.cu:74).  Writes nparts+1 tile-row boundaries. */
+void tilespmv_partition_tilerows(const Tile_matrix *matrix, int nparts, int *bounds);
+
+/* Library facts. */
+int tilespmv_sizeof_value(void);    /* 8 or 4 */
+const char *tilespmv_version(void);
+int tilespmv_device_count(void);    /* 0 when no HIP device is visible */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TILESPMV_H_ */

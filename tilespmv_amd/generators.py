@@ -1,0 +1,202 @@
+"""Deterministic synthetic CSR matrices for the BASELINE configs and the parity tests.
+
+No SuiteSparse file ships with the reference and there is no network, so each
+BASELINE config has a generator with the same shape / nnz class; a real ``.mtx`` is used
+instead when ``$TILESPMV_MATRIX_DIR/<name>.mtx`` exists (see ``bench.py``).
+
+All generators return ``(rows, cols, rowptr[int32], colidx[int32])``; values are assigned by
+the caller: ``compat_values`` reproduces the reference driver's synthetic data
+(``val[i] = i % 10``, ``x[i] = i % 10``: reference src/main.cu:68-69, :93-97).
+"""
+import numpy as np
+
+
+def compat_values(nnz, dtype=np.float64):
+    return (np.arange(nnz, dtype=np.int64) % 10).astype(dtype)
+
+
+def compat_x(n, dtype=np.float64):
+    return (np.arange(n, dtype=np.int64) % 10).astype(dtype)
+
+
+def _from_mask(cand, mask):
+    """cand/mask: (rows, k) candidate columns in the wanted per-row order + validity."""
+    counts = mask.sum(axis=1, dtype=np.int64)
+    rowptr = np.zeros(cand.shape[0] + 1, dtype=np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    colidx = cand[mask].astype(np.int32)
+    assert rowptr[-1] < 2**31
+    return rowptr.astype(np.int32), colidx
+
+
+def laplacian5pt(n):
+    """5-point stencil on an n x n row-major grid; per-row order up,left,centre,right,down
+    (SURVEY.md §8c known-answer generator; BASELINE config 4 is n=4096)."""
+    N = n * n
+    idx = np.arange(N, dtype=np.int64)
+    i, j = idx // n, idx % n
+    cand = np.stack([idx - n, idx - 1, idx, idx + 1, idx + n], axis=1)
+    mask = np.stack([i > 0, j > 0, np.ones(N, bool), j < n - 1, i < n - 1], axis=1)
+    rowptr, colidx = _from_mask(cand, mask)
+    return N, N, rowptr, colidx
+
+
+def band(n, hbw, ncols=None):
+    """Full band: row r holds columns r-hbw..r+hbw (clipped), ascending."""
+    ncols = n if ncols is None else ncols
+    r = np.arange(n, dtype=np.int64)[:, None]
+    cand = r + np.arange(-hbw, hbw + 1, dtype=np.int64)[None, :]
+    mask = (cand >= 0) & (cand < ncols)
+    rowptr, colidx = _from_mask(cand, mask)
+    return n, ncols, rowptr, colidx
+
+
+def from_coo(rows, cols, ri, ci, sort_cols=True):
+    """CSR from coordinate lists (duplicates removed); columns ascending inside a row."""
+    ri = np.asarray(ri, dtype=np.int64); ci = np.asarray(ci, dtype=np.int64)
+    key = np.unique(ri * cols + ci)
+    ri, ci = key // cols, key % cols
+    rowptr = np.zeros(rows + 1, dtype=np.int64)
+    np.add.at(rowptr, ri + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    return rows, cols, rowptr.astype(np.int32), ci.astype(np.int32)
+
+
+def random_uniform(rows, cols, density, seed):
+    rng = np.random.default_rng(seed)
+    nnz = int(rows * cols * density)
+    return from_coo(rows, cols, rng.integers(0, rows, nnz), rng.integers(0, cols, nnz))
+
+
+def all_formats(nblk=12, seed=7, cols_pad=0):
+    """Small matrix whose 16x16 tiles are built on purpose to hit every selection rule of
+    reference src/csr2tile.h:143-325: dense, COO, dense-row, dense-col, ELL, CSR and (only when
+    the HYB rule is enabled) HYB.  ``cols_pad`` > 0 makes the last tile column partial."""
+    rng = np.random.default_rng(seed)
+    rows = 16 * nblk
+    cols = 16 * nblk - (16 - cols_pad if cols_pad else 0)
+    R, Cc = [], []
+
+    def put(bi, bj, lr, lc):
+        lr = np.asarray(lr); lc = np.asarray(lc)
+        ok = (16 * bj + lc) < cols
+        R.extend((16 * bi + lr[ok]).tolist()); Cc.extend((16 * bj + lc[ok]).tolist())
+
+    g = np.arange(16)
+    for bi in range(nblk):
+        kinds = ["dense", "coo", "dnsrow", "dnscol", "ell", "csr", "hyb", "ell1", "coo1", "dense75"]
+        if bi % 3 == 1:
+            kinds = kinds[bi % 4::3]  # short tile-rows (<= 4 tiles: not split by the schedule)
+        for k, kind in enumerate(kinds):
+            bj = (bi + k) % nblk if bi % 2 == 0 else (bi + nblk - k) % nblk
+            if kind == "dense":
+                lr, lc = np.meshgrid(g, g, indexing="ij"); put(bi, bj, lr.ravel(), lc.ravel())
+            elif kind == "dense75":
+                m = rng.random((16, 16)) < 0.85
+                lr, lc = np.nonzero(m); put(bi, bj, lr, lc)
+            elif kind == "coo":
+                n = int(rng.integers(1, 13)); p = rng.choice(256, n, replace=False); put(bi, bj, p // 16, p % 16)
+            elif kind == "coo1":
+                put(bi, bj, np.array([int(rng.integers(16))]), np.array([int(rng.integers(16))]))
+            elif kind == "dnsrow":
+                rs = rng.choice(16, int(rng.integers(1, 6)), replace=False)
+                lr, lc = np.meshgrid(rs, g, indexing="ij"); put(bi, bj, lr.ravel(), lc.ravel())
+            elif kind == "dnscol":
+                cs = rng.choice(16, int(rng.integers(1, 6)), replace=False)
+                lr, lc = np.meshgrid(g, cs, indexing="ij"); put(bi, bj, lr.ravel(), lc.ravel())
+            elif kind == "ell":
+                w = int(rng.integers(2, 7))
+                for r in range(16):
+                    put(bi, bj, np.full(w, r), rng.choice(16, w, replace=False))
+            elif kind == "ell1":
+                put(bi, bj, g, (g + bi) % 16)
+            elif kind == "csr":
+                for r in range(16):
+                    w = int(rng.integers(0, 9))
+                    if w: put(bi, bj, np.full(w, r), rng.choice(16, w, replace=False))
+            elif kind == "hyb":  # ten 1-entry rows + one long row: variation >= 1, remainder <= 4
+                rs = rng.choice(16, 11, replace=False)
+                for r in rs[:10]:
+                    put(bi, bj, np.array([r]), np.array([int(rng.integers(16))]))
+                put(bi, bj, np.full(4, rs[10]), rng.choice(16, 4, replace=False))
+    return from_coo(rows, cols, R, Cc)
+
+
+def powerlaw(n, seed=2, alpha=2.1, maxdeg=4700, near=30):
+    """webbase-1M stand-in (BASELINE config 3): Zipf(alpha) out-degrees, half the targets near
+    the diagonal (+-near), half Pareto-popular columns; n x n."""
+    rng = np.random.default_rng(seed)
+    deg = np.minimum(rng.zipf(alpha, n), maxdeg).astype(np.int64)
+    tot = int(deg.sum())
+    ri = np.repeat(np.arange(n, dtype=np.int64), deg)
+    local = rng.random(tot) < 0.5
+    off = rng.integers(-near, near + 1, tot)
+    pop = np.minimum((rng.pareto(1.2, tot) * (n / 2000.0)).astype(np.int64), n - 1)
+    ci = np.where(local, np.clip(ri + off, 0, n - 1), pop)
+    return from_coo(n, n, ri, ci)
+
+
+def circuit_like(n, seed=1, avg_off=4.6, ndense=6):
+    """scircuit stand-in (BASELINE config 2): diagonal + a few local off-diagonals per row + a
+    handful of dense rows/columns, plus injected 16x16 block patterns so that every tile format
+    occurs."""
+    rng = np.random.default_rng(seed)
+    k = rng.poisson(avg_off, n).astype(np.int64)
+    ri = np.repeat(np.arange(n, dtype=np.int64), k)
+    span = np.where(rng.random(ri.size) < 0.8, 40, n)
+    ci = np.clip(ri + (rng.standard_normal(ri.size) * span).astype(np.int64), 0, n - 1)
+    R = [np.arange(n, dtype=np.int64), ri]; Cc = [np.arange(n, dtype=np.int64), ci]
+    hubs = rng.choice(n, ndense, replace=False)
+    for h in hubs:
+        m = rng.choice(n, n // 400, replace=False)
+        R += [np.full(m.size, h), m]; Cc += [m, np.full(m.size, h)]
+    g = np.arange(16)
+    nb = n // 16
+    for b in rng.choice(nb - 1, min(200, nb - 1), replace=False):
+        kind = int(rng.integers(0, 5)); bj = int(rng.integers(0, nb - 1))
+        if kind == 0: lr, lc = np.meshgrid(g, g, indexing="ij")
+        elif kind == 1: lr, lc = np.meshgrid(rng.choice(16, 3, replace=False), g, indexing="ij")
+        elif kind == 2: lr, lc = np.meshgrid(g, rng.choice(16, 3, replace=False), indexing="ij")
+        elif kind == 3: lr, lc = np.repeat(g, 3), rng.integers(0, 16, 48)
+        else:
+            lr = np.concatenate([g[:10], np.full(4, 12)]); lc = rng.integers(0, 16, 14)
+        R.append(16 * b + lr.ravel()); Cc.append(16 * bj + lc.ravel())
+    return from_coo(n, n, np.concatenate(R), np.concatenate(Cc))
+
+
+def kkt_like(g, seed=5):
+    """nlpkkt160 stand-in (BASELINE config 5): symmetric [[H, A^T],[A, 0]] on a g^3 grid —
+    H is a 27-point stencil on g^3 unknowns, A couples each of the g^3 constraints to a 7-point
+    neighbourhood.  g=160 gives 8.19 M rows and ~2.2e8 nnz."""
+    n = g * g * g
+    idx = np.arange(n, dtype=np.int64)
+    z, y, x = idx // (g * g), (idx // g) % g, idx % g
+    Rs, Cs = [], []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                ok = (z + dz >= 0) & (z + dz < g) & (y + dy >= 0) & (y + dy < g) & (x + dx >= 0) & (x + dx < g)
+                Rs.append(idx[ok]); Cs.append(idx[ok] + (dz * g + dy) * g + dx)
+    for dz, dy, dx in ((0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
+        ok = (z + dz >= 0) & (z + dz < g) & (y + dy >= 0) & (y + dy < g) & (x + dx >= 0) & (x + dx < g)
+        a_r = n + idx[ok]; a_c = idx[ok] + (dz * g + dy) * g + dx
+        Rs += [a_r, a_c]; Cs += [a_c, a_r]
+    R = np.concatenate(Rs); Cc = np.concatenate(Cs)
+    order = np.lexsort((Cc, R))
+    R, Cc = R[order], Cc[order]
+    rowptr = np.zeros(2 * n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(R, minlength=2 * n), out=rowptr[1:])
+    return 2 * n, 2 * n, rowptr.astype(np.int32), Cc.astype(np.int32)
+
+
+def write_mtx(path, rows, cols, rowptr, colidx, vals=None, field="real"):
+    """Write a general coordinate Matrix Market file in CSR (row-major) order."""
+    ri = np.repeat(np.arange(rows), np.diff(rowptr))
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate %s general\n" % field)
+        f.write("%d %d %d\n" % (rows, cols, len(colidx)))
+        if field == "pattern":
+            for r, c in zip(ri, colidx): f.write("%d %d\n" % (r + 1, c + 1))
+        else:
+            v = np.ones(len(colidx)) if vals is None else vals
+            for r, c, a in zip(ri, colidx, v): f.write("%d %d %.17g\n" % (r + 1, c + 1, a))
