@@ -1,0 +1,98 @@
+"""Loads the in-tree C-ABI libraries (``tilespmv_amd/lib/libtilespmv_{f64,f32}.so``).
+
+There is deliberately no fallback: if the HIP extension has not been built the import of the
+library raises, and the GPU entry points return an error / abort when no device is visible.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .tile_matrix import TileMatrixF32, TileMatrixF64
+
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+_I = C.POINTER(C.c_int)
+_U = C.POINTER(C.c_uint)
+_CACHE = {}
+
+INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel",
+              "num_tasks", "num_split_rows", "fallback_nnz"]
+
+
+class PlanOptions(C.Structure):
+    _fields_ = [("coo_mode", C.c_int), ("dense_mode", C.c_int), ("kernel", C.c_int),
+                ("tilerow_begin", C.c_int), ("tilerow_end", C.c_int), ("reserved", C.c_int * 3)]
+
+
+def lib_path(dtype):
+    suf = "f64" if np.dtype(dtype) == np.float64 else "f32"
+    return os.path.join(_ROOT, "lib", "libtilespmv_%s.so" % suf)
+
+
+def build(verbose=False):
+    """Compile the HIP/C++ sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_ROOT, "csrc"), "-j8", "all"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building tilespmv_amd/csrc failed")
+    return [lib_path(np.float64), lib_path(np.float32)]
+
+
+def load(dtype=np.float64):
+    dtype = np.dtype(dtype)
+    if dtype in _CACHE:
+        return _CACHE[dtype]
+    path = lib_path(dtype)
+    if not os.path.exists(path):
+        raise RuntimeError("HIP extension %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or `make -C tilespmv_amd/csrc`); there is no CPU fallback" % path)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL if False else C.RTLD_LOCAL)
+    vt = C.c_double if dtype == np.float64 else C.c_float
+    TM = TileMatrixF64 if dtype == np.float64 else TileMatrixF32
+    VP, TP = C.POINTER(vt), C.POINTER(TM)
+    assert lib.tilespmv_sizeof_value() == dtype.itemsize
+    lib.Tile_create.argtypes = [TP, C.c_int, C.c_int, C.c_int, _I, _I, VP]
+    lib.Tile_create.restype = None
+    lib.Tile_create_ex.argtypes = [TP, C.c_int, C.c_int, C.c_int, _I, _I, VP, C.c_uint]
+    lib.Tile_create_ex.restype = None
+    lib.Tile_destroy.argtypes = [TP]
+    lib.Tile_destroy.restype = None
+    lib.tilespmv_cpu.argtypes = [TP, _I, _I, _I, C.POINTER(_U), C.POINTER(_I), C.POINTER(_I), C.c_int, C.c_int, C.c_int,
+                                 _I, _I, VP, VP, VP, VP]
+    lib.tilespmv_cpu.restype = None
+    lib.mmio_allinone.argtypes = [_I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(VP), C.c_char_p]
+    lib.mmio_allinone.restype = C.c_int
+    lib.call_tilespmv_hip.argtypes = [C.c_char_p, TP, _I, _I, C.c_int, _U, _I, _I, C.c_int, C.c_int, C.c_int, _I, _I, VP,
+                                      vt, VP, VP, VP]
+    lib.call_tilespmv_hip.restype = None
+    lib.tilespmv_plan_create.argtypes = [C.POINTER(C.c_void_p), TP, C.c_int, C.c_int, C.c_int, C.POINTER(PlanOptions)]
+    lib.tilespmv_plan_create.restype = C.c_int
+    lib.tilespmv_plan_destroy.argtypes = [C.c_void_p]
+    lib.tilespmv_plan_destroy.restype = None
+    lib.tilespmv_plan_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.tilespmv_plan_spmv.restype = C.c_int
+    lib.tilespmv_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    lib.tilespmv_plan_info.restype = None
+    lib.tilespmv_plan_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.tilespmv_plan_time.restype = C.c_double
+    lib.tilespmv_partition_tilerows.argtypes = [TP, C.c_int, _I]
+    lib.tilespmv_partition_tilerows.restype = None
+    lib.tilespmv_device_count.restype = C.c_int
+    lib.tilespmv_version.restype = C.c_char_p
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free.restype = None
+    lib._free = libc.free
+    lib._vt, lib._TM, lib._dtype = vt, TM, dtype
+    _CACHE[dtype] = lib
+    return lib
+
+
+# every symbol include/tilespmv.h declares (checked by tests/test_abi.py)
+DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_cpu", "mmio_allinone", "call_tilespmv_hip",
+                    "tilespmv_plan_create", "tilespmv_plan_destroy", "tilespmv_plan_spmv", "tilespmv_plan_info",
+                    "tilespmv_plan_time", "tilespmv_partition_tilerows", "tilespmv_sizeof_value", "tilespmv_version",
+                    "tilespmv_device_count"]

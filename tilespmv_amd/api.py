@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference's driver interface (same names and argument meaning as
+reference src/main.cu calls them), over the C ABI of ``include/tilespmv.h``.
+
+    tm = Tile_create(rowA, colA, nnzA, rowptr, colidx, vals)        # src/csr2tile.h:629
+    sched = tilespmv_cpu(tm, rowA, colA, nnzA, rowptr, colidx, vals, x, y_golden)   # src/tilespmv_cpu.h:3
+    y = call_tilespmv_hip("A.mtx", tm, sched, rowA, colA, nnzA, rowptr, colidx, vals, x)  # src/tilespmv_cuda.h:794
+    plan = Plan(tm, rowA, colA, nnzA); plan.spmv(x_dev_ptr, y_dev_ptr)            # resident-plan API (new)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .tile_matrix import to_dict  # noqa: F401  (re-export)
+
+_I, _U = _lib._I, _lib._U
+
+COO_AUTO, COO_IN_TILE, COO_FALLBACK = 0, 1, 2
+DENSE_AUTO, DENSE_MFMA, DENSE_VALU = 0, 1, 2
+CREATE_HYB, CREATE_QUIET = 1, 2
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _take(lib, ptr, n, dtype):
+    if not ptr:
+        return np.zeros(0, dtype=dtype)
+    addr = C.cast(ptr, C.c_void_p).value
+    out = np.frombuffer((C.c_char * (max(n, 0) * np.dtype(dtype).itemsize)).from_address(addr), dtype=dtype, count=max(n, 0)).copy()
+    lib._free(C.cast(ptr, C.c_void_p))
+    return out
+
+
+def _csr(lib, rowptr, colidx, vals):
+    return (np.ascontiguousarray(rowptr, dtype=np.int32), np.ascontiguousarray(colidx, dtype=np.int32),
+            np.ascontiguousarray(vals, dtype=lib._dtype))
+
+
+def Tile_create(rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, hyb=False, quiet=True):
+    dtype = np.dtype(dtype or np.asarray(csrValA).dtype)
+    lib = _lib.load(dtype)
+    rp, ci, v = _csr(lib, csrRowPtrA, csrColIdxA, csrValA)
+    tm = lib._TM()
+    flags = (CREATE_HYB if hyb else 0) | (CREATE_QUIET if quiet else 0)
+    lib.Tile_create_ex(C.byref(tm), rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int), _p(v, lib._vt), flags)
+    tm._keep = (rp, ci, v)
+    tm._lib = lib
+    return tm
+
+
+def Tile_destroy(tm):
+    tm._lib.Tile_destroy(C.byref(tm))
+
+
+def tilespmv_cpu(tm, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, x, y_golden):
+    lib = tm._lib
+    rp, ci, v = _csr(lib, csrRowPtrA, csrColIdxA, csrValA)
+    x = np.ascontiguousarray(x, dtype=lib._dtype)
+    yg = np.ascontiguousarray(y_golden, dtype=lib._dtype)
+    n = tm.tilenum
+    p1 = np.zeros(max(n, 1), dtype=np.int32); p2 = np.zeros(max(n, 1), dtype=np.int32)
+    y = np.zeros(rowA + 16, dtype=lib._dtype)
+    nb = C.c_int(0); a, b, c = _U(), _I(), _I()
+    lib.tilespmv_cpu(C.byref(tm), _p(p1, C.c_int), _p(p2, C.c_int), C.byref(nb), C.byref(a), C.byref(b), C.byref(c),
+                     rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int), _p(v, lib._vt), _p(x, lib._vt), _p(y, lib._vt), _p(yg, lib._vt))
+    k = nb.value
+    return {"y": y[:rowA].copy(), "ptroffset1": p1[:n].copy(), "ptroffset2": p2[:n].copy(), "rowblkblock": k,
+            "blkcoostylerowidx": _take(lib, a, k, np.uint32), "blkcoostylerowidx_colstart": _take(lib, b, k, np.int32),
+            "blkcoostylerowidx_colstop": _take(lib, c, k, np.int32),
+            "errcount": int(np.count_nonzero(y[:rowA] != yg[:rowA]))}
+
+
+def mmio_allinone(filename, dtype=np.float64):
+    lib = _lib.load(dtype)
+    VP = C.POINTER(lib._vt)
+    m, n, nnz, sym = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rp, ci, cv = _I(), _I(), VP()
+    rc = lib.mmio_allinone(C.byref(m), C.byref(n), C.byref(nnz), C.byref(sym), C.byref(rp), C.byref(ci), C.byref(cv), filename.encode())
+    if rc != 0:
+        return {"rc": rc}
+    return {"rc": 0, "m": m.value, "n": n.value, "nnz": nnz.value, "sym": sym.value,
+            "rowptr": _take(lib, rp, m.value + 1, np.int32), "colidx": _take(lib, ci, nnz.value, np.int32),
+            "val": _take(lib, cv, nnz.value, lib._dtype)}
+
+
+def call_tilespmv_hip(filename, tm, sched, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, x, alpha=1.0):
+    """Host pointers in, y (host) out — the reference's one-shot GPU entry (timing + results.csv included)."""
+    lib = tm._lib
+    rp, ci, v = _csr(lib, csrRowPtrA, csrColIdxA, csrValA)
+    x = np.ascontiguousarray(x, dtype=lib._dtype)
+    y = np.zeros(rowA + 16, dtype=lib._dtype)
+    yg = np.zeros(rowA + 16, dtype=lib._dtype)
+    p1 = np.ascontiguousarray(sched["ptroffset1"], dtype=np.int32) if sched else np.zeros(max(tm.tilenum, 1), np.int32)
+    p2 = np.ascontiguousarray(sched["ptroffset2"], dtype=np.int32) if sched else np.zeros(max(tm.tilenum, 1), np.int32)
+    ri = np.ascontiguousarray(sched["blkcoostylerowidx"], dtype=np.uint32) if sched else np.zeros(1, np.uint32)
+    c0 = np.ascontiguousarray(sched["blkcoostylerowidx_colstart"], dtype=np.int32) if sched else np.zeros(1, np.int32)
+    c1 = np.ascontiguousarray(sched["blkcoostylerowidx_colstop"], dtype=np.int32) if sched else np.zeros(1, np.int32)
+    lib.call_tilespmv_hip(filename.encode(), C.byref(tm), _p(p1, C.c_int), _p(p2, C.c_int), int(sched["rowblkblock"]) if sched else 0,
+                          _p(ri, C.c_uint), _p(c0, C.c_int), _p(c1, C.c_int), rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int),
+                          _p(v, lib._vt), alpha, _p(x, lib._vt), _p(y, lib._vt), _p(yg, lib._vt))
+    return y[:rowA].copy()
+
+
+def partition_tilerows(tm, nparts):
+    b = np.zeros(nparts + 1, dtype=np.int32)
+    tm._lib.tilespmv_partition_tilerows(C.byref(tm), nparts, _p(b, C.c_int))
+    return b
+
+
+class Plan:
+    """Device-resident tiled matrix (or one tile-row shard of it)."""
+
+    def __init__(self, tm, rowA, colA, nnzA, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0):
+        self.lib = tm._lib
+        self.rowA, self.colA, self.nnzA = rowA, colA, nnzA
+        opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end)
+        h = C.c_void_p()
+        rc = self.lib.tilespmv_plan_create(C.byref(h), C.byref(tm), rowA, colA, nnzA, C.byref(opts))
+        if rc != 0 or not h:
+            raise RuntimeError("tilespmv_plan_create failed (%d): no usable HIP device / extension" % rc)
+        self.h = h
+
+    def spmv(self, d_x, d_y, stream=0):
+        rc = self.lib.tilespmv_plan_spmv(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError("tilespmv_plan_spmv: HIP error %d" % rc)
+
+    def time(self, d_x, d_y, stream=0, warmup=10, reps=50):
+        ms = self.lib.tilespmv_plan_time(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream), warmup, reps)
+        if ms < 0:
+            raise RuntimeError("tilespmv_plan_time failed")
+        return ms
+
+    def info(self):
+        out = (C.c_longlong * 16)()
+        self.lib.tilespmv_plan_info(self.h, out)
+        return {k: int(out[i]) for i, k in enumerate(_lib.INFO_NAMES)}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tilespmv_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def algorithmic_bytes(nnz, rows, cols, itemsize):
+    """B_alg = nnz*(s_v+4) + 4*(m+1) + s_v*(n+m)."""
+    return nnz * (itemsize + 4) + 4 * (rows + 1) + itemsize * (cols + rows)

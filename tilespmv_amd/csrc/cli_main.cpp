@@ -1,0 +1,89 @@
+// cli_main.cpp — the `test` command line of the reference driver (src/main.cu:15-205), same
+// argv and the same stdout lines in the same order, running on the HIP engine:
+//     ./test -d <device_id> <matrix.mtx>
+// argc < 2 -> usage line, exit 0 (:18-22); argv[1] != "-d" -> silent exit 0 (:47); the file
+// name is argv[3] (:58).  Matrix values are replaced by i % 10 and x by i % 10 (:68-69,:93-97)
+// and the last rowA % 16 rows are dropped (:71), exactly like the reference, so that its
+// PASS / NO PASS check (1 % relative, :186-197) means the same thing.
+#include <hip/hip_runtime.h>
+#include <sys/time.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+#include "../../include/tilespmv.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) {
+        printf("Run the code by './test matrix.mtx'.\n");
+        return 0;
+    }
+    printf("--------------------------------!!!!!!!!------------------------------------\n");
+    if (strcmp(argv[1], "-d") != 0) return 0;
+    int device_id = argc > 2 ? atoi(argv[2]) : 0;
+    printf("device_id = %i\n", device_id);
+    if (argc < 4) { fprintf(stderr, "usage: %s -d <device_id> <matrix.mtx>\n", argv[0]); return 1; }
+    char *filename = argv[3];
+    printf("MAT: -------------- %s --------------\n", filename);
+
+    int rowA = 0, colA = 0, isSymmetricA = 0;
+    MAT_PTR_TYPE nnzA = 0;
+    MAT_PTR_TYPE *csrRowPtrA = NULL; int *csrColIdxA = NULL; MAT_VAL_TYPE *csrValA = NULL;
+    timeval t1, t2;
+    gettimeofday(&t1, NULL);
+    int rc = mmio_allinone(&rowA, &colA, &nnzA, &isSymmetricA, &csrRowPtrA, &csrColIdxA, &csrValA, filename);
+    gettimeofday(&t2, NULL);
+    if (rc != 0) { fprintf(stderr, "cannot read %s (mmio_allinone returned %d)\n", filename, rc); return 1; }
+    double time_loadmat = (t2.tv_sec - t1.tv_sec) * 1000.0 + (t2.tv_usec - t1.tv_usec) / 1000.0;
+    printf("  input matrix A: ( %i, %i ) nnz = %i\n  loadfile time    = %4.5f sec\n", rowA, colA, nnzA, time_loadmat / 1000.0);
+
+    for (int i = 0; i < nnzA; i++) csrValA[i] = i % 10;
+    rowA = (rowA / TILESPMV_BLOCK_SIZE) * TILESPMV_BLOCK_SIZE;
+
+    if (hipSetDevice(device_id) != hipSuccess) { fprintf(stderr, "hipSetDevice(%d) failed: no such HIP device\n", device_id); return 2; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { fprintf(stderr, "hipGetDeviceProperties failed\n"); return 2; }
+    printf("---------------------------------------------------------------------------------------------\n");
+    printf("Device [ %i ] %s @ %4.2f MHz\n", device_id, prop.name, prop.clockRate * 1e-3f);
+
+    Tile_matrix *matrixA = (Tile_matrix *)malloc(sizeof(Tile_matrix));
+    Tile_create(matrixA, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA);
+
+    MAT_VAL_TYPE *x = (MAT_VAL_TYPE *)malloc(sizeof(MAT_VAL_TYPE) * colA);
+    for (int i = 0; i < colA; i++) x[i] = i % 10;
+    MAT_VAL_TYPE *y_golden = (MAT_VAL_TYPE *)malloc(sizeof(MAT_VAL_TYPE) * (rowA + 1));
+    for (int i = 0; i < rowA; i++) {
+        MAT_VAL_TYPE sum = 0;
+        for (int j = csrRowPtrA[i]; j < csrRowPtrA[i + 1]; j++) sum += csrValA[j] * x[csrColIdxA[j]];
+        y_golden[i] = sum;
+    }
+    MAT_VAL_TYPE *y = (MAT_VAL_TYPE *)calloc((size_t)rowA + 1, sizeof(MAT_VAL_TYPE));
+    int tilenum = matrixA->tilenum;
+    int *ptroffset1 = (int *)calloc((size_t)tilenum + 1, sizeof(int));
+    int *ptroffset2 = (int *)calloc((size_t)tilenum + 1, sizeof(int));
+    int rowblkblock = 0;
+    unsigned int *blkcoostylerowidx; int *blkcoostylerowidx_colstart; int *blkcoostylerowidx_colstop;
+    tilespmv_cpu(matrixA, ptroffset1, ptroffset2, &rowblkblock, &blkcoostylerowidx, &blkcoostylerowidx_colstart,
+                 &blkcoostylerowidx_colstop, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, x, y, y_golden);
+
+    MAT_VAL_TYPE alpha = 1.0;
+    memset(y, 0, sizeof(MAT_VAL_TYPE) * rowA);
+    call_tilespmv_hip(filename, matrixA, ptroffset1, ptroffset2, rowblkblock, blkcoostylerowidx, blkcoostylerowidx_colstart,
+                      blkcoostylerowidx_colstop, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, alpha, x, y, y_golden);
+
+    int error_count = 0;
+    for (int i = 0; i < rowA; i++)
+        if (std::fabs(y_golden[i] - y[i]) > 0.01 * std::fabs(y[i])) error_count++;
+    if (error_count == 0) std::cout << "Check... PASS!" << std::endl;
+    else std::cout << "Check... NO PASS! error_count_cuda = " << error_count << std::endl;
+
+    Tile_destroy(matrixA); free(matrixA);
+    free(csrValA); free(csrColIdxA); free(csrRowPtrA);
+    free(x); free(y); free(y_golden); free(ptroffset1); free(ptroffset2);
+    free(blkcoostylerowidx); free(blkcoostylerowidx_colstart); free(blkcoostylerowidx_colstop);
+    return error_count == 0 ? 0 : 4;
+}

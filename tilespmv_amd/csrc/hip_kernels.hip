@@ -1,0 +1,293 @@
+// hip_kernels.hip — hand-written CDNA4 (gfx950, wave64) kernels of the y = A*x hot path.
+//
+//   k_tiles_direct   fused tile SpMV: one 16-lane lane group ("strip") walks whole tile-rows,
+//                    one tile at a time, through the seven per-tile routines below; four strips
+//                    per wavefront, sixteen per workgroup.  Replaces the reference's
+//                    stir_spmv_cuda_kernel_v6 (src/tilespmv_cuda.h:394-792).
+//   k_fixup_split    sums the partial results of split (very long) tile-rows in a fixed order
+//                    (the reference uses global atomicAdd, src/tilespmv_cuda.h:784-790).
+//   k_fallback_csr   very-sparse CSR fallback, y += A_coo x over the extracted matrix
+//                    (the reference hands this to CSR5, src/tilespmv_cuda.h:1011-1029,:1080).
+//
+// Per-tile routines (lane r = lane & 15 owns row r of the tile):
+//   CSR      reference src/tilespmv_cuda.h:531-561   row-per-lane walk of the byte row pointer
+//   COO      :462-488                                16 entries per step, LDS scatter-add
+//   ELL      :579-605                                slot-major, 128 B of values per step
+//   HYB      :606-663 (+ v5 :185-234 remainder)      ELL part + COO remainder
+//   dense    :664-710                                v_mfma_f64_16x16x4_f64 (wave-cooperative) or VALU
+//   dense-row:711-750                                16-lane DPP reduction per dense row
+//   dense-col:751-778                                like ELL with a per-column id
+// x is staged per tile as a 16-value LDS segment (the reference: s_x_warp / register + shfl).
+#include <hip/hip_runtime.h>
+
+#include "hip_plan.h"
+
+namespace tilespmv {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int GROUPS_PER_BLOCK = 16;  // 256 threads
+constexpr int FB_NNZ = 512;           // products staged per wave in the fallback kernel
+
+__device__ __forceinline__ int nibble_of(const unsigned char *__restrict__ base, int p)
+{
+    const unsigned b = base[p >> 1];
+    return (p & 1) ? (int)(b & 15u) : (int)(b >> 4);
+}
+
+// ---- 16-lane all-reduce with DPP row rotations (a DPP "row" is exactly one 16-lane strip)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <class T>
+__device__ __forceinline__ T strip_allreduce(T v)
+{
+    v += dpp_mov<0x128>(v);  // row_ror:8
+    v += dpp_mov<0x124>(v);  // row_ror:4
+    v += dpp_mov<0x122>(v);  // row_ror:2
+    v += dpp_mov<0x121>(v);  // row_ror:1
+    return v;
+}
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // LDS operations of one wavefront complete in issue order; this only stops the compiler
+    // from moving accesses across the point where other lanes' data is consumed.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- dense tile on the matrix cores, whole wavefront on one tile:
+// A[row][k] = tile[row][4s+k] (64 consecutive values = one coalesced 512-B load per k-step),
+// B[k][*]  = x[4s+k];  after 4 steps D[row][*] = (tile * x)[row] in every column.
+__device__ __forceinline__ void mfma_dense_tile(const val_t *__restrict__ tile, const val_t *xseg, int lane, val_t *out16)
+{
+#if defined(TILESPMV_F32)
+    v4f d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; s++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(tile[64 * s + lane], xseg[4 * s + (lane >> 4)], d, 0, 0, 0);
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) out16[4 * (lane >> 4) + i] = d[i];  // f32 C/D map: row = 4*(lane>>4)+i
+    }
+#else
+    v4d d = {0., 0., 0., 0.};
+#pragma unroll
+    for (int s = 0; s < 4; s++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(tile[64 * s + lane], xseg[4 * s + (lane >> 4)], d, 0, 0, 0);
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) out16[(lane >> 4) + 4 * i] = d[i];  // f64 C/D map: row = (lane>>4)+4*i
+    }
+#endif
+}
+
+// ================================================================================================
+// Fused tile kernel, direct global loads.
+// ================================================================================================
+template <bool DENSE_MFMA>
+__global__ __launch_bounds__(256) void k_tiles_direct(DevPlan P, const val_t *__restrict__ x, val_t *__restrict__ y)
+{
+    __shared__ val_t s_x[GROUPS_PER_BLOCK][16];    // x segment of the strip's current tile
+    __shared__ val_t s_acc[GROUPS_PER_BLOCK][16];  // scatter accumulator (COO / HYB remainder)
+    __shared__ val_t s_t[4][16];                   // MFMA result hand-off, one per wave
+
+    const int tid = threadIdx.x, lane = tid & 63, r = tid & 15, g = tid >> 4, wave = tid >> 6;
+    const long long task_id = (long long)blockIdx.x * GROUPS_PER_BLOCK + g;
+    const bool have = task_id < P.ntasks;
+    Task tk;
+    if (have) tk = P.task[task_id];
+    else { tk.tile_begin = tk.tile_end = 0; tk.val_off = tk.idx_off = 0; tk.row = 0; tk.partial = -1; }
+
+    int t = tk.tile_begin;
+    const int tend = tk.tile_end;
+    long long voff = tk.val_off, ioff = tk.idx_off;
+    int row = tk.row;
+    val_t acc = 0;
+    bool dirty = false;
+    s_acc[g][r] = 0;
+
+    while (__ballot(t < tend) != 0ull) {
+        const bool on = t < tend;
+        unsigned meta = DESC_FMT_NOP;
+        int cb = 0;
+        if (on) {
+            const uint2 d = P.desc[t];
+            cb = (int)d.x; meta = d.y;
+            const long long xi = (long long)cb * 16 + r;
+            s_x[g][r] = (xi < P.colA) ? x[xi] : (val_t)0;
+        }
+        const int fmt = (int)(meta & DESC_FMT_MASK);
+        const int p1 = (int)((meta >> DESC_P1_SHIFT) & 255u), p2 = (int)((meta >> DESC_P2_SHIFT) & 255u);
+        wave_lds_fence();
+
+        if (DENSE_MFMA) {  // wave-uniform: every strip of the wave helps with each dense tile in turn
+            unsigned long long pending = __ballot(on && fmt == TILESPMV_FMT_DNS);
+            while (pending) {
+                const int gl = (__ffsll((long long)pending) - 1) >> 4;  // strip (0..3) inside the wave
+                const int lo = __builtin_amdgcn_readlane((int)(voff & 0xffffffffll), gl * 16);
+                const int hi = __builtin_amdgcn_readlane((int)(voff >> 32), gl * 16);
+                const long long vo = ((long long)hi << 32) | (unsigned)lo;
+                mfma_dense_tile(P.val + vo, &s_x[wave * 4 + gl][0], lane, &s_t[wave][0]);
+                wave_lds_fence();
+                if (((lane >> 4) == gl)) acc += s_t[wave][r];
+                wave_lds_fence();
+                pending &= ~(0xFFFFull << (gl * 16));
+            }
+        }
+
+        if (on) {
+            const val_t *__restrict__ v = P.val + voff;
+            const unsigned char *__restrict__ ix = P.idx + ioff;
+            const val_t *xs = &s_x[g][0];
+            int nv = 0, ni = 0;
+            switch (fmt) {
+            case TILESPMV_FMT_ELL: {
+                for (int s = 0; s < p1; s++) acc += v[16 * s + r] * xs[nibble_of(ix, 16 * s + r)];
+                nv = 16 * p1; ni = 8 * p1;
+                break;
+            }
+            case TILESPMV_FMT_CSR: {
+                const int k0 = ix[r], k1 = (r == 15) ? p1 : (int)ix[r + 1];
+                for (int k = k0; k < k1; k++) acc += v[k] * xs[nibble_of(ix + 16, k)];
+                nv = p1; ni = 16 + ((p1 + 1) >> 1);
+                break;
+            }
+            case TILESPMV_FMT_COO: {
+                if (r < p1) {
+                    const unsigned b = ix[r];
+                    atomicAdd(&s_acc[g][b >> 4], v[r] * xs[b & 15u]);
+                }
+                dirty = true; nv = p1; ni = p1;
+                break;
+            }
+            case TILESPMV_FMT_HYB: {
+                for (int s = 0; s < p1; s++) acc += v[16 * s + r] * xs[nibble_of(ix, 16 * s + r)];
+                if (r < p2) {
+                    const unsigned b = ix[8 * p1 + r];
+                    atomicAdd(&s_acc[g][b >> 4], v[16 * p1 + r] * xs[b & 15u]);
+                }
+                dirty = true; nv = 16 * p1 + p2; ni = 8 * p1 + p2;
+                break;
+            }
+            case TILESPMV_FMT_DNS: {
+                if (!DENSE_MFMA) {
+#pragma unroll 4
+                    for (int c = 0; c < 16; c++) acc += v[16 * c + r] * xs[c];
+                }
+                nv = 256; ni = 0;
+                break;
+            }
+            case TILESPMV_FMT_DNSROW: {
+                const val_t xr = xs[r];
+                for (int k = 0; k < p1; k++) {
+                    const val_t sum = strip_allreduce(v[16 * k + r] * xr);
+                    if (r == (int)ix[k]) acc += sum;
+                }
+                nv = 16 * p1; ni = p1;
+                break;
+            }
+            case TILESPMV_FMT_DNSCOL: {
+                for (int k = 0; k < p1; k++) acc += v[16 * k + r] * xs[ix[k]];
+                nv = 16 * p1; ni = p1;
+                break;
+            }
+            default: break;
+            }
+            voff += nv; ioff += ni;
+            t++;
+            if ((meta & DESC_EOR) && tk.partial < 0) {  // tile-row finished: write its 16 results
+                wave_lds_fence();
+                val_t out = acc;
+                if (dirty) { out += s_acc[g][r]; s_acc[g][r] = 0; dirty = false; }
+                const long long yi = (long long)row * 16 + r;
+                if (yi < P.rowA) y[yi] = out;
+                acc = 0; row++;
+            }
+        }
+        wave_lds_fence();
+    }
+    if (have && tk.partial >= 0) {  // piece of a split tile-row: combined later in a fixed order
+        val_t out = acc;
+        if (dirty) out += s_acc[g][r];
+        P.partial[(long long)tk.partial * 16 + r] = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fixup_split(DevPlan P, val_t *__restrict__ y)
+{
+    const int r = threadIdx.x & 15;
+    const int i = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x >> 4);
+    if (i >= P.nfix) return;
+    const FixRow f = P.fix[i];
+    val_t sum = 0;
+    for (int k = 0; k < f.count; k++) sum += P.partial[(long long)(f.first + k) * 16 + r];
+    const long long yi = (long long)f.row * 16 + r;
+    if (yi < P.rowA) y[yi] = sum;
+}
+
+// ================================================================================================
+// Very-sparse CSR fallback: y[row] += sum_j val[j] * x[col[j]] over the extracted matrix.
+// One wavefront per row block: short rows are "streamed" (coalesced loads of up to FB_NNZ
+// entries, products parked in LDS, then one lane per row adds its run in storage order), a row
+// longer than FB_NNZ gets the whole wavefront.
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_fallback_csr(DevPlan P, const val_t *__restrict__ x, val_t *__restrict__ y)
+{
+    __shared__ val_t s_prod[4][FB_NNZ];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = blockIdx.x * 4 + wave;
+    if (blk >= P.f_nblk) return;
+    const int r0 = P.f_blk[2 * blk], r1 = P.f_blk[2 * blk + 1];
+    const int p0 = P.f_ptr[r0], n = P.f_ptr[r1] - p0;
+    if (n > FB_NNZ) {  // a single long row (the host never groups such a row with others)
+        val_t sum = 0;
+        for (int k = lane; k < n; k += 64) sum += P.f_val[p0 + k] * x[P.f_col[p0 + k]];
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+        if (lane == 0) y[P.f_row0 + r0] += sum;
+        return;
+    }
+    for (int k = lane; k < n; k += 64) s_prod[wave][k] = P.f_val[p0 + k] * x[P.f_col[p0 + k]];
+    wave_lds_fence();
+    for (int row = r0 + lane; row < r1; row += 64) {
+        const int a = P.f_ptr[row] - p0, b = P.f_ptr[row + 1] - p0;
+        if (b > a) {
+            val_t sum = 0;
+            for (int k = a; k < b; k++) sum += s_prod[wave][k];
+            y[P.f_row0 + row] += sum;
+        }
+    }
+}
+
+// ---- launchers (host) ---------------------------------------------------------------------------
+hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, const val_t *x, val_t *y, hipStream_t st)
+{
+    if (P.ntasks > 0) {
+        const unsigned grid = (unsigned)((P.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK);
+        if (dense_mfma) hipLaunchKernelGGL(k_tiles_direct<true>, dim3(grid), dim3(256), 0, st, P, x, y);
+        else hipLaunchKernelGGL(k_tiles_direct<false>, dim3(grid), dim3(256), 0, st, P, x, y);
+    }
+    if (P.nfix > 0)
+        hipLaunchKernelGGL(k_fixup_split, dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st)
+{
+    if (P.f_nblk > 0) hipLaunchKernelGGL(k_fallback_csr, dim3((P.f_nblk + 3) / 4), dim3(256), 0, st, P, x, y);
+    return hipGetLastError();
+}
+
+int fallback_block_nnz() { return FB_NNZ; }
+
+}  // namespace tilespmv

@@ -1,0 +1,73 @@
+// hip_plan.h — device-resident layout of one Tile_matrix shard ("plan") for gfx950.
+//
+// Data layout in HBM (all streams are in tile order = tile-row major, so the bytes one
+// workgroup consumes are one contiguous run of each stream):
+//
+//   desc[]  uint2 per emitted tile   .x = column block, .y = packed meta (DESC_* below)
+//   val[]   val_t                    every tile's payload values back to back, in the tile's
+//                                    own format layout (row stride always 16, zero padded)
+//   idx[]   bytes                    every tile's index bytes back to back (tile-local packing)
+//   task[]  Task                     one per 16-lane lane group: a strip of whole tile-rows,
+//                                    or one piece of a split (very long) tile-row
+//
+// Formats keep the reference's semantics; only WHERE the bytes sit
+// changes (the reference keeps one array per format, src/format.h:26-50).
+#pragma once
+#include <cstdint>
+
+#include "host_util.h"
+
+namespace tilespmv {
+
+// desc.y bit fields
+constexpr unsigned DESC_FMT_MASK = 7u;    // TILESPMV_FMT_* ; 7 = no-op (empty tile-row)
+constexpr unsigned DESC_FMT_NOP = 7u;
+constexpr unsigned DESC_EOR = 8u;         // last tile of its tile-row
+constexpr int DESC_P1_SHIFT = 4;          // 8 bits: CSR nnz | COO count | ELL/HYB width | #dense rows/cols
+constexpr int DESC_P2_SHIFT = 12;         // 8 bits: HYB remainder count
+
+struct Task {
+    int tile_begin, tile_end;  // range in desc[]
+    long long val_off;         // element offset of tile_begin's payload in val[]
+    long long idx_off;         // byte offset in idx[]
+    int row;                   // tile-row of tile_begin (global numbering)
+    int partial;               // -1: whole tile-rows, results go to y; >=0: slot in partial[]
+};
+
+struct FixRow { int row, first, count, pad; };  // split tile-row: partial[first .. first+count) -> y
+
+struct DevPlan {
+    const uint2 *desc;
+    const val_t *val;
+    const unsigned char *idx;
+    const Task *task;
+    int ntasks;
+    int rowA, colA;
+    val_t *partial;
+    const FixRow *fix;
+    int nfix;
+    // very-sparse CSR fallback (extracted matrix of the shard's rows)
+    const int *f_ptr;       // deferredcoo_ptr restricted to the shard, rebased to 0
+    const int *f_col;
+    const val_t *f_val;
+    const int *f_blk;       // row-block boundaries (local row ids), nblk+1 entries
+    int f_nblk;
+    int f_row0;             // first global row of the shard
+    int f_rows;
+};
+
+inline void tile_stream_sizes(int fmt, int p1, int p2, int *nv, int *ni)
+{
+    switch (fmt) {
+    case TILESPMV_FMT_CSR: *nv = p1; *ni = 16 + (p1 + 1) / 2; break;
+    case TILESPMV_FMT_COO: *nv = p1; *ni = p1; break;
+    case TILESPMV_FMT_ELL: *nv = 16 * p1; *ni = 8 * p1; break;
+    case TILESPMV_FMT_HYB: *nv = 16 * p1 + p2; *ni = 8 * p1 + p2; break;
+    case TILESPMV_FMT_DNS: *nv = 256; *ni = 0; break;
+    case TILESPMV_FMT_DNSROW: *nv = 16 * p1; *ni = p1; break;
+    case TILESPMV_FMT_DNSCOL: *nv = 16 * p1; *ni = p1; break;
+    default: *nv = 0; *ni = 0; break;
+    }
+}
+
+}  // namespace tilespmv

@@ -1,0 +1,423 @@
+// host_tile_create.cpp — CSR -> Tile_matrix on the host (the kept preprocessing API).
+//
+// Replaces Tile_create / convert_step1..4 of the reference (src/csr2tile.h:5-1020) with an
+// O(nnz) many-core algorithm that produces the SAME bytes:
+//   * the reference clears and scans tilen-sized scratch per tile-row (O(tilem*tilen),
+//     src/csr2tile.h:26,67-71,89) and searches the tile list per nonzero (:406-418); here every
+//     tile-row is handled with a stamp array (no clearing) and one stable bucket pass;
+//   * all sizes are accumulated in 64 bits and checked against the int32 offsets that the
+//     Tile_matrix API exposes (the reference overflows silently, e.g. :912);
+//   * threads come from std::thread (no OpenMP runtime dependency).
+// What each output field means: SURVEY.md Appendix A.  Selection rules: src/csr2tile.h:143-325.
+#include <cmath>
+
+#include "host_util.h"
+
+namespace tilespmv {
+namespace {
+
+struct Choice { int fmt = 0, stored = 0, width = 0, ndr = 0, ndc = 0, hybcoo = 0, extracted = 0, csrptr = 0; };
+
+// One tile.  cnt_row[r]: entries in local row r.  lrc: (row<<4|col) byte of each entry.
+Choice select_format(int nnz, int rowlen, int collen, const uint8_t *cnt_row, const uint8_t *lrc, bool allow_hyb)
+{
+    Choice c;
+    if (nnz >= (int)(rowlen * collen * 0.75)) {  // near-dense tile stored dense (src/csr2tile.h:150-158)
+        c.fmt = TILESPMV_FMT_DNS; c.stored = rowlen * collen; return c;
+    }
+    if (nnz <= TILESPMV_COO_NNZ_TH) {  // very sparse tile: COO + copy into the extracted matrix (:159-168)
+        c.fmt = TILESPMV_FMT_COO; c.stored = nnz; c.extracted = nnz; return c;
+    }
+    if (nnz % collen == 0 || nnz % rowlen == 0) {  // candidates for whole-row / whole-column storage (:169-242)
+        bool usable = false; int full = 0;
+        for (int r = 0; r < rowlen; r++) {
+            if (cnt_row[r] % collen) { usable = false; break; }
+            if (cnt_row[r] == collen) { usable = true; full++; }
+        }
+        if (usable) { c.fmt = TILESPMV_FMT_DNSROW; c.ndr = full; c.stored = full * collen; return c; }
+        uint8_t cnt_col[BS] = {0};
+        for (int k = 0; k < nnz; k++) cnt_col[lrc[k] & 15]++;
+        usable = false; full = 0;
+        for (int j = 0; j < collen; j++) {
+            if (cnt_col[j] % rowlen) { usable = false; break; }
+            if (cnt_col[j] == rowlen) { usable = true; full++; }
+        }
+        if (usable) { c.fmt = TILESPMV_FMT_DNSCOL; c.ndc = full; c.stored = full * rowlen; return c; }
+    }
+    int widest = 0;
+    for (int r = 0; r < rowlen; r++) widest = std::max<int>(widest, cnt_row[r]);
+    const double mean = ((double)nnz) / rowlen;
+    double var = 0.0;
+    for (int r = 0; r < rowlen; r++) { double d = (double)(cnt_row[r] - mean); var += d * d; }
+    var /= rowlen;
+    const double variation = std::sqrt(var) / mean;  // (:251-265)
+    if (variation <= 0.2) {  // regular rows: ELL padded to the widest row (:270-276)
+        c.fmt = TILESPMV_FMT_ELL; c.width = widest; c.stored = widest * rowlen; return c;
+    }
+    if (allow_hyb && variation >= 1.0) {  // dormant in the shipped reference (:279-316)
+        const int sv = (int)sizeof(val_t);
+        auto bytes = [&](int w, int spill) { return w * rowlen * sv + (w * rowlen + 1) / 2 + spill * (sv + 1); };
+        int hw = widest, best = bytes(widest, 0), best_spill = 0;
+        for (int w = widest - 1; w > 0; w--) {
+            int spill = 0;
+            for (int r = 0; r < rowlen; r++) spill += std::max(0, (int)cnt_row[r] - w);
+            int b = bytes(w, spill);
+            if (best <= b) { hw = w + 1; break; }
+            hw = w; best = b; best_spill = spill;
+        }
+        if (best_spill <= 4) {
+            c.fmt = TILESPMV_FMT_HYB; c.width = hw; c.hybcoo = best_spill;
+            c.stored = best_spill + hw * rowlen; c.extracted = best_spill; return c;
+        }
+    }
+    c.fmt = TILESPMV_FMT_CSR; c.stored = nnz; c.csrptr = rowlen;  // (:318-323)
+    return c;
+}
+
+// First-element-pivot partition sort of the reference (src/utils.h:103-137), restated so that
+// rows holding duplicate column ids come out in the same (unstable) order.
+void pivot_sort(int *key, val_t *val, int n)
+{
+    while (n > 1) {
+        const int pivot = key[0];
+        std::swap(key[0], key[n - 1]); std::swap(val[0], val[n - 1]);
+        int lo = 0;
+        for (int i = 0; i < n; i++)
+            if (key[i] < pivot) { std::swap(key[i], key[lo]); std::swap(val[i], val[lo]); lo++; }
+        std::swap(key[n - 1], key[lo]); std::swap(val[n - 1], val[lo]);
+        pivot_sort(key, val, lo);
+        key += lo + 1; val += lo + 1; n -= lo + 1;
+    }
+}
+
+struct RowScratch {
+    std::vector<int> stamp, local, touched, cursor;
+    explicit RowScratch(int tilen) : stamp((size_t)tilen, -1), local((size_t)tilen, 0) {}
+};
+
+void pack_nibble_stream(const uint8_t *src, uint8_t *dst, int64_t n)
+{
+    parallel_chunks((n + 1) / 2, 1 << 16, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; i++) {
+            uint8_t hi = src[2 * i], lo = (2 * i + 1 < n) ? src[2 * i + 1] : 0;
+            dst[i] = (uint8_t)((hi << 4) + lo);
+        }
+    });
+}
+
+}  // namespace
+
+void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *rowptr, const int *colidx,
+                      const val_t *vals, unsigned flags)
+{
+    memset(T, 0, sizeof(*T));
+    const bool allow_hyb = flags & TILESPMV_CREATE_HYB;
+    const int tilem = (rowA + BS - 1) / BS, tilen = (colA + BS - 1) / BS;
+    T->tilem = tilem; T->tilen = tilen;
+    T->tile_ptr = zalloc<int>((size_t)tilem + 1);
+    const int nthreads = host_threads();
+    std::vector<RowScratch *> scratch((size_t)nthreads, nullptr);
+    auto get_scratch = [&](int tid) { if (!scratch[tid]) scratch[tid] = new RowScratch(tilen); return scratch[tid]; };
+
+    // ---- pass 1: number of populated column blocks per tile-row
+    parallel_chunks(tilem, 512, [&](int64_t b, int64_t e, int tid) {
+        RowScratch *S = get_scratch(tid);
+        for (int bi = (int)b; bi < (int)e; bi++) {
+            const int r0 = bi * BS, r1 = std::min(rowA, r0 + BS);
+            int n = 0;
+            for (int j = rowptr[r0]; j < rowptr[r1]; j++) {
+                int cb = colidx[j] >> 4;
+                if (S->stamp[cb] != bi) { S->stamp[cb] = bi; n++; }
+            }
+            T->tile_ptr[bi] = n;
+        }
+    });
+    exclusive_scan_checked(T->tile_ptr, (int64_t)tilem + 1, "tile count");
+    const int tilenum = T->tile_ptr[tilem];
+    T->tilenum = tilenum;
+    if (!(flags & TILESPMV_CREATE_QUIET)) printf("\n  The number of tile = %i\n", tilenum);
+
+    const int64_t nnz_used = rowptr[rowA];
+    const size_t np1 = (size_t)tilenum + 1;
+    T->tile_columnidx = zalloc<int>(tilenum);
+    T->tile_nnz = zalloc<int>(np1);
+    uint8_t *cnt_row = zalloc<uint8_t>((size_t)tilenum * BS);
+    int *ent = zalloc<int>((size_t)nnz_used);        // CSR position of each entry, tile order
+    uint8_t *lrc = zalloc<uint8_t>((size_t)nnz_used);  // (local row << 4) | local col, tile order
+
+    // ---- pass 2: tile list (ascending column block), per-row counts and the tile-ordered gather.
+    // Because tiles are numbered tile-row-major, the nonzeros of tile-row bi occupy the same
+    // index range [rowptr[16bi], rowptr[16bi+16)) before and after the gather.
+    parallel_chunks(tilem, 256, [&](int64_t b, int64_t e, int tid) {
+        RowScratch *S = get_scratch(tid);
+        for (int bi = (int)b; bi < (int)e; bi++) {
+            const int r0 = bi * BS, r1 = std::min(rowA, r0 + BS);
+            const int t0 = T->tile_ptr[bi], nt = T->tile_ptr[bi + 1] - t0;
+            const int stampv = tilem + bi;  // distinct from pass 1's stamps
+            S->touched.clear();
+            for (int j = rowptr[r0]; j < rowptr[r1]; j++) {
+                int cb = colidx[j] >> 4;
+                if (S->stamp[cb] != stampv) { S->stamp[cb] = stampv; S->touched.push_back(cb); }
+            }
+            if (!std::is_sorted(S->touched.begin(), S->touched.end())) std::sort(S->touched.begin(), S->touched.end());
+            S->cursor.assign((size_t)nt + 1, 0);
+            for (int k = 0; k < nt; k++) { S->local[S->touched[k]] = k; T->tile_columnidx[t0 + k] = S->touched[k]; }
+            for (int r = r0; r < r1; r++)
+                for (int j = rowptr[r]; j < rowptr[r + 1]; j++) {
+                    int k = S->local[colidx[j] >> 4];
+                    S->cursor[k + 1]++;
+                    cnt_row[(size_t)(t0 + k) * BS + (r - r0)]++;
+                }
+            int run = rowptr[r0];
+            for (int k = 0; k < nt; k++) { int c = S->cursor[k + 1]; T->tile_nnz[t0 + k] = run; S->cursor[k] = run; run += c; }
+            for (int r = r0; r < r1; r++)
+                for (int j = rowptr[r]; j < rowptr[r + 1]; j++) {
+                    int k = S->local[colidx[j] >> 4];
+                    int pos = S->cursor[k]++;
+                    ent[pos] = j;
+                    lrc[pos] = (uint8_t)(((r - r0) << 4) | (colidx[j] & 15));
+                }
+        }
+    });
+    T->tile_nnz[tilenum] = (int)nnz_used;
+    for (auto *s : scratch) delete s;
+
+    // ---- per-tile metadata + format selection
+    T->Format = zalloc<char>(tilenum);
+    T->blknnz = zalloc<int>(np1);
+    T->blknnznnz = zalloc<unsigned char>(np1);
+    T->dnsrowptr = zalloc<int>(np1);
+    T->dnscolptr = zalloc<int>(np1);
+    T->tilewidth = zalloc<char>(tilenum);
+    T->csr_offset = zalloc<int>(np1);
+    T->csrptr_offset = zalloc<int>(np1);
+    T->coo_offset = zalloc<int>(np1);
+    T->ell_offset = zalloc<int>(np1);
+    T->hyb_offset = zalloc<int>(np1);
+    T->hyb_coocount = zalloc<int>(np1);
+    T->dns_offset = zalloc<int>(np1);
+    T->dnsrow_offset = zalloc<int>(np1);
+    T->dnscol_offset = zalloc<int>(np1);
+    T->new_coocount = zalloc<int>(np1);
+
+    parallel_chunks(tilem, 256, [&](int64_t b, int64_t e, int) {
+        for (int bi = (int)b; bi < (int)e; bi++) {
+            const int rowlen = tile_rowlen(bi, tilem, rowA);
+            for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+                const int collen = tile_collen(T->tile_columnidx[t], tilen, colA);
+                const int n = T->tile_nnz[t + 1] - T->tile_nnz[t];
+                Choice c = select_format(n, rowlen, collen, cnt_row + (size_t)t * BS, lrc + T->tile_nnz[t], allow_hyb);
+                T->Format[t] = (char)c.fmt;
+                T->blknnz[t] = c.stored;
+                T->blknnznnz[t] = (unsigned char)c.stored;
+                T->tilewidth[t] = (char)c.width;
+                T->dnsrowptr[t] = c.ndr; T->dnscolptr[t] = c.ndc;
+                T->hyb_coocount[t] = c.hybcoo; T->new_coocount[t] = c.extracted;
+                T->csrptr_offset[t] = c.csrptr;
+                int *dst[7] = { T->csr_offset, T->coo_offset, T->ell_offset, T->hyb_offset, T->dns_offset,
+                                T->dnsrow_offset, T->dnscol_offset };
+                dst[c.fmt][t] = c.stored;
+            }
+        }
+    });
+    int64_t hybell = 0;
+    for (int bi = 0; bi < tilem; bi++) {
+        const int rowlen = tile_rowlen(bi, tilem, rowA);
+        for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++)
+            if (T->Format[t] == TILESPMV_FMT_HYB) hybell += (int64_t)T->tilewidth[t] * rowlen;
+    }
+    int *scans[] = { T->csr_offset, T->csrptr_offset, T->coo_offset, T->ell_offset, T->hyb_offset, T->dns_offset,
+                     T->dnsrow_offset, T->dnscol_offset, T->dnsrowptr, T->dnscolptr, T->hyb_coocount,
+                     T->new_coocount, T->blknnz };
+    static const char *names[] = { "csr_offset", "csrptr_offset", "coo_offset", "ell_offset", "hyb_offset", "dns_offset",
+                                   "dnsrow_offset", "dnscol_offset", "dnsrowptr", "dnscolptr", "hyb_coocount",
+                                   "new_coocount", "blknnz" };
+    {
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < sizeof(scans) / sizeof(*scans); k++)
+            th.emplace_back([&, k] { exclusive_scan_checked(scans[k], (int64_t)np1, names[k]); });
+        for (auto &t : th) t.join();
+    }
+    T->csrsize = T->csr_offset[tilenum]; T->csrptrlen = T->csrptr_offset[tilenum];
+    T->coosize = T->coo_offset[tilenum]; T->ellsize = T->ell_offset[tilenum];
+    T->hybsize = T->hyb_offset[tilenum]; T->hybellsize = (int)hybell; T->hybcoosize = T->hyb_coocount[tilenum];
+    T->dnssize = T->dns_offset[tilenum]; T->dnsrowsize = T->dnsrow_offset[tilenum];
+    T->dnscolsize = T->dnscol_offset[tilenum]; T->coototal = T->new_coocount[tilenum];
+
+    // ---- payload arrays
+    T->Blockcsr_Val = zalloc<val_t>(T->csrsize);
+    T->Blockcsr_Ptr = zalloc<unsigned char>(T->csrptrlen);
+    T->csr_compressedIdx = zalloc<unsigned char>(((size_t)T->csrsize + 1) / 2);
+    T->Blockcoo_Val = zalloc<val_t>(T->coosize);
+    T->coo_compressed_Idx = zalloc<unsigned char>(T->coosize);
+    T->Blockell_Val = zalloc<val_t>(T->ellsize);
+    T->ell_compressedIdx = zalloc<unsigned char>(((size_t)T->ellsize + 1) / 2);
+    T->Blockhyb_Val = zalloc<val_t>((size_t)T->hybellsize + T->hybcoosize);
+    T->hybIdx = zalloc<unsigned char>(((size_t)T->hybellsize + 1) / 2 + T->hybcoosize + (size_t)tilem + 8);
+    T->Blockdense_Val = zalloc<val_t>(T->dnssize);
+    T->Blockdenserow_Val = zalloc<val_t>(T->dnsrowsize);
+    T->denserowid = zalloc<char>(T->dnsrowptr[tilenum]);
+    T->Blockdensecol_Val = zalloc<val_t>(T->dnscolsize);
+    T->densecolid = zalloc<char>(T->dnscolptr[tilenum]);
+    T->deferredcoo_val = zalloc<val_t>(T->coototal);
+    T->deferredcoo_colidx = zalloc<int>(T->coototal);
+    T->deferredcoo_ptr = zalloc<int>((size_t)rowA + 1);
+
+    uint8_t *csr_col = zalloc<uint8_t>(T->csrsize), *ell_col = zalloc<uint8_t>(T->ellsize);
+    uint8_t *hyb_col = zalloc<uint8_t>((size_t)T->hybellsize + T->hybcoosize), *hyb_row = zalloc<uint8_t>(T->hybcoosize);
+    int *x_row = zalloc<int>(T->coototal);  // extracted entries in tile order: local row | column | value
+    int *x_col = zalloc<int>(T->coototal);
+    val_t *x_val = zalloc<val_t>(T->coototal);
+
+    // ---- pass 3: pack every tile into its format's arrays (src/csr2tile.h:420-622) and, per
+    // tile-row, turn its slice of the extracted list into CSR rows (src/csr2tile.h:899-960).
+    parallel_chunks(tilem, 128, [&](int64_t b, int64_t e, int) {
+        for (int bi = (int)b; bi < (int)e; bi++) {
+            const int rowlen = tile_rowlen(bi, tilem, rowA);
+            for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+                const int cb = T->tile_columnidx[t], collen = tile_collen(cb, tilen, colA);
+                const int e0 = T->tile_nnz[t], n = T->tile_nnz[t + 1] - e0, w = T->tilewidth[t];
+                const uint8_t *rc = lrc + e0; const int *src = ent + e0;
+                int start[BS + 1]; start[0] = 0;
+                for (int r = 0; r < BS; r++) start[r + 1] = start[r] + cnt_row[(size_t)t * BS + r];
+                switch (T->Format[t]) {
+                case TILESPMV_FMT_CSR: {
+                    const int off = T->csr_offset[t], poff = T->csrptr_offset[t];
+                    for (int k = 0; k < n; k++) { T->Blockcsr_Val[off + k] = vals[src[k]]; csr_col[off + k] = rc[k] & 15; }
+                    for (int r = 0; r < rowlen; r++) T->Blockcsr_Ptr[poff + r] = (unsigned char)start[r];
+                    break;
+                }
+                case TILESPMV_FMT_COO: {
+                    const int off = T->coo_offset[t], xo = T->new_coocount[t];
+                    for (int k = 0; k < n; k++) {
+                        T->Blockcoo_Val[off + k] = vals[src[k]];
+                        T->coo_compressed_Idx[off + k] = rc[k];
+                        x_row[xo + k] = rc[k] >> 4; x_col[xo + k] = colidx[src[k]]; x_val[xo + k] = vals[src[k]];
+                    }
+                    break;
+                }
+                case TILESPMV_FMT_ELL: {
+                    const int off = T->ell_offset[t];
+                    for (int k = 0; k < n; k++) {
+                        int r = rc[k] >> 4, p = off + (k - start[r]) * rowlen + r;
+                        T->Blockell_Val[p] = vals[src[k]]; ell_col[p] = rc[k] & 15;
+                    }
+                    break;
+                }
+                case TILESPMV_FMT_HYB: {
+                    const int off = T->hyb_offset[t], xo = T->new_coocount[t], ro = T->hyb_coocount[t];
+                    int spill = 0;
+                    for (int k = 0; k < n; k++) {
+                        int r = rc[k] >> 4, s = k - start[r];
+                        if (s < w) { T->Blockhyb_Val[off + s * rowlen + r] = vals[src[k]]; hyb_col[off + s * rowlen + r] = rc[k] & 15; }
+                        else {
+                            T->Blockhyb_Val[off + w * rowlen + spill] = vals[src[k]]; hyb_col[off + w * rowlen + spill] = rc[k] & 15;
+                            hyb_row[ro + spill] = (uint8_t)r;
+                            x_row[xo + spill] = r; x_col[xo + spill] = colidx[src[k]]; x_val[xo + spill] = vals[src[k]];
+                            spill++;
+                        }
+                    }
+                    break;
+                }
+                case TILESPMV_FMT_DNS: {
+                    const int off = T->dns_offset[t];
+                    for (int k = 0; k < n; k++) T->Blockdense_Val[off + (rc[k] & 15) * rowlen + (rc[k] >> 4)] = vals[src[k]];
+                    break;
+                }
+                case TILESPMV_FMT_DNSROW: {
+                    const int off = T->dnsrow_offset[t], ro = T->dnsrowptr[t];
+                    int nr = 0;
+                    for (int r = 0; r < rowlen; r++) {
+                        if (start[r + 1] - start[r] != collen) continue;
+                        T->denserowid[ro + nr++] = (char)r;
+                        for (int k = start[r]; k < start[r + 1]; k++) T->Blockdenserow_Val[off + k] = vals[src[k]];
+                    }
+                    break;
+                }
+                case TILESPMV_FMT_DNSCOL: {
+                    const int off = T->dnscol_offset[t], co = T->dnscolptr[t];
+                    for (int k = start[0]; k < start[1]; k++) T->densecolid[co + k] = (char)(rc[k] & 15);
+                    for (int k = 0; k < n; k++) { int r = rc[k] >> 4; T->Blockdensecol_Val[off + (k - start[r]) * rowlen + r] = vals[src[k]]; }
+                    break;
+                }
+                }
+            }
+            // extracted entries of this tile-row -> per-row counts (rows of other tile-rows never appear here)
+            const int x0 = T->new_coocount[T->tile_ptr[bi]], x1 = T->new_coocount[T->tile_ptr[bi + 1]];
+            for (int i = x0; i < x1; i++) T->deferredcoo_ptr[bi * BS + x_row[i]]++;
+        }
+    });
+    exclusive_scan_checked(T->deferredcoo_ptr, (int64_t)rowA + 1, "deferredcoo_ptr");
+    parallel_chunks(tilem, 256, [&](int64_t b, int64_t e, int) {
+        for (int bi = (int)b; bi < (int)e; bi++) {
+            const int rowlen = tile_rowlen(bi, tilem, rowA);
+            const int x0 = T->new_coocount[T->tile_ptr[bi]], x1 = T->new_coocount[T->tile_ptr[bi + 1]];
+            if (x0 == x1) continue;
+            int fill[BS] = {0};
+            for (int i = x0; i < x1; i++) {  // stable scatter in order of appearance (:943-950)
+                int r = x_row[i], p = T->deferredcoo_ptr[bi * BS + r] + fill[r]++;
+                T->deferredcoo_colidx[p] = x_col[i]; T->deferredcoo_val[p] = x_val[i];
+            }
+            for (int r = 0; r < rowlen; r++) {
+                int p = T->deferredcoo_ptr[bi * BS + r], len = T->deferredcoo_ptr[bi * BS + r + 1] - p;
+                int *k = T->deferredcoo_colidx + p;
+                bool increasing = true;  // tiles arrive in ascending column order: usually nothing to do
+                for (int i = 1; i < len && increasing; i++) increasing = k[i - 1] < k[i];
+                if (!increasing) pivot_sort(k, T->deferredcoo_val + p, len);
+            }
+        }
+    });
+
+    // ---- index compression (src/csr2tile.h:973-1008; nibble layout src/encode.h:29-50)
+    pack_nibble_stream(csr_col, T->csr_compressedIdx, T->csrsize);
+    pack_nibble_stream(ell_col, T->ell_compressedIdx, T->ellsize);
+    if (T->hybsize > 0) {
+        int64_t src = 0, dst = 0, seen = 0;
+        for (int bi = 0; bi < tilem; bi++) {
+            const int rowlen = tile_rowlen(bi, tilem, rowA);
+            for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+                if (T->Format[t] != TILESPMV_FMT_HYB) continue;
+                const int nell = T->tilewidth[t] * rowlen, ncoo = T->blknnz[t + 1] - T->blknnz[t] - nell;
+                for (int p = 0; p < nell; p += 2)
+                    T->hybIdx[dst + (p >> 1)] = (uint8_t)((hyb_col[src + p] << 4) + (p + 1 < nell ? hyb_col[src + p + 1] : 0));
+                dst += (nell + 1) / 2;
+                for (int i = 0; i < ncoo; i++) T->hybIdx[dst + i] = (uint8_t)((hyb_row[seen + i] << 4) + hyb_col[src + nell + i]);
+                seen += ncoo; src += nell + ncoo; dst += ncoo;
+            }
+        }
+    }
+    free(csr_col); free(ell_col); free(hyb_col); free(hyb_row);
+    free(x_row); free(x_col); free(x_val);
+    free(cnt_row); free(ent); free(lrc);
+}
+
+}  // namespace tilespmv
+
+extern "C" {
+
+void Tile_create_ex(Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *csrRowPtrA,
+                    const int *csrColIdxA, const MAT_VAL_TYPE *csrValA, unsigned flags)
+{
+    (void)nnzA;  // like the reference, the row pointer decides how many nonzeros are used
+    tilespmv::tile_create_impl(matrix, rowA, colA, csrRowPtrA, csrColIdxA, csrValA, flags);
+}
+
+void Tile_create(Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA, MAT_PTR_TYPE *csrRowPtrA,
+                 int *csrColIdxA, MAT_VAL_TYPE *csrValA)
+{
+    Tile_create_ex(matrix, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, 0u);
+}
+
+void Tile_destroy(Tile_matrix *T)
+{
+    void *all[] = { T->tile_ptr, T->tile_columnidx, T->tile_nnz, T->Format, T->blknnz, T->blknnznnz, T->dnsrowptr,
+        T->dnscolptr, T->tilewidth, T->csr_offset, T->csrptr_offset, T->coo_offset, T->ell_offset, T->hyb_offset,
+        T->hyb_coocount, T->dns_offset, T->dnsrow_offset, T->dnscol_offset, T->new_coocount, T->Blockcsr_Val,
+        T->Blockcsr_Ptr, T->csr_compressedIdx, T->Blockcoo_Val, T->coo_compressed_Idx, T->Blockell_Val,
+        T->ell_compressedIdx, T->Blockhyb_Val, T->hybIdx, T->Blockdense_Val, T->Blockdenserow_Val, T->denserowid,
+        T->Blockdensecol_Val, T->densecolid, T->deferredcoo_val, T->deferredcoo_colidx, T->deferredcoo_ptr };
+    for (void *p : all) free(p);
+    memset(T, 0, sizeof(*T));
+}
+
+}  // extern "C"
