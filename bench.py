@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — y = A*x throughput of the HIP TileSpMV engine on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W [--workload laplacian4096] [--dtype f64]
+
+A "step" is one SpMV over the whole (row-partitioned) matrix.  Inputs are resident in HBM when
+the timed region starts.  Rank 0 prints ONE JSON line.  Metric/config follow BASELINE.json:
+fp64 SpMV GFLOP/s + achieved (algorithmic) HBM GB/s as a fraction of the 8 TB/s roofline.
+
+Workloads (synthetic stand-ins unless $TILESPMV_MATRIX_DIR/<name>.mtx exists):
+  laplacian4096  5-pt Laplacian on a 4096^2 grid, 16.7 M rows, 83.9 M nnz  (config 4; default —
+                 the >= 10 M-nnz fp64 case the roofline target is quoted on, fits one GPU)
+  scircuit       circuit-like, 171 k rows, ~1 M nnz (config 2)       webbase   power-law 1 M rows (config 3)
+  nlpkkt160      KKT-like, 8.2 M rows, ~2.2e8 nnz, fp32 by default (config 5)
+Multi-GPU: contiguous nnz-balanced tile-row blocks, one rank per GPU, x replicated, y left
+sharded (the SpMV needs no collective: SURVEY.md §8e) => "scaling": "strong" on the fixed matrix;
+--combine allgather|allreduce adds the RCCL y combine to every step, and the default run also
+reports both combine variants beside the headline value when N > 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_matrix(name):
+    from tilespmv_amd import api, generators as G
+    d = os.environ.get("TILESPMV_MATRIX_DIR")
+    real = {"laplacian4096": None, "scircuit": "scircuit", "webbase": "webbase-1M", "nlpkkt160": "nlpkkt160"}.get(name)
+    if d and real and os.path.exists(os.path.join(d, real + ".mtx")):
+        r = api.mmio_allinone(os.path.join(d, real + ".mtx"))
+        return r["m"], r["n"], r["rowptr"], r["colidx"], "file:" + real + ".mtx"
+    if name == "laplacian4096":
+        return G.laplacian5pt(4096) + ("synthetic 5-pt Laplacian 4096^2",)
+    if name.startswith("laplacian"):
+        return G.laplacian5pt(int(name[len("laplacian"):])) + ("synthetic 5-pt Laplacian",)
+    if name == "scircuit":
+        return G.circuit_like(170998, seed=1) + ("synthetic circuit-like stand-in for scircuit",)
+    if name == "webbase":
+        return G.powerlaw(1000005, seed=2) + ("synthetic power-law stand-in for webbase-1M",)
+    if name == "nlpkkt160":
+        return G.kkt_like(160, seed=5) + ("synthetic KKT-like stand-in for nlpkkt160",)
+    raise SystemExit("unknown workload " + name)
+
+
+def cpu_baseline(rows, cols, rowptr, colidx, vals, x, dtype, budget_s=12.0):
+    """The CPU path of the reference timed on this box's host cores (rank 0, N=1 only), on a
+    bounded sample of the same workload: its first <= 1,048,576 rows.  kind = "reference" when
+    the prebuilt oracle/_ref (the reference's own headers) is present, else "port" (our C
+    restatement).  Single-threaded like the reference (src/tilespmv_cpu.h:125).  Timed: the whole
+    tilespmv_cpu call (schedule arrays + serial tile SpMV + self-check), Tile_create excluded."""
+    from oracle.oracle import CpuImpl, available
+    kind = "ref" if available("ref", dtype) else "oracle"
+    impl = CpuImpl(kind, dtype)
+    srows = min(rows, 1 << 20)
+    nz = int(rowptr[srows])
+    rp, ci, v = rowptr[:srows + 1], colidx[:nz], vals[:nz]
+    devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); sys.stdout.flush(); os.dup2(devnull, 1)
+    try:
+        tm = impl.tile_create(srows, cols, nz, rp, ci, v)
+        yg = impl.csr_spmv(srows, rp, ci, v, x)
+        times = []
+        t_end = time.time() + budget_s
+        while len(times) < 3 or (time.time() < t_end and len(times) < 40):
+            t0 = time.perf_counter()
+            impl.spmv(tm, srows, cols, nz, rp, ci, v, x, yg)
+            times.append(time.perf_counter() - t0)
+    finally:
+        sys.stdout.flush(); os.dup2(saved, 1); os.close(devnull); os.close(saved)
+    t = float(np.median(times))
+    return {"value": round(2.0 * nz / t * 1e-9, 4), "unit": "GFLOP/s", "cores": 1,
+            "kind": "reference" if kind == "ref" else "port", "seconds_per_spmv": round(t, 6), "runs": len(times),
+            "sample": "first %d rows (%d nnz) of the workload matrix; tilespmv_cpu whole call, median of %d runs" % (srows, nz, len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="laplacian4096")
+    ap.add_argument("--dtype", default=None, choices=[None, "f64", "f32"])
+    ap.add_argument("--combine", default="none", choices=["none", "allgather", "allreduce"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tilespmv_amd import api, generators as G
+    from tilespmv_amd.dist import ShardedSpMV
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    dtype = np.dtype(np.float32 if (args.dtype == "f32" or (args.dtype is None and args.workload == "nlpkkt160")) else np.float64)
+    tdtype = torch.float64 if dtype == np.float64 else torch.float32
+    t0 = time.time()
+    m, n, rowptr, colidx, source = build_matrix(args.workload)
+    rows = (m // 16) * 16                      # the driver rule of the reference (src/main.cu:71)
+    nnz = int(rowptr[rows])
+    vals, x = G.compat_values(len(colidx), dtype), G.compat_x(n, dtype)   # reference's synthetic data (src/main.cu:68-69,:93-97)
+    t_gen = time.time() - t0
+
+    t0 = time.time()
+    sh = ShardedSpMV(rank, world, rows, n, rowptr, colidx, vals, dtype)
+    t_prep = time.time() - t0
+    info = sh.local.info()
+    stream = torch.cuda.current_stream()
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros(rows + 16, dtype=tdtype, device="cuda")
+
+    def step(combine):
+        sh.spmv(xd, yd, stream.cuda_stream)
+        if combine != "none":
+            sh.combine(yd, combine)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(combine, steps, warmup):
+        for _ in range(warmup):
+            step(combine)
+        sync_all()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(steps):
+            step(combine)
+        e1.record(stream)
+        sync_all()
+        wall = time.perf_counter() - t0
+        dev_ms = e0.elapsed_time(e1)          # HIP events on the launch stream, over the timed region
+        if world > 1:
+            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, dev_ms = float(t[0]), float(t[1])
+        return wall, dev_ms
+
+    # parity spot check of the resident plan before timing (exact: integer-valued data)
+    check = "skipped"
+    if not args.no_check:
+        step("none"); torch.cuda.synchronize()
+        rs = np.unique(np.concatenate([np.arange(sh.r0, min(sh.r0 + 4096, sh.r1)), np.random.default_rng(rank).integers(sh.r0, max(sh.r1, sh.r0 + 1), 20000)]))
+        rs = rs[rs < sh.r1]
+        got = yd[torch.from_numpy(rs).cuda()].cpu().numpy()
+        want = np.array([np.dot(vals[rowptr[r]:rowptr[r + 1]].astype(np.float64), x[colidx[rowptr[r]:rowptr[r + 1]]].astype(np.float64)) for r in rs[:6000]])
+        ok = np.array_equal(got[:len(want)].astype(np.float64), want)
+        check = "pass" if ok else "FAIL"
+        if not ok:
+            raise SystemExit("bench.py: HIP result differs from the CSR golden on sampled rows")
+
+    wall, dev_ms = timed(args.combine, args.steps, args.warmup)
+    ms_per_step = wall * 1e3 / args.steps
+    flops = 2.0 * nnz
+    b_alg_total = api.algorithmic_bytes(nnz, rows, n, dtype.itemsize)
+    value = flops / (wall / args.steps) * 1e-9
+
+    # roofline of the dominant kernel (k_tiles_direct): algorithmic bytes of THIS rank's launch
+    # divided by its average duration, from HIP events on the launch stream over the timed region.
+    b_alg_launch = api.algorithmic_bytes(sh.local_nnz, sh.local_rows, n, dtype.itemsize)
+    kernel_ms = dev_ms / args.steps
+    achieved = b_alg_launch / (kernel_ms * 1e-3) * 1e-9
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, "f64" if dtype == np.float64 else "f32"))
+    if world == 1 and os.path.exists(tj):
+        traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "kernel": "k_tiles_direct", "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_launch": int(b_alg_launch),
+                "plan_stream_bytes_per_launch": info["stream_bytes"], "timing": "hip events on the launch stream, timed region"}
+
+    extra = {}
+    if world > 1 and args.combine == "none":
+        for mode in ("allgather", "allreduce"):
+            w2, _ = timed(mode, max(5, args.steps // 10), 3)
+            extra[mode] = {"ms_per_step": round(w2 * 1e3 / max(5, args.steps // 10), 5), "gflops": round(flops / (w2 / max(5, args.steps // 10)) * 1e-9, 2)}
+
+    out = {
+        "metric": "fp%d SpMV GFLOP/s (y = A*x, tiled format)" % (dtype.itemsize * 8), "value": round(value, 2), "unit": "GFLOP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64" if dtype == np.float64 else "f32", "data": "synthetic (reference driver data: val[i]=i%10, x[i]=i%10)",
+        "config": {"workload": args.workload, "source": source, "rows": rows, "cols": n, "nnz": nnz,
+                   "partition": "tile-row blocks, nnz-balanced, %d rank(s)" % world, "y_combine": args.combine,
+                   "tiles": info["tiles"], "coo_mode": info["coo_mode"], "dense_mode": info["dense_mode"]},
+        "hbm_gbps_algorithmic": round(b_alg_total / (wall / args.steps) * 1e-9, 1),
+        "hbm_roofline_frac": round(b_alg_total / (wall / args.steps) * 1e-9 / (HBM_PEAK_GBPS * world), 4),
+        "roofline": roofline, "check": check,
+        "prep_seconds": {"generate": round(t_gen, 2), "tile_create_and_upload": round(t_prep, 2)},
+    }
+    if extra:
+        out["with_y_combine"] = extra
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(rows, n, rowptr, colidx, vals, x, dtype)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    sh.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

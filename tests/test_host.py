@@ -1,0 +1,181 @@
+"""Product host code (tilespmv_amd/csrc/host_*.cpp through the C ABI) against the oracle:
+Tile_create byte-for-byte, tilespmv_cpu (schedule arrays + y), mmio_allinone; structural
+invariants of SURVEY.md Appendix A; hypothesis property tests on random CSR."""
+import json
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from cases import SMALL, MEDIUM, truncated_rows, values_for
+from oracle.oracle import CpuImpl
+from tilespmv_amd import api, generators as G
+from tilespmv_amd.tile_matrix import to_dict
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _both(name, gen, dtype, hyb, real=False, rowA=None):
+    m, n, rp, ci = gen()
+    nnz = len(ci)
+    rowA = truncated_rows(m) if rowA is None else rowA
+    vals, x = values_for(name, nnz, n, dtype, real)
+    O = CpuImpl("oracle", dtype)
+    to = O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=hyb)
+    so = O.spmv(to, rowA, n, nnz, rp, ci, vals, x)
+    tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=hyb)
+    sp = api.tilespmv_cpu(tp, rowA, n, nnz, rp, ci, vals, x, so["y_golden"])
+    return to_dict(to, rowA), so, to_dict(tp, rowA), sp, tp
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("hyb", [False, True])
+@pytest.mark.parametrize("name", sorted(SMALL) + sorted(MEDIUM))
+def test_tile_create_and_cpu_path_match_oracle(name, dtype, hyb):
+    gen = SMALL.get(name) or MEDIUM[name]
+    for real in (False, True):
+        do, so, dp, sp, tp = _both(name, gen, dtype, hyb, real)
+        for k in do:
+            assert np.array_equal(np.asarray(do[k]), np.asarray(dp[k])), (k, real)
+        for k in sp:
+            assert np.array_equal(np.asarray(sp[k]), np.asarray(so[k])), (k, real)
+        api.Tile_destroy(tp)
+
+
+@pytest.mark.parametrize("rowA", [187, 177, 1])
+def test_partial_last_tile_row(rowA):
+    """Tile_create accepts rowA % 16 != 0 (the CPU path of the reference handles it)."""
+    do, so, dp, sp, tp = _both("allfmt_pad5", SMALL["allfmt_pad5"], np.float64, True, rowA=rowA)
+    for k in do:
+        assert np.array_equal(np.asarray(do[k]), np.asarray(dp[k])), k
+    assert np.array_equal(sp["y"], so["y"]) and sp["errcount"] == 0
+
+
+def test_structural_invariants():
+    """offsets recorded by tilespmv_cpu equal the *_offset prefixes, etc."""
+    for name in ("allfmt", "circuit8k", "powerlaw20k"):
+        do, so, dp, sp, tp = _both(name, SMALL[name], np.float64, True)
+        fmt = dp["Format"]
+        off = {0: "csr_offset", 1: "coo_offset", 2: "ell_offset", 3: "hyb_offset", 4: "dns_offset", 5: "dnsrow_offset", 6: "dnscol_offset"}
+        for f, key in off.items():
+            sel = fmt == f
+            assert np.array_equal(sp["ptroffset1"][sel], dp[key][:-1][sel])
+        assert np.array_equal(sp["ptroffset2"][fmt == 0], dp["csrptr_offset"][:-1][fmt == 0])
+        stored = np.diff(dp["blknnz"])
+        assert np.array_equal(dp["blknnznnz"][:-1], stored.astype(np.uint8))
+        assert dp["deferredcoo_ptr"][-1] == dp["coototal"]
+        ntiles = sp["blkcoostylerowidx_colstop"] - sp["blkcoostylerowidx_colstart"]
+        assert (ntiles[(sp["blkcoostylerowidx"] >> 31) == 1] <= 4).all()
+        for r in range(len(dp["deferredcoo_ptr"]) - 1):
+            c = dp["deferredcoo_colidx"][dp["deferredcoo_ptr"][r]:dp["deferredcoo_ptr"][r + 1]]
+            assert (np.diff(c) > 0).all()
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(1, 90), st.integers(1, 90), st.integers(0, 2 ** 31 - 1), st.floats(0.002, 0.6), st.booleans(), st.booleans())
+def test_random_csr_property(m, n, seed, density, hyb, unsorted):
+    rng = np.random.default_rng(seed)
+    mask = rng.random((m, n)) < density
+    if seed % 3 == 0:  # plant block structure so dense / dense-row / dense-col rules fire
+        mask[: min(m, 16), : min(n, 16)] = True
+        if m > 20: mask[16:32, :] = False; mask[17, : min(n, 16)] = True
+        if n > 36: mask[: min(m, 16), 32:48] = False; mask[: min(m, 16), 35] = True
+    ri, ci = np.nonzero(mask)
+    rowptr = np.zeros(m + 1, np.int32); np.add.at(rowptr, ri + 1, 1); rowptr = np.cumsum(rowptr).astype(np.int32)
+    ci = ci.astype(np.int32)
+    if unsorted:  # columns inside a row in arbitrary order, as a symmetric .mtx produces
+        for r in range(m):
+            seg = ci[rowptr[r]:rowptr[r + 1]]
+            ci[rowptr[r]:rowptr[r + 1]] = rng.permutation(seg)
+    nnz = len(ci)
+    vals, x = G.compat_values(nnz), G.compat_x(n)
+    O = CpuImpl("oracle", np.float64)
+    to = O.tile_create(m, n, nnz, rowptr, ci, vals, hyb=hyb)
+    tp = api.Tile_create(m, n, nnz, rowptr, ci, vals, hyb=hyb)
+    do, dp = to_dict(to, m), to_dict(tp, m)
+    for k in do:
+        assert np.array_equal(np.asarray(do[k]), np.asarray(dp[k])), k
+    so = O.spmv(to, m, n, nnz, rowptr, ci, vals, x)
+    sp = api.tilespmv_cpu(tp, m, n, nnz, rowptr, ci, vals, x, so["y_golden"])
+    assert np.array_equal(sp["y"], so["y"])
+    if not unsorted:
+        assert sp["errcount"] == 0  # tile SpMV == CSR golden exactly (integer-valued data)
+    api.Tile_destroy(tp)
+
+
+def test_duplicate_entries_keep_reference_order():
+    """Duplicate (i,j) are kept as separate nonzeros; the extracted rows go through the reference's
+    unstable first-pivot sort, which the product restates (src/utils.h:103-137)."""
+    rp = np.array([0, 6, 6, 9] + [9] * 14, dtype=np.int32)
+    ci = np.array([40, 3, 40, 3, 40, 7, 100, 100, 2], dtype=np.int32)
+    vals = np.arange(1, 10, dtype=np.float64)
+    O = CpuImpl("oracle", np.float64)
+    to = O.tile_create(16, 128, 9, rp, ci, vals)
+    tp = api.Tile_create(16, 128, 9, rp, ci, vals)
+    do, dp = to_dict(to, 16), to_dict(tp, 16)
+    for k in do:
+        assert np.array_equal(np.asarray(do[k]), np.asarray(dp[k])), k
+
+
+def test_mmio_matches_oracle_and_known_answers(tmp_path):
+    kat = json.load(open(os.path.join(HERE, "golden", "mmio_kat.json")))
+    O = CpuImpl("oracle", np.float64)
+    files = [os.path.join(HERE, "golden", f) for f in kat]
+    # more header variants: pattern / integer / complex / skew / hermitian / comments / blank size line
+    variants = {
+        "pat.mtx": "%%MatrixMarket matrix coordinate pattern general\n% c\n%c2\n4 5 3\n1 1\n4 5\n2 3\n",
+        "int.mtx": "%%MatrixMarket MATRIX Coordinate Integer Symmetric\n3 3 3\n2 1 7\n3 3 -2\n3 1 4\n",
+        "cplx.mtx": "%%MatrixMarket matrix coordinate complex hermitian\n3 3 2\n2 1 1.5 -2\n3 3 4 0\n",
+        "skew.mtx": "%%MatrixMarket matrix coordinate real skew-symmetric\n3 3 2\n2 1 1.5\n3 2 -4e-1\n",
+        "blank.mtx": "%%MatrixMarket matrix coordinate real general\n\n 2 2 2\n1 2 3.25\n2 1 1e3\n",
+    }
+    for fn, text in variants.items():
+        p = tmp_path / fn; p.write_text(text); files.append(str(p))
+    for f in files:
+        a, b = O.mmio(f), api.mmio_allinone(f)
+        assert a["rc"] == b["rc"] == 0, f
+        for k in ("m", "n", "nnz", "sym"):
+            assert a[k] == b[k], (f, k)
+        for k in ("rowptr", "colidx", "val"):
+            assert np.array_equal(a[k], b[k]), (f, k)
+    assert api.mmio_allinone(str(tmp_path / "missing.mtx"))["rc"] == -1
+    bad = tmp_path / "bad.mtx"; bad.write_text("not a banner\n")
+    assert api.mmio_allinone(str(bad))["rc"] == -2
+    nosize = tmp_path / "nosize.mtx"; nosize.write_text("%%MatrixMarket matrix coordinate real general\n% only comments\n")
+    assert api.mmio_allinone(str(nosize))["rc"] == -4
+    for dtype in (np.float32,):
+        a, b = CpuImpl("oracle", dtype).mmio(files[0]), api.mmio_allinone(files[0], dtype)
+        assert np.array_equal(a["val"], b["val"]) and np.array_equal(a["colidx"], b["colidx"])
+
+
+def test_config1_test_mtx_cpu_path():
+    """BASELINE config 1: test.mtx, fp64, CPU path only — loader -> driver value rule -> Tile_create ->
+    tilespmv_cpu; pass = errcount 0 and equality with the committed reference dump."""
+    r = api.mmio_allinone(os.path.join(HERE, "golden", "test.mtx"))
+    m, n, nnz = r["m"], r["n"], r["nnz"]
+    vals, x = G.compat_values(nnz), G.compat_x(n)  # the driver overwrites file values (src/main.cu:68-69)
+    rowA = truncated_rows(m)
+    tp = api.Tile_create(rowA, n, nnz, r["rowptr"], r["colidx"], vals)
+    yg = CpuImpl("oracle").csr_spmv(rowA, r["rowptr"], r["colidx"], vals, x)
+    sp = api.tilespmv_cpu(tp, rowA, n, nnz, r["rowptr"], r["colidx"], vals, x, yg)
+    assert sp["errcount"] == 0
+    z = np.load(os.path.join(HERE, "golden", "allfmt_f64.npz"))
+    d = to_dict(tp, rowA)
+    for k, v in d.items():
+        assert np.array_equal(np.asarray(v), z[k]), k
+    assert np.array_equal(sp["y"], z["spmv_y"])
+
+
+def test_partition_tilerows_balanced():
+    m, n, rp, ci = MEDIUM["powerlaw200k"]()
+    nnz = len(ci); rowA = truncated_rows(m)
+    tp = api.Tile_create(rowA, n, nnz, rp, ci, G.compat_values(nnz))
+    d = to_dict(tp, rowA)
+    for parts in (1, 2, 3, 8):
+        b = api.partition_tilerows(tp, parts)
+        assert b[0] == 0 and b[-1] == d["tilem"] and (np.diff(b) >= 0).all()
+        load = np.diff(d["blknnz"][d["tile_ptr"][b]])
+        assert load.sum() == d["blknnz"][-1]
+        if parts > 1:
+            assert load.max() <= 1.5 * load.sum() / parts + 4096

@@ -1,0 +1,100 @@
+"""Row-block sharding of y = A*x across the GPUs of one node (new; the reference is single-GPU,
+src/main.cu:74).  One process per GPU, ``torch.distributed`` for the optional y combine
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Each output row depends on exactly one tile-row of A plus x, so contiguous blocks of whole
+tile-rows are independent units: rank k preprocesses and holds only its own
+row block, x is replicated, and the SpMV itself needs NO collective.  A combine of y is offered
+for callers that need the full vector on every rank:
+
+* ``allgather`` — every rank receives the other slices (7/8 of |y| spread over 7 xGMI links);
+* ``allreduce`` — the "RCCL reduce on y" of the north star: every rank holds a zero-filled
+  full-length y with its own slice filled in; the sum is bit-identical to the gather because
+  the other contributions are exact zeros.
+"""
+import numpy as np
+
+
+def partition_rows(rowptr, rows, nparts, align=16):
+    """nnz-balanced contiguous row blocks whose boundaries are multiples of ``align`` rows
+    (= whole tile-rows).  Returns nparts+1 row boundaries; the last one is ``rows``."""
+    rowptr = np.asarray(rowptr)
+    nblk = (rows + align - 1) // align
+    edges = np.minimum(np.arange(nblk + 1, dtype=np.int64) * align, rows)
+    work = rowptr[edges].astype(np.int64) + 2 * edges  # nonzeros + a little per-row cost
+    want = work[-1] * np.arange(1, nparts, dtype=np.float64) / nparts
+    cut = np.searchsorted(work, want, side="left")
+    b = np.concatenate([[0], np.minimum(cut, nblk), [nblk]]).astype(np.int64)
+    b = np.maximum.accumulate(b)
+    out = np.minimum(b * align, rows)
+    out[-1] = rows
+    return out
+
+
+def shard_csr(rowptr, colidx, vals, r0, r1):
+    """Rows [r0, r1) of a CSR matrix as a CSR matrix with a rebased row pointer (views, no copy of payload)."""
+    lo, hi = int(rowptr[r0]), int(rowptr[r1])
+    rp = (np.asarray(rowptr[r0:r1 + 1], dtype=np.int64) - lo).astype(np.int32)
+    return rp, colidx[lo:hi], vals[lo:hi]
+
+
+class ShardedSpMV:
+    """One rank's share of a row-partitioned SpMV.
+
+    ``local`` is the object that multiplies the local row block: by default a HIP ``Plan``;
+    the CPU (gloo) tests inject a stand-in so that the partition / combine logic can be
+    exercised without a GPU.
+    """
+
+    def __init__(self, rank, world, rows, cols, rowptr, colidx, vals, dtype=np.float64, make_local=None, **plan_kw):
+        from . import api
+        self.rank, self.world, self.rows, self.cols = rank, world, rows, cols
+        self.dtype = np.dtype(dtype)
+        self.bounds = partition_rows(rowptr, rows, world)
+        self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
+        rp, ci, v = shard_csr(rowptr, colidx, vals, self.r0, self.r1)
+        self.local_rows, self.local_nnz = self.r1 - self.r0, int(rp[-1])
+        if make_local is not None:
+            self.local = make_local(self.local_rows, cols, rp, ci, v)
+            self.tm = None
+        else:
+            self.tm = api.Tile_create(self.local_rows, cols, self.local_nnz, rp, ci, v, dtype=self.dtype)
+            self.local = api.Plan(self.tm, self.local_rows, cols, self.local_nnz, **plan_kw)
+        self.slice_max = int(np.diff(self.bounds).max())
+        self.equal_slices = bool((np.diff(self.bounds) == self.slice_max).all())
+        self._gather = None
+
+    # y_full: torch tensor with >= rows elements on the compute device; x: torch tensor with cols elements
+    def spmv(self, x, y_full, stream=0):
+        """y_full[r0:r1] = A[r0:r1, :] @ x — no communication."""
+        ysl = y_full[self.r0:]
+        self.local.spmv(x.data_ptr(), ysl.data_ptr(), stream)
+
+    def combine(self, y_full, mode):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1 or mode == "none":
+            return
+        if mode == "allreduce":
+            if self.r0 > 0:
+                y_full[:self.r0].zero_()
+            if self.r1 < self.rows:
+                y_full[self.r1:self.rows].zero_()
+            dist.all_reduce(y_full[:self.rows], op=dist.ReduceOp.SUM)
+        elif mode == "allgather":
+            if self._gather is None:
+                self._gather = torch.empty(self.world * self.slice_max, dtype=y_full.dtype, device=y_full.device)
+                self._send = torch.zeros(self.slice_max, dtype=y_full.dtype, device=y_full.device)
+            self._send[:self.local_rows].copy_(y_full[self.r0:self.r1])
+            dist.all_gather_into_tensor(self._gather, self._send)
+            for k in range(self.world):
+                if k == self.rank:
+                    continue
+                a, b = int(self.bounds[k]), int(self.bounds[k + 1])
+                y_full[a:b].copy_(self._gather[k * self.slice_max:k * self.slice_max + (b - a)])
+        else:
+            raise ValueError(mode)
+
+    def close(self):
+        if hasattr(self.local, "close"):
+            self.local.close()
