@@ -181,8 +181,8 @@ typedef struct tilespmv_plan tilespmv_plan;
 
 /* Fused-kernel generation. */
 #define TILESPMV_KERNEL_AUTO 0
-#define TILESPMV_KERNEL_DIRECT 1  /* strip-per-16-lanes, direct global loads */
-#define TILESPMV_KERNEL_STAGED 2  /* wave-private LDS staging of the payload stream */
+#define TILESPMV_KERNEL_DIRECT 1  /* strip-per-16-lanes, one tile at a time (first generation) */
+#define TILESPMV_KERNEL_STREAM 2  /* flat, index-addressed unit stream (second generation; default) */
 
 typedef struct {
     int coo_mode;       /* TILESPMV_COO_*    */

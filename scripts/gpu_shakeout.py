@@ -3,10 +3,13 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import cases as tests_cases
+sys.modules['tests_cases']=tests_cases
 from oracle.oracle import CpuImpl
 from tilespmv_amd import generators as G, api
 
-def run_case(name, m, n, rp, ci, dt, hyb, coo_mode, dense_mode, real=False):
+def run_case(name, m, n, rp, ci, dt, hyb, coo_mode, dense_mode, real=False, kernel=0):
     nnz = len(ci)
     rowA = (m // 16) * 16
     if real:
@@ -18,7 +21,7 @@ def run_case(name, m, n, rp, ci, dt, hyb, coo_mode, dense_mode, real=False):
     to = O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=hyb)
     so = O.spmv(to, rowA, n, nnz, rp, ci, vals, x)
     tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dt, hyb=hyb)
-    plan = api.Plan(tp, rowA, n, nnz, coo_mode=coo_mode, dense_mode=dense_mode)
+    plan = api.Plan(tp, rowA, n, nnz, coo_mode=coo_mode, dense_mode=dense_mode, kernel=kernel)
     xd = torch.from_numpy(x).cuda(); yd = torch.full((rowA + 16,), 777.0, dtype=xd.dtype, device="cuda")
     plan.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize()
     y = yd.cpu().numpy()[:rowA]
@@ -29,8 +32,8 @@ def run_case(name, m, n, rp, ci, dt, hyb, coo_mode, dense_mode, real=False):
     else:
         bad = int(np.count_nonzero(y != so["y"]))
     info = plan.info()
-    print("%-12s %-7s hyb=%d coo=%d dns=%d real=%d rows=%d nnz=%d tasks=%d split=%d fb=%d -> mismatches %d" % (
-        name, np.dtype(dt).name, hyb, info["coo_mode"], info["dense_mode"], real, rowA, nnz, info["num_tasks"], info["num_split_rows"], info["fallback_nnz"], bad), flush=True)
+    print("%-12s %-7s k=%d hyb=%d coo=%d dns=%d real=%d rows=%d nnz=%d tasks=%d split=%d fb=%d -> mismatches %d" % (
+        name, np.dtype(dt).name, info["kernel"], hyb, info["coo_mode"], info["dense_mode"], real, rowA, nnz, info["num_tasks"], info["num_split_rows"], info["fallback_nnz"], bad), flush=True)
     if bad:
         w = np.nonzero(y != so["y"])[0][:8]
         print("   first bad rows", w, y[w], so["y"][w])
@@ -38,7 +41,8 @@ def run_case(name, m, n, rp, ci, dt, hyb, coo_mode, dense_mode, real=False):
     return bad
 
 total = 0
-cases = [("lap64", G.laplacian5pt(64)), ("band_8", G.band(4096, 8)), ("band_40", G.band(4096, 40)), ("band1000", G.band(1000, 3)),
+from tests_cases import SMALL
+cases = [(k, g()) for k, g in SMALL.items()] + [("lap64", G.laplacian5pt(64)), ("band_8", G.band(4096, 8)), ("band_40", G.band(4096, 40)), ("band1000", G.band(1000, 3)),
          ("allfmt", G.all_formats()), ("allfmt_pad", G.all_formats(cols_pad=5)), ("rand", G.random_uniform(500, 700, 0.02, 3)),
          ("pl", G.powerlaw(20000)), ("circ", G.circuit_like(8000))]
 for dt in (np.float64, np.float32):
@@ -46,12 +50,13 @@ for dt in (np.float64, np.float32):
         for hyb in (False, True):
             for coo in (1, 2):
                 for dns in (1, 2):
-                    total += run_case(name, m, n, rp, ci, dt, hyb, coo, dns)
-        total += run_case(name, m, n, rp, ci, dt, True, 0, 0, real=True)
+                    for kern in (1, 2):
+                        total += run_case(name, m, n, rp, ci, dt, hyb, coo, dns, kernel=kern)
+        total += run_case(name, m, n, rp, ci, dt, True, 0, 0, real=True, kernel=2)
 print("TOTAL MISMATCHES", total, flush=True)
 
 # first timing
-for N in (1024, 4096):
+for N in (1024,):
     m, n, rp, ci = G.laplacian5pt(N); nnz = len(ci)
     vals = G.compat_values(nnz); x = G.compat_x(n)
     t0 = time.time(); tp = api.Tile_create(m, n, nnz, rp, ci, vals); t1 = time.time()

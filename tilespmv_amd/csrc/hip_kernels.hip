@@ -291,3 +291,175 @@ hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream
 int fallback_block_nnz() { return FB_NNZ; }
 
 }  // namespace tilespmv
+
+// ================================================================================================
+// Second generation: unit-stream kernel (layout: hip_plan.h "unit stream").
+// One 16-lane strip per task as before, but the common formats are consumed as a flat run of
+// self-describing 16-value units whose addresses depend only on the unit index:
+//   phase 1  COO entry list of the strip      -> LDS scatter-add (ds_add) into s_y[strip row][row]
+//   phase 2  heavy tiles (CSR, dense-row, dense on MFMA), one tile at a time, x segment in LDS
+//   phase 3  units (ELL slots, HYB ELL part, dense-col / dense columns) in batches of UB with all
+//            descriptor + payload loads of a batch issued before the first use; the tile-row's 16
+//            results are written when the unit flagged end-of-row retires.
+// ================================================================================================
+namespace tilespmv {
+
+template <bool DENSE_MFMA, int UB>
+__global__ __launch_bounds__(256) void k_tiles_stream(DevPlan P, DevStream S, const val_t *__restrict__ x, val_t *__restrict__ y)
+{
+    __shared__ val_t s_y[GROUPS_PER_BLOCK][STRIP_MAX_ROWS][16];
+    __shared__ val_t s_x[GROUPS_PER_BLOCK][16];
+    __shared__ val_t s_t[4][16];
+
+    const int tid = threadIdx.x, lane = tid & 63, r = tid & 15, g = tid >> 4, wave = tid >> 6;
+    const long long task_id = (long long)blockIdx.x * GROUPS_PER_BLOCK + g;
+    const bool have = task_id < S.ntasks;
+    STask tk;
+    if (have) tk = S.task[task_id];
+    else { memset(&tk, 0, sizeof(tk)); tk.partial = -1; }
+    const bool side = (tk.coo_end > tk.coo_begin) || (tk.heavy_end > tk.heavy_begin);
+
+    if (side) {
+        for (int k = 0; k < tk.nrows; k++) s_y[g][k][r] = 0;
+    }
+    wave_lds_fence();
+
+    // ---- phase 1: COO entries, 16 per step per strip
+    for (int e = tk.coo_begin + r; e < tk.coo_end; e += 16) {
+        const unsigned rb = S.crow[e];
+        atomicAdd(&s_y[g][rb >> 4][rb & 15u], S.cval[e] * x[S.ccol[e]]);
+    }
+
+    // ---- phase 2: heavy tiles
+    {
+        int ht = tk.heavy_begin;
+        long long hv = tk.hval_off, hi = tk.hidx_off;
+        while (__ballot(ht < tk.heavy_end) != 0ull) {
+            const bool on = ht < tk.heavy_end;
+            unsigned meta = DESC_FMT_NOP;
+            if (on) {
+                const uint2 d = S.hdesc[ht];
+                meta = d.y;
+                const long long xi = (long long)d.x * 16 + r;
+                s_x[g][r] = (xi < P.colA) ? x[xi] : (val_t)0;
+            }
+            const int fmt = (int)(meta & DESC_FMT_MASK), p1 = (int)((meta >> DESC_P1_SHIFT) & 255u);
+            val_t tacc = 0;
+            wave_lds_fence();
+            if (DENSE_MFMA) {
+                unsigned long long pending = __ballot(on && fmt == TILESPMV_FMT_DNS);
+                while (pending) {
+                    const int gl = (__ffsll((long long)pending) - 1) >> 4;
+                    const int lo = __builtin_amdgcn_readlane((int)(hv & 0xffffffffll), gl * 16);
+                    const int hi32 = __builtin_amdgcn_readlane((int)(hv >> 32), gl * 16);
+                    const long long vo = ((long long)hi32 << 32) | (unsigned)lo;
+                    mfma_dense_tile(S.hval + vo, &s_x[wave * 4 + gl][0], lane, &s_t[wave][0]);
+                    wave_lds_fence();
+                    if ((lane >> 4) == gl) tacc += s_t[wave][r];
+                    wave_lds_fence();
+                    pending &= ~(0xFFFFull << (gl * 16));
+                }
+            }
+            if (on) {
+                const val_t *__restrict__ v = S.hval + hv;
+                const unsigned char *__restrict__ ix = S.hidx + hi;
+                const val_t *xs = &s_x[g][0];
+                int nv = 0, ni = 0;
+                switch (fmt) {
+                case TILESPMV_FMT_CSR: {
+                    const int k0 = ix[r], k1 = (r == 15) ? p1 : (int)ix[r + 1];
+                    for (int k = k0; k < k1; k++) tacc += v[k] * xs[nibble_of(ix + 16, k)];
+                    nv = p1; ni = 16 + ((p1 + 1) >> 1);
+                    break;
+                }
+                case TILESPMV_FMT_DNS: {
+                    if (!DENSE_MFMA) {
+#pragma unroll 4
+                        for (int c = 0; c < 16; c++) tacc += v[16 * c + r] * xs[c];
+                    }
+                    nv = 256;
+                    break;
+                }
+                case TILESPMV_FMT_DNSROW: {
+                    const val_t xr = xs[r];
+                    for (int k = 0; k < p1; k++) {
+                        const val_t sum = strip_allreduce(v[16 * k + r] * xr);
+                        if (r == (int)ix[k]) tacc += sum;
+                    }
+                    nv = 16 * p1; ni = p1;
+                    break;
+                }
+                default: break;
+                }
+                s_y[g][(meta >> HDESC_ROW_SHIFT) & 7u][r] += tacc;
+                hv += nv; hi += ni; ht++;
+            }
+            wave_lds_fence();
+        }
+    }
+    wave_lds_fence();
+
+    // ---- phase 3: units
+    val_t acc = 0;
+    for (int u = tk.unit_begin; u < tk.unit_end; u += UB) {
+        uint4 d[UB];
+        val_t v[UB], xv[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const int uu = min(u + k, tk.unit_end - 1);
+            d[k] = S.udesc[uu];
+            v[k] = S.uval[(long long)uu * 16 + r];
+        }
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const unsigned word = (r < 8) ? d[k].y : d[k].z;
+            const unsigned nib = (word >> (28 - 4 * (r & 7))) & 15u;
+            xv[k] = x[(long long)d[k].x * 16 + nib];
+        }
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            if (u + k < tk.unit_end) {
+                acc += v[k] * xv[k];
+                if (d[k].w & UNIT_EOR) {
+                    const int kr = (int)((d[k].w >> UNIT_ROW_SHIFT) & 7u);
+                    val_t out = acc;
+                    if (side) out += s_y[g][kr][r];
+                    const long long yi = (long long)(tk.row + kr) * 16 + r;
+                    if (yi < P.rowA) y[yi] = out;
+                    acc = 0;
+                }
+            }
+        }
+    }
+    if (have) {
+        if (tk.partial >= 0) {
+            val_t out = acc;
+            if (side) out += s_y[g][0][r];
+            P.partial[(long long)tk.partial * 16 + r] = out;
+        } else {
+            unsigned m = tk.nounit_mask;
+            while (m) {
+                const int kr = __ffs((int)m) - 1;
+                m &= m - 1;
+                const long long yi = (long long)(tk.row + kr) * 16 + r;
+                if (yi < P.rowA) y[yi] = side ? s_y[g][kr][r] : (val_t)0;
+            }
+        }
+    }
+}
+
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, bool dense_mfma, int ub, const val_t *x, val_t *y, hipStream_t st)
+{
+    if (S.ntasks > 0) {
+        const dim3 grid((unsigned)((S.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), blk(256);
+#define TSPMV_LAUNCH(M, U) hipLaunchKernelGGL((k_tiles_stream<M, U>), grid, blk, 0, st, P, S, x, y)
+        if (dense_mfma) { if (ub == 2) TSPMV_LAUNCH(true, 2); else if (ub == 8) TSPMV_LAUNCH(true, 8); else TSPMV_LAUNCH(true, 4); }
+        else { if (ub == 2) TSPMV_LAUNCH(false, 2); else if (ub == 8) TSPMV_LAUNCH(false, 8); else TSPMV_LAUNCH(false, 4); }
+#undef TSPMV_LAUNCH
+    }
+    if (P.nfix > 0)
+        hipLaunchKernelGGL(k_fixup_split, dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, y);
+    return hipGetLastError();
+}
+
+}  // namespace tilespmv

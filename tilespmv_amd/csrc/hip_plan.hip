@@ -16,6 +16,7 @@
 namespace tilespmv {
 
 hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, const val_t *x, val_t *y, hipStream_t st);
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, bool dense_mfma, int ub, const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
 int fallback_block_nnz();
 
@@ -41,6 +42,8 @@ using namespace tilespmv;
 
 struct tilespmv_plan {
     DevPlan dev{};
+    DevStream st{};
+    int unit_batch = 4;
     std::vector<void *> allocs;
     long long info[TILESPMV_INFO_COUNT] = {0};
     int coo_mode = 0, dense_mode = 0, kernel = 0;
@@ -152,6 +155,225 @@ void repack_tile(const Tile_matrix *T, int t, const Emit &e, int rowlen, int col
 
 }  // namespace
 
+
+// ------------------------------------------------------------------------------------------------
+// Second-generation layout builder (hip_plan.h "unit stream").
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct RowCount { int nunits, ncoo, nheavy; long long hval, hidx; long long cost; };
+
+inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma)
+{
+    RowCount c{0, 0, 0, 0, 0, 0};
+    for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
+        switch (fmt) {
+        case TILESPMV_FMT_ELL: c.nunits += w; break;
+        case TILESPMV_FMT_HYB: c.nunits += w; if (coo_in_tile) c.ncoo += stored - w * rowlen; break;
+        case TILESPMV_FMT_DNSCOL: c.nunits += T->dnscolptr[t + 1] - T->dnscolptr[t]; break;
+        case TILESPMV_FMT_DNS:
+            if (dense_mfma) { c.nheavy++; c.hval += 256; }
+            else c.nunits += tile_collen(T->tile_columnidx[t], tilen, colA);
+            break;
+        case TILESPMV_FMT_COO: if (coo_in_tile) c.ncoo += stored; break;
+        case TILESPMV_FMT_CSR: c.nheavy++; c.hval += stored; c.hidx += 16 + (stored + 1) / 2; break;
+        case TILESPMV_FMT_DNSROW: { int k = T->dnsrowptr[t + 1] - T->dnsrowptr[t]; c.nheavy++; c.hval += 16 * k; c.hidx += k; break; }
+        }
+    }
+    c.cost = 16LL * c.nunits + 3LL * c.ncoo + c.hval + 16LL * c.nheavy + 8;
+    return c;
+}
+
+}  // namespace
+
+static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,
+                        bool dense_mfma, const std::vector<long long> &hyb_off, int target, int split_above, int piece,
+                        std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes)
+{
+    const int tilem = T->tilem, tilen = T->tilen, ntr = std::max(0, tr1 - tr0), sv = (int)sizeof(val_t);
+    std::vector<RowCount> rc_((size_t)ntr);
+    parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; i++) rc_[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma);
+    });
+    std::vector<long long> pu((size_t)ntr + 1, 0), pc((size_t)ntr + 1, 0), ph((size_t)ntr + 1, 0), phv((size_t)ntr + 1, 0), phi((size_t)ntr + 1, 0);
+    for (int i = 0; i < ntr; i++) {
+        pu[i + 1] = pu[i] + rc_[i].nunits; pc[i + 1] = pc[i] + rc_[i].ncoo; ph[i + 1] = ph[i] + rc_[i].nheavy;
+        phv[i + 1] = phv[i] + rc_[i].hval; phi[i + 1] = phi[i] + rc_[i].hidx;
+    }
+    const long long NU = pu[ntr], NC = pc[ntr], NH = ph[ntr], NHV = phv[ntr], NHI = phi[ntr];
+    if (NU > INT32_MAX || NC > INT32_MAX || NH > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit unit ids\n"); return -2; }
+
+    // ---- strips (<= STRIP_MAX_ROWS whole tile-rows up to the cost target) and pieces of very long tile-rows
+    std::vector<STask> tasks;
+    std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
+    auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
+    for (int i = 0; i < ntr;) {
+        if (rc_[i].cost > split_above) {
+            row_split[i] = 1;
+            FixRow f{tr0 + i, npartial, 0, 0};
+            const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, piece / 3);
+            for (long long u = pu[i]; u < pu[i + 1]; u += pu_) {
+                STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
+                k.unit_begin = (int)u; k.unit_end = (int)std::min(pu[i + 1], u + pu_);
+                tasks.push_back(k); f.count++;
+            }
+            for (long long c = pc[i]; c < pc[i + 1]; c += pc_) {
+                STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
+                k.coo_begin = (int)c; k.coo_end = (int)std::min(pc[i + 1], c + pc_);
+                tasks.push_back(k); f.count++;
+            }
+            if (rc_[i].nheavy > 0) {  // heavy tiles of a split row: cut at tile boundaries by payload size
+                long long h = ph[i], hv = phv[i], hi = phi[i];
+                int t = T->tile_ptr[tr0 + i];
+                while (h < ph[i + 1]) {
+                    STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
+                    k.heavy_begin = (int)h; k.hval_off = hv; k.hidx_off = hi;
+                    long long c = 0;
+                    while (h < ph[i + 1] && (c == 0 || c < piece)) {
+                        // advance t to the next heavy tile of this row
+                        for (;; t++) {
+                            const int fmt = T->Format[t];
+                            if (fmt == TILESPMV_FMT_CSR || fmt == TILESPMV_FMT_DNSROW || (fmt == TILESPMV_FMT_DNS && dense_mfma)) break;
+                        }
+                        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t];
+                        int nv = 0, ni = 0;
+                        if (fmt == TILESPMV_FMT_CSR) { nv = stored; ni = 16 + (stored + 1) / 2; }
+                        else if (fmt == TILESPMV_FMT_DNS) { nv = 256; }
+                        else { int kk = T->dnsrowptr[t + 1] - T->dnsrowptr[t]; nv = 16 * kk; ni = kk; }
+                        hv += nv; hi += ni; c += nv + 16; h++; t++;
+                    }
+                    k.heavy_end = (int)h;
+                    tasks.push_back(k); f.count++;
+                }
+            }
+            if (f.count == 0) {  // cannot happen (cost > split_above implies content), keep y defined anyway
+                STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
+                tasks.push_back(k); f.count++;
+            }
+            fix.push_back(f);
+            i++;
+            continue;
+        }
+        STask k = blank();
+        k.row = tr0 + i;
+        k.unit_begin = (int)pu[i]; k.coo_begin = (int)pc[i]; k.heavy_begin = (int)ph[i]; k.hval_off = phv[i]; k.hidx_off = phi[i];
+        long long c = 0;
+        int j = i;
+        while (j < ntr && j - i < STRIP_MAX_ROWS && rc_[j].cost <= split_above && (j == i || c + rc_[j].cost <= target)) {
+            row_k[j] = (unsigned char)(j - i);
+            if (rc_[j].nunits == 0) k.nounit_mask |= 1u << (j - i);
+            c += rc_[j].cost; j++;
+        }
+        k.nrows = j - i;
+        k.unit_end = (int)pu[j]; k.coo_end = (int)pc[j]; k.heavy_end = (int)ph[j];
+        tasks.push_back(k);
+        i = j;
+    }
+
+    // ---- fill
+    std::vector<uint4> h_udesc((size_t)NU);
+    val_t *h_uval = zalloc<val_t>((size_t)NU * 16);
+    val_t *h_cval = zalloc<val_t>((size_t)NC);
+    std::vector<int> h_ccol((size_t)NC);
+    std::vector<unsigned char> h_crow((size_t)NC);
+    std::vector<uint2> h_hdesc((size_t)NH);
+    val_t *h_hval = zalloc<val_t>((size_t)NHV);
+    unsigned char *h_hidx = zalloc<unsigned char>((size_t)NHI + 16);
+    parallel_chunks(ntr, 256, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; i++) {
+            const int bi = tr0 + (int)i, rowlen = tile_rowlen(bi, tilem, rowA);
+            const unsigned kr = row_k[i];
+            long long u = pu[i], c = pc[i], h = ph[i], hv = phv[i], hi = phi[i];
+            auto put_unit = [&](int cb, const val_t *src, int stride_ok_rows, unsigned long long nibs) {
+                // src: rowlen consecutive values of this column; nibs: 16 nibbles, row 0 in the top nibble
+                for (int r = 0; r < stride_ok_rows; r++) h_uval[u * 16 + r] = src[r];
+                h_udesc[(size_t)u] = make_uint4((unsigned)cb, (unsigned)(nibs >> 32), (unsigned)(nibs & 0xffffffffull), kr << UNIT_ROW_SHIFT);
+                u++;
+            };
+            for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+                const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
+                const int cb = T->tile_columnidx[t], collen = tile_collen(cb, tilen, colA);
+                switch (fmt) {
+                case TILESPMV_FMT_ELL: {
+                    const int off = T->ell_offset[t];
+                    for (int s = 0; s < w; s++) {
+                        unsigned long long nibs = 0;
+                        for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib(T->ell_compressedIdx, (long long)off + s * rowlen + r) << (60 - 4 * r);
+                        put_unit(cb, T->Blockell_Val + off + s * rowlen, rowlen, nibs);
+                    }
+                    break;
+                }
+                case TILESPMV_FMT_HYB: {
+                    const int off = T->hyb_offset[t], nell = w * rowlen;
+                    const unsigned char *src = T->hybIdx + hyb_off[t];
+                    for (int s = 0; s < w; s++) {
+                        unsigned long long nibs = 0;
+                        for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib(src, s * rowlen + r) << (60 - 4 * r);
+                        put_unit(cb, T->Blockhyb_Val + off + s * rowlen, rowlen, nibs);
+                    }
+                    if (coo_in_tile)
+                        for (int q = 0; q < stored - nell; q++) {
+                            const unsigned char rcb = src[(nell + 1) / 2 + q];
+                            h_cval[c] = T->Blockhyb_Val[off + nell + q]; h_ccol[(size_t)c] = cb * 16 + (rcb & 15);
+                            h_crow[(size_t)c] = (unsigned char)((kr << 4) | (rcb >> 4)); c++;
+                        }
+                    break;
+                }
+                case TILESPMV_FMT_DNSCOL: {
+                    const int off = T->dnscol_offset[t], co = T->dnscolptr[t], k = T->dnscolptr[t + 1] - co;
+                    for (int q = 0; q < k; q++) put_unit(cb, T->Blockdensecol_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)(T->densecolid[co + q] & 15));
+                    break;
+                }
+                case TILESPMV_FMT_COO:
+                    if (coo_in_tile) {
+                        const int off = T->coo_offset[t];
+                        for (int q = 0; q < stored; q++) {
+                            const unsigned char rcb = T->coo_compressed_Idx[off + q];
+                            h_cval[c] = T->Blockcoo_Val[off + q]; h_ccol[(size_t)c] = cb * 16 + (rcb & 15);
+                            h_crow[(size_t)c] = (unsigned char)((kr << 4) | (rcb >> 4)); c++;
+                        }
+                    }
+                    break;
+                case TILESPMV_FMT_DNS:
+                    if (!dense_mfma) {
+                        const int off = T->dns_offset[t];
+                        for (int q = 0; q < collen; q++) put_unit(cb, T->Blockdense_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)q);
+                        break;
+                    }
+                    // fallthrough: dense tile as a heavy (whole) tile for the matrix cores
+                case TILESPMV_FMT_CSR:
+                case TILESPMV_FMT_DNSROW: {
+                    Emit em = emit_of(T, t, rowlen, true);
+                    repack_tile(T, t, em, rowlen, collen, 0, h_hval + hv, h_hidx + hi);
+                    h_hdesc[(size_t)h] = make_uint2((unsigned)cb, (unsigned)em.fmt | ((unsigned)em.p1 << DESC_P1_SHIFT) | (kr << HDESC_ROW_SHIFT));
+                    h++; hv += em.nv; hi += em.ni;
+                    break;
+                }
+                }
+            }
+            if (!row_split[i] && u > pu[i]) h_udesc[(size_t)u - 1].w |= UNIT_EOR;
+        }
+    });
+
+    int rc = 0;
+    DevStream &S = plan->st;
+    rc |= plan->upload(h_udesc.data(), (size_t)NU, &S.udesc);
+    rc |= plan->upload(h_uval, (size_t)NU * 16, &S.uval);
+    rc |= plan->upload(h_cval, (size_t)NC, &S.cval);
+    rc |= plan->upload(h_ccol.data(), (size_t)NC, &S.ccol);
+    rc |= plan->upload(h_crow.data(), (size_t)NC, &S.crow);
+    rc |= plan->upload(h_hdesc.data(), (size_t)NH, &S.hdesc);
+    rc |= plan->upload(h_hval, (size_t)NHV, &S.hval);
+    rc |= plan->upload(h_hidx, (size_t)NHI, &S.hidx);
+    rc |= plan->upload(tasks.data(), tasks.size(), &S.task);
+    free(h_uval); free(h_cval); free(h_hval); free(h_hidx);
+    S.ntasks = (int)tasks.size();
+    n_tasks = (long long)tasks.size();
+    model_bytes = NU * (16 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask);
+    return rc;
+}
+
 extern "C" {
 
 int tilespmv_device_count(void)
@@ -220,7 +442,7 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     const bool coo_in_tile = coo_mode == TILESPMV_COO_IN_TILE;
     int dense_mode = o.dense_mode ? o.dense_mode : env_int("TILESPMV_DENSE_MODE", 0);
     if (dense_mode == TILESPMV_DENSE_AUTO) dense_mode = TILESPMV_DENSE_MFMA;
-    plan->coo_mode = coo_mode; plan->dense_mode = dense_mode; plan->kernel = TILESPMV_KERNEL_DIRECT;
+    plan->coo_mode = coo_mode; plan->dense_mode = dense_mode;
 
     // ---- HYB tiles address hybIdx by a running byte offset (reference ptroffset2, src/tilespmv_cpu.h:195-196)
     std::vector<long long> hyb_off;
@@ -238,6 +460,21 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
         }
     }
 
+    int kernel = o.kernel ? o.kernel : env_int("TILESPMV_KERNEL", 0);
+    if (kernel == TILESPMV_KERNEL_AUTO) kernel = TILESPMV_KERNEL_STREAM;
+    plan->kernel = kernel;
+    plan->unit_batch = env_int("TILESPMV_UNIT_BATCH", 4);
+    const int target = std::max(32, env_int("TILESPMV_STRIP_COST", kernel == TILESPMV_KERNEL_STREAM ? 400 : 192));
+    const int split_above = 6 * target, piece = 2 * target;
+    std::vector<FixRow> fix;
+    int npartial = 0;
+    long long n_tasks = 0, model_bytes = 0;
+    int rc = 0;
+    DevPlan &D = plan->dev;
+    if (kernel == TILESPMV_KERNEL_STREAM) {
+        rc = build_stream(plan, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mode == TILESPMV_DENSE_MFMA, hyb_off, target, split_above, piece,
+                          fix, npartial, n_tasks, model_bytes);
+    } else {
     // ---- pass 1: stream sizes per tile-row
     std::vector<long long> row_tile((size_t)ntr + 1, 0), row_val((size_t)ntr + 1, 0), row_idx((size_t)ntr + 1, 0);
     parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
@@ -283,11 +520,7 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
 
     // ---- strips: consecutive whole tile-rows up to a cost target; very long tile-rows are cut
     // at tile boundaries into pieces whose partial sums are combined by k_fixup_split.
-    const int target = std::max(32, env_int("TILESPMV_STRIP_COST", 192));
-    const int split_above = 6 * target, piece = 2 * target;
     std::vector<Task> tasks;
-    std::vector<FixRow> fix;
-    int npartial = 0;
     {
         auto row_cost = [&](int i) { long long c = 0; for (long long d = row_tile[i]; d < row_tile[i + 1]; d++) c += h_cost[d]; return c; };
         int i = 0;
@@ -321,6 +554,15 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
         }
     }
 
+    rc |= plan->upload(h_desc.data(), (size_t)n_desc, &D.desc);
+    rc |= plan->upload(h_val, (size_t)n_val, &D.val);
+    rc |= plan->upload(h_idx, (size_t)n_idx, &D.idx);
+    rc |= plan->upload(tasks.data(), tasks.size(), &D.task);
+    free(h_val); free(h_idx);
+    D.ntasks = (int)tasks.size();
+    n_tasks = (long long)tasks.size();
+    model_bytes = n_desc * 8 + n_val * sv + n_idx + n_tasks * (long long)sizeof(Task);
+    }
     // ---- very-sparse fallback matrix: the shard's rows of deferredcoo_*, plus its row blocks
     std::vector<int> f_ptr, f_blk;
     long long f_nnz = 0;
@@ -343,15 +585,8 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
         }
     }
 
-    // ---- upload
-    int rc = 0;
-    DevPlan &D = plan->dev;
-    rc |= plan->upload(h_desc.data(), (size_t)n_desc, &D.desc);
-    rc |= plan->upload(h_val, (size_t)n_val, &D.val);
-    rc |= plan->upload(h_idx, (size_t)n_idx, &D.idx);
-    rc |= plan->upload(tasks.data(), tasks.size(), &D.task);
+    // ---- upload the rest
     rc |= plan->upload(fix.data(), fix.size(), &D.fix);
-    free(h_val); free(h_idx);
     if (npartial > 0) {
         void *p = nullptr;
         if (hipMalloc(&p, (size_t)npartial * 16 * sizeof(val_t)) != hipSuccess) rc = -3;
@@ -366,7 +601,7 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
         D.f_nblk = (int)(f_blk.size() / 2);
     }
     if (rc) { tilespmv_plan_destroy(plan); return rc; }
-    D.ntasks = (int)tasks.size(); D.nfix = (int)fix.size();
+    D.nfix = (int)fix.size();
     D.rowA = std::min<long long>(rowA, (long long)tr1 * 16); D.colA = colA;
     D.f_row0 = row0; D.f_rows = rows;
 
@@ -375,11 +610,10 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     I[TILESPMV_INFO_ROWS] = rows;
     I[TILESPMV_INFO_TILES] = t_end - t_begin;
     I[TILESPMV_INFO_COO_MODE] = coo_mode; I[TILESPMV_INFO_DENSE_MODE] = dense_mode; I[TILESPMV_INFO_KERNEL] = plan->kernel;
-    I[TILESPMV_INFO_NUM_TASKS] = (long long)tasks.size(); I[TILESPMV_INFO_NUM_SPLIT_ROWS] = (long long)fix.size();
+    I[TILESPMV_INFO_NUM_TASKS] = n_tasks; I[TILESPMV_INFO_NUM_SPLIT_ROWS] = (long long)fix.size();
     I[TILESPMV_INFO_FALLBACK_NNZ] = f_nnz;
     // bytes one SpMV has to move at least: the three streams + tasks + x once + y once (+ fallback)
-    I[TILESPMV_INFO_STREAM_BYTES] = n_desc * 8 + n_val * sv + n_idx + (long long)tasks.size() * (long long)sizeof(Task) +
-                                    (long long)colA * sv + (long long)rows * sv +
+    I[TILESPMV_INFO_STREAM_BYTES] = model_bytes + (long long)colA * sv + (long long)rows * sv +
                                     (f_nnz ? f_nnz * (sv + 4) + (long long)rows * 4 + (long long)f_blk.size() * 4 : 0);
     *out = plan;
     return 0;
@@ -388,7 +622,9 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
 int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = launch_tiles_direct(plan->dev, plan->dense_mode == TILESPMV_DENSE_MFMA, d_x, d_y, st);
+    const bool mfma = plan->dense_mode == TILESPMV_DENSE_MFMA;
+    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, mfma, plan->unit_batch, d_x, d_y, st)
+                                                          : launch_tiles_direct(plan->dev, mfma, d_x, d_y, st);
     if (e != hipSuccess) return (int)e;
     return (int)launch_fallback(plan->dev, d_x, d_y, st);
 }
