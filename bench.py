@@ -186,7 +186,7 @@ def main():
         traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "kernel": "k_tiles_direct", "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_launch": int(b_alg_launch),
+                "kernel": "k_units" if info["kernel"] == 2 else "k_tiles_direct", "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_launch": int(b_alg_launch),
                 "plan_stream_bytes_per_launch": info["stream_bytes"], "timing": "hip events on the launch stream, timed region"}
 
     extra = {}

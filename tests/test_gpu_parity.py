@@ -62,10 +62,12 @@ def test_all_formats_all_modes_bit_exact(torch_cuda, name, dtype):
         to = O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=hyb)
         want = O.spmv(to, rowA, n, nnz, rp, ci, vals, x)["y"]
         tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=hyb)
-        for coo in (api.COO_IN_TILE, api.COO_FALLBACK, api.COO_AUTO):
-            for dns in (api.DENSE_MFMA, api.DENSE_VALU):
-                y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, coo_mode=coo, dense_mode=dns)
-                assert np.array_equal(y, want), (name, hyb, coo, dns, int(np.count_nonzero(y != want)))
+        for kernel in (api.KERNEL_STREAM, api.KERNEL_DIRECT):
+            for coo in (api.COO_IN_TILE, api.COO_FALLBACK, api.COO_AUTO):
+                for dns in (api.DENSE_MFMA, api.DENSE_VALU):
+                    y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, coo_mode=coo, dense_mode=dns, kernel=kernel)
+                    assert info["kernel"] == kernel
+                    assert np.array_equal(y, want), (name, hyb, kernel, coo, dns, int(np.count_nonzero(y != want)))
         api.Tile_destroy(tp)
 
 
@@ -82,9 +84,10 @@ def test_real_values_within_tolerance(torch_cuda, name, dtype):
     want = O.spmv(to, rowA, n, nnz, rp, ci, vals, x)["y"].astype(np.float64)
     tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=True)
     bound = TOL[np.dtype(dtype)] * _abs_bound(rowA, rp, ci, vals, x) + 1e-300
-    for coo in (api.COO_IN_TILE, api.COO_FALLBACK):
-        y, _ = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, coo_mode=coo)
-        assert (np.abs(y.astype(np.float64) - want) <= bound).all(), (name, coo)
+    for kernel in (api.KERNEL_STREAM, api.KERNEL_DIRECT):
+        for coo in (api.COO_IN_TILE, api.COO_FALLBACK):
+            y, _ = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, coo_mode=coo, kernel=kernel)
+            assert (np.abs(y.astype(np.float64) - want) <= bound).all(), (name, kernel, coo)
 
 
 @pytest.mark.parametrize("name", sorted(MEDIUM))
@@ -97,9 +100,33 @@ def test_medium_matrices_bit_exact(torch_cuda, name):
     O = CpuImpl("oracle", np.float64)
     want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals), rowA, n, nnz, rp, ci, vals, x)["y"]
     tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
-    for coo in (api.COO_IN_TILE, api.COO_FALLBACK):
-        y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, coo_mode=coo)
-        assert np.array_equal(y, want), (name, coo)
+    for kernel in (api.KERNEL_STREAM, api.KERNEL_DIRECT):
+        for coo in (api.COO_IN_TILE, api.COO_FALLBACK):
+            y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, coo_mode=coo, kernel=kernel)
+            assert np.array_equal(y, want), (name, kernel, coo)
+
+
+def test_split_rows_and_tiny_strips(torch_cuda, monkeypatch):
+    """Force the very-long-tile-row path (pieces + fixed-order fix-up) and 1-row strips."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api
+    monkeypatch.setenv("TILESPMV_STRIP_COST", "32")
+    for name in ("one_long_row", "wide_row_tiles", "allfmt", "band4096_40", "circuit8k"):
+        m, n, rp, ci = SMALL[name]()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, x = values_for(name, nnz, n, np.float64)
+        O = CpuImpl("oracle", np.float64)
+        want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, x)["y"]
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, hyb=True)
+        split_seen = 0
+        for kernel in (api.KERNEL_STREAM, api.KERNEL_DIRECT):
+            for coo in (api.COO_IN_TILE, api.COO_FALLBACK):
+                for dns in (api.DENSE_MFMA, api.DENSE_VALU):
+                    y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, coo_mode=coo, dense_mode=dns, kernel=kernel)
+                    split_seen += info["num_split_rows"]
+                    assert np.array_equal(y, want), (name, kernel, coo, dns)
+        if name in ("one_long_row", "wide_row_tiles", "band4096_40"):
+            assert split_seen > 0, name
 
 
 def test_partial_last_tile_row_and_column(torch_cuda):
@@ -114,9 +141,11 @@ def test_partial_last_tile_row_and_column(torch_cuda):
     for rowA in (187, 178, 33):
         want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, x)["y"]
         tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, hyb=True)
-        for coo in (api.COO_IN_TILE, api.COO_FALLBACK):
-            y, _ = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, coo_mode=coo)
-            assert np.array_equal(y, want), (rowA, coo)
+        for kernel in (api.KERNEL_STREAM, api.KERNEL_DIRECT):
+            for coo in (api.COO_IN_TILE, api.COO_FALLBACK):
+                for dns in (api.DENSE_MFMA, api.DENSE_VALU):
+                    y, _ = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, coo_mode=coo, dense_mode=dns, kernel=kernel)
+                    assert np.array_equal(y, want), (rowA, kernel, coo, dns)
 
 
 def test_shards_reproduce_full_result(torch_cuda):

@@ -17,6 +17,7 @@ _I, _U = _lib._I, _lib._U
 
 COO_AUTO, COO_IN_TILE, COO_FALLBACK = 0, 1, 2
 DENSE_AUTO, DENSE_MFMA, DENSE_VALU = 0, 1, 2
+KERNEL_AUTO, KERNEL_DIRECT, KERNEL_STREAM = 0, 1, 2
 CREATE_HYB, CREATE_QUIET = 1, 2
 
 

@@ -28,6 +28,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int GROUPS_PER_BLOCK = 16;  // 256 threads
+#ifndef TILESPMV_STREAM_MIN_WAVES
+#define TILESPMV_STREAM_MIN_WAVES 1     // second __launch_bounds__ argument = waves per SIMD asked of the register allocator
+#endif
 constexpr int FB_NNZ = 512;           // products staged per wave in the fallback kernel
 
 __device__ __forceinline__ int nibble_of(const unsigned char *__restrict__ base, int p)
@@ -95,7 +98,7 @@ __device__ __forceinline__ void mfma_dense_tile(const val_t *__restrict__ tile, 
 // ================================================================================================
 // Fused tile kernel, direct global loads.
 // ================================================================================================
-template <bool DENSE_MFMA>
+template <bool DENSE_MFMA, bool ACCUM>
 __global__ __launch_bounds__(256) void k_tiles_direct(DevPlan P, const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     __shared__ val_t s_x[GROUPS_PER_BLOCK][16];    // x segment of the strip's current tile
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void k_tiles_direct(DevPlan P, const val_t *__
                 val_t out = acc;
                 if (dirty) { out += s_acc[g][r]; s_acc[g][r] = 0; dirty = false; }
                 const long long yi = (long long)row * 16 + r;
-                if (yi < P.rowA) y[yi] = out;
+                if (yi < P.rowA) { if (ACCUM) y[yi] += out; else y[yi] = out; }
                 acc = 0; row++;
             }
         }
@@ -270,14 +273,16 @@ __global__ __launch_bounds__(256) void k_fallback_csr(DevPlan P, const val_t *__
 }
 
 // ---- launchers (host) ---------------------------------------------------------------------------
-hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, const val_t *x, val_t *y, hipStream_t st)
+hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulate, bool fixup, const val_t *x, val_t *y, hipStream_t st)
 {
     if (P.ntasks > 0) {
-        const unsigned grid = (unsigned)((P.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK);
-        if (dense_mfma) hipLaunchKernelGGL(k_tiles_direct<true>, dim3(grid), dim3(256), 0, st, P, x, y);
-        else hipLaunchKernelGGL(k_tiles_direct<false>, dim3(grid), dim3(256), 0, st, P, x, y);
+        const dim3 grid((unsigned)((P.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), blk(256);
+        if (dense_mfma) { if (accumulate) hipLaunchKernelGGL((k_tiles_direct<true, true>), grid, blk, 0, st, P, x, y);
+                          else hipLaunchKernelGGL((k_tiles_direct<true, false>), grid, blk, 0, st, P, x, y); }
+        else { if (accumulate) hipLaunchKernelGGL((k_tiles_direct<false, true>), grid, blk, 0, st, P, x, y);
+               else hipLaunchKernelGGL((k_tiles_direct<false, false>), grid, blk, 0, st, P, x, y); }
     }
-    if (P.nfix > 0)
+    if (fixup && P.nfix > 0)
         hipLaunchKernelGGL(k_fixup_split, dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, y);
     return hipGetLastError();
 }
@@ -296,170 +301,171 @@ int fallback_block_nnz() { return FB_NNZ; }
 // Second generation: unit-stream kernel (layout: hip_plan.h "unit stream").
 // One 16-lane strip per task as before, but the common formats are consumed as a flat run of
 // self-describing 16-value units whose addresses depend only on the unit index:
-//   phase 1  COO entry list of the strip      -> LDS scatter-add (ds_add) into s_y[strip row][row]
-//   phase 2  heavy tiles (CSR, dense-row, dense on MFMA), one tile at a time, x segment in LDS
-//   phase 3  units (ELL slots, HYB ELL part, dense-col / dense columns) in batches of UB with all
+//   phase 1  COO entry list of the strip -> LDS scatter-add (ds_add) into s_y[strip row][row]
+//   phase 2  units (ELL slots, HYB ELL part, dense-col / dense columns) in batches of UB with all
 //            descriptor + payload loads of a batch issued before the first use; the tile-row's 16
 //            results are written when the unit flagged end-of-row retires.
+// CSR / dense-row / MFMA-dense tiles ("heavy" tiles) are not in this kernel: they run afterwards
+// through k_tiles_direct<.., ACCUM=true>, which keeps the hot kernel at <= 64 VGPRs (8 waves/SIMD).
 // ================================================================================================
 namespace tilespmv {
 
-template <bool DENSE_MFMA, int UB>
-__global__ __launch_bounds__(256) void k_tiles_stream(DevPlan P, DevStream S, const val_t *__restrict__ x, val_t *__restrict__ y)
+// Descriptor word layout (16 B per unit, two identical-purpose halves so that a lane loads 8 B):
+//   word 0 / word 2 : column block (24 bits) | flags << 24   (flag bit 0 = end of tile-row, bits 1-3 = row in strip)
+//   word 1          : column nibbles of rows 0-7  (row 0 in the top nibble)
+//   word 3          : column nibbles of rows 8-15
+template <class T>
+__device__ __forceinline__ T stream_load(const T *p, bool nt)
+{
+    return nt ? __builtin_nontemporal_load(p) : *p;
+}
+__device__ __forceinline__ uint2 stream_load2(const uint2 *p, bool nt)
+{
+    if (!nt) return *p;
+    const unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p));
+    return make_uint2((unsigned)(w & 0xffffffffull), (unsigned)(w >> 32));
+}
+
+template <int UB, int XCD_REMAP, bool NT>
+__global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int xcd_chunk, int ablate, val_t *__restrict__ partial, const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     __shared__ val_t s_y[GROUPS_PER_BLOCK][STRIP_MAX_ROWS][16];
-    __shared__ val_t s_x[GROUPS_PER_BLOCK][16];
-    __shared__ val_t s_t[4][16];
-
-    const int tid = threadIdx.x, lane = tid & 63, r = tid & 15, g = tid >> 4, wave = tid >> 6;
-    const long long task_id = (long long)blockIdx.x * GROUPS_PER_BLOCK + g;
-    const bool have = task_id < S.ntasks;
-    STask tk;
-    if (have) tk = S.task[task_id];
-    else { memset(&tk, 0, sizeof(tk)); tk.partial = -1; }
-    const bool side = (tk.coo_end > tk.coo_begin) || (tk.heavy_end > tk.heavy_begin);
-
-    if (side) {
-        for (int k = 0; k < tk.nrows; k++) s_y[g][k][r] = 0;
+    const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), each
+    // with a private L2; XCD_REMAP gives every XCD one contiguous eighth of the strips (bijective
+    // for any grid size, cdna_hip_programming.md T1).  Placement only affects speed.
+    unsigned bid = blockIdx.x;
+    if (XCD_REMAP == 1) {
+        const unsigned nb = gridDim.x, q = nb >> 3, rem = nb & 7u, xcd = bid & 7u, idx = bid >> 3;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    } else if (XCD_REMAP >= 2) {
+        // windows of 8*C workgroups; inside a window XCD group k owns C consecutive ones, so all
+        // eight L2s work in one 8*C window (spread over the HBM channels) yet neighbours share an L2
+        const unsigned C = (unsigned)xcd_chunk, W = 8u * C, win = bid / W, off = bid % W, k = off & 7u;
+        // XCD group k walks its C workgroups starting k*C/8 in, so the eight L2s are never at the
+        // same offset of their chunks (equal offsets alias onto the same HBM channels)
+        if ((win + 1) * W <= gridDim.x) bid = win * W + k * C + ((off >> 3) + (XCD_REMAP == 3 ? k * (C >> 3) + k : 0u)) % C;
     }
-    wave_lds_fence();
+    const long long task_id = (long long)bid * GROUPS_PER_BLOCK + g;
+    if (task_id >= S.ntasks) return;  // whole strips only: no wave-wide operation below
+    const int4 t0 = reinterpret_cast<const int4 *>(S.task)[task_id * 2];
+    const int4 t1 = reinterpret_cast<const int4 *>(S.task)[task_id * 2 + 1];
+    const int unit_begin = t0.x, unit_end = t0.y, coo_begin = t0.z, coo_end = t0.w;
+    const int row0 = t1.x, part = t1.y, nrows = t1.w;
+    const unsigned nounit = (unsigned)t1.z;
+    const bool side = (coo_end > coo_begin) && !(ablate & 1);   // ablate bit 0: no COO phase
+    const uint2 *__restrict__ udesc = reinterpret_cast<const uint2 *>(S.udesc) + (r >> 3);
+    const val_t *__restrict__ uval = S.uval + r;
+    const int last = unit_end - 1;
+    const bool have_units = unit_begin < unit_end;
 
-    // ---- phase 1: COO entries, 16 per step per strip
-    for (int e = tk.coo_begin + r; e < tk.coo_end; e += 16) {
-        const unsigned rb = S.crow[e];
-        atomicAdd(&s_y[g][rb >> 4][rb & 15u], S.cval[e] * x[S.ccol[e]]);
-    }
-
-    // ---- phase 2: heavy tiles
-    {
-        int ht = tk.heavy_begin;
-        long long hv = tk.hval_off, hi = tk.hidx_off;
-        while (__ballot(ht < tk.heavy_end) != 0ull) {
-            const bool on = ht < tk.heavy_end;
-            unsigned meta = DESC_FMT_NOP;
-            if (on) {
-                const uint2 d = S.hdesc[ht];
-                meta = d.y;
-                const long long xi = (long long)d.x * 16 + r;
-                s_x[g][r] = (xi < P.colA) ? x[xi] : (val_t)0;
-            }
-            const int fmt = (int)(meta & DESC_FMT_MASK), p1 = (int)((meta >> DESC_P1_SHIFT) & 255u);
-            val_t tacc = 0;
-            wave_lds_fence();
-            if (DENSE_MFMA) {
-                unsigned long long pending = __ballot(on && fmt == TILESPMV_FMT_DNS);
-                while (pending) {
-                    const int gl = (__ffsll((long long)pending) - 1) >> 4;
-                    const int lo = __builtin_amdgcn_readlane((int)(hv & 0xffffffffll), gl * 16);
-                    const int hi32 = __builtin_amdgcn_readlane((int)(hv >> 32), gl * 16);
-                    const long long vo = ((long long)hi32 << 32) | (unsigned)lo;
-                    mfma_dense_tile(S.hval + vo, &s_x[wave * 4 + gl][0], lane, &s_t[wave][0]);
-                    wave_lds_fence();
-                    if ((lane >> 4) == gl) tacc += s_t[wave][r];
-                    wave_lds_fence();
-                    pending &= ~(0xFFFFull << (gl * 16));
-                }
-            }
-            if (on) {
-                const val_t *__restrict__ v = S.hval + hv;
-                const unsigned char *__restrict__ ix = S.hidx + hi;
-                const val_t *xs = &s_x[g][0];
-                int nv = 0, ni = 0;
-                switch (fmt) {
-                case TILESPMV_FMT_CSR: {
-                    const int k0 = ix[r], k1 = (r == 15) ? p1 : (int)ix[r + 1];
-                    for (int k = k0; k < k1; k++) tacc += v[k] * xs[nibble_of(ix + 16, k)];
-                    nv = p1; ni = 16 + ((p1 + 1) >> 1);
-                    break;
-                }
-                case TILESPMV_FMT_DNS: {
-                    if (!DENSE_MFMA) {
-#pragma unroll 4
-                        for (int c = 0; c < 16; c++) tacc += v[16 * c + r] * xs[c];
-                    }
-                    nv = 256;
-                    break;
-                }
-                case TILESPMV_FMT_DNSROW: {
-                    const val_t xr = xs[r];
-                    for (int k = 0; k < p1; k++) {
-                        const val_t sum = strip_allreduce(v[16 * k + r] * xr);
-                        if (r == (int)ix[k]) tacc += sum;
-                    }
-                    nv = 16 * p1; ni = p1;
-                    break;
-                }
-                default: break;
-                }
-                s_y[g][(meta >> HDESC_ROW_SHIFT) & 7u][r] += tacc;
-                hv += nv; hi += ni; ht++;
-            }
-            wave_lds_fence();
+    // ---- issue order: first COO chunk, then the first unit batch; both are in flight together
+    unsigned rb0 = 0; int cc0 = 0; val_t cv0 = 0;
+    const bool coo0 = side && (coo_begin + r < coo_end);
+    if (coo0) { rb0 = S.crow[coo_begin + r]; cc0 = S.ccol[coo_begin + r]; cv0 = S.cval[coo_begin + r]; }
+    uint2 d[UB];
+    val_t v[UB];
+    if (have_units) {
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const long long uu = min(unit_begin + k, last);
+            d[k] = stream_load2(udesc + uu * 2, NT);
+            v[k] = stream_load(uval + uu * 16, NT);
         }
     }
-    wave_lds_fence();
+    if (side) {  // phase 1: COO entries, 16 per step, LDS scatter-add
+        for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
+        wave_lds_fence();
+        if (coo0) atomicAdd(&s_y[g][rb0 >> 4][rb0 & 15u], cv0 * x[cc0]);
+        for (int e = coo_begin + 16 + r; e < coo_end; e += 16) {
+            const unsigned rb = S.crow[e];
+            atomicAdd(&s_y[g][rb >> 4][rb & 15u], S.cval[e] * x[S.ccol[e]]);
+        }
+        wave_lds_fence();
+    }
 
-    // ---- phase 3: units
     val_t acc = 0;
-    for (int u = tk.unit_begin; u < tk.unit_end; u += UB) {
-        uint4 d[UB];
-        val_t v[UB], xv[UB];
-#pragma unroll
-        for (int k = 0; k < UB; k++) {
-            const int uu = min(u + k, tk.unit_end - 1);
-            d[k] = S.udesc[uu];
-            v[k] = S.uval[(long long)uu * 16 + r];
+    auto retire = [&](val_t prod, unsigned flags) {  // one unit's contribution; writes y at end of tile-row
+        acc += prod;
+        if (flags & UNIT_EOR) {
+            const int kr = (int)((flags >> UNIT_ROW_SHIFT) & 7u);
+            val_t out = acc;
+            if (side) out += s_y[g][kr][r];
+            const long long yi = (long long)(row0 + kr) * 16 + r;
+            if (yi < rowA && (!(ablate & 4) || out == (val_t)123.456)) y[yi] = out;   // bit 2: no y store
+            acc = 0;
         }
+    };
+    if (have_units) {  // phase 2: software-pipelined by one batch
+        int u = unit_begin;
+        // steady state: every batch is full and the next batch's loads are issued UNCONDITIONALLY
+        // between this batch's x gathers and its first use, so the waits are exact counts
+        // (a conditional prefetch makes hipcc wait for the join's worst case, i.e. for the prefetch)
+        for (; u + UB < unit_end; u += UB) {
+            val_t xv[UB];
+            unsigned fl[UB];
 #pragma unroll
-        for (int k = 0; k < UB; k++) {
-            const unsigned word = (r < 8) ? d[k].y : d[k].z;
-            const unsigned nib = (word >> (28 - 4 * (r & 7))) & 15u;
-            xv[k] = x[(long long)d[k].x * 16 + nib];
-        }
-#pragma unroll
-        for (int k = 0; k < UB; k++) {
-            if (u + k < tk.unit_end) {
-                acc += v[k] * xv[k];
-                if (d[k].w & UNIT_EOR) {
-                    const int kr = (int)((d[k].w >> UNIT_ROW_SHIFT) & 7u);
-                    val_t out = acc;
-                    if (side) out += s_y[g][kr][r];
-                    const long long yi = (long long)(tk.row + kr) * 16 + r;
-                    if (yi < P.rowA) y[yi] = out;
-                    acc = 0;
-                }
+            for (int k = 0; k < UB; k++) {
+                const unsigned nib = (d[k].y >> (28 - 4 * (r & 7))) & 15u;
+                xv[k] = (ablate & 2) ? (val_t)(nib + d[k].x) : x[(long long)(d[k].x & 0xFFFFFFu) * 16 + nib];   // bit 1: no x gather
+                fl[k] = d[k].x >> 24;
             }
+            uint2 dn[UB];
+            val_t vn[UB];
+#pragma unroll
+            for (int k = 0; k < UB; k++) {
+                const long long uu = min(u + UB + k, last);
+                dn[k] = stream_load2(udesc + uu * 2, NT);
+                vn[k] = stream_load(uval + uu * 16, NT);
+            }
+#pragma unroll
+            for (int k = 0; k < UB; k++) retire(v[k] * xv[k], fl[k]);
+#pragma unroll
+            for (int k = 0; k < UB; k++) { d[k] = dn[k]; v[k] = vn[k]; }
+        }
+        {   // last (possibly partial) batch: nothing left to prefetch
+            val_t xv[UB];
+#pragma unroll
+            for (int k = 0; k < UB; k++) {
+                const unsigned nib = (d[k].y >> (28 - 4 * (r & 7))) & 15u;
+                xv[k] = x[(long long)(d[k].x & 0xFFFFFFu) * 16 + nib];
+            }
+#pragma unroll
+            for (int k = 0; k < UB; k++)
+                if (u + k < unit_end) retire(v[k] * xv[k], d[k].x >> 24);
         }
     }
-    if (have) {
-        if (tk.partial >= 0) {
-            val_t out = acc;
-            if (side) out += s_y[g][0][r];
-            P.partial[(long long)tk.partial * 16 + r] = out;
-        } else {
-            unsigned m = tk.nounit_mask;
-            while (m) {
-                const int kr = __ffs((int)m) - 1;
-                m &= m - 1;
-                const long long yi = (long long)(tk.row + kr) * 16 + r;
-                if (yi < P.rowA) y[yi] = side ? s_y[g][kr][r] : (val_t)0;
-            }
+    if (part >= 0) {
+        val_t out = acc;
+        if (side) out += s_y[g][0][r];
+        partial[(long long)part * 16 + r] = out;
+    } else {
+        unsigned m = nounit;
+        while (m) {
+            const int kr = __ffs((int)m) - 1;
+            m &= m - 1;
+            const long long yi = (long long)(row0 + kr) * 16 + r;
+            if (yi < rowA) y[yi] = side ? s_y[g][kr][r] : (val_t)0;
         }
     }
 }
 
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, bool dense_mfma, int ub, const val_t *x, val_t *y, hipStream_t st)
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, bool dense_mfma, int ub, int xcd_remap, int xcd_chunk, bool nt,
+                               const val_t *x, val_t *y, hipStream_t st)
 {
+    static const int ablate = getenv("TILESPMV_ABLATE") ? atoi(getenv("TILESPMV_ABLATE")) : 0;  // timing experiments only
     if (S.ntasks > 0) {
         const dim3 grid((unsigned)((S.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), blk(256);
-#define TSPMV_LAUNCH(M, U) hipLaunchKernelGGL((k_tiles_stream<M, U>), grid, blk, 0, st, P, S, x, y)
-        if (dense_mfma) { if (ub == 2) TSPMV_LAUNCH(true, 2); else if (ub == 8) TSPMV_LAUNCH(true, 8); else TSPMV_LAUNCH(true, 4); }
-        else { if (ub == 2) TSPMV_LAUNCH(false, 2); else if (ub == 8) TSPMV_LAUNCH(false, 8); else TSPMV_LAUNCH(false, 4); }
-#undef TSPMV_LAUNCH
+#define TSPMV_L3(U, X, N) hipLaunchKernelGGL((k_units<U, X, N>), grid, blk, 0, st, S, P.rowA, xcd_chunk, ablate, P.partial, x, y)
+#define TSPMV_L2(U, X) do { if (nt) TSPMV_L3(U, X, true); else TSPMV_L3(U, X, false); } while (0)
+#define TSPMV_L1(U) do { if (xcd_remap == 1) TSPMV_L2(U, 1); else if (xcd_remap == 2) TSPMV_L2(U, 2); else if (xcd_remap == 3) TSPMV_L2(U, 3); else TSPMV_L2(U, 0); } while (0)
+        if (ub == 2) TSPMV_L1(2); else if (ub == 8) TSPMV_L1(8); else if (ub == 6) TSPMV_L1(6); else TSPMV_L1(4);
+#undef TSPMV_L1
+#undef TSPMV_L2
+#undef TSPMV_L3
     }
-    if (P.nfix > 0)
-        hipLaunchKernelGGL(k_fixup_split, dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, y);
-    return hipGetLastError();
+    // heavy tiles (CSR, dense-row, MFMA dense): y += ..., then the split-row fix-up
+    return launch_tiles_direct(P, dense_mfma, /*accumulate=*/true, /*fixup=*/true, x, y, st);
 }
 
 }  // namespace tilespmv

@@ -63,33 +63,28 @@ struct DevPlan {
 // next units never wait on decoding the previous tile.  COO tiles (and HYB remainders) of a
 // strip are flattened into an entry list with global column ids; CSR / dense-row tiles (and
 // dense tiles when they run on the matrix cores) stay whole tiles in a "heavy" list that
-// keeps the first-generation per-tile layout.
+// keeps the first-generation per-tile layout (DevPlan streams) and is executed by the
+// first-generation kernel in accumulate mode after the unit kernel has written y.
 constexpr int STRIP_MAX_ROWS = 8;         // tile-rows per strip (3 bits of row-in-strip)
-constexpr unsigned UNIT_EOR = 1u;         // udesc.w bit 0: last unit of its tile-row -> write y
-constexpr int UNIT_ROW_SHIFT = 4;         // udesc.w bits 4-6: tile-row inside the strip
-constexpr int HDESC_ROW_SHIFT = 20;       // heavy desc .y bits 20-22: tile-row inside the strip
+constexpr unsigned UNIT_EOR = 1u;         // unit flag bit 0: last unit of its tile-row -> write y
+constexpr int UNIT_ROW_SHIFT = 1;         // unit flag bits 1-3: tile-row inside the strip
+constexpr int UNIT_FLAG_SHIFT = 24;       // flags live above the 24-bit column block in words 0 and 2
 
-struct STask {                            // 64 bytes
+struct STask {                            // 32 bytes
     int unit_begin, unit_end;
     int coo_begin, coo_end;
-    int heavy_begin, heavy_end;
-    long long hval_off, hidx_off;
     int row;                              // first tile-row of the strip (global numbering)
     int partial;                          // -1 or slot in partial[]
     unsigned nounit_mask;                 // bit k: tile-row k of the strip has no unit (flushed at the end)
     int nrows;
-    int pad[2];
 };
 
 struct DevStream {
-    const uint4 *udesc;                   // per unit: .x column block, .y/.z 16 column nibbles (row 0 = top nibble of .y), .w flags
+    const uint4 *udesc;                   // per unit: .x = .z = column block | flags << 24, .y / .w = column nibbles of rows 0-7 / 8-15
     const val_t *uval;                    // 16 values per unit
     const val_t *cval;                    // COO entry list: value, global column, (row-in-strip << 4) | row
     const int *ccol;
     const unsigned char *crow;
-    const uint2 *hdesc;                   // heavy tiles: first-generation descriptor + row-in-strip
-    const val_t *hval;
-    const unsigned char *hidx;
     const STask *task;
     int ntasks;
 };

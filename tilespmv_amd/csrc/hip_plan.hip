@@ -15,8 +15,9 @@
 
 namespace tilespmv {
 
-hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, const val_t *x, val_t *y, hipStream_t st);
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, bool dense_mfma, int ub, const val_t *x, val_t *y, hipStream_t st);
+hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulate, bool fixup, const val_t *x, val_t *y, hipStream_t st);
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, bool dense_mfma, int ub, int xcd_remap, int xcd_chunk, bool nt,
+                               const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
 int fallback_block_nnz();
 
@@ -44,6 +45,8 @@ struct tilespmv_plan {
     DevPlan dev{};
     DevStream st{};
     int unit_batch = 4;
+    int xcd_remap = 0, xcd_chunk = 64;
+    bool nontemporal = false;
     std::vector<void *> allocs;
     long long info[TILESPMV_INFO_COUNT] = {0};
     int coo_mode = 0, dense_mode = 0, kernel = 0;
@@ -202,12 +205,26 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         phv[i + 1] = phv[i] + rc_[i].hval; phi[i + 1] = phi[i] + rc_[i].hidx;
     }
     const long long NU = pu[ntr], NC = pc[ntr], NH = ph[ntr], NHV = phv[ntr], NHI = phi[ntr];
+    if (tilen > (1 << UNIT_FLAG_SHIFT)) { fprintf(stderr, "tilespmv: more than 2^24 column blocks: use TILESPMV_KERNEL=1\n"); return -2; }
     if (NU > INT32_MAX || NC > INT32_MAX || NH > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit unit ids\n"); return -2; }
 
-    // ---- strips (<= STRIP_MAX_ROWS whole tile-rows up to the cost target) and pieces of very long tile-rows
+    // ---- strips (<= STRIP_MAX_ROWS whole tile-rows up to the cost target) for the unit kernel, one
+    // heavy task per tile-row that owns heavy tiles, and pieces of very long tile-rows (all three
+    // kinds of pieces write partial[] slots that k_fixup_split adds up in a fixed order).
     std::vector<STask> tasks;
+    std::vector<Task> htasks;
     std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
     auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
+    auto is_heavy = [&](int t) {
+        const int fmt = T->Format[t];
+        return fmt == TILESPMV_FMT_CSR || fmt == TILESPMV_FMT_DNSROW || (fmt == TILESPMV_FMT_DNS && dense_mfma);
+    };
+    auto heavy_sizes = [&](int t, int *nv, int *ni) {
+        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t];
+        if (fmt == TILESPMV_FMT_CSR) { *nv = stored; *ni = 16 + (stored + 1) / 2; }
+        else if (fmt == TILESPMV_FMT_DNS) { *nv = 256; *ni = 0; }
+        else { int kk = T->dnsrowptr[t + 1] - T->dnsrowptr[t]; *nv = 16 * kk; *ni = kk; }
+    };
     for (int i = 0; i < ntr;) {
         if (rc_[i].cost > split_above) {
             row_split[i] = 1;
@@ -223,33 +240,18 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
                 k.coo_begin = (int)c; k.coo_end = (int)std::min(pc[i + 1], c + pc_);
                 tasks.push_back(k); f.count++;
             }
-            if (rc_[i].nheavy > 0) {  // heavy tiles of a split row: cut at tile boundaries by payload size
-                long long h = ph[i], hv = phv[i], hi = phi[i];
-                int t = T->tile_ptr[tr0 + i];
-                while (h < ph[i + 1]) {
-                    STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
-                    k.heavy_begin = (int)h; k.hval_off = hv; k.hidx_off = hi;
-                    long long c = 0;
-                    while (h < ph[i + 1] && (c == 0 || c < piece)) {
-                        // advance t to the next heavy tile of this row
-                        for (;; t++) {
-                            const int fmt = T->Format[t];
-                            if (fmt == TILESPMV_FMT_CSR || fmt == TILESPMV_FMT_DNSROW || (fmt == TILESPMV_FMT_DNS && dense_mfma)) break;
-                        }
-                        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t];
-                        int nv = 0, ni = 0;
-                        if (fmt == TILESPMV_FMT_CSR) { nv = stored; ni = 16 + (stored + 1) / 2; }
-                        else if (fmt == TILESPMV_FMT_DNS) { nv = 256; }
-                        else { int kk = T->dnsrowptr[t + 1] - T->dnsrowptr[t]; nv = 16 * kk; ni = kk; }
-                        hv += nv; hi += ni; c += nv + 16; h++; t++;
-                    }
-                    k.heavy_end = (int)h;
-                    tasks.push_back(k); f.count++;
+            long long h = ph[i], hv = phv[i], hi = phi[i];
+            int t = T->tile_ptr[tr0 + i];
+            while (h < ph[i + 1]) {  // heavy tiles of a split row: cut at tile boundaries by payload size
+                Task k{(int)h, (int)h, hv, hi, tr0 + i, npartial++};
+                long long c = 0;
+                while (h < ph[i + 1] && (c == 0 || c < piece)) {
+                    while (!is_heavy(t)) t++;
+                    int nv, ni; heavy_sizes(t, &nv, &ni);
+                    hv += nv; hi += ni; c += nv + 16; h++; t++;
                 }
-            }
-            if (f.count == 0) {  // cannot happen (cost > split_above implies content), keep y defined anyway
-                STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
-                tasks.push_back(k); f.count++;
+                k.tile_end = (int)h;
+                htasks.push_back(k); f.count++;
             }
             fix.push_back(f);
             i++;
@@ -257,16 +259,17 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         }
         STask k = blank();
         k.row = tr0 + i;
-        k.unit_begin = (int)pu[i]; k.coo_begin = (int)pc[i]; k.heavy_begin = (int)ph[i]; k.hval_off = phv[i]; k.hidx_off = phi[i];
+        k.unit_begin = (int)pu[i]; k.coo_begin = (int)pc[i];
         long long c = 0;
         int j = i;
         while (j < ntr && j - i < STRIP_MAX_ROWS && rc_[j].cost <= split_above && (j == i || c + rc_[j].cost <= target)) {
             row_k[j] = (unsigned char)(j - i);
             if (rc_[j].nunits == 0) k.nounit_mask |= 1u << (j - i);
+            if (rc_[j].nheavy > 0) htasks.push_back(Task{(int)ph[j], (int)ph[j + 1], phv[j], phi[j], tr0 + j, -1});
             c += rc_[j].cost; j++;
         }
         k.nrows = j - i;
-        k.unit_end = (int)pu[j]; k.coo_end = (int)pc[j]; k.heavy_end = (int)ph[j];
+        k.unit_end = (int)pu[j]; k.coo_end = (int)pc[j];
         tasks.push_back(k);
         i = j;
     }
@@ -288,7 +291,8 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
             auto put_unit = [&](int cb, const val_t *src, int stride_ok_rows, unsigned long long nibs) {
                 // src: rowlen consecutive values of this column; nibs: 16 nibbles, row 0 in the top nibble
                 for (int r = 0; r < stride_ok_rows; r++) h_uval[u * 16 + r] = src[r];
-                h_udesc[(size_t)u] = make_uint4((unsigned)cb, (unsigned)(nibs >> 32), (unsigned)(nibs & 0xffffffffull), kr << UNIT_ROW_SHIFT);
+                const unsigned w0 = (unsigned)cb | ((kr << UNIT_ROW_SHIFT) << UNIT_FLAG_SHIFT);
+                h_udesc[(size_t)u] = make_uint4(w0, (unsigned)(nibs >> 32), w0, (unsigned)(nibs & 0xffffffffull));
                 u++;
             };
             for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
@@ -346,13 +350,14 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
                 case TILESPMV_FMT_DNSROW: {
                     Emit em = emit_of(T, t, rowlen, true);
                     repack_tile(T, t, em, rowlen, collen, 0, h_hval + hv, h_hidx + hi);
-                    h_hdesc[(size_t)h] = make_uint2((unsigned)cb, (unsigned)em.fmt | ((unsigned)em.p1 << DESC_P1_SHIFT) | (kr << HDESC_ROW_SHIFT));
+                    h_hdesc[(size_t)h] = make_uint2((unsigned)cb, (unsigned)em.fmt | ((unsigned)em.p1 << DESC_P1_SHIFT));
                     h++; hv += em.nv; hi += em.ni;
                     break;
                 }
                 }
             }
-            if (!row_split[i] && u > pu[i]) h_udesc[(size_t)u - 1].w |= UNIT_EOR;
+            if (!row_split[i] && u > pu[i]) { h_udesc[(size_t)u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; h_udesc[(size_t)u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
+            if (h > ph[i]) h_hdesc[(size_t)h - 1].y |= DESC_EOR;
         }
     });
 
@@ -363,14 +368,18 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     rc |= plan->upload(h_cval, (size_t)NC, &S.cval);
     rc |= plan->upload(h_ccol.data(), (size_t)NC, &S.ccol);
     rc |= plan->upload(h_crow.data(), (size_t)NC, &S.crow);
-    rc |= plan->upload(h_hdesc.data(), (size_t)NH, &S.hdesc);
-    rc |= plan->upload(h_hval, (size_t)NHV, &S.hval);
-    rc |= plan->upload(h_hidx, (size_t)NHI, &S.hidx);
+    DevPlan &D = plan->dev;  // heavy tiles reuse the first-generation streams + kernel (accumulate mode)
+    rc |= plan->upload(h_hdesc.data(), (size_t)NH, &D.desc);
+    rc |= plan->upload(h_hval, (size_t)NHV, &D.val);
+    rc |= plan->upload(h_hidx, (size_t)NHI, &D.idx);
+    rc |= plan->upload(htasks.data(), htasks.size(), &D.task);
+    D.ntasks = (int)htasks.size();
     rc |= plan->upload(tasks.data(), tasks.size(), &S.task);
     free(h_uval); free(h_cval); free(h_hval); free(h_hidx);
     S.ntasks = (int)tasks.size();
     n_tasks = (long long)tasks.size();
-    model_bytes = NU * (16 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask);
+    model_bytes = NU * (16 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
+                  (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv);  // heavy pass re-reads and re-writes its rows of y
     return rc;
 }
 
@@ -464,6 +473,9 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     if (kernel == TILESPMV_KERNEL_AUTO) kernel = TILESPMV_KERNEL_STREAM;
     plan->kernel = kernel;
     plan->unit_batch = env_int("TILESPMV_UNIT_BATCH", 4);
+    plan->xcd_remap = env_int("TILESPMV_XCD_REMAP", 0);
+    plan->xcd_chunk = std::max(1, env_int("TILESPMV_XCD_CHUNK", 64));
+    plan->nontemporal = env_int("TILESPMV_NT", 0) != 0;
     const int target = std::max(32, env_int("TILESPMV_STRIP_COST", kernel == TILESPMV_KERNEL_STREAM ? 400 : 192));
     const int split_above = 6 * target, piece = 2 * target;
     std::vector<FixRow> fix;
@@ -623,8 +635,8 @@ int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYP
 {
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = plan->dense_mode == TILESPMV_DENSE_MFMA;
-    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, mfma, plan->unit_batch, d_x, d_y, st)
-                                                          : launch_tiles_direct(plan->dev, mfma, d_x, d_y, st);
+    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, mfma, plan->unit_batch, plan->xcd_remap, plan->xcd_chunk, plan->nontemporal, d_x, d_y, st)
+                                                          : launch_tiles_direct(plan->dev, mfma, false, true, d_x, d_y, st);
     if (e != hipSuccess) return (int)e;
     return (int)launch_fallback(plan->dev, d_x, d_y, st);
 }
