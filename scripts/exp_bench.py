@@ -16,7 +16,8 @@ def main():
     vals, x = G.compat_values(len(ci), dtype), G.compat_x(n, dtype)
     tm = api.Tile_create(rows, n, nnz, rp, ci, vals, dtype=dtype)
     xd = torch.from_numpy(x).cuda(); yd = torch.zeros(rows + 16, dtype=xd.dtype, device="cuda")
-    seg = np.add.reduceat(vals.astype(np.float64) * x[ci].astype(np.float64), rp[:-1][:rows]) if nnz < 3e8 else None
+    import scipy.sparse as sp
+    seg = sp.csr_matrix((vals[:nnz].astype(np.float64), ci[:nnz], rp[:rows + 1]), shape=(rows, n)) @ x.astype(np.float64)
     balg = api.algorithmic_bytes(nnz, rows, n, np.dtype(dtype).itemsize)
     plans = []
     for v in variants:

@@ -106,6 +106,25 @@ def test_medium_matrices_bit_exact(torch_cuda, name):
             assert np.array_equal(y, want), (name, kernel, coo)
 
 
+def test_csr_tiles_as_whole_tiles(torch_cuda, monkeypatch):
+    """TILESPMV_CSR_SPLIT=0: CSR tiles run through the per-tile CSR routine (heavy list) instead of
+    being executed as units + COO entries."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api
+    monkeypatch.setenv("TILESPMV_CSR_SPLIT", "0")
+    for name in ("allfmt", "circuit8k", "powerlaw20k", "band4096_8", "rand500x700"):
+        for dtype in (np.float64, np.float32):
+            m, n, rp, ci = SMALL[name]()
+            nnz, rowA = len(ci), truncated_rows(m)
+            vals, x = values_for(name, nnz, n, dtype)
+            O = CpuImpl("oracle", dtype)
+            want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals), rowA, n, nnz, rp, ci, vals, x)["y"]
+            tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype)
+            for dns in (api.DENSE_MFMA, api.DENSE_VALU):
+                y, _ = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, kernel=api.KERNEL_STREAM, dense_mode=dns)
+                assert np.array_equal(y, want), (name, dtype, dns)
+
+
 def test_split_rows_and_tiny_strips(torch_cuda, monkeypatch):
     """Force the very-long-tile-row path (pieces + fixed-order fix-up) and 1-row strips."""
     from oracle.oracle import CpuImpl

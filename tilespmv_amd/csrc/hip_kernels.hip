@@ -327,7 +327,7 @@ __device__ __forceinline__ uint2 stream_load2(const uint2 *p, bool nt)
 }
 
 template <int UB, int XCD_REMAP, bool NT>
-__global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int xcd_chunk, int ablate, val_t *__restrict__ partial, const val_t *__restrict__ x, val_t *__restrict__ y)
+__global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, int ablate, val_t *__restrict__ partial, const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     __shared__ val_t s_y[GROUPS_PER_BLOCK][STRIP_MAX_ROWS][16];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
@@ -358,6 +358,7 @@ __global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int xcd_ch
     const val_t *__restrict__ uval = S.uval + r;
     const int last = unit_end - 1;
     const bool have_units = unit_begin < unit_end;
+    const long long xlast = (long long)colA - 1;  // row units of a partial last column block: zero payload, clamped x index
 
     // ---- issue order: first COO chunk, then the first unit batch; both are in flight together
     unsigned rb0 = 0; int cc0 = 0; val_t cv0 = 0;
@@ -377,15 +378,29 @@ __global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int xcd_ch
         for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
         wave_lds_fence();
         if (coo0) atomicAdd(&s_y[g][rb0 >> 4][rb0 & 15u], cv0 * x[cc0]);
-        for (int e = coo_begin + 16 + r; e < coo_end; e += 16) {
-            const unsigned rb = S.crow[e];
-            atomicAdd(&s_y[g][rb >> 4][rb & 15u], S.cval[e] * x[S.ccol[e]]);
+        // remaining entries, 4 x 16 per trip: all index/value loads of a trip first, then the x gathers
+        for (int e0 = coo_begin + 16; e0 < coo_end; e0 += 64) {
+            unsigned rb[4]; int cc[4]; val_t cv[4], xx[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int e = min(e0 + 16 * q + r, coo_end - 1);
+                rb[q] = S.crow[e]; cc[q] = S.ccol[e]; cv[q] = S.cval[e];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) xx[q] = x[cc[q]];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (e0 + 16 * q + r < coo_end) atomicAdd(&s_y[g][rb[q] >> 4][rb[q] & 15u], cv[q] * xx[q]);
         }
         wave_lds_fence();
     }
 
     val_t acc = 0;
-    auto retire = [&](val_t prod, unsigned flags) {  // one unit's contribution; writes y at end of tile-row
+    auto retire = [&](val_t prod, unsigned flags, unsigned word1) {  // one unit's contribution; writes y at end of tile-row
+        if (flags & UNIT_ROWUNIT) {  // dense-row unit: lanes hold one row's products
+            prod = strip_allreduce(prod);
+            if (r != (int)(word1 & 15u)) prod = 0;
+        }
         acc += prod;
         if (flags & UNIT_EOR) {
             const int kr = (int)((flags >> UNIT_ROW_SHIFT) & 7u);
@@ -406,9 +421,10 @@ __global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int xcd_ch
             unsigned fl[UB];
 #pragma unroll
             for (int k = 0; k < UB; k++) {
-                const unsigned nib = (d[k].y >> (28 - 4 * (r & 7))) & 15u;
-                xv[k] = (ablate & 2) ? (val_t)(nib + d[k].x) : x[(long long)(d[k].x & 0xFFFFFFu) * 16 + nib];   // bit 1: no x gather
                 fl[k] = d[k].x >> 24;
+                const unsigned nib = (fl[k] & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
+                const long long xi = min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast);
+                xv[k] = (ablate & 2) ? (val_t)(nib + d[k].x) : x[xi];   // bit 1: no x gather
             }
             uint2 dn[UB];
             val_t vn[UB];
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int xcd_ch
                 vn[k] = stream_load(uval + uu * 16, NT);
             }
 #pragma unroll
-            for (int k = 0; k < UB; k++) retire(v[k] * xv[k], fl[k]);
+            for (int k = 0; k < UB; k++) retire(v[k] * xv[k], fl[k], d[k].y);
 #pragma unroll
             for (int k = 0; k < UB; k++) { d[k] = dn[k]; v[k] = vn[k]; }
         }
@@ -427,12 +443,12 @@ __global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int xcd_ch
             val_t xv[UB];
 #pragma unroll
             for (int k = 0; k < UB; k++) {
-                const unsigned nib = (d[k].y >> (28 - 4 * (r & 7))) & 15u;
-                xv[k] = x[(long long)(d[k].x & 0xFFFFFFu) * 16 + nib];
+                const unsigned nib = ((d[k].x >> 24) & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
+                xv[k] = x[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast)];
             }
 #pragma unroll
             for (int k = 0; k < UB; k++)
-                if (u + k < unit_end) retire(v[k] * xv[k], d[k].x >> 24);
+                if (u + k < unit_end) retire(v[k] * xv[k], d[k].x >> 24, d[k].y);
         }
     }
     if (part >= 0) {
@@ -456,7 +472,7 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, bool dense_
     static const int ablate = getenv("TILESPMV_ABLATE") ? atoi(getenv("TILESPMV_ABLATE")) : 0;  // timing experiments only
     if (S.ntasks > 0) {
         const dim3 grid((unsigned)((S.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), blk(256);
-#define TSPMV_L3(U, X, N) hipLaunchKernelGGL((k_units<U, X, N>), grid, blk, 0, st, S, P.rowA, xcd_chunk, ablate, P.partial, x, y)
+#define TSPMV_L3(U, X, N) hipLaunchKernelGGL((k_units<U, X, N>), grid, blk, 0, st, S, P.rowA, P.colA, xcd_chunk, ablate, P.partial, x, y)
 #define TSPMV_L2(U, X) do { if (nt) TSPMV_L3(U, X, true); else TSPMV_L3(U, X, false); } while (0)
 #define TSPMV_L1(U) do { if (xcd_remap == 1) TSPMV_L2(U, 1); else if (xcd_remap == 2) TSPMV_L2(U, 2); else if (xcd_remap == 3) TSPMV_L2(U, 3); else TSPMV_L2(U, 0); } while (0)
         if (ub == 2) TSPMV_L1(2); else if (ub == 8) TSPMV_L1(8); else if (ub == 6) TSPMV_L1(6); else TSPMV_L1(4);

@@ -166,8 +166,28 @@ namespace {
 
 struct RowCount { int nunits, ncoo, nheavy; long long hval, hidx; long long cost; };
 
-inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma)
+// A CSR tile is executed as w ELL-style units (the first w entries of every row) plus the rest of
+// its entries on the strip's COO list; w minimises the bytes moved (HYB's idea, src/csr2tile.h:279-306,
+// with this kernel's byte costs).  Returns w and the number of remainder entries.
+inline int csr_split_width(const unsigned char *ptr, int rowlen, int nnz, int *remainder)
 {
+    const long long unit_b = 16 + 16 * (long long)sizeof(val_t), entry_b = (long long)sizeof(val_t) + 5;
+    int len[16], wmax = 0;
+    for (int r = 0; r < 16; r++) { len[r] = r < rowlen ? ((r == rowlen - 1 ? nnz : ptr[r + 1]) - ptr[r]) : 0; wmax = std::max(wmax, len[r]); }
+    int best_w = 0, best_rem = nnz; long long best = entry_b * nnz;
+    for (int w = 1; w <= wmax; w++) {
+        int rem = 0;
+        for (int r = 0; r < 16; r++) rem += std::max(0, len[r] - w);
+        const long long b = unit_b * w + entry_b * rem;
+        if (b < best) { best = b; best_w = w; best_rem = rem; }
+    }
+    *remainder = best_rem;
+    return best_w;
+}
+
+inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, bool csr_split)
+{
+    static const int coo_cost = env_int("TILESPMV_COO_COST", 3);
     RowCount c{0, 0, 0, 0, 0, 0};
     for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
         const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
@@ -180,24 +200,28 @@ inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, i
             else c.nunits += tile_collen(T->tile_columnidx[t], tilen, colA);
             break;
         case TILESPMV_FMT_COO: if (coo_in_tile) c.ncoo += stored; break;
-        case TILESPMV_FMT_CSR: c.nheavy++; c.hval += stored; c.hidx += 16 + (stored + 1) / 2; break;
-        case TILESPMV_FMT_DNSROW: { int k = T->dnsrowptr[t + 1] - T->dnsrowptr[t]; c.nheavy++; c.hval += 16 * k; c.hidx += k; break; }
+        case TILESPMV_FMT_CSR:
+            if (csr_split) { int rem; c.nunits += csr_split_width(T->Blockcsr_Ptr + T->csrptr_offset[t], rowlen, stored, &rem); c.ncoo += rem; }
+            else { c.nheavy++; c.hval += stored; c.hidx += 16 + (stored + 1) / 2; }
+            break;
+        case TILESPMV_FMT_DNSROW: c.nunits += T->dnsrowptr[t + 1] - T->dnsrowptr[t]; break;  // one row unit per dense row
         }
     }
-    c.cost = 16LL * c.nunits + 3LL * c.ncoo + c.hval + 16LL * c.nheavy + 8;
+    // heavy tiles are latency-bound (one tile at a time): weigh them so that long lists get split
+    c.cost = 16LL * c.nunits + (long long)coo_cost * c.ncoo + c.hval + 256LL * c.nheavy + 8;
     return c;
 }
 
 }  // namespace
 
 static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,
-                        bool dense_mfma, const std::vector<long long> &hyb_off, int target, int split_above, int piece,
+                        bool dense_mfma, bool csr_split, const std::vector<long long> &hyb_off, int target, int split_above, int piece,
                         std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes)
 {
     const int tilem = T->tilem, tilen = T->tilen, ntr = std::max(0, tr1 - tr0), sv = (int)sizeof(val_t);
     std::vector<RowCount> rc_((size_t)ntr);
     parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
-        for (int64_t i = b; i < e; i++) rc_[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma);
+        for (int64_t i = b; i < e; i++) rc_[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, csr_split);
     });
     std::vector<long long> pu((size_t)ntr + 1, 0), pc((size_t)ntr + 1, 0), ph((size_t)ntr + 1, 0), phv((size_t)ntr + 1, 0), phi((size_t)ntr + 1, 0);
     for (int i = 0; i < ntr; i++) {
@@ -217,19 +241,18 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
     auto is_heavy = [&](int t) {
         const int fmt = T->Format[t];
-        return fmt == TILESPMV_FMT_CSR || fmt == TILESPMV_FMT_DNSROW || (fmt == TILESPMV_FMT_DNS && dense_mfma);
+        return (fmt == TILESPMV_FMT_CSR && !csr_split) || (fmt == TILESPMV_FMT_DNS && dense_mfma);
     };
     auto heavy_sizes = [&](int t, int *nv, int *ni) {
         const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t];
         if (fmt == TILESPMV_FMT_CSR) { *nv = stored; *ni = 16 + (stored + 1) / 2; }
-        else if (fmt == TILESPMV_FMT_DNS) { *nv = 256; *ni = 0; }
-        else { int kk = T->dnsrowptr[t + 1] - T->dnsrowptr[t]; *nv = 16 * kk; *ni = kk; }
+        else { *nv = 256; *ni = 0; }
     };
     for (int i = 0; i < ntr;) {
         if (rc_[i].cost > split_above) {
             row_split[i] = 1;
             FixRow f{tr0 + i, npartial, 0, 0};
-            const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, piece / 3);
+            const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, piece / std::max(1, env_int("TILESPMV_COO_COST", 3)));
             for (long long u = pu[i]; u < pu[i + 1]; u += pu_) {
                 STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
                 k.unit_begin = (int)u; k.unit_end = (int)std::min(pu[i + 1], u + pu_);
@@ -248,7 +271,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
                 while (h < ph[i + 1] && (c == 0 || c < piece)) {
                     while (!is_heavy(t)) t++;
                     int nv, ni; heavy_sizes(t, &nv, &ni);
-                    hv += nv; hi += ni; c += nv + 16; h++; t++;
+                    hv += nv; hi += ni; c += nv + 256; h++; t++;
                 }
                 k.tile_end = (int)h;
                 htasks.push_back(k); f.count++;
@@ -345,9 +368,48 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
                         for (int q = 0; q < collen; q++) put_unit(cb, T->Blockdense_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)q);
                         break;
                     }
-                    // fallthrough: dense tile as a heavy (whole) tile for the matrix cores
-                case TILESPMV_FMT_CSR:
+                    goto heavy_tile;  // dense tile as a heavy (whole) tile for the matrix cores
                 case TILESPMV_FMT_DNSROW: {
+                    const int off = T->dnsrow_offset[t], ro = T->dnsrowptr[t], k = T->dnsrowptr[t + 1] - ro;
+                    for (int q = 0; q < k; q++) {
+                        for (int cc = 0; cc < collen; cc++) h_uval[u * 16 + cc] = T->Blockdenserow_Val[off + q * collen + cc];
+                        const unsigned w0 = (unsigned)cb | (((kr << UNIT_ROW_SHIFT) | UNIT_ROWUNIT) << UNIT_FLAG_SHIFT);
+                        const unsigned rid = (unsigned)(T->denserowid[ro + q] & 15);
+                        h_udesc[(size_t)u] = make_uint4(w0, rid, w0, rid);
+                        u++;
+                    }
+                    break;
+                }
+                case TILESPMV_FMT_CSR:
+                    if (csr_split) {
+                        const int off = T->csr_offset[t];
+                        const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
+                        int rem;
+                        const int w = csr_split_width(ptr, rowlen, stored, &rem);
+                        const long long u0 = u;
+                        for (int sidx = 0; sidx < w; sidx++) {  // descriptors first (zero nibbles), payload below
+                            const unsigned w0 = (unsigned)cb | ((kr << UNIT_ROW_SHIFT) << UNIT_FLAG_SHIFT);
+                            h_udesc[(size_t)u] = make_uint4(w0, 0u, w0, 0u);
+                            u++;
+                        }
+                        for (int r = 0; r < rowlen; r++) {
+                            const int k0 = ptr[r], k1 = (r == rowlen - 1) ? stored : ptr[r + 1];
+                            for (int kk = k0; kk < k1; kk++) {
+                                const int lc = nib(T->csr_compressedIdx, (long long)off + kk), sidx = kk - k0;
+                                if (sidx < w) {
+                                    h_uval[(u0 + sidx) * 16 + r] = T->Blockcsr_Val[off + kk];
+                                    if (r < 8) h_udesc[(size_t)(u0 + sidx)].y |= (unsigned)lc << (28 - 4 * r);
+                                    else h_udesc[(size_t)(u0 + sidx)].w |= (unsigned)lc << (28 - 4 * (r - 8));
+                                } else {
+                                    h_cval[c] = T->Blockcsr_Val[off + kk]; h_ccol[(size_t)c] = cb * 16 + lc;
+                                    h_crow[(size_t)c] = (unsigned char)((kr << 4) | r); c++;
+                                }
+                            }
+                        }
+                        break;
+                    }
+                    // fallthrough: CSR tile as a heavy (whole) tile
+                heavy_tile: {
                     Emit em = emit_of(T, t, rowlen, true);
                     repack_tile(T, t, em, rowlen, collen, 0, h_hval + hv, h_hidx + hi);
                     h_hdesc[(size_t)h] = make_uint2((unsigned)cb, (unsigned)em.fmt | ((unsigned)em.p1 << DESC_P1_SHIFT));
@@ -450,7 +512,12 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     }
     const bool coo_in_tile = coo_mode == TILESPMV_COO_IN_TILE;
     int dense_mode = o.dense_mode ? o.dense_mode : env_int("TILESPMV_DENSE_MODE", 0);
-    if (dense_mode == TILESPMV_DENSE_AUTO) dense_mode = TILESPMV_DENSE_MFMA;
+    int kernel = o.kernel ? o.kernel : env_int("TILESPMV_KERNEL", 0);
+    if (kernel == TILESPMV_KERNEL_AUTO) kernel = TILESPMV_KERNEL_STREAM;
+    // Dense tiles: the matrix-core routine handles one tile per wavefront at a time; in the unit
+    // kernel a dense tile is 16 streamed units instead, which measures faster on MI355X
+    // (DESIGN.md §5), so AUTO keeps MFMA for the tile-at-a-time kernel only.
+    if (dense_mode == TILESPMV_DENSE_AUTO) dense_mode = kernel == TILESPMV_KERNEL_STREAM ? TILESPMV_DENSE_VALU : TILESPMV_DENSE_MFMA;
     plan->coo_mode = coo_mode; plan->dense_mode = dense_mode;
 
     // ---- HYB tiles address hybIdx by a running byte offset (reference ptroffset2, src/tilespmv_cpu.h:195-196)
@@ -469,8 +536,6 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
         }
     }
 
-    int kernel = o.kernel ? o.kernel : env_int("TILESPMV_KERNEL", 0);
-    if (kernel == TILESPMV_KERNEL_AUTO) kernel = TILESPMV_KERNEL_STREAM;
     plan->kernel = kernel;
     plan->unit_batch = env_int("TILESPMV_UNIT_BATCH", 4);
     plan->xcd_remap = env_int("TILESPMV_XCD_REMAP", 0);
@@ -484,7 +549,8 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     int rc = 0;
     DevPlan &D = plan->dev;
     if (kernel == TILESPMV_KERNEL_STREAM) {
-        rc = build_stream(plan, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mode == TILESPMV_DENSE_MFMA, hyb_off, target, split_above, piece,
+        const bool csr_split = env_int("TILESPMV_CSR_SPLIT", 1) != 0;
+        rc = build_stream(plan, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mode == TILESPMV_DENSE_MFMA, csr_split, hyb_off, target, split_above, piece,
                           fix, npartial, n_tasks, model_bytes);
     } else {
     // ---- pass 1: stream sizes per tile-row
