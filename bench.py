@@ -42,6 +42,9 @@ def build_matrix(name):
         return G.laplacian5pt(4096) + ("synthetic 5-pt Laplacian 4096^2",)
     if name.startswith("laplacian"):
         return G.laplacian5pt(int(name[len("laplacian"):])) + ("synthetic 5-pt Laplacian",)
+    if name.startswith("band"):  # e.g. band40_2000000: full band, half-bandwidth 40 (dense-tile dominated)
+        hbw, nn = name[4:].split("_")
+        return G.band(int(nn), int(hbw)) + ("synthetic full band hbw=%s" % hbw,)
     if name == "scircuit":
         return G.circuit_like(170998, seed=1) + ("synthetic circuit-like stand-in for scircuit",)
     if name == "webbase":

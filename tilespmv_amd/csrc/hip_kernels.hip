@@ -466,7 +466,81 @@ __global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int colA, 
     }
 }
 
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, bool dense_mfma, int ub, int xcd_remap, int xcd_chunk, bool nt,
+// ------------------------------------------------------------------------------------------------
+// Dense tiles on the matrix cores (reference dense kernel: src/tilespmv_cuda.h:664-710).
+// One wavefront per tile-row.  A dense tile is 256 contiguous values (column-major): k-step s of
+// v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 takes A[row][k] = tile[row][4s+k], i.e. lane l
+// reads element 64s + l -> one fully coalesced 512-B load per k-step; B[k][*] = x[16cb + 4s + k].
+// The accumulator D is carried ACROSS the tiles of the tile-row (C-in = previous D), so a row with
+// n dense tiles costs 4n MFMAs and one 16-value update of y at the end; summation order is fixed.
+// Loads of the next tile are issued before the MFMAs of the current one (unconditionally, clamped).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_mfma(DevDense D, int rowA, int colA, val_t *__restrict__ partial,
+                                                    const val_t *__restrict__ x, val_t *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= D.nrows) return;  // whole wavefronts only
+    const int4 dr = reinterpret_cast<const int4 *>(D.rows)[w];
+    const int row = dr.x, t0 = dr.y, t1 = dr.z, part = dr.w;
+    const int last = t1 - 1, kq = lane >> 4;
+    const long long xlast = (long long)colA - 1;
+#if defined(TILESPMV_F32)
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+#else
+    v4d acc = {0., 0., 0., 0.};
+#endif
+    val_t a[4], b[4];
+    {
+        const int cb = D.cb[t0];
+        const val_t *tv = D.val + (long long)t0 * 256 + lane;
+#pragma unroll
+        for (int s = 0; s < 4; s++) { a[s] = tv[64 * s]; b[s] = x[min((long long)cb * 16 + 4 * s + kq, xlast)]; }
+    }
+    for (int t = t0; t < t1; t++) {
+        val_t an[4], bn[4];
+        {
+            const int tn = min(t + 1, last);
+            const int cb = D.cb[tn];
+            const val_t *tv = D.val + (long long)tn * 256 + lane;
+#pragma unroll
+            for (int s = 0; s < 4; s++) { an[s] = tv[64 * s]; bn[s] = x[min((long long)cb * 16 + 4 * s + kq, xlast)]; }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#if defined(TILESPMV_F32)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+#else
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+#endif
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) { a[s] = an[s]; b[s] = bn[s]; }
+    }
+    if ((lane & 15) == 0) {  // every column of D holds the same 16 results; column 0 writes them
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#if defined(TILESPMV_F32)
+            const int rr = 4 * kq + i;   // f32 C/D map
+#else
+            const int rr = kq + 4 * i;   // f64 C/D map
+#endif
+            if (part >= 0) partial[(long long)part * 16 + rr] = acc[i];
+            else {
+                const long long yi = (long long)row * 16 + rr;
+                if (yi < rowA) y[yi] += acc[i];
+            }
+        }
+    }
+}
+
+hipError_t launch_dense_mfma(const DevDense &D, int rowA, int colA, val_t *partial, const val_t *x, val_t *y, hipStream_t st)
+{
+    if (D.nrows > 0) hipLaunchKernelGGL(k_dense_mfma, dim3((D.nrows + 3) / 4), dim3(256), 0, st, D, rowA, colA, partial, x, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int ub, int xcd_remap, int xcd_chunk, bool nt,
                                const val_t *x, val_t *y, hipStream_t st)
 {
     static const int ablate = getenv("TILESPMV_ABLATE") ? atoi(getenv("TILESPMV_ABLATE")) : 0;  // timing experiments only
@@ -480,8 +554,14 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, bool dense_
 #undef TSPMV_L2
 #undef TSPMV_L3
     }
-    // heavy tiles (CSR, dense-row, MFMA dense): y += ..., then the split-row fix-up
-    return launch_tiles_direct(P, dense_mfma, /*accumulate=*/true, /*fixup=*/true, x, y, st);
+    // whole-tile passes (y += ...): CSR tiles kept as tiles, dense tiles on the matrix cores; then the split-row fix-up
+    hipError_t e = launch_tiles_direct(P, dense_mfma, /*accumulate=*/true, /*fixup=*/false, x, y, st);
+    if (e != hipSuccess) return e;
+    e = launch_dense_mfma(DN, P.rowA, P.colA, P.partial, x, y, st);
+    if (e != hipSuccess) return e;
+    if (P.nfix > 0)
+        hipLaunchKernelGGL(k_fixup_split, dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, y);
+    return hipGetLastError();
 }
 
 }  // namespace tilespmv

@@ -91,6 +91,15 @@ struct DevStream {
     int ntasks;
 };
 
+// Dense tiles on the matrix cores (generation 2): one wavefront per tile-row that owns dense tiles.
+struct DenseRow { int row, tile_begin, tile_end, partial; };  // partial: -1 -> y += result, else slot in partial[]
+struct DevDense {
+    const int *cb;          // column block per dense tile
+    const val_t *val;       // 256 values per tile, column-major, row stride 16, zero padded
+    const DenseRow *rows;
+    int nrows;
+};
+
 inline void tile_stream_sizes(int fmt, int p1, int p2, int *nv, int *ni)
 {
     switch (fmt) {

@@ -16,7 +16,7 @@
 namespace tilespmv {
 
 hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulate, bool fixup, const val_t *x, val_t *y, hipStream_t st);
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, bool dense_mfma, int ub, int xcd_remap, int xcd_chunk, bool nt,
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int ub, int xcd_remap, int xcd_chunk, bool nt,
                                const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
 int fallback_block_nnz();
@@ -44,6 +44,7 @@ using namespace tilespmv;
 struct tilespmv_plan {
     DevPlan dev{};
     DevStream st{};
+    DevDense dn{};
     int unit_batch = 4;
     int xcd_remap = 0, xcd_chunk = 64;
     bool nontemporal = false;
@@ -164,7 +165,7 @@ void repack_tile(const Tile_matrix *T, int t, const Emit &e, int rowlen, int col
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-struct RowCount { int nunits, ncoo, nheavy; long long hval, hidx; long long cost; };
+struct RowCount { int nunits, ncoo, nheavy, ndense; long long hval, hidx; long long cost; };
 
 // A CSR tile is executed as w ELL-style units (the first w entries of every row) plus the rest of
 // its entries on the strip's COO list; w minimises the bytes moved (HYB's idea, src/csr2tile.h:279-306,
@@ -188,7 +189,7 @@ inline int csr_split_width(const unsigned char *ptr, int rowlen, int nnz, int *r
 inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, bool csr_split)
 {
     static const int coo_cost = env_int("TILESPMV_COO_COST", 3);
-    RowCount c{0, 0, 0, 0, 0, 0};
+    RowCount c{0, 0, 0, 0, 0, 0, 0};
     for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
         const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
         switch (fmt) {
@@ -196,7 +197,7 @@ inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, i
         case TILESPMV_FMT_HYB: c.nunits += w; if (coo_in_tile) c.ncoo += stored - w * rowlen; break;
         case TILESPMV_FMT_DNSCOL: c.nunits += T->dnscolptr[t + 1] - T->dnscolptr[t]; break;
         case TILESPMV_FMT_DNS:
-            if (dense_mfma) { c.nheavy++; c.hval += 256; }
+            if (dense_mfma) c.ndense++;
             else c.nunits += tile_collen(T->tile_columnidx[t], tilen, colA);
             break;
         case TILESPMV_FMT_COO: if (coo_in_tile) c.ncoo += stored; break;
@@ -208,7 +209,7 @@ inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, i
         }
     }
     // heavy tiles are latency-bound (one tile at a time): weigh them so that long lists get split
-    c.cost = 16LL * c.nunits + (long long)coo_cost * c.ncoo + c.hval + 256LL * c.nheavy + 8;
+    c.cost = 16LL * c.nunits + (long long)coo_cost * c.ncoo + c.hval + 256LL * c.nheavy + 64LL * c.ndense + 8;
     return c;
 }
 
@@ -224,6 +225,10 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         for (int64_t i = b; i < e; i++) rc_[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, csr_split);
     });
     std::vector<long long> pu((size_t)ntr + 1, 0), pc((size_t)ntr + 1, 0), ph((size_t)ntr + 1, 0), phv((size_t)ntr + 1, 0), phi((size_t)ntr + 1, 0);
+    std::vector<long long> pd((size_t)ntr + 1, 0);
+    for (int i = 0; i < ntr; i++) pd[i + 1] = pd[i] + rc_[i].ndense;
+    const long long ND = pd[ntr];
+    std::vector<DenseRow> drows;
     for (int i = 0; i < ntr; i++) {
         pu[i + 1] = pu[i] + rc_[i].nunits; pc[i + 1] = pc[i] + rc_[i].ncoo; ph[i + 1] = ph[i] + rc_[i].nheavy;
         phv[i + 1] = phv[i] + rc_[i].hval; phi[i + 1] = phi[i] + rc_[i].hidx;
@@ -241,12 +246,11 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
     auto is_heavy = [&](int t) {
         const int fmt = T->Format[t];
-        return (fmt == TILESPMV_FMT_CSR && !csr_split) || (fmt == TILESPMV_FMT_DNS && dense_mfma);
+        return fmt == TILESPMV_FMT_CSR && !csr_split;
     };
     auto heavy_sizes = [&](int t, int *nv, int *ni) {
         const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t];
-        if (fmt == TILESPMV_FMT_CSR) { *nv = stored; *ni = 16 + (stored + 1) / 2; }
-        else { *nv = 256; *ni = 0; }
+        (void)fmt; *nv = stored; *ni = 16 + (stored + 1) / 2;
     };
     for (int i = 0; i < ntr;) {
         if (rc_[i].cost > split_above) {
@@ -276,6 +280,10 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
                 k.tile_end = (int)h;
                 htasks.push_back(k); f.count++;
             }
+            for (long long dq = pd[i]; dq < pd[i + 1]; dq += 32) {  // dense tiles of a split row: 32 per piece
+                drows.push_back(DenseRow{tr0 + i, (int)dq, (int)std::min(pd[i + 1], dq + 32), npartial++});
+                f.count++;
+            }
             fix.push_back(f);
             i++;
             continue;
@@ -289,6 +297,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
             row_k[j] = (unsigned char)(j - i);
             if (rc_[j].nunits == 0) k.nounit_mask |= 1u << (j - i);
             if (rc_[j].nheavy > 0) htasks.push_back(Task{(int)ph[j], (int)ph[j + 1], phv[j], phi[j], tr0 + j, -1});
+            if (rc_[j].ndense > 0) drows.push_back(DenseRow{tr0 + j, (int)pd[j], (int)pd[j + 1], -1});
             c += rc_[j].cost; j++;
         }
         k.nrows = j - i;
@@ -306,11 +315,13 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     std::vector<uint2> h_hdesc((size_t)NH);
     val_t *h_hval = zalloc<val_t>((size_t)NHV);
     unsigned char *h_hidx = zalloc<unsigned char>((size_t)NHI + 16);
+    std::vector<int> h_dcb((size_t)ND);
+    val_t *h_dval = zalloc<val_t>((size_t)ND * 256);
     parallel_chunks(ntr, 256, [&](int64_t b, int64_t e, int) {
         for (int64_t i = b; i < e; i++) {
             const int bi = tr0 + (int)i, rowlen = tile_rowlen(bi, tilem, rowA);
             const unsigned kr = row_k[i];
-            long long u = pu[i], c = pc[i], h = ph[i], hv = phv[i], hi = phi[i];
+            long long u = pu[i], c = pc[i], h = ph[i], hv = phv[i], hi = phi[i], dq = pd[i];
             auto put_unit = [&](int cb, const val_t *src, int stride_ok_rows, unsigned long long nibs) {
                 // src: rowlen consecutive values of this column; nibs: 16 nibbles, row 0 in the top nibble
                 for (int r = 0; r < stride_ok_rows; r++) h_uval[u * 16 + r] = src[r];
@@ -368,7 +379,15 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
                         for (int q = 0; q < collen; q++) put_unit(cb, T->Blockdense_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)q);
                         break;
                     }
-                    goto heavy_tile;  // dense tile as a heavy (whole) tile for the matrix cores
+                    {   // dense tile for the matrix cores: 256 values, column-major, stride 16, zero padded
+                        const int off = T->dns_offset[t];
+                        val_t *dst = h_dval + dq * 256;
+                        for (int cc = 0; cc < collen; cc++)
+                            for (int r = 0; r < rowlen; r++) dst[16 * cc + r] = T->Blockdense_Val[off + cc * rowlen + r];
+                        h_dcb[(size_t)dq] = cb;
+                        dq++;
+                    }
+                    break;
                 case TILESPMV_FMT_DNSROW: {
                     const int off = T->dnsrow_offset[t], ro = T->dnsrowptr[t], k = T->dnsrowptr[t + 1] - ro;
                     for (int q = 0; q < k; q++) {
@@ -409,7 +428,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
                         break;
                     }
                     // fallthrough: CSR tile as a heavy (whole) tile
-                heavy_tile: {
+                {
                     Emit em = emit_of(T, t, rowlen, true);
                     repack_tile(T, t, em, rowlen, collen, 0, h_hval + hv, h_hidx + hi);
                     h_hdesc[(size_t)h] = make_uint2((unsigned)cb, (unsigned)em.fmt | ((unsigned)em.p1 << DESC_P1_SHIFT));
@@ -437,11 +456,16 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     rc |= plan->upload(htasks.data(), htasks.size(), &D.task);
     D.ntasks = (int)htasks.size();
     rc |= plan->upload(tasks.data(), tasks.size(), &S.task);
-    free(h_uval); free(h_cval); free(h_hval); free(h_hidx);
+    rc |= plan->upload(h_dcb.data(), (size_t)ND, &plan->dn.cb);
+    rc |= plan->upload(h_dval, (size_t)ND * 256, &plan->dn.val);
+    rc |= plan->upload(drows.data(), drows.size(), &plan->dn.rows);
+    plan->dn.nrows = (int)drows.size();
+    free(h_uval); free(h_cval); free(h_hval); free(h_hidx); free(h_dval);
     S.ntasks = (int)tasks.size();
     n_tasks = (long long)tasks.size();
     model_bytes = NU * (16 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
-                  (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv);  // heavy pass re-reads and re-writes its rows of y
+                  (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
+                  ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
     return rc;
 }
 
@@ -517,7 +541,18 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     // Dense tiles: the matrix-core routine handles one tile per wavefront at a time; in the unit
     // kernel a dense tile is 16 streamed units instead, which measures faster on MI355X
     // (DESIGN.md §5), so AUTO keeps MFMA for the tile-at-a-time kernel only.
-    if (dense_mode == TILESPMV_DENSE_AUTO) dense_mode = kernel == TILESPMV_KERNEL_STREAM ? TILESPMV_DENSE_VALU : TILESPMV_DENSE_MFMA;
+    if (dense_mode == TILESPMV_DENSE_AUTO) {
+        if (kernel != TILESPMV_KERNEL_STREAM) dense_mode = TILESPMV_DENSE_MFMA;
+        else {
+            // generation 2: dense tiles run on the matrix cores in their own pass (k_dense_mfma) when they
+            // carry a real share of the payload (band40: 0.358 ms vs 0.399 ms as streamed units); a
+            // handful of dense tiles is cheaper as 16 units each than as an extra launch
+            long long dense_vals = 0;
+            for (int t = t_begin; t < t_end; t++) if (T->Format[t] == TILESPMV_FMT_DNS) dense_vals += 256;
+            const long long all_vals = (long long)T->blknnz[t_end] - T->blknnz[t_begin];
+            dense_mode = (dense_vals * 10 >= all_vals && dense_vals >= 256 * 1024) ? TILESPMV_DENSE_MFMA : TILESPMV_DENSE_VALU;
+        }
+    }
     plan->coo_mode = coo_mode; plan->dense_mode = dense_mode;
 
     // ---- HYB tiles address hybIdx by a running byte offset (reference ptroffset2, src/tilespmv_cpu.h:195-196)
@@ -701,7 +736,7 @@ int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYP
 {
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = plan->dense_mode == TILESPMV_DENSE_MFMA;
-    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, mfma, plan->unit_batch, plan->xcd_remap, plan->xcd_chunk, plan->nontemporal, d_x, d_y, st)
+    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, plan->dn, mfma, plan->unit_batch, plan->xcd_remap, plan->xcd_chunk, plan->nontemporal, d_x, d_y, st)
                                                           : launch_tiles_direct(plan->dev, mfma, false, true, d_x, d_y, st);
     if (e != hipSuccess) return (int)e;
     return (int)launch_fallback(plan->dev, d_x, d_y, st);
