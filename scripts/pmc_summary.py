@@ -3,7 +3,7 @@ import csv, glob, os, sys, json
 from collections import defaultdict
 root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(root, "set*", "**", "*counter_collection.csv"), recursive=True):
+for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "")
         if "tilespmv" not in name: continue

@@ -576,8 +576,12 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     plan->xcd_remap = env_int("TILESPMV_XCD_REMAP", 0);
     plan->xcd_chunk = std::max(1, env_int("TILESPMV_XCD_CHUNK", 64));
     plan->nontemporal = env_int("TILESPMV_NT", 0) != 0;
-    const int target = std::max(32, env_int("TILESPMV_STRIP_COST", kernel == TILESPMV_KERNEL_STREAM ? 400 : 192));
-    const int split_above = 6 * target, piece = 2 * target;
+    // Strip size: ~400 cost units (20 units) amortises the per-strip round trips; measured flat between 200
+    // and 800 on large matrices and neutral on small (cache-resident) ones, where launch latency dominates.
+    int target = env_int("TILESPMV_STRIP_COST", 0);
+    if (target <= 0) target = kernel == TILESPMV_KERNEL_STREAM ? 400 : 192;
+    target = std::max(32, target);
+    const int split_above = std::max(6 * target, env_int("TILESPMV_SPLIT_ABOVE", 2400)), piece = std::max(2 * target, split_above / 3);
     std::vector<FixRow> fix;
     int npartial = 0;
     long long n_tasks = 0, model_bytes = 0;
