@@ -12,7 +12,7 @@ for set in "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum" "TA_ADDR_STALLED_BY_TC_CYCLE
            "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum" \
            "TD_TD_BUSY_sum TD_TC_STALL_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   i=$((i+1))
-  timeout -k 5 90 rocprofv3 --pmc $set --output-format csv -d $out/a$i -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-check "$@" > $out/a$i.log 2>&1 || echo "a$i failed: $set"
+  timeout -k 5 90 rocprofv3 --pmc $set --output-format csv -d $out/a$i -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-check "$@" > $out/a$i.log 2>&1 || echo "a$i failed: $set"
   timeout -k 5 60 rocprofv3 --pmc $set --output-format csv -d $out/b$i -- $GRAFT_REPO_ROOT/scripts/micro/stream_patterns > $out/b$i.log 2>&1 || echo "b$i failed: $set"
   echo "set $i done"
 done

@@ -9,10 +9,10 @@ export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline "$@" > $out/bench_under_trace.json 2> $out/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras "$@" > $out/bench_under_trace.json 2> $out/trace.err
 cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-check "$@" > /dev/null 2> $out/pmc_$c.err
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-check "$@" > /dev/null 2> $out/pmc_$c.err
   cp $(ls $out/pmc_$c/*/*counter_collection.csv | head -1) $out/pmc_$c.csv
 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/calib -- $GRAFT_REPO_ROOT/scripts/micro/stream_patterns > $out/calib.log 2> $out/calib.err

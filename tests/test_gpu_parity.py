@@ -106,6 +106,72 @@ def test_medium_matrices_bit_exact(torch_cuda, name):
             assert np.array_equal(y, want), (name, kernel, coo)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_block_structured_matrices(torch_cuda, seed):
+    """Random mixtures of dense blocks, full rows/columns, regular and ragged tiles, partial last
+    tile row/column, unsorted columns inside rows — every kernel generation and mode, bit-exact."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api
+    rng = np.random.default_rng(1000 + seed)
+    m, n = int(rng.integers(20, 400)), int(rng.integers(20, 400))
+    mask = rng.random((m, n)) < rng.choice([0.01, 0.05, 0.2, 0.5])
+    for _ in range(int(rng.integers(0, 12))):
+        bi, bj = int(rng.integers(0, (m + 15) // 16)) * 16, int(rng.integers(0, (n + 15) // 16)) * 16
+        kind = int(rng.integers(0, 5))
+        blk = np.zeros((16, 16), bool)
+        if kind == 0: blk[:] = True
+        elif kind == 1: blk[rng.choice(16, int(rng.integers(1, 6)), replace=False), :] = True
+        elif kind == 2: blk[:, rng.choice(16, int(rng.integers(1, 6)), replace=False)] = True
+        elif kind == 3: blk[np.arange(16)[:, None], rng.integers(0, 16, (16, 3))] = True
+        else: blk[rng.choice(16, 11, replace=False)[:10], rng.integers(0, 16, 10)] = True; blk[int(rng.integers(16)), :4] = True
+        sub = mask[bi:bi + 16, bj:bj + 16]
+        sub[:] = blk[:sub.shape[0], :sub.shape[1]]
+    ri, ci = np.nonzero(mask)
+    rp = np.zeros(m + 1, np.int64); np.add.at(rp, ri + 1, 1); rp = np.cumsum(rp).astype(np.int32)
+    ci = ci.astype(np.int32)
+    if seed % 2:
+        for r in range(m):
+            ci[rp[r]:rp[r + 1]] = rng.permutation(ci[rp[r]:rp[r + 1]])
+    nnz = len(ci)
+    rowA = m if seed % 3 else truncated_rows(m)
+    for dtype in (np.float64, np.float32):
+        vals, x = values_for("rnd", nnz, n, dtype)
+        O = CpuImpl("oracle", dtype)
+        for hyb in (False, True):
+            want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=hyb), rowA, n, nnz, rp, ci, vals, x)["y"]
+            tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=hyb)
+            for kernel in (api.KERNEL_STREAM, api.KERNEL_DIRECT):
+                for coo in (api.COO_IN_TILE, api.COO_FALLBACK):
+                    for dns in (api.DENSE_MFMA, api.DENSE_VALU):
+                        y, _ = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, coo_mode=coo, dense_mode=dns, kernel=kernel)
+                        assert np.array_equal(y, want), (seed, dtype, hyb, kernel, coo, dns)
+            api.Tile_destroy(tp)
+
+
+def test_dense_dominated_band_mfma_and_units(torch_cuda):
+    """Band matrix whose tiles are mostly dense: the dedicated MFMA pass (k_dense_mfma) and the
+    dense-as-units path agree with the oracle; AUTO picks MFMA here (payload share rule)."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    m, n, rp, ci = G.band(40000, 40)
+    nnz = len(ci)
+    for dtype in (np.float64, np.float32):
+        for real in (False, True):
+            vals, x = values_for("band", nnz, n, dtype, real)
+            O = CpuImpl("oracle", dtype)
+            want = O.spmv(O.tile_create(m, n, nnz, rp, ci, vals), m, n, nnz, rp, ci, vals, x)["y"]
+            tp = api.Tile_create(m, n, nnz, rp, ci, vals, dtype=dtype)
+            for dns in (api.DENSE_AUTO, api.DENSE_MFMA, api.DENSE_VALU):
+                y, info = _gpu_y(torch_cuda, tp, m, n, nnz, x, dense_mode=dns)
+                if dns == api.DENSE_AUTO:
+                    assert info["dense_mode"] == api.DENSE_MFMA
+                if real:
+                    bound = TOL[np.dtype(dtype)] * _abs_bound(m, rp, ci, vals, x) + 1e-300
+                    assert (np.abs(y.astype(np.float64) - want.astype(np.float64)) <= bound).all(), (dtype, dns)
+                else:
+                    assert np.array_equal(y, want), (dtype, dns)
+
+
 def test_csr_tiles_as_whole_tiles(torch_cuda, monkeypatch):
     """TILESPMV_CSR_SPLIT=0: CSR tiles run through the per-tile CSR routine (heavy list) instead of
     being executed as units + COO entries."""
@@ -130,6 +196,7 @@ def test_split_rows_and_tiny_strips(torch_cuda, monkeypatch):
     from oracle.oracle import CpuImpl
     from tilespmv_amd import api
     monkeypatch.setenv("TILESPMV_STRIP_COST", "32")
+    monkeypatch.setenv("TILESPMV_SPLIT_ABOVE", "200")
     for name in ("one_long_row", "wide_row_tiles", "allfmt", "band4096_40", "circuit8k"):
         m, n, rp, ci = SMALL[name]()
         nnz, rowA = len(ci), truncated_rows(m)
