@@ -148,6 +148,28 @@ def test_random_block_structured_matrices(torch_cuda, seed):
             api.Tile_destroy(tp)
 
 
+def test_degenerate_inputs(torch_cuda):
+    """No nonzeros at all, a single nonzero, a 16x16 matrix, rows but no columns used."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api
+    cases = {
+        "empty": (64, 80, np.zeros(65, np.int32), np.zeros(0, np.int32)),
+        "single": (48, 48, np.r_[np.zeros(20), np.ones(29)].astype(np.int32), np.array([47], np.int32)),
+        "one_tile_dense": (16, 16, (np.arange(17) * 16).astype(np.int32), np.tile(np.arange(16), 16).astype(np.int32)),
+        "one_row": (16, 5000, np.r_[0, np.full(16, 2500)].astype(np.int32), np.arange(0, 5000, 2).astype(np.int32)),
+    }
+    for name, (m, n, rp, ci) in cases.items():
+        nnz = len(ci)
+        vals, x = values_for(name, nnz, n, np.float64)
+        O = CpuImpl("oracle", np.float64)
+        want = O.spmv(O.tile_create(m, n, nnz, rp, ci, vals), m, n, nnz, rp, ci, vals, x)["y"]
+        tp = api.Tile_create(m, n, nnz, rp, ci, vals)
+        for kernel in (api.KERNEL_STREAM, api.KERNEL_DIRECT):
+            for coo in (api.COO_IN_TILE, api.COO_FALLBACK):
+                y, _ = _gpu_y(torch_cuda, tp, m, n, nnz, x, coo_mode=coo, kernel=kernel)
+                assert np.array_equal(y, want), (name, kernel, coo)
+
+
 def test_dense_dominated_band_mfma_and_units(torch_cuda):
     """Band matrix whose tiles are mostly dense: the dedicated MFMA pass (k_dense_mfma) and the
     dense-as-units path agree with the oracle; AUTO picks MFMA here (payload share rule)."""

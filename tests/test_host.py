@@ -104,6 +104,21 @@ def test_random_csr_property(m, n, seed, density, hyb, unsorted):
     api.Tile_destroy(tp)
 
 
+def test_degenerate_matrices_host():
+    O = CpuImpl("oracle", np.float64)
+    for m, n, rp, ci in [(64, 80, np.zeros(65, np.int32), np.zeros(0, np.int32)),
+                         (16, 16, np.zeros(17, np.int32), np.zeros(0, np.int32)),
+                         (48, 48, np.r_[np.zeros(20), np.ones(29)].astype(np.int32), np.array([47], np.int32))]:
+        vals = G.compat_values(len(ci)); x = G.compat_x(n)
+        to = O.tile_create(m, n, len(ci), rp, ci, vals); tp = api.Tile_create(m, n, len(ci), rp, ci, vals)
+        do, dp = to_dict(to, m), to_dict(tp, m)
+        for k in do:
+            assert np.array_equal(np.asarray(do[k]), np.asarray(dp[k])), k
+        so = O.spmv(to, m, n, len(ci), rp, ci, vals, x)
+        sp = api.tilespmv_cpu(tp, m, n, len(ci), rp, ci, vals, x, so["y_golden"])
+        assert np.array_equal(sp["y"], so["y"]) and sp["rowblkblock"] == so["rowblkblock"]
+
+
 def test_duplicate_entries_keep_reference_order():
     """Duplicate (i,j) are kept as separate nonzeros; the extracted rows go through the reference's
     unstable first-pivot sort, which the product restates (src/utils.h:103-137)."""

@@ -537,7 +537,8 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     const bool coo_in_tile = coo_mode == TILESPMV_COO_IN_TILE;
     int dense_mode = o.dense_mode ? o.dense_mode : env_int("TILESPMV_DENSE_MODE", 0);
     int kernel = o.kernel ? o.kernel : env_int("TILESPMV_KERNEL", 0);
-    if (kernel == TILESPMV_KERNEL_AUTO) kernel = TILESPMV_KERNEL_STREAM;
+    if (kernel == TILESPMV_KERNEL_AUTO)  // the unit descriptor keeps the column block in 24 bits
+        kernel = tilen <= (1 << UNIT_FLAG_SHIFT) ? TILESPMV_KERNEL_STREAM : TILESPMV_KERNEL_DIRECT;
     // Dense tiles: the matrix-core routine handles one tile per wavefront at a time; in the unit
     // kernel a dense tile is 16 streamed units instead, which measures faster on MI355X
     // (DESIGN.md §5), so AUTO keeps MFMA for the tile-at-a-time kernel only.
