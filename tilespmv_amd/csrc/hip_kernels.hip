@@ -310,40 +310,40 @@ int fallback_block_nnz() { return FB_NNZ; }
 // ================================================================================================
 namespace tilespmv {
 
-// Descriptor word layout (16 B per unit, two identical-purpose halves so that a lane loads 8 B):
-//   word 0 / word 2 : column block (24 bits) | flags << 24   (flag bit 0 = end of tile-row, bits 1-3 = row in strip)
-//   word 1          : column nibbles of rows 0-7  (row 0 in the top nibble)
-//   word 3          : column nibbles of rows 8-15
 template <class T>
 __device__ __forceinline__ T stream_load(const T *p, bool nt)
 {
     return nt ? __builtin_nontemporal_load(p) : *p;
 }
-__device__ __forceinline__ uint2 stream_load2(const uint2 *p, bool nt)
-{
-    if (!nt) return *p;
-    const unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p));
-    return make_uint2((unsigned)(w & 0xffffffffull), (unsigned)(w >> 32));
-}
+
+// Descriptor word layout (16 B per unit, two identical-purpose halves so that a lane reads 8 B):
+//   word 0 / word 2 : column block (24 bits) | flags << 24   (flag bit 0 = end of tile-row, bits 1-3 = row in strip,
+//                     bit 4 = row unit)
+//   word 1          : column nibbles of rows 0-7  (row 0 in the top nibble)   [row unit: target row]
+//   word 3          : column nibbles of rows 8-15
+// Descriptors reach the lanes through LDS: one coalesced 16-B-per-lane load brings the descriptors of 16
+// consecutive units (lane j loads unit j's), the strip parks them in LDS and every unit then costs one
+// ds_read_b64 instead of one global load.  (Measured: per-unit descriptor loads, 6 % of the bytes, cost 19 %
+// of the kernel — the CU's vector-memory pipeline is the bottleneck, not HBM)
+constexpr int DCHUNK = 16;  // units per descriptor chunk
 
 template <int UB, int XCD_REMAP, bool NT>
-__global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, int ablate, val_t *__restrict__ partial, const val_t *__restrict__ x, val_t *__restrict__ y)
+__global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+                                               const val_t *__restrict__ x, val_t *__restrict__ y)
 {
+    static_assert(DCHUNK % UB == 0, "a batch never straddles a descriptor chunk");
     __shared__ val_t s_y[GROUPS_PER_BLOCK][STRIP_MAX_ROWS][16];
+    __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), each
-    // with a private L2; XCD_REMAP gives every XCD one contiguous eighth of the strips (bijective
-    // for any grid size, cdna_hip_programming.md T1).  Placement only affects speed.
+    // with a private L2; the XCD_REMAP variants give every XCD contiguous runs of strips (bijective
+    // for any grid size, cdna_hip_programming.md T1).  Placement only affects speed (measured: none).
     unsigned bid = blockIdx.x;
     if (XCD_REMAP == 1) {
         const unsigned nb = gridDim.x, q = nb >> 3, rem = nb & 7u, xcd = bid & 7u, idx = bid >> 3;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
     } else if (XCD_REMAP >= 2) {
-        // windows of 8*C workgroups; inside a window XCD group k owns C consecutive ones, so all
-        // eight L2s work in one 8*C window (spread over the HBM channels) yet neighbours share an L2
         const unsigned C = (unsigned)xcd_chunk, W = 8u * C, win = bid / W, off = bid % W, k = off & 7u;
-        // XCD group k walks its C workgroups starting k*C/8 in, so the eight L2s are never at the
-        // same offset of their chunks (equal offsets alias onto the same HBM channels)
         if ((win + 1) * W <= gridDim.x) bid = win * W + k * C + ((off >> 3) + (XCD_REMAP == 3 ? k * (C >> 3) + k : 0u)) % C;
     }
     const long long task_id = (long long)bid * GROUPS_PER_BLOCK + g;
@@ -353,26 +353,23 @@ __global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int colA, 
     const int unit_begin = t0.x, unit_end = t0.y, coo_begin = t0.z, coo_end = t0.w;
     const int row0 = t1.x, part = t1.y, nrows = t1.w;
     const unsigned nounit = (unsigned)t1.z;
-    const bool side = (coo_end > coo_begin) && !(ablate & 1);   // ablate bit 0: no COO phase
-    const uint2 *__restrict__ udesc = reinterpret_cast<const uint2 *>(S.udesc) + (r >> 3);
+    const bool side = coo_end > coo_begin;
     const val_t *__restrict__ uval = S.uval + r;
     const int last = unit_end - 1;
     const bool have_units = unit_begin < unit_end;
     const long long xlast = (long long)colA - 1;  // row units of a partial last column block: zero payload, clamped x index
 
-    // ---- issue order: first COO chunk, then the first unit batch; both are in flight together
+    // ---- issue order: first COO chunk, descriptor chunk 0 (+1), first value batch: all in flight together
     unsigned rb0 = 0; int cc0 = 0; val_t cv0 = 0;
     const bool coo0 = side && (coo_begin + r < coo_end);
     if (coo0) { rb0 = S.crow[coo_begin + r]; cc0 = S.ccol[coo_begin + r]; cv0 = S.cval[coo_begin + r]; }
-    uint2 d[UB];
+    uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
     val_t v[UB];
     if (have_units) {
+        dcur = S.udesc[min(unit_begin + r, last)];
+        dnext = S.udesc[min(unit_begin + DCHUNK + r, last)];
 #pragma unroll
-        for (int k = 0; k < UB; k++) {
-            const long long uu = min(unit_begin + k, last);
-            d[k] = stream_load2(udesc + uu * 2, NT);
-            v[k] = stream_load(uval + uu * 16, NT);
-        }
+        for (int k = 0; k < UB; k++) v[k] = stream_load(uval + (long long)min(unit_begin + k, last) * 16, NT);
     }
     if (side) {  // phase 1: COO entries, 16 per step, LDS scatter-add
         for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
@@ -396,7 +393,10 @@ __global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int colA, 
     }
 
     val_t acc = 0;
-    auto retire = [&](val_t prod, unsigned flags, unsigned word1) {  // one unit's contribution; writes y at end of tile-row
+    // A finished tile-row parks its 16 results in s_y; y is written once per strip at the end with 16-B
+    // lane stores.  (Stores share the in-order vmcnt queue with the loads on CDNA4: a store in the middle
+    // of the unit loop makes every later counted wait also wait for its write acknowledge.)
+    auto retire = [&](val_t prod, unsigned flags, unsigned word1) {
         if (flags & UNIT_ROWUNIT) {  // dense-row unit: lanes hold one row's products
             prod = strip_allreduce(prod);
             if (r != (int)(word1 & 15u)) prod = 0;
@@ -406,49 +406,42 @@ __global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int colA, 
             const int kr = (int)((flags >> UNIT_ROW_SHIFT) & 7u);
             val_t out = acc;
             if (side) out += s_y[g][kr][r];
-            const long long yi = (long long)(row0 + kr) * 16 + r;
-            if (yi < rowA && (!(ablate & 4) || out == (val_t)123.456)) y[yi] = out;   // bit 2: no y store
+            s_y[g][kr][r] = out;
             acc = 0;
         }
     };
-    if (have_units) {  // phase 2: software-pipelined by one batch
-        int u = unit_begin;
-        // steady state: every batch is full and the next batch's loads are issued UNCONDITIONALLY
-        // between this batch's x gathers and its first use, so the waits are exact counts
-        // (a conditional prefetch makes hipcc wait for the join's worst case, i.e. for the prefetch)
-        for (; u + UB < unit_end; u += UB) {
-            val_t xv[UB];
-            unsigned fl[UB];
-#pragma unroll
-            for (int k = 0; k < UB; k++) {
-                fl[k] = d[k].x >> 24;
-                const unsigned nib = (fl[k] & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
-                const long long xi = min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast);
-                xv[k] = (ablate & 2) ? (val_t)(nib + d[k].x) : x[xi];   // bit 1: no x gather
+    if (have_units) {  // phase 2: units, value loads software-pipelined by one batch
+        const uint2 *sd = reinterpret_cast<const uint2 *>(&s_d[g][0]) + (r >> 3);  // this lane's 8-B half of a descriptor
+        s_d[g][r] = dcur;
+        wave_lds_fence();
+        int chunk_end = unit_begin + DCHUNK;  // first unit NOT described by the chunk in LDS
+        for (int u = unit_begin; u < unit_end; u += UB) {
+            if (u == chunk_end) {  // next descriptor chunk: already in registers, fetch the one after it
+                wave_lds_fence();
+                s_d[g][r] = dnext;
+                wave_lds_fence();
+                chunk_end += DCHUNK;
+                dnext = S.udesc[min(chunk_end + r, last)];
             }
-            uint2 dn[UB];
-            val_t vn[UB];
-#pragma unroll
-            for (int k = 0; k < UB; k++) {
-                const long long uu = min(u + UB + k, last);
-                dn[k] = stream_load2(udesc + uu * 2, NT);
-                vn[k] = stream_load(uval + uu * 16, NT);
-            }
-#pragma unroll
-            for (int k = 0; k < UB; k++) retire(v[k] * xv[k], fl[k], d[k].y);
-#pragma unroll
-            for (int k = 0; k < UB; k++) { d[k] = dn[k]; v[k] = vn[k]; }
-        }
-        {   // last (possibly partial) batch: nothing left to prefetch
+            const int j0 = u - (chunk_end - DCHUNK);
+            uint2 d[UB];
             val_t xv[UB];
 #pragma unroll
+            for (int k = 0; k < UB; k++) d[k] = sd[2 * (j0 + k)];
+#pragma unroll
             for (int k = 0; k < UB; k++) {
-                const unsigned nib = ((d[k].x >> 24) & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
+                const unsigned fl = d[k].x >> 24;
+                const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
                 xv[k] = x[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast)];
             }
+            val_t vn[UB];
+#pragma unroll
+            for (int k = 0; k < UB; k++) vn[k] = stream_load(uval + (long long)min(u + UB + k, last) * 16, NT);  // unconditional: exact vmcnt
 #pragma unroll
             for (int k = 0; k < UB; k++)
                 if (u + k < unit_end) retire(v[k] * xv[k], d[k].x >> 24, d[k].y);
+#pragma unroll
+            for (int k = 0; k < UB; k++) v[k] = vn[k];
         }
     }
     if (part >= 0) {
@@ -456,12 +449,21 @@ __global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int colA, 
         if (side) out += s_y[g][0][r];
         partial[(long long)part * 16 + r] = out;
     } else {
-        unsigned m = nounit;
-        while (m) {
-            const int kr = __ffs((int)m) - 1;
-            m &= m - 1;
-            const long long yi = (long long)(row0 + kr) * 16 + r;
-            if (yi < rowA) y[yi] = side ? s_y[g][kr][r] : (val_t)0;
+        if (!side) {  // rows without any unit and no COO contribution are zero
+            unsigned m = nounit;
+            while (m) { const int kr = __ffs((int)m) - 1; m &= m - 1; s_y[g][kr][r] = 0; }
+        }
+        wave_lds_fence();
+        constexpr int VEC = 16 / (int)sizeof(val_t);  // values per 16-B lane store
+        const val_t *res = &s_y[g][0][0];
+        const long long ybase = (long long)row0 * 16;
+        for (int i = r * VEC; i < 16 * nrows; i += 16 * VEC) {
+            if (ybase + i + VEC <= rowA) {
+                *reinterpret_cast<uint4 *>(y + ybase + i) = *reinterpret_cast<const uint4 *>(res + i);
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC; q++) if (ybase + i + q < rowA) y[ybase + i + q] = res[i + q];
+            }
         }
     }
 }
@@ -543,13 +545,12 @@ hipError_t launch_dense_mfma(const DevDense &D, int rowA, int colA, val_t *parti
 hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int ub, int xcd_remap, int xcd_chunk, bool nt,
                                const val_t *x, val_t *y, hipStream_t st)
 {
-    static const int ablate = getenv("TILESPMV_ABLATE") ? atoi(getenv("TILESPMV_ABLATE")) : 0;  // timing experiments only
     if (S.ntasks > 0) {
         const dim3 grid((unsigned)((S.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), blk(256);
-#define TSPMV_L3(U, X, N) hipLaunchKernelGGL((k_units<U, X, N>), grid, blk, 0, st, S, P.rowA, P.colA, xcd_chunk, ablate, P.partial, x, y)
+#define TSPMV_L3(U, X, N) hipLaunchKernelGGL((k_units<U, X, N>), grid, blk, 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
 #define TSPMV_L2(U, X) do { if (nt) TSPMV_L3(U, X, true); else TSPMV_L3(U, X, false); } while (0)
 #define TSPMV_L1(U) do { if (xcd_remap == 1) TSPMV_L2(U, 1); else if (xcd_remap == 2) TSPMV_L2(U, 2); else if (xcd_remap == 3) TSPMV_L2(U, 3); else TSPMV_L2(U, 0); } while (0)
-        if (ub == 2) TSPMV_L1(2); else if (ub == 8) TSPMV_L1(8); else if (ub == 6) TSPMV_L1(6); else TSPMV_L1(4);
+        if (ub == 2) TSPMV_L1(2); else if (ub == 8) TSPMV_L1(8); else TSPMV_L1(4);
 #undef TSPMV_L1
 #undef TSPMV_L2
 #undef TSPMV_L3
