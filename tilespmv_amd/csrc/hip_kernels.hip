@@ -470,9 +470,9 @@ __global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int colA, 
 
 // ------------------------------------------------------------------------------------------------
 // Dense tiles on the matrix cores (reference dense kernel: src/tilespmv_cuda.h:664-710).
-// One wavefront per tile-row.  A dense tile is 256 contiguous values (column-major): k-step s of
-// v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 takes A[row][k] = tile[row][4s+k], i.e. lane l
-// reads element 64s + l -> one fully coalesced 512-B load per k-step; B[k][*] = x[16cb + 4s + k].
+// One wavefront per tile-row.  A dense tile is 256 contiguous values (column-major); k-step s of
+// v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 with lane group q (= k index) covers tile column
+// 4q + s: A[row][k=q] = tile[row][4q+s] (four 128-B runs per load), B[k=q][*] = x[16cb + 4q + s].
 // The accumulator D is carried ACROSS the tiles of the tile-row (C-in = previous D), so a row with
 // n dense tiles costs 4n MFMAs and one 16-value update of y at the end; summation order is fixed.
 // Loads of the next tile are issued before the MFMAs of the current one (unconditionally, clamped).
@@ -485,39 +485,48 @@ __global__ __launch_bounds__(256) void k_dense_mfma(DevDense D, int rowA, int co
     if (w >= D.nrows) return;  // whole wavefronts only
     const int4 dr = reinterpret_cast<const int4 *>(D.rows)[w];
     const int row = dr.x, t0 = dr.y, t1 = dr.z, part = dr.w;
-    const int last = t1 - 1, kq = lane >> 4;
+    const int last = t1 - 1, kq = lane >> 4, rr0 = lane & 15;
     const long long xlast = (long long)colA - 1;
 #if defined(TILESPMV_F32)
     v4f acc = {0.f, 0.f, 0.f, 0.f};
 #else
     v4d acc = {0., 0., 0., 0.};
 #endif
-    val_t a[4], b[4];
-    {
-        const int cb = D.cb[t0];
-        const val_t *tv = D.val + (long long)t0 * 256 + lane;
+    // k-step s of lane group q covers tile column c = 4q + s (any bijection of the 16 columns onto
+    // (s, q) works as long as A and B agree): the four B values of a lane are then x[16cb + 4q .. +3],
+    // 32 contiguous bytes, and its four A values are val[(4q + s) * 16 + row].
+    // column blocks of the whole row piece in one load (<= 64 tiles per piece by construction), then
+    // broadcast per tile with v_readlane: the per-tile loads depend on nothing but the loop counter
+    const int cbv = D.cb[min(t0 + lane, last)];
+    auto load_tile = [&](int t, val_t (&a)[4], val_t (&b)[4]) {
+        const int cb = __builtin_amdgcn_readlane(cbv, __builtin_amdgcn_readfirstlane(min(t, last) - t0));
+        const long long xb = (long long)cb * 16 + 4 * kq;
+        const val_t *tv = D.val + (long long)min(t, last) * 256 + 64 * kq + rr0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) { a[s] = tv[64 * s]; b[s] = x[min((long long)cb * 16 + 4 * s + kq, xlast)]; }
-    }
-    for (int t = t0; t < t1; t++) {
-        val_t an[4], bn[4];
-        {
-            const int tn = min(t + 1, last);
-            const int cb = D.cb[tn];
-            const val_t *tv = D.val + (long long)tn * 256 + lane;
+        for (int s = 0; s < 4; s++) a[s] = tv[16 * s];
+        if (xb + 3 <= xlast) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) { an[s] = tv[64 * s]; bn[s] = x[min((long long)cb * 16 + 4 * s + kq, xlast)]; }
+            for (int s = 0; s < 4; s++) b[s] = x[xb + s];   // contiguous: merged into 16-B loads
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; s++) b[s] = x[min(xb + s, xlast)];  // partial last column block (payload is zero there)
         }
+    };
+    val_t a0[4], b0[4];
+    load_tile(t0, a0, b0);
+    for (int t = t0; t < t1; t++) {  // next tile in flight ahead of the MFMAs; loads unconditional (clamped): exact wait counts
+        val_t a1[4], b1[4];
+        load_tile(t + 1, a1, b1);
 #pragma unroll
         for (int s = 0; s < 4; s++) {
 #if defined(TILESPMV_F32)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc, 0, 0, 0);
 #else
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b0[s], acc, 0, 0, 0);
 #endif
         }
 #pragma unroll
-        for (int s = 0; s < 4; s++) { a[s] = an[s]; b[s] = bn[s]; }
+        for (int s = 0; s < 4; s++) { a0[s] = a1[s]; b0[s] = b1[s]; }
     }
     if ((lane & 15) == 0) {  // every column of D holds the same 16 results; column 0 writes them
 #pragma unroll
