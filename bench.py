@@ -104,6 +104,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:  # one process per GPU shares the host cores: keep the preprocessing threads per rank modest
+        os.environ.setdefault("TILESPMV_NUM_THREADS", str(max(2, min(16, (os.cpu_count() or 16) // world))))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():

@@ -142,6 +142,13 @@ void tilespmv_cpu(Tile_matrix *matrix, int *ptroffset1, int *ptroffset2, int *ro
 int mmio_allinone(int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric, MAT_PTR_TYPE **csrRowPtr,
                   int **csrColIdx, MAT_VAL_TYPE **csrVal, char *filename);
 
+/* Binary cache of a created Tile_matrix (new: the reference never serialises it; a multi-GB
+ * .mtx is otherwise re-parsed and re-tiled on every run).  save: 0 on success, -1 cannot open,
+ * -3 short write.  load: callee mallocs every member (free with Tile_destroy); 0 on success,
+ * -1 cannot open, -2 not a cache file, -3 truncated, -5 written by the other value type. */
+int tilespmv_matrix_save(const Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA, const char *path);
+int tilespmv_matrix_load(Tile_matrix *matrix, int *rowA, int *colA, MAT_PTR_TYPE *nnzA, const char *path);
+
 /* ------------------------------------------------------------------------------------------
  * GPU hot path.
  * ---------------------------------------------------------------------------------------- */

@@ -182,6 +182,32 @@ def test_config1_test_mtx_cpu_path():
     assert np.array_equal(sp["y"], z["spmv_y"])
 
 
+def test_matrix_cache_roundtrip(tmp_path):
+    """tilespmv_matrix_save / _load (new): byte-identical Tile_matrix after a round trip; wrong value type rejected."""
+    for name, hyb in (("allfmt", True), ("circuit8k", False), ("empty_rows", False)):
+        m, n, rp, ci = SMALL[name]()
+        nnz, rowA = len(ci), truncated_rows(m)
+        for dtype in (np.float64, np.float32):
+            vals, x = values_for(name, nnz, n, dtype, real=True)
+            tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=hyb)
+            path = str(tmp_path / ("%s_%s.tspmv" % (name, np.dtype(dtype).name)))
+            api.matrix_save(tp, rowA, n, nnz, path)
+            tl, r2, c2, z2 = api.matrix_load(path, dtype)
+            assert (r2, c2, z2) == (rowA, n, nnz)
+            a, b = to_dict(tp, rowA), to_dict(tl, rowA)
+            for k in a:
+                assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (name, k)
+            other = np.float32 if dtype == np.float64 else np.float64
+            with pytest.raises(OSError, match="-5"):
+                api.matrix_load(path, other)
+            api.Tile_destroy(tl); api.Tile_destroy(tp)
+    with pytest.raises(OSError, match="-1"):
+        api.matrix_load(str(tmp_path / "missing.tspmv"))
+    junk = tmp_path / "junk.tspmv"; junk.write_bytes(b"not a cache file at all")
+    with pytest.raises(OSError, match="-2"):
+        api.matrix_load(str(junk))
+
+
 def test_partition_tilerows_balanced():
     m, n, rp, ci = MEDIUM["powerlaw200k"]()
     nnz = len(ci); rowA = truncated_rows(m)

@@ -80,6 +80,10 @@ def load(dtype=np.float64):
     lib.tilespmv_plan_time.restype = C.c_double
     lib.tilespmv_partition_tilerows.argtypes = [TP, C.c_int, _I]
     lib.tilespmv_partition_tilerows.restype = None
+    lib.tilespmv_matrix_save.argtypes = [TP, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    lib.tilespmv_matrix_save.restype = C.c_int
+    lib.tilespmv_matrix_load.argtypes = [TP, _I, _I, _I, C.c_char_p]
+    lib.tilespmv_matrix_load.restype = C.c_int
     lib.tilespmv_device_count.restype = C.c_int
     lib.tilespmv_version.restype = C.c_char_p
     libc = C.CDLL(None)
@@ -95,4 +99,4 @@ def load(dtype=np.float64):
 DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_cpu", "mmio_allinone", "call_tilespmv_hip",
                     "tilespmv_plan_create", "tilespmv_plan_destroy", "tilespmv_plan_spmv", "tilespmv_plan_info",
                     "tilespmv_plan_time", "tilespmv_partition_tilerows", "tilespmv_sizeof_value", "tilespmv_version",
-                    "tilespmv_device_count"]
+                    "tilespmv_device_count", "tilespmv_matrix_save", "tilespmv_matrix_load"]

@@ -104,6 +104,24 @@ def call_tilespmv_hip(filename, tm, sched, rowA, colA, nnzA, csrRowPtrA, csrColI
     return y[:rowA].copy()
 
 
+def matrix_save(tm, rowA, colA, nnzA, path):
+    rc = tm._lib.tilespmv_matrix_save(C.byref(tm), rowA, colA, nnzA, path.encode())
+    if rc != 0:
+        raise OSError("tilespmv_matrix_save(%s) failed: %d" % (path, rc))
+
+
+def matrix_load(path, dtype=np.float64):
+    """Returns (Tile_matrix, rowA, colA, nnzA) read from a cache file written by matrix_save."""
+    lib = _lib.load(dtype)
+    tm = lib._TM()
+    r, c, z = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.tilespmv_matrix_load(C.byref(tm), C.byref(r), C.byref(c), C.byref(z), path.encode())
+    if rc != 0:
+        raise OSError("tilespmv_matrix_load(%s) failed: %d" % (path, rc))
+    tm._lib = lib
+    return tm, r.value, c.value, z.value
+
+
 def partition_tilerows(tm, nparts):
     b = np.zeros(nparts + 1, dtype=np.int32)
     tm._lib.tilespmv_partition_tilerows(C.byref(tm), nparts, _p(b, C.c_int))

@@ -24,6 +24,7 @@ inline int host_threads()
         if (!e) e = getenv("OMP_NUM_THREADS");
         int v = e ? atoi(e) : 0;
         if (v <= 0) v = (int)std::thread::hardware_concurrency();
+        if (!e) v = std::min(v, 32);  // default: enough to saturate host memory bandwidth, polite on shared nodes
         return v > 0 ? std::min(v, 256) : 1;
     }();
     return n;
