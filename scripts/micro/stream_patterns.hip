@@ -115,6 +115,29 @@ __global__ __launch_bounds__(256) void k_group_rec(const char *__restrict__ a, d
     if (acc == 123.456) out[0] = acc;
 }
 
+// G: E (payload + descriptor stream, 20 units per lane group) plus what a strip writes: 4 rows x 128 B per group,
+// either as four 8-B-per-lane stores or as two 16-B-per-lane stores, or none
+template <int UB, int STORE>
+__global__ __launch_bounds__(256) void k_group_desc_store(const double *__restrict__ a, const uint2 *__restrict__ dsc, double *__restrict__ y, long long n_per_group)
+{
+    const int r = threadIdx.x & 15;
+    const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const double *p = a + grp * n_per_group;
+    const uint2 *q = dsc + grp * (n_per_group / 16) * 2 + (r >> 3);
+    double acc = 0;
+    for (long long i = 0; i < n_per_group; i += 16 * UB) {
+        double v[UB]; uint2 d[UB];
+#pragma unroll
+        for (int k = 0; k < UB; k++) { d[k] = q[(i / 16 + k) * 2]; v[k] = p[i + 16 * k + r]; }
+#pragma unroll
+        for (int k = 0; k < UB; k++) acc += v[k] * (double)(d[k].x + d[k].y);
+    }
+    double *yo = y + grp * 64;
+    if (STORE == 1) { for (int k = 0; k < 4; k++) yo[16 * k + r] = acc + k; }
+    else if (STORE == 2) { double2 t0 = {acc, acc + 1}, t1 = {acc + 2, acc + 3}; reinterpret_cast<double2 *>(yo)[r] = t0; reinterpret_cast<double2 *>(yo)[16 + r] = t1; }
+    else if (acc == 123.456) yo[0] = acc;
+}
+
 template <class F> double timeit(F f)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -158,6 +181,12 @@ int main()
     double ms = timeit([&] { hipLaunchKernelGGL((k_group_rec<UB, RECB>), g, dim3(256), 0, 0, (const char *)a, out, upg); }); \
     printf("F unit records %dB (payload+desc interleaved) UB=%d units/group=%d : %.4f ms  %.0f GB/s\n", RECB, UB, UPG, ms, (double)grps * upg * RECB / 1e9 / ms * 1e3); }
     RUNF(4, 144, 20) RUNF(4, 144, 32) RUNF(2, 144, 20) RUNF(8, 144, 32) RUNF(4, 160, 20) RUNF(4, 256, 20) RUNF(5, 144, 20)
+    { uint2 *dsc; hipMalloc(&dsc, N / 16 * 16); hipMemset(dsc, 0, N / 16 * 16); double *yy; hipMalloc(&yy, N / 320 * 64 * 8 + 4096);
+      long long pg = 320, grps = N / pg; grps -= grps % 16; dim3 g((unsigned)(grps / 16));
+      double m0 = timeit([&] { hipLaunchKernelGGL((k_group_desc_store<4, 0>), g, dim3(256), 0, 0, a, dsc, yy, pg); });
+      double m1 = timeit([&] { hipLaunchKernelGGL((k_group_desc_store<4, 1>), g, dim3(256), 0, 0, a, dsc, yy, pg); });
+      double m2 = timeit([&] { hipLaunchKernelGGL((k_group_desc_store<4, 2>), g, dim3(256), 0, 0, a, dsc, yy, pg); });
+      printf("G 20-unit strips + desc: no store %.4f ms | 4x8B-lane stores %.4f ms | 2x16B-lane stores %.4f ms  (reads %.0f MB, writes %.0f MB)\n", m0, m1, m2, gb * 1125, (double)grps * 512 / 1e6); }
     RUNC(1, 1, 1024) RUNC(2, 1, 1024) RUNC(4, 1, 1024) RUNC(4, 1, 4096) RUNC(8, 1, 4096)
     return 0;
 }
