@@ -221,21 +221,30 @@ def main():
         out["other_workloads"] = {}
         for wl in ("scircuit", "webbase"):
             try:
+                from tilespmv_amd.tile_matrix import field_array
                 m2, n2, rp2, ci2, src2 = build_matrix(wl)
                 r2 = (m2 // 16) * 16; nz2 = int(rp2[r2])
                 v2, x2 = G.compat_values(len(ci2), dtype), G.compat_x(n2, dtype)
-                tm2 = api.Tile_create(r2, n2, nz2, rp2, ci2, v2, dtype=dtype)
-                p2 = api.Plan(tm2, r2, n2, nz2)
-                xd2 = torch.from_numpy(x2).cuda(); yd2 = torch.zeros(r2 + 16, dtype=tdtype, device="cuda")
-                ms2 = p2.time(xd2.data_ptr(), yd2.data_ptr(), stream.cuda_stream, warmup=20, reps=200)
+                # config 2 must exercise all seven tile formats: HYB is only reachable with the opt-in rule
+                tm2 = api.Tile_create(r2, n2, nz2, rp2, ci2, v2, dtype=dtype, hyb=(wl == "scircuit"))
+                hist = np.bincount(field_array(tm2, "Format", tm2.tilenum), minlength=7).tolist()
                 import scipy.sparse as sp
                 ref2 = sp.csr_matrix((v2[:nz2].astype(np.float64), ci2[:nz2], rp2[:r2 + 1]), shape=(r2, n2)) @ x2.astype(np.float64)
-                ok2 = bool(np.array_equal(yd2.cpu().numpy()[:r2].astype(np.float64), ref2))
                 b2 = api.algorithmic_bytes(nz2, r2, n2, dtype.itemsize)
-                out["other_workloads"][wl] = {"source": src2, "rows": r2, "nnz": nz2, "ms_per_spmv": round(ms2, 5),
-                                              "gflops": round(2.0 * nz2 / ms2 * 1e-6, 1), "hbm_gbps_algorithmic": round(b2 / ms2 * 1e-6, 1),
-                                              "check": "pass" if ok2 else "FAIL", "note": "cache-resident: launch/latency-bound, roofline time %.1f us" % (b2 / 8e12 * 1e6)}
-                p2.close(); api.Tile_destroy(tm2)
+                rec = {"source": src2, "rows": r2, "nnz": nz2, "tile_format_histogram[csr,coo,ell,hyb,dns,dnsrow,dnscol]": hist,
+                       "note": "cache-resident: launch/latency-bound, roofline time %.1f us" % (b2 / 8e12 * 1e6)}
+                xd2 = torch.from_numpy(x2).cuda()
+                for label, coo in (("coo_in_tile", api.COO_IN_TILE), ("coo_csr_fallback", api.COO_FALLBACK)):
+                    p2 = api.Plan(tm2, r2, n2, nz2, coo_mode=coo)
+                    yd2 = torch.zeros(r2 + 16, dtype=tdtype, device="cuda")
+                    ms2 = p2.time(xd2.data_ptr(), yd2.data_ptr(), stream.cuda_stream, warmup=20, reps=200)
+                    ok2 = bool(np.array_equal(yd2.cpu().numpy()[:r2].astype(np.float64), ref2))
+                    rec[label] = {"ms_per_spmv": round(ms2, 5), "gflops": round(2.0 * nz2 / ms2 * 1e-6, 1),
+                                  "hbm_gbps_algorithmic": round(b2 / ms2 * 1e-6, 1), "check": "pass" if ok2 else "FAIL",
+                                  "fallback_nnz": p2.info()["fallback_nnz"]}
+                    p2.close()
+                out["other_workloads"][wl] = rec
+                api.Tile_destroy(tm2)
             except Exception as e:  # never let an extra break the headline line
                 out["other_workloads"][wl] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

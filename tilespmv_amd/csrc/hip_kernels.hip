@@ -31,7 +31,7 @@ constexpr int GROUPS_PER_BLOCK = 16;  // 256 threads
 #ifndef TILESPMV_STREAM_MIN_WAVES
 #define TILESPMV_STREAM_MIN_WAVES 1     // second __launch_bounds__ argument = waves per SIMD asked of the register allocator
 #endif
-constexpr int FB_NNZ = 512;           // products staged per wave in the fallback kernel
+constexpr int FB_NNZ = 256;           // products staged per wave in the fallback kernel (4 entries per lane, all loads in flight at once)
 
 __device__ __forceinline__ int nibble_of(const unsigned char *__restrict__ base, int p)
 {
@@ -255,14 +255,44 @@ __global__ __launch_bounds__(256) void k_fallback_csr(DevPlan P, const val_t *__
     const int p0 = P.f_ptr[r0], n = P.f_ptr[r1] - p0;
     if (n > FB_NNZ) {  // a single long row (the host never groups such a row with others)
         val_t sum = 0;
-        for (int k = lane; k < n; k += 64) sum += P.f_val[p0 + k] * x[P.f_col[p0 + k]];
+        for (int k0 = 0; k0 < n; k0 += 256) {  // 4 x 64 entries per trip: loads first, then the gathers
+            val_t v[4], xx[4]; int c[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int k = min(k0 + lane + 64 * q, n - 1); v[q] = P.f_val[p0 + k]; c[q] = P.f_col[p0 + k]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) xx[q] = x[c[q]];
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (k0 + lane + 64 * q < n) sum += v[q] * xx[q];
+        }
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
         if (lane == 0) y[P.f_row0 + r0] += sum;
         return;
     }
-    for (int k = lane; k < n; k += 64) s_prod[wave][k] = P.f_val[p0 + k] * x[P.f_col[p0 + k]];
+    // row bounds and old y of the first 64 rows travel together with the entry loads
+    const int rowl = min(r0 + lane, r1 - 1);
+    const int pa0 = P.f_ptr[rowl] - p0, pb0 = P.f_ptr[rowl + 1] - p0;
+    const val_t yold0 = y[P.f_row0 + rowl];
+    {   // n <= FB_NNZ = 4 x 64: every lane issues its (up to) four value/column loads, then the four x gathers
+        val_t v[4]; int c[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = min(lane + 64 * q, n - 1);
+            v[q] = P.f_val[p0 + k]; c[q] = P.f_col[p0 + k];
+        }
+        val_t xx[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) xx[q] = x[c[q]];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (lane + 64 * q < n) s_prod[wave][lane + 64 * q] = v[q] * xx[q];
+    }
     wave_lds_fence();
-    for (int row = r0 + lane; row < r1; row += 64) {
+    if (r0 + lane < r1 && pb0 > pa0) {
+        val_t sum = 0;
+        for (int k = pa0; k < pb0; k++) sum += s_prod[wave][k];
+        y[P.f_row0 + rowl] = yold0 + sum;
+    }
+    for (int row = r0 + 64 + lane; row < r1; row += 64) {
         const int a = P.f_ptr[row] - p0, b = P.f_ptr[row + 1] - p0;
         if (b > a) {
             val_t sum = 0;
