@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one GPU per rank); gloo only to rehearse the N>1 path on a single GPU")
     args = ap.parse_args()
 
     import torch
@@ -110,10 +112,14 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     dtype = np.dtype(np.float32 if (args.dtype == "f32" or (args.dtype is None and args.workload == "nlpkkt160")) else np.float64)
     tdtype = torch.float64 if dtype == np.float64 else torch.float32
@@ -157,7 +163,7 @@ def main():
         wall = time.perf_counter() - t0
         dev_ms = e0.elapsed_time(e1)          # HIP events on the launch stream, over the timed region
         if world > 1:
-            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall, dev_ms = float(t[0]), float(t[1])
         return wall, dev_ms
@@ -207,7 +213,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64" if dtype == np.float64 else "f32", "data": "synthetic (reference driver data: val[i]=i%10, x[i]=i%10)",
         "config": {"workload": args.workload, "source": source, "rows": rows, "cols": n, "nnz": nnz,
-                   "partition": "tile-row blocks, nnz-balanced, %d rank(s)" % world, "y_combine": args.combine,
+                   "partition": "tile-row blocks, nnz-balanced, %d rank(s)" % world, "y_combine": args.combine, "backend": args.backend if world > 1 else None,
                    "tiles": info["tiles"], "coo_mode": info["coo_mode"], "dense_mode": info["dense_mode"]},
         "hbm_gbps_algorithmic": round(b_alg_total / (wall / args.steps) * 1e-9, 1),
         "hbm_roofline_frac": round(b_alg_total / (wall / args.steps) * 1e-9 / (HBM_PEAK_GBPS * world), 4),

@@ -1,0 +1,47 @@
+"""bench.py keeps the driver's contract: one JSON line with the required keys; the N>1 path runs end to end
+(rehearsed with two ranks sharing the one GPU over gloo — RCCL needs one GPU per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "laplacian512", "--steps", "10", "--warmup", "3"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["check"] == "pass"
+    assert d["config"]["workload"] == "laplacian512" and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
+    assert abs(d["value"] - 2 * d["config"]["nnz"] / (d["ms_per_step"] * 1e-3) * 1e-9) / d["value"] < 0.02
+
+
+def test_two_rank_rehearsal_over_gloo():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "3", "--backend", "gloo",
+           "--workload", "laplacian512"]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["check"] == "pass" and d["scaling"] == "strong"
+    assert set(d["with_y_combine"]) == {"allgather", "allreduce"} and d["cpu_baseline"] is None
