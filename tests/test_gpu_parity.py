@@ -277,11 +277,12 @@ def test_shards_reproduce_full_result(torch_cuda):
             assert np.array_equal(yd.cpu().numpy()[:rowA], full), (name, world)
         # plan-level tile-row windows of ONE Tile_matrix
         b = api.partition_tilerows(tp, 4)
-        yd = torch.full((rowA + 16,), -1.0, dtype=torch.float64, device="cuda")
-        for k in range(4):
-            p = api.Plan(tp, rowA, n, nnz, tilerow_begin=int(b[k]), tilerow_end=int(b[k + 1]))
-            p.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize(); p.close()
-        assert np.array_equal(yd.cpu().numpy()[:rowA], full), name
+        for kw in ({}, {"coo_mode": api.COO_FALLBACK}, {"kernel": api.KERNEL_DIRECT, "coo_mode": api.COO_FALLBACK}, {"dense_mode": api.DENSE_MFMA}):
+            yd = torch.full((rowA + 16,), -1.0, dtype=torch.float64, device="cuda")
+            for k in range(4):
+                p = api.Plan(tp, rowA, n, nnz, tilerow_begin=int(b[k]), tilerow_end=int(b[k + 1]), **kw)
+                p.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize(); p.close()
+            assert np.array_equal(yd.cpu().numpy()[:rowA], full), (name, kw)
 
 
 def test_call_tilespmv_hip_drop_in(torch_cuda, tmp_path, monkeypatch):
