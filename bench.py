@@ -149,15 +149,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def run(combine, count):  # exactly `count` steps, back to back on the launch stream
+        if combine == "none":
+            sh.spmv(xd, yd, stream.cuda_stream, count=count)   # one C call issuing `count` launches
+        else:
+            for _ in range(count):
+                step(combine)
+
     def timed(combine, steps, warmup):
-        for _ in range(warmup):
-            step(combine)
+        run(combine, warmup)
         sync_all()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record(stream)
-        for _ in range(steps):
-            step(combine)
+        run(combine, steps)
         e1.record(stream)
         sync_all()
         wall = time.perf_counter() - t0

@@ -212,6 +212,10 @@ void tilespmv_plan_destroy(tilespmv_plan *plan);
 int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y,
                        void *stream);
 
+/* `count` back-to-back SpMVs on `stream` (same as calling tilespmv_plan_spmv `count` times; saves the
+ * caller's per-call overhead when one SpMV takes tens of microseconds).  Returns a hipError_t value. */
+int tilespmv_plan_spmv_n(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y, void *stream, int count);
+
 /* Plan facts for reports: index into `out` by TILESPMV_INFO_*. */
 enum {
     TILESPMV_INFO_DEVICE_BYTES = 0,   /* bytes of the resident plan */

@@ -23,7 +23,7 @@ class _OracleLocal:
         self.tm = self.O.tile_create(rows, cols, len(ci), rp, ci, v)
         self.rows = rows
 
-    def spmv(self, x_ptr, y_ptr, stream=0):
+    def spmv(self, x_ptr, y_ptr, stream=0):  # noqa
         import ctypes as C
         rows, cols, nnz, rp, ci, v = self.args
         dt = self.O.dtype

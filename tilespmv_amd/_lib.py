@@ -74,6 +74,8 @@ def load(dtype=np.float64):
     lib.tilespmv_plan_destroy.restype = None
     lib.tilespmv_plan_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.tilespmv_plan_spmv.restype = C.c_int
+    lib.tilespmv_plan_spmv_n.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.tilespmv_plan_spmv_n.restype = C.c_int
     lib.tilespmv_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     lib.tilespmv_plan_info.restype = None
     lib.tilespmv_plan_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -99,4 +101,4 @@ def load(dtype=np.float64):
 DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_cpu", "mmio_allinone", "call_tilespmv_hip",
                     "tilespmv_plan_create", "tilespmv_plan_destroy", "tilespmv_plan_spmv", "tilespmv_plan_info",
                     "tilespmv_plan_time", "tilespmv_partition_tilerows", "tilespmv_sizeof_value", "tilespmv_version",
-                    "tilespmv_device_count", "tilespmv_matrix_save", "tilespmv_matrix_load"]
+                    "tilespmv_device_count", "tilespmv_matrix_save", "tilespmv_matrix_load", "tilespmv_plan_spmv_n"]

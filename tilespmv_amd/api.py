@@ -146,6 +146,11 @@ class Plan:
         if rc != 0:
             raise RuntimeError("tilespmv_plan_spmv: HIP error %d" % rc)
 
+    def spmv_n(self, d_x, d_y, stream=0, count=1):
+        rc = self.lib.tilespmv_plan_spmv_n(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream), count)
+        if rc != 0:
+            raise RuntimeError("tilespmv_plan_spmv_n: HIP error %d" % rc)
+
     def time(self, d_x, d_y, stream=0, warmup=10, reps=50):
         ms = self.lib.tilespmv_plan_time(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream), warmup, reps)
         if ms < 0:

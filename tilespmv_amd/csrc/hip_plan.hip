@@ -747,6 +747,15 @@ int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYP
     return (int)launch_fallback(plan->dev, d_x, d_y, st);
 }
 
+int tilespmv_plan_spmv_n(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y, void *stream, int count)
+{
+    for (int i = 0; i < count; i++) {
+        const int rc = tilespmv_plan_spmv(plan, d_x, d_y, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out)
 {
     memcpy(out, plan->info, sizeof(plan->info));

@@ -65,10 +65,13 @@ class ShardedSpMV:
         self._gather = None
 
     # y_full: torch tensor with >= rows elements on the compute device; x: torch tensor with cols elements
-    def spmv(self, x, y_full, stream=0):
-        """y_full[r0:r1] = A[r0:r1, :] @ x — no communication."""
-        ysl = y_full[self.r0:]
-        self.local.spmv(x.data_ptr(), ysl.data_ptr(), stream)
+    def spmv(self, x, y_full, stream=0, count=1):
+        """y_full[r0:r1] = A[r0:r1, :] @ x — no communication.  ``count`` > 1 repeats it back to back."""
+        yp = y_full.data_ptr() + self.r0 * y_full.element_size()
+        if count == 1:
+            self.local.spmv(x.data_ptr(), yp, stream)
+        else:
+            self.local.spmv_n(x.data_ptr(), yp, stream, count)
 
     def combine(self, y_full, mode):
         import torch
