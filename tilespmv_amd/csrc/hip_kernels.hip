@@ -542,22 +542,26 @@ __global__ __launch_bounds__(256) void k_dense_mfma(DevDense D, int rowA, int co
             for (int s = 0; s < 4; s++) b[s] = x[min(xb + s, xlast)];  // partial last column block (payload is zero there)
         }
     };
-    val_t a0[4], b0[4];
-    load_tile(t0, a0, b0);
-    for (int t = t0; t < t1; t++) {  // next tile in flight ahead of the MFMAs; loads unconditional (clamped): exact wait counts
-        val_t a1[4], b1[4];
-        load_tile(t + 1, a1, b1);
+    auto mfma4 = [&](const val_t (&a)[4], const val_t (&b)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; s++) {
 #if defined(TILESPMV_F32)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
 #else
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b0[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
 #endif
         }
+    };
+    val_t a0[4], b0[4];
+    load_tile(t0, a0, b0);
+    for (int t = t0; t < last; t++) {  // next tile's loads in flight ahead of this tile's MFMAs (unconditional: exact wait counts)
+        val_t a1[4], b1[4];
+        load_tile(t + 1, a1, b1);
+        mfma4(a0, b0);
 #pragma unroll
         for (int s = 0; s < 4; s++) { a0[s] = a1[s]; b0[s] = b1[s]; }
     }
+    mfma4(a0, b0);  // last tile: nothing left to prefetch
     if ((lane & 15) == 0) {  // every column of D holds the same 16 results; column 0 writes them
 #pragma unroll
         for (int i = 0; i < 4; i++) {
