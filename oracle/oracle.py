@@ -142,6 +142,18 @@ class CpuImpl:
             "blkcoostylerowidx_colstop": _take(c, nblk, np.int32, self.free),
         }
 
+    def spmv_all_cores(self, tm, rowA, colA, x):
+        """Tile-row-parallel (OpenMP) tile SpMV; returns (y, threads used).  Restatement only."""
+        assert self.kind == "oracle"
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        y = np.zeros(max(rowA, 1) + 16, dtype=self.dtype)
+        f = self.lib.oracle_tilespmv_cpu_omp
+        VP = C.POINTER(self.vt)
+        f.argtypes = [C.POINTER(self.TM), C.c_int, C.c_int, VP, VP]
+        f.restype = C.c_int
+        nt = f(C.byref(tm), rowA, colA, _p(x, self.vt), _p(y, self.vt))
+        return y[:rowA].copy(), nt
+
     def csr_spmv(self, rowA, rowptr, colidx, vals, x):
         """Serial CSR golden, reference src/main.cu:101-110 (same loop in every checker)."""
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)

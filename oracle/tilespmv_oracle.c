@@ -9,7 +9,7 @@
  *
  * Parity status: PINNED.  Every function here is compared field-by-field / bit-by-bit with the
  * reference's own headers compiled unmodified (oracle/_ref, built by oracle/Makefile from
- * /root/reference/src) in tests/test_oracle_vs_ref.py, and with the known-answer table of
+ * /root/reference/src) in tests/test_oracle_golden.py, and with the known-answer table of
  * SURVEY.md §8(c) (hashes committed under tests/golden/).
  *
  * Each routine cites the reference lines whose behaviour it restates.  The code is organised
@@ -576,6 +576,110 @@ int oracle_tilespmv_cpu(const Tile_matrix *T, int *ptroffset1, int *ptroffset2, 
     int bad = 0;
     if (y_golden) for (int i = 0; i < rowA; i++) if (y[i] != y_golden[i]) bad++;
     return bad;
+}
+
+/* Tile-row-parallel variant of the tile SpMV (OpenMP over tile-rows) for the "all host cores" CPU
+ * baseline of SURVEY.md §8(d).  Same per-tile arithmetic and order as oracle_tilespmv_cpu, so y is
+ * bit-identical; the per-tile payload offsets are read from the *_offset prefixes that Tile_create
+ * stores (they equal the running counters of the serial loop).  HYB tiles need a
+ * running byte offset into hybIdx, computed serially first.  Returns the thread count used. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int oracle_tilespmv_cpu_omp(const Tile_matrix *T, int rowA, int colA, const val_t *x, val_t *y)
+{
+    const int tilem = T->tilem, tilen = T->tilen;
+    int *hybidx = NULL;
+    if (T->hybsize > 0) {
+        hybidx = zalloc((size_t)T->tilenum + 1, sizeof(int));
+        int at = 0;
+        for (int bi = 0; bi < tilem; bi++) {
+            const int rowlen = (bi == tilem - 1) ? rowA - (tilem - 1) * BS : BS;
+            for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++)
+                if (T->Format[t] == TILESPMV_FMT_HYB) {
+                    const int nell = T->tilewidth[t] * rowlen;
+                    hybidx[t] = at; at += (nell + 1) / 2 + (T->blknnz[t + 1] - T->blknnz[t] - nell);
+                }
+        }
+    }
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 256)
+#endif
+    for (int bi = 0; bi < tilem; bi++) {
+        const int rowlen = (bi == tilem - 1) ? rowA - (tilem - 1) * BS : BS;
+        val_t *yb = y + (size_t)bi * BS;
+        for (int ri = 0; ri < rowlen; ri++) yb[ri] = 0;
+        for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+            const int collen = (T->tile_columnidx[t] == tilen - 1) ? colA - (tilen - 1) * BS : BS;
+            const val_t *xb = x + (size_t)T->tile_columnidx[t] * BS;
+            const int stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
+            switch (T->Format[t]) {
+            case TILESPMV_FMT_CSR: {
+                const int o = T->csr_offset[t], po = T->csrptr_offset[t];
+                for (int ri = 0; ri < rowlen; ri++) {
+                    val_t sum = 0;
+                    int k1 = (ri == rowlen - 1) ? stored : T->Blockcsr_Ptr[po + ri + 1];
+                    for (int k = T->Blockcsr_Ptr[po + ri]; k < k1; k++) sum += xb[nibble_at(T->csr_compressedIdx, o + k)] * T->Blockcsr_Val[o + k];
+                    yb[ri] += sum;
+                }
+                break;
+            }
+            case TILESPMV_FMT_COO: {
+                const int o = T->coo_offset[t];
+                for (int k = 0; k < stored; k++) { unsigned char b = T->coo_compressed_Idx[o + k]; yb[b >> 4] += T->Blockcoo_Val[o + k] * xb[b & 15]; }
+                break;
+            }
+            case TILESPMV_FMT_ELL: {
+                const int o = T->ell_offset[t];
+                for (int ri = 0; ri < rowlen; ri++) {
+                    val_t sum = 0;
+                    for (int s2 = 0; s2 < w; s2++) { int p = o + s2 * rowlen + ri; if (T->Blockell_Val[p] != 0) sum += T->Blockell_Val[p] * xb[nibble_at(T->ell_compressedIdx, p)]; }
+                    yb[ri] += sum;
+                }
+                break;
+            }
+            case TILESPMV_FMT_HYB: {
+                const int o = T->hyb_offset[t], nell = w * rowlen, ncoo = stored - nell;
+                const unsigned char *ix = T->hybIdx + hybidx[t];
+                for (int ri = 0; ri < rowlen; ri++) {
+                    val_t sum = 0;
+                    for (int s2 = 0; s2 < w; s2++) { int p = s2 * rowlen + ri; if (T->Blockhyb_Val[o + p] != 0) sum += T->Blockhyb_Val[o + p] * xb[nibble_at(ix, p)]; }
+                    yb[ri] += sum;
+                }
+                ix += (nell + 1) / 2;
+                for (int i = 0; i < ncoo; i++) yb[ix[i] >> 4] += T->Blockhyb_Val[o + nell + i] * xb[ix[i] & 15];
+                break;
+            }
+            case TILESPMV_FMT_DNS: {
+                const int o = T->dns_offset[t];
+                for (int ri = 0; ri < rowlen; ri++) for (int c = 0; c < collen; c++) yb[ri] += xb[c] * T->Blockdense_Val[o + c * rowlen + ri];
+                break;
+            }
+            case TILESPMV_FMT_DNSROW: {
+                const int o = T->dnsrow_offset[t];
+                for (int k = T->dnsrowptr[t]; k < T->dnsrowptr[t + 1]; k++) {
+                    val_t sum = 0;
+                    for (int c = 0; c < collen; c++) sum += xb[c] * T->Blockdenserow_Val[o + (k - T->dnsrowptr[t]) * collen + c];
+                    yb[(int)T->denserowid[k]] += sum;
+                }
+                break;
+            }
+            case TILESPMV_FMT_DNSCOL: {
+                const int o = T->dnscol_offset[t];
+                for (int ri = 0; ri < rowlen; ri++) {
+                    val_t sum = 0;
+                    for (int k = T->dnscolptr[t]; k < T->dnscolptr[t + 1]; k++) sum += T->Blockdensecol_Val[o + (k - T->dnscolptr[t]) * rowlen + ri] * xb[(int)T->densecolid[k]];
+                    yb[ri] += sum;
+                }
+                break;
+            }
+            }
+        }
+    }
+    free(hybidx);
+    return nthreads;
 }
 
 /* Serial CSR golden (reference src/main.cu:101-110). */

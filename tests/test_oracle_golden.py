@@ -96,6 +96,21 @@ def test_oracle_vs_compiled_reference_live(dtype, hyb):
                 assert np.array_equal(np.asarray(so[k]), np.asarray(sr[k])), (name, k, real)  # y is BIT-identical
 
 
+def test_all_cores_variant_is_bit_identical():
+    """The OpenMP tile-row-parallel CPU SpMV (bench.py's all-cores baseline) == the serial restatement, bit for bit."""
+    for dtype in (np.float64, np.float32):
+        O = CpuImpl("oracle", dtype)
+        for name in ("allfmt", "circuit8k", "powerlaw20k", "lap64", "band4096_40"):
+            for real in (False, True):
+                m, n, rp, ci = SMALL[name]()
+                nnz, rowA = len(ci), truncated_rows(m)
+                vals, x = values_for(name, nnz, n, dtype, real)
+                tm = O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True)
+                want = O.spmv(tm, rowA, n, nnz, rp, ci, vals, x)["y"]
+                got, nt = O.spmv_all_cores(tm, rowA, n, x)
+                assert nt >= 1 and np.array_equal(got, want), (name, dtype, real)
+
+
 def test_mmio_loader_known_answers(tmp_path):
     kat = json.load(open(os.path.join(HERE, "golden", "mmio_kat.json")))
     O = CpuImpl("oracle", np.float64)
