@@ -40,6 +40,10 @@ def build_matrix(name):
         return r["m"], r["n"], r["rowptr"], r["colidx"], "file:" + real + ".mtx"
     if name == "laplacian4096":
         return G.laplacian5pt(4096) + ("synthetic 5-pt Laplacian 4096^2",)
+    if name.startswith("lap3d"):
+        return G.laplacian7pt(int(name[5:])) + ("synthetic 7-pt Laplacian on a cube",)
+    if name.startswith("powerlaw"):
+        return G.powerlaw(int(name[8:]), seed=2) + ("synthetic power-law",)
     if name.startswith("laplacian"):
         return G.laplacian5pt(int(name[len("laplacian"):])) + ("synthetic 5-pt Laplacian",)
     if name.startswith("band"):  # e.g. band40_2000000: full band, half-bandwidth 40 (dense-tile dominated)

@@ -41,6 +41,17 @@ def laplacian5pt(n):
     return N, N, rowptr, colidx
 
 
+def laplacian7pt(n):
+    """7-point stencil on an n^3 grid (row-major), per-row order by ascending column."""
+    N = n * n * n
+    idx = np.arange(N, dtype=np.int64)
+    k, j, i = idx // (n * n), (idx // n) % n, idx % n
+    cand = np.stack([idx - n * n, idx - n, idx - 1, idx, idx + 1, idx + n, idx + n * n], axis=1)
+    mask = np.stack([k > 0, j > 0, i > 0, np.ones(N, bool), i < n - 1, j < n - 1, k < n - 1], axis=1)
+    rowptr, colidx = _from_mask(cand, mask)
+    return N, N, rowptr, colidx
+
+
 def band(n, hbw, ncols=None):
     """Full band: row r holds columns r-hbw..r+hbw (clipped), ascending."""
     ncols = n if ncols is None else ncols
