@@ -356,9 +356,12 @@ __device__ __forceinline__ T stream_load(const T *p, bool nt)
 // ds_read_b64 instead of one global load.  (Measured: per-unit descriptor loads, 6 % of the bytes, cost 19 %
 // of the kernel — the CU's vector-memory pipeline is the bottleneck, not HBM)
 constexpr int DCHUNK = 16;  // units per descriptor chunk
+#ifndef UNITS_MIN_WAVES
+#define UNITS_MIN_WAVES 8  // waves per SIMD asked of the register allocator (64 VGPRs)
+#endif
 
 template <int UB, int XCD_REMAP, bool NT>
-__global__ __launch_bounds__(256) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+__global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0, "a batch never straddles a descriptor chunk");
