@@ -1,9 +1,10 @@
-"""Quick GPU shake-out: parity of the HIP path vs the oracle on small matrices + a first timing."""
+"""Quick GPU shake-out (manual tool, lives under tests/ because it uses the oracle): parity of the HIP path
+vs the oracle on all small matrices x kernels x modes + a first timing.  Run: python tests/gpu_shakeout.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import cases as tests_cases
 sys.modules['tests_cases']=tests_cases
 from oracle.oracle import CpuImpl
