@@ -197,7 +197,7 @@ typedef struct {
     int kernel;         /* TILESPMV_KERNEL_* */
     int tilerow_begin;  /* shard: first tile-row (0 for the whole matrix) */
     int tilerow_end;    /* shard: one past the last tile-row (<=0 means tilem) */
-    int reserved[3];
+    int reserved[3];    /* reserved[0] != 0 (or env TILESPMV_AUTOTUNE=1): decide the AUTO modes by timing the candidates */
 } tilespmv_plan_options;
 
 /* Returns 0 on success, non-zero (message on stderr) when no HIP device / extension is

@@ -148,6 +148,22 @@ def test_random_block_structured_matrices(torch_cuda, seed):
             api.Tile_destroy(tp)
 
 
+def test_autotuned_plan(torch_cuda):
+    """autotune=True: the AUTO modes are decided by timing the candidates; the result is still exact."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api
+    for name in ("circuit8k", "band4096_40", "lap64"):
+        m, n, rp, ci = SMALL[name]()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, x = values_for(name, nnz, n, np.float64)
+        O = CpuImpl("oracle", np.float64)
+        want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals), rowA, n, nnz, rp, ci, vals, x)["y"]
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
+        y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, autotune=True)
+        assert np.array_equal(y, want), name
+        assert info["coo_mode"] in (api.COO_IN_TILE, api.COO_FALLBACK) and info["dense_mode"] in (api.DENSE_MFMA, api.DENSE_VALU)
+
+
 def test_degenerate_inputs(torch_cuda):
     """No nonzeros at all, a single nonzero, a 16x16 matrix, rows but no columns used."""
     from oracle.oracle import CpuImpl

@@ -131,10 +131,11 @@ def partition_tilerows(tm, nparts):
 class Plan:
     """Device-resident tiled matrix (or one tile-row shard of it)."""
 
-    def __init__(self, tm, rowA, colA, nnzA, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0):
+    def __init__(self, tm, rowA, colA, nnzA, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, autotune=False):
         self.lib = tm._lib
         self.rowA, self.colA, self.nnzA = rowA, colA, nnzA
         opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end)
+        opts.reserved[0] = 1 if autotune else 0
         h = C.c_void_p()
         rc = self.lib.tilespmv_plan_create(C.byref(h), C.byref(tm), rowA, colA, nnzA, C.byref(opts))
         if rc != 0 or not h:

@@ -502,8 +502,55 @@ void tilespmv_plan_destroy(tilespmv_plan *plan)
     delete plan;
 }
 
+static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA,
+                           const tilespmv_plan_options *opts);
+
+// Measured selection (execution side): when opts->reserved[0] != 0 or TILESPMV_AUTOTUNE=1, the
+// choices that AUTO otherwise makes from byte models — COO tiles in-tile vs CSR fallback, dense tiles on the
+// matrix cores vs as streamed units — are decided by timing each candidate plan on this device.
 int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA,
                          const tilespmv_plan_options *opts)
+{
+    tilespmv_plan_options o{};
+    if (opts) o = *opts;
+    const bool tune = o.reserved[0] != 0 || env_int("TILESPMV_AUTOTUNE", 0) != 0;
+    o.reserved[0] = 0;
+    if (!tune) return plan_create_one(out, T, rowA, colA, nnzA, &o);
+    *out = nullptr;
+    const int tilem = T->tilem;
+    const int tr0 = std::max(0, o.tilerow_begin), tr1 = (o.tilerow_end <= 0 || o.tilerow_end > tilem) ? tilem : o.tilerow_end;
+    bool has_dense = false;
+    for (int t = T->tile_ptr[tr0]; t < T->tile_ptr[tr1] && !has_dense; t++) has_dense = T->Format[t] == TILESPMV_FMT_DNS;
+    const bool has_extracted = T->new_coocount[T->tile_ptr[tr1]] > T->new_coocount[T->tile_ptr[tr0]];
+    val_t *dx = nullptr, *dy = nullptr;
+    if (hipMalloc((void **)&dx, ((size_t)colA + 16) * sizeof(val_t)) != hipSuccess) return -3;
+    if (hipMalloc((void **)&dy, ((size_t)rowA + 16) * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); return -3; }
+    (void)hipMemset(dx, 0, ((size_t)colA + 16) * sizeof(val_t));
+    tilespmv_plan *best = nullptr;
+    double best_ms = 0;
+    auto try_one = [&](tilespmv_plan_options cand) {
+        tilespmv_plan *p = nullptr;
+        if (plan_create_one(&p, T, rowA, colA, nnzA, &cand) != 0 || !p) return;
+        const double ms = tilespmv_plan_time(p, dx, dy, nullptr, 3, 12);
+        if (ms > 0 && (!best || ms < best_ms)) { tilespmv_plan_destroy(best); best = p; best_ms = ms; }
+        else tilespmv_plan_destroy(p);
+    };
+    const int coo_cands[2] = {TILESPMV_COO_IN_TILE, TILESPMV_COO_FALLBACK}, dns_cands[2] = {TILESPMV_DENSE_MFMA, TILESPMV_DENSE_VALU};
+    for (int ci = 0; ci < ((o.coo_mode == TILESPMV_COO_AUTO && has_extracted) ? 2 : 1); ci++)
+        for (int di = 0; di < ((o.dense_mode == TILESPMV_DENSE_AUTO && has_dense) ? 2 : 1); di++) {
+            tilespmv_plan_options cand = o;
+            if (o.coo_mode == TILESPMV_COO_AUTO && has_extracted) cand.coo_mode = coo_cands[ci];
+            if (o.dense_mode == TILESPMV_DENSE_AUTO && has_dense) cand.dense_mode = dns_cands[di];
+            try_one(cand);
+        }
+    (void)hipFree(dx); (void)hipFree(dy);
+    if (!best) return -4;
+    *out = best;
+    return 0;
+}
+
+static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA,
+                           const tilespmv_plan_options *opts)
 {
     (void)nnzA;
     *out = nullptr;
