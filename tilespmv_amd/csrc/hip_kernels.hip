@@ -1,9 +1,13 @@
 // hip_kernels.hip — hand-written CDNA4 (gfx950, wave64) kernels of the y = A*x hot path.
 //
-//   k_tiles_direct   fused tile SpMV: one 16-lane lane group ("strip") walks whole tile-rows,
-//                    one tile at a time, through the seven per-tile routines below; four strips
-//                    per wavefront, sixteen per workgroup.  Replaces the reference's
-//                    stir_spmv_cuda_kernel_v6 (src/tilespmv_cuda.h:394-792).
+//   k_units          (default) unit-stream kernel: one 16-lane strip per task consumes a flat run of
+//                    self-describing 16-value units (ELL / HYB slots, dense and dense-col columns, the
+//                    leading entries of CSR tile rows, dense-row "row units") plus the strip's COO
+//                    entry list.  Replaces stir_spmv_cuda_kernel_v6 (src/tilespmv_cuda.h:394-792).
+//   k_dense_mfma     dense tiles on the matrix cores, one wavefront per tile-row (y +=).
+//   k_tiles_direct   first-generation fused tile SpMV: a strip walks whole tile-rows one tile at a
+//                    time through the seven per-tile routines below (TILESPMV_KERNEL=1), and the
+//                    pass for CSR tiles kept whole in generation 2 (ACCUM).
 //   k_fixup_split    sums the partial results of split (very long) tile-rows in a fixed order
 //                    (the reference uses global atomicAdd, src/tilespmv_cuda.h:784-790).
 //   k_fallback_csr   very-sparse CSR fallback, y += A_coo x over the extracted matrix
@@ -332,11 +336,12 @@ int fallback_block_nnz() { return FB_NNZ; }
 // One 16-lane strip per task as before, but the common formats are consumed as a flat run of
 // self-describing 16-value units whose addresses depend only on the unit index:
 //   phase 1  COO entry list of the strip -> LDS scatter-add (ds_add) into s_y[strip row][row]
-//   phase 2  units (ELL slots, HYB ELL part, dense-col / dense columns) in batches of UB with all
-//            descriptor + payload loads of a batch issued before the first use; the tile-row's 16
-//            results are written when the unit flagged end-of-row retires.
-// CSR / dense-row / MFMA-dense tiles ("heavy" tiles) are not in this kernel: they run afterwards
-// through k_tiles_direct<.., ACCUM=true>, which keeps the hot kernel at <= 64 VGPRs (8 waves/SIMD).
+//   phase 2  units in batches of UB: descriptors come from LDS (one coalesced load per 16 units), the
+//            x gathers of a batch are issued at once, the next batch's value loads go in flight before
+//            the first use; a finished tile-row parks its 16 results in LDS and y is written once per
+//            strip with 16-B lane stores.
+// Dense tiles for the matrix cores (k_dense_mfma) and CSR tiles kept whole (k_tiles_direct<.., ACCUM>)
+// run after this kernel, which keeps it at 60 VGPRs (8 waves/SIMD).
 // ================================================================================================
 namespace tilespmv {
 
