@@ -46,7 +46,7 @@ struct tilespmv_plan {
     DevStream st{};
     DevDense dn{};
     int unit_batch = 4;
-    int xcd_remap = 2, xcd_chunk = 32;  // windows of 8 x 32 workgroups: neighbouring strips share an XCD L2 (+1.5 % on laplacian4096)
+    int xcd_remap = 2, xcd_chunk = 16;  // windows of 8 x 16 workgroups: neighbouring strips share an XCD L2 (+1 % laplacian4096, +7 % KKT fp64 vs 32)
     bool nontemporal = false;
     std::vector<void *> allocs;
     long long info[TILESPMV_INFO_COUNT] = {0};
@@ -622,7 +622,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     plan->kernel = kernel;
     plan->unit_batch = env_int("TILESPMV_UNIT_BATCH", 4);
     plan->xcd_remap = env_int("TILESPMV_XCD_REMAP", 2);
-    plan->xcd_chunk = std::max(1, env_int("TILESPMV_XCD_CHUNK", 32));
+    plan->xcd_chunk = std::max(1, env_int("TILESPMV_XCD_CHUNK", 16));
     plan->nontemporal = env_int("TILESPMV_NT", 0) != 0;
     // Strip size: ~400 cost units (20 units) amortises the per-strip round trips; measured flat between 200
     // and 800 on large matrices and neutral on small (cache-resident) ones, where launch latency dominates.
