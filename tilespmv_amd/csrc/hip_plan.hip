@@ -2,9 +2,10 @@
 //
 // Replaces the host half of call_tilespmv_cuda (reference src/tilespmv_cuda.h:794-1180): instead
 // of ~35 cudaMalloc+cudaMemcpy pairs of the per-format arrays (:867-1004) the Tile_matrix is
-// re-laid-out once into three tile-ordered streams (hip_plan.h) and uploaded; the chunk
-// schedule that the reference derives inside tilespmv_cpu (:68-118) and patches up with a
-// one-off v5 launch (:1045-1056) is replaced by a cost-balanced strip list built here.
+// re-laid-out once into tile-ordered streams (hip_plan.h: the unit stream of generation 2, or the
+// tile stream of generation 1) and uploaded; the chunk schedule that the reference derives inside
+// tilespmv_cpu (:68-118) and patches up with a one-off v5 launch (:1045-1056) is replaced by a
+// cost-balanced strip list built here.
 #include <hip/hip_runtime.h>
 #include <sys/time.h>
 
