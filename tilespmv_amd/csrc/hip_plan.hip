@@ -189,7 +189,7 @@ inline int csr_split_width(const unsigned char *ptr, int rowlen, int nnz, int *r
 
 inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, bool csr_split)
 {
-    static const int coo_cost = env_int("TILESPMV_COO_COST", 3);
+    const int coo_cost = env_int("TILESPMV_COO_COST", 3);
     RowCount c{0, 0, 0, 0, 0, 0, 0};
     for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
         const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
@@ -257,7 +257,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         if (rc_[i].cost > split_above) {
             row_split[i] = 1;
             FixRow f{tr0 + i, npartial, 0, 0};
-            const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, piece / std::max(1, env_int("TILESPMV_COO_COST", 3)));
+            const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, env_int("TILESPMV_COO_PIECE", piece / std::max(1, env_int("TILESPMV_COO_COST", 3))));
             for (long long u = pu[i]; u < pu[i + 1]; u += pu_) {
                 STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
                 k.unit_begin = (int)u; k.unit_end = (int)std::min(pu[i + 1], u + pu_);
