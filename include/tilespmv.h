@@ -168,6 +168,29 @@ void call_tilespmv_hip(char *filename, Tile_matrix *matrix, int *ptroffset1, int
                        MAT_VAL_TYPE *csrValA, MAT_VAL_TYPE alpha, MAT_VAL_TYPE *x,
                        MAT_VAL_TYPE *y, MAT_VAL_TYPE *y_golden);
 
+/* Multi-device form of the same driver (new: the reference is single-GPU, src/main.cu:74; SURVEY.md
+ * S8(b) "New").  Same 18 arguments, then the devices to use and what to do with y afterwards.
+ * The matrix is cut into `ngpus` nnz-balanced blocks of whole tile-rows (tilespmv_partition_tilerows),
+ * one resident plan per device, x replicated; the SpMV needs no exchange.  y_combine_mode:
+ *   TILESPMV_Y_SHARDED   every device keeps its own rows (the timed figure of the other modes too);
+ *   TILESPMV_Y_ALLGATHER every device receives the other shards' rows by peer copies (xGMI);
+ *   TILESPMV_Y_ALLREDUCE ncclAllReduce(sum) of full-length vectors that are zero outside the owner's
+ *                        rows (bit-identical to the gather); librccl is dlopen'ed for this mode only.
+ * Prints the reference's runtime line for the sharded SpMV plus one "  HIP ..." line that also
+ * carries the SpMV+combine time, appends results.csv, returns y on the host (in the combine modes
+ * taken from the last device's full-length copy).  A device id may be repeated (several shards on
+ * one device) except in all-reduce mode.  Aborts with a message and exit status 3 on any error. */
+#define TILESPMV_Y_SHARDED 0
+#define TILESPMV_Y_ALLGATHER 1
+#define TILESPMV_Y_ALLREDUCE 2
+void call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int *ptroffset1, int *ptroffset2,
+                             int rowblkblock, unsigned int *blkcoostylerowidx,
+                             int *blkcoostylerowidx_colstart, int *blkcoostylerowidx_colstop,
+                             int rowA, int colA, MAT_PTR_TYPE nnzA, MAT_PTR_TYPE *csrRowPtrA,
+                             int *csrColIdxA, MAT_VAL_TYPE *csrValA, MAT_VAL_TYPE alpha,
+                             MAT_VAL_TYPE *x, MAT_VAL_TYPE *y, MAT_VAL_TYPE *y_golden, int ngpus,
+                             const int *device_ids, int y_combine_mode);
+
 /*
  * Resident-plan API (new; what call_tilespmv_hip is built from).  A plan owns the device
  * copy of one Tile_matrix (or of one contiguous block of its tile-rows: the multi-GPU shard),

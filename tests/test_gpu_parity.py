@@ -319,6 +319,45 @@ def test_call_tilespmv_hip_drop_in(torch_cuda, tmp_path, monkeypatch):
     assert line[0] == "circuit8k.mtx" and [int(v) for v in line[1:4]] == [rowA, n, nnz] and float(line[5]) > 0
 
 
+@pytest.mark.parametrize("ids,mode", [([0], 0), ([0], 1), ([0], 2), ([0, 0], 0), ([0, 0, 0], 1), ([0] * 5, 1)])
+def test_call_tilespmv_hip_multi(torch_cuda, tmp_path, monkeypatch, capfd, ids, mode):
+    """Multi-device form of the one-shot entry (SURVEY S8(b) "New"): tile-row shards, one plan per listed device
+    (ids may repeat, so the shard + gather logic runs on a one-GPU box), y left sharded / peer-copy all-gather /
+    RCCL all-reduce.  Result is bit-identical to the one-device entry in every mode."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("TILESPMV_WARMUP", "2"); monkeypatch.setenv("TILESPMV_BENCH_REPEAT", "3"); monkeypatch.setenv("TILESPMV_COMBINE_REPEAT", "2")
+    for name in ("allfmt", "circuit8k"):
+        m, n, rp, ci = SMALL[name]()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, x = values_for(name, nnz, n, np.float64)
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
+        yg = CpuImpl("oracle").csr_spmv(rowA, rp, ci, vals, x)
+        y = api.call_tilespmv_hip(name + ".mtx", tp, None, rowA, n, nnz, rp, ci, vals, x, device_ids=ids, y_combine_mode=mode)
+        assert np.array_equal(y, yg), (name, ids, mode)
+    out = capfd.readouterr().out
+    assert "CUDA SpMV runtime" in out and "HIP SpMV on %d device(s)" % len(ids) in out
+    assert len(open(tmp_path / "results.csv").read().strip().splitlines()) == 2
+
+
+def test_cli_device_list(torch_cuda, tmp_path):
+    """`./test -d 0,0 test.mtx [--combine=…]` takes the multi-device path and still PASSes; `-d 0` is untouched."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tilespmv_amd", "bin", "test_f64")
+    env = dict(os.environ, TILESPMV_WARMUP="2", TILESPMV_BENCH_REPEAT="3", TILESPMV_COMBINE_REPEAT="2")
+    mtx = os.path.join(root, "tests", "golden", "test.mtx")
+    for extra in ([], ["--combine=none"], ["--combine=allgather"]):
+        r = subprocess.run([exe, "-d", "0,0", mtx] + extra, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, (extra, r.stdout, r.stderr)
+        assert "HIP SpMV on 2 device(s)" in r.stdout and "Check... PASS!" in r.stdout
+    r = subprocess.run([exe, "-d", "0,7", mtx], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 3 and "no such HIP device" in r.stderr
+    r = subprocess.run([exe, "-d", "0,0", mtx, "--combine=bogus"], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1
+
+
 def test_cli_same_stdout_lines_and_pass(torch_cuda, tmp_path):
     """`./test -d 0 test.mtx` prints the reference's lines in the reference's order and PASSes."""
     import subprocess

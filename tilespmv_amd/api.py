@@ -86,8 +86,13 @@ def mmio_allinone(filename, dtype=np.float64):
             "val": _take(lib, cv, nnz.value, lib._dtype)}
 
 
-def call_tilespmv_hip(filename, tm, sched, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, x, alpha=1.0):
-    """Host pointers in, y (host) out — the reference's one-shot GPU entry (timing + results.csv included)."""
+Y_SHARDED, Y_ALLGATHER, Y_ALLREDUCE = 0, 1, 2
+
+
+def call_tilespmv_hip(filename, tm, sched, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, x, alpha=1.0,
+                      device_ids=None, y_combine_mode=Y_ALLGATHER):
+    """Host pointers in, y (host) out — the reference's one-shot GPU entry (timing + results.csv included).
+    With ``device_ids`` (a list, ids may repeat) the multi-device form ``call_tilespmv_hip_multi`` runs instead."""
     lib = tm._lib
     rp, ci, v = _csr(lib, csrRowPtrA, csrColIdxA, csrValA)
     x = np.ascontiguousarray(x, dtype=lib._dtype)
@@ -98,9 +103,14 @@ def call_tilespmv_hip(filename, tm, sched, rowA, colA, nnzA, csrRowPtrA, csrColI
     ri = np.ascontiguousarray(sched["blkcoostylerowidx"], dtype=np.uint32) if sched else np.zeros(1, np.uint32)
     c0 = np.ascontiguousarray(sched["blkcoostylerowidx_colstart"], dtype=np.int32) if sched else np.zeros(1, np.int32)
     c1 = np.ascontiguousarray(sched["blkcoostylerowidx_colstop"], dtype=np.int32) if sched else np.zeros(1, np.int32)
-    lib.call_tilespmv_hip(filename.encode(), C.byref(tm), _p(p1, C.c_int), _p(p2, C.c_int), int(sched["rowblkblock"]) if sched else 0,
-                          _p(ri, C.c_uint), _p(c0, C.c_int), _p(c1, C.c_int), rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int),
-                          _p(v, lib._vt), alpha, _p(x, lib._vt), _p(y, lib._vt), _p(yg, lib._vt))
+    args = (filename.encode(), C.byref(tm), _p(p1, C.c_int), _p(p2, C.c_int), int(sched["rowblkblock"]) if sched else 0,
+            _p(ri, C.c_uint), _p(c0, C.c_int), _p(c1, C.c_int), rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int),
+            _p(v, lib._vt), alpha, _p(x, lib._vt), _p(y, lib._vt), _p(yg, lib._vt))
+    if device_ids is None:
+        lib.call_tilespmv_hip(*args)
+    else:
+        ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+        lib.call_tilespmv_hip_multi(*args, len(ids), _p(ids, C.c_int), int(y_combine_mode))
     return y[:rowA].copy()
 
 

@@ -5,6 +5,9 @@
 // name is argv[3] (:58).  Matrix values are replaced by i % 10 and x by i % 10 (:68-69,:93-97)
 // and the last rowA % 16 rows are dropped (:71), exactly like the reference, so that its
 // PASS / NO PASS check (1 % relative, :186-197) means the same thing.
+// Extension that leaves `-d <int>` untouched: `-d 0,1,2,3` shards the matrix by
+// tile-rows over the listed devices (call_tilespmv_hip_multi); an optional 4th argument
+// `--combine=none|allgather|allreduce` (default allgather) says what happens to y afterwards.
 #include <hip/hip_runtime.h>
 #include <sys/time.h>
 
@@ -25,6 +28,22 @@ int main(int argc, char **argv)
     printf("--------------------------------!!!!!!!!------------------------------------\n");
     if (strcmp(argv[1], "-d") != 0) return 0;
     int device_id = argc > 2 ? atoi(argv[2]) : 0;
+    int devices[64], ndev = 0;
+    if (argc > 2 && strchr(argv[2], ','))
+        for (const char *p = argv[2]; *p && ndev < 64;) {
+            devices[ndev++] = atoi(p);
+            p = strchr(p, ',');
+            if (!p) break;
+            p++;
+        }
+    if (ndev > 0) device_id = devices[0];
+    int combine = TILESPMV_Y_ALLGATHER;
+    if (argc > 4) {
+        if (strcmp(argv[4], "--combine=none") == 0) combine = TILESPMV_Y_SHARDED;
+        else if (strcmp(argv[4], "--combine=allgather") == 0) combine = TILESPMV_Y_ALLGATHER;
+        else if (strcmp(argv[4], "--combine=allreduce") == 0) combine = TILESPMV_Y_ALLREDUCE;
+        else { fprintf(stderr, "unknown option %s (expected --combine=none|allgather|allreduce)\n", argv[4]); return 1; }
+    }
     printf("device_id = %i\n", device_id);
     if (argc < 4) { fprintf(stderr, "usage: %s -d <device_id> <matrix.mtx>\n", argv[0]); return 1; }
     char *filename = argv[3];
@@ -72,8 +91,13 @@ int main(int argc, char **argv)
 
     MAT_VAL_TYPE alpha = 1.0;
     memset(y, 0, sizeof(MAT_VAL_TYPE) * rowA);
-    call_tilespmv_hip(filename, matrixA, ptroffset1, ptroffset2, rowblkblock, blkcoostylerowidx, blkcoostylerowidx_colstart,
-                      blkcoostylerowidx_colstop, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, alpha, x, y, y_golden);
+    if (ndev > 0)
+        call_tilespmv_hip_multi(filename, matrixA, ptroffset1, ptroffset2, rowblkblock, blkcoostylerowidx,
+                                blkcoostylerowidx_colstart, blkcoostylerowidx_colstop, rowA, colA, nnzA, csrRowPtrA,
+                                csrColIdxA, csrValA, alpha, x, y, y_golden, ndev, devices, combine);
+    else
+        call_tilespmv_hip(filename, matrixA, ptroffset1, ptroffset2, rowblkblock, blkcoostylerowidx, blkcoostylerowidx_colstart,
+                          blkcoostylerowidx_colstop, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, alpha, x, y, y_golden);
 
     int error_count = 0;
     for (int i = 0; i < rowA; i++)

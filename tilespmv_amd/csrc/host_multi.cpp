@@ -1,0 +1,229 @@
+// host_multi.cpp — single-process multi-device driver (new: the reference is single-GPU,
+// src/main.cu:74).  Tile-rows are independent work items (src/tilespmv_cpu.h:94-118), so the
+// matrix is cut into nnz-balanced blocks of whole tile-rows, one resident plan per device, x
+// replicated; the SpMV itself needs no exchange.  What a caller may want afterwards is y in one
+// piece on every device: either peer copies of each shard's rows over xGMI (all-gather: every
+// link pair carries one shard, all 7 links of a device busy at once), or the BASELINE's "RCCL
+// y-reduce": ncclAllReduce(sum) of full-length vectors that are zero outside the owner's rows.
+// RCCL is loaded with dlopen only for that mode, so the library has no link dependency on it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <sys/time.h>
+
+#include <string>
+#include <vector>
+
+#include "host_util.h"
+
+namespace {
+
+using tilespmv::val_t;
+
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
+[[noreturn]] void die(const char *what, int code)
+{
+    fprintf(stderr, "call_tilespmv_hip_multi: %s failed (%d)\n", what, code);
+    exit(3);
+}
+
+#define CK(call) do { int rc_ = (int)(call); if (rc_) die(#call, rc_); } while (0)
+
+// The five RCCL entry points the all-reduce mode needs (signatures: /opt/rocm/include/rccl/rccl.h).
+struct Rccl {
+    void *h = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    bool load()
+    {
+        for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+        AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce;
+    }
+};
+constexpr int kNcclSum = 0;                                        // ncclSum
+constexpr int kNcclValue = sizeof(val_t) == 8 ? 8 : 7;             // ncclFloat64 : ncclFloat32
+
+struct Shard {
+    int device = 0, tr0 = 0, tr1 = 0;
+    long long row0 = 0, rows = 0;
+    hipStream_t stream = nullptr;
+    tilespmv_plan *plan = nullptr;
+    val_t *d_x = nullptr, *d_y = nullptr;
+};
+
+}  // namespace
+
+extern "C" void call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int *ptroffset1, int *ptroffset2, int rowblkblock,
+                                        unsigned int *blkcoostylerowidx, int *blkcoostylerowidx_colstart,
+                                        int *blkcoostylerowidx_colstop, int rowA, int colA, MAT_PTR_TYPE nnzA,
+                                        MAT_PTR_TYPE *csrRowPtrA, int *csrColIdxA, MAT_VAL_TYPE *csrValA, MAT_VAL_TYPE alpha,
+                                        MAT_VAL_TYPE *x, MAT_VAL_TYPE *y, MAT_VAL_TYPE *y_golden, int ngpus,
+                                        const int *device_ids, int y_combine_mode)
+{
+    (void)ptroffset1; (void)ptroffset2; (void)rowblkblock; (void)blkcoostylerowidx; (void)blkcoostylerowidx_colstart;
+    (void)blkcoostylerowidx_colstop; (void)csrRowPtrA; (void)csrColIdxA; (void)csrValA; (void)alpha; (void)y_golden;
+    if (ngpus < 1 || !device_ids) die("argument check (ngpus >= 1, device_ids != NULL)", ngpus);
+    if (y_combine_mode < TILESPMV_Y_SHARDED || y_combine_mode > TILESPMV_Y_ALLREDUCE) die("argument check (y_combine_mode)", y_combine_mode);
+    const int visible = tilespmv_device_count();
+    for (int g = 0; g < ngpus; g++)
+        if (device_ids[g] < 0 || device_ids[g] >= visible) die("device id check (no such HIP device)", device_ids[g]);
+    int prev_device = 0;
+    CK(hipGetDevice(&prev_device));
+
+    // ---- shards: nnz-balanced whole tile-rows, one plan + stream + x copy + full-length y per device
+    std::vector<int> bounds((size_t)ngpus + 1);
+    tilespmv_partition_tilerows(matrix, ngpus, bounds.data());
+    std::vector<Shard> S((size_t)ngpus);
+    const size_t ybytes = ((size_t)rowA + 16) * sizeof(val_t);
+    for (int g = 0; g < ngpus; g++) {
+        Shard &s = S[g];
+        s.device = device_ids[g]; s.tr0 = bounds[g]; s.tr1 = bounds[g + 1];
+        s.row0 = (long long)s.tr0 * 16;
+        s.rows = std::max<long long>(0, std::min<long long>(rowA, (long long)s.tr1 * 16) - s.row0);
+        CK(hipSetDevice(s.device));
+        CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        tilespmv_plan_options o;
+        memset(&o, 0, sizeof(o));
+        o.tilerow_begin = s.tr0; o.tilerow_end = s.tr1;
+        if (s.tr1 > s.tr0) CK(tilespmv_plan_create(&s.plan, matrix, rowA, colA, nnzA, &o));
+        CK(hipMalloc((void **)&s.d_x, ((size_t)colA + 16) * sizeof(val_t)));
+        CK(hipMalloc((void **)&s.d_y, ybytes));
+        CK(hipMemcpy(s.d_x, x, (size_t)colA * sizeof(val_t), hipMemcpyHostToDevice));
+        CK(hipMemset(s.d_y, 0, ybytes));
+    }
+    // peer access for the gather (a no-op between shards that share a device)
+    if (y_combine_mode == TILESPMV_Y_ALLGATHER)
+        for (int g = 0; g < ngpus; g++)
+            for (int p = 0; p < ngpus; p++) {
+                if (S[g].device == S[p].device) continue;
+                int can = 0;
+                CK(hipDeviceCanAccessPeer(&can, S[g].device, S[p].device));
+                if (!can) continue;  // hipMemcpyPeerAsync then stages through the host
+                CK(hipSetDevice(S[g].device));
+                const hipError_t e = hipDeviceEnablePeerAccess(S[p].device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) die("hipDeviceEnablePeerAccess", (int)e);
+                (void)hipGetLastError();
+            }
+    Rccl rccl;
+    std::vector<void *> comms;
+    if (y_combine_mode == TILESPMV_Y_ALLREDUCE) {
+        if (!rccl.load()) die("dlopen(librccl.so) for the all-reduce y combine", 1);
+        comms.resize((size_t)ngpus);
+        CK(rccl.CommInitAll(comms.data(), ngpus, device_ids));  // refuses duplicate devices
+    }
+
+    auto spmv_all = [&]() {
+        for (Shard &s : S) {
+            if (!s.plan) continue;
+            CK(hipSetDevice(s.device));
+            CK(tilespmv_plan_spmv(s.plan, s.d_x, s.d_y, s.stream));
+        }
+    };
+    auto combine = [&]() {
+        if (y_combine_mode == TILESPMV_Y_ALLGATHER) {
+            for (int g = 0; g < ngpus; g++) {
+                Shard &s = S[g];
+                if (s.rows == 0) continue;
+                CK(hipSetDevice(s.device));
+                for (int k = 1; k < ngpus; k++) {  // rotate the peer order so no device is everyone's first target
+                    Shard &p = S[(g + k) % ngpus];
+                    CK(hipMemcpyPeerAsync(p.d_y + s.row0, p.device, s.d_y + s.row0, s.device, (size_t)s.rows * sizeof(val_t), s.stream));
+                }
+            }
+        } else if (y_combine_mode == TILESPMV_Y_ALLREDUCE) {
+            CK(rccl.GroupStart());
+            for (int g = 0; g < ngpus; g++) {
+                CK(hipSetDevice(S[g].device));
+                CK(rccl.AllReduce(S[g].d_y, S[g].d_y, (size_t)rowA, kNcclValue, kNcclSum, comms[g], S[g].stream));
+            }
+            CK(rccl.GroupEnd());
+        }
+    };
+    // all-reduce needs exact zeros outside the owner's rows on every iteration (in place, the
+    // previous result is there); the gather overwrites foreign rows, so it needs nothing.
+    auto rezero = [&]() {
+        if (y_combine_mode != TILESPMV_Y_ALLREDUCE) return;
+        for (Shard &s : S) {
+            CK(hipSetDevice(s.device));
+            if (s.row0 > 0) CK(hipMemsetAsync(s.d_y, 0, (size_t)s.row0 * sizeof(val_t), s.stream));
+            const long long tail = rowA - (s.row0 + s.rows);
+            if (tail > 0) CK(hipMemsetAsync(s.d_y + s.row0 + s.rows, 0, (size_t)tail * sizeof(val_t), s.stream));
+        }
+    };
+    auto sync_all = [&]() {
+        for (Shard &s : S) { CK(hipSetDevice(s.device)); CK(hipStreamSynchronize(s.stream)); }
+    };
+    auto wall = [&](int reps, bool with_combine) {
+        timeval t1, t2;
+        double ms = 0;
+        for (int i = 0; i < reps; i++) {
+            if (with_combine) { rezero(); sync_all(); }
+            gettimeofday(&t1, NULL);
+            spmv_all();
+            if (with_combine) { sync_all(); combine(); }  // every shard complete before anyone's rows travel
+            sync_all();
+            gettimeofday(&t2, NULL);
+            ms += (t2.tv_sec - t1.tv_sec) * 1000.0 + (t2.tv_usec - t1.tv_usec) / 1000.0;
+        }
+        return ms / reps;
+    };
+
+    const int warm = env_int("TILESPMV_WARMUP", 200), reps = std::max(1, env_int("TILESPMV_BENCH_REPEAT", 1000));
+    for (int i = 0; i < warm; i++) spmv_all();
+    sync_all();
+    const double ms_sharded = wall(reps, false);
+    double ms_combined = ms_sharded;
+    if (y_combine_mode != TILESPMV_Y_SHARDED) {
+        const int creps = std::max(1, std::min(reps, env_int("TILESPMV_COMBINE_REPEAT", 100)));
+        rezero(); spmv_all(); sync_all(); combine(); sync_all();  // warm the copy engines / RCCL channels
+        ms_combined = wall(creps, true);
+    }
+    const double gflops = 2 * (double)nnzA * 1.0e-6 / ms_sharded;
+    printf("  CUDA SpMV runtime %4.2f ms, %4.2f GFlops\n\n", ms_sharded, gflops);
+    static const char *mode_name[] = {"y left sharded", "peer-copy all-gather of y", "RCCL all-reduce of y"};
+    printf("  HIP SpMV on %d device(s): %.4f ms sharded (%.2f GFlops); with %s %.4f ms\n\n", ngpus, ms_sharded, gflops,
+           mode_name[y_combine_mode], ms_combined);
+
+    FILE *fout = fopen("results.csv", "a");
+    if (fout == NULL) printf("Writing results fails.\n");
+    else {
+        fprintf(fout, "%s,%i,%i,%i,%f,%f\n", filename, rowA, colA, nnzA, ms_sharded, gflops);
+        fclose(fout);
+    }
+
+    // ---- result: sharded -> every device hands back its own rows; combined -> the LAST device's
+    // full-length copy (so a broken combine cannot hide behind the owner's rows)
+    if (y_combine_mode == TILESPMV_Y_SHARDED) {
+        for (Shard &s : S) {
+            if (s.rows == 0) continue;
+            CK(hipSetDevice(s.device));
+            CK(hipMemcpy(y + s.row0, s.d_y + s.row0, (size_t)s.rows * sizeof(val_t), hipMemcpyDeviceToHost));
+        }
+    } else {
+        Shard &s = S[(size_t)ngpus - 1];
+        CK(hipSetDevice(s.device));
+        CK(hipMemcpy(y, s.d_y, (size_t)rowA * sizeof(val_t), hipMemcpyDeviceToHost));
+    }
+    for (size_t g = 0; g < comms.size(); g++) (void)rccl.CommDestroy(comms[g]);
+    for (Shard &s : S) {
+        CK(hipSetDevice(s.device));
+        if (s.plan) tilespmv_plan_destroy(s.plan);
+        (void)hipFree(s.d_x); (void)hipFree(s.d_y);
+        (void)hipStreamDestroy(s.stream);
+    }
+    (void)hipSetDevice(prev_device);
+}
