@@ -401,3 +401,46 @@ def test_full_size_properties_laplacian4096(torch_cuda):
     assert np.array_equal(ys[0][rows], seg[rows])
     assert np.array_equal(ys[3], np.add.reduceat(vals, rp[:-1]))     # A * 1 = row sums
     plan.close()
+
+
+def test_halo_spmv_and_cg_one_gpu(torch_cuda):
+    """HaloSpMV on the real HIP plan (world 1): matvec bit-exact, CG reaches the manufactured solution."""
+    import torch
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import generators as G
+    from tilespmv_amd.halo import HaloSpMV, cg
+    m, n, rp, ci = G.laplacian5pt(128)
+    vals, x = G.compat_values(len(ci)), G.compat_x(n)
+    A = HaloSpMV(0, 1, n, rp, ci, vals)
+    y = A.matvec(torch.from_numpy(x).cuda(), A.new_vector())
+    torch.cuda.synchronize()
+    assert np.array_equal(y[:n].cpu().numpy(), CpuImpl("oracle").csr_spmv(n, rp, ci, vals, x))
+    A.close()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    spd = np.where(ci == rows, 4.01, -1.0)
+    A = HaloSpMV(0, 1, n, rp, ci, spd)
+    xs = np.random.default_rng(3).uniform(-1, 1, n)
+    b = A.matvec(torch.from_numpy(xs).cuda(), A.new_vector()).clone()
+    xg, it, rel = cg(A, b, tol=1e-10, maxiter=2000)
+    assert rel <= 1e-10 and it < 2000
+    assert np.linalg.norm(xg[:n].cpu().numpy() - xs) <= 1e-7 * np.linalg.norm(xs)
+    A.close()
+
+
+def test_halo_cg_two_ranks_sharing_the_gpu_over_gloo():
+    """examples/cg_halo.py with two ranks on the one GPU (gloo; RCCL needs a GPU per rank): same iteration count
+    and solution as one rank."""
+    import json, subprocess, sys  # noqa: E401
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = subprocess.run([sys.executable, "examples/cg_halo.py", "--grid", "256"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29577", "examples/cg_halo.py", "--grid", "256", "--backend", "gloo"], cwd=root,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    d2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["ranks"] == 2 and d2["halo_bytes_per_rank"] == 2 * 256 * 8 and d2["row_blocks"] == 2
+    # residual tolerance 1e-8 at a condition number of ~8e3: the error bound is ~1e-4; both runs take the same path
+    assert abs(d1["iterations"] - d2["iterations"]) <= 8 and d1["relative_error"] < 1e-4 and d2["relative_error"] < 1e-4
+    assert d1["relative_residual"] <= 1e-8 and d2["relative_residual"] <= 1e-8
