@@ -239,6 +239,18 @@ int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYP
  * caller's per-call overhead when one SpMV takes tens of microseconds).  Returns a hipError_t value. */
 int tilespmv_plan_spmv_n(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y, void *stream, int count);
 
+/* Multi-vector form (SpMM; new): Y[rows][nvec] = A_shard * X[colA][nvec], X and Y
+ * row-major (the nvec values of one row are contiguous) and 16-byte aligned, nvec in {1, 2, 4, 8}.
+ * The matrix is streamed once for all nvec right-hand sides.  d_Y points at row 0 of the full-length
+ * Y.  Covered: unit-stream plans with in-tile COO and split CSR tiles (the defaults); returns
+ * hipErrorNotSupported (801) for plans built with TILESPMV_COO_FALLBACK, TILESPMV_KERNEL_DIRECT or
+ * TILESPMV_CSR_SPLIT=0, hipErrorInvalidValue (1) for other nvec / misaligned pointers. */
+#define TILESPMV_MAX_NVEC 8
+int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y, int nvec,
+                       void *stream);
+double tilespmv_plan_time_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y,
+                               int nvec, void *stream, int warmup, int reps);
+
 /* Plan facts for reports: index into `out` by TILESPMV_INFO_*. */
 enum {
     TILESPMV_INFO_DEVICE_BYTES = 0,   /* bytes of the resident plan */

@@ -444,3 +444,72 @@ def test_halo_cg_two_ranks_sharing_the_gpu_over_gloo():
     # residual tolerance 1e-8 at a condition number of ~8e3: the error bound is ~1e-4; both runs take the same path
     assert abs(d1["iterations"] - d2["iterations"]) <= 8 and d1["relative_error"] < 1e-4 and d2["relative_error"] < 1e-4
     assert d1["relative_residual"] <= 1e-8 and d2["relative_residual"] <= 1e-8
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("nvec", [2, 4, 8])
+def test_spmm_multi_vector_matches_oracle_per_column(torch_cuda, monkeypatch, nvec, dtype):
+    """tilespmv_plan_spmm (SURVEY S8 f4): Y[:, j] equals the oracle's SpMV of column j, bit-exact on integer data;
+    covers regular strips, strips with > 16 COO entries, dense-row units, split rows and the dense MFMA pass."""
+    import torch
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api
+    O = CpuImpl("oracle", dtype)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    monkeypatch.setenv("TILESPMV_SPLIT_ABOVE", "200")   # so that the small matrices have split rows too
+    cases = [("lap64", {}), ("allfmt", {}), ("allfmt_pad5", {}), ("powerlaw20k", {}), ("circuit8k", {}), ("one_long_row", {}),
+             ("wide_row_tiles", {}), ("empty_rows", {}), ("band4096_40", {"dense_mode": api.DENSE_MFMA}), ("band4096_8", {"dense_mode": api.DENSE_VALU})]
+    for name, kw in cases:
+        m, n, rp, ci = SMALL[name]()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals = values_for(name, nnz, n, dtype)[0]
+        rng = np.random.default_rng(nvec)
+        Xh = rng.integers(0, 4, (n, nvec)).astype(dtype)   # small integers: every partial sum is exact in fp32 too
+        vals = (vals % 4).astype(dtype)
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype)
+        plan = api.Plan(tp, rowA, n, nnz, **kw)
+        Xd = torch.from_numpy(Xh).cuda()
+        Yd = torch.full((rowA + 16, nvec), -5.0, dtype=tdt, device="cuda")
+        plan.spmm(Xd.data_ptr(), Yd.data_ptr(), nvec); plan.spmm(Xd.data_ptr(), Yd.data_ptr(), nvec)
+        torch.cuda.synchronize()
+        Y = Yd.cpu().numpy()
+        for j in range(nvec):
+            want = O.csr_spmv(rowA, rp, ci, vals, np.ascontiguousarray(Xh[:, j]))
+            assert np.array_equal(Y[:rowA, j], want), (name, nvec, j, np.flatnonzero(Y[:rowA, j] != want)[:8])
+        assert (Y[rowA:] == -5.0).all()                    # nothing written past the last row
+        plan.close()
+
+
+def test_spmm_real_values_and_unsupported_plans(torch_cuda):
+    import torch
+    from tilespmv_amd import api
+    import scipy.sparse as sp
+    m, n, rp, ci = MEDIUM["kkt12"]()
+    nnz, rowA = len(ci), truncated_rows(m)
+    rng = np.random.default_rng(5)
+    vals = rng.uniform(-1, 1, nnz); X = rng.uniform(-1, 1, (n, 4))
+    tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
+    plan = api.Plan(tp, rowA, n, nnz)
+    Xd = torch.from_numpy(X).cuda(); Yd = torch.zeros((rowA + 16, 4), dtype=torch.float64, device="cuda")
+    plan.spmm(Xd.data_ptr(), Yd.data_ptr(), 4); torch.cuda.synchronize()
+    A = sp.csr_matrix((vals[:rp[rowA]], ci[:rp[rowA]], rp[:rowA + 1]), shape=(rowA, n))
+    ref = A @ X
+    bound = 1e-12 * (abs(A) @ np.abs(X))                   # |y - y_ref| <= 1e-12 * sum |a_ij x_j|  (SURVEY S8d)
+    assert (np.abs(Yd.cpu().numpy()[:rowA] - ref) <= bound + 1e-300).all()
+    # nvec = 1 is the ordinary SpMV; other counts and misaligned pointers are rejected
+    yd = torch.zeros(rowA + 16, dtype=torch.float64, device="cuda")
+    plan.spmm(Xd[:, 0].contiguous().data_ptr(), yd.data_ptr(), 1); torch.cuda.synchronize()
+    assert (np.abs(yd.cpu().numpy()[:rowA] - ref[:, 0]) <= bound[:, 0] + 1e-300).all()
+    with pytest.raises(RuntimeError):
+        plan.spmm(Xd.data_ptr(), Yd.data_ptr(), 3)
+    with pytest.raises(RuntimeError):
+        plan.spmm(Xd.data_ptr() + 8, Yd.data_ptr(), 2)
+    plan.close()
+    for kw in ({"coo_mode": api.COO_FALLBACK}, {"kernel": api.KERNEL_DIRECT}):
+        m2, n2, rp2, ci2 = SMALL["powerlaw20k"]()
+        v2 = values_for("powerlaw20k", len(ci2), n2, np.float64)[0]
+        t2 = api.Tile_create(truncated_rows(m2), n2, len(ci2), rp2, ci2, v2)
+        p2 = api.Plan(t2, truncated_rows(m2), n2, len(ci2), **kw)
+        with pytest.raises(NotImplementedError):
+            p2.spmm(Xd.data_ptr(), Yd.data_ptr(), 4)
+        p2.close()

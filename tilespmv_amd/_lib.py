@@ -71,6 +71,10 @@ def load(dtype=np.float64):
     lib.call_tilespmv_hip_multi.argtypes = [C.c_char_p, TP, _I, _I, C.c_int, _U, _I, _I, C.c_int, C.c_int, C.c_int, _I, _I, VP,
                                             vt, VP, VP, VP, C.c_int, _I, C.c_int]
     lib.call_tilespmv_hip_multi.restype = None
+    lib.tilespmv_plan_spmm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.tilespmv_plan_spmm.restype = C.c_int
+    lib.tilespmv_plan_time_spmm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    lib.tilespmv_plan_time_spmm.restype = C.c_double
     lib.tilespmv_plan_create.argtypes = [C.POINTER(C.c_void_p), TP, C.c_int, C.c_int, C.c_int, C.POINTER(PlanOptions)]
     lib.tilespmv_plan_create.restype = C.c_int
     lib.tilespmv_plan_destroy.argtypes = [C.c_void_p]
@@ -105,4 +109,4 @@ DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_c
                     "tilespmv_plan_create", "tilespmv_plan_destroy", "tilespmv_plan_spmv", "tilespmv_plan_info",
                     "tilespmv_plan_time", "tilespmv_partition_tilerows", "tilespmv_sizeof_value", "tilespmv_version",
                     "tilespmv_device_count", "tilespmv_matrix_save", "tilespmv_matrix_load", "tilespmv_plan_spmv_n",
-                    "call_tilespmv_hip_multi"]
+                    "call_tilespmv_hip_multi", "tilespmv_plan_spmm", "tilespmv_plan_time_spmm"]

@@ -162,6 +162,20 @@ class Plan:
         if rc != 0:
             raise RuntimeError("tilespmv_plan_spmv_n: HIP error %d" % rc)
 
+    def spmm(self, d_X, d_Y, nvec, stream=0):
+        """Y[rows][nvec] = A X[cols][nvec], row-major device arrays (16-B aligned), nvec in {1, 2, 4, 8}."""
+        rc = self.lib.tilespmv_plan_spmm(self.h, C.c_void_p(d_X), C.c_void_p(d_Y), nvec, C.c_void_p(stream))
+        if rc == 801:
+            raise NotImplementedError("tilespmv_plan_spmm: this plan uses the CSR fallback / whole-tile passes (no multi-vector kernel)")
+        if rc != 0:
+            raise RuntimeError("tilespmv_plan_spmm: HIP error %d" % rc)
+
+    def time_spmm(self, d_X, d_Y, nvec, stream=0, warmup=10, reps=50):
+        ms = self.lib.tilespmv_plan_time_spmm(self.h, C.c_void_p(d_X), C.c_void_p(d_Y), nvec, C.c_void_p(stream), warmup, reps)
+        if ms < 0:
+            raise RuntimeError("tilespmv_plan_time_spmm failed")
+        return ms
+
     def time(self, d_x, d_y, stream=0, warmup=10, reps=50):
         ms = self.lib.tilespmv_plan_time(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream), warmup, reps)
         if ms < 0:

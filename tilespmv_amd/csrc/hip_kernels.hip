@@ -600,6 +600,283 @@ hipError_t launch_dense_mfma(const DevDense &D, int rowA, int colA, val_t *parti
     return hipGetLastError();
 }
 
+// ================================================================================================
+// Multi-vector form (SpMM): Y[rows][NV] = A * X[cols][NV], both row-major, so the NV
+// values of one row of X are one 16/32/64-byte load and the matrix streams (values, descriptors, COO
+// entries, tasks) are read once for NV right-hand sides.  Same plan, same units; per lane NV accumulators.
+// COO entries of a strip are held in registers (first 16) and scattered per tile-row into a 16 x NV LDS
+// slab when that tile-row retires, so the LDS footprint does not grow with the strip's row count.
+// ================================================================================================
+template <int NV>
+struct alignas(NV * sizeof(val_t) >= 16 ? 16 : NV * sizeof(val_t)) MVec { val_t v[NV]; };
+
+// A lane carries NL = min(NV, 2) right-hand sides (16-byte gathers in fp64); Q = NV / NL lane groups of a
+// wavefront work on the SAME strip with different slices of the NV vectors, so a wide NV costs no extra
+// registers, the stores of one Y row (NV values) come from Q lanes of one store instruction, and a
+// wavefront sees the store latency of one strip instead of four (stores retire in order with the loads).
+template <int NVT>
+__global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+                                                  const val_t *__restrict__ X, val_t *__restrict__ Y)
+{
+    constexpr int NV = NVT < 2 ? NVT : 2;   // vectors per lane
+    constexpr int Q = NVT / NV;             // lane groups per strip
+    constexpr int STRIPS = GROUPS_PER_BLOCK / Q;
+    typedef MVec<NV> vec_t;
+    constexpr int UB = 2;
+    __shared__ val_t s_c[GROUPS_PER_BLOCK][16][NV];
+    __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
+    const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned C = (unsigned)xcd_chunk, W = 8u * C, win = bid / W, off = bid % W, k = off & 7u;
+        if (C > 0 && (win + 1) * W <= gridDim.x) bid = win * W + k * C + (off >> 3);
+    }
+    const int q = g % Q;                    // this lane group's slice: vectors q*NV .. q*NV + NV-1
+    const long long task_id = (long long)bid * STRIPS + g / Q;
+    if (task_id >= S.ntasks) return;
+    const int4 t0 = reinterpret_cast<const int4 *>(S.task)[task_id * 2];
+    const int4 t1 = reinterpret_cast<const int4 *>(S.task)[task_id * 2 + 1];
+    const int unit_begin = t0.x, unit_end = t0.y, coo_begin = t0.z, coo_end = t0.w;
+    const int row0 = t1.x, part = t1.y;
+    const unsigned nounit = (unsigned)t1.z;
+    const int ncoo = coo_end - coo_begin;
+    const val_t *__restrict__ uval = S.uval + r;
+    const vec_t *__restrict__ Xv = reinterpret_cast<const vec_t *>(X) + q;   // row i, slice q: Xv[i * Q]
+    vec_t *__restrict__ Yv = reinterpret_cast<vec_t *>(Y) + q;
+    const int last = unit_end - 1;
+    const bool have_units = unit_begin < unit_end;
+    const long long xlast = (long long)colA - 1;
+
+    // first 16 COO entries of the strip: loaded and multiplied up front, scattered when their tile-row retires
+    unsigned rb0 = 0xFFFFFFFFu;
+    vec_t p0;
+#pragma unroll
+    for (int j = 0; j < NV; j++) p0.v[j] = 0;
+    if (r < ncoo) {
+        rb0 = S.crow[coo_begin + r];
+        const int cc = S.ccol[coo_begin + r];
+        const val_t cv = S.cval[coo_begin + r];
+        const vec_t xx = Xv[(long long)cc * Q];
+#pragma unroll
+        for (int j = 0; j < NV; j++) p0.v[j] = cv * xx.v[j];
+    }
+    uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
+    val_t v[UB];
+    if (have_units) {
+        dcur = S.udesc[min(unit_begin + r, last)];
+        dnext = S.udesc[min(unit_begin + DCHUNK + r, last)];
+#pragma unroll
+        for (int k = 0; k < UB; k++) v[k] = uval[(long long)min(unit_begin + k, last) * 16];
+    }
+    if (ncoo > 0) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) s_c[g][r][j] = 0;
+        wave_lds_fence();
+    }
+    val_t acc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) acc[j] = 0;
+
+    // COO contributions of tile-row kr (of the strip) -> acc
+    auto coo_add = [&](int kr) {
+        if (ncoo == 0) return;
+        if ((rb0 >> 4) == (unsigned)kr) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) atomicAdd(&s_c[g][rb0 & 15u][j], p0.v[j]);
+        }
+        for (int e0 = coo_begin + 16; e0 < coo_end; e0 += 16) {  // irregular strips only: rescanned per tile-row
+            if (e0 + r < coo_end) {
+                const unsigned rb = S.crow[e0 + r];
+                if ((rb >> 4) == (unsigned)kr) {
+                    const val_t cv = S.cval[e0 + r];
+                    const vec_t xx = Xv[(long long)S.ccol[e0 + r] * Q];
+#pragma unroll
+                    for (int j = 0; j < NV; j++) atomicAdd(&s_c[g][rb & 15u][j], cv * xx.v[j]);
+                }
+            }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < NV; j++) { acc[j] += s_c[g][r][j]; s_c[g][r][j] = 0; }
+        wave_lds_fence();
+    };
+    auto store_row = [&](int kr) {
+        const long long yi = ((long long)row0 + kr) * 16 + r;
+        if (yi < rowA) {
+            vec_t o;
+#pragma unroll
+            for (int j = 0; j < NV; j++) o.v[j] = acc[j];
+            Yv[yi * Q] = o;
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++) acc[j] = 0;
+    };
+
+    if (have_units) {
+        const uint2 *sd = reinterpret_cast<const uint2 *>(&s_d[g][0]) + (r >> 3);
+        s_d[g][r] = dcur;
+        wave_lds_fence();
+        int chunk_end = unit_begin + DCHUNK;
+        for (int u = unit_begin; u < unit_end; u += UB) {
+            if (u == chunk_end) {
+                wave_lds_fence();
+                s_d[g][r] = dnext;
+                wave_lds_fence();
+                chunk_end += DCHUNK;
+                dnext = S.udesc[min(chunk_end + r, last)];
+            }
+            const int j0 = u - (chunk_end - DCHUNK);
+            uint2 d[UB];
+            vec_t xv[UB];
+#pragma unroll
+            for (int k = 0; k < UB; k++) d[k] = sd[2 * (j0 + k)];
+#pragma unroll
+            for (int k = 0; k < UB; k++) {
+                const unsigned fl = d[k].x >> 24;
+                const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
+                xv[k] = Xv[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast) * Q];
+            }
+            val_t vn[UB];
+#pragma unroll
+            for (int k = 0; k < UB; k++) vn[k] = uval[(long long)min(u + UB + k, last) * 16];
+#pragma unroll
+            for (int k = 0; k < UB; k++) {
+                if (u + k >= unit_end) break;
+                const unsigned fl = d[k].x >> 24;
+                if (fl & UNIT_ROWUNIT) {
+                    const bool target = r == (int)(d[k].y & 15u);
+#pragma unroll
+                    for (int j = 0; j < NV; j++) {
+                        const val_t sum = strip_allreduce(v[k] * xv[k].v[j]);
+                        if (target) acc[j] += sum;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NV; j++) acc[j] += v[k] * xv[k].v[j];
+                }
+                if (fl & UNIT_EOR) {
+                    const int kr = (int)((fl >> UNIT_ROW_SHIFT) & 7u);
+                    coo_add(kr);
+                    store_row(kr);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UB; k++) v[k] = vn[k];
+        }
+    }
+    if (part >= 0) {  // piece of a split tile-row: its partial sums go to the slot, k_fixup_split_mv adds the slots up
+        coo_add(0);
+        vec_t o;
+#pragma unroll
+        for (int j = 0; j < NV; j++) o.v[j] = acc[j];
+        reinterpret_cast<vec_t *>(partial)[((long long)part * 16 + r) * Q + q] = o;
+    } else {
+        unsigned m = nounit;  // tile-rows without any unit: COO contributions only (or zero)
+        while (m) { const int kr = __ffs((int)m) - 1; m &= m - 1; coo_add(kr); store_row(kr); }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_fixup_split_mv(DevPlan P, val_t *__restrict__ Y)
+{
+    const int f_id = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x >> 4), r = threadIdx.x & 15;
+    if (f_id >= P.nfix) return;
+    const FixRow f = P.fix[f_id];
+    val_t sum[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) sum[j] = 0;
+    for (int k = 0; k < f.count; k++)
+#pragma unroll
+        for (int j = 0; j < NV; j++) sum[j] += P.partial[((long long)(f.first + k) * 16 + r) * NV + j];
+    const long long yi = (long long)f.row * 16 + r;
+    if (yi < P.rowA)
+#pragma unroll
+        for (int j = 0; j < NV; j++) Y[yi * NV + j] = sum[j];
+}
+
+// Dense tiles, multi-vector: the B operand finally is a matrix — B[k][n] = X[16 cb + col(k)][n] for the
+// n < NV right-hand sides (zero beyond), D[row][n] accumulates across the tiles of the tile-row as before.
+template <int NV>
+__global__ __launch_bounds__(256) void k_dense_mfma_mv(DevDense D, int rowA, int colA, val_t *__restrict__ partial,
+                                                       const val_t *__restrict__ X, val_t *__restrict__ Y)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= D.nrows) return;
+    const int4 dr = reinterpret_cast<const int4 *>(D.rows)[w];
+    const int row = dr.x, t0 = dr.y, t1 = dr.z, part = dr.w;
+    const int last = t1 - 1, kq = lane >> 4, n = lane & 15;
+    const long long xlast = (long long)colA - 1;
+#if defined(TILESPMV_F32)
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+#else
+    v4d acc = {0., 0., 0., 0.};
+#endif
+    const int cbv = D.cb[min(t0 + lane, last)];
+    for (int t = t0; t < t1; t++) {
+        const int cb = __builtin_amdgcn_readlane(cbv, __builtin_amdgcn_readfirstlane(t - t0));
+        const long long xb = (long long)cb * 16 + 4 * kq;
+        const val_t *tv = D.val + (long long)t * 256 + 64 * kq + n;
+        val_t a[4], b[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) a[s] = tv[16 * s];
+#pragma unroll
+        for (int s = 0; s < 4; s++) b[s] = n < NV ? X[min(xb + s, xlast) * NV + n] : (val_t)0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#if defined(TILESPMV_F32)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+#else
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+#endif
+        }
+    }
+    if (n < NV) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#if defined(TILESPMV_F32)
+            const int rr = 4 * kq + i;
+#else
+            const int rr = kq + 4 * i;
+#endif
+            if (part >= 0) partial[((long long)part * 16 + rr) * NV + n] = acc[i];
+            else {
+                const long long yi = (long long)row * 16 + rr;
+                if (yi < rowA) Y[yi * NV + n] += acc[i];
+            }
+        }
+    }
+}
+
+template <int NV>
+static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int xcd_chunk, const val_t *X, val_t *Y, hipStream_t st)
+{
+    if (S.ntasks > 0)
+    {
+        constexpr int strips = GROUPS_PER_BLOCK / (NV < 2 ? 1 : NV / 2);  // per workgroup (k_units_mv: Q lane groups per strip)
+        hipLaunchKernelGGL((k_units_mv<NV>), dim3((unsigned)((S.ntasks + strips - 1) / strips)), dim3(256), 0, st,
+                           S, P.rowA, P.colA, xcd_chunk, P.partial, X, Y);
+    }
+    if (DN.nrows > 0)
+        hipLaunchKernelGGL((k_dense_mfma_mv<NV>), dim3((DN.nrows + 3) / 4), dim3(256), 0, st, DN, P.rowA, P.colA, P.partial, X, Y);
+    if (P.nfix > 0)
+        hipLaunchKernelGGL((k_fixup_split_mv<NV>), dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, Y);
+    return hipGetLastError();
+}
+
+// nvec in {2, 4, 8}.  The plan must be a unit-stream plan without whole-tile passes and without the CSR
+// fallback (the defaults); the caller checks that (hip_plan.hip).
+hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, const val_t *X, val_t *Y,
+                                  hipStream_t st)
+{
+    switch (nvec) {
+    case 2: return launch_mv<2>(P, S, DN, xcd_chunk, X, Y, st);
+    case 4: return launch_mv<4>(P, S, DN, xcd_chunk, X, Y, st);
+    case 8: return launch_mv<8>(P, S, DN, xcd_chunk, X, Y, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int ub, int xcd_remap, int xcd_chunk, bool nt,
                                const val_t *x, val_t *y, hipStream_t st)
 {

@@ -20,6 +20,8 @@ hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulat
 hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int ub, int xcd_remap, int xcd_chunk, bool nt,
                                const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
+hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, const val_t *X, val_t *Y,
+                                  hipStream_t st);
 int fallback_block_nnz();
 
 #define HIP_TRY(expr)                                                                                   \
@@ -755,7 +757,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     rc |= plan->upload(fix.data(), fix.size(), &D.fix);
     if (npartial > 0) {
         void *p = nullptr;
-        if (hipMalloc(&p, (size_t)npartial * 16 * sizeof(val_t)) != hipSuccess) rc = -3;
+        if (hipMalloc(&p, (size_t)npartial * 16 * sizeof(val_t) * TILESPMV_MAX_NVEC) != hipSuccess) rc = -3;  // slots are nvec wide in tilespmv_plan_spmm
         else { plan->allocs.push_back(p); D.partial = (val_t *)p; }
     }
     if (!f_blk.empty()) {
@@ -793,6 +795,34 @@ int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYP
                                                           : launch_tiles_direct(plan->dev, mfma, false, true, d_x, d_y, st);
     if (e != hipSuccess) return (int)e;
     return (int)launch_fallback(plan->dev, d_x, d_y, st);
+}
+
+int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y, int nvec, void *stream)
+{
+    if (nvec == 1) return tilespmv_plan_spmv(plan, d_X, d_Y, stream);
+    if (nvec != 2 && nvec != 4 && nvec != 8) return (int)hipErrorInvalidValue;
+    if (((uintptr_t)d_X | (uintptr_t)d_Y) & 15u) return (int)hipErrorInvalidValue;  // rows of X / Y travel as 16-B vectors
+    // covered: unit-stream plans whose COO entries run in-tile and whose CSR tiles were split into units
+    // (the defaults).  Whole-tile passes and the CSR fallback have no multi-vector kernel.
+    if (plan->kernel != TILESPMV_KERNEL_STREAM || plan->dev.ntasks > 0 || plan->dev.f_nblk > 0) return (int)hipErrorNotSupported;
+    static const int mv_chunk = env_int("TILESPMV_MV_XCD_CHUNK", -1);
+    return (int)launch_tiles_stream_mv(plan->dev, plan->st, plan->dn, nvec, mv_chunk >= 0 ? mv_chunk : (plan->xcd_remap >= 2 ? plan->xcd_chunk : 0), d_X, d_Y, (hipStream_t)stream);
+}
+
+double tilespmv_plan_time_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y, int nvec, void *stream, int warmup, int reps)
+{
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0;
+    for (int i = 0; i < warmup; i++) if (tilespmv_plan_spmm(plan, d_X, d_Y, nvec, stream)) return -1.0;
+    (void)hipEventRecord(a, st);
+    for (int i = 0; i < reps; i++) if (tilespmv_plan_spmm(plan, d_X, d_Y, nvec, stream)) return -1.0;
+    (void)hipEventRecord(b, st);
+    if (hipEventSynchronize(b) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return reps > 0 ? (double)ms / reps : 0.0;
 }
 
 int tilespmv_plan_spmv_n(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y, void *stream, int count)
