@@ -398,11 +398,12 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
     const long long xlast = (long long)colA - 1;  // row units of a partial last column block: zero payload, clamped x index
 
     // ---- issue order: first COO chunk, descriptor chunk 0 (+1), first value batch: all in flight together.
-    // Strips with more than 16 COO entries (irregular matrices) run their entry list first, 6 x 16 entries per
-    // trip with every load of a trip in flight before its gathers, and only then start the unit pipeline.
+    // Strips with many COO entries (> coo_heavy_min, default 32: irregular matrices) run their entry list first,
+    // 6 x 16 entries per trip with every load of a trip in flight before its gathers, and only then start the
+    // unit pipeline; the others keep the unit prologue in flight across their (short) entry list.
     constexpr int CT = 6;  // sub-chunks of 16 entries per trip
     const int ncoo = coo_end - coo_begin;
-    const bool coo_heavy = ncoo > 16;
+    const bool coo_heavy = ncoo > S.coo_heavy_min;
     if (side) {
         for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
         wave_lds_fence();
@@ -434,8 +435,23 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
 #pragma unroll
         for (int k = 0; k < UB; k++) v[k] = stream_load(uval + (long long)min(unit_begin + k, last) * 16, NT);
     }
-    if (coo0) atomicAdd(&s_y[g][rb0 >> 4][rb0 & 15u], cv0 * x[cc0]);
-    if (side) wave_lds_fence();
+    if (side && !coo_heavy) {  // up to coo_heavy_min entries: 16 with the prologue loads, the rest 4 x 16 per trip
+        if (coo0) atomicAdd(&s_y[g][rb0 >> 4][rb0 & 15u], cv0 * x[cc0]);
+        for (int e0 = coo_begin + 16; e0 < coo_end; e0 += 64) {
+            unsigned rb[4]; int cc[4]; val_t cv[4], xx[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int e = min(e0 + 16 * q + r, coo_end - 1);
+                rb[q] = S.crow[e]; cc[q] = S.ccol[e]; cv[q] = S.cval[e];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) xx[q] = x[cc[q]];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (e0 + 16 * q + r < coo_end) atomicAdd(&s_y[g][rb[q] >> 4][rb[q] & 15u], cv[q] * xx[q]);
+        }
+        wave_lds_fence();
+    }
 
     val_t acc = 0;
     // A finished tile-row parks its 16 results in s_y; y is written once per strip at the end with 16-B

@@ -89,6 +89,7 @@ struct DevStream {
     const unsigned char *crow;
     const STask *task;
     int ntasks;
+    int coo_heavy_min;                    // strips with more COO entries than this run their entry list before the unit pipeline
 };
 
 // Dense tiles on the matrix cores (generation 2): one wavefront per tile-row that owns dense tiles.

@@ -465,6 +465,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     plan->dn.nrows = (int)drows.size();
     free(h_uval); free(h_cval); free(h_hval); free(h_hidx); free(h_dval);
     S.ntasks = (int)tasks.size();
+    S.coo_heavy_min = std::max(0, env_int("TILESPMV_COO_HEAVY_MIN", 32));  // swept on KKT fp64 / scircuit / webbase stand-ins: 32 best or within 1 %
     n_tasks = (long long)tasks.size();
     model_bytes = NU * (16 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
