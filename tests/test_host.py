@@ -164,6 +164,46 @@ def test_mmio_matches_oracle_and_known_answers(tmp_path):
         assert np.array_equal(a["val"], b["val"]) and np.array_equal(a["colidx"], b["colidx"])
 
 
+def test_mmio_parallel_chunks_and_number_formats(tmp_path):
+    """A file big enough for several parser chunks (> 1 MiB each), every number spelling the fast path and its strtod
+    fallback see, CRLF line ends, a symmetric file; a file whose entries span lines (token-stream fallback); an entry
+    outside the declared size.  Same arrays as the oracle's fscanf-style reader, bit for bit."""
+    rng = np.random.default_rng(4)
+    m = n = 5000
+    k = 150000
+    ii, jj = rng.integers(1, m + 1, k), rng.integers(1, n + 1, k)
+    vals = rng.standard_normal(k) * 10.0 ** rng.integers(-40, 40, k)
+    fmts = ["%.17g", "%.6e", "%g", "%.3f", "%.25f", "%.15g", "%+.8E", "%.1f"]
+    big = tmp_path / "big.mtx"
+    with open(big, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% generated\n" + "%d %d %d\n" % (m, n, k))
+        for t in range(k):
+            f.write(("%d %d " + fmts[t % len(fmts)] + ("\r\n" if t % 7 == 0 else "\n")) % (ii[t], jj[t], vals[t]))
+    assert os.path.getsize(big) > 3 * (1 << 20)
+    sym = tmp_path / "sym.mtx"
+    with open(sym, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n" + "%d %d %d\n" % (m, n, k))
+        for t in range(k):
+            f.write("  %d\t%d   %.12e  \n" % (max(ii[t], jj[t]), min(ii[t], jj[t]), vals[t]))
+    span = tmp_path / "span.mtx"
+    with open(span, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n" + "%d %d %d\n" % (m, n, 2000))
+        for t in range(2000):
+            f.write("%d\n%d %.17g " % (ii[t], jj[t], vals[t]))
+    for dtype in (np.float64, np.float32):
+        O = CpuImpl("oracle", dtype)
+        for fpath in (big, sym, span):
+            a, b = O.mmio(str(fpath)), api.mmio_allinone(str(fpath), dtype)
+            assert a["rc"] == b["rc"] == 0 and a["nnz"] == b["nnz"] and a["sym"] == b["sym"], fpath
+            for key in ("rowptr", "colidx", "val"):
+                assert np.array_equal(a[key], b[key]), (fpath, key)
+    bad = tmp_path / "range.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1.0\n4 1 2.0\n")
+    assert api.mmio_allinone(str(bad))["rc"] == -4
+    empty = tmp_path / "empty.mtx"; empty.write_text("")
+    assert api.mmio_allinone(str(empty))["rc"] == -2
+
+
 def test_config1_test_mtx_cpu_path():
     """BASELINE config 1: test.mtx, fp64, CPU path only — loader -> driver value rule -> Tile_create ->
     tilespmv_cpu; pass = errcount 0 and equality with the committed reference dump."""

@@ -3,8 +3,15 @@
 //
 // Same observable result as the reference (return codes; nnz after mirroring; entries in FILE
 // order, each off-diagonal of a symmetric/hermitian file appended to row i and then to row j;
-// columns never sorted) but the file is read once into memory and tokenised by hand instead
-// of one fscanf per entry, so multi-GB inputs (nlpkkt160) load in seconds, not minutes.
+// columns never sorted) but the file is mmap'ed (no second copy of a multi-GB text) and the entry
+// lines are parsed by all host threads in newline-aligned chunks with a hand tokenizer (exact
+// decimal fast path, strtod for everything else), instead of one fscanf per entry.  A file whose
+// entries do not sit one per line (legal for fscanf) takes the sequential token-stream path.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cctype>
 #include <string>
 
@@ -16,21 +23,28 @@ struct Cursor {
     const char *p, *end;
     void skip_ws() { while (p < end && isspace((unsigned char)*p)) p++; }
     bool eof() { skip_ws(); return p >= end; }
+    // bounded (the mapping is not NUL-terminated): strtol / strtod never see the file directly
     bool next_int(long *out)
     {
         skip_ws();
-        if (p >= end) return false;
-        char *q; long v = strtol(p, &q, 10);
-        if (q == p) return false;
-        p = q; *out = v; return true;
+        const char *q = p;
+        bool neg = false;
+        if (q < end && (*q == '-' || *q == '+')) { neg = *q == '-'; q++; }
+        if (q >= end || *q < '0' || *q > '9') return false;
+        long v = 0;
+        while (q < end && *q >= '0' && *q <= '9') { v = v * 10 + (*q - '0'); q++; }
+        p = q; *out = neg ? -v : v; return true;
     }
     bool next_real(double *out)
     {
         skip_ws();
-        if (p >= end) return false;
-        char *q; double v = strtod(p, &q);
-        if (q == p) return false;
-        p = q; *out = v; return true;
+        char tmp[128];
+        size_t len = 0;
+        while (p + len < end && !isspace((unsigned char)p[len]) && len + 1 < sizeof(tmp)) { tmp[len] = p[len]; len++; }
+        tmp[len] = 0;
+        char *q; double v = strtod(tmp, &q);
+        if (q == tmp) return false;
+        p += q - tmp; *out = v; return true;
     }
     std::string line()
     {
@@ -42,6 +56,100 @@ struct Cursor {
     }
 };
 
+// ---- per-line fast parser -------------------------------------------------------------------
+inline bool is_blank(char c) { return c == ' ' || c == '\t' || c == '\r'; }
+
+inline bool fast_int(const char *&p, const char *end, long *out)
+{
+    while (p < end && is_blank(*p)) p++;
+    bool neg = false;
+    if (p < end && (*p == '-' || *p == '+')) { neg = *p == '-'; p++; }
+    if (p >= end || *p < '0' || *p > '9') return false;
+    long v = 0;
+    int nd = 0;
+    while (p < end && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); p++; if (++nd > 18) return false; }
+    if (p < end && !is_blank(*p) && *p != '\n') return false;  // "12.5" or "1e3" where an integer is expected
+    *out = neg ? -v : v;
+    return true;
+}
+
+// Correctly rounded for <= 15 significant digits and |exponent| <= 22 (mantissa and power of ten are
+// both exact doubles, one rounding in the multiply / divide); anything else goes through strtod.
+inline bool fast_real(const char *&p, const char *end, double *out)
+{
+    static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    while (p < end && is_blank(*p)) p++;
+    const char *start = p;
+    bool neg = false;
+    if (p < end && (*p == '-' || *p == '+')) { neg = *p == '-'; p++; }
+    unsigned long long mant = 0;
+    int nd = 0, frac = 0, any = 0;
+    while (p < end && *p >= '0' && *p <= '9') { if (mant || *p != '0') { mant = mant * 10 + (unsigned)(*p - '0'); nd++; } any = 1; p++; if (nd > 15) break; }
+    if (nd <= 15 && p < end && *p == '.') {
+        p++;
+        while (p < end && *p >= '0' && *p <= '9') { if (mant || *p != '0') { mant = mant * 10 + (unsigned)(*p - '0'); nd++; } frac++; any = 1; p++; if (nd > 15) break; }
+    }
+    int e10 = 0;
+    bool ok = any && nd <= 15;
+    if (ok && p < end && (*p == 'e' || *p == 'E' || *p == 'd' || *p == 'D')) {
+        if (*p == 'd' || *p == 'D') ok = false;  // Fortran exponents: let strtod decide exactly like the reference's scanf
+        else {
+            p++;
+            bool eneg = false;
+            if (p < end && (*p == '-' || *p == '+')) { eneg = *p == '-'; p++; }
+            int ed = 0;
+            if (p >= end || *p < '0' || *p > '9') ok = false;
+            while (ok && p < end && *p >= '0' && *p <= '9') { e10 = e10 * 10 + (*p - '0'); p++; if (++ed > 4) ok = false; }
+            if (eneg) e10 = -e10;
+        }
+    }
+    if (ok && p < end && !is_blank(*p) && *p != '\n') ok = false;
+    e10 -= frac;
+    if (ok && e10 >= -22 && e10 <= 22) {
+        double v = (double)mant;
+        v = e10 < 0 ? v / p10[-e10] : v * p10[e10];
+        *out = neg ? -v : v;
+        return true;
+    }
+    // slow path: the token as strtod sees it (the buffer ends with a newline or NUL, so it cannot run away)
+    char tmp[128];
+    size_t len = 0;
+    const char *q = start;
+    while (q < end && !is_blank(*q) && *q != '\n' && len + 1 < sizeof(tmp)) tmp[len++] = *q++;
+    tmp[len] = 0;
+    char *stop;
+    const double v = strtod(tmp, &stop);
+    if (stop == tmp) return false;
+    p = start + (stop - tmp);
+    if (p < end && !is_blank(*p) && *p != '\n') return false;
+    *out = v;
+    return true;
+}
+
+struct ChunkOut { std::vector<int> r, c; std::vector<tilespmv::val_t> v; bool ok = true; long bad_a = 0, bad_b = 0; bool range_error = false; };
+
+// Parses whole lines of [p, end): one entry per non-blank, non-comment line.
+void parse_chunk(const char *p, const char *end, int kind, long M, long N, ChunkOut &o)
+{
+    while (p < end) {
+        while (p < end && is_blank(*p)) p++;
+        if (p >= end) break;
+        if (*p == '\n') { p++; continue; }
+        if (*p == '%') { while (p < end && *p != '\n') p++; continue; }
+        long a, b, iv = 0;
+        double v = 1.0, im = 0.0;
+        bool ok = fast_int(p, end, &a) && fast_int(p, end, &b);
+        if (ok && kind == 0) ok = fast_real(p, end, &v);
+        else if (ok && kind == 1) ok = fast_real(p, end, &v) && fast_real(p, end, &im);
+        else if (ok && kind == 2) { ok = fast_int(p, end, &iv); v = (double)iv; }
+        while (ok && p < end && is_blank(*p)) p++;
+        if (!ok || (p < end && *p != '\n')) { o.ok = false; return; }  // not "one entry per line": caller falls back
+        a--; b--;
+        if (a < 0 || a >= M || b < 0 || b >= N) { o.range_error = true; o.bad_a = a + 1; o.bad_b = b + 1; return; }
+        o.r.push_back((int)a); o.c.push_back((int)b); o.v.push_back((tilespmv::val_t)v);
+    }
+}
+
 std::string lower(std::string s) { for (auto &c : s) c = (char)tolower((unsigned char)c); return s; }
 
 }  // namespace
@@ -50,16 +158,18 @@ extern "C" int mmio_allinone(int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric
                              int **csrColIdx, MAT_VAL_TYPE **csrVal, char *filename)
 {
     using namespace tilespmv;
-    FILE *f = fopen(filename, "rb");
-    if (!f) return -1;
-    fseek(f, 0, SEEK_END);
-    long fsize = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    std::vector<char> buf((size_t)fsize + 1);
-    size_t got = fread(buf.data(), 1, (size_t)fsize, f);
-    fclose(f);
-    buf[got] = '\0';
-    Cursor c{buf.data(), buf.data() + got};
+    const int fd = open(filename, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size <= 0) { close(fd); return sb.st_size == 0 ? -2 : -1; }
+    const size_t got = (size_t)sb.st_size;
+    void *map = mmap(nullptr, got, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return -1;
+    (void)madvise(map, got, MADV_SEQUENTIAL);
+    struct Unmap { void *p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, got};
+    const char *text = (const char *)map;
+    Cursor c{text, text + got};
 
     // banner: "%%MatrixMarket matrix coordinate <field> <symmetry>", fields 2..5 case-insensitive
     char t0[65] = "", t1[65] = "", t2[65] = "", t3[65] = "", t4[65] = "";
@@ -89,11 +199,66 @@ extern "C" int mmio_allinone(int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric
         if (!c.next_int(&M) || !c.next_int(&N) || !c.next_int(&NZ)) return -4;
     }
 
-    std::vector<int> ri((size_t)NZ), ci((size_t)NZ);
-    std::vector<val_t> vv((size_t)NZ);
+    struct Free { void *p; ~Free() { free(p); } };
+    int *ri = (int *)malloc(sizeof(int) * (size_t)std::max(NZ, 1L)), *ci = (int *)malloc(sizeof(int) * (size_t)std::max(NZ, 1L));
+    val_t *vv = (val_t *)malloc(sizeof(val_t) * (size_t)std::max(NZ, 1L));
+    Free free_ri{ri}, free_ci{ci}, free_vv{vv};
+    if (!ri || !ci || !vv) { fprintf(stderr, "mmio_allinone: out of host memory for %ld entries\n", NZ); return -4; }
     int *count = zalloc<int>((size_t)M + 1);
     const int kind = field == "real" ? 0 : field == "complex" ? 1 : field == "integer" ? 2 : 3;
-    for (long i = 0; i < NZ; i++) {
+
+    // ---- fast path: newline-aligned chunks parsed by all host threads, one entry per line
+    bool parsed = false;
+    {
+        const char *body = c.p, *end = c.end;
+        const size_t bytes = (size_t)(end - body);
+        const int nchunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads() * 4, bytes / (1u << 20)));
+        std::vector<const char *> cut((size_t)nchunk + 1);
+        cut[0] = body; cut[(size_t)nchunk] = end;
+        for (int k = 1; k < nchunk; k++) {
+            const char *q = body + bytes / (size_t)nchunk * (size_t)k;
+            if (q < cut[(size_t)k - 1]) q = cut[(size_t)k - 1];
+            while (q < end && *q != '\n') q++;
+            cut[(size_t)k] = q < end ? q + 1 : end;
+        }
+        std::vector<ChunkOut> outs((size_t)nchunk);
+        parallel_chunks(nchunk, 1, [&](int64_t b0, int64_t b1, int) {
+            for (int64_t k = b0; k < b1; k++) {
+                outs[(size_t)k].r.reserve((size_t)(cut[(size_t)k + 1] - cut[(size_t)k]) / 12);
+                parse_chunk(cut[(size_t)k], cut[(size_t)k + 1], kind, M, N, outs[(size_t)k]);
+            }
+        });
+        bool ok = true;
+        size_t total_entries = 0;
+        for (auto &o : outs) {
+            if (o.range_error) {
+                fprintf(stderr, "mmio_allinone: entry (%ld,%ld) outside %ld x %ld in %s\n", o.bad_a, o.bad_b, M, N, filename);
+                free(count);
+                return -4;
+            }
+            ok = ok && o.ok;
+            total_entries += o.r.size();
+        }
+        if (ok && total_entries >= (size_t)NZ) {  // extra lines beyond the declared count are ignored, like the reference's loop
+            std::vector<size_t> at((size_t)nchunk + 1, 0);
+            for (int k = 0; k < nchunk; k++) at[(size_t)k + 1] = std::min((size_t)NZ, at[(size_t)k] + outs[(size_t)k].r.size());
+            parallel_chunks(nchunk, 1, [&](int64_t b0, int64_t b1, int) {
+                for (int64_t k = b0; k < b1; k++) {
+                    ChunkOut &o = outs[(size_t)k];
+                    const size_t take = at[(size_t)k + 1] - at[(size_t)k];
+                    if (take) {
+                        memcpy(ri + at[(size_t)k], o.r.data(), take * sizeof(int));
+                        memcpy(ci + at[(size_t)k], o.c.data(), take * sizeof(int));
+                        memcpy(vv + at[(size_t)k], o.v.data(), take * sizeof(val_t));
+                    }
+                    std::vector<int>().swap(o.r); std::vector<int>().swap(o.c); std::vector<val_t>().swap(o.v);
+                }
+            });
+            for (long i = 0; i < NZ; i++) count[ri[(size_t)i]]++;
+            parsed = true;
+        }
+    }
+    for (long i = 0; !parsed && i < NZ; i++) {
         long a = 0, b = 0, iv = 0; double v = 1.0, im = 0.0;
         if (!c.next_int(&a) || !c.next_int(&b)) { a = b = 0; }
         if (kind == 0) c.next_real(&v);
