@@ -11,7 +11,7 @@ Workloads (synthetic stand-ins unless $TILESPMV_MATRIX_DIR/<name>.mtx exists; SU
   laplacian4096  5-pt Laplacian on a 4096^2 grid, 16.7 M rows, 83.9 M nnz  (config 4; default —
                  the >= 10 M-nnz fp64 case the roofline target is quoted on, fits one GPU)
   scircuit       circuit-like, 171 k rows, ~1 M nnz (config 2)       webbase   power-law 1 M rows (config 3)
-  nlpkkt160      KKT-like, 8.2 M rows, ~2.2e8 nnz, fp32 by default (config 5)
+  nlpkkt160      KKT-like, 8.2 M rows, 1.66e8 nnz, fp32 by default (config 5)
 Multi-GPU: contiguous nnz-balanced tile-row blocks, one rank per GPU, x replicated, y left
 sharded (the SpMV needs no collective: SURVEY.md §8e) => "scaling": "strong" on the fixed matrix;
 --combine allgather|allreduce adds the RCCL y combine to every step, and the default run also
@@ -242,35 +242,46 @@ def main():
     }
     if extra:
         out["with_y_combine"] = extra
-    # the two cache-resident BASELINE configs (stand-ins), reported beside the headline; never `value`
+    # the other BASELINE configs (stand-ins) at one GPU, reported beside the headline; never `value`:
+    # configs 2-3 are cache-resident (launch/latency-bound), config 5 is the fp32 HBM-roofline case
     if rank == 0 and world == 1 and args.workload == "laplacian4096" and not args.no_extras:
+        sh.close()  # the headline plan is done: give its 1 GB back before the other matrices are measured
+        del xd, yd
+        torch.cuda.empty_cache()
         out["other_workloads"] = {}
-        for wl in ("scircuit", "webbase"):
+        for wl, dt2 in (("scircuit", dtype), ("webbase", dtype), ("nlpkkt160", np.dtype(np.float32))):
             try:
                 from tilespmv_amd.tile_matrix import field_array
+                import scipy.sparse as sp
+                small = wl != "nlpkkt160"
+                td2 = torch.float64 if dt2 == np.float64 else torch.float32
                 m2, n2, rp2, ci2, src2 = build_matrix(wl)
                 r2 = (m2 // 16) * 16; nz2 = int(rp2[r2])
-                v2, x2 = G.compat_values(len(ci2), dtype), G.compat_x(n2, dtype)
+                v2, x2 = G.compat_values(len(ci2), dt2), G.compat_x(n2, dt2)
                 # config 2 must exercise all seven tile formats: HYB is only reachable with the opt-in rule
-                tm2 = api.Tile_create(r2, n2, nz2, rp2, ci2, v2, dtype=dtype, hyb=(wl == "scircuit"))
+                tm2 = api.Tile_create(r2, n2, nz2, rp2, ci2, v2, dtype=dt2, hyb=(wl == "scircuit"))
                 hist = np.bincount(field_array(tm2, "Format", tm2.tilenum), minlength=7).tolist()
-                import scipy.sparse as sp
-                ref2 = sp.csr_matrix((v2[:nz2].astype(np.float64), ci2[:nz2], rp2[:r2 + 1]), shape=(r2, n2)) @ x2.astype(np.float64)
-                b2 = api.algorithmic_bytes(nz2, r2, n2, dtype.itemsize)
-                rec = {"source": src2, "rows": r2, "nnz": nz2, "tile_format_histogram[csr,coo,ell,hyb,dns,dnsrow,dnscol]": hist,
-                       "note": "cache-resident: launch/latency-bound, roofline time %.1f us" % (b2 / 8e12 * 1e6)}
+                ref2 = sp.csr_matrix((v2[:nz2], ci2[:nz2], rp2[:r2 + 1]), shape=(r2, n2)).astype(np.float64) @ x2.astype(np.float64)
+                b2 = api.algorithmic_bytes(nz2, r2, n2, dt2.itemsize)
+                rec = {"source": src2, "dtype": "f64" if dt2 == np.float64 else "f32", "rows": r2, "nnz": nz2,
+                       "tile_format_histogram[csr,coo,ell,hyb,dns,dnsrow,dnscol]": hist,
+                       "note": ("cache-resident: launch/latency-bound, roofline time %.1f us" % (b2 / 8e12 * 1e6)) if small
+                               else "HBM-bound; integer-valued data, checked exactly against scipy CSR"}
                 xd2 = torch.from_numpy(x2).cuda()
-                for label, coo in (("coo_in_tile", api.COO_IN_TILE), ("coo_csr_fallback", api.COO_FALLBACK)):
+                modes = (("coo_in_tile", api.COO_IN_TILE), ("coo_csr_fallback", api.COO_FALLBACK)) if small else (("default_plan", api.COO_AUTO),)
+                for label, coo in modes:
                     p2 = api.Plan(tm2, r2, n2, nz2, coo_mode=coo)
-                    yd2 = torch.zeros(r2 + 16, dtype=tdtype, device="cuda")
-                    ms2 = p2.time(xd2.data_ptr(), yd2.data_ptr(), stream.cuda_stream, warmup=20, reps=200)
+                    yd2 = torch.zeros(r2 + 16, dtype=td2, device="cuda")
+                    ms2 = p2.time(xd2.data_ptr(), yd2.data_ptr(), stream.cuda_stream, warmup=20, reps=200 if small else 50)
                     ok2 = bool(np.array_equal(yd2.cpu().numpy()[:r2].astype(np.float64), ref2))
                     rec[label] = {"ms_per_spmv": round(ms2, 5), "gflops": round(2.0 * nz2 / ms2 * 1e-6, 1),
-                                  "hbm_gbps_algorithmic": round(b2 / ms2 * 1e-6, 1), "check": "pass" if ok2 else "FAIL",
-                                  "fallback_nnz": p2.info()["fallback_nnz"]}
+                                  "hbm_gbps_algorithmic": round(b2 / ms2 * 1e-6, 1), "frac_of_8TBps": round(b2 / ms2 * 1e-6 / HBM_PEAK_GBPS, 4),
+                                  "check": "pass" if ok2 else "FAIL", "fallback_nnz": p2.info()["fallback_nnz"]}
                     p2.close()
+                    del yd2
                 out["other_workloads"][wl] = rec
                 api.Tile_destroy(tm2)
+                del m2, n2, rp2, ci2, v2, x2, ref2, xd2
             except Exception as e:  # never let an extra break the headline line
                 out["other_workloads"][wl] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

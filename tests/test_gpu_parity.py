@@ -403,6 +403,35 @@ def test_full_size_properties_laplacian4096(torch_cuda):
     plan.close()
 
 
+def test_full_size_properties_kkt160_f32(torch_cuda):
+    """BASELINE config 5 stand-in at full size (8.2 M rows, 1.66e8 nnz, fp32): the whole y against the CSR golden
+    (integer data, every partial sum exact in fp32), linearity, and the 4-vector SpMM against four SpMVs."""
+    import torch
+    from tilespmv_amd import api, generators as G
+    m, n, rp, ci = G.kkt_like(160)
+    nnz = len(ci)
+    vals = G.compat_values(nnz, np.float32)
+    tp = api.Tile_create(m, n, nnz, rp, ci, vals, dtype=np.float32)
+    plan = api.Plan(tp, m, n, nnz)
+    rng = np.random.default_rng(1)
+    X = rng.integers(0, 4, (n, 4)).astype(np.float32)
+    X[:, 2] = X[:, 0] + X[:, 1]
+    ys = []
+    for j in range(4):
+        xd = torch.from_numpy(np.ascontiguousarray(X[:, j])).cuda(); yd = torch.zeros(m + 16, dtype=torch.float32, device="cuda")
+        plan.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize()
+        ys.append(yd.cpu().numpy()[:m])
+    seg = np.add.reduceat(vals.astype(np.float64) * X[ci, 0].astype(np.float64), rp[:-1])   # every row has entries
+    assert (np.diff(rp) > 0).all() and np.array_equal(ys[0].astype(np.float64), seg)
+    assert np.array_equal(ys[0] + ys[1], ys[2])                                              # linearity, exact
+    Xd = torch.from_numpy(X).cuda(); Yd = torch.zeros((m + 16, 4), dtype=torch.float32, device="cuda")
+    plan.spmm(Xd.data_ptr(), Yd.data_ptr(), 4); torch.cuda.synchronize()
+    Y = Yd.cpu().numpy()[:m]
+    for j in range(4):
+        assert np.array_equal(Y[:, j], ys[j]), j
+    plan.close()
+
+
 def test_halo_spmv_and_cg_one_gpu(torch_cuda):
     """HaloSpMV on the real HIP plan (world 1): matvec bit-exact, CG reaches the manufactured solution."""
     import torch
