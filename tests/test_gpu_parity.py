@@ -542,3 +542,12 @@ def test_spmm_real_values_and_unsupported_plans(torch_cuda):
         with pytest.raises(NotImplementedError):
             p2.spmm(Xd.data_ptr(), Yd.data_ptr(), 4)
         p2.close()
+
+
+def test_randomised_structures_short_fuzz(torch_cuda):
+    """A short run of tests/gpu_fuzz.py (random mixes of every tile format, bands, long rows, odd column counts, tiny
+    strip / split thresholds): Tile_matrix == oracle field by field, SpMV in every mode and SpMM 2/4/8 bit-exact."""
+    import gpu_fuzz
+    for seed in range(3000, 3016):
+        bad, shape = gpu_fuzz.check(seed)
+        assert bad == 0, (seed, shape)
