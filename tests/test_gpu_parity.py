@@ -551,3 +551,39 @@ def test_randomised_structures_short_fuzz(torch_cuda):
     for seed in range(3000, 3016):
         bad, shape = gpu_fuzz.check(seed)
         assert bad == 0, (seed, shape)
+
+
+def test_inline_fixup_of_split_rows_is_stable_across_launches(torch_cuda, monkeypatch):
+    """Split tile-rows are summed inside k_units by the piece that finishes last (agent-scope slot stores, a counter,
+    fixed slot order).  Rows with many pieces spread over workgroups on different XCDs, 300 launches each, result
+    checked after every launch; plus the separate-kernel fix-up (TILESPMV_FIX_INLINE=0) for equality."""
+    import torch
+    import scipy.sparse as sp
+    from tilespmv_amd import api, generators as G
+    rng = np.random.default_rng(0)
+    rows, cols = 64, 120000
+    R, C = [], []
+    for r in (3, 17, 40, 41):
+        k = int(rng.integers(30000, 100000)); R.append(np.full(k, r)); C.append(rng.choice(cols, k, replace=False))
+    for r in range(rows):
+        k = int(rng.integers(0, 40)); R.append(np.full(k, r)); C.append(rng.choice(cols, k, replace=False))
+    r = np.concatenate(R); c = np.concatenate(C)
+    key = np.unique(r.astype(np.int64) * cols + c)
+    m, n, rp, ci = G.from_coo(rows, cols, key // cols, key % cols)
+    nnz = len(ci)
+    vals = rng.integers(1, 4, nnz).astype(np.float64); x = rng.integers(0, 4, n).astype(np.float64)
+    want = torch.from_numpy(sp.csr_matrix((vals, ci, rp), shape=(m, n)) @ x).cuda()
+    tm = api.Tile_create(m, n, nnz, rp, ci, vals)
+    xd = torch.from_numpy(x).cuda()
+    for env in ({}, {"TILESPMV_XCD_REMAP": "0", "TILESPMV_SPLIT_ABOVE": "300", "TILESPMV_STRIP_COST": "48"}, {"TILESPMV_FIX_INLINE": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p = api.Plan(tm, m, n, nnz)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert p.info()["num_split_rows"] >= 3
+        yd = torch.zeros(m + 16, dtype=torch.float64, device="cuda")
+        for it in range(300):
+            p.spmv(xd.data_ptr(), yd.data_ptr()); p.spmv(xd.data_ptr(), yd.data_ptr())
+            assert torch.equal(yd[:m], want), (env, it)
+        p.close()

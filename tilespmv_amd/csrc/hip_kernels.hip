@@ -508,7 +508,30 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
     if (part >= 0) {
         val_t out = acc;
         if (side) out += s_y[g][0][r];
-        partial[(long long)part * 16 + r] = out;
+        if (S.ifix_count == nullptr || nounit == 0xFFFFFFFFu) {
+            partial[(long long)part * 16 + r] = out;  // k_fixup_split adds the slots up after all passes
+        } else {
+            // All pieces of this tile-row run in this kernel: the piece that finishes last adds the slots up, in slot
+            // order (same sum as k_fixup_split).  Slots and counter are agent-scope atomics (performed at the device's
+            // point of coherence, past the per-XCD L2s), the counter is bumped only after this strip's 16 slot stores
+            // have been acknowledged, and the slot loads are issued only after the counter value has come back.
+            __hip_atomic_store(&partial[(long long)part * 16 + r], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const FixRow f = S.ifix[nounit];
+            unsigned prev = 0;
+            if (r == 0) prev = __hip_atomic_fetch_add(&S.ifix_count[nounit], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev = (unsigned)__shfl((int)prev, tid & 48, 64);  // lane 0 of this strip
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (prev == (unsigned)f.count - 1u) {
+                val_t sum = 0;
+                for (int k = 0; k < f.count; k++)
+                    sum += __hip_atomic_load(&partial[(long long)(f.first + k) * 16 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long yi = (long long)f.row * 16 + r;
+                if (yi < rowA) y[yi] = sum;
+                if (r == 0) __hip_atomic_store(&S.ifix_count[nounit], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            }
+        }
     } else {
         if (!side) {  // rows without any unit and no COO contribution are zero
             unsigned m = nounit;
@@ -911,8 +934,11 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
     if (e != hipSuccess) return e;
     e = launch_dense_mfma(DN, P.rowA, P.colA, P.partial, x, y, st);
     if (e != hipSuccess) return e;
-    if (P.nfix > 0)
-        hipLaunchKernelGGL(k_fixup_split, dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, y);
+    if (P.nfix_late > 0) {  // split rows with pieces outside k_units (whole-tile / matrix-core passes)
+        DevPlan Q = P;
+        Q.fix = P.fix_late; Q.nfix = P.nfix_late;
+        hipLaunchKernelGGL(k_fixup_split, dim3((Q.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, Q, y);
+    }
     return hipGetLastError();
 }
 

@@ -44,8 +44,10 @@ struct DevPlan {
     int ntasks;
     int rowA, colA;
     val_t *partial;
-    const FixRow *fix;
+    const FixRow *fix;      // every split tile-row (first-generation kernel, multi-vector path)
     int nfix;
+    const FixRow *fix_late; // split tile-rows with pieces outside the unit kernel: summed by k_fixup_split after all passes
+    int nfix_late;
     // very-sparse CSR fallback (extracted matrix of the shard's rows)
     const int *f_ptr;       // deferredcoo_ptr restricted to the shard, rebased to 0
     const int *f_col;
@@ -77,7 +79,8 @@ struct STask {                            // 32 bytes
     int coo_begin, coo_end;
     int row;                              // first tile-row of the strip (global numbering)
     int partial;                          // -1 or slot in partial[]
-    unsigned nounit_mask;                 // bit k: tile-row k of the strip has no unit (flushed at the end)
+    unsigned nounit_mask;                 // bit k: tile-row k of the strip has no unit (flushed at the end);
+                                          //   pieces (partial >= 0): index into DevStream::ifix, or 0xFFFFFFFF
     int nrows;
 };
 
@@ -90,6 +93,10 @@ struct DevStream {
     const STask *task;
     int ntasks;
     int coo_heavy_min;                    // strips with more COO entries than this run their entry list before the unit pipeline
+    // split tile-rows whose pieces all live in the unit kernel are summed in that kernel by the piece that
+    // finishes last (fixed slot order): ifix[i] describes row i, ifix_count[i] counts finished pieces
+    const FixRow *ifix;
+    unsigned *ifix_count;
 };
 
 // Dense tiles on the matrix cores (generation 2): one wavefront per tile-row that owns dense tiles.

@@ -191,7 +191,7 @@ inline int csr_split_width(const unsigned char *ptr, int rowlen, int nnz, int *r
 
 inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, bool csr_split)
 {
-    const int coo_cost = env_int("TILESPMV_COO_COST", 3);
+    const int coo_cost = env_int("TILESPMV_COO_COST", 4);
     RowCount c{0, 0, 0, 0, 0, 0, 0};
     for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
         const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
@@ -245,6 +245,8 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     // kinds of pieces write partial[] slots that k_fixup_split adds up in a fixed order).
     std::vector<STask> tasks;
     std::vector<Task> htasks;
+    std::vector<FixRow> ifix, fix_late;   // split rows summed inside the unit kernel / by k_fixup_split after all passes
+    const bool fix_inline_on = env_int("TILESPMV_FIX_INLINE", 1) != 0;
     std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
     auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
     auto is_heavy = [&](int t) {
@@ -259,7 +261,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         if (rc_[i].cost > split_above) {
             row_split[i] = 1;
             FixRow f{tr0 + i, npartial, 0, 0};
-            const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, env_int("TILESPMV_COO_PIECE", piece / std::max(1, env_int("TILESPMV_COO_COST", 3))));
+            const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, env_int("TILESPMV_COO_PIECE", piece / std::max(1, env_int("TILESPMV_COO_COST", 4))));
             for (long long u = pu[i]; u < pu[i + 1]; u += pu_) {
                 STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
                 k.unit_begin = (int)u; k.unit_end = (int)std::min(pu[i + 1], u + pu_);
@@ -270,6 +272,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
                 k.coo_begin = (int)c; k.coo_end = (int)std::min(pc[i + 1], c + pc_);
                 tasks.push_back(k); f.count++;
             }
+            const int stream_pieces = f.count;  // pieces executed by the unit kernel
             long long h = ph[i], hv = phv[i], hi = phi[i];
             int t = T->tile_ptr[tr0 + i];
             while (h < ph[i + 1]) {  // heavy tiles of a split row: cut at tile boundaries by payload size
@@ -287,6 +290,10 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
                 drows.push_back(DenseRow{tr0 + i, (int)dq, (int)std::min(pd[i + 1], dq + 32), npartial++});
                 f.count++;
             }
+            // all pieces inside the unit kernel -> the last one to finish adds the slots up there
+            const bool inline_fix = fix_inline_on && f.count == stream_pieces;
+            for (int q = 0; q < stream_pieces; q++) tasks[tasks.size() - 1 - (size_t)q].nounit_mask = inline_fix ? (unsigned)ifix.size() : 0xFFFFFFFFu;
+            if (inline_fix) ifix.push_back(f); else fix_late.push_back(f);
             fix.push_back(f);
             i++;
             continue;
@@ -465,6 +472,16 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     plan->dn.nrows = (int)drows.size();
     free(h_uval); free(h_cval); free(h_hval); free(h_hidx); free(h_dval);
     S.ntasks = (int)tasks.size();
+    S.ifix = nullptr; S.ifix_count = nullptr;
+    if (!ifix.empty()) {
+        rc |= plan->upload(ifix.data(), ifix.size(), &S.ifix);
+        std::vector<unsigned> zeros(ifix.size(), 0u);
+        const unsigned *cnt = nullptr;
+        rc |= plan->upload(zeros.data(), zeros.size(), &cnt);
+        S.ifix_count = const_cast<unsigned *>(cnt);
+    }
+    rc |= plan->upload(fix_late.data(), fix_late.size(), &plan->dev.fix_late);
+    plan->dev.nfix_late = (int)fix_late.size();
     S.coo_heavy_min = std::max(0, env_int("TILESPMV_COO_HEAVY_MIN", 32));  // swept on KKT fp64 / scircuit / webbase stand-ins: 32 best or within 1 %
     n_tasks = (long long)tasks.size();
     model_bytes = NU * (16 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
