@@ -231,7 +231,9 @@ void tilespmv_plan_destroy(tilespmv_plan *plan);
 
 /* y[16*tilerow_begin .. 16*tilerow_end) = A_shard * x.  d_x has colA elements, d_y points at
  * element 0 of the FULL-length y (the shard writes only its own rows).  Asynchronous on
- * `stream`.  Returns a hipError_t value (0 = success). */
+ * `stream`, no allocation or synchronisation inside (safe to capture into a hipGraph).  One plan
+ * must not execute on two streams at the same time: split tile-rows use per-plan scratch slots
+ * and counters.  Returns a hipError_t value (0 = success). */
 int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y,
                        void *stream);
 
