@@ -226,6 +226,13 @@ def main():
         for mode in ("allgather", "allreduce"):
             w2, _ = timed(mode, max(5, args.steps // 10), 3)
             extra[mode] = {"ms_per_step": round(w2 * 1e3 / max(5, args.steps // 10), 5), "gflops": round(flops / (w2 / max(5, args.steps // 10)) * 1e-9, 2)}
+            if not args.no_check:  # after the combine every rank holds the whole y: sampled rows of ALL shards, exact
+                ra = np.unique(np.random.default_rng(100 + rank).integers(0, rows, 3000))
+                got = yd[torch.from_numpy(ra).cuda()].cpu().numpy().astype(np.float64)
+                want = np.array([np.dot(vals[rowptr[r]:rowptr[r + 1]].astype(np.float64), x[colidx[rowptr[r]:rowptr[r + 1]]].astype(np.float64)) for r in ra])
+                okc = torch.tensor([1.0 if np.array_equal(got, want) else 0.0], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+                dist.all_reduce(okc, op=dist.ReduceOp.MIN)
+                extra[mode]["check_full_y_on_every_rank"] = "pass" if float(okc[0]) == 1.0 else "FAIL"
 
     out = {
         "metric": "fp%d SpMV GFLOP/s (y = A*x, tiled format)" % (dtype.itemsize * 8), "value": round(value, 2), "unit": "GFLOP/s",

@@ -45,3 +45,4 @@ def test_two_rank_rehearsal_over_gloo():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["check"] == "pass" and d["scaling"] == "strong"
     assert set(d["with_y_combine"]) == {"allgather", "allreduce"} and d["cpu_baseline"] is None
+    assert all(v["check_full_y_on_every_rank"] == "pass" for v in d["with_y_combine"].values())
