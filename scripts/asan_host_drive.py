@@ -1,0 +1,58 @@
+"""Driver for scripts/asan_host.sh: every small test matrix through Tile_create (both selection rules, truncated and
+untruncated row counts), tilespmv_cpu, the cache round trip and the .mtx reader (good and malformed files)."""
+import ctypes as C, sys, os, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from tilespmv_amd.tile_matrix import TileMatrixF64, to_dict
+from tilespmv_amd import generators as G
+import cases
+lib = C.CDLL('' + os.environ.get('TILESPMV_ASAN_LIB', '/tmp/tilespmv_asan/libhost_asan.so') + '')
+I = C.POINTER(C.c_int); D = C.POINTER(C.c_double); U = C.POINTER(C.c_uint)
+def p(a, t): return a.ctypes.data_as(C.POINTER(t))
+lib.Tile_create_ex.argtypes = [C.POINTER(TileMatrixF64), C.c_int, C.c_int, C.c_int, I, I, D, C.c_uint]
+lib.tilespmv_cpu.argtypes = [C.POINTER(TileMatrixF64), I, I, I, C.POINTER(U), C.POINTER(I), C.POINTER(I), C.c_int, C.c_int, C.c_int, I, I, D, D, D, D]
+lib.Tile_destroy.argtypes = [C.POINTER(TileMatrixF64)]
+lib.tilespmv_matrix_save.argtypes = [C.POINTER(TileMatrixF64), C.c_int, C.c_int, C.c_int, C.c_char_p]
+lib.tilespmv_matrix_load.argtypes = [C.POINTER(TileMatrixF64), I, I, I, C.c_char_p]
+lib.mmio_allinone.argtypes = [I, I, I, I, C.POINTER(I), C.POINTER(I), C.POINTER(D), C.c_char_p]
+libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+names = list(cases.SMALL) + ["lap256", "kkt12"]
+for name in names:
+    m, n, rp, ci = (cases.SMALL.get(name) or cases.MEDIUM[name])()
+    rows = (m // 16) * 16; nnz = len(ci)
+    rp = np.ascontiguousarray(rp, np.int32); ci = np.ascontiguousarray(ci, np.int32)
+    vals = G.compat_values(nnz); x = G.compat_x(n)
+    for flags in (2, 3):
+        for r_ in (rows, m):   # truncated and untruncated row counts
+            nn = int(rp[r_])
+            tm = TileMatrixF64()
+            lib.Tile_create_ex(C.byref(tm), r_, n, nn, p(rp, C.c_int), p(ci, C.c_int), p(vals, C.c_double), flags)
+            p1 = np.zeros(max(tm.tilenum, 1), np.int32); p2 = np.zeros(max(tm.tilenum, 1), np.int32)
+            y = np.zeros(r_ + 16); yg = np.zeros(r_ + 16)
+            nb = C.c_int(); a, b, c = U(), I(), I()
+            lib.tilespmv_cpu(C.byref(tm), p(p1, C.c_int), p(p2, C.c_int), C.byref(nb), C.byref(a), C.byref(b), C.byref(c), r_, n, nn,
+                             p(rp, C.c_int), p(ci, C.c_int), p(vals, C.c_double), p(x, C.c_double), p(y, C.c_double), p(yg, C.c_double))
+            for q in (a, b, c): libc.free(C.cast(q, C.c_void_p))
+            path = b"/tmp/tilespmv_asan/t.tspmv"
+            assert lib.tilespmv_matrix_save(C.byref(tm), r_, n, nn, path) == 0
+            t2 = TileMatrixF64(); ra, ca, za = C.c_int(), C.c_int(), C.c_int()
+            assert lib.tilespmv_matrix_load(C.byref(t2), C.byref(ra), C.byref(ca), C.byref(za), path) == 0
+            lib.Tile_destroy(C.byref(t2)); lib.Tile_destroy(C.byref(tm))
+    print(name, "ok", flush=True)
+# reader on assorted files
+import glob
+for f in glob.glob(os.path.join(ROOT, 'tests', 'golden', '*.mtx')):
+    mm, nn_, zz, ss = C.c_int(), C.c_int(), C.c_int(), C.c_int(); rpp, cii = I(), I(); vv = D()
+    rc = lib.mmio_allinone(C.byref(mm), C.byref(nn_), C.byref(zz), C.byref(ss), C.byref(rpp), C.byref(cii), C.byref(vv), f.encode())
+    if rc == 0:
+        for q in (rpp, cii, vv): libc.free(C.cast(q, C.c_void_p))
+    print(os.path.basename(f), rc, flush=True)
+# truncated / malformed files
+open('/tmp/tilespmv_asan/trunc.mtx', 'w').write("%%MatrixMarket matrix coordinate real general\n5 5 4\n1 1 1.0\n2 2")
+open('/tmp/tilespmv_asan/short.mtx', 'w').write("%%MatrixMarket matrix coordinate real general\n5 5 4\n1 1 1.0\n")
+open('/tmp/tilespmv_asan/junk.mtx', 'w').write("%%MatrixMarket matrix coordinate real general\n5 5 2\n1 x 1.0\n2 2 abc\n")
+for f in ('trunc', 'short', 'junk'):
+    mm, nn_, zz, ss = C.c_int(), C.c_int(), C.c_int(), C.c_int(); rpp, cii = I(), I(); vv = D()
+    rc = lib.mmio_allinone(C.byref(mm), C.byref(nn_), C.byref(zz), C.byref(ss), C.byref(rpp), C.byref(cii), C.byref(vv), ('/tmp/tilespmv_asan/%s.mtx' % f).encode())
+    print(f, rc, flush=True)
+print("DONE")
