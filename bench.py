@@ -221,6 +221,24 @@ def main():
                 "kernel": "k_units" if info["kernel"] == 2 else "k_tiles_direct", "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_launch": int(b_alg_launch),
                 "plan_stream_bytes_per_launch": info["stream_bytes"], "timing": "hip events on the launch stream, timed region"}
 
+    # measured device ceilings beside the 8 TB/s spec figure: read-only and copy streams of 1 GiB buffers
+    if rank == 0 and world == 1:
+        try:
+            big = torch.ones(1 << 27, dtype=torch.float64, device="cuda"); dst = torch.empty_like(big)
+            def _bw(f, nbytes):
+                for _ in range(3): f()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); [f() for _ in range(10)]; b.record(); torch.cuda.synchronize()
+                return nbytes * 10 / (a.elapsed_time(b) * 1e-3) * 1e-9
+            rd = _bw(lambda: torch.sum(big), big.numel() * 8); cp = _bw(lambda: dst.copy_(big), 2 * big.numel() * 8)
+            roofline["measured_ceilings_gbps"] = {"read_only_stream": round(rd, 0), "copy_stream_read_plus_write": round(cp, 0)}
+            if traffic:
+                roofline["actual_traffic_gbps"] = round(traffic / (kernel_ms * 1e-3) * 1e-9, 1)
+                roofline["actual_traffic_over_read_ceiling"] = round(traffic / (kernel_ms * 1e-3) * 1e-9 / rd, 4)
+            del big, dst
+        except Exception as e:
+            roofline["measured_ceilings_gbps"] = {"error": repr(e)}
+
     extra = {}
     if world > 1 and args.combine == "none":
         for mode in ("allgather", "allreduce"):
