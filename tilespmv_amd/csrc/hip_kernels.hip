@@ -351,7 +351,15 @@ __device__ __forceinline__ T stream_load(const T *p, bool nt)
     return nt ? __builtin_nontemporal_load(p) : *p;
 }
 
-// Descriptor word layout (16 B per unit, two identical-purpose halves so that a lane reads 8 B):
+// 12-B descriptor in HBM -> the 16-B form the strip parks in LDS (both halves carry word 0)
+__device__ __forceinline__ uint4 load_udesc(const UDesc *__restrict__ d, int i)
+{
+    const UDesc u = d[i];
+    return make_uint4(u.w0, u.n0, u.w0, u.n1);
+}
+
+// Descriptor word layout in LDS (16 B per unit, two identical-purpose halves so that a lane reads 8 B; HBM holds the
+// 12-B form without the duplicate word, UDesc):
 //   word 0 / word 2 : column block (24 bits) | flags << 24   (flag bit 0 = end of tile-row, bits 1-3 = row in strip,
 //                     bit 4 = row unit)
 //   word 1          : column nibbles of rows 0-7  (row 0 in the top nibble)   [row unit: target row]
@@ -430,8 +438,8 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
     uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
     val_t v[UB];
     if (have_units) {
-        dcur = S.udesc[min(unit_begin + r, last)];
-        dnext = S.udesc[min(unit_begin + DCHUNK + r, last)];
+        dcur = load_udesc(S.udesc, min(unit_begin + r, last));
+        dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
 #pragma unroll
         for (int k = 0; k < UB; k++) v[k] = stream_load(uval + (long long)min(unit_begin + k, last) * 16, NT);
     }
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
                 s_d[g][r] = dnext;
                 wave_lds_fence();
                 chunk_end += DCHUNK;
-                dnext = S.udesc[min(chunk_end + r, last)];
+                dnext = load_udesc(S.udesc, min(chunk_end + r, last));
             }
             const int j0 = u - (chunk_end - DCHUNK);
             uint2 d[UB];
@@ -702,8 +710,8 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
     uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
     val_t v[UB];
     if (have_units) {
-        dcur = S.udesc[min(unit_begin + r, last)];
-        dnext = S.udesc[min(unit_begin + DCHUNK + r, last)];
+        dcur = load_udesc(S.udesc, min(unit_begin + r, last));
+        dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
 #pragma unroll
         for (int k = 0; k < UB; k++) v[k] = uval[(long long)min(unit_begin + k, last) * 16];
     }
@@ -762,7 +770,7 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
                 s_d[g][r] = dnext;
                 wave_lds_fence();
                 chunk_end += DCHUNK;
-                dnext = S.udesc[min(chunk_end + r, last)];
+                dnext = load_udesc(S.udesc, min(chunk_end + r, last));
             }
             const int j0 = u - (chunk_end - DCHUNK);
             uint2 d[UB];

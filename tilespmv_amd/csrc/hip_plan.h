@@ -74,6 +74,8 @@ constexpr unsigned UNIT_ROWUNIT = 16u;    // unit flag bit 4: "row unit" = 16 va
                                           //   lane = column, word 1/3 hold the target row, result needs a 16-lane reduction
 constexpr int UNIT_FLAG_SHIFT = 24;       // flags live above the 24-bit column block in words 0 and 2
 
+struct UDesc { unsigned w0, n0, n1; };    // 12 bytes in HBM; lanes expand it to (w0, n0, w0, n1) in LDS so that a lane reads one 8-B half
+
 struct STask {                            // 32 bytes
     int unit_begin, unit_end;
     int coo_begin, coo_end;
@@ -85,7 +87,7 @@ struct STask {                            // 32 bytes
 };
 
 struct DevStream {
-    const uint4 *udesc;                   // per unit: .x = .z = column block | flags << 24, .y / .w = column nibbles of rows 0-7 / 8-15
+    const UDesc *udesc;                   // per unit, 12 B: column block | flags << 24, column nibbles of rows 0-7, of rows 8-15
     const val_t *uval;                    // 16 values per unit
     const val_t *cval;                    // COO entry list: value, global column, (row-in-strip << 4) | row
     const int *ccol;

@@ -454,7 +454,11 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
 
     int rc = 0;
     DevStream &S = plan->st;
-    rc |= plan->upload(h_udesc.data(), (size_t)NU, &S.udesc);
+    {
+        std::vector<UDesc> packed((size_t)NU);   // HBM form: the duplicate of word 0 is dropped
+        for (size_t i = 0; i < (size_t)NU; i++) packed[i] = UDesc{h_udesc[i].x, h_udesc[i].y, h_udesc[i].w};
+        rc |= plan->upload(packed.data(), (size_t)NU, &S.udesc);
+    }
     rc |= plan->upload(h_uval, (size_t)NU * 16, &S.uval);
     rc |= plan->upload(h_cval, (size_t)NC, &S.cval);
     rc |= plan->upload(h_ccol.data(), (size_t)NC, &S.ccol);
@@ -484,7 +488,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     plan->dev.nfix_late = (int)fix_late.size();
     S.coo_heavy_min = std::max(0, env_int("TILESPMV_COO_HEAVY_MIN", 32));  // swept on KKT fp64 / scircuit / webbase stand-ins: 32 best or within 1 %
     n_tasks = (long long)tasks.size();
-    model_bytes = NU * (16 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
+    model_bytes = NU * (12 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
                   ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
     return rc;
