@@ -369,6 +369,10 @@ __device__ __forceinline__ uint4 load_udesc(const UDesc *__restrict__ d, int i)
 // ds_read_b64 instead of one global load.  (Measured: per-unit descriptor loads, 6 % of the bytes, cost 19 %
 // of the kernel — the CU's vector-memory pipeline is the bottleneck, not HBM)
 constexpr int DCHUNK = 16;  // units per descriptor chunk
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+#ifndef NT_Y
+#define NT_Y 1  // y is written once and not re-read by this kernel: streaming (nontemporal) stores keep it from displacing x in L2 (+1-2 %)
+#endif
 #ifndef UNITS_MIN_WAVES
 #define UNITS_MIN_WAVES 8  // waves per SIMD asked of the register allocator (64 VGPRs)
 #endif
@@ -551,7 +555,8 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
         const long long ybase = (long long)row0 * 16;
         for (int i = r * VEC; i < 16 * nrows; i += 16 * VEC) {
             if (ybase + i + VEC <= rowA) {
-                *reinterpret_cast<uint4 *>(y + ybase + i) = *reinterpret_cast<const uint4 *>(res + i);
+                if (NT_Y) __builtin_nontemporal_store(*reinterpret_cast<const v4u_t *>(res + i), reinterpret_cast<v4u_t *>(y + ybase + i));
+                else *reinterpret_cast<uint4 *>(y + ybase + i) = *reinterpret_cast<const uint4 *>(res + i);
             } else {
 #pragma unroll
                 for (int q = 0; q < VEC; q++) if (ybase + i + q < rowA) y[ybase + i + q] = res[i + q];
