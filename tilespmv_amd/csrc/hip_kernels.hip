@@ -370,6 +370,7 @@ __device__ __forceinline__ uint4 load_udesc(const UDesc *__restrict__ d, int i)
 // of the kernel — the CU's vector-memory pipeline is the bottleneck, not HBM)
 constexpr int DCHUNK = 16;  // units per descriptor chunk
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 #ifndef NT_Y
 #define NT_Y 1  // y is written once and not re-read by this kernel: streaming (nontemporal) stores keep it from displacing x in L2 (+1-2 %)
 #endif
@@ -758,7 +759,15 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
             vec_t o;
 #pragma unroll
             for (int j = 0; j < NV; j++) o.v[j] = acc[j];
-            Yv[yi * Q] = o;
+            if constexpr (sizeof(vec_t) == 16) {  // streaming stores, as in k_units
+                v4u_t w; __builtin_memcpy(&w, &o, 16);
+                __builtin_nontemporal_store(w, reinterpret_cast<v4u_t *>(&Yv[yi * Q]));
+            } else if constexpr (sizeof(vec_t) == 8) {
+                v2u_t w; __builtin_memcpy(&w, &o, 8);
+                __builtin_nontemporal_store(w, reinterpret_cast<v2u_t *>(&Yv[yi * Q]));
+            } else {
+                Yv[yi * Q] = o;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NV; j++) acc[j] = 0;
