@@ -603,7 +603,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     const int sv = (int)sizeof(val_t);
 
     auto *plan = new tilespmv_plan();
-    HIP_TRY(hipGetDevice(&plan->device));
+    if (hipGetDevice(&plan->device) != hipSuccess) { fprintf(stderr, "tilespmv: hipGetDevice failed\n"); delete plan; return -1; }
 
     // ---- how are COO tiles executed?  (bytes model)
     const int t_begin = T->tile_ptr[tr0], t_end = T->tile_ptr[tr1];
@@ -846,16 +846,18 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
 double tilespmv_plan_time_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y, int nvec, void *stream, int warmup, int reps)
 {
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0;
-    for (int i = 0; i < warmup; i++) if (tilespmv_plan_spmm(plan, d_X, d_Y, nvec, stream)) return -1.0;
-    (void)hipEventRecord(a, st);
-    for (int i = 0; i < reps; i++) if (tilespmv_plan_spmm(plan, d_X, d_Y, nvec, stream)) return -1.0;
-    (void)hipEventRecord(b, st);
-    if (hipEventSynchronize(b) != hipSuccess) return -1.0;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess) return -1.0;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return -1.0; }
+    bool ok = true;
+    for (int i = 0; ok && i < warmup; i++) ok = tilespmv_plan_spmm(plan, d_X, d_Y, nvec, stream) == 0;
+    if (ok) ok = hipEventRecord(a, st) == hipSuccess;
+    for (int i = 0; ok && i < reps; i++) ok = tilespmv_plan_spmm(plan, d_X, d_Y, nvec, stream) == 0;
+    if (ok) ok = hipEventRecord(b, st) == hipSuccess && hipEventSynchronize(b) == hipSuccess;
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, a, b);
+    if (ok) ok = hipEventElapsedTime(&ms, a, b) == hipSuccess;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (!ok) return -1.0;
     return reps > 0 ? (double)ms / reps : 0.0;
 }
 
@@ -876,16 +878,18 @@ void tilespmv_plan_info(const tilespmv_plan *plan, long long *out)
 double tilespmv_plan_time(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y, void *stream, int warmup, int reps)
 {
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0;
-    for (int i = 0; i < warmup; i++) if (tilespmv_plan_spmv(plan, d_x, d_y, stream)) return -1.0;
-    (void)hipEventRecord(a, st);
-    for (int i = 0; i < reps; i++) if (tilespmv_plan_spmv(plan, d_x, d_y, stream)) return -1.0;
-    (void)hipEventRecord(b, st);
-    if (hipEventSynchronize(b) != hipSuccess) return -1.0;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess) return -1.0;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return -1.0; }
+    bool ok = true;
+    for (int i = 0; ok && i < warmup; i++) ok = tilespmv_plan_spmv(plan, d_x, d_y, stream) == 0;
+    if (ok) ok = hipEventRecord(a, st) == hipSuccess;
+    for (int i = 0; ok && i < reps; i++) ok = tilespmv_plan_spmv(plan, d_x, d_y, stream) == 0;
+    if (ok) ok = hipEventRecord(b, st) == hipSuccess && hipEventSynchronize(b) == hipSuccess;
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, a, b);
+    if (ok) ok = hipEventElapsedTime(&ms, a, b) == hipSuccess;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (!ok) return -1.0;
     return reps > 0 ? (double)ms / reps : 0.0;
 }
 
