@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
 
 // ------------------------------------------------------------------------------------------------
 // Dense tiles on the matrix cores (reference dense kernel: src/tilespmv_cuda.h:664-710).
-// One wavefront per tile-row.  A dense tile is 256 contiguous values (column-major); k-step s of
+// One wavefront per tile-row.  A dense tile is 256 contiguous values (stored in operand order, below); k-step s of
 // v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 with lane group q (= k index) covers tile column
 // 4q + s: A[row][k=q] = tile[row][4q+s] (four 128-B runs per load), B[k=q][*] = x[16cb + 4q + s].
 // The accumulator D is carried ACROSS the tiles of the tile-row (C-in = previous D), so a row with
@@ -599,9 +599,9 @@ __global__ __launch_bounds__(256) void k_dense_mfma(DevDense D, int rowA, int co
     auto load_tile = [&](int t, val_t (&a)[4], val_t (&b)[4]) {
         const int cb = __builtin_amdgcn_readlane(cbv, __builtin_amdgcn_readfirstlane(min(t, last) - t0));
         const long long xb = (long long)cb * 16 + 4 * kq;
-        const val_t *tv = D.val + (long long)min(t, last) * 256 + 64 * kq + rr0;
+        const val_t *tv = D.val + (long long)min(t, last) * 256 + (16 * kq + rr0) * 4;  // operand order: 4 contiguous values per lane
 #pragma unroll
-        for (int s = 0; s < 4; s++) a[s] = tv[16 * s];
+        for (int s = 0; s < 4; s++) a[s] = tv[s];
         if (xb + 3 <= xlast) {
 #pragma unroll
             for (int s = 0; s < 4; s++) b[s] = x[xb + s];   // contiguous: merged into 16-B loads
@@ -877,10 +877,10 @@ __global__ __launch_bounds__(256) void k_dense_mfma_mv(DevDense D, int rowA, int
     for (int t = t0; t < t1; t++) {
         const int cb = __builtin_amdgcn_readlane(cbv, __builtin_amdgcn_readfirstlane(t - t0));
         const long long xb = (long long)cb * 16 + 4 * kq;
-        const val_t *tv = D.val + (long long)t * 256 + 64 * kq + n;
+        const val_t *tv = D.val + (long long)t * 256 + (16 * kq + n) * 4;
         val_t a[4], b[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) a[s] = tv[16 * s];
+        for (int s = 0; s < 4; s++) a[s] = tv[s];
 #pragma unroll
         for (int s = 0; s < 4; s++) b[s] = n < NV ? X[min(xb + s, xlast) * NV + n] : (val_t)0;
 #pragma unroll

@@ -105,7 +105,7 @@ struct DevStream {
 struct DenseRow { int row, tile_begin, tile_end, partial; };  // partial: -1 -> y += result, else slot in partial[]
 struct DevDense {
     const int *cb;          // column block per dense tile
-    const val_t *val;       // 256 values per tile, column-major, row stride 16, zero padded
+    const val_t *val;       // 256 values per tile, zero padded, MFMA operand order: tile[r][c] at ((c >> 2) * 16 + r) * 4 + (c & 3)
     const DenseRow *rows;
     int nrows;
 };
