@@ -382,7 +382,7 @@ template <int UB, int XCD_REMAP, bool NT>
 __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
-    static_assert(DCHUNK % UB == 0, "a batch never straddles a descriptor chunk");
+    static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
     __shared__ val_t s_y[GROUPS_PER_BLOCK][STRIP_MAX_ROWS][16];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
@@ -405,8 +405,14 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
     const int row0 = t1.x, part = t1.y, nrows = t1.w;
     const unsigned nounit = (unsigned)t1.z;
     const bool side = coo_end > coo_begin;
-    const val_t *__restrict__ uval = S.uval + r;
+    // values are stored in groups of G = UNIT_GROUP units of one task (hip_plan.hip): row r of the group that starts at
+    // task-relative unit j (a multiple of G) sits at uval[(unit_begin + j) * 16 + G r .. + G - 1]; a batch of UB units
+    // is UB / G sixteen-byte loads per lane
+    constexpr int G = UNIT_GROUP;
+    typedef val_t grp_t __attribute__((ext_vector_type(UNIT_GROUP)));
+    const grp_t *__restrict__ ugrp = reinterpret_cast<const grp_t *>(S.uval) + r;
     const int last = unit_end - 1;
+    const int last_grp = unit_begin + (unit_end - 1 - unit_begin) / UNIT_GROUP * UNIT_GROUP;  // first unit of the task's last group
     const bool have_units = unit_begin < unit_end;
     const long long xlast = (long long)colA - 1;  // row units of a partial last column block: zero payload, clamped x index
 
@@ -446,7 +452,11 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
         dcur = load_udesc(S.udesc, min(unit_begin + r, last));
         dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
 #pragma unroll
-        for (int k = 0; k < UB; k++) v[k] = stream_load(uval + (long long)min(unit_begin + k, last) * 16, NT);
+        for (int k = 0; k < UB; k += G) {
+            const grp_t pv = stream_load(ugrp + (long long)min(unit_begin + k, last_grp) * (16 / G), NT);
+#pragma unroll
+            for (int q = 0; q < G; q++) v[k + q] = pv[q];
+        }
     }
     if (side && !coo_heavy) {  // up to coo_heavy_min entries: 16 with the prologue loads, the rest 4 x 16 per trip
         if (coo0) atomicAdd(&s_y[g][rb0 >> 4][rb0 & 15u], cv0 * x[cc0]);
@@ -510,7 +520,11 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
             }
             val_t vn[UB];
 #pragma unroll
-            for (int k = 0; k < UB; k++) vn[k] = stream_load(uval + (long long)min(u + UB + k, last) * 16, NT);  // unconditional: exact vmcnt
+            for (int k = 0; k < UB; k += G) {  // unconditional (clamped to the task's last group): exact vmcnt
+                const grp_t pv = stream_load(ugrp + (long long)min(u + UB + k, last_grp) * (16 / G), NT);
+#pragma unroll
+                for (int q = 0; q < G; q++) vn[k + q] = pv[q];
+            }
 #pragma unroll
             for (int k = 0; k < UB; k++)
                 if (u + k < unit_end) retire(v[k] * xv[k], d[k].x >> 24, d[k].y);
@@ -693,10 +707,11 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
     const int row0 = t1.x, part = t1.y;
     const unsigned nounit = (unsigned)t1.z;
     const int ncoo = coo_end - coo_begin;
-    const val_t *__restrict__ uval = S.uval + r;
+    const val_t *__restrict__ uval = S.uval + UNIT_GROUP * r;  // group layout: unit j of the task, row r -> (unit_begin + j / G * G) * 16 + G r + j % G
     const vec_t *__restrict__ Xv = reinterpret_cast<const vec_t *>(X) + q;   // row i, slice q: Xv[i * Q]
     vec_t *__restrict__ Yv = reinterpret_cast<vec_t *>(Y) + q;
     const int last = unit_end - 1;
+    auto uaddr = [&](int u) { const int j = min(u, last) - unit_begin; return uval + (long long)(unit_begin + j / UNIT_GROUP * UNIT_GROUP) * 16 + j % UNIT_GROUP; };
     const bool have_units = unit_begin < unit_end;
     const long long xlast = (long long)colA - 1;
 
@@ -719,7 +734,7 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
         dcur = load_udesc(S.udesc, min(unit_begin + r, last));
         dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
 #pragma unroll
-        for (int k = 0; k < UB; k++) v[k] = uval[(long long)min(unit_begin + k, last) * 16];
+        for (int k = 0; k < UB; k++) v[k] = *uaddr(unit_begin + k);
     }
     if (ncoo > 0) {
 #pragma unroll
@@ -799,7 +814,7 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
             }
             val_t vn[UB];
 #pragma unroll
-            for (int k = 0; k < UB; k++) vn[k] = uval[(long long)min(u + UB + k, last) * 16];
+            for (int k = 0; k < UB; k++) vn[k] = *uaddr(u + UB + k);
 #pragma unroll
             for (int k = 0; k < UB; k++) {
                 if (u + k >= unit_end) break;
@@ -946,7 +961,8 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
 #define TSPMV_L3(U, X, N) hipLaunchKernelGGL((k_units<U, X, N>), grid, blk, 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
 #define TSPMV_L2(U, X) do { if (nt) TSPMV_L3(U, X, true); else TSPMV_L3(U, X, false); } while (0)
 #define TSPMV_L1(U) do { if (xcd_remap == 1) TSPMV_L2(U, 1); else if (xcd_remap == 2) TSPMV_L2(U, 2); else if (xcd_remap == 3) TSPMV_L2(U, 3); else TSPMV_L2(U, 0); } while (0)
-        if (ub == 2) TSPMV_L1(2); else if (ub == 8) TSPMV_L1(8); else TSPMV_L1(4);
+        if constexpr (UNIT_GROUP <= 2) { if (ub == 2) { TSPMV_L1(2); } else if (ub == 8) { TSPMV_L1(8); } else { TSPMV_L1(4); } }
+        else { if (ub == 8) { TSPMV_L1(8); } else { TSPMV_L1(4); } }  // fp32: a batch is whole groups of 4 units
 #undef TSPMV_L1
 #undef TSPMV_L2
 #undef TSPMV_L3

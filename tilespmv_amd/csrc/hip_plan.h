@@ -72,6 +72,7 @@ constexpr unsigned UNIT_EOR = 1u;         // unit flag bit 0: last unit of its t
 constexpr int UNIT_ROW_SHIFT = 1;         // unit flag bits 1-3: tile-row inside the strip
 constexpr unsigned UNIT_ROWUNIT = 16u;    // unit flag bit 4: "row unit" = 16 values of ONE tile row (dense-row tiles);
                                           //   lane = column, word 1/3 hold the target row, result needs a 16-lane reduction
+constexpr int UNIT_GROUP = 16 / (int)sizeof(val_t);  // units whose values share one 16-byte lane load (2 in fp64, 4 in fp32)
 constexpr int UNIT_FLAG_SHIFT = 24;       // flags live above the 24-bit column block in words 0 and 2
 
 struct UDesc { unsigned w0, n0, n1; };    // 12 bytes in HBM; lanes expand it to (w0, n0, w0, n1) in LDS so that a lane reads one 8-B half
@@ -88,7 +89,7 @@ struct STask {                            // 32 bytes
 
 struct DevStream {
     const UDesc *udesc;                   // per unit, 12 B: column block | flags << 24, column nibbles of rows 0-7, of rows 8-15
-    const val_t *uval;                    // 16 values per unit
+    const val_t *uval;                    // 16 values per unit, stored in groups of UNIT_GROUP units of one task, interleaved per row
     const val_t *cval;                    // COO entry list: value, global column, (row-in-strip << 4) | row
     const int *ccol;
     const unsigned char *crow;

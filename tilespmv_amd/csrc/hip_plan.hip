@@ -455,12 +455,40 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
 
     int rc = 0;
     DevStream &S = plan->st;
+    // ---- final HBM form of the unit streams.  Descriptors: 12 B (the duplicate of word 0 is dropped).  Values: the
+    // units of one task are stored in GROUPS of G = 16 / sizeof(value) units (2 in fp64, 4 in fp32) — the values of
+    // the G units interleaved per row, so that a lane fetches G units with one 16-byte load (row r of the group at
+    // +16 r bytes).  A task whose unit count is not a multiple of G gets padding units (zero values, never executed:
+    // unit_end excludes them) so that its last group exists.
+    constexpr long long G = UNIT_GROUP;
+    auto padded = [&](long long n) { return (n + G - 1) / G * G; };
+    long long NUP = 0;
+    for (const STask &k : tasks) NUP += padded(k.unit_end - k.unit_begin);
+    if (NUP > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit unit ids\n"); return -2; }
     {
-        std::vector<UDesc> packed((size_t)NU);   // HBM form: the duplicate of word 0 is dropped
-        for (size_t i = 0; i < (size_t)NU; i++) packed[i] = UDesc{h_udesc[i].x, h_udesc[i].y, h_udesc[i].w};
-        rc |= plan->upload(packed.data(), (size_t)NU, &S.udesc);
+        std::vector<UDesc> packed((size_t)NUP, UDesc{0u, 0u, 0u});
+        val_t *paired = zalloc<val_t>((size_t)NUP * 16);
+        std::vector<long long> new_begin(tasks.size());
+        long long at = 0;
+        for (size_t i = 0; i < tasks.size(); i++) { new_begin[i] = at; at += padded(tasks[i].unit_end - tasks[i].unit_begin); }
+        parallel_chunks((int64_t)tasks.size(), 512, [&](int64_t b, int64_t e, int) {
+            for (int64_t i = b; i < e; i++) {
+                STask &k = tasks[(size_t)i];
+                const long long ub = k.unit_begin, n = k.unit_end - ub, nb = new_begin[(size_t)i];
+                for (long long j = 0; j < n; j++) {
+                    const uint4 d = h_udesc[(size_t)(ub + j)];
+                    packed[(size_t)(nb + j)] = UDesc{d.x, d.y, d.w};
+                    const val_t *src = h_uval + (ub + j) * 16;
+                    val_t *dst = paired + (nb + j / G * G) * 16 + (j % G);
+                    for (int r = 0; r < 16; r++) dst[G * r] = src[r];
+                }
+                if (n > 0) { k.unit_begin = (int)nb; k.unit_end = (int)(nb + n); }
+            }
+        });
+        rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc);
+        rc |= plan->upload(paired, (size_t)NUP * 16, &S.uval);
+        free(paired);
     }
-    rc |= plan->upload(h_uval, (size_t)NU * 16, &S.uval);
     rc |= plan->upload(h_cval, (size_t)NC, &S.cval);
     rc |= plan->upload(h_ccol.data(), (size_t)NC, &S.ccol);
     rc |= plan->upload(h_crow.data(), (size_t)NC, &S.crow);
@@ -489,7 +517,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     plan->dev.nfix_late = (int)fix_late.size();
     S.coo_heavy_min = std::max(0, env_int("TILESPMV_COO_HEAVY_MIN", 32));  // swept on KKT fp64 / scircuit / webbase stand-ins: 32 best or within 1 %
     n_tasks = (long long)tasks.size();
-    model_bytes = NU * (12 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
+    model_bytes = NUP * (12 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
                   ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
     return rc;
