@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
     constexpr int Q = NVT / NV;             // lane groups per strip
     constexpr int STRIPS = GROUPS_PER_BLOCK / Q;
     typedef MVec<NV> vec_t;
-    constexpr int UB = 2;
+    constexpr int UB = UNIT_GROUP;          // one 16-byte value load per batch (2 units fp64, 4 units fp32)
     __shared__ val_t s_c[GROUPS_PER_BLOCK][16][NV];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
@@ -707,11 +707,17 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
     const int row0 = t1.x, part = t1.y;
     const unsigned nounit = (unsigned)t1.z;
     const int ncoo = coo_end - coo_begin;
-    const val_t *__restrict__ uval = S.uval + UNIT_GROUP * r;  // group layout: unit j of the task, row r -> (unit_begin + j / G * G) * 16 + G r + j % G
+    typedef val_t grp_t __attribute__((ext_vector_type(UNIT_GROUP)));
+    const grp_t *__restrict__ ugrp = reinterpret_cast<const grp_t *>(S.uval) + r;  // group layout (hip_plan.hip): one 16-byte load = UNIT_GROUP units
     const vec_t *__restrict__ Xv = reinterpret_cast<const vec_t *>(X) + q;   // row i, slice q: Xv[i * Q]
     vec_t *__restrict__ Yv = reinterpret_cast<vec_t *>(Y) + q;
     const int last = unit_end - 1;
-    auto uaddr = [&](int u) { const int j = min(u, last) - unit_begin; return uval + (long long)(unit_begin + j / UNIT_GROUP * UNIT_GROUP) * 16 + j % UNIT_GROUP; };
+    const int last_grp = unit_begin + (unit_end - 1 - unit_begin) / UNIT_GROUP * UNIT_GROUP;
+    auto load_grp = [&](int u, val_t (&out)[UB]) {
+        const grp_t pv = ugrp[(long long)min(u, last_grp) * (16 / UNIT_GROUP)];
+#pragma unroll
+        for (int k = 0; k < UB; k++) out[k] = pv[k];
+    };
     const bool have_units = unit_begin < unit_end;
     const long long xlast = (long long)colA - 1;
 
@@ -733,8 +739,7 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
     if (have_units) {
         dcur = load_udesc(S.udesc, min(unit_begin + r, last));
         dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
-#pragma unroll
-        for (int k = 0; k < UB; k++) v[k] = *uaddr(unit_begin + k);
+        load_grp(unit_begin, v);
     }
     if (ncoo > 0) {
 #pragma unroll
@@ -813,8 +818,7 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
                 xv[k] = Xv[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast) * Q];
             }
             val_t vn[UB];
-#pragma unroll
-            for (int k = 0; k < UB; k++) vn[k] = *uaddr(u + UB + k);
+            load_grp(u + UB, vn);
 #pragma unroll
             for (int k = 0; k < UB; k++) {
                 if (u + k >= unit_end) break;
