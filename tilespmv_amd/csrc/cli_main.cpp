@@ -67,7 +67,7 @@ int main(int argc, char **argv)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { fprintf(stderr, "hipGetDeviceProperties failed\n"); return 2; }
     printf("---------------------------------------------------------------------------------------------\n");
-    printf("Device [ %i ] %s @ %4.2f MHz\n", device_id, prop.name, prop.clockRate * 1e-3f);
+    printf("Device [ %i ] %s @ %4.2f MHz\n", device_id, prop.name[0] ? prop.name : prop.gcnArchName, prop.clockRate * 1e-3f);  // marketing name can be empty in containers
 
     Tile_matrix *matrixA = (Tile_matrix *)malloc(sizeof(Tile_matrix));
     Tile_create(matrixA, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA);
