@@ -247,6 +247,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     std::vector<Task> htasks;
     std::vector<FixRow> ifix, fix_late;   // split rows summed inside the unit kernel / by k_fixup_split after all passes
     const bool fix_inline_on = env_int("TILESPMV_FIX_INLINE", 1) != 0;
+    const bool strip_even = env_int("TILESPMV_STRIP_EVEN", 1) != 0;
     std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
     auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
     auto is_heavy = [&](int t) {
@@ -303,7 +304,21 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         k.unit_begin = (int)pu[i]; k.coo_begin = (int)pc[i];
         long long c = 0;
         int j = i;
-        while (j < ntr && j - i < STRIP_MAX_ROWS && rc_[j].cost <= split_above && (j == i || c + rc_[j].cost <= target)) {
+        // how many tile-rows: up to the cost target, then nudged by one row either way if that leaves fewer padding
+        // units (the strip's values are stored in groups of UNIT_GROUP units, tail padded with zero units)
+        int jend = i;
+        {
+            long long cc = 0;
+            while (jend < ntr && jend - i < STRIP_MAX_ROWS && rc_[jend].cost <= split_above && (jend == i || cc + rc_[jend].cost <= target)) { cc += rc_[jend].cost; jend++; }
+            auto pad = [&](int e) { return (int)((UNIT_GROUP - (pu[e] - pu[i]) % UNIT_GROUP) % UNIT_GROUP); };
+            if (strip_even && pad(jend) > 0) {
+                int best = jend;
+                if (jend < ntr && jend - i < STRIP_MAX_ROWS && rc_[jend].cost <= split_above && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
+                if (best == jend && jend - i >= 3 && pad(jend - 1) < pad(best)) best = jend - 1;
+                jend = best;
+            }
+        }
+        while (j < jend) {
             row_k[j] = (unsigned char)(j - i);
             if (rc_[j].nunits == 0) k.nounit_mask |= 1u << (j - i);
             if (rc_[j].nheavy > 0) htasks.push_back(Task{(int)ph[j], (int)ph[j + 1], phv[j], phi[j], tr0 + j, -1});
