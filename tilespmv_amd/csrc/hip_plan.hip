@@ -247,7 +247,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     std::vector<Task> htasks;
     std::vector<FixRow> ifix, fix_late;   // split rows summed inside the unit kernel / by k_fixup_split after all passes
     const bool fix_inline_on = env_int("TILESPMV_FIX_INLINE", 1) != 0;
-    const bool strip_even = env_int("TILESPMV_STRIP_EVEN", 1) != 0;
+    const int strip_even = env_int("TILESPMV_STRIP_EVEN", 4);  // 0 off, 1 = value group, n > 1 = multiples of n units
     std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
     auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
     auto is_heavy = [&](int t) {
@@ -310,7 +310,9 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         {
             long long cc = 0;
             while (jend < ntr && jend - i < STRIP_MAX_ROWS && rc_[jend].cost <= split_above && (jend == i || cc + rc_[jend].cost <= target)) { cc += rc_[jend].cost; jend++; }
-            auto pad = [&](int e) { return (int)((UNIT_GROUP - (pu[e] - pu[i]) % UNIT_GROUP) % UNIT_GROUP); };
+            // (whole batches of 4 units, which are also whole value groups: a half-empty last batch costs as much as a full one)
+            const int quantum = strip_even > 1 ? strip_even : UNIT_GROUP;
+            auto pad = [&](int e) { return (int)((quantum - (pu[e] - pu[i]) % quantum) % quantum); };
             if (strip_even && pad(jend) > 0) {
                 int best = jend;
                 if (jend < ntr && jend - i < STRIP_MAX_ROWS && rc_[jend].cost <= split_above && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
