@@ -266,6 +266,8 @@ enum {
     TILESPMV_INFO_NUM_TASKS = 8,
     TILESPMV_INFO_NUM_SPLIT_ROWS = 9,
     TILESPMV_INFO_FALLBACK_NNZ = 10,  /* nonzeros executed by the CSR fallback kernel */
+    TILESPMV_INFO_BUILD_US = 11,      /* host time of the re-layout (plan build), microseconds */
+    TILESPMV_INFO_UPLOAD_US = 12,     /* hipMalloc + hipMemcpy time of the plan's streams, microseconds */
     TILESPMV_INFO_COUNT = 16
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);

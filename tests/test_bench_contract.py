@@ -33,16 +33,21 @@ def test_single_gpu_line():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
+    assert cb["sample"].startswith("the full workload") and cb["format_loop_only"]["serial_1_core"]["errcount"] == 0
+    assert d["ranks"] == 1 and d["devices"] == [0] and d["reference_style_timing"]["ms_per_spmv"] > 0
+    assert {"tile_create", "plan_build", "plan_upload"} <= set(d["prep_seconds"])
     assert abs(d["value"] - 2 * d["config"]["nnz"] / (d["ms_per_step"] * 1e-3) * 1e-9) / d["value"] < 0.02
 
 
 def test_two_rank_rehearsal_over_gloo():
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "3", "--backend", "gloo",
-           "--workload", "laplacian512"]
-    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    # the driver's command shape, bare: bench.py starts its own ranks (child torch.distributed.run) and relays the line
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "3", "--backend", "gloo", "--workload", "laplacian512"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["check"] == "pass" and d["scaling"] == "strong"
+    assert d["ranks"] == 2 and len(d["devices"]) == 2 and d["backend"] == "gloo" and d["launched_by"].startswith("self")
+    assert len(d["per_rank_ms_per_step"]["wall"]) == 2 and d["per_rank_ms_per_step"]["max"] >= d["per_rank_ms_per_step"]["min"] > 0
     assert set(d["with_y_combine"]) == {"allgather", "allreduce"} and d["cpu_baseline"] is None
     assert all(v["check_full_y_on_every_rank"] == "pass" for v in d["with_y_combine"].values())

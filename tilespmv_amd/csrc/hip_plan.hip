@@ -34,6 +34,13 @@ int fallback_block_nnz();
         }                                                                                               \
     } while (0)
 
+static double now_us()
+{
+    timeval t;
+    gettimeofday(&t, NULL);
+    return t.tv_sec * 1e6 + t.tv_usec;
+}
+
 static int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
@@ -58,11 +65,13 @@ struct tilespmv_plan {
     template <class T>
     int upload(const T *host, size_t n, const T **out)
     {
+        const double t0 = now_us();
         void *d = nullptr;
         HIP_TRY(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T) + 256));  // slack: masked tail lanes never fault
         allocs.push_back(d);
         if (n) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
         info[TILESPMV_INFO_DEVICE_BYTES] += (long long)(n * sizeof(T));
+        info[TILESPMV_INFO_UPLOAD_US] += (long long)(now_us() - t0);
         *out = (const T *)d;
         return 0;
     }
@@ -258,8 +267,13 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t];
         (void)fmt; *nv = stored; *ni = 16 + (stored + 1) / 2;
     };
+    // k_dense_mfma broadcasts the column blocks of one DenseRow piece from a single 64-lane load: a piece holds at most
+    // 64 dense tiles.  Split rows cut their dense tiles into pieces of 32; an unsplit row is one piece, so a row with
+    // more dense tiles than that is always split, whatever the cost knobs say (TILESPMV_STRIP_COST / _SPLIT_ABOVE).
+    constexpr int DENSE_PIECE = 32;
+    auto must_split = [&](int i) { return rc_[i].cost > split_above || rc_[i].ndense > DENSE_PIECE; };
     for (int i = 0; i < ntr;) {
-        if (rc_[i].cost > split_above) {
+        if (must_split(i)) {
             row_split[i] = 1;
             FixRow f{tr0 + i, npartial, 0, 0};
             const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, env_int("TILESPMV_COO_PIECE", piece / std::max(1, env_int("TILESPMV_COO_COST", 4))));
@@ -287,8 +301,8 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
                 k.tile_end = (int)h;
                 htasks.push_back(k); f.count++;
             }
-            for (long long dq = pd[i]; dq < pd[i + 1]; dq += 32) {  // dense tiles of a split row: 32 per piece
-                drows.push_back(DenseRow{tr0 + i, (int)dq, (int)std::min(pd[i + 1], dq + 32), npartial++});
+            for (long long dq = pd[i]; dq < pd[i + 1]; dq += DENSE_PIECE) {  // dense tiles of a split row: 32 per piece
+                drows.push_back(DenseRow{tr0 + i, (int)dq, (int)std::min(pd[i + 1], dq + DENSE_PIECE), npartial++});
                 f.count++;
             }
             // all pieces inside the unit kernel -> the last one to finish adds the slots up there
@@ -309,13 +323,13 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         int jend = i;
         {
             long long cc = 0;
-            while (jend < ntr && jend - i < STRIP_MAX_ROWS && rc_[jend].cost <= split_above && (jend == i || cc + rc_[jend].cost <= target)) { cc += rc_[jend].cost; jend++; }
+            while (jend < ntr && jend - i < STRIP_MAX_ROWS && !must_split(jend) && (jend == i || cc + rc_[jend].cost <= target)) { cc += rc_[jend].cost; jend++; }
             // (whole batches of 4 units, which are also whole value groups: a half-empty last batch costs as much as a full one)
             const int quantum = strip_even > 1 ? strip_even : UNIT_GROUP;
             auto pad = [&](int e) { return (int)((quantum - (pu[e] - pu[i]) % quantum) % quantum); };
             if (strip_even && pad(jend) > 0) {
                 int best = jend;
-                if (jend < ntr && jend - i < STRIP_MAX_ROWS && rc_[jend].cost <= split_above && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
+                if (jend < ntr && jend - i < STRIP_MAX_ROWS && !must_split(jend) && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
                 if (best == jend && jend - i >= 3 && pad(jend - 1) < pad(best)) best = jend - 1;
                 jend = best;
             }
@@ -520,6 +534,8 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     rc |= plan->upload(h_dval, (size_t)ND * 256, &plan->dn.val);
     rc |= plan->upload(drows.data(), drows.size(), &plan->dn.rows);
     plan->dn.nrows = (int)drows.size();
+    for (const DenseRow &dr : drows)
+        if (dr.tile_end - dr.tile_begin > 64) { fprintf(stderr, "tilespmv: internal error: dense piece of %d tiles\n", dr.tile_end - dr.tile_begin); rc = -6; }
     free(h_uval); free(h_cval); free(h_hval); free(h_hidx); free(h_dval);
     S.ntasks = (int)tasks.size();
     S.ifix = nullptr; S.ifix_count = nullptr;
@@ -637,6 +653,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
 {
     (void)nnzA;
     *out = nullptr;
+    const double t_create0 = now_us();
     if (tilespmv_device_count() <= 0) {
         fprintf(stderr, "tilespmv: no HIP device visible — the GPU path has no CPU fallback\n");
         return -1;
@@ -860,6 +877,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     I[TILESPMV_INFO_COO_MODE] = coo_mode; I[TILESPMV_INFO_DENSE_MODE] = dense_mode; I[TILESPMV_INFO_KERNEL] = plan->kernel;
     I[TILESPMV_INFO_NUM_TASKS] = n_tasks; I[TILESPMV_INFO_NUM_SPLIT_ROWS] = (long long)fix.size();
     I[TILESPMV_INFO_FALLBACK_NNZ] = f_nnz;
+    I[TILESPMV_INFO_BUILD_US] = (long long)(now_us() - t_create0) - I[TILESPMV_INFO_UPLOAD_US];
     // bytes one SpMV has to move at least: the three streams + tasks + x once + y once (+ fallback)
     I[TILESPMV_INFO_STREAM_BYTES] = model_bytes + (long long)colA * sv + (long long)rows * sv +
                                     (f_nnz ? f_nnz * (sv + 4) + (long long)rows * 4 + (long long)f_blk.size() * 4 : 0);

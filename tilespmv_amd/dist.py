@@ -54,12 +54,24 @@ class ShardedSpMV:
         self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
         rp, ci, v = shard_csr(rowptr, colidx, vals, self.r0, self.r1)
         self.local_rows, self.local_nnz = self.r1 - self.r0, int(rp[-1])
+        self.seconds = {}
         if make_local is not None:
             self.local = make_local(self.local_rows, cols, rp, ci, v)
             self.tm = None
         else:
+            import time
+            t0 = time.perf_counter()
             self.tm = api.Tile_create(self.local_rows, cols, self.local_nnz, rp, ci, v, dtype=self.dtype)
+            t1 = time.perf_counter()
             self.local = api.Plan(self.tm, self.local_rows, cols, self.local_nnz, **plan_kw)
+            t2 = time.perf_counter()
+            self.tiles = int(self.tm.tilenum)
+            # the plan holds its own device copy: the host Tile_matrix (about 1 GB for config 4) is not needed any more
+            api.Tile_destroy(self.tm)
+            self.tm = None
+            info = self.local.info()
+            self.seconds = {"tile_create": t1 - t0, "plan_build": info["build_us"] * 1e-6, "plan_upload": info["upload_us"] * 1e-6,
+                            "plan_create_total": t2 - t1}
         self.slice_max = int(np.diff(self.bounds).max())
         self.equal_slices = bool((np.diff(self.bounds) == self.slice_max).all())
         self._gather = None
@@ -101,3 +113,7 @@ class ShardedSpMV:
     def close(self):
         if hasattr(self.local, "close"):
             self.local.close()
+        if getattr(self, "tm", None) is not None:
+            from . import api
+            api.Tile_destroy(self.tm)
+            self.tm = None

@@ -104,8 +104,8 @@ class HaloSpMV:
                 loc = make_local(q1 - q0, self.cols_ext, brp, bci, bv)
             else:
                 tm = api.Tile_create(q1 - q0, self.cols_ext, int(brp[-1]), brp, bci, bv, dtype=self.dtype)
-                self._tms.append(tm)
                 loc = api.Plan(tm, q1 - q0, self.cols_ext, int(brp[-1]), **plan_kw)
+                api.Tile_destroy(tm)   # the plan owns its device copy; the host Tile_matrix is not needed afterwards
             self.blocks.append((q0, q1, loc, bool(touches[q0 // 16:q1 // 16].any())))
         self.local_nnz = int(rp[-1])
 
