@@ -10,8 +10,8 @@ fp64 SpMV GFLOP/s + achieved (algorithmic) HBM GB/s as a fraction of the 8 TB/s 
 Workloads (synthetic stand-ins unless $TILESPMV_MATRIX_DIR/<name>.mtx exists):
   laplacian4096  5-pt Laplacian on a 4096^2 grid, 16.7 M rows, 83.9 M nnz  (config 4; default —
                  the >= 10 M-nnz fp64 case the roofline target is quoted on, fits one GPU)
-  scircuit       circuit-like, 171 k rows, ~1 M nnz (config 2)       webbase   power-law 1 M rows (config 3)
-  nlpkkt160      KKT-like, 8.2 M rows, 1.66e8 nnz, fp32 by default (config 5)
+  scircuit       circuit-like, 170,998 rows, 958,936 nnz (config 2)   webbase   power-law, 1,000,005 rows, 3,105,536 nnz (config 3)
+  nlpkkt160      KKT-like, 8,345,600 rows, 229,518,112 nnz, fp32 by default (config 5)
 Multi-GPU: contiguous nnz-balanced tile-row blocks, one rank per GPU, x replicated, y left
 sharded (the SpMV needs no collective: SURVEY.md §8e) => "scaling": "strong" on the fixed matrix;
 --combine allgather|allreduce adds the RCCL y combine to every step, and the default run also
@@ -49,12 +49,13 @@ def build_matrix(name):
     if name.startswith("band"):  # e.g. band40_2000000: full band, half-bandwidth 40 (dense-tile dominated)
         hbw, nn = name[4:].split("_")
         return G.band(int(nn), int(hbw)) + ("synthetic full band hbw=%s" % hbw,)
+    # stand-ins sized like the matrices they stand for (reference src/external/CSR5_cuda/2757-matrix.csv:544,:2379,:1903)
     if name == "scircuit":
-        return G.circuit_like(170998, seed=1) + ("synthetic circuit-like stand-in for scircuit",)
+        return G.retarget_nnz(*G.circuit_like(170998, seed=1), target_nnz=958936, seed=1) + ("synthetic circuit-like stand-in for scircuit, same rows / nnz",)
     if name == "webbase":
-        return G.powerlaw(1000005, seed=2) + ("synthetic power-law stand-in for webbase-1M",)
+        return G.retarget_nnz(*G.powerlaw(1000005, seed=2), target_nnz=3105536, seed=2) + ("synthetic power-law stand-in for webbase-1M, same rows / nnz",)
     if name == "nlpkkt160":
-        return G.kkt_like(160, seed=5) + ("synthetic KKT-like stand-in for nlpkkt160",)
+        return G.nlpkkt_like(160) + ("synthetic KKT stand-in for nlpkkt160, same rows / nnz",)
     raise SystemExit("unknown workload " + name)
 
 
@@ -369,7 +370,8 @@ def main():
         "dtype": "f64" if dtype == np.float64 else "f32", "data": "synthetic (reference driver data: val[i]=i%10, x[i]=i%10)",
         "config": {"workload": args.workload, "source": source, "rows": rows, "cols": n, "nnz": nnz,
                    "partition": "tile-row blocks, nnz-balanced, %d rank(s)" % world, "y_combine": args.combine, "backend": args.backend if world > 1 else None,
-                   "tiles": info["tiles"], "tasks": info["num_tasks"], "coo_mode": info["coo_mode"], "dense_mode": info["dense_mode"]},
+                   "tiles": info["tiles"], "tasks": info["num_tasks"], "coo_mode": info["coo_mode"], "dense_mode": info["dense_mode"],
+                   "entry_mode": info["entry_mode"], "sums_bit_reproducible": bool(info["entry_ordered"]), "strip_cost": info["strip_cost"]},
         "hbm_gbps_algorithmic": round(b_alg_total / (wall / args.steps) * 1e-9, 1),
         "hbm_roofline_frac": round(b_alg_total / (wall / args.steps) * 1e-9 / (HBM_PEAK_GBPS * world), 4),
         "roofline": roofline, "check": check,
@@ -418,7 +420,9 @@ def main():
                     ok2 = bool(np.array_equal(yd2.cpu().numpy()[:r2].astype(np.float64), ref2))
                     rec[label] = {"ms_per_spmv": round(ms2, 5), "gflops": round(2.0 * nz2 / ms2 * 1e-6, 1),
                                   "hbm_gbps_algorithmic": round(b2 / ms2 * 1e-6, 1), "frac_of_8TBps": round(b2 / ms2 * 1e-6 / HBM_PEAK_GBPS, 4),
-                                  "check": "pass" if ok2 else "FAIL", "fallback_nnz": p2.info()["fallback_nnz"]}
+                                  "check": "pass" if ok2 else "FAIL", "fallback_nnz": p2.info()["fallback_nnz"],
+                                  "entry_mode": p2.info()["entry_mode"], "sums_bit_reproducible": bool(p2.info()["entry_ordered"]),
+                                  "strip_cost": p2.info()["strip_cost"], "tasks": p2.info()["num_tasks"]}
                     p2.close()
                     del yd2
                 out["other_workloads"][wl] = rec

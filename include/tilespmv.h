@@ -268,6 +268,9 @@ enum {
     TILESPMV_INFO_FALLBACK_NNZ = 10,  /* nonzeros executed by the CSR fallback kernel */
     TILESPMV_INFO_BUILD_US = 11,      /* host time of the re-layout (plan build), microseconds */
     TILESPMV_INFO_UPLOAD_US = 12,     /* hipMalloc + hipMemcpy time of the plan's streams, microseconds */
+    TILESPMV_INFO_ENTRY_MODE = 13,    /* COO entry lists run per strip (0), per wavefront (1), per workgroup (2) */
+    TILESPMV_INFO_ENTRY_ORDERED = 14, /* 1: the order of the additions is fixed by the plan (bit-reproducible y) */
+    TILESPMV_INFO_STRIP_COST = 15,    /* strip size target the plan was cut with */
     TILESPMV_INFO_COUNT = 16
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);

@@ -17,7 +17,7 @@ _U = C.POINTER(C.c_uint)
 _CACHE = {}
 
 INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel",
-              "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us"]
+              "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us", "entry_mode", "entry_ordered", "strip_cost"]
 
 
 class PlanOptions(C.Structure):

@@ -24,6 +24,8 @@
 // x is staged per tile as a 16-value LDS segment (the reference: s_x_warp / register + shfl).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "hip_plan.h"
 
 namespace tilespmv {
@@ -374,33 +376,106 @@ typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 #ifndef NT_Y
 #define NT_Y 1  // y is written once and not re-read by this kernel: streaming (nontemporal) stores keep it from displacing x in L2 (+1-2 %)
 #endif
+#ifndef WCOO_HEAVY_CT
+#define WCOO_HEAVY_CT 6  // sub-chunks of 64 entries per trip of an entry-heavy wavefront
+#endif
 #ifndef UNITS_MIN_WAVES
 #define UNITS_MIN_WAVES 8  // waves per SIMD asked of the register allocator (64 VGPRs)
 #endif
 
-template <int UB, int XCD_REMAP, bool NT>
-__global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+// ---- wave-cooperative entry phase of k_units<.., 1>: the COO entry lists of the wavefront's four strips, merged and ordered
+// by column at plan time, are walked by all 64 lanes; products go to the owning strip's slab of the wavefront's part of
+// s_y with ds_add (column word = global column | strip-in-wavefront << 28).  A wavefront's time follows its TOTAL entry
+// count, not its longest strip; every load is a full 64-lane access; neighbouring lanes of a gather read the same or
+// adjacent x lines, and the four wavefronts of a workgroup sweep the columns side by side, so they find each other's lines
+// in the CU's L1.  Only this wavefront adds into its slabs: the order of the additions is fixed by the plan (bit-
+// reproducible).  CT x 64 entries per trip: every load of a trip, then its gathers, then the adds.
+template <int CT>
+__device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t *__restrict__ x, val_t *swave, int lane, int gb, int ge)
+{
+    const bool coo_nt = S.coo_nt != 0;
+    for (int e0 = gb; e0 < ge; e0 += 64 * CT) {
+        int cc[CT]; unsigned rb[CT]; val_t cv[CT], xx[CT];
+#pragma unroll
+        for (int q = 0; q < CT; q++) {
+            const int e = min(e0 + 64 * q + lane, ge - 1);
+            // the entry streams are read once: the nontemporal hint is meant to keep them out of the CU's 32 KB L1 (measured neutral)
+            rb[q] = stream_load(S.grow + e, coo_nt); cc[q] = stream_load(S.gcol + e, coo_nt); cv[q] = stream_load(S.gval + e, coo_nt);
+        }
+#pragma unroll
+        for (int q = 0; q < CT; q++) xx[q] = x[cc[q] & 0x0FFFFFFF];
+#pragma unroll
+        for (int q = 0; q < CT; q++)
+            if (e0 + 64 * q + lane < ge) atomicAdd(&swave[((unsigned)cc[q] >> 28) * (STRIP_MAX_ROWS * 16) + rb[q]], cv[q] * xx[q]);
+    }
+}
+
+// ---- workgroup-cooperative entry phase of k_units<.., 2>: the entries of the workgroup's 16 strips, merged and ordered by
+// column at plan time, walked by all 256 lanes.  Neighbouring lanes of a gather then read the same or adjacent x lines: on
+// power-law matrices the number of distinct x lines per batch drops from 0.48 per entry (one strip at a time) to 0.15
+// (64 tile-rows at a time), and the CU's L1 -> L2 request rate is what bounds those matrices.
+template <int CT>
+__device__ __forceinline__ void wg_entry_trips(const DevStream &S, const val_t *__restrict__ x, val_t *sy, int tid, int gb, int ge)
+{
+    const bool coo_nt = S.coo_nt != 0;
+    for (int e0 = gb; e0 < ge; e0 += 256 * CT) {
+        int cc[CT]; unsigned rb[CT]; val_t cv[CT], xx[CT];
+#pragma unroll
+        for (int q = 0; q < CT; q++) {
+            const int e = min(e0 + 256 * q + tid, ge - 1);
+            rb[q] = stream_load(S.grow + e, coo_nt); cc[q] = stream_load(S.gcol + e, coo_nt); cv[q] = stream_load(S.gval + e, coo_nt);
+        }
+#pragma unroll
+        for (int q = 0; q < CT; q++) xx[q] = x[cc[q] & 0x0FFFFFFF];
+        if (S.coo_ordered) {
+            // the four wavefronts add in turn: the order of the additions into one y element is then fixed by the plan (entry
+            // order inside a wavefront instruction, instruction order inside a wavefront, wavefront 0..3 inside a trip), not by
+            // timing, and two launches give the same bits (the reference's atomicAdd, src/tilespmv_cuda.h:784-790, does not)
+            for (int w = 0; w < 4; w++) {
+                if ((tid >> 6) == w) {
+#pragma unroll
+                    for (int q = 0; q < CT; q++)
+                        if (e0 + 256 * q + tid < ge) atomicAdd(&sy[((unsigned)cc[q] >> 28) * (STRIP_MAX_ROWS * 16) + rb[q]], cv[q] * xx[q]);
+                }
+                __syncthreads();
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < CT; q++)
+                if (e0 + 256 * q + tid < ge) atomicAdd(&sy[((unsigned)cc[q] >> 28) * (STRIP_MAX_ROWS * 16) + rb[q]], cv[q] * xx[q]);
+        }
+    }
+}
+
+// ECOO: how the COO entry lists are executed — 0 per 16-lane strip (regular matrices: a handful of entries per strip),
+// 1 per wavefront (the four strips' lists concatenated), 2 per workgroup (merged + column-ordered list, see above).
+template <int UB, int XCD_REMAP, int ECOO>
+__global__ __launch_bounds__(256, ECOO ? UNITS_MIN_WAVES - 1 : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
+    constexpr bool NT = false;  // nontemporal value loads: measured neutral
     __shared__ val_t s_y[GROUPS_PER_BLOCK][STRIP_MAX_ROWS][16];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), each
-    // with a private L2; the XCD_REMAP variants give every XCD contiguous runs of strips (bijective
-    // for any grid size, cdna_hip_programming.md T1).  Placement only affects speed (measured: none).
+    // with a private L2; XCD_REMAP = 2 gives every XCD runs of xcd_chunk consecutive workgroups inside
+    // windows of 8 x xcd_chunk (bijective for any grid size, cdna_hip_programming.md T1).  Speed only.
     unsigned bid = blockIdx.x;
-    if (XCD_REMAP == 1) {
-        const unsigned nb = gridDim.x, q = nb >> 3, rem = nb & 7u, xcd = bid & 7u, idx = bid >> 3;
-        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-    } else if (XCD_REMAP >= 2) {
+    if (XCD_REMAP == 2) {
         const unsigned C = (unsigned)xcd_chunk, W = 8u * C, win = bid / W, off = bid % W, k = off & 7u;
-        if ((win + 1) * W <= gridDim.x) bid = win * W + k * C + ((off >> 3) + (XCD_REMAP == 3 ? k * (C >> 3) + k : 0u)) % C;
+        if ((win + 1) * W <= gridDim.x) bid = win * W + k * C + (off >> 3);
     }
     const long long task_id = (long long)bid * GROUPS_PER_BLOCK + g;
-    if (task_id >= S.ntasks) return;  // whole strips only: no wave-wide operation below
-    const int4 t0 = reinterpret_cast<const int4 *>(S.task)[task_id * 2];
-    const int4 t1 = reinterpret_cast<const int4 *>(S.task)[task_id * 2 + 1];
+    const bool have = task_id < S.ntasks;
+    constexpr bool WCOO = ECOO == 1;
+    if (ECOO == 1) { if ((long long)bid * GROUPS_PER_BLOCK + (g & ~3) >= S.ntasks) return; }  // whole wavefronts leave together (wave-cooperative entry phase)
+    else if (ECOO == 0 && !have) return;                                                      // ECOO == 2: every wavefront reaches the two barriers
+    int4 t0 = make_int4(0, 0, 0, 0), t1 = make_int4(0, -1, 0, 0);
+    if (have) {
+        t0 = reinterpret_cast<const int4 *>(S.task)[task_id * 2];
+        t1 = reinterpret_cast<const int4 *>(S.task)[task_id * 2 + 1];
+    }
     const int unit_begin = t0.x, unit_end = t0.y, coo_begin = t0.z, coo_end = t0.w;
     const int row0 = t1.x, part = t1.y, nrows = t1.w;
     const unsigned nounit = (unsigned)t1.z;
@@ -415,13 +490,55 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
     const int last_grp = unit_begin + (unit_end - 1 - unit_begin) / UNIT_GROUP * UNIT_GROUP;  // first unit of the task's last group
     const bool have_units = unit_begin < unit_end;
     const long long xlast = (long long)colA - 1;  // row units of a partial last column block: zero payload, clamped x index
+    const int ncoo = coo_end - coo_begin;
+    uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
+    val_t v[UB];
+    auto unit_prologue = [&]() {  // descriptor chunks 0 and 1, first value batch: in flight across the entry phase
+        if (have_units) {
+            dcur = load_udesc(S.udesc, min(unit_begin + r, last));
+            dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
+#pragma unroll
+            for (int k = 0; k < UB; k += G) {
+                const grp_t pv = stream_load(ugrp + (long long)min(unit_begin + k, last_grp) * (16 / G), NT);
+#pragma unroll
+                for (int q = 0; q < G; q++) v[k + q] = pv[q];
+            }
+        }
+    };
 
+    if constexpr (ECOO == 2) {
+        const int2 wr = S.wg_coo[bid];
+        if (wr.y > wr.x) {  // workgroup-uniform
+            if (side) for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
+            __syncthreads();
+        }
+        unit_prologue();
+        if (wr.y > wr.x) {
+            wg_entry_trips<WCOO_HEAVY_CT>(S, x, &s_y[0][0][0], tid, wr.x, wr.y);
+            __syncthreads();
+        }
+    } else if constexpr (WCOO) {
+        const int lane = tid & 63;
+        const int2 wr = S.wg_coo[(long long)bid * (GROUPS_PER_BLOCK / 4) + (g >> 2)];  // this wavefront's merged list
+        const int tot = wr.y - wr.x;
+        val_t *swave = &s_y[g & ~3][0][0];  // the wavefront's four slabs of STRIP_MAX_ROWS x 16 values
+        if (tot > 0) {
+            if (side) for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
+            wave_lds_fence();
+        }
+        // more than one light trip's worth: the entry list runs first, 6 x 64 per trip, and the unit pipeline starts
+        // afterwards (registers); otherwise the unit prologue loads stay in flight across the single 4 x 64 trip
+        const bool wave_heavy = tot > S.coo_heavy_min;
+        if (wave_heavy) wave_entry_trips<WCOO_HEAVY_CT>(S, x, swave, lane, wr.x, wr.y);
+        unit_prologue();
+        if (tot > 0 && !wave_heavy) wave_entry_trips<4>(S, x, swave, lane, wr.x, wr.y);
+        if (tot > 0) wave_lds_fence();
+    } else {
     // ---- issue order: first COO chunk, descriptor chunk 0 (+1), first value batch: all in flight together.
     // Strips with many COO entries (> coo_heavy_min, default 32: irregular matrices) run their entry list first,
     // 6 x 16 entries per trip with every load of a trip in flight before its gathers, and only then start the
     // unit pipeline; the others keep the unit prologue in flight across their (short) entry list.
     constexpr int CT = 6;  // sub-chunks of 16 entries per trip
-    const int ncoo = coo_end - coo_begin;
     const bool coo_heavy = ncoo > S.coo_heavy_min;
     if (side) {
         for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
@@ -446,18 +563,7 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
     unsigned rb0 = 0; int cc0 = 0; val_t cv0 = 0;
     const bool coo0 = side && !coo_heavy && (coo_begin + r < coo_end);
     if (coo0) { rb0 = S.crow[coo_begin + r]; cc0 = S.ccol[coo_begin + r]; cv0 = S.cval[coo_begin + r]; }
-    uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
-    val_t v[UB];
-    if (have_units) {
-        dcur = load_udesc(S.udesc, min(unit_begin + r, last));
-        dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
-#pragma unroll
-        for (int k = 0; k < UB; k += G) {
-            const grp_t pv = stream_load(ugrp + (long long)min(unit_begin + k, last_grp) * (16 / G), NT);
-#pragma unroll
-            for (int q = 0; q < G; q++) v[k + q] = pv[q];
-        }
-    }
+    unit_prologue();
     if (side && !coo_heavy) {  // up to coo_heavy_min entries: 16 with the prologue loads, the rest 4 x 16 per trip
         if (coo0) atomicAdd(&s_y[g][rb0 >> 4][rb0 & 15u], cv0 * x[cc0]);
         for (int e0 = coo_begin + 16; e0 < coo_end; e0 += 64) {
@@ -474,6 +580,7 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
                 if (e0 + 16 * q + r < coo_end) atomicAdd(&s_y[g][rb[q] >> 4][rb[q] & 15u], cv[q] * xx[q]);
         }
         wave_lds_fence();
+    }
     }
 
     val_t acc = 0;
@@ -552,8 +659,14 @@ __global__ __launch_bounds__(256, UNITS_MIN_WAVES) void k_units(DevStream S, int
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (prev == (unsigned)f.count - 1u) {
                 val_t sum = 0;
-                for (int k = 0; k < f.count; k++)
-                    sum += __hip_atomic_load(&partial[(long long)(f.first + k) * 16 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k0 = 0; k0 < f.count; k0 += 8) {  // 8 slot loads in flight, added in slot order
+                    val_t sv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        sv[j] = __hip_atomic_load(&partial[(long long)(f.first + min(k0 + j, f.count - 1)) * 16 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) if (k0 + j < f.count) sum += sv[j];
+                }
                 const long long yi = (long long)f.row * 16 + r;
                 if (yi < rowA) y[yi] = sum;
                 if (r == 0) __hip_atomic_store(&S.ifix_count[nounit], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
@@ -957,19 +1070,16 @@ hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const De
     }
 }
 
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int ub, int xcd_remap, int xcd_chunk, bool nt,
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st)
 {
     if (S.ntasks > 0) {
         const dim3 grid((unsigned)((S.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), blk(256);
-#define TSPMV_L3(U, X, N) hipLaunchKernelGGL((k_units<U, X, N>), grid, blk, 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
-#define TSPMV_L2(U, X) do { if (nt) TSPMV_L3(U, X, true); else TSPMV_L3(U, X, false); } while (0)
-#define TSPMV_L1(U) do { if (xcd_remap == 1) TSPMV_L2(U, 1); else if (xcd_remap == 2) TSPMV_L2(U, 2); else if (xcd_remap == 3) TSPMV_L2(U, 3); else TSPMV_L2(U, 0); } while (0)
-        if constexpr (UNIT_GROUP <= 2) { if (ub == 2) { TSPMV_L1(2); } else if (ub == 8) { TSPMV_L1(8); } else { TSPMV_L1(4); } }
-        else { if (ub == 8) { TSPMV_L1(8); } else { TSPMV_L1(4); } }  // fp32: a batch is whole groups of 4 units
+#define TSPMV_L2(X, W) hipLaunchKernelGGL((k_units<4, X, W>), grid, blk, 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_L1(X) do { if (entry_mode == 2) TSPMV_L2(X, 2); else if (entry_mode == 1) TSPMV_L2(X, 1); else TSPMV_L2(X, 0); } while (0)
+        if (xcd_remap == 2) TSPMV_L1(2); else TSPMV_L1(0);
 #undef TSPMV_L1
 #undef TSPMV_L2
-#undef TSPMV_L3
     }
     // whole-tile passes (y += ...): CSR tiles kept as tiles, dense tiles on the matrix cores; then the split-row fix-up
     hipError_t e = launch_tiles_direct(P, dense_mfma, /*accumulate=*/true, /*fixup=*/false, x, y, st);

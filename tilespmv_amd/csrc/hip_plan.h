@@ -95,7 +95,15 @@ struct DevStream {
     const unsigned char *crow;
     const STask *task;
     int ntasks;
-    int coo_heavy_min;                    // strips with more COO entries than this run their entry list before the unit pipeline
+    int coo_heavy_min;                    // strips (wavefronts, with the wave-cooperative entry phase) with more COO entries than this run their entry list before the unit pipeline
+    int coo_nt;                           // entry streams loaded with the nontemporal hint
+    int coo_ordered;                      // workgroup entry mode: wavefronts add in turn (bit-reproducible sums)
+    // entry mode 2 (k_units<.., 2>): the entries of the 16 strips of one workgroup, merged and ordered by column, so that
+    // the lanes of one gather share x lines; column word = global column | strip-in-workgroup << 28, row byte as in crow
+    const int2 *wg_coo;                   // per workgroup: [begin, end) in gval / gcol / grow
+    const val_t *gval;
+    const int *gcol;
+    const unsigned char *grow;
     // split tile-rows whose pieces all live in the unit kernel are summed in that kernel by the piece that
     // finishes last (fixed slot order): ifix[i] describes row i, ifix_count[i] counts finished pieces
     const FixRow *ifix;

@@ -17,7 +17,7 @@
 namespace tilespmv {
 
 hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulate, bool fixup, const val_t *x, val_t *y, hipStream_t st);
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int ub, int xcd_remap, int xcd_chunk, bool nt,
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, const val_t *X, val_t *Y,
@@ -55,9 +55,8 @@ struct tilespmv_plan {
     DevPlan dev{};
     DevStream st{};
     DevDense dn{};
-    int unit_batch = 4;
     int xcd_remap = 2, xcd_chunk = 32;  // windows of 8 x 32 workgroups: neighbouring strips share an XCD L2 (sweep 4..64: flat within 2.5 %, 32 best on 3 of 4 large matrices)
-    bool nontemporal = false;
+    int entry_mode = 0;                 // COO entry lists walked per 16-lane strip (0), per wavefront (1) or per workgroup, column-ordered (2)
     std::vector<void *> allocs;
     long long info[TILESPMV_INFO_COUNT] = {0};
     int coo_mode = 0, dense_mode = 0, kernel = 0;
@@ -228,7 +227,7 @@ inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, i
 }  // namespace
 
 static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,
-                        bool dense_mfma, bool csr_split, const std::vector<long long> &hyb_off, int target, int split_above, int piece,
+                        bool dense_mfma, bool csr_split, const std::vector<long long> &hyb_off, int target_in, int split_above_in,
                         std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes)
 {
     const int tilem = T->tilem, tilen = T->tilen, ntr = std::max(0, tr1 - tr0), sv = (int)sizeof(val_t);
@@ -256,6 +255,35 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     std::vector<Task> htasks;
     std::vector<FixRow> ifix, fix_late;   // split rows summed inside the unit kernel / by k_fixup_split after all passes
     const bool fix_inline_on = env_int("TILESPMV_FIX_INLINE", 1) != 0;
+    // Entry lists walked by whole wavefronts (k_units<.., WCOO>): on when the shard is entry-heavy.  The per-strip form
+    // stays for regular matrices, where a strip has a handful of entries and the wave-wide index arithmetic is pure cost.
+    // How the COO entry lists run (TILESPMV_WAVE_COO = 0 / 1 / 2 overrides):
+    //   0  per 16-lane strip — regular matrices (a handful of entries per strip);
+    //   1  per wavefront, the four strips' lists merged and ordered by column — entry-heavy but small grids, where the
+    //      kernel is a chain of round trips and a workgroup barrier costs more than shared x lines save;
+    //   2  per workgroup, the sixteen strips' lists merged and ordered by column — entry-heavy shards that fill the chip:
+    //      distinct x lines per batch drop 3x and the CU's L1 -> L2 request rate is what bounds those.
+    // Strip size.  Regular matrices: ~400 cost units (20 units) amortise the per-strip round trips; flat between 200 and 800
+    // on large matrices.  Entry-heavy shards want MANY tile-rows per workgroup (power-law 8 M rows: 0.149 ms at 400,
+    // 0.120 ms at 1600) but still >= 4 workgroups per CU (webbase-like best at 800, scircuit-like at <= 400).
+    const bool entry_heavy = NC >= 6LL * ntr;
+    long long total_cost = 0;
+    for (int i = 0; i < ntr; i++) total_cost += rc_[i].cost;
+    int target = target_in;
+    if (target <= 0) target = entry_heavy ? (int)std::min<long long>(1600, std::max<long long>(400, total_cost / (4 * 256 * 16))) : 400;
+    target = std::max(32, target);
+    const long long est_wgs = total_cost / (16LL * target) + 1;
+    const int wave_coo_env = env_int("TILESPMV_WAVE_COO", -1);
+    const int entry_mode = wave_coo_env >= 0 ? std::min(2, wave_coo_env) : (!entry_heavy ? 0 : est_wgs < 768 ? 1 : 2);
+    const bool wave_coo = entry_mode != 0;
+    plan->entry_mode = entry_mode;
+    // Workgroup mode: the four wavefronts add into shared slabs.  Taking turns (4 barriers per trip) fixes the order of the
+    // additions -> bit-reproducible sums; free or a gain on large grids (fewer LDS conflicts: power-law 8 M rows 0.122 ->
+    // 0.118 ms), +8 % on mid-size ones (webbase-like 14.2 -> 15.3 us), which therefore add unordered unless
+    // TILESPMV_COO_ORDERED=1 asks for reproducible bits.  Modes 0 and 1 are always ordered (one wavefront per slab).
+    const int ordered_env = env_int("TILESPMV_COO_ORDERED", -1);
+    const bool coo_ordered = ordered_env >= 0 ? ordered_env != 0 : est_wgs >= 2048;
+    const int split_above = std::max(6 * target, split_above_in), piece = std::max(2 * target, split_above / 3);
     const int strip_even = env_int("TILESPMV_STRIP_EVEN", 4);  // 0 off, 1 = value group, n > 1 = multiples of n units
     std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
     auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
@@ -276,7 +304,8 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         if (must_split(i)) {
             row_split[i] = 1;
             FixRow f{tr0 + i, npartial, 0, 0};
-            const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, env_int("TILESPMV_COO_PIECE", piece / std::max(1, env_int("TILESPMV_COO_COST", 4))));
+            // entry pieces: four consecutive pieces share a wavefront, which walks their lists together (4 x 192 = 2 trips of 6 x 64)
+            const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, env_int("TILESPMV_COO_PIECE", entry_mode == 1 ? 192 : piece / std::max(1, env_int("TILESPMV_COO_COST", 4))));
             for (long long u = pu[i]; u < pu[i + 1]; u += pu_) {
                 STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
                 k.unit_begin = (int)u; k.unit_end = (int)std::min(pu[i + 1], u + pu_);
@@ -323,7 +352,13 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         int jend = i;
         {
             long long cc = 0;
-            while (jend < ntr && jend - i < STRIP_MAX_ROWS && !must_split(jend) && (jend == i || cc + rc_[jend].cost <= target)) { cc += rc_[jend].cost; jend++; }
+            while (jend < ntr && jend - i < STRIP_MAX_ROWS && !must_split(jend)) {
+                const long long nc = cc + rc_[jend].cost;
+                // entry-heavy shards round to the nearest strip size (rows cost 100-400 each there: "never above the target"
+                // would leave most strips half empty and double the number of wavefronts)
+                if (jend > i && nc > target && !(wave_coo && nc - target < target - cc && nc <= target + target / 2)) break;
+                cc = nc; jend++;
+            }
             // (whole batches of 4 units, which are also whole value groups: a half-empty last batch costs as much as a full one)
             const int quantum = strip_even > 1 ? strip_even : UNIT_GROUP;
             auto pad = [&](int e) { return (int)((quantum - (pu[e] - pu[i]) % quantum) % quantum); };
@@ -495,7 +530,29 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     auto padded = [&](long long n) { return (n + G - 1) / G * G; };
     long long NUP = 0;
     for (const STask &k : tasks) NUP += padded(k.unit_end - k.unit_begin);
-    if (NUP > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit unit ids\n"); return -2; }
+    if (NUP > INT32_MAX) {
+        fprintf(stderr, "tilespmv: shard too large for 32-bit unit ids\n");
+        free(h_uval); free(h_cval); free(h_hval); free(h_hidx); free(h_dval);
+        return -2;
+    }
+    if (env_int("TILESPMV_COO_SORT", 0) != 0) {
+        // entries of one strip ordered by column: neighbouring lanes of a gather then share x lines (the order of the
+        // additions into one y element changes with it; the list has no other consumer that depends on its order)
+        parallel_chunks((int64_t)tasks.size(), 256, [&](int64_t b, int64_t e, int) {
+            std::vector<std::pair<long long, int>> key;
+            std::vector<val_t> tv; std::vector<int> tc; std::vector<unsigned char> tr;
+            for (int64_t i = b; i < e; i++) {
+                const STask &k = tasks[(size_t)i];
+                const int n = k.coo_end - k.coo_begin;
+                if (n < 2) continue;
+                key.resize((size_t)n); tv.resize((size_t)n); tc.resize((size_t)n); tr.resize((size_t)n);
+                for (int q = 0; q < n; q++) key[(size_t)q] = {((long long)h_ccol[(size_t)k.coo_begin + q] << 20) | q, q};
+                std::sort(key.begin(), key.end());
+                for (int q = 0; q < n; q++) { const int o = k.coo_begin + key[(size_t)q].second; tv[(size_t)q] = h_cval[o]; tc[(size_t)q] = h_ccol[(size_t)o]; tr[(size_t)q] = h_crow[(size_t)o]; }
+                for (int q = 0; q < n; q++) { const int o = k.coo_begin + q; h_cval[o] = tv[(size_t)q]; h_ccol[(size_t)o] = tc[(size_t)q]; h_crow[(size_t)o] = tr[(size_t)q]; }
+            }
+        });
+    }
     {
         std::vector<UDesc> packed((size_t)NUP, UDesc{0u, 0u, 0u});
         val_t *paired = zalloc<val_t>((size_t)NUP * 16);
@@ -519,6 +576,47 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc);
         rc |= plan->upload(paired, (size_t)NUP * 16, &S.uval);
         free(paired);
+    }
+    S.wg_coo = nullptr; S.gval = nullptr; S.gcol = nullptr; S.grow = nullptr;
+    if (entry_mode != 0) {
+        const size_t GS = entry_mode == 2 ? 16 : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
+        const size_t nwg = (tasks.size() + GS - 1) / GS;
+        std::vector<int2> wg((size_t)nwg);
+        long long at = 0;
+        for (size_t w = 0; w < nwg; w++) {
+            long long n = 0;
+            for (size_t t = GS * w; t < std::min(tasks.size(), GS * w + GS); t++) n += tasks[t].coo_end - tasks[t].coo_begin;
+            wg[w] = make_int2((int)at, (int)(at + n));
+            at += n;
+        }
+        val_t *g_val = zalloc<val_t>((size_t)NC);
+        std::vector<int> g_col((size_t)NC);
+        std::vector<unsigned char> g_row((size_t)NC);
+        parallel_chunks((int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
+            std::vector<std::pair<unsigned long long, int>> key;
+            for (int64_t w = b; w < e; w++) {
+                key.clear();
+                for (size_t t = GS * (size_t)w; t < std::min(tasks.size(), GS * (size_t)w + GS); t++)
+                    for (int q = tasks[t].coo_begin; q < tasks[t].coo_end; q++)   // column-major order; ties keep strip / list order
+                        key.push_back({((unsigned long long)(unsigned)h_ccol[(size_t)q] << 32) | (unsigned long long)key.size(), (int)((t & (GS - 1)) << 28)});
+                // remember the source position next to the key: rebuild it from the running index
+                std::vector<int> src; src.reserve(key.size());
+                for (size_t t = GS * (size_t)w; t < std::min(tasks.size(), GS * (size_t)w + GS); t++)
+                    for (int q = tasks[t].coo_begin; q < tasks[t].coo_end; q++) src.push_back(q);
+                std::sort(key.begin(), key.end());
+                long long o = wg[(size_t)w].x;
+                for (const auto &k : key) {
+                    const int q = src[(size_t)(k.first & 0xFFFFFFFFull)];
+                    g_val[o] = h_cval[q]; g_col[(size_t)o] = h_ccol[(size_t)q] | k.second; g_row[(size_t)o] = h_crow[(size_t)q];
+                    o++;
+                }
+            }
+        });
+        rc |= plan->upload(wg.data(), wg.size(), &S.wg_coo);
+        rc |= plan->upload(g_val, (size_t)NC, &S.gval);
+        rc |= plan->upload(g_col.data(), (size_t)NC, &S.gcol);
+        rc |= plan->upload(g_row.data(), (size_t)NC, &S.grow);
+        free(g_val);
     }
     rc |= plan->upload(h_cval, (size_t)NC, &S.cval);
     rc |= plan->upload(h_ccol.data(), (size_t)NC, &S.ccol);
@@ -548,7 +646,13 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     }
     rc |= plan->upload(fix_late.data(), fix_late.size(), &plan->dev.fix_late);
     plan->dev.nfix_late = (int)fix_late.size();
-    S.coo_heavy_min = std::max(0, env_int("TILESPMV_COO_HEAVY_MIN", 32));  // swept on KKT fp64 / scircuit / webbase stand-ins: 32 best or within 1 %
+    // per strip (default 32; swept on KKT fp64 / scircuit / webbase stand-ins: best or within 1 %), per wavefront with wave_coo (256 = one light trip)
+    S.coo_heavy_min = std::max(0, env_int("TILESPMV_COO_HEAVY_MIN", wave_coo ? 256 : 32));
+    S.coo_nt = env_int("TILESPMV_COO_NT", 0);
+    S.coo_ordered = coo_ordered ? 1 : 0;
+    plan->info[TILESPMV_INFO_ENTRY_MODE] = entry_mode;
+    plan->info[TILESPMV_INFO_ENTRY_ORDERED] = (entry_mode != 2 || coo_ordered) ? 1 : 0;
+    plan->info[TILESPMV_INFO_STRIP_COST] = target;
     n_tasks = (long long)tasks.size();
     model_bytes = NUP * (12 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
@@ -720,16 +824,15 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     }
 
     plan->kernel = kernel;
-    plan->unit_batch = env_int("TILESPMV_UNIT_BATCH", 4);
-    plan->xcd_remap = env_int("TILESPMV_XCD_REMAP", 2);
+    plan->xcd_remap = env_int("TILESPMV_XCD_REMAP", 2) ? 2 : 0;  // 0 = round-robin, 2 = windows of 8 x xcd_chunk workgroups
     plan->xcd_chunk = std::max(1, env_int("TILESPMV_XCD_CHUNK", 32));
-    plan->nontemporal = env_int("TILESPMV_NT", 0) != 0;
     // Strip size: ~400 cost units (20 units) amortises the per-strip round trips; measured flat between 200
     // and 800 on large matrices and neutral on small (cache-resident) ones, where launch latency dominates.
-    int target = env_int("TILESPMV_STRIP_COST", 0);
-    if (target <= 0) target = kernel == TILESPMV_KERNEL_STREAM ? 400 : 192;
+    const int target_env = env_int("TILESPMV_STRIP_COST", 0), split_env = env_int("TILESPMV_SPLIT_ABOVE", 2400);
+    int target = target_env;    // generation 1 below; the unit-stream builder picks its own default (build_stream)
+    if (target <= 0) target = 192;
     target = std::max(32, target);
-    const int split_above = std::max(6 * target, env_int("TILESPMV_SPLIT_ABOVE", 2400)), piece = std::max(2 * target, split_above / 3);
+    const int split_above = std::max(6 * target, split_env), piece = std::max(2 * target, split_above / 3);
     std::vector<FixRow> fix;
     int npartial = 0;
     long long n_tasks = 0, model_bytes = 0;
@@ -737,7 +840,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     DevPlan &D = plan->dev;
     if (kernel == TILESPMV_KERNEL_STREAM) {
         const bool csr_split = env_int("TILESPMV_CSR_SPLIT", 1) != 0;
-        rc = build_stream(plan, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mode == TILESPMV_DENSE_MFMA, csr_split, hyb_off, target, split_above, piece,
+        rc = build_stream(plan, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mode == TILESPMV_DENSE_MFMA, csr_split, hyb_off, target_env, split_env,
                           fix, npartial, n_tasks, model_bytes);
     } else {
     // ---- pass 1: stream sizes per tile-row
@@ -877,6 +980,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     I[TILESPMV_INFO_COO_MODE] = coo_mode; I[TILESPMV_INFO_DENSE_MODE] = dense_mode; I[TILESPMV_INFO_KERNEL] = plan->kernel;
     I[TILESPMV_INFO_NUM_TASKS] = n_tasks; I[TILESPMV_INFO_NUM_SPLIT_ROWS] = (long long)fix.size();
     I[TILESPMV_INFO_FALLBACK_NNZ] = f_nnz;
+    if (plan->kernel != TILESPMV_KERNEL_STREAM) { I[TILESPMV_INFO_ENTRY_ORDERED] = 1; I[TILESPMV_INFO_STRIP_COST] = target; }
     I[TILESPMV_INFO_BUILD_US] = (long long)(now_us() - t_create0) - I[TILESPMV_INFO_UPLOAD_US];
     // bytes one SpMV has to move at least: the three streams + tasks + x once + y once (+ fallback)
     I[TILESPMV_INFO_STREAM_BYTES] = model_bytes + (long long)colA * sv + (long long)rows * sv +
@@ -889,7 +993,7 @@ int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYP
 {
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = plan->dense_mode == TILESPMV_DENSE_MFMA;
-    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, plan->dn, mfma, plan->unit_batch, plan->xcd_remap, plan->xcd_chunk, plan->nontemporal, d_x, d_y, st)
+    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, plan->dn, mfma, plan->entry_mode, plan->xcd_remap, plan->xcd_chunk, d_x, d_y, st)
                                                           : launch_tiles_direct(plan->dev, mfma, false, true, d_x, d_y, st);
     if (e != hipSuccess) return (int)e;
     return (int)launch_fallback(plan->dev, d_x, d_y, st);

@@ -73,6 +73,30 @@ def from_coo(rows, cols, ri, ci, sort_cols=True):
     return rows, cols, rowptr.astype(np.int32), ci.astype(np.int32)
 
 
+def retarget_nnz(rows, cols, rowptr, colidx, target_nnz, seed=0, near=40):
+    """Same structure with exactly ``target_nnz`` nonzeros: a surplus is removed uniformly at random, a deficit is
+    filled with new off-diagonals within +-``near`` of the diagonal (deterministic for a given seed).  Used to size the
+    SuiteSparse stand-ins like the matrices they stand for (reference src/external/CSR5_cuda/2757-matrix.csv)."""
+    rng = np.random.default_rng(seed)
+    ri = np.repeat(np.arange(rows, dtype=np.int64), np.diff(rowptr))
+    key = ri * cols + np.asarray(colidx, dtype=np.int64)          # sorted and unique: rows ascending, columns ascending inside
+    if len(key) > target_nnz:
+        keep = np.sort(rng.choice(len(key), target_nnz, replace=False))
+        key = key[keep]
+    while len(key) < target_nnz:
+        need = target_nnz - len(key)
+        r = rng.integers(0, rows, int(need * 1.3) + 16)
+        c = np.clip(r + rng.integers(-near, near + 1, r.size), 0, cols - 1)
+        new = np.setdiff1d(np.unique(r * cols + c), key, assume_unique=True)
+        if new.size > need:
+            new = np.sort(rng.choice(new, need, replace=False))
+        key = np.union1d(key, new)
+    ri, ci = key // cols, key % cols
+    rp = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(ri, minlength=rows), out=rp[1:])
+    return rows, cols, rp.astype(np.int32), ci.astype(np.int32)
+
+
 def random_uniform(rows, cols, density, seed):
     rng = np.random.default_rng(seed)
     nnz = int(rows * cols * density)
@@ -176,9 +200,8 @@ def circuit_like(n, seed=1, avg_off=4.6, ndense=6):
 
 
 def kkt_like(g, seed=5):
-    """nlpkkt160 stand-in (BASELINE config 5): symmetric [[H, A^T],[A, 0]] on a g^3 grid —
-    H is a 27-point stencil on g^3 unknowns, A couples each of the g^3 constraints to a 7-point
-    neighbourhood.  g=160 gives 8.19 M rows and ~2.2e8 nnz."""
+    """Small KKT-like test matrix (tests/cases.py ``kkt12``): symmetric [[H, A^T],[A, 0]] on a g^3 grid — H is a
+    27-point stencil on g^3 unknowns, A couples each of the g^3 constraints to a 7-point neighbourhood."""
     n = g * g * g
     idx = np.arange(n, dtype=np.int64)
     z, y, x = idx // (g * g), (idx // g) % g, idx % g
@@ -198,6 +221,73 @@ def kkt_like(g, seed=5):
     rowptr = np.zeros(2 * n + 1, dtype=np.int64)
     np.cumsum(np.bincount(R, minlength=2 * n), out=rowptr[1:])
     return 2 * n, 2 * n, rowptr.astype(np.int32), Cc.astype(np.int32)
+
+
+NLPKKT160_ROWS, NLPKKT160_NNZ = 8345600, 229518112   # reference src/external/CSR5_cuda/2757-matrix.csv:1903
+
+
+def nlpkkt_like(g=160, target_nnz=None, seed=5):
+    """nlpkkt160 stand-in (BASELINE config 5), sized like the real matrix: symmetric [[H, A^T],[A, 0]] with
+    g*g*(g+6) primal unknowns on a (g+6) x g x g grid (H = 27-point stencil) and g^3 constraints, each coupled to a
+    15-point neighbourhood (7-point star + 8 corners) of the primal cell three planes up.  g = 160 gives exactly
+    8,345,600 rows (= 2*160^3 + 6*160^2, the row count of nlpkkt160) and, with ``target_nnz`` (default: the real
+    229,518,112), exactly that many nonzeros: the surplus is taken off one corner coupling, symmetrically, for a hashed
+    subset of the constraints.  Built row by row from ascending candidate columns: no sort of the 2.3e8 entries."""
+    if target_nnz is None and g == 160:
+        target_nnz = NLPKKT160_NNZ
+    gz = g + 6
+    n1, n2 = gz * g * g, g * g * g
+    st27 = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    st15 = sorted([(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)] +
+                  [(a, b, c) for a in (-1, 1) for b in (-1, 1) for c in (-1, 1)])
+    thin = (1, 1, 1)                                        # the coupling that absorbs the surplus
+    # constraint c = (z, y, x) couples to primal (z + 3 + dz, y + dy, x + dx): always inside in z, clipped in y and x
+    c_idx = np.arange(n2, dtype=np.int64)
+    cz, cy, cx = c_idx // (g * g), (c_idx // g) % g, c_idx % g
+    hashv = (c_idx * 2654435761) % (1 << 32)
+
+    def a_valid(dz, dy, dx):
+        return (cy + dy >= 0) & (cy + dy < g) & (cx + dx >= 0) & (cx + dx < g)
+
+    p_idx = np.arange(n1, dtype=np.int64)
+    pz, py, px = p_idx // (g * g), (p_idx // g) % g, p_idx % g
+    h_masks = [((pz + dz >= 0) & (pz + dz < gz) & (py + dy >= 0) & (py + dy < g) & (px + dx >= 0) & (px + dx < g)) for dz, dy, dx in st27]
+    nnz_h = int(sum(int(m.sum()) for m in h_masks))
+    nnz_a = int(sum(int(a_valid(*o).sum()) for o in st15))
+    drop = np.zeros(n2, dtype=bool)
+    if target_nnz is not None:
+        surplus = nnz_h + 2 * nnz_a - target_nnz
+        assert surplus >= 0 and surplus % 2 == 0, (nnz_h, nnz_a, target_nnz)
+        cand = np.nonzero(a_valid(*thin))[0]
+        assert surplus // 2 <= cand.size
+        order = cand[np.argsort(hashv[cand], kind="stable")]
+        drop[order[:surplus // 2]] = True
+    # ---- primal rows: H columns ascending, then the A^T columns (n1 + constraint) ascending
+    cand_cols, cand_mask = [], []
+    for (dz, dy, dx), m in zip(st27, h_masks):
+        cand_cols.append(p_idx + (dz * g + dy) * g + dx); cand_mask.append(m)
+    del h_masks
+    # primal p is coupled to constraint c with p = c + (3 + dz, dy, dx)  <=>  c = p - (3 + dz, dy, dx); ascending c = descending offset
+    for dz, dy, dx in sorted(st15, reverse=True):
+        qz, qy, qx = pz - 3 - dz, py - dy, px - dx
+        ok = (qz >= 0) & (qz < g) & (qy >= 0) & (qy < g) & (qx >= 0) & (qx < g)
+        c = (qz * g + qy) * g + qx
+        if (dz, dy, dx) == thin:
+            ok &= ~drop[np.where(ok, c, 0)]
+        cand_cols.append(n1 + c); cand_mask.append(ok)
+    rp1, ci1 = _from_mask(np.stack(cand_cols, axis=1), np.stack(cand_mask, axis=1))
+    del cand_cols, cand_mask
+    # ---- constraint rows: A columns ascending
+    cand_cols, cand_mask = [], []
+    for dz, dy, dx in st15:
+        ok = a_valid(dz, dy, dx)
+        if (dz, dy, dx) == thin:
+            ok = ok & ~drop
+        cand_cols.append(((cz + 3 + dz) * g + cy + dy) * g + cx + dx); cand_mask.append(ok)
+    rp2, ci2 = _from_mask(np.stack(cand_cols, axis=1), np.stack(cand_mask, axis=1))
+    rowptr = np.concatenate([rp1.astype(np.int64), rp1[-1].astype(np.int64) + rp2[1:].astype(np.int64)])
+    assert rowptr[-1] < 2**31
+    return n1 + n2, n1 + n2, rowptr.astype(np.int32), np.concatenate([ci1, ci2])
 
 
 def write_mtx(path, rows, cols, rowptr, colidx, vals=None, field="real"):
