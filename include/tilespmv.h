@@ -244,9 +244,10 @@ int tilespmv_plan_spmv_n(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_T
 /* Multi-vector form (SpMM; new): Y[rows][nvec] = A_shard * X[colA][nvec], X and Y
  * row-major (the nvec values of one row are contiguous) and 16-byte aligned, nvec in {1, 2, 4, 8}.
  * The matrix is streamed once for all nvec right-hand sides.  d_Y points at row 0 of the full-length
- * Y.  Covered: unit-stream plans with in-tile COO and split CSR tiles (the defaults); returns
- * hipErrorNotSupported (801) for plans built with TILESPMV_COO_FALLBACK, TILESPMV_KERNEL_DIRECT or
- * TILESPMV_CSR_SPLIT=0, hipErrorInvalidValue (1) for other nvec / misaligned pointers. */
+ * Y.  Unit-stream plans with in-tile COO and split CSR tiles (the defaults) run the native multi-vector
+ * kernels; plans built with TILESPMV_COO_FALLBACK, TILESPMV_KERNEL_DIRECT or TILESPMV_CSR_SPLIT=0 go one
+ * right-hand side at a time through their own SpMV (column gathered / scattered by two small kernels).
+ * Returns hipErrorInvalidValue (1) for other nvec / misaligned pointers. */
 #define TILESPMV_MAX_NVEC 8
 int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y, int nvec,
                        void *stream);

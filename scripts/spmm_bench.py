@@ -1,4 +1,4 @@
-"""Multi-vector SpMM vs repeated SpMV on one GPU: python scripts/spmm_bench.py [workload] [dtype]
+"""Multi-vector SpMM vs repeated SpMV on one GPU: python scripts/spmm_bench.py [workload] [dtype] [nvec,nvec,...]
 Prints, per nvec, ms per launch, the equivalent per-vector time, and B_alg-based GB/s where
 B_alg(nvec) = nnz*(s_v+4) + 4(m+1) + nvec*s_v*(n+m)  (matrix once, X and Y per vector)."""
 import json
@@ -29,7 +29,8 @@ def main():
     sv = np.dtype(dtype).itemsize
     out = {"workload": wl, "dtype": np.dtype(dtype).name, "rows": rowA, "nnz": int(rp[rowA]), "results": []}
     rng = np.random.default_rng(0)
-    for nv in (1, 2, 4, 8):
+    nvs = tuple(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else (1, 2, 4, 8)
+    for nv in nvs:
         X = torch.from_numpy(rng.integers(0, 4, (n, nv)).astype(dtype)).cuda()
         Y = torch.zeros((rowA + 16, nv), dtype=tdt, device="cuda")
         ms = plan.time_spmm(X.data_ptr(), Y.data_ptr(), nv, 0, 10, 50)

@@ -509,7 +509,7 @@ def test_spmm_multi_vector_matches_oracle_per_column(torch_cuda, monkeypatch, nv
         plan.close()
 
 
-def test_spmm_real_values_and_unsupported_plans(torch_cuda):
+def test_spmm_real_values_and_plans_without_native_kernel(torch_cuda):
     import torch
     from tilespmv_amd import api
     import scipy.sparse as sp
@@ -534,14 +534,34 @@ def test_spmm_real_values_and_unsupported_plans(torch_cuda):
     with pytest.raises(RuntimeError):
         plan.spmm(Xd.data_ptr() + 8, Yd.data_ptr(), 2)
     plan.close()
-    for kw in ({"coo_mode": api.COO_FALLBACK}, {"kernel": api.KERNEL_DIRECT}):
-        m2, n2, rp2, ci2 = SMALL["powerlaw20k"]()
-        v2 = values_for("powerlaw20k", len(ci2), n2, np.float64)[0]
-        t2 = api.Tile_create(truncated_rows(m2), n2, len(ci2), rp2, ci2, v2)
-        p2 = api.Plan(t2, truncated_rows(m2), n2, len(ci2), **kw)
-        with pytest.raises(NotImplementedError):
-            p2.spmm(Xd.data_ptr(), Yd.data_ptr(), 4)
-        p2.close()
+    # plans without a native multi-vector kernel (CSR fallback, generation 1, whole CSR tiles) go one column at a time
+    # through their own SpMV: same answer, bit for bit on integer data, in a tile-row shard too
+    from oracle.oracle import CpuImpl
+    for name in ("powerlaw20k", "allfmt"):
+        m2, n2, rp2, ci2 = SMALL[name]()
+        r2, z2 = truncated_rows(m2), len(ci2)
+        v2 = values_for(name, z2, n2, np.float64)[0]
+        X2 = np.random.default_rng(9).integers(0, 4, (n2, 4)).astype(np.float64)
+        want = np.stack([CpuImpl("oracle").csr_spmv(r2, rp2, ci2, v2, np.ascontiguousarray(X2[:, j])) for j in range(4)], axis=1)
+        t2 = api.Tile_create(r2, n2, z2, rp2, ci2, v2)
+        X2d = torch.from_numpy(X2).cuda()
+        for kw, env in (({"coo_mode": api.COO_FALLBACK}, {}), ({"kernel": api.KERNEL_DIRECT}, {}), ({"kernel": api.KERNEL_DIRECT, "coo_mode": api.COO_FALLBACK}, {}),
+                        ({}, {"TILESPMV_CSR_SPLIT": "0"})):
+            os.environ.update(env)
+            try:
+                Y2d = torch.full((r2 + 16, 4), -5.0, dtype=torch.float64, device="cuda")
+                b = api.partition_tilerows(t2, 2)
+                for k in range(2):
+                    p2 = api.Plan(t2, r2, n2, z2, tilerow_begin=int(b[k]), tilerow_end=int(b[k + 1]), **kw)
+                    p2.spmm(X2d.data_ptr(), Y2d.data_ptr(), 4)
+                    torch.cuda.synchronize()
+                    p2.close()
+            finally:
+                for q in env:
+                    os.environ.pop(q)
+            Y2 = Y2d.cpu().numpy()
+            assert np.array_equal(Y2[:r2], want) and (Y2[r2:] == -5.0).all(), (name, kw, env)
+        api.Tile_destroy(t2)
 
 
 def test_randomised_structures_short_fuzz(torch_cuda):

@@ -379,6 +379,9 @@ typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 #ifndef WCOO_HEAVY_CT
 #define WCOO_HEAVY_CT 6  // sub-chunks of 64 entries per trip of an entry-heavy wavefront
 #endif
+#ifndef ECOO2_MIN_WAVES
+#define ECOO2_MIN_WAVES 6  // workgroup entry mode: 80 VGPRs
+#endif
 #ifndef UNITS_MIN_WAVES
 #define UNITS_MIN_WAVES 8  // waves per SIMD asked of the register allocator (64 VGPRs)
 #endif
@@ -450,7 +453,7 @@ __device__ __forceinline__ void wg_entry_trips(const DevStream &S, const val_t *
 // ECOO: how the COO entry lists are executed — 0 per 16-lane strip (regular matrices: a handful of entries per strip),
 // 1 per wavefront (the four strips' lists concatenated), 2 per workgroup (merged + column-ordered list, see above).
 template <int UB, int XCD_REMAP, int ECOO>
-__global__ __launch_bounds__(256, ECOO ? UNITS_MIN_WAVES - 1 : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+__global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
@@ -506,6 +509,21 @@ __global__ __launch_bounds__(256, ECOO ? UNITS_MIN_WAVES - 1 : UNITS_MIN_WAVES) 
         }
     };
 
+    // descriptors (from the chunk parked in LDS) and x gathers of one unit batch; j0 = position of the batch in the chunk
+    const uint2 *sd = reinterpret_cast<const uint2 *>(&s_d[g][0]) + (r >> 3);  // this lane's 8-B half of a descriptor
+    uint2 d[UB];
+    val_t xv[UB];
+    auto fetch_batch = [&](int j0) {
+#pragma unroll
+        for (int k = 0; k < UB; k++) d[k] = sd[2 * (j0 + k)];
+#pragma unroll
+        for (int k = 0; k < UB; k++) {
+            const unsigned fl = d[k].x >> 24;
+            const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
+            xv[k] = x[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast)];
+        }
+    };
+
     if constexpr (ECOO == 2) {
         const int2 wr = S.wg_coo[bid];
         if (wr.y > wr.x) {  // workgroup-uniform
@@ -518,21 +536,39 @@ __global__ __launch_bounds__(256, ECOO ? UNITS_MIN_WAVES - 1 : UNITS_MIN_WAVES) 
             __syncthreads();
         }
     } else if constexpr (WCOO) {
+        // ---- small grids (entry mode 1 is chosen when the whole grid is resident at once): the kernel is a chain of
+        // round trips, so everything that can be in flight together is: task -> {unit prologue, entry loads} -> {x gathers
+        // of the first unit batch, x gathers of the entries} -> adds -> unit loop.  Registers are not a constraint here
+        // (4 waves/SIMD asked of the allocator).
+        constexpr int CT = 6;
         const int lane = tid & 63;
         const int2 wr = S.wg_coo[(long long)bid * (GROUPS_PER_BLOCK / 4) + (g >> 2)];  // this wavefront's merged list
         const int tot = wr.y - wr.x;
         val_t *swave = &s_y[g & ~3][0][0];  // the wavefront's four slabs of STRIP_MAX_ROWS x 16 values
+        unit_prologue();
+        int cc[CT]; unsigned rb[CT]; val_t cv[CT], xx[CT];
         if (tot > 0) {
             if (side) for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
+#pragma unroll
+            for (int q = 0; q < CT; q++) {
+                const int e = min(wr.x + 64 * q + lane, wr.y - 1);
+                rb[q] = S.grow[e]; cc[q] = S.gcol[e]; cv[q] = S.gval[e];
+            }
+        }
+        if (have_units) {  // waits for the descriptor chunk only (older than the entry loads)
+            s_d[g][r] = dcur;
+            wave_lds_fence();
+            fetch_batch(0);
+        } else if (tot > 0) wave_lds_fence();
+        if (tot > 0) {
+#pragma unroll
+            for (int q = 0; q < CT; q++) xx[q] = x[cc[q] & 0x0FFFFFFF];
+#pragma unroll
+            for (int q = 0; q < CT; q++)
+                if (wr.x + 64 * q + lane < wr.y) atomicAdd(&swave[((unsigned)cc[q] >> 28) * (STRIP_MAX_ROWS * 16) + rb[q]], cv[q] * xx[q]);
+            if (tot > 64 * CT) wave_entry_trips<CT>(S, x, swave, lane, wr.x + 64 * CT, wr.y);
             wave_lds_fence();
         }
-        // more than one light trip's worth: the entry list runs first, 6 x 64 per trip, and the unit pipeline starts
-        // afterwards (registers); otherwise the unit prologue loads stay in flight across the single 4 x 64 trip
-        const bool wave_heavy = tot > S.coo_heavy_min;
-        if (wave_heavy) wave_entry_trips<WCOO_HEAVY_CT>(S, x, swave, lane, wr.x, wr.y);
-        unit_prologue();
-        if (tot > 0 && !wave_heavy) wave_entry_trips<4>(S, x, swave, lane, wr.x, wr.y);
-        if (tot > 0) wave_lds_fence();
     } else {
     // ---- issue order: first COO chunk, descriptor chunk 0 (+1), first value batch: all in flight together.
     // Strips with many COO entries (> coo_heavy_min, default 32: irregular matrices) run their entry list first,
@@ -602,9 +638,10 @@ __global__ __launch_bounds__(256, ECOO ? UNITS_MIN_WAVES - 1 : UNITS_MIN_WAVES) 
         }
     };
     if (have_units) {  // phase 2: units, value loads software-pipelined by one batch
-        const uint2 *sd = reinterpret_cast<const uint2 *>(&s_d[g][0]) + (r >> 3);  // this lane's 8-B half of a descriptor
-        s_d[g][r] = dcur;
-        wave_lds_fence();
+        if (ECOO != 1) {  // (entry mode 1 parked the first chunk and fetched the first batch before its entry phase)
+            s_d[g][r] = dcur;
+            wave_lds_fence();
+        }
         int chunk_end = unit_begin + DCHUNK;  // first unit NOT described by the chunk in LDS
         for (int u = unit_begin; u < unit_end; u += UB) {
             if (u == chunk_end) {  // next descriptor chunk: already in registers, fetch the one after it
@@ -614,17 +651,7 @@ __global__ __launch_bounds__(256, ECOO ? UNITS_MIN_WAVES - 1 : UNITS_MIN_WAVES) 
                 chunk_end += DCHUNK;
                 dnext = load_udesc(S.udesc, min(chunk_end + r, last));
             }
-            const int j0 = u - (chunk_end - DCHUNK);
-            uint2 d[UB];
-            val_t xv[UB];
-#pragma unroll
-            for (int k = 0; k < UB; k++) d[k] = sd[2 * (j0 + k)];
-#pragma unroll
-            for (int k = 0; k < UB; k++) {
-                const unsigned fl = d[k].x >> 24;
-                const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
-                xv[k] = x[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast)];
-            }
+            if (!(ECOO == 1 && u == unit_begin)) fetch_batch(u - (chunk_end - DCHUNK));
             val_t vn[UB];
 #pragma unroll
             for (int k = 0; k < UB; k += G) {  // unconditional (clamped to the task's last group): exact vmcnt
@@ -1068,6 +1095,30 @@ hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const De
     case 8: return launch_mv<8>(P, S, DN, xcd_chunk, X, Y, st);
     default: return hipErrorInvalidValue;
     }
+}
+
+// ---- multi-vector product for plans without a native multi-vector kernel (generation-1 plans, whole CSR tiles, CSR
+// fallback): one right-hand side at a time through the plan's own SpMV, with a column of the row-major X gathered into a
+// contiguous vector before and the result scattered into its column of Y afterwards.
+__global__ __launch_bounds__(256) void k_col_extract(const val_t *__restrict__ X, int nvec, int j, long long n, val_t *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = X[i * nvec + j];
+}
+__global__ __launch_bounds__(256) void k_col_scatter(const val_t *__restrict__ in, int nvec, int j, long long row0, long long rows, val_t *__restrict__ Y)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) Y[(row0 + i) * nvec + j] = in[i];
+}
+hipError_t launch_col_extract(const val_t *X, int nvec, int j, long long n, val_t *out, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_col_extract, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, nvec, j, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_col_scatter(const val_t *in, int nvec, int j, long long row0, long long rows, val_t *Y, hipStream_t st)
+{
+    if (rows > 0) hipLaunchKernelGGL(k_col_scatter, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, in, nvec, j, row0, rows, Y);
+    return hipGetLastError();
 }
 
 hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int xcd_remap, int xcd_chunk,

@@ -23,6 +23,8 @@ hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream
 hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, const val_t *X, val_t *Y,
                                   hipStream_t st);
 int fallback_block_nnz();
+hipError_t launch_col_extract(const val_t *X, int nvec, int j, long long n, val_t *out, hipStream_t st);
+hipError_t launch_col_scatter(const val_t *in, int nvec, int j, long long row0, long long rows, val_t *Y, hipStream_t st);
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -56,6 +58,7 @@ struct tilespmv_plan {
     DevStream st{};
     DevDense dn{};
     int xcd_remap = 2, xcd_chunk = 32;  // windows of 8 x 32 workgroups: neighbouring strips share an XCD L2 (sweep 4..64: flat within 2.5 %, 32 best on 3 of 4 large matrices)
+    val_t *mv_x = nullptr, *mv_y = nullptr;  // plans without a native multi-vector kernel: one column of X / Y at a time
     int entry_mode = 0;                 // COO entry lists walked per 16-lane strip (0), per wavefront (1) or per workgroup, column-ordered (2)
     std::vector<void *> allocs;
     long long info[TILESPMV_INFO_COUNT] = {0};
@@ -265,12 +268,13 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     //      distinct x lines per batch drop 3x and the CU's L1 -> L2 request rate is what bounds those.
     // Strip size.  Regular matrices: ~400 cost units (20 units) amortise the per-strip round trips; flat between 200 and 800
     // on large matrices.  Entry-heavy shards want MANY tile-rows per workgroup (power-law 8 M rows: 0.149 ms at 400,
-    // 0.120 ms at 1600) but still >= 4 workgroups per CU (webbase-like best at 800, scircuit-like at <= 400).
+    // 0.120 ms at 1600) but still about 3 workgroups per CU on small matrices (webbase-like: 12.9-13.1 us at ~760
+    // workgroups, 13.6-14.3 at 1000, 15.4 at 570; scircuit-like flat 7.2-7.8 us from 250 to 670 workgroups).
     const bool entry_heavy = NC >= 6LL * ntr;
     long long total_cost = 0;
     for (int i = 0; i < ntr; i++) total_cost += rc_[i].cost;
     int target = target_in;
-    if (target <= 0) target = entry_heavy ? (int)std::min<long long>(1600, std::max<long long>(400, total_cost / (4 * 256 * 16))) : 400;
+    if (target <= 0) target = entry_heavy ? (int)std::min<long long>(1600, std::max<long long>(400, total_cost / (3 * 256 * 16))) : 400;
     target = std::max(32, target);
     const long long est_wgs = total_cost / (16LL * target) + 1;
     const int wave_coo_env = env_int("TILESPMV_WAVE_COO", -1);
@@ -283,105 +287,111 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     // TILESPMV_COO_ORDERED=1 asks for reproducible bits.  Modes 0 and 1 are always ordered (one wavefront per slab).
     const int ordered_env = env_int("TILESPMV_COO_ORDERED", -1);
     const bool coo_ordered = ordered_env >= 0 ? ordered_env != 0 : est_wgs >= 2048;
-    const int split_above = std::max(6 * target, split_above_in), piece = std::max(2 * target, split_above / 3);
-    const int strip_even = env_int("TILESPMV_STRIP_EVEN", 4);  // 0 off, 1 = value group, n > 1 = multiples of n units
     std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
-    auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
-    auto is_heavy = [&](int t) {
-        const int fmt = T->Format[t];
-        return fmt == TILESPMV_FMT_CSR && !csr_split;
-    };
-    auto heavy_sizes = [&](int t, int *nv, int *ni) {
-        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t];
-        (void)fmt; *nv = stored; *ni = 16 + (stored + 1) / 2;
-    };
-    // k_dense_mfma broadcasts the column blocks of one DenseRow piece from a single 64-lane load: a piece holds at most
-    // 64 dense tiles.  Split rows cut their dense tiles into pieces of 32; an unsplit row is one piece, so a row with
-    // more dense tiles than that is always split, whatever the cost knobs say (TILESPMV_STRIP_COST / _SPLIT_ABOVE).
-    constexpr int DENSE_PIECE = 32;
-    auto must_split = [&](int i) { return rc_[i].cost > split_above || rc_[i].ndense > DENSE_PIECE; };
-    for (int i = 0; i < ntr;) {
-        if (must_split(i)) {
-            row_split[i] = 1;
-            FixRow f{tr0 + i, npartial, 0, 0};
-            // entry pieces: four consecutive pieces share a wavefront, which walks their lists together (4 x 192 = 2 trips of 6 x 64)
-            const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, env_int("TILESPMV_COO_PIECE", entry_mode == 1 ? 192 : piece / std::max(1, env_int("TILESPMV_COO_COST", 4))));
-            for (long long u = pu[i]; u < pu[i + 1]; u += pu_) {
-                STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
-                k.unit_begin = (int)u; k.unit_end = (int)std::min(pu[i + 1], u + pu_);
-                tasks.push_back(k); f.count++;
-            }
-            for (long long c = pc[i]; c < pc[i + 1]; c += pc_) {
-                STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
-                k.coo_begin = (int)c; k.coo_end = (int)std::min(pc[i + 1], c + pc_);
-                tasks.push_back(k); f.count++;
-            }
-            const int stream_pieces = f.count;  // pieces executed by the unit kernel
-            long long h = ph[i], hv = phv[i], hi = phi[i];
-            int t = T->tile_ptr[tr0 + i];
-            while (h < ph[i + 1]) {  // heavy tiles of a split row: cut at tile boundaries by payload size
-                Task k{(int)h, (int)h, hv, hi, tr0 + i, npartial++};
-                long long c = 0;
-                while (h < ph[i + 1] && (c == 0 || c < piece)) {
-                    while (!is_heavy(t)) t++;
-                    int nv, ni; heavy_sizes(t, &nv, &ni);
-                    hv += nv; hi += ni; c += nv + 256; h++; t++;
+    const int npartial0 = npartial;
+    auto cut = [&](int target) {
+        const int split_above = std::max(6 * target, split_above_in), piece = std::max(2 * target, split_above / 3);
+        tasks.clear(); htasks.clear(); ifix.clear(); fix_late.clear(); fix.clear(); drows.clear(); npartial = npartial0;
+        std::fill(row_k.begin(), row_k.end(), 0); std::fill(row_split.begin(), row_split.end(), 0);
+        const int strip_even = env_int("TILESPMV_STRIP_EVEN", 4);  // 0 off, 1 = value group, n > 1 = multiples of n units
+        auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
+        auto is_heavy = [&](int t) {
+            const int fmt = T->Format[t];
+            return fmt == TILESPMV_FMT_CSR && !csr_split;
+        };
+        auto heavy_sizes = [&](int t, int *nv, int *ni) {
+            const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t];
+            (void)fmt; *nv = stored; *ni = 16 + (stored + 1) / 2;
+        };
+        // k_dense_mfma broadcasts the column blocks of one DenseRow piece from a single 64-lane load: a piece holds at most
+        // 64 dense tiles.  Split rows cut their dense tiles into pieces of 32; an unsplit row is one piece, so a row with
+        // more dense tiles than that is always split, whatever the cost knobs say (TILESPMV_STRIP_COST / _SPLIT_ABOVE).
+        constexpr int DENSE_PIECE = 32;
+        auto must_split = [&](int i) { return rc_[i].cost > split_above || rc_[i].ndense > DENSE_PIECE; };
+        for (int i = 0; i < ntr;) {
+            if (must_split(i)) {
+                row_split[i] = 1;
+                FixRow f{tr0 + i, npartial, 0, 0};
+                // entry pieces: four consecutive pieces share a wavefront, which walks their lists together (4 x 192 = 2 trips of 6 x 64)
+                const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, env_int("TILESPMV_COO_PIECE", entry_mode == 1 ? 192 : piece / std::max(1, env_int("TILESPMV_COO_COST", 4))));
+                for (long long u = pu[i]; u < pu[i + 1]; u += pu_) {
+                    STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
+                    k.unit_begin = (int)u; k.unit_end = (int)std::min(pu[i + 1], u + pu_);
+                    tasks.push_back(k); f.count++;
                 }
-                k.tile_end = (int)h;
-                htasks.push_back(k); f.count++;
+                for (long long c = pc[i]; c < pc[i + 1]; c += pc_) {
+                    STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
+                    k.coo_begin = (int)c; k.coo_end = (int)std::min(pc[i + 1], c + pc_);
+                    tasks.push_back(k); f.count++;
+                }
+                const int stream_pieces = f.count;  // pieces executed by the unit kernel
+                long long h = ph[i], hv = phv[i], hi = phi[i];
+                int t = T->tile_ptr[tr0 + i];
+                while (h < ph[i + 1]) {  // heavy tiles of a split row: cut at tile boundaries by payload size
+                    Task k{(int)h, (int)h, hv, hi, tr0 + i, npartial++};
+                    long long c = 0;
+                    while (h < ph[i + 1] && (c == 0 || c < piece)) {
+                        while (!is_heavy(t)) t++;
+                        int nv, ni; heavy_sizes(t, &nv, &ni);
+                        hv += nv; hi += ni; c += nv + 256; h++; t++;
+                    }
+                    k.tile_end = (int)h;
+                    htasks.push_back(k); f.count++;
+                }
+                for (long long dq = pd[i]; dq < pd[i + 1]; dq += DENSE_PIECE) {  // dense tiles of a split row: 32 per piece
+                    drows.push_back(DenseRow{tr0 + i, (int)dq, (int)std::min(pd[i + 1], dq + DENSE_PIECE), npartial++});
+                    f.count++;
+                }
+                // all pieces inside the unit kernel -> the last one to finish adds the slots up there
+                const bool inline_fix = fix_inline_on && f.count == stream_pieces;
+                for (int q = 0; q < stream_pieces; q++) tasks[tasks.size() - 1 - (size_t)q].nounit_mask = inline_fix ? (unsigned)ifix.size() : 0xFFFFFFFFu;
+                if (inline_fix) ifix.push_back(f); else fix_late.push_back(f);
+                fix.push_back(f);
+                i++;
+                continue;
             }
-            for (long long dq = pd[i]; dq < pd[i + 1]; dq += DENSE_PIECE) {  // dense tiles of a split row: 32 per piece
-                drows.push_back(DenseRow{tr0 + i, (int)dq, (int)std::min(pd[i + 1], dq + DENSE_PIECE), npartial++});
-                f.count++;
+            STask k = blank();
+            k.row = tr0 + i;
+            k.unit_begin = (int)pu[i]; k.coo_begin = (int)pc[i];
+            long long c = 0;
+            int j = i;
+            // how many tile-rows: up to the cost target, then nudged by one row either way if that leaves fewer padding
+            // units (the strip's values are stored in groups of UNIT_GROUP units, tail padded with zero units)
+            int jend = i;
+            {
+                long long cc = 0;
+                while (jend < ntr && jend - i < STRIP_MAX_ROWS && !must_split(jend)) {
+                    const long long nc = cc + rc_[jend].cost;
+                    // entry-heavy shards round to the nearest strip size (rows cost 100-400 each there: "never above the target"
+                    // would leave most strips half empty and double the number of wavefronts)
+                    if (jend > i && nc > target && !(wave_coo && nc - target < target - cc && nc <= target + target / 2)) break;
+                    cc = nc; jend++;
+                }
+                // (whole batches of 4 units, which are also whole value groups: a half-empty last batch costs as much as a full one)
+                const int quantum = strip_even > 1 ? strip_even : UNIT_GROUP;
+                auto pad = [&](int e) { return (int)((quantum - (pu[e] - pu[i]) % quantum) % quantum); };
+                if (strip_even && pad(jend) > 0) {
+                    int best = jend;
+                    if (jend < ntr && jend - i < STRIP_MAX_ROWS && !must_split(jend) && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
+                    if (best == jend && jend - i >= 3 && pad(jend - 1) < pad(best)) best = jend - 1;
+                    jend = best;
+                }
             }
-            // all pieces inside the unit kernel -> the last one to finish adds the slots up there
-            const bool inline_fix = fix_inline_on && f.count == stream_pieces;
-            for (int q = 0; q < stream_pieces; q++) tasks[tasks.size() - 1 - (size_t)q].nounit_mask = inline_fix ? (unsigned)ifix.size() : 0xFFFFFFFFu;
-            if (inline_fix) ifix.push_back(f); else fix_late.push_back(f);
-            fix.push_back(f);
-            i++;
-            continue;
+            while (j < jend) {
+                row_k[j] = (unsigned char)(j - i);
+                if (rc_[j].nunits == 0) k.nounit_mask |= 1u << (j - i);
+                if (rc_[j].nheavy > 0) htasks.push_back(Task{(int)ph[j], (int)ph[j + 1], phv[j], phi[j], tr0 + j, -1});
+                if (rc_[j].ndense > 0) drows.push_back(DenseRow{tr0 + j, (int)pd[j], (int)pd[j + 1], -1});
+                c += rc_[j].cost; j++;
+            }
+            k.nrows = j - i;
+            k.unit_end = (int)pu[j]; k.coo_end = (int)pc[j];
+            tasks.push_back(k);
+            i = j;
         }
-        STask k = blank();
-        k.row = tr0 + i;
-        k.unit_begin = (int)pu[i]; k.coo_begin = (int)pc[i];
-        long long c = 0;
-        int j = i;
-        // how many tile-rows: up to the cost target, then nudged by one row either way if that leaves fewer padding
-        // units (the strip's values are stored in groups of UNIT_GROUP units, tail padded with zero units)
-        int jend = i;
-        {
-            long long cc = 0;
-            while (jend < ntr && jend - i < STRIP_MAX_ROWS && !must_split(jend)) {
-                const long long nc = cc + rc_[jend].cost;
-                // entry-heavy shards round to the nearest strip size (rows cost 100-400 each there: "never above the target"
-                // would leave most strips half empty and double the number of wavefronts)
-                if (jend > i && nc > target && !(wave_coo && nc - target < target - cc && nc <= target + target / 2)) break;
-                cc = nc; jend++;
-            }
-            // (whole batches of 4 units, which are also whole value groups: a half-empty last batch costs as much as a full one)
-            const int quantum = strip_even > 1 ? strip_even : UNIT_GROUP;
-            auto pad = [&](int e) { return (int)((quantum - (pu[e] - pu[i]) % quantum) % quantum); };
-            if (strip_even && pad(jend) > 0) {
-                int best = jend;
-                if (jend < ntr && jend - i < STRIP_MAX_ROWS && !must_split(jend) && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
-                if (best == jend && jend - i >= 3 && pad(jend - 1) < pad(best)) best = jend - 1;
-                jend = best;
-            }
-        }
-        while (j < jend) {
-            row_k[j] = (unsigned char)(j - i);
-            if (rc_[j].nunits == 0) k.nounit_mask |= 1u << (j - i);
-            if (rc_[j].nheavy > 0) htasks.push_back(Task{(int)ph[j], (int)ph[j + 1], phv[j], phi[j], tr0 + j, -1});
-            if (rc_[j].ndense > 0) drows.push_back(DenseRow{tr0 + j, (int)pd[j], (int)pd[j + 1], -1});
-            c += rc_[j].cost; j++;
-        }
-        k.nrows = j - i;
-        k.unit_end = (int)pu[j]; k.coo_end = (int)pc[j];
-        tasks.push_back(k);
-        i = j;
-    }
 
+    };
+    cut(target);
     // ---- fill
     std::vector<uint4> h_udesc((size_t)NU);
     val_t *h_uval = zalloc<val_t>((size_t)NU * 16);
@@ -719,21 +729,68 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     (void)hipMemset(dx, 0, ((size_t)colA + 16) * sizeof(val_t));
     tilespmv_plan *best = nullptr;
     double best_ms = 0;
-    auto try_one = [&](tilespmv_plan_options cand) {
+    std::string log = "{\"rows\": " + std::to_string(rowA) + ", \"cols\": " + std::to_string(colA) + ", \"nnz\": " + std::to_string((long long)nnzA) +
+                      ", \"value_bytes\": " + std::to_string(sizeof(val_t)) + ", \"candidates\": [";
+    bool first = true;
+    // env knobs a candidate overrides for the duration of its build (the builder reads them at plan creation)
+    struct EnvSet { const char *name; std::string val; };
+    auto with_env = [&](const std::vector<EnvSet> &es, auto &&fn) {
+        std::vector<std::pair<std::string, std::string>> saved;
+        for (const EnvSet &e : es) { const char *o = getenv(e.name); saved.push_back({e.name, o ? o : "\x01"}); setenv(e.name, e.val.c_str(), 1); }
+        fn();
+        for (auto &sv : saved) { if (sv.second == "\x01") unsetenv(sv.first.c_str()); else setenv(sv.first.c_str(), sv.second.c_str(), 1); }
+    };
+    auto try_one = [&](tilespmv_plan_options cand, const std::vector<EnvSet> &es, const char *label) {
         tilespmv_plan *p = nullptr;
-        if (plan_create_one(&p, T, rowA, colA, nnzA, &cand) != 0 || !p) return;
+        int rc1 = 0;
+        with_env(es, [&]() { rc1 = plan_create_one(&p, T, rowA, colA, nnzA, &cand); });
+        if (rc1 != 0 || !p) return;
         const double ms = tilespmv_plan_time(p, dx, dy, nullptr, 3, 12);
-        if (ms > 0 && (!best || ms < best_ms)) { tilespmv_plan_destroy(best); best = p; best_ms = ms; }
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s{\"label\": \"%s\", \"coo_mode\": %d, \"dense_mode\": %d, \"entry_mode\": %d, \"ordered\": %lld, \"strip_cost\": %lld, \"tasks\": %lld, \"ms\": %.5f}",
+                 first ? "" : ", ", label, p->coo_mode, p->dense_mode, p->entry_mode, p->info[TILESPMV_INFO_ENTRY_ORDERED], p->info[TILESPMV_INFO_STRIP_COST],
+                 p->info[TILESPMV_INFO_NUM_TASKS], ms);
+        log += buf; first = false;
+        if (ms > 0 && (!best || ms < best_ms * 0.985)) { tilespmv_plan_destroy(best); best = p; best_ms = ms; }  // a later candidate must be clearly better
         else tilespmv_plan_destroy(p);
     };
     const int coo_cands[2] = {TILESPMV_COO_IN_TILE, TILESPMV_COO_FALLBACK}, dns_cands[2] = {TILESPMV_DENSE_MFMA, TILESPMV_DENSE_VALU};
+    try_one(o, {}, "default");   // what AUTO picks from its byte models: stays unless something is clearly faster
+    const tilespmv_plan *dflt = best;
+    const int d_coo = dflt ? dflt->coo_mode : 0, d_dns = dflt ? dflt->dense_mode : 0, d_entry = dflt ? dflt->entry_mode : 0;
+    const long long d_cost = dflt ? dflt->info[TILESPMV_INFO_STRIP_COST] : 400, d_ord = dflt ? dflt->info[TILESPMV_INFO_ENTRY_ORDERED] : 1;  // (copies: `best` may be replaced)
     for (int ci = 0; ci < ((o.coo_mode == TILESPMV_COO_AUTO && has_extracted) ? 2 : 1); ci++)
         for (int di = 0; di < ((o.dense_mode == TILESPMV_DENSE_AUTO && has_dense) ? 2 : 1); di++) {
             tilespmv_plan_options cand = o;
             if (o.coo_mode == TILESPMV_COO_AUTO && has_extracted) cand.coo_mode = coo_cands[ci];
             if (o.dense_mode == TILESPMV_DENSE_AUTO && has_dense) cand.dense_mode = dns_cands[di];
-            try_one(cand);
+            const bool coo_var = o.coo_mode == TILESPMV_COO_AUTO && has_extracted, dns_var = o.dense_mode == TILESPMV_DENSE_AUTO && has_dense;
+            if ((!coo_var || cand.coo_mode == d_coo) && (!dns_var || cand.dense_mode == d_dns)) continue;   // that is the default, already timed
+            try_one(cand, {}, "coo/dense mode");
         }
+    // how the entry lists run and how large the strips are (generation 2, in-tile entries): the other entry modes at the
+    // default strip size, then the winning mode at half and twice the size.  Unordered workgroup adds are only a candidate
+    // when the caller has not asked for reproducible sums (TILESPMV_COO_ORDERED=1).
+    if (best && best->kernel == TILESPMV_KERNEL_STREAM && best->coo_mode == TILESPMV_COO_IN_TILE && !getenv("TILESPMV_WAVE_COO") && !getenv("TILESPMV_STRIP_COST")) {
+        tilespmv_plan_options cand = o;
+        cand.coo_mode = best->coo_mode; cand.dense_mode = best->dense_mode;
+        const bool may_unorder = env_int("TILESPMV_COO_ORDERED", -1) != 1;
+        for (int em = 0; em <= 2; em++) {
+            if (em == d_entry && !(em == 2)) continue;
+            if (em == 2) {
+                if (d_entry != 2 || d_ord == 0) try_one(cand, {{"TILESPMV_WAVE_COO", "2"}, {"TILESPMV_COO_ORDERED", "1"}}, "entry mode 2, ordered");
+                if (may_unorder && (d_entry != 2 || d_ord == 1)) try_one(cand, {{"TILESPMV_WAVE_COO", "2"}, {"TILESPMV_COO_ORDERED", "0"}}, "entry mode 2, unordered");
+            } else try_one(cand, {{"TILESPMV_WAVE_COO", std::to_string(em)}}, em == 0 ? "entry mode 0" : "entry mode 1");
+        }
+        const int w_entry = best->entry_mode; const long long w_ord = best->info[TILESPMV_INFO_ENTRY_ORDERED], w_cost = best->info[TILESPMV_INFO_STRIP_COST];
+        for (long long c : {w_cost / 2, w_cost * 2}) {
+            if (c < 100 || c > 3200 || c == d_cost) continue;
+            std::vector<EnvSet> es = {{"TILESPMV_WAVE_COO", std::to_string(w_entry)}, {"TILESPMV_STRIP_COST", std::to_string(c)}};
+            if (w_entry == 2) es.push_back({"TILESPMV_COO_ORDERED", w_ord ? "1" : "0"});
+            try_one(cand, es, "strip size");
+        }
+    }
+    log += "], \"xcd_maps\": [";
     // the workgroup -> XCD mapping is a launch parameter: time the alternatives on the winning plan
     if (best && best->kernel == TILESPMV_KERNEL_STREAM && !getenv("TILESPMV_XCD_REMAP") && !getenv("TILESPMV_XCD_CHUNK")) {
         const int maps[3][2] = {{best->xcd_remap, best->xcd_chunk}, {0, best->xcd_chunk}, {2, 8}};
@@ -742,9 +799,22 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
         for (int k = 0; k < 3; k++) {
             best->xcd_remap = maps[k][0]; best->xcd_chunk = maps[k][1];
             const double ms = tilespmv_plan_time(best, dx, dy, nullptr, 3, 20);
+            char buf[128];
+            snprintf(buf, sizeof(buf), "%s{\"remap\": %d, \"chunk\": %d, \"ms\": %.5f}", k ? ", " : "", maps[k][0], maps[k][1], ms);
+            log += buf;
             if (ms > 0 && (k == 0 || ms < pick_ms * 0.985)) { pick = k; pick_ms = ms; }  // leave the default unless clearly better
         }
         best->xcd_remap = maps[pick][0]; best->xcd_chunk = maps[pick][1];
+        best_ms = std::min(best_ms, pick_ms);
+    }
+    if (best) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "], \"choice\": {\"coo_mode\": %d, \"dense_mode\": %d, \"entry_mode\": %d, \"ordered\": %lld, \"strip_cost\": %lld, \"xcd_remap\": %d, \"xcd_chunk\": %d, \"ms\": %.5f}}",
+                 best->coo_mode, best->dense_mode, best->entry_mode, best->info[TILESPMV_INFO_ENTRY_ORDERED], best->info[TILESPMV_INFO_STRIP_COST], best->xcd_remap, best->xcd_chunk, best_ms);
+        log += buf;
+        if (const char *path = getenv("TILESPMV_AUTOTUNE_LOG")) {   // one JSON line per tuned plan
+            if (FILE *f = fopen(path, "a")) { fprintf(f, "%s\n", log.c_str()); fclose(f); }
+        }
     }
     (void)hipFree(dx); (void)hipFree(dy);
     if (!best) return -4;
@@ -968,6 +1038,13 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         rc |= plan->upload(f_blk.data(), f_blk.size(), &D.f_blk);
         D.f_nblk = (int)(f_blk.size() / 2);
     }
+    if (plan->kernel != TILESPMV_KERNEL_STREAM || D.ntasks > 0 || D.f_nblk > 0) {  // no native multi-vector kernel: column buffers for tilespmv_plan_spmm
+        void *px = nullptr, *py = nullptr;
+        if (hipMalloc(&px, ((size_t)colA + 16) * sizeof(val_t)) != hipSuccess || hipMalloc(&py, ((size_t)rows + 16) * sizeof(val_t)) != hipSuccess) rc = -3;
+        if (px) plan->allocs.push_back(px);
+        if (py) plan->allocs.push_back(py);
+        plan->mv_x = (val_t *)px; plan->mv_y = (val_t *)py;
+    }
     if (rc) { tilespmv_plan_destroy(plan); return rc; }
     D.nfix = (int)fix.size();
     D.rowA = std::min<long long>(rowA, (long long)tr1 * 16); D.colA = colA;
@@ -1004,9 +1081,21 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
     if (nvec == 1) return tilespmv_plan_spmv(plan, d_X, d_Y, stream);
     if (nvec != 2 && nvec != 4 && nvec != 8) return (int)hipErrorInvalidValue;
     if (((uintptr_t)d_X | (uintptr_t)d_Y) & 15u) return (int)hipErrorInvalidValue;  // rows of X / Y travel as 16-B vectors
-    // covered: unit-stream plans whose COO entries run in-tile and whose CSR tiles were split into units
-    // (the defaults).  Whole-tile passes and the CSR fallback have no multi-vector kernel.
-    if (plan->kernel != TILESPMV_KERNEL_STREAM || plan->dev.ntasks > 0 || plan->dev.f_nblk > 0) return (int)hipErrorNotSupported;
+    // native multi-vector kernels: unit-stream plans whose COO entries run in-tile and whose CSR tiles were split into units
+    // (the defaults).  Generation-1 plans, whole-tile passes and the CSR fallback go one right-hand side at a time.
+    if (plan->kernel != TILESPMV_KERNEL_STREAM || plan->dev.ntasks > 0 || plan->dev.f_nblk > 0) {
+        hipStream_t st = (hipStream_t)stream;
+        const long long row0 = plan->dev.f_row0, rows = plan->dev.f_rows;
+        for (int j = 0; j < nvec; j++) {
+            hipError_t e = launch_col_extract(d_X, nvec, j, plan->dev.colA, plan->mv_x, st);
+            if (e != hipSuccess) return (int)e;
+            const int rc = tilespmv_plan_spmv(plan, plan->mv_x, plan->mv_y - row0, stream);  // the plan writes rows row0 .. row0 + rows of what it is handed
+            if (rc) return rc;
+            e = launch_col_scatter(plan->mv_y, nvec, j, row0, rows, d_Y, st);
+            if (e != hipSuccess) return (int)e;
+        }
+        return 0;
+    }
     static const int mv_chunk = env_int("TILESPMV_MV_XCD_CHUNK", -1);
     return (int)launch_tiles_stream_mv(plan->dev, plan->st, plan->dn, nvec, mv_chunk >= 0 ? mv_chunk : (plan->xcd_remap >= 2 ? plan->xcd_chunk : 0), d_X, d_Y, (hipStream_t)stream);
 }
