@@ -145,7 +145,10 @@ int mmio_allinone(int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric, MAT_PTR_T
 /* Binary cache of a created Tile_matrix (new: the reference never serialises it; a multi-GB
  * .mtx is otherwise re-parsed and re-tiled on every run).  save: 0 on success, -1 cannot open,
  * -3 short write.  load: callee mallocs every member (free with Tile_destroy); 0 on success,
- * -1 cannot open, -2 not a cache file, -3 truncated, -5 written by the other value type. */
+ * -1 cannot open, -2 not a cache file (or another format version), -3 read error, -5 written by the other value
+ * type, -6 corrupt / truncated / stale: the header's counts, the file length, the payload checksum (FNV-1a-64) and the
+ * prefix arrays are all checked before a matrix is handed back.  A cache does not record the Tile_create flags: keep
+ * caches built with TILESPMV_CREATE_HYB apart from the others (the Format array tells them apart after loading). */
 int tilespmv_matrix_save(const Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA, const char *path);
 int tilespmv_matrix_load(Tile_matrix *matrix, int *rowA, int *colA, MAT_PTR_TYPE *nnzA, const char *path);
 
@@ -229,7 +232,12 @@ int tilespmv_plan_create(tilespmv_plan **plan, const Tile_matrix *matrix, int ro
                          MAT_PTR_TYPE nnzA, const tilespmv_plan_options *opts);
 void tilespmv_plan_destroy(tilespmv_plan *plan);
 
-/* y[16*tilerow_begin .. 16*tilerow_end) = A_shard * x.  d_x has colA elements, d_y points at
+/* Values: x (and the matrix values) must be FINITE.  Zero-padded payload is multiplied by real x entries — the padding
+ * slots of ELL / HYB tiles exactly as in the reference (src/tilespmv_cpu.h:173-192 walks all `width` slots), and in
+ * this engine also CSR tiles re-expressed as units, dense tiles, and the clamped reads of a partial last column block —
+ * so an Inf or NaN in x can reach rows that store no entry in that column (0 * Inf = NaN).
+ *
+ * y[16*tilerow_begin .. 16*tilerow_end) = A_shard * x.  d_x has colA elements, d_y points at
  * element 0 of the FULL-length y (the shard writes only its own rows).  Asynchronous on
  * `stream`, no allocation or synchronisation inside (safe to capture into a hipGraph).  One plan
  * must not execute on two streams at the same time: split tile-rows use per-plan scratch slots

@@ -195,6 +195,62 @@ def test_real_values_bitwise_where_the_order_cannot_matter_and_run_to_run(torch_
     api.Tile_destroy(tp)
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2u", "2o"])
+def test_entry_modes_real_values_within_tolerance(torch_cuda, mode):
+    """Every entry mode on real-valued data: |y - y_ref| <= tol * sum_j |a_ij x_j| (1e-12 fp64 / 1e-5 fp32),
+    on an irregular matrix with split rows, in both dtypes."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    env = {"0": {"TILESPMV_WAVE_COO": "0"}, "1": {"TILESPMV_WAVE_COO": "1"}, "2u": {"TILESPMV_WAVE_COO": "2", "TILESPMV_COO_ORDERED": "0"},
+           "2o": {"TILESPMV_WAVE_COO": "2", "TILESPMV_COO_ORDERED": "1"}}[mode]
+    m, n, rp, ci = G.powerlaw(200000)
+    m = (m // 16) * 16
+    nnz = len(ci)
+    rng = np.random.default_rng(11)
+    for dtype, tol in ((np.float64, 1e-12), (np.float32, 1e-5)):
+        vals = rng.uniform(-1, 1, nnz).astype(dtype); x = rng.uniform(-1, 1, n).astype(dtype)
+        O = CpuImpl("oracle", dtype)
+        want = O.spmv(O.tile_create(m, n, nnz, rp, ci, vals), m, n, nnz, rp, ci, vals, x)["y"].astype(np.float64)
+        ri = np.repeat(np.arange(m), np.diff(rp[:m + 1]))
+        bound = np.zeros(m); np.add.at(bound, ri, np.abs(vals[:rp[m]].astype(np.float64) * x[ci[:rp[m]]].astype(np.float64)))
+        tp = api.Tile_create(m, n, nnz, rp, ci, vals, dtype=dtype)
+        os.environ.update(env)
+        try:
+            y, info = _gpu_y(torch_cuda, tp, m, n, nnz, x)
+        finally:
+            for k in env:
+                os.environ.pop(k)
+        assert info["entry_mode"] == int(mode[0])
+        assert (np.abs(y.astype(np.float64) - want) <= tol * bound + 1e-300).all(), (mode, dtype)
+        api.Tile_destroy(tp)
+
+
+def test_non_finite_x_reaches_only_what_the_header_says(torch_cuda):
+    """include/tilespmv.h: x must be finite.  What happens otherwise is pinned here so that it cannot change silently: rows
+    that store an entry in the Inf column become non-finite, and so may rows whose tiles hold zero PADDING in that column
+    block (ELL slots as in the reference, units, dense tiles); rows whose tile-row has no tile in that column block stay
+    exactly as they were."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    m, n, rp, ci = G.laplacian5pt(64)
+    nnz = len(ci)
+    vals, x = G.compat_values(nnz), G.compat_x(n)
+    base = CpuImpl("oracle").csr_spmv(m, rp, ci, vals, x)
+    bad = 1000
+    x2 = x.copy(); x2[bad] = np.inf
+    tp = api.Tile_create(m, n, nnz, rp, ci, vals)
+    y, _ = _gpu_y(torch_cuda, tp, m, n, nnz, x2)
+    ri = np.repeat(np.arange(m), np.diff(rp))
+    direct = np.unique(ri[ci == bad])                               # rows with a stored entry in that column
+    assert not np.isfinite(y[direct]).any()
+    touched = np.unique(ri[(ci // 16) == bad // 16] // 16)          # tile-rows with a tile in that column block
+    clean = np.ones(m, bool)
+    for tr in touched:
+        clean[16 * tr:16 * tr + 16] = False
+    assert np.array_equal(y[clean], base[clean])
+    api.Tile_destroy(tp)
+
+
 def _mtx_files():
     d = os.environ.get("TILESPMV_MATRIX_DIR")
     return sorted(glob.glob(os.path.join(d, "*.mtx"))) if d and os.path.isdir(d) else []

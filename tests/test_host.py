@@ -248,6 +248,44 @@ def test_matrix_cache_roundtrip(tmp_path):
         api.matrix_load(str(junk))
 
 
+def test_matrix_cache_rejects_damaged_files(tmp_path):
+    """A truncated, bit-flipped or inconsistent cache must come back as an error (-6), never as a matrix: the plan
+    builder and tilespmv_cpu index with its prefix arrays."""
+    m, n, rp, ci = SMALL["allfmt"]()
+    nnz, rowA = len(ci), truncated_rows(m)
+    vals = G.compat_values(nnz)
+    tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, hyb=True)
+    good = tmp_path / "good.tspmv"
+    api.matrix_save(tp, rowA, n, nnz, str(good))
+    raw = bytearray(good.read_bytes())
+    api.Tile_destroy(tp)
+    header = 8 + 4 * 4 + 14 * 4 + 2 * 8 + 2 * 8
+    def load_bytes(b):
+        f = tmp_path / "bad.tspmv"; f.write_bytes(bytes(b))
+        return api.matrix_load(str(f))
+    with pytest.raises(OSError, match="-6"):
+        load_bytes(raw[:-100])                                  # truncated payload
+    with pytest.raises(OSError, match="-6"):
+        load_bytes(raw + b"\0" * 8)                             # trailing bytes
+    with pytest.raises(OSError, match="-3|-6"):
+        load_bytes(raw[:header - 4])                            # truncated header
+    flipped = bytearray(raw); flipped[header + 4 * (rowA // 16 + 1) + 7] ^= 0x40   # one bit in tile_columnidx
+    with pytest.raises(OSError, match="-6"):
+        load_bytes(flipped)
+    neg = bytearray(raw); neg[8 + 16 + 2 * 4: 8 + 16 + 3 * 4] = (-5).to_bytes(4, "little", signed=True)   # tilenum < 0
+    with pytest.raises(OSError, match="-6"):
+        load_bytes(neg)
+    big = bytearray(raw); big[8 + 16 + 3 * 4: 8 + 16 + 4 * 4] = (1 << 30).to_bytes(4, "little")             # csrsize absurd
+    with pytest.raises(OSError, match="-6"):
+        load_bytes(big)
+    old = bytearray(raw); old[7] = ord("1")                     # the round-1 format: no checksum -> not accepted
+    with pytest.raises(OSError, match="-2"):
+        load_bytes(old)
+    tl, r2, c2, z2 = load_bytes(raw)                            # and the intact bytes still load
+    assert (r2, c2, z2) == (rowA, n, nnz)
+    api.Tile_destroy(tl)
+
+
 def test_partition_tilerows_balanced():
     m, n, rp, ci = MEDIUM["powerlaw200k"]()
     nnz = len(ci); rowA = truncated_rows(m)

@@ -1,12 +1,32 @@
 // host_matrix_io.cpp — binary cache of a created Tile_matrix (new; the reference never serialises
 // its format, src/format.h:3-56, so large inputs are re-parsed and re-tiled on every run: SURVEY §8 f2).
-// Layout: 8-byte magic, value size, rowA, colA, nnzA, the 14 scalar fields, then every member array in
-// declaration order with the element counts of SURVEY.md Appendix A (derived from the scalars).
+// Layout: 8-byte magic (format version 002), value size, rowA, colA, nnzA, the 14 scalar fields, the two id-array
+// lengths, the payload byte count and an FNV-1a-64 of the payload, then every member array in declaration order with
+// the element counts of SURVEY.md Appendix A (derived from the scalars).  A load checks all of it before returning a
+// matrix: counts, file length, checksum, and the prefix arrays the plan builder and tilespmv_cpu index with.
 #include "host_util.h"
 
 namespace {
 
-const char MAGIC[8] = {'T', 'S', 'P', 'M', 'V', '0', '0', '1'};
+const char MAGIC[8] = {'T', 'S', 'P', 'M', 'V', '0', '0', '2'};
+
+unsigned long long fnv1a(const void *p, size_t n, unsigned long long h)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    // 8 bytes per step keeps a multi-GB cache cheap to verify; the tail goes byte by byte
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { unsigned long long w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x100000001B3ull; }
+    for (; i < n; i++) h = (h ^ b[i]) * 0x100000001B3ull;
+    return h;
+}
+
+bool monotone(const int *a, long long n, long long last)   // exclusive prefix: starts at 0, never decreases, ends at `last`
+{
+    if (n <= 0) return false;
+    if (a[0] != 0 || a[n - 1] != last) return false;
+    for (long long i = 1; i < n; i++) if (a[i] < a[i - 1]) return false;
+    return true;
+}
 
 struct Field { void **ptr; size_t elem; long long count; };
 
@@ -55,6 +75,10 @@ extern "C" int tilespmv_matrix_save(const Tile_matrix *matrix, int rowA, int col
     for (int i = 0; i < 14 && ok; i++) ok = fwrite(scalars_of(T, i), sizeof(int), 1, f) == 1;
     long long extra[2] = {T->tilenum >= 0 ? T->dnsrowptr[T->tilenum] : 0, T->tilenum >= 0 ? T->dnscolptr[T->tilenum] : 0};
     ok = ok && fwrite(extra, sizeof(long long), 2, f) == 2;
+    unsigned long long sum[2] = {0, 0xCBF29CE484222325ull};   // payload bytes, FNV-1a-64 of the payload
+    for (auto &fd : fields_of(T, rowA, extra[0], extra[1]))
+        if (fd.count > 0) { sum[0] += (unsigned long long)fd.count * fd.elem; sum[1] = fnv1a(*fd.ptr, (size_t)fd.count * fd.elem, sum[1]); }
+    ok = ok && fwrite(sum, sizeof(unsigned long long), 2, f) == 2;
     for (auto &fd : fields_of(T, rowA, extra[0], extra[1])) {
         if (!ok) break;
         if (fd.count > 0) ok = fwrite(*fd.ptr, fd.elem, (size_t)fd.count, f) == (size_t)fd.count;
@@ -75,14 +99,39 @@ extern "C" int tilespmv_matrix_load(Tile_matrix *matrix, int *rowA, int *colA, M
     for (int i = 0; i < 14 && ok; i++) ok = fread(scalars_of(matrix, i), sizeof(int), 1, f) == 1;
     long long extra[2] = {0, 0};
     ok = ok && fread(extra, sizeof(long long), 2, f) == 2;
-    if (ok)
-        for (auto &fd : fields_of(matrix, head[1], extra[0], extra[1])) {
-            *fd.ptr = calloc((size_t)std::max<long long>(fd.count, 1), fd.elem);
-            if (!*fd.ptr) { ok = false; break; }
-            if (fd.count > 0 && fread(*fd.ptr, fd.elem, (size_t)fd.count, f) != (size_t)fd.count) { ok = false; break; }
-        }
+    unsigned long long sum[2] = {0, 0};
+    ok = ok && fread(sum, sizeof(unsigned long long), 2, f) == 2;
+    if (!ok) { fclose(f); memset(matrix, 0, sizeof(*matrix)); return -3; }
+    // ---- the header must describe a possible matrix before anything is allocated from it
+    Tile_matrix *T = matrix;
+    bool sane = head[1] >= 0 && head[2] >= 0 && head[3] >= 0 && extra[0] >= 0 && extra[1] >= 0;
+    for (int i = 0; i < 14 && sane; i++) sane = *scalars_of(T, i) >= 0;
+    sane = sane && T->tilem == (head[1] + 15) / 16 && T->tilen == (head[2] + 15) / 16 && T->hybsize == T->hybellsize + T->hybcoosize;
+    unsigned long long bytes = 0;
+    if (sane) for (auto &fd : fields_of(T, head[1], extra[0], extra[1])) bytes += (unsigned long long)std::max<long long>(fd.count, 0) * fd.elem;
+    const long here = ftell(f);
+    sane = sane && bytes == sum[0] && fseek(f, 0, SEEK_END) == 0 && (unsigned long long)(ftell(f) - here) == bytes && fseek(f, here, SEEK_SET) == 0;
+    if (!sane) { fclose(f); memset(matrix, 0, sizeof(*matrix)); return -6; }   // corrupt, truncated or stale cache
+    unsigned long long h = 0xCBF29CE484222325ull;
+    for (auto &fd : fields_of(matrix, head[1], extra[0], extra[1])) {
+        *fd.ptr = calloc((size_t)std::max<long long>(fd.count, 1), fd.elem);
+        if (!*fd.ptr) { ok = false; break; }
+        if (fd.count > 0 && fread(*fd.ptr, fd.elem, (size_t)fd.count, f) != (size_t)fd.count) { ok = false; break; }
+        if (fd.count > 0) h = fnv1a(*fd.ptr, (size_t)fd.count * fd.elem, h);
+    }
     fclose(f);
     if (!ok) { Tile_destroy(matrix); return -3; }
+    // ---- payload intact, and the prefix arrays that everything else indexes with are consistent
+    const long long n = T->tilenum;
+    sane = h == sum[1] && monotone(T->tile_ptr, (long long)T->tilem + 1, n) && monotone(T->tile_nnz, n + 1, T->tile_nnz[n]) &&
+           monotone(T->blknnz, n + 1, T->blknnz[n]) && monotone(T->csr_offset, n + 1, T->csrsize) && monotone(T->csrptr_offset, n + 1, T->csrptrlen) &&
+           monotone(T->coo_offset, n + 1, T->coosize) && monotone(T->ell_offset, n + 1, T->ellsize) && monotone(T->hyb_offset, n + 1, T->hybsize) &&
+           monotone(T->dns_offset, n + 1, T->dnssize) && monotone(T->dnsrow_offset, n + 1, T->dnsrowsize) && monotone(T->dnscol_offset, n + 1, T->dnscolsize) &&
+           monotone(T->dnsrowptr, n + 1, extra[0]) && monotone(T->dnscolptr, n + 1, extra[1]) && monotone(T->new_coocount, n + 1, T->coototal) &&
+           monotone(T->deferredcoo_ptr, (long long)head[1] + 1, T->coototal) && T->tile_nnz[n] <= head[3];
+    for (long long t = 0; t < n && sane; t++) sane = T->tile_columnidx[t] >= 0 && T->tile_columnidx[t] < T->tilen && T->Format[t] >= 0 && T->Format[t] <= 6;
+    for (long long i = 0; i < T->coototal && sane; i++) sane = T->deferredcoo_colidx[i] >= 0 && T->deferredcoo_colidx[i] < head[2];
+    if (!sane) { Tile_destroy(matrix); return -6; }
     *rowA = head[1]; *colA = head[2]; *nnzA = head[3];
     return 0;
 }
