@@ -425,6 +425,11 @@ def main():
                                   "strip_cost": p2.info()["strip_cost"], "tasks": p2.info()["num_tasks"]}
                     p2.close()
                     del yd2
+                tj2 = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (wl, "f64" if dt2 == np.float64 else "f32"))
+                if os.path.exists(tj2):   # HBM-side bytes per launch of the default plan, from the committed counter passes (not live)
+                    t2 = json.load(open(tj2))
+                    rec["traffic"] = {"hbm_bytes_per_launch": t2.get("hbm_bytes_per_launch"), "kernel": t2.get("kernel"), "measured": t2.get("measured"),
+                                      "file": os.path.relpath(tj2, ROOT), "live": False}
                 out["other_workloads"][wl] = rec
                 api.Tile_destroy(tm2)
                 del m2, n2, rp2, ci2, v2, x2, ref2, xd2

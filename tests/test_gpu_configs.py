@@ -69,7 +69,7 @@ def _all_modes(torch, name, dtype, hyb):
                 seen.add((info["kernel"], info["coo_mode"], info["dense_mode"]))
     assert len(seen) == 8                                    # AUTO resolves to one of the two explicit COO modes
     for env in ({"TILESPMV_WAVE_COO": "0"}, {"TILESPMV_WAVE_COO": "1"}, {"TILESPMV_WAVE_COO": "2", "TILESPMV_COO_ORDERED": "1"},
-                {"TILESPMV_WAVE_COO": "2", "TILESPMV_COO_ORDERED": "0"}, {"TILESPMV_WAVE_COO": "0", "TILESPMV_COO_SORT": "1"}):
+                {"TILESPMV_WAVE_COO": "2", "TILESPMV_COO_ORDERED": "0"}):
         os.environ.update(env)
         try:
             y, _ = _gpu_y(torch, tp, rowA, n, nnz, x)

@@ -890,22 +890,31 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
 #pragma unroll
     for (int j = 0; j < NV; j++) acc[j] = 0;
 
-    // COO contributions of tile-row kr (of the strip) -> acc
-    auto coo_add = [&](int kr) {
+    // COO contributions of tile-row kr (of the strip) -> acc.  The strip's list is in tile-row order (the plan appends it
+    // tile-row by tile-row), so rows retired in ascending order (`in_order`: the unit loop) continue where the previous row
+    // stopped and stop at the first chunk that already holds a later row; rows without units, flushed at the end, scan it all.
+    int scan_from = coo_begin + 16;
+    auto coo_add = [&](int kr, bool in_order) {
         if (ncoo == 0) return;
         if ((rb0 >> 4) == (unsigned)kr) {
 #pragma unroll
             for (int j = 0; j < NV; j++) atomicAdd(&s_c[g][rb0 & 15u][j], p0.v[j]);
         }
-        for (int e0 = coo_begin + 16; e0 < coo_end; e0 += 16) {  // irregular strips only: rescanned per tile-row
+        for (int e0 = in_order ? scan_from : coo_begin + 16; e0 < coo_end; e0 += 16) {
+            unsigned rb = 0xFFFFFFFFu;
             if (e0 + r < coo_end) {
-                const unsigned rb = S.crow[e0 + r];
+                rb = S.crow[e0 + r];
                 if ((rb >> 4) == (unsigned)kr) {
                     const val_t cv = S.cval[e0 + r];
                     const vec_t xx = Xv[(long long)S.ccol[e0 + r] * Q];
 #pragma unroll
                     for (int j = 0; j < NV; j++) atomicAdd(&s_c[g][rb & 15u][j], cv * xx.v[j]);
                 }
+            }
+            if (in_order) {
+                scan_from = e0;   // the next row starts looking here
+                const unsigned long long later = __ballot(rb != 0xFFFFFFFFu && (rb >> 4) > (unsigned)kr);
+                if ((later >> (tid & 48)) & 0xFFFFull) break;   // this chunk already holds a later tile-row: nothing of kr beyond it
             }
         }
         wave_lds_fence();
@@ -976,7 +985,7 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
                 }
                 if (fl & UNIT_EOR) {
                     const int kr = (int)((fl >> UNIT_ROW_SHIFT) & 7u);
-                    coo_add(kr);
+                    coo_add(kr, true);
                     store_row(kr);
                 }
             }
@@ -985,14 +994,14 @@ __global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int col
         }
     }
     if (part >= 0) {  // piece of a split tile-row: its partial sums go to the slot, k_fixup_split_mv adds the slots up
-        coo_add(0);
+        coo_add(0, false);
         vec_t o;
 #pragma unroll
         for (int j = 0; j < NV; j++) o.v[j] = acc[j];
         reinterpret_cast<vec_t *>(partial)[((long long)part * 16 + r) * Q + q] = o;
     } else {
         unsigned m = nounit;  // tile-rows without any unit: COO contributions only (or zero)
-        while (m) { const int kr = __ffs((int)m) - 1; m &= m - 1; coo_add(kr); store_row(kr); }
+        while (m) { const int kr = __ffs((int)m) - 1; m &= m - 1; coo_add(kr, false); store_row(kr); }
     }
 }
 
@@ -1098,26 +1107,29 @@ hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const De
 }
 
 // ---- multi-vector product for plans without a native multi-vector kernel (generation-1 plans, whole CSR tiles, CSR
-// fallback): one right-hand side at a time through the plan's own SpMV, with a column of the row-major X gathered into a
-// contiguous vector before and the result scattered into its column of Y afterwards.
-__global__ __launch_bounds__(256) void k_col_extract(const val_t *__restrict__ X, int nvec, int j, long long n, val_t *__restrict__ out)
+// fallback) and for plans whose work is mostly COO entries: one right-hand side at a time through the plan's own SpMV.  The
+// row-major X is transposed into nvec contiguous vectors first and the results are transposed back into Y afterwards (one
+// pass each: a thread moves one row, so both sides of both kernels are coalesced).
+__global__ __launch_bounds__(256) void k_rows_to_columns(const val_t *__restrict__ X, int nvec, long long n, long long ld, val_t *__restrict__ XT)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = X[i * nvec + j];
+    if (i >= n) return;
+    for (int j = 0; j < nvec; j++) XT[j * ld + i] = X[i * nvec + j];
 }
-__global__ __launch_bounds__(256) void k_col_scatter(const val_t *__restrict__ in, int nvec, int j, long long row0, long long rows, val_t *__restrict__ Y)
+__global__ __launch_bounds__(256) void k_columns_to_rows(const val_t *__restrict__ YT, int nvec, long long row0, long long rows, long long ld, val_t *__restrict__ Y)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < rows) Y[(row0 + i) * nvec + j] = in[i];
+    if (i >= rows) return;
+    for (int j = 0; j < nvec; j++) Y[(row0 + i) * nvec + j] = YT[j * ld + i];
 }
-hipError_t launch_col_extract(const val_t *X, int nvec, int j, long long n, val_t *out, hipStream_t st)
+hipError_t launch_rows_to_columns(const val_t *X, int nvec, long long n, long long ld, val_t *XT, hipStream_t st)
 {
-    if (n > 0) hipLaunchKernelGGL(k_col_extract, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, nvec, j, n, out);
+    if (n > 0) hipLaunchKernelGGL(k_rows_to_columns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, nvec, n, ld, XT);
     return hipGetLastError();
 }
-hipError_t launch_col_scatter(const val_t *in, int nvec, int j, long long row0, long long rows, val_t *Y, hipStream_t st)
+hipError_t launch_columns_to_rows(const val_t *YT, int nvec, long long row0, long long rows, long long ld, val_t *Y, hipStream_t st)
 {
-    if (rows > 0) hipLaunchKernelGGL(k_col_scatter, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, in, nvec, j, row0, rows, Y);
+    if (rows > 0) hipLaunchKernelGGL(k_columns_to_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, YT, nvec, row0, rows, ld, Y);
     return hipGetLastError();
 }
 

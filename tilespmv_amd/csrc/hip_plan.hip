@@ -23,8 +23,8 @@ hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream
 hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, const val_t *X, val_t *Y,
                                   hipStream_t st);
 int fallback_block_nnz();
-hipError_t launch_col_extract(const val_t *X, int nvec, int j, long long n, val_t *out, hipStream_t st);
-hipError_t launch_col_scatter(const val_t *in, int nvec, int j, long long row0, long long rows, val_t *Y, hipStream_t st);
+hipError_t launch_rows_to_columns(const val_t *X, int nvec, long long n, long long ld, val_t *XT, hipStream_t st);
+hipError_t launch_columns_to_rows(const val_t *YT, int nvec, long long row0, long long rows, long long ld, val_t *Y, hipStream_t st);
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -58,7 +58,9 @@ struct tilespmv_plan {
     DevStream st{};
     DevDense dn{};
     int xcd_remap = 2, xcd_chunk = 32;  // windows of 8 x 32 workgroups: neighbouring strips share an XCD L2 (sweep 4..64: flat within 2.5 %, 32 best on 3 of 4 large matrices)
-    val_t *mv_x = nullptr, *mv_y = nullptr;  // plans without a native multi-vector kernel: one column of X / Y at a time
+    val_t *mv_x = nullptr, *mv_y = nullptr;  // plans without a native multi-vector kernel: X / Y as mv_nvec contiguous vectors (allocated at the first such call)
+    int mv_nvec = 0;
+    bool mv_by_columns = false;              // ... and plans whose work is mostly COO entries (the multi-vector kernel walks them per 16-lane strip)
     int entry_mode = 0;                 // COO entry lists walked per 16-lane strip (0), per wavefront (1) or per workgroup, column-ordered (2)
     std::vector<void *> allocs;
     long long info[TILESPMV_INFO_COUNT] = {0};
@@ -273,6 +275,9 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     const bool entry_heavy = NC >= 6LL * ntr;
     long long total_cost = 0;
     for (int i = 0; i < ntr; i++) total_cost += rc_[i].cost;
+    // tilespmv_plan_spmm: k_units_mv walks a strip's entries with its 16 lanes, tile-row by tile-row; where entries are most
+    // of the work (webbase-like: nvec 2 took 0.11 ms against 0.013 ms for one SpMV) one SpMV per right-hand side is faster
+    const bool entry_dominated = (long long)env_int("TILESPMV_COO_COST", 4) * NC * 2 > total_cost;
     int target = target_in;
     if (target <= 0) target = entry_heavy ? (int)std::min<long long>(1600, std::max<long long>(400, total_cost / (3 * 256 * 16))) : 400;
     target = std::max(32, target);
@@ -545,24 +550,6 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         free(h_uval); free(h_cval); free(h_hval); free(h_hidx); free(h_dval);
         return -2;
     }
-    if (env_int("TILESPMV_COO_SORT", 0) != 0) {
-        // entries of one strip ordered by column: neighbouring lanes of a gather then share x lines (the order of the
-        // additions into one y element changes with it; the list has no other consumer that depends on its order)
-        parallel_chunks((int64_t)tasks.size(), 256, [&](int64_t b, int64_t e, int) {
-            std::vector<std::pair<long long, int>> key;
-            std::vector<val_t> tv; std::vector<int> tc; std::vector<unsigned char> tr;
-            for (int64_t i = b; i < e; i++) {
-                const STask &k = tasks[(size_t)i];
-                const int n = k.coo_end - k.coo_begin;
-                if (n < 2) continue;
-                key.resize((size_t)n); tv.resize((size_t)n); tc.resize((size_t)n); tr.resize((size_t)n);
-                for (int q = 0; q < n; q++) key[(size_t)q] = {((long long)h_ccol[(size_t)k.coo_begin + q] << 20) | q, q};
-                std::sort(key.begin(), key.end());
-                for (int q = 0; q < n; q++) { const int o = k.coo_begin + key[(size_t)q].second; tv[(size_t)q] = h_cval[o]; tc[(size_t)q] = h_ccol[(size_t)o]; tr[(size_t)q] = h_crow[(size_t)o]; }
-                for (int q = 0; q < n; q++) { const int o = k.coo_begin + q; h_cval[o] = tv[(size_t)q]; h_ccol[(size_t)o] = tc[(size_t)q]; h_crow[(size_t)o] = tr[(size_t)q]; }
-            }
-        });
-    }
     {
         std::vector<UDesc> packed((size_t)NUP, UDesc{0u, 0u, 0u});
         val_t *paired = zalloc<val_t>((size_t)NUP * 16);
@@ -663,6 +650,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     plan->info[TILESPMV_INFO_ENTRY_MODE] = entry_mode;
     plan->info[TILESPMV_INFO_ENTRY_ORDERED] = (entry_mode != 2 || coo_ordered) ? 1 : 0;
     plan->info[TILESPMV_INFO_STRIP_COST] = target;
+    plan->mv_by_columns = entry_dominated && target >= 800;   // (small strips hold few entries each: scircuit-like 18 / 22 / 32 us native against 22 / 41 / 78 us)
     n_tasks = (long long)tasks.size();
     model_bytes = NUP * (12 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
@@ -1038,13 +1026,6 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         rc |= plan->upload(f_blk.data(), f_blk.size(), &D.f_blk);
         D.f_nblk = (int)(f_blk.size() / 2);
     }
-    if (plan->kernel != TILESPMV_KERNEL_STREAM || D.ntasks > 0 || D.f_nblk > 0) {  // no native multi-vector kernel: column buffers for tilespmv_plan_spmm
-        void *px = nullptr, *py = nullptr;
-        if (hipMalloc(&px, ((size_t)colA + 16) * sizeof(val_t)) != hipSuccess || hipMalloc(&py, ((size_t)rows + 16) * sizeof(val_t)) != hipSuccess) rc = -3;
-        if (px) plan->allocs.push_back(px);
-        if (py) plan->allocs.push_back(py);
-        plan->mv_x = (val_t *)px; plan->mv_y = (val_t *)py;
-    }
     if (rc) { tilespmv_plan_destroy(plan); return rc; }
     D.nfix = (int)fix.size();
     D.rowA = std::min<long long>(rowA, (long long)tr1 * 16); D.colA = colA;
@@ -1083,18 +1064,29 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
     if (((uintptr_t)d_X | (uintptr_t)d_Y) & 15u) return (int)hipErrorInvalidValue;  // rows of X / Y travel as 16-B vectors
     // native multi-vector kernels: unit-stream plans whose COO entries run in-tile and whose CSR tiles were split into units
     // (the defaults).  Generation-1 plans, whole-tile passes and the CSR fallback go one right-hand side at a time.
-    if (plan->kernel != TILESPMV_KERNEL_STREAM || plan->dev.ntasks > 0 || plan->dev.f_nblk > 0) {
+    static const int mv_native = env_int("TILESPMV_MV_NATIVE", -1);   // 1 / 0: force the multi-vector kernel / the one-at-a-time path on entry-dominated plans
+    const bool has_native = plan->kernel == TILESPMV_KERNEL_STREAM && plan->dev.ntasks == 0 && plan->dev.f_nblk == 0;
+    // entry-dominated plans: the multi-vector kernel only pays from 8 right-hand sides on (webbase-like: 38 / 77 / 154 us one
+    // at a time against 110 / 125 / 142 us for nvec 2 / 4 / 8)
+    const bool one_at_a_time = !has_native || (plan->mv_by_columns && (mv_native >= 0 ? mv_native == 0 : nvec < 8));
+    if (one_at_a_time) {
         hipStream_t st = (hipStream_t)stream;
-        const long long row0 = plan->dev.f_row0, rows = plan->dev.f_rows;
-        for (int j = 0; j < nvec; j++) {
-            hipError_t e = launch_col_extract(d_X, nvec, j, plan->dev.colA, plan->mv_x, st);
-            if (e != hipSuccess) return (int)e;
-            const int rc = tilespmv_plan_spmv(plan, plan->mv_x, plan->mv_y - row0, stream);  // the plan writes rows row0 .. row0 + rows of what it is handed
-            if (rc) return rc;
-            e = launch_col_scatter(plan->mv_y, nvec, j, row0, rows, d_Y, st);
-            if (e != hipSuccess) return (int)e;
+        const long long row0 = plan->dev.f_row0, rows = plan->dev.f_rows, ldx = (long long)plan->dev.colA + 16, ldy = rows + 16;
+        if (plan->mv_nvec < nvec) {   // first call (or a wider one): the transposed copies of X and Y live with the plan
+            void *px = nullptr, *py = nullptr;
+            if (hipMalloc(&px, (size_t)ldx * nvec * sizeof(val_t)) != hipSuccess) return (int)hipErrorOutOfMemory;
+            if (hipMalloc(&py, (size_t)ldy * nvec * sizeof(val_t)) != hipSuccess) { (void)hipFree(px); return (int)hipErrorOutOfMemory; }
+            plan->allocs.push_back(px); plan->allocs.push_back(py);   // (an earlier, narrower pair stays allocated until the plan goes)
+            plan->mv_x = (val_t *)px; plan->mv_y = (val_t *)py; plan->mv_nvec = nvec;
         }
-        return 0;
+        hipError_t e = launch_rows_to_columns(d_X, nvec, plan->dev.colA, ldx, plan->mv_x, st);
+        if (e != hipSuccess) return (int)e;
+        for (int j = 0; j < nvec; j++) {
+            const int rc = tilespmv_plan_spmv(plan, plan->mv_x + j * ldx, plan->mv_y + j * ldy - row0, stream);  // the plan writes rows row0 .. row0 + rows of what it is handed
+            if (rc) return rc;
+        }
+        e = launch_columns_to_rows(plan->mv_y, nvec, row0, rows, ldy, d_Y, st);
+        return (int)e;
     }
     static const int mv_chunk = env_int("TILESPMV_MV_XCD_CHUNK", -1);
     return (int)launch_tiles_stream_mv(plan->dev, plan->st, plan->dn, nvec, mv_chunk >= 0 ? mv_chunk : (plan->xcd_remap >= 2 ? plan->xcd_chunk : 0), d_X, d_Y, (hipStream_t)stream);
