@@ -450,6 +450,18 @@ __device__ __forceinline__ void wg_entry_trips(const DevStream &S, const val_t *
     }
 }
 
+#ifdef TILESPMV_STAMPS
+// Diagnostic build (never the product): lane 0 of every wavefront records the shader clock at a few points of k_units; the
+// stamps go to a buffer of their own and no output depends on them.  Read the SHARES, not the length (the waits the stamps
+// force are not in the real kernel).
+#define TSPMV_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        __builtin_amdgcn_sched_barrier(0); stamp_[i] = t_; } while (0)
+#define TSPMV_STAMP_WAIT(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TSPMV_STAMP(i); } while (0)
+#else
+#define TSPMV_STAMP(i) do { } while (0)
+#define TSPMV_STAMP_WAIT(i) do { } while (0)
+#endif
+
 // ECOO: how the COO entry lists are executed — 0 per 16-lane strip (regular matrices: a handful of entries per strip),
 // 1 per wavefront (the four strips' lists concatenated), 2 per workgroup (merged + column-ordered list, see above).
 template <int UB, int XCD_REMAP, int ECOO>
@@ -469,6 +481,11 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
         const unsigned C = (unsigned)xcd_chunk, W = 8u * C, win = bid / W, off = bid % W, k = off & 7u;
         if ((win + 1) * W <= gridDim.x) bid = win * W + k * C + (off >> 3);
     }
+#ifdef TILESPMV_STAMPS
+    unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); stamp_[7] = rt_; }
+#endif
+    TSPMV_STAMP(0);
     const long long task_id = (long long)bid * GROUPS_PER_BLOCK + g;
     const bool have = task_id < S.ntasks;
     constexpr bool WCOO = ECOO == 1;
@@ -526,15 +543,18 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
 
     if constexpr (ECOO == 2) {
         const int2 wr = S.wg_coo[bid];
+        TSPMV_STAMP_WAIT(1);   // task and list range have arrived
         if (wr.y > wr.x) {  // workgroup-uniform
             if (side) for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
             __syncthreads();
         }
         unit_prologue();
+        TSPMV_STAMP_WAIT(2);   // prologue has arrived (the entry loads are inside the trips)
         if (wr.y > wr.x) {
             wg_entry_trips<WCOO_HEAVY_CT>(S, x, &s_y[0][0][0], tid, wr.x, wr.y);
             __syncthreads();
         }
+        TSPMV_STAMP_WAIT(3);   // entry phase done
     } else if constexpr (WCOO) {
         // ---- small grids (entry mode 1 is chosen when the whole grid is resident at once): the kernel is a chain of
         // round trips, so everything that can be in flight together is: task -> {unit prologue, entry loads} -> {x gathers
@@ -545,6 +565,7 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
         const int2 wr = S.wg_coo[(long long)bid * (GROUPS_PER_BLOCK / 4) + (g >> 2)];  // this wavefront's merged list
         const int tot = wr.y - wr.x;
         val_t *swave = &s_y[g & ~3][0][0];  // the wavefront's four slabs of STRIP_MAX_ROWS x 16 values
+        TSPMV_STAMP_WAIT(1);   // task and list range have arrived
         unit_prologue();
         int cc[CT]; unsigned rb[CT]; val_t cv[CT], xx[CT];
         if (tot > 0) {
@@ -560,6 +581,7 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
             wave_lds_fence();
             fetch_batch(0);
         } else if (tot > 0) wave_lds_fence();
+        TSPMV_STAMP_WAIT(2);   // prologue + entry loads (and the first unit batch's gathers) have arrived
         if (tot > 0) {
 #pragma unroll
             for (int q = 0; q < CT; q++) xx[q] = x[cc[q] & 0x0FFFFFFF];
@@ -569,6 +591,7 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
             if (tot > 64 * CT) wave_entry_trips<CT>(S, x, swave, lane, wr.x + 64 * CT, wr.y);
             wave_lds_fence();
         }
+        TSPMV_STAMP_WAIT(3);   // entry phase done
     } else {
     // ---- issue order: first COO chunk, descriptor chunk 0 (+1), first value batch: all in flight together.
     // Strips with many COO entries (> coo_heavy_min, default 32: irregular matrices) run their entry list first,
@@ -666,6 +689,7 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
             for (int k = 0; k < UB; k++) v[k] = vn[k];
         }
     }
+    TSPMV_STAMP_WAIT(4);       // unit loop done
     if (part >= 0) {
         val_t out = acc;
         if (side) out += s_y[g][0][r];
@@ -718,6 +742,14 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
             }
         }
     }
+#ifdef TILESPMV_STAMPS
+    TSPMV_STAMP(5);            // stores issued
+    TSPMV_STAMP_WAIT(6);       // stores acknowledged
+    if (S.stamps && (tid & 63) == 0) {
+        unsigned long long *o = S.stamps + ((long long)blockIdx.x * 4 + (tid >> 6)) * 8;
+        for (int i = 0; i < 8; i++) o[i] = stamp_[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

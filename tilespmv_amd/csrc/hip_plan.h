@@ -108,6 +108,9 @@ struct DevStream {
     // finishes last (fixed slot order): ifix[i] describes row i, ifix_count[i] counts finished pieces
     const FixRow *ifix;
     unsigned *ifix_count;
+#ifdef TILESPMV_STAMPS
+    unsigned long long *stamps;           // diagnostic build only (scripts/stamps_probe.py): 8 clock stamps per wavefront
+#endif
 };
 
 // Dense tiles on the matrix cores (generation 2): one wavefront per tile-row that owns dense tiles.

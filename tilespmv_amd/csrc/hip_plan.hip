@@ -633,6 +633,10 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         if (dr.tile_end - dr.tile_begin > 64) { fprintf(stderr, "tilespmv: internal error: dense piece of %d tiles\n", dr.tile_end - dr.tile_begin); rc = -6; }
     free(h_uval); free(h_cval); free(h_hval); free(h_hidx); free(h_dval);
     S.ntasks = (int)tasks.size();
+#ifdef TILESPMV_STAMPS
+    { void *sp = nullptr; const size_t nst = ((tasks.size() + 15) / 16) * 4 * 8;
+      if (hipMalloc(&sp, nst * 8 + 64) == hipSuccess) { (void)hipMemset(sp, 0, nst * 8 + 64); plan->allocs.push_back(sp); } S.stamps = (unsigned long long *)sp; }
+#endif
     S.ifix = nullptr; S.ifix_count = nullptr;
     if (!ifix.empty()) {
         rc |= plan->upload(ifix.data(), ifix.size(), &S.ifix);
@@ -1118,6 +1122,17 @@ int tilespmv_plan_spmv_n(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_T
     }
     return 0;
 }
+
+#ifdef TILESPMV_STAMPS
+// diagnostic build only: copies the per-wavefront clock stamps of the last k_units launch (8 per wavefront) to the host
+long long tilespmv_plan_stamps(const tilespmv_plan *plan, unsigned long long *out, long long max_words)
+{
+    const long long n = ((long long)plan->st.ntasks + 15) / 16 * 4 * 8;
+    if (!plan->st.stamps || n > max_words) return -n;
+    if (hipMemcpy(out, plan->st.stamps, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+#endif
 
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out)
 {
