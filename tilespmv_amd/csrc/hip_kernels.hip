@@ -2,8 +2,9 @@
 //
 //   k_units          (default) unit-stream kernel: one 16-lane strip per task consumes a flat run of
 //                    self-describing 16-value units (ELL / HYB slots, dense and dense-col columns, the
-//                    leading entries of CSR tile rows, dense-row "row units") plus the strip's COO
-//                    entry list.  Replaces stir_spmv_cuda_kernel_v6 (src/tilespmv_cuda.h:394-792).
+//                    leading entries of CSR tile rows, dense-row "row units") plus the COO entry list —
+//                    walked per strip, or, on entry-heavy shards, as one merged, column-ordered list per
+//                    wavefront / per workgroup.  Replaces stir_spmv_cuda_kernel_v6 (src/tilespmv_cuda.h:394-792).
 //   k_dense_mfma     dense tiles on the matrix cores, one wavefront per tile-row (y +=).
 //   k_tiles_direct   first-generation fused tile SpMV: a strip walks whole tile-rows one tile at a
 //                    time through the seven per-tile routines below (TILESPMV_KERNEL=1), and the
@@ -23,8 +24,6 @@
 //   dense-col:751-778                                like ELL with a per-column id
 // x is staged per tile as a 16-value LDS segment (the reference: s_x_warp / register + shfl).
 #include <hip/hip_runtime.h>
-
-#include <type_traits>
 
 #include "hip_plan.h"
 
@@ -377,7 +376,7 @@ typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 #define NT_Y 1  // y is written once and not re-read by this kernel: streaming (nontemporal) stores keep it from displacing x in L2 (+1-2 %)
 #endif
 #ifndef WCOO_HEAVY_CT
-#define WCOO_HEAVY_CT 6  // sub-chunks of 64 entries per trip of an entry-heavy wavefront
+#define WCOO_HEAVY_CT 6  // sub-chunks (of 64 / 256 entries) per trip of the wavefront / workgroup entry phase
 #endif
 #ifndef ECOO2_MIN_WAVES
 #define ECOO2_MIN_WAVES 6  // workgroup entry mode: 80 VGPRs

@@ -95,12 +95,13 @@ struct DevStream {
     const unsigned char *crow;
     const STask *task;
     int ntasks;
-    int coo_heavy_min;                    // strips (wavefronts, with the wave-cooperative entry phase) with more COO entries than this run their entry list before the unit pipeline
+    int coo_heavy_min;                    // entry mode 0: strips with more COO entries than this run their entry list before the unit pipeline
     int coo_nt;                           // entry streams loaded with the nontemporal hint
     int coo_ordered;                      // workgroup entry mode: wavefronts add in turn (bit-reproducible sums)
-    // entry mode 2 (k_units<.., 2>): the entries of the 16 strips of one workgroup, merged and ordered by column, so that
-    // the lanes of one gather share x lines; column word = global column | strip-in-workgroup << 28, row byte as in crow
-    const int2 *wg_coo;                   // per workgroup: [begin, end) in gval / gcol / grow
+    // entry modes 1 / 2 (k_units<.., 1 | 2>): the entries of the 4 strips of one wavefront / the 16 strips of one workgroup,
+    // merged and ordered by column, so that the lanes of one gather share x lines; column word = global column |
+    // strip-in-group << 28, row byte as in crow
+    const int2 *wg_coo;                   // per group (wavefront or workgroup): [begin, end) in gval / gcol / grow
     const val_t *gval;
     const int *gcol;
     const unsigned char *grow;

@@ -647,8 +647,9 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     }
     rc |= plan->upload(fix_late.data(), fix_late.size(), &plan->dev.fix_late);
     plan->dev.nfix_late = (int)fix_late.size();
-    // per strip (default 32; swept on KKT fp64 / scircuit / webbase stand-ins: best or within 1 %), per wavefront with wave_coo (256 = one light trip)
-    S.coo_heavy_min = std::max(0, env_int("TILESPMV_COO_HEAVY_MIN", wave_coo ? 256 : 32));
+    // entry mode 0 only: strips with more entries than this run their list before the unit pipeline (32: swept on KKT fp64 / scircuit /
+    // webbase stand-ins in round 1, best or within 1 %)
+    S.coo_heavy_min = std::max(0, env_int("TILESPMV_COO_HEAVY_MIN", 32));
     S.coo_nt = env_int("TILESPMV_COO_NT", 0);
     S.coo_ordered = coo_ordered ? 1 : 0;
     plan->info[TILESPMV_INFO_ENTRY_MODE] = entry_mode;
