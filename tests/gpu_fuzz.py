@@ -68,6 +68,10 @@ def check(seed):
     if seed % 3 == 0: env["TILESPMV_SPLIT_ABOVE"] = "150"
     if seed % 4 == 0: env["TILESPMV_STRIP_COST"] = "64"
     if seed % 5 == 0: env["TILESPMV_COO_HEAVY_MIN"] = "4"
+    # how the COO entry lists run (round 2): default choice / per strip / per wavefront / per workgroup ordered, unordered
+    env.update([{}, {"TILESPMV_WAVE_COO": "0"}, {"TILESPMV_WAVE_COO": "1"}, {"TILESPMV_WAVE_COO": "2", "TILESPMV_COO_ORDERED": "1"},
+                {"TILESPMV_WAVE_COO": "2", "TILESPMV_COO_ORDERED": "0"}][seed % 5 if seed % 2 else (seed // 2) % 5])
+    if seed % 11 == 0: env["TILESPMV_STRIP_COST"] = "1600"
     os.environ.update(env)
     for dt in (np.float64, np.float32):
         vals = rng.integers(1, 4, nnz).astype(dt)
