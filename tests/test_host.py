@@ -298,3 +298,36 @@ def test_partition_tilerows_balanced():
         assert load.sum() == d["blknnz"][-1]
         if parts > 1:
             assert load.max() <= 1.5 * load.sum() / parts + 4096
+
+
+def test_stand_in_generators_have_the_sizes_of_the_real_matrices():
+    """bench.build_matrix: the scircuit / webbase-1M stand-ins have exactly the rows and nnz of the SuiteSparse matrices
+    (reference src/external/CSR5_cuda/2757-matrix.csv:544, :2379); nlpkkt_like is symmetric, column-sorted, hits a requested
+    nnz exactly and has the row count of nlpkkt160 at g = 160 (8,345,600 = 2*160^3 + 6*160^2; :1903)."""
+    import sys
+    import scipy.sparse as sp
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    argv, sys.argv = sys.argv, sys.argv[:1]
+    try:
+        import bench
+    finally:
+        sys.argv = argv
+    for name, rows, nnz in (("scircuit", 170998, 958936), ("webbase", 1000005, 3105536)):
+        m, n, rp, ci, src = bench.build_matrix(name)
+        assert (m, n, len(ci), int(rp[-1])) == (rows, rows, nnz, nnz) and "synthetic" in src
+        assert (np.diff(rp) >= 0).all() and ci.min() >= 0 and ci.max() < n
+        seg_sorted = np.ones(len(ci), bool); seg_sorted[1:] = np.diff(ci.astype(np.int64)) > 0
+        seg_sorted[rp[:-1][np.diff(rp) > 0]] = True
+        assert seg_sorted.all()                                   # columns ascending inside every row, no duplicates
+    g = 12
+    m, n, rp, ci = G.nlpkkt_like(g, target_nnz=None)
+    assert m == n == 2 * g ** 3 + 6 * g ** 2
+    A = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(m, n))
+    assert (A != A.T).nnz == 0 and A.has_sorted_indices
+    full = len(ci)
+    m2, n2, rp2, ci2 = G.nlpkkt_like(g, target_nnz=full - 2 * 137)
+    A2 = sp.csr_matrix((np.ones(len(ci2)), ci2, rp2), shape=(m2, n2))
+    assert len(ci2) == full - 2 * 137 and (A2 != A2.T).nnz == 0
+    assert 2 * 160 ** 3 + 6 * 160 ** 2 == G.NLPKKT160_ROWS
+    m3, n3, rp3, ci3 = G.retarget_nnz(*G.circuit_like(3000, seed=4), target_nnz=20000, seed=4)
+    assert len(ci3) == 20000 and int(rp3[-1]) == 20000
