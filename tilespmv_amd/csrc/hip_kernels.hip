@@ -11,8 +11,8 @@
 //                    pass for CSR tiles kept whole in generation 2 (ACCUM).
 //   k_fixup_split    sums the partial results of split (very long) tile-rows in a fixed order
 //                    (the reference uses global atomicAdd, src/tilespmv_cuda.h:784-790).
-//   k_fallback_csr   very-sparse CSR fallback, y += A_coo x over the extracted matrix
-//                    (the reference hands this to CSR5, src/tilespmv_cuda.h:1011-1029,:1080).
+//   k_fallback_entries  very-sparse fallback, y += A_coo x over the extracted matrix: nnz-balanced row blocks,
+//                    column-ordered, one workgroup each (the reference hands this to CSR5, src/tilespmv_cuda.h:1011-1029,:1080).
 //
 // Per-tile routines (lane r = lane & 15 owns row r of the tile):
 //   CSR      reference src/tilespmv_cuda.h:531-561   row-per-lane walk of the byte row pointer
@@ -36,7 +36,6 @@ constexpr int GROUPS_PER_BLOCK = 16;  // 256 threads
 #ifndef TILESPMV_STREAM_MIN_WAVES
 #define TILESPMV_STREAM_MIN_WAVES 1     // second __launch_bounds__ argument = waves per SIMD asked of the register allocator
 #endif
-constexpr int FB_NNZ = 256;           // products staged per wave in the fallback kernel (4 entries per lane, all loads in flight at once)
 
 __device__ __forceinline__ int nibble_of(const unsigned char *__restrict__ base, int p)
 {
@@ -244,69 +243,6 @@ __global__ __launch_bounds__(256) void k_fixup_split(DevPlan P, val_t *__restric
     if (yi < P.rowA) y[yi] = sum;
 }
 
-// ================================================================================================
-// Very-sparse CSR fallback: y[row] += sum_j val[j] * x[col[j]] over the extracted matrix.
-// One wavefront per row block: short rows are "streamed" (coalesced loads of up to FB_NNZ
-// entries, products parked in LDS, then one lane per row adds its run in storage order), a row
-// longer than FB_NNZ gets the whole wavefront.
-// ================================================================================================
-__global__ __launch_bounds__(256) void k_fallback_csr(DevPlan P, const val_t *__restrict__ x, val_t *__restrict__ y)
-{
-    __shared__ val_t s_prod[4][FB_NNZ];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int blk = blockIdx.x * 4 + wave;
-    if (blk >= P.f_nblk) return;
-    const int r0 = P.f_blk[2 * blk], r1 = P.f_blk[2 * blk + 1];
-    const int p0 = P.f_ptr[r0], n = P.f_ptr[r1] - p0;
-    if (n > FB_NNZ) {  // a single long row (the host never groups such a row with others)
-        val_t sum = 0;
-        for (int k0 = 0; k0 < n; k0 += 256) {  // 4 x 64 entries per trip: loads first, then the gathers
-            val_t v[4], xx[4]; int c[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const int k = min(k0 + lane + 64 * q, n - 1); v[q] = P.f_val[p0 + k]; c[q] = P.f_col[p0 + k]; }
-#pragma unroll
-            for (int q = 0; q < 4; q++) xx[q] = x[c[q]];
-#pragma unroll
-            for (int q = 0; q < 4; q++) if (k0 + lane + 64 * q < n) sum += v[q] * xx[q];
-        }
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
-        if (lane == 0) y[P.f_row0 + r0] += sum;
-        return;
-    }
-    // row bounds and old y of the first 64 rows travel together with the entry loads
-    const int rowl = min(r0 + lane, r1 - 1);
-    const int pa0 = P.f_ptr[rowl] - p0, pb0 = P.f_ptr[rowl + 1] - p0;
-    const val_t yold0 = y[P.f_row0 + rowl];
-    {   // n <= FB_NNZ = 4 x 64: every lane issues its (up to) four value/column loads, then the four x gathers
-        val_t v[4]; int c[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int k = min(lane + 64 * q, n - 1);
-            v[q] = P.f_val[p0 + k]; c[q] = P.f_col[p0 + k];
-        }
-        val_t xx[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) xx[q] = x[c[q]];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (lane + 64 * q < n) s_prod[wave][lane + 64 * q] = v[q] * xx[q];
-    }
-    wave_lds_fence();
-    if (r0 + lane < r1 && pb0 > pa0) {
-        val_t sum = 0;
-        for (int k = pa0; k < pb0; k++) sum += s_prod[wave][k];
-        y[P.f_row0 + rowl] = yold0 + sum;
-    }
-    for (int row = r0 + 64 + lane; row < r1; row += 64) {
-        const int a = P.f_ptr[row] - p0, b = P.f_ptr[row + 1] - p0;
-        if (b > a) {
-            val_t sum = 0;
-            for (int k = a; k < b; k++) sum += s_prod[wave][k];
-            y[P.f_row0 + row] += sum;
-        }
-    }
-}
-
 // ---- launchers (host) ---------------------------------------------------------------------------
 hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulate, bool fixup, const val_t *x, val_t *y, hipStream_t st)
 {
@@ -321,14 +257,6 @@ hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulat
         hipLaunchKernelGGL(k_fixup_split, dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, y);
     return hipGetLastError();
 }
-
-hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st)
-{
-    if (P.f_nblk > 0) hipLaunchKernelGGL(k_fallback_csr, dim3((P.f_nblk + 3) / 4), dim3(256), 0, st, P, x, y);
-    return hipGetLastError();
-}
-
-int fallback_block_nnz() { return FB_NNZ; }
 
 }  // namespace tilespmv
 
@@ -417,19 +345,19 @@ __device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t
 // power-law matrices the number of distinct x lines per batch drops from 0.48 per entry (one strip at a time) to 0.15
 // (64 tile-rows at a time), and the CU's L1 -> L2 request rate is what bounds those matrices.
 template <int CT>
-__device__ __forceinline__ void wg_entry_trips(const DevStream &S, const val_t *__restrict__ x, val_t *sy, int tid, int gb, int ge)
+__device__ __forceinline__ void wg_entry_trips(const val_t *__restrict__ gval, const int *__restrict__ gcol, const unsigned char *__restrict__ grow,
+                                               bool coo_nt, bool ordered, const val_t *__restrict__ x, val_t *sy, int tid, int gb, int ge)
 {
-    const bool coo_nt = S.coo_nt != 0;
     for (int e0 = gb; e0 < ge; e0 += 256 * CT) {
         int cc[CT]; unsigned rb[CT]; val_t cv[CT], xx[CT];
 #pragma unroll
         for (int q = 0; q < CT; q++) {
             const int e = min(e0 + 256 * q + tid, ge - 1);
-            rb[q] = stream_load(S.grow + e, coo_nt); cc[q] = stream_load(S.gcol + e, coo_nt); cv[q] = stream_load(S.gval + e, coo_nt);
+            rb[q] = stream_load(grow + e, coo_nt); cc[q] = stream_load(gcol + e, coo_nt); cv[q] = stream_load(gval + e, coo_nt);
         }
 #pragma unroll
         for (int q = 0; q < CT; q++) xx[q] = x[cc[q] & 0x0FFFFFFF];
-        if (S.coo_ordered) {
+        if (ordered) {
             // the four wavefronts add in turn: the order of the additions into one y element is then fixed by the plan (entry
             // order inside a wavefront instruction, instruction order inside a wavefront, wavefront 0..3 inside a trip), not by
             // timing, and two launches give the same bits (the reference's atomicAdd, src/tilespmv_cuda.h:784-790, does not)
@@ -447,6 +375,40 @@ __device__ __forceinline__ void wg_entry_trips(const DevStream &S, const val_t *
                 if (e0 + 256 * q + tid < ge) atomicAdd(&sy[((unsigned)cc[q] >> 28) * (STRIP_MAX_ROWS * 16) + rb[q]], cv[q] * xx[q]);
         }
     }
+}
+
+// ================================================================================================
+// Very-sparse fallback: y[row] += sum_j val[j] * x[col[j]] over the extracted matrix (the reference hands it to CSR5,
+// src/tilespmv_cuda.h:1011-1029,:1080; kernels src/external/CSR5_cuda/detail/cuda/csr5_spmv_cuda.h:277-420).
+// nnz-balanced like CSR5 — one workgroup per row block of <= FB_CAP nonzeros (and <= FB_ROWS rows), a longer row cut into
+// pieces that add atomically as CSR5's calibrate step does (:315-384) — but with what bounds this chip on such matrices in
+// mind: the block's nonzeros are ordered by column at plan time and walked by all 256 lanes, so that the
+// lanes of one gather share x lines, and the row sums are accumulated in LDS.
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_fallback_entries(DevPlan P, const val_t *__restrict__ x, val_t *__restrict__ y)
+{
+    __shared__ val_t s_acc[FB_ROWS];
+    const int tid = threadIdx.x;
+    const int4 b = P.f_blk[blockIdx.x];
+    const int nrows = b.y < 0 ? 1 : b.y;
+    for (int i = tid; i < nrows; i += 256) s_acc[i] = 0;
+    __syncthreads();
+    wg_entry_trips<6>(P.f_val, P.f_col, P.f_row, false, P.f_ordered != 0, x, s_acc, tid, b.z, b.w);
+    __syncthreads();
+    if (b.y < 0) {
+        if (tid == 0) atomicAdd(&y[(long long)P.f_row0 + b.x], s_acc[0]);
+    } else {
+        for (int i = tid; i < nrows; i += 256) {
+            const val_t v = s_acc[i];
+            if (v != (val_t)0) y[(long long)P.f_row0 + b.x + i] += v;   // a row without extracted nonzeros holds an exact zero: nothing to add
+        }
+    }
+}
+
+hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st)
+{
+    if (P.f_nblk > 0) hipLaunchKernelGGL(k_fallback_entries, dim3((unsigned)P.f_nblk), dim3(256), 0, st, P, x, y);
+    return hipGetLastError();
 }
 
 #ifdef TILESPMV_STAMPS
@@ -550,7 +512,7 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
         unit_prologue();
         TSPMV_STAMP_WAIT(2);   // prologue has arrived (the entry loads are inside the trips)
         if (wr.y > wr.x) {
-            wg_entry_trips<WCOO_HEAVY_CT>(S, x, &s_y[0][0][0], tid, wr.x, wr.y);
+            wg_entry_trips<WCOO_HEAVY_CT>(S.gval, S.gcol, S.grow, S.coo_nt != 0, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y);
             __syncthreads();
         }
         TSPMV_STAMP_WAIT(3);   // entry phase done

@@ -48,12 +48,15 @@ struct DevPlan {
     int nfix;
     const FixRow *fix_late; // split tile-rows with pieces outside the unit kernel: summed by k_fixup_split after all passes
     int nfix_late;
-    // very-sparse CSR fallback (extracted matrix of the shard's rows)
-    const int *f_ptr;       // deferredcoo_ptr restricted to the shard, rebased to 0
-    const int *f_col;
+    // very-sparse fallback (the extracted matrix of the shard's rows, deferredcoo_*): row blocks of <= FB_ROWS rows and
+    // <= FB_CAP nonzeros, one workgroup each, the block's nonzeros ordered by column (same list form as the workgroup
+    // entry mode of the unit kernel: column word = column | (row-in-block >> 7) << 28, row byte = row-in-block & 127)
+    const int4 *f_blk;      // per block: first local row, #rows (-1: one piece of a single row longer than FB_CAP -> atomic add), [begin, end) in f_val / f_col / f_row
     const val_t *f_val;
-    const int *f_blk;       // row-block boundaries (local row ids), nblk+1 entries
+    const int *f_col;
+    const unsigned char *f_row;
     int f_nblk;
+    int f_ordered;          // wavefronts add in turn (bit-reproducible sums)
     int f_row0;             // first global row of the shard
     int f_rows;
 };
@@ -67,6 +70,8 @@ struct DevPlan {
 // dense tiles when they run on the matrix cores) stay whole tiles in a "heavy" list that
 // keeps the first-generation per-tile layout (DevPlan streams) and is executed by the
 // first-generation kernel in accumulate mode after the unit kernel has written y.
+constexpr int FB_ROWS = 2048;             // fallback row block: rows (= 16 x 128: the entry lists' 4 + 7 destination bits) ...
+constexpr int FB_CAP = 6144;              // ... and nonzeros (4 trips of 6 x 256)
 constexpr int STRIP_MAX_ROWS = 8;         // tile-rows per strip (3 bits of row-in-strip)
 constexpr unsigned UNIT_EOR = 1u;         // unit flag bit 0: last unit of its tile-row -> write y
 constexpr int UNIT_ROW_SHIFT = 1;         // unit flag bits 1-3: tile-row inside the strip

@@ -22,7 +22,6 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, const val_t *X, val_t *Y,
                                   hipStream_t st);
-int fallback_block_nnz();
 hipError_t launch_rows_to_columns(const val_t *X, int nvec, long long n, long long ld, val_t *XT, hipStream_t st);
 hipError_t launch_columns_to_rows(const val_t *YT, int nvec, long long row0, long long rows, long long ld, val_t *Y, hipStream_t st);
 
@@ -719,7 +718,10 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     val_t *dx = nullptr, *dy = nullptr;
     if (hipMalloc((void **)&dx, ((size_t)colA + 16) * sizeof(val_t)) != hipSuccess) return -3;
     if (hipMalloc((void **)&dy, ((size_t)rowA + 16) * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); return -3; }
-    (void)hipMemset(dx, 0, ((size_t)colA + 16) * sizeof(val_t));
+    {   // x = 1: an all-zero x would make every product zero, and the fallback kernel skips rows whose sum is exactly zero
+        std::vector<val_t> ones((size_t)colA + 16, (val_t)1);
+        (void)hipMemcpy(dx, ones.data(), ones.size() * sizeof(val_t), hipMemcpyHostToDevice);
+    }
     tilespmv_plan *best = nullptr;
     double best_ms = 0;
     std::string log = "{\"rows\": " + std::to_string(rowA) + ", \"cols\": " + std::to_string(colA) + ", \"nnz\": " + std::to_string((long long)nnzA) +
@@ -994,26 +996,59 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     n_tasks = (long long)tasks.size();
     model_bytes = n_desc * 8 + n_val * sv + n_idx + n_tasks * (long long)sizeof(Task);
     }
-    // ---- very-sparse fallback matrix: the shard's rows of deferredcoo_*, plus its row blocks
-    std::vector<int> f_ptr, f_blk;
+    // ---- very-sparse fallback matrix: the shard's rows of deferredcoo_*, cut into nnz-balanced row blocks (<= FB_CAP nonzeros,
+    // <= FB_ROWS rows, one workgroup each; a single longer row becomes several one-row pieces that add atomically), the nonzeros
+    // of a block ordered by column with their row-in-block split over the column word's top bits and the row byte (hip_plan.h)
+    std::vector<int4> f_blk;
     long long f_nnz = 0;
     const int row0 = tr0 * 16, rows = (int)shard_rows;
+    val_t *f_val = nullptr;
+    std::vector<int> f_col;
+    std::vector<unsigned char> f_row;
     if (!coo_in_tile && extracted > 0) {
-        const int base = T->deferredcoo_ptr[row0];
-        f_ptr.resize((size_t)rows + 1);
-        for (int r = 0; r <= rows; r++) f_ptr[r] = T->deferredcoo_ptr[row0 + r] - base;
-        f_nnz = f_ptr[rows];
-        const int cap = fallback_block_nnz(), maxrows = 256;
+        const int *P0 = T->deferredcoo_ptr + row0;
+        const int base = P0[0];
+        f_nnz = P0[rows] - base;
+        // block size: FB_CAP nonzeros when there is enough work for ~3 workgroups per CU, smaller blocks (down to one trip) otherwise
+        const int cap = (int)std::max<long long>(1536, std::min<long long>(FB_CAP, f_nnz / (3 * 256)));
         int r = 0;
         while (r < rows) {
-            if (f_ptr[r + 1] == f_ptr[r]) { r++; continue; }  // runs of empty rows are not covered at all
-            int e = r;
-            if (f_ptr[r + 1] - f_ptr[r] > cap) e = r + 1;
-            else while (e < rows && e - r < maxrows && f_ptr[e + 1] - f_ptr[r] <= cap) e++;
-            while (e > r + 1 && f_ptr[e] == f_ptr[e - 1]) e--;  // drop trailing empty rows
-            f_blk.push_back(r); f_blk.push_back(e);
+            const int nr = P0[r + 1] - P0[r];
+            if (nr == 0) { r++; continue; }   // runs of empty rows are not covered at all
+            if (nr > FB_CAP) {
+                for (int sft = P0[r]; sft < P0[r + 1]; sft += FB_CAP) f_blk.push_back(make_int4(r, -1, sft - base, std::min(sft + FB_CAP, P0[r + 1]) - base));
+                r++;
+                continue;
+            }
+            int e = r, cnt = 0;
+            while (e < rows && e - r < FB_ROWS && (P0[e + 1] - P0[e]) <= FB_CAP && (e == r || cnt + (P0[e + 1] - P0[e]) <= cap)) { cnt += P0[e + 1] - P0[e]; e++; }
+            while (e > r + 1 && P0[e] == P0[e - 1]) e--;  // drop trailing empty rows
+            f_blk.push_back(make_int4(r, e - r, P0[r] - base, P0[e] - base));
             r = e;
         }
+        f_val = zalloc<val_t>((size_t)f_nnz);
+        f_col.resize((size_t)f_nnz); f_row.resize((size_t)f_nnz);
+        parallel_chunks((int64_t)f_blk.size(), 16, [&](int64_t b0, int64_t b1, int) {
+            std::vector<std::pair<unsigned long long, int>> key;
+            for (int64_t b = b0; b < b1; b++) {
+                const int4 k = f_blk[(size_t)b];
+                key.clear();
+                if (k.y < 0) {
+                    for (int q = k.z; q < k.w; q++) key.push_back({((unsigned long long)(unsigned)T->deferredcoo_colidx[base + q] << 32) | (unsigned)(q - k.z), 0});
+                } else {
+                    for (int rr = k.x; rr < k.x + k.y; rr++)
+                        for (int q = P0[rr] - base; q < P0[rr + 1] - base; q++)
+                            key.push_back({((unsigned long long)(unsigned)T->deferredcoo_colidx[base + q] << 32) | (unsigned)(q - k.z), rr - k.x});
+                }
+                std::sort(key.begin(), key.end());   // by column; ties keep the extracted matrix's order
+                for (size_t i = 0; i < key.size(); i++) {
+                    const int q = k.z + (int)(key[i].first & 0xFFFFFFFFull), dest = key[i].second;
+                    f_val[(size_t)k.z + i] = T->deferredcoo_val[base + q];
+                    f_col[(size_t)k.z + i] = (int)((unsigned)T->deferredcoo_colidx[base + q] | ((unsigned)(dest >> 7) << 28));
+                    f_row[(size_t)k.z + i] = (unsigned char)(dest & 127);
+                }
+            }
+        });
     }
 
     // ---- upload the rest
@@ -1024,13 +1059,16 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         else { plan->allocs.push_back(p); D.partial = (val_t *)p; }
     }
     if (!f_blk.empty()) {
-        const int base = T->deferredcoo_ptr[row0];
-        rc |= plan->upload(f_ptr.data(), f_ptr.size(), &D.f_ptr);
-        rc |= plan->upload(T->deferredcoo_colidx + base, (size_t)f_nnz, &D.f_col);
-        rc |= plan->upload(T->deferredcoo_val + base, (size_t)f_nnz, &D.f_val);
+        rc |= plan->upload(f_val, (size_t)f_nnz, &D.f_val);
+        rc |= plan->upload(f_col.data(), (size_t)f_nnz, &D.f_col);
+        rc |= plan->upload(f_row.data(), (size_t)f_nnz, &D.f_row);
         rc |= plan->upload(f_blk.data(), f_blk.size(), &D.f_blk);
-        D.f_nblk = (int)(f_blk.size() / 2);
+        D.f_nblk = (int)f_blk.size();
+        // taking turns costs latency on small grids and nothing on large ones (as in the unit kernel's workgroup entry mode)
+        const int ordered_env = env_int("TILESPMV_COO_ORDERED", -1);
+        D.f_ordered = ordered_env >= 0 ? ordered_env != 0 : f_blk.size() >= 2048;
     }
+    free(f_val);
     if (rc) { tilespmv_plan_destroy(plan); return rc; }
     D.nfix = (int)fix.size();
     D.rowA = std::min<long long>(rowA, (long long)tr1 * 16); D.colA = colA;
@@ -1047,7 +1085,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     I[TILESPMV_INFO_BUILD_US] = (long long)(now_us() - t_create0) - I[TILESPMV_INFO_UPLOAD_US];
     // bytes one SpMV has to move at least: the three streams + tasks + x once + y once (+ fallback)
     I[TILESPMV_INFO_STREAM_BYTES] = model_bytes + (long long)colA * sv + (long long)rows * sv +
-                                    (f_nnz ? f_nnz * (sv + 4) + (long long)rows * 4 + (long long)f_blk.size() * 4 : 0);
+                                    (f_nnz ? f_nnz * (sv + 5) + 2LL * sv * rows + (long long)f_blk.size() * 16 : 0);   // the fallback re-reads and re-writes its rows of y
     *out = plan;
     return 0;
 }
