@@ -259,8 +259,6 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     std::vector<Task> htasks;
     std::vector<FixRow> ifix, fix_late;   // split rows summed inside the unit kernel / by k_fixup_split after all passes
     const bool fix_inline_on = env_int("TILESPMV_FIX_INLINE", 1) != 0;
-    // Entry lists walked by whole wavefronts (k_units<.., WCOO>): on when the shard is entry-heavy.  The per-strip form
-    // stays for regular matrices, where a strip has a handful of entries and the wave-wide index arithmetic is pure cost.
     // How the COO entry lists run (TILESPMV_WAVE_COO = 0 / 1 / 2 overrides):
     //   0  per 16-lane strip — regular matrices (a handful of entries per strip);
     //   1  per wavefront, the four strips' lists merged and ordered by column — entry-heavy but small grids, where the
