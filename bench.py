@@ -375,7 +375,7 @@ def main():
         "hbm_gbps_algorithmic": round(b_alg_total / (wall / args.steps) * 1e-9, 1),
         "hbm_roofline_frac": round(b_alg_total / (wall / args.steps) * 1e-9 / (HBM_PEAK_GBPS * world), 4),
         "roofline": roofline, "check": check,
-        "ranks": world, "devices": [int(r[0]) for r in main_per_rank], "backend": (args.backend if world > 1 else None),
+        "ranks": (dist.get_world_size() if world > 1 else 1), "devices": [int(r[0]) for r in main_per_rank], "backend": (args.backend if world > 1 else None),
         "per_rank_ms_per_step": {"wall": [round(r[1], 5) for r in main_per_rank], "device": [round(r[2], 5) for r in main_per_rank],
                                  "min": round(min(r[1] for r in main_per_rank), 5), "max": round(max(r[1] for r in main_per_rank), 5)},
         "launched_by": "self (child torch.distributed.run)" if os.environ.get("TILESPMV_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "direct"),
