@@ -306,6 +306,9 @@ typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 #ifndef WCOO_HEAVY_CT
 #define WCOO_HEAVY_CT 6  // sub-chunks (of 64 / 256 entries) per trip of the wavefront / workgroup entry phase
 #endif
+#ifndef MV_MIN_WAVES
+#define MV_MIN_WAVES 6  // multi-vector kernel: 80 VGPRs (5 waves: 84 VGPRs, nvec 8 0.79 ms; 6: 0.74 ms; 7 spills: 1.01 ms)
+#endif
 #ifndef ECOO2_MIN_WAVES
 #define ECOO2_MIN_WAVES 6  // workgroup entry mode: 80 VGPRs
 #endif
@@ -815,7 +818,7 @@ struct alignas(NV * sizeof(val_t) >= 16 ? 16 : NV * sizeof(val_t)) MVec { val_t 
 // registers, the stores of one Y row (NV values) come from Q lanes of one store instruction, and a
 // wavefront sees the store latency of one strip instead of four (stores retire in order with the loads).
 template <int NVT>
-__global__ __launch_bounds__(256) void k_units_mv(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+__global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                   const val_t *__restrict__ X, val_t *__restrict__ Y)
 {
     constexpr int NV = NVT < 2 ? NVT : 2;   // vectors per lane
