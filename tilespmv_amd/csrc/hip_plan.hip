@@ -276,7 +276,19 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     // of the work (webbase-like: nvec 2 took 0.11 ms against 0.013 ms for one SpMV) one SpMV per right-hand side is faster
     const bool entry_dominated = (long long)env_int("TILESPMV_COO_COST", 4) * NC * 2 > total_cost;
     int target = target_in;
-    if (target <= 0) target = entry_heavy ? (int)std::min<long long>(1600, std::max<long long>(400, total_cost / (3 * 256 * 16))) : 400;
+    if (target <= 0) {
+        target = 400;
+        if (entry_heavy) {
+            // balanced, entry-dominated shards (uniform random: 0.075 ms at 1600, 0.060 ms at 3200; band + random fill 0.126 -> 0.117)
+            // take strips of up to 3200; skewed ones (R-MAT scale 20: 0.054 ms at 1600, 0.076 ms at 3200) and unit-dominated ones
+            // (KKT-like 64^3: 0.022 ms at 967, 0.051 ms at 3200) stop at 1600
+            long long max_cost = 0;
+            for (int i = 0; i < ntr; i++) max_cost = std::max(max_cost, rc_[i].cost);
+            const bool balanced = ntr > 0 && max_cost * ntr <= 4 * total_cost;
+            const long long cap = (entry_dominated && balanced) ? 3200 : 1600;
+            target = (int)std::min<long long>(cap, std::max<long long>(400, total_cost / (3 * 256 * 16)));
+        }
+    }
     target = std::max(32, target);
     const long long est_wgs = total_cost / (16LL * target) + 1;
     const int wave_coo_env = env_int("TILESPMV_WAVE_COO", -1);
@@ -292,7 +304,12 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
     const int npartial0 = npartial;
     auto cut = [&](int target) {
-        const int split_above = std::max(6 * target, split_above_in), piece = std::max(2 * target, split_above / 3);
+        // rows above this cost are cut into pieces.  With the wavefront / workgroup entry modes a long row is no longer one strip's
+        // private burden, but an unsplit one still makes its workgroup the last to finish: the threshold stops growing with the
+        // strip size there (R-MAT scale 20 at strip size 3200: 0.099 ms with rows of up to 19,200 cost units kept whole)
+        const int split_cap = env_int("TILESPMV_SPLIT_CAP", 4800);
+        const int split_above = wave_coo ? std::max(split_above_in, std::min(6 * target, split_cap)) : std::max(6 * target, split_above_in);
+        const int piece = std::max(wave_coo ? std::min(2 * target, 1600) : 2 * target, split_above / 3);
         tasks.clear(); htasks.clear(); ifix.clear(); fix_late.clear(); fix.clear(); drows.clear(); npartial = npartial0;
         std::fill(row_k.begin(), row_k.end(), 0); std::fill(row_split.begin(), row_split.end(), 0);
         const int strip_even = env_int("TILESPMV_STRIP_EVEN", 4);  // 0 off, 1 = value group, n > 1 = multiples of n units
@@ -843,29 +860,42 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         if (T->Format[t] == TILESPMV_FMT_COO) { ncoo_tiles++; ncoo_vals += T->blknnz[t + 1] - T->blknnz[t]; }
     const long long extracted = T->new_coocount[t_end] - T->new_coocount[t_begin];
     int coo_mode = o.coo_mode ? o.coo_mode : env_int("TILESPMV_COO_MODE", 0);
-    if (coo_mode == TILESPMV_COO_AUTO) {
-        const long long in_tile = ncoo_tiles * 8 + ncoo_vals * (sv + 1);
-        const long long fallback = extracted * (sv + 4) + shard_rows * 4 + shard_rows * 2 * sv;
-        coo_mode = (extracted > 0 && fallback * 10 < in_tile * 9) ? TILESPMV_COO_FALLBACK : TILESPMV_COO_IN_TILE;
-    }
-    const bool coo_in_tile = coo_mode == TILESPMV_COO_IN_TILE;
     int dense_mode = o.dense_mode ? o.dense_mode : env_int("TILESPMV_DENSE_MODE", 0);
     int kernel = o.kernel ? o.kernel : env_int("TILESPMV_KERNEL", 0);
     if (kernel == TILESPMV_KERNEL_AUTO)  // the unit descriptor keeps the column block in 24 bits
         kernel = tilen <= (1 << UNIT_FLAG_SHIFT) ? TILESPMV_KERNEL_STREAM : TILESPMV_KERNEL_DIRECT;
+    if (coo_mode == TILESPMV_COO_AUTO) {
+        if (kernel == TILESPMV_KERNEL_STREAM) {
+            // unit-stream kernel: the in-tile entry list is the extracted matrix folded into the fused launch (s_v + 5 bytes per
+            // nonzero, no per-tile descriptor); the fallback moves the same bytes plus a second launch and its rows of y twice.
+            // It never wins (1.1-2x behind on every measured matrix, 1.1-1.4x on uniform random ones).
+            coo_mode = TILESPMV_COO_IN_TILE;
+        } else {
+            const long long in_tile = ncoo_tiles * 8 + ncoo_vals * (sv + 1);   // generation 1: 8-byte descriptor per COO tile
+            const long long fallback = extracted * (sv + 5) + shard_rows * 2 * sv;
+            coo_mode = (extracted > 0 && fallback * 10 < in_tile * 9) ? TILESPMV_COO_FALLBACK : TILESPMV_COO_IN_TILE;
+        }
+    }
+    const bool coo_in_tile = coo_mode == TILESPMV_COO_IN_TILE;
     // Dense tiles: the matrix-core routine handles one tile per wavefront at a time; in the unit
     // kernel a dense tile is 16 streamed units instead, which measures faster on MI355X
     // (DESIGN.md §5), so AUTO keeps MFMA for the tile-at-a-time kernel only.
     if (dense_mode == TILESPMV_DENSE_AUTO) {
         if (kernel != TILESPMV_KERNEL_STREAM) dense_mode = TILESPMV_DENSE_MFMA;
         else {
-            // generation 2: dense tiles run on the matrix cores in their own pass (k_dense_mfma) when they
-            // carry a real share of the payload (band40: 0.358 ms vs 0.399 ms as streamed units); a
-            // handful of dense tiles is cheaper as 16 units each than as an extra launch
-            long long dense_vals = 0;
-            for (int t = t_begin; t < t_end; t++) if (T->Format[t] == TILESPMV_FMT_DNS) dense_vals += 256;
+            // generation 2: dense tiles run on the matrix cores in their own pass (k_dense_mfma, one wavefront per tile-row,
+            // accumulator carried across the row's dense tiles) when they carry a real share of the payload AND a tile-row
+            // holds several of them (band hbw 40, 5 per row: 0.263 ms vs 0.30-0.32 ms as streamed units; band hbw 12, one per
+            // row: 0.066 ms vs 0.050 ms — a one-tile chain does not pay for the extra launch and its y update); a handful
+            // of dense tiles is cheaper as 16 units each
+            long long dense_vals = 0, dense_rows = 0;
+            for (int bi = tr0; bi < tr1; bi++) {
+                long long nd = 0;
+                for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) if (T->Format[t] == TILESPMV_FMT_DNS) nd++;
+                dense_vals += 256 * nd; dense_rows += nd > 0;
+            }
             const long long all_vals = (long long)T->blknnz[t_end] - T->blknnz[t_begin];
-            dense_mode = (dense_vals * 10 >= all_vals && dense_vals >= 256 * 1024) ? TILESPMV_DENSE_MFMA : TILESPMV_DENSE_VALU;
+            dense_mode = (dense_vals * 10 >= all_vals && dense_vals >= 256 * 1024 && dense_vals >= 256 * 5 * dense_rows / 2) ? TILESPMV_DENSE_MFMA : TILESPMV_DENSE_VALU;
         }
     }
     plan->coo_mode = coo_mode; plan->dense_mode = dense_mode;
