@@ -203,9 +203,10 @@ typedef struct tilespmv_plan tilespmv_plan;
 
 /* How COO tiles (and HYB remainders) are executed — reference has both paths
  * (in-kernel deferred COO: src/tilespmv_cuda.h:462-488; extracted CSR + CSR5: :1011-1029,:1080). */
-#define TILESPMV_COO_AUTO 0      /* pick by modelled bytes */
-#define TILESPMV_COO_IN_TILE 1   /* COO tile kernel inside the fused launch */
-#define TILESPMV_COO_FALLBACK 2  /* very-sparse CSR fallback kernel (y += A_coo x) */
+#define TILESPMV_COO_AUTO 0      /* in-tile with the unit-stream kernel (the fallback is a second launch and never wins there);
+                                    by modelled bytes with TILESPMV_KERNEL_DIRECT */
+#define TILESPMV_COO_IN_TILE 1   /* COO entries inside the fused launch */
+#define TILESPMV_COO_FALLBACK 2  /* very-sparse fallback kernel over the extracted matrix (y += A_coo x), as the reference's CSR5 call */
 
 /* Dense-tile arithmetic. */
 #define TILESPMV_DENSE_AUTO 0
