@@ -918,8 +918,36 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
         for (int j = 0; j < NV; j++) { acc[j] += s_c[g][r][j]; s_c[g][r][j] = 0; }
         wave_lds_fence();
     };
+    // Stores count in the same in-order vmcnt queue as loads: a store issued at the end of a batch makes the next batch's wait
+    // for its gathers also wait for the store's acknowledge.  Where registers allow (no spill at 6 waves/SIMD), a retired row
+    // waits in registers and is stored right AFTER the next batch's loads have been issued: nvec 2 fp64 0.256 -> 0.249 ms, nvec 8
+    // fp32 0.494 -> 0.465 ms; with the spills it brings elsewhere (fp64 nvec 4 / 8: 6 VGPRs) it loses 5-7 %, so it is per variant.
+    constexpr bool MV_DEFER_STORE = NVT == 2 || (sizeof(val_t) == 4 && NVT == 8);
+    vec_t pend; int pend_kr = -1;
+    auto store_vec = [&](int kr, const vec_t &o) {
+        const long long yi = ((long long)row0 + kr) * 16 + r;
+        if (yi < rowA) {
+            if constexpr (sizeof(vec_t) == 16) {
+                v4u_t w; __builtin_memcpy(&w, &o, 16);
+                __builtin_nontemporal_store(w, reinterpret_cast<v4u_t *>(&Yv[yi * Q]));
+            } else if constexpr (sizeof(vec_t) == 8) {
+                v2u_t w; __builtin_memcpy(&w, &o, 8);
+                __builtin_nontemporal_store(w, reinterpret_cast<v2u_t *>(&Yv[yi * Q]));
+            } else {
+                Yv[yi * Q] = o;
+            }
+        }
+    };
+    auto flush_pending = [&]() { if (pend_kr >= 0) { store_vec(pend_kr, pend); pend_kr = -1; } };
     auto store_row = [&](int kr) {
         const long long yi = ((long long)row0 + kr) * 16 + r;
+        if (MV_DEFER_STORE) {
+            flush_pending();
+#pragma unroll
+            for (int j = 0; j < NV; j++) { pend.v[j] = acc[j]; acc[j] = 0; }
+            pend_kr = kr;
+            return;
+        }
         if (yi < rowA) {
             vec_t o;
 #pragma unroll
@@ -964,6 +992,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
             }
             val_t vn[UB];
             load_grp(u + UB, vn);
+            if (MV_DEFER_STORE) flush_pending();   // the row retired by the previous batch: behind this batch's loads
 #pragma unroll
             for (int k = 0; k < UB; k++) {
                 if (u + k >= unit_end) break;
@@ -989,6 +1018,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
             for (int k = 0; k < UB; k++) v[k] = vn[k];
         }
     }
+    if (MV_DEFER_STORE) flush_pending();
     if (part >= 0) {  // piece of a split tile-row: its partial sums go to the slot, k_fixup_split_mv adds the slots up
         coo_add(0, false);
         vec_t o;
@@ -998,6 +1028,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     } else {
         unsigned m = nounit;  // tile-rows without any unit: COO contributions only (or zero)
         while (m) { const int kr = __ffs((int)m) - 1; m &= m - 1; coo_add(kr, false); store_row(kr); }
+        if (MV_DEFER_STORE) flush_pending();
     }
 }
 
