@@ -296,3 +296,26 @@ def test_matrix_dir_hook_with_a_generated_file(torch_cuda, tmp_path, monkeypatch
     bm = _bench().build_matrix("scircuit")
     assert bm[4] == "file:scircuit.mtx" and bm[0] == m and len(bm[3]) == len(ci)
     test_real_matrix_files_through_cli_and_plan(torch_cuda, tmp_path)
+
+
+def test_auto_rules_pick_what_was_measured(torch_cuda):
+    """The AUTO choices that round 2's sweep over unseen matrices corrected stay put: with the unit-stream
+    kernel COO entries always run in-tile (also on uniform random matrices, where the old byte model chose the fallback); the
+    matrix-core pass is used for dense tiles only when a tile-row holds several of them; entry-heavy shards use the merged
+    lists, regular ones the per-strip walk; and every choice still gives the oracle's y."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    cases = [("uniform random", G.random_uniform(200000, 200000, 8.0 / 200000, 1), {"coo_mode": api.COO_IN_TILE, "entry_mode": (1, 2)}),
+             ("band hbw 12", G.band(200000, 12), {"coo_mode": api.COO_IN_TILE, "dense_mode": api.DENSE_VALU}),
+             ("band hbw 40", G.band(400000, 40), {"coo_mode": api.COO_IN_TILE, "dense_mode": api.DENSE_MFMA}),
+             ("5-pt Laplacian", G.laplacian5pt(512), {"coo_mode": api.COO_IN_TILE, "entry_mode": (0,)}),
+             ("power-law", G.powerlaw(300000, seed=9), {"coo_mode": api.COO_IN_TILE, "entry_mode": (1, 2)})]
+    for name, (m, n, rp, ci), want in cases:
+        rowA, nnz = (m // 16) * 16, len(ci)
+        vals, x = G.compat_values(nnz), G.compat_x(n)
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
+        y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x)
+        assert np.array_equal(y, CpuImpl("oracle").csr_spmv(rowA, rp, ci, vals, x)), name
+        for k, v in want.items():
+            assert (info[k] in v) if isinstance(v, tuple) else (info[k] == v), (name, k, info[k], v)
+        api.Tile_destroy(tp)
