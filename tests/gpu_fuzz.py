@@ -109,6 +109,22 @@ def check(seed):
                                     print("  seed %d: SpMM mismatch nvec=%d dns=%d hyb=%d %s env=%s" % (seed, nv, dns, hyb, np.dtype(dt).name, env)); bad += 1
                         plan.close()
             api.Tile_destroy(tp)
+    # real-valued data, same plan knobs: |y - y_ref| <= tol * sum_j |a_ij x_j| (1e-12 fp64 / 1e-5 fp32)
+    ri = np.repeat(np.arange(m), np.diff(rp[:m + 1]))
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 1e-5)):
+        vals = rng.uniform(-1, 1, nnz).astype(dt); xr = rng.uniform(-1, 1, n).astype(dt)
+        ref = np.zeros(m); np.add.at(ref, ri, vals[:rp[m]].astype(np.float64) * xr[ci[:rp[m]]].astype(np.float64))
+        bound = np.zeros(m); np.add.at(bound, ri, np.abs(vals[:rp[m]].astype(np.float64) * xr[ci[:rp[m]]].astype(np.float64)))
+        tp = api.Tile_create(m, n, nnz, rp, ci, vals, dtype=dt, hyb=bool(seed & 1))
+        xd = torch.from_numpy(xr).cuda()
+        for coo in (1, 2):
+            plan = api.Plan(tp, m, n, nnz, coo_mode=coo)
+            yd = torch.zeros(m + 16, dtype=xd.dtype, device="cuda")
+            plan.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize()
+            if not (np.abs(yd.cpu().numpy()[:m].astype(np.float64) - ref) <= tol * bound + 1e-300).all():
+                print("  seed %d: real-valued SpMV outside tolerance coo=%d %s env=%s" % (seed, coo, np.dtype(dt).name, env)); bad += 1
+            plan.close()
+        api.Tile_destroy(tp)
     for k in env: os.environ.pop(k)
     return bad, (m, n, nnz)
 
