@@ -37,7 +37,19 @@ for name in names:
             assert lib.tilespmv_matrix_save(C.byref(tm), r_, n, nn, path) == 0
             t2 = TileMatrixF64(); ra, ca, za = C.c_int(), C.c_int(), C.c_int()
             assert lib.tilespmv_matrix_load(C.byref(t2), C.byref(ra), C.byref(ca), C.byref(za), path) == 0
-            lib.Tile_destroy(C.byref(t2)); lib.Tile_destroy(C.byref(tm))
+            lib.Tile_destroy(C.byref(t2))
+            # damaged cache files: every one must be rejected (-6 / -3 / -2) without touching memory it does not own
+            raw = bytearray(open(path, "rb").read())
+            rng = np.random.default_rng(len(raw))
+            bad = [raw[:len(raw) // 2], raw[:120], raw + b"\0" * 16]
+            for _ in range(40):
+                q = bytearray(raw); pos = int(rng.integers(8, len(q))); q[pos] ^= 1 << int(rng.integers(0, 8)); bad.append(q)
+            for q in bad:
+                open("/tmp/tilespmv_asan/bad.tspmv", "wb").write(bytes(q))
+                t3 = TileMatrixF64()
+                rc = lib.tilespmv_matrix_load(C.byref(t3), C.byref(ra), C.byref(ca), C.byref(za), b"/tmp/tilespmv_asan/bad.tspmv")
+                assert rc != 0, "a damaged cache file was accepted"
+            lib.Tile_destroy(C.byref(tm))
     print(name, "ok", flush=True)
 # reader on assorted files
 import glob

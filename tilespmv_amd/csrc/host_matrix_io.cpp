@@ -75,7 +75,10 @@ extern "C" int tilespmv_matrix_save(const Tile_matrix *matrix, int rowA, int col
     for (int i = 0; i < 14 && ok; i++) ok = fwrite(scalars_of(T, i), sizeof(int), 1, f) == 1;
     long long extra[2] = {T->tilenum >= 0 ? T->dnsrowptr[T->tilenum] : 0, T->tilenum >= 0 ? T->dnscolptr[T->tilenum] : 0};
     ok = ok && fwrite(extra, sizeof(long long), 2, f) == 2;
-    unsigned long long sum[2] = {0, 0xCBF29CE484222325ull};   // payload bytes, FNV-1a-64 of the payload
+    unsigned long long sum[2] = {0, 0xCBF29CE484222325ull};   // payload bytes, FNV-1a-64 of header fields + payload
+    sum[1] = fnv1a(head, sizeof(head), sum[1]);
+    for (int i = 0; i < 14; i++) sum[1] = fnv1a(scalars_of(T, i), sizeof(int), sum[1]);
+    sum[1] = fnv1a(extra, sizeof(extra), sum[1]);
     for (auto &fd : fields_of(T, rowA, extra[0], extra[1]))
         if (fd.count > 0) { sum[0] += (unsigned long long)fd.count * fd.elem; sum[1] = fnv1a(*fd.ptr, (size_t)fd.count * fd.elem, sum[1]); }
     ok = ok && fwrite(sum, sizeof(unsigned long long), 2, f) == 2;
@@ -113,6 +116,9 @@ extern "C" int tilespmv_matrix_load(Tile_matrix *matrix, int *rowA, int *colA, M
     sane = sane && bytes == sum[0] && fseek(f, 0, SEEK_END) == 0 && (unsigned long long)(ftell(f) - here) == bytes && fseek(f, here, SEEK_SET) == 0;
     if (!sane) { fclose(f); memset(matrix, 0, sizeof(*matrix)); return -6; }   // corrupt, truncated or stale cache
     unsigned long long h = 0xCBF29CE484222325ull;
+    h = fnv1a(head, sizeof(head), h);
+    for (int i = 0; i < 14; i++) h = fnv1a(scalars_of(matrix, i), sizeof(int), h);
+    h = fnv1a(extra, sizeof(extra), h);
     for (auto &fd : fields_of(matrix, head[1], extra[0], extra[1])) {
         *fd.ptr = calloc((size_t)std::max<long long>(fd.count, 1), fd.elem);
         if (!*fd.ptr) { ok = false; break; }
