@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--setup-launches", type=int, default=200,
+                    help="untimed SpMVs issued during setup, before the --warmup steps (the reference warms up with 200 launches, "
+                         "src/tilespmv_cuda.h:1059-1082): clocks and caches are at steady state even when the driver asks for few steps")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo only to rehearse the N>1 path on a single GPU")
     args = ap.parse_args()
@@ -293,6 +296,9 @@ def main():
         if not ok:
             raise SystemExit("bench.py: HIP result differs from the CSR golden on sampled rows")
 
+    if args.setup_launches > 0:   # setup, not part of the W warm-up steps nor of the K timed ones; reported as `setup_launches`
+        run("none", args.setup_launches)
+        sync_all()
     wall, dev_ms = timed(args.combine, args.steps, args.warmup)
     ms_per_step = wall * 1e3 / args.steps
     flops = 2.0 * nnz
@@ -366,7 +372,7 @@ def main():
     out = {
         "metric": "fp%d SpMV GFLOP/s (y = A*x, tiled format)" % (dtype.itemsize * 8), "value": round(value, 2), "unit": "GFLOP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "setup_launches": args.setup_launches, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64" if dtype == np.float64 else "f32", "data": "synthetic (reference driver data: val[i]=i%10, x[i]=i%10)",
         "config": {"workload": args.workload, "source": source, "rows": rows, "cols": n, "nnz": nnz,
                    "partition": "tile-row blocks, nnz-balanced, %d rank(s)" % world, "y_combine": args.combine, "backend": args.backend if world > 1 else None,

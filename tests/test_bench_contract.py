@@ -34,7 +34,7 @@ def test_single_gpu_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
     assert cb["sample"].startswith("the full workload") and cb["format_loop_only"]["serial_1_core"]["errcount"] == 0
-    assert d["ranks"] == 1 and d["devices"] == [0] and d["reference_style_timing"]["ms_per_spmv"] > 0
+    assert d["ranks"] == 1 and d["devices"] == [0] and d["reference_style_timing"]["ms_per_spmv"] > 0 and d["setup_launches"] == 200
     assert {"tile_create", "plan_build", "plan_upload"} <= set(d["prep_seconds"])
     assert abs(d["value"] - 2 * d["config"]["nnz"] / (d["ms_per_step"] * 1e-3) * 1e-9) / d["value"] < 0.02
 
