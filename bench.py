@@ -267,18 +267,18 @@ def main():
         run(combine, steps)
         e1.record(stream)
         torch.cuda.synchronize()
-        own = time.perf_counter() - t0        # this rank's own steps done
-        sync_all()
-        wall = time.perf_counter() - t0       # barrier + synchronize on both sides of the timed region
+        own = time.perf_counter() - t0        # this rank's K steps are done (barrier + synchronize before, synchronize here)
+        sync_all()                            # ... and the closing barrier + synchronize
         dev_ms = e0.elapsed_time(e1)          # HIP events on the launch stream, over the timed region
-        per_rank = [[float(dev), own * 1e3 / steps, dev_ms / steps, wall]]
+        per_rank = [[float(dev), own * 1e3 / steps, dev_ms / steps]]
+        wall = own
         if world > 1:
             cdev = "cuda" if args.backend == "nccl" else "cpu"
             mine = torch.tensor(per_rank[0], dtype=torch.float64, device=cdev)
             allr = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allr, mine)          # every rank's device id, own wall ms/step, device ms/step, bracketed wall
+            dist.all_gather(allr, mine)          # every rank's device id, wall ms/step, device ms/step
             per_rank = [[float(v) for v in t.cpu()] for t in allr]
-            wall = max(r[3] for r in per_rank)   # MAX over ranks
+            wall = max(r[1] for r in per_rank) * steps * 1e-3   # MAX over ranks of the time each rank needed for its K steps
             dev_ms = max(r[2] for r in per_rank) * steps
         timed.per_rank = per_rank
         return wall, dev_ms
