@@ -218,14 +218,43 @@ typedef struct tilespmv_plan tilespmv_plan;
 #define TILESPMV_KERNEL_DIRECT 1  /* strip-per-16-lanes, one tile at a time (first generation) */
 #define TILESPMV_KERNEL_STREAM 2  /* flat, index-addressed unit stream (second generation; default) */
 
+/* Plan options.  VERSIONED: set `size = sizeof(tilespmv_plan_options)` (tilespmv_plan_options_init does, and sets every
+ * knob to TILESPMV_KNOB_DEFAULT); a library built against a longer struct gives the fields beyond `size` their defaults,
+ * one built against a shorter struct ignores the tail.  opts == NULL = all defaults.
+ * The tuning knobs replace what used to travel through the process environment: an unset knob (TILESPMV_KNOB_DEFAULT)
+ * takes the value of the environment variable named beside it if that is set — read with getenv at plan creation,
+ * never written: the library does not call setenv / unsetenv — and the built-in default otherwise.  Two host threads may
+ * create differently tuned plans at the same time (scripts/tsan_host.sh). */
+#define TILESPMV_KNOB_DEFAULT (-1)
 typedef struct {
-    int coo_mode;       /* TILESPMV_COO_*    */
-    int dense_mode;     /* TILESPMV_DENSE_*  */
-    int kernel;         /* TILESPMV_KERNEL_* */
+    unsigned size;      /* sizeof(tilespmv_plan_options) in the caller's build */
+    int coo_mode;       /* TILESPMV_COO_*    (0 = AUTO; env TILESPMV_COO_MODE)   */
+    int dense_mode;     /* TILESPMV_DENSE_*  (0 = AUTO; env TILESPMV_DENSE_MODE) */
+    int kernel;         /* TILESPMV_KERNEL_* (0 = AUTO; env TILESPMV_KERNEL)     */
     int tilerow_begin;  /* shard: first tile-row (0 for the whole matrix) */
     int tilerow_end;    /* shard: one past the last tile-row (<=0 means tilem) */
-    int reserved[3];    /* reserved[0] != 0 (or env TILESPMV_AUTOTUNE=1): decide the AUTO modes by timing the candidates */
+    int autotune;       /* != 0 (or env TILESPMV_AUTOTUNE=1): decide the AUTO modes, entry mode, strip size and XCD map by timing candidates */
+    /* ---- knobs (TILESPMV_KNOB_DEFAULT = unset) */
+    int entry_mode;     /* COO entry lists per 16-lane strip (0), per wavefront (1), per workgroup (2)      TILESPMV_WAVE_COO */
+    int entry_ordered;  /* workgroup entry mode: 1 = wavefronts add in turn (bit-reproducible sums), 0 = not  TILESPMV_COO_ORDERED */
+    int strip_cost;     /* strip size target in cost units (<= 0: chosen from the shard)                     TILESPMV_STRIP_COST */
+    int split_above;    /* tile-rows above this cost are cut into pieces                                     TILESPMV_SPLIT_ABOVE */
+    int split_cap;      /* ... and the cap of that threshold in the wavefront / workgroup entry modes        TILESPMV_SPLIT_CAP */
+    int xcd_remap;      /* workgroup -> XCD map: 0 round-robin, 2 windows of 8 x xcd_chunk workgroups         TILESPMV_XCD_REMAP */
+    int xcd_chunk;      /*                                                                                   TILESPMV_XCD_CHUNK */
+    int csr_split;      /* CSR tiles as units + entries (1) or whole tiles in their own pass (0)             TILESPMV_CSR_SPLIT */
+    int fix_inline;     /* split tile-rows summed inside the unit kernel (1) or by k_fixup_split (0)         TILESPMV_FIX_INLINE */
+    int coo_cost;       /* cost units per COO entry in the strip cutter                                      TILESPMV_COO_COST */
+    int coo_heavy_min;  /* entry mode 0: strips with more entries run their list before the unit pipeline    TILESPMV_COO_HEAVY_MIN */
+    int coo_piece;      /* entries per piece of a split tile-row                                             TILESPMV_COO_PIECE */
+    int strip_even;     /* strips end on multiples of this many units                                        TILESPMV_STRIP_EVEN */
+    int wg_strips;      /* workgroup entry mode: 16 (256-thread workgroups) or 32 (512 threads) strips per workgroup  TILESPMV_WG_STRIPS */
+    int x_window;       /* stencil-like shards: 1 = workgroups own bricks of the grid and stage their x window in LDS, 0 = off   TILESPMV_X_WINDOW */
+    int mv_native;      /* tilespmv_plan_spmm on entry-dominated plans: 1 multi-vector kernel, 0 one vector at a time           TILESPMV_MV_NATIVE */
+    int mv_xcd_chunk;   /* XCD window of the multi-vector kernel                                             TILESPMV_MV_XCD_CHUNK */
+    int reserved[8];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
+void tilespmv_plan_options_init(tilespmv_plan_options *opts);
 
 /* Returns 0 on success, non-zero (message on stderr) when no HIP device / extension is
  * usable — there is no CPU fallback behind this entry point. */
@@ -262,6 +291,15 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
                        void *stream);
 double tilespmv_plan_time_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y,
                                int nvec, void *stream, int warmup, int reps);
+
+/* Test / diagnostic entry (new): builds the plan's device layout ON THE HOST ONLY — no HIP call, works without a GPU — with
+ * exactly the code tilespmv_plan_create runs, hashes every stream it would upload (FNV-1a-64 over element counts and bytes,
+ * in upload order) and checks that the packed entry lists decode back to their entries.  Returns 0 and the digest (and the
+ * plan facts, `info` may be NULL), or the error tilespmv_plan_create would return.  Used by the CPU test-suite and by the
+ * ThreadSanitizer driver (two threads building differently tuned layouts); it is not part of any compute path. */
+int tilespmv_plan_layout_digest(const Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA,
+                                const tilespmv_plan_options *opts, unsigned long long *digest,
+                                long long *info /* [TILESPMV_INFO_COUNT] or NULL */);
 
 /* Plan facts for reports: index into `out` by TILESPMV_INFO_*. */
 enum {

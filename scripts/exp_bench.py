@@ -22,8 +22,16 @@ def main():
     plans = []
     for v in variants:
         kv = dict(s.split("=") for s in v.split(",") if s)
+        libv = kv.pop("LIB", None)   # LIB=_abl1: a diagnostic build made with `make VARIANT=_abl1 ... libs` (same Tile_matrix struct)
         for k, val in kv.items(): os.environ[k] = val
+        base_lib = tm._lib
+        if libv is not None:
+            from tilespmv_amd import _lib
+            os.environ["TILESPMV_LIB_VARIANT"] = libv; _lib._CACHE.pop(np.dtype(dtype), None)
+            tm._lib = _lib.load(dtype)
+            os.environ.pop("TILESPMV_LIB_VARIANT"); _lib._CACHE[np.dtype(dtype)] = base_lib
         p = api.Plan(tm, rows, n, nnz)
+        tm._lib = base_lib
         for k in kv: os.environ.pop(k)
         yd.fill_(-1); p.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize()
         ok = bool(np.array_equal(yd.cpu().numpy()[:rows].astype(np.float64), seg)) if seg is not None else None

@@ -1,10 +1,24 @@
-// ThreadSanitizer driver for the multi-threaded host code (Tile_create, .mtx reader): scripts/tsan_host.sh
+// ThreadSanitizer driver for the multi-threaded host code (Tile_create, .mtx reader, plan layout builder): scripts/tsan_host.sh
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <thread>
 #include <vector>
 
-#include "../include/tilespmv.h"
+#include <hip/hip_runtime.h>
+
+#include "../tilespmv_amd/csrc/hip_plan.h"
+
+// The plan builder (hip_plan.hip, compiled host-only here) references the kernel launchers of hip_kernels.hip; the layout-digest
+// build never launches anything, so the driver supplies empty stand-ins for the linker (test scaffolding, not product code).
+namespace tilespmv {
+hipError_t launch_tiles_direct(const DevPlan &, bool, bool, bool, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_tiles_stream(const DevPlan &, const DevStream &, const DevDense &, bool, int, int, int, int, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_fallback(const DevPlan &, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_tiles_stream_mv(const DevPlan &, const DevStream &, const DevDense &, int, int, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_rows_to_columns(const val_t *, int, long long, long long, val_t *, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_columns_to_rows(const val_t *, int, long long, long long, long long, val_t *, hipStream_t) { return hipErrorNotSupported; }
+}
 
 int main()
 {
@@ -24,6 +38,22 @@ int main()
         Tile_matrix T;
         Tile_create_ex(&T, rows, cols, (int)ci.size(), rp.data(), ci.data(), v.data(), flags);
         printf("flags %u tiles %d\n", flags, T.tilenum);
+        // two host threads build differently tuned plan layouts of the same matrix at the same time (the knobs travel in
+        // tilespmv_plan_options, nothing in the environment): digests must equal the ones of the serial builds
+        unsigned long long serial[4], par[4];
+        auto build = [&](int i, unsigned long long *out) {
+            tilespmv_plan_options o;
+            tilespmv_plan_options_init(&o);
+            o.entry_mode = i % 3; o.strip_cost = 200 + 300 * i; o.entry_ordered = i & 1; o.wg_strips = (i & 2) ? 32 : 16;
+            if (i == 3) o.coo_mode = TILESPMV_COO_FALLBACK;
+            if (tilespmv_plan_layout_digest(&T, rows, cols, (int)ci.size(), &o, out + i, nullptr) != 0) out[i] = 0;
+        };
+        for (int i = 0; i < 4; i++) build(i, serial);
+        std::thread a([&] { build(0, par); build(2, par); }), b([&] { build(1, par); build(3, par); });
+        a.join(); b.join();
+        int same = 0;
+        for (int i = 0; i < 4; i++) same += serial[i] != 0 && serial[i] == par[i];
+        printf("flags %u plan layouts from two threads: %d of 4 equal the serial digests\n", flags, same);
         Tile_destroy(&T);
     }
     const char *path = "/tmp/tilespmv_tsan.mtx";

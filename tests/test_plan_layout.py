@@ -1,0 +1,106 @@
+"""Plan layout built on the host only (tilespmv_plan_layout_digest: the exact builder of tilespmv_plan_create, no HIP call):
+versioned options, knobs through the struct instead of the environment, packed entry lists that decode back to their entries
+(checked inside the builder), two threads building differently tuned layouts.  No GPU needed."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from tests import cases
+from tilespmv_amd import _lib, api, generators as G
+
+
+def _tm(name, dtype=np.float64, hyb=False):
+    m, n, rp, ci = (cases.SMALL.get(name) or cases.MEDIUM[name])()
+    rows = cases.truncated_rows(m)
+    nnz = int(rp[rows])
+    vals, _ = cases.values_for(name, len(ci), n, dtype)
+    return api.Tile_create(rows, n, nnz, rp, ci, vals, dtype=dtype, hyb=hyb), rows, n, nnz
+
+
+def test_options_struct_is_versioned_and_mirrored():
+    lib = _lib.load(np.float64)
+    o = _lib.PlanOptions()
+    raw = (C.c_int * (C.sizeof(o) // 4))()
+    lib.tilespmv_plan_options_init(C.cast(raw, C.POINTER(_lib.PlanOptions)))
+    init = C.cast(raw, C.POINTER(_lib.PlanOptions)).contents
+    assert init.size == C.sizeof(_lib.PlanOptions)                  # same layout on both sides of the ABI
+    assert (init.coo_mode, init.dense_mode, init.kernel, init.tilerow_begin, init.tilerow_end, init.autotune) == (0, 0, 0, 0, 0, 0)
+    for k in _lib.KNOB_NAMES:
+        assert getattr(init, k) == _lib.KNOB_DEFAULT, k
+    assert all(v == _lib.KNOB_DEFAULT for v in init.reserved)
+    with pytest.raises(TypeError):
+        _lib.PlanOptions(no_such_knob=1)
+
+
+@pytest.mark.parametrize("name", ["allfmt", "powerlaw20k", "circuit8k", "one_long_row", "lap64", "kkt12"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_every_entry_mode_packs_and_decodes(name, dtype):
+    """The builder re-decodes every packed list in digest builds and fails (-6) on a mismatch: all modes must build."""
+    tm, rows, n, nnz = _tm(name, dtype, hyb=(name == "allfmt"))
+    seen = set()
+    for kw in ({"entry_mode": 0}, {"entry_mode": 1}, {"entry_mode": 2, "wg_strips": 16}, {"entry_mode": 2, "wg_strips": 32},
+               {"coo_mode": api.COO_FALLBACK}, {"kernel": api.KERNEL_DIRECT}, {"entry_mode": 2, "strip_cost": 64, "split_above": 200}):
+        d, info = api.plan_layout_digest(tm, rows, n, nnz, **kw)
+        d2, _ = api.plan_layout_digest(tm, rows, n, nnz, **kw)
+        assert d == d2                                   # deterministic (threaded builder, plan-fixed order)
+        assert info["nnz"] == nnz and info["rows"] == rows
+        seen.add(d)
+    assert len(seen) >= 5                                # different knobs really produce different layouts
+    api.Tile_destroy(tm)
+
+
+def test_environment_is_only_a_default(monkeypatch):
+    tm, rows, n, nnz = _tm("powerlaw20k")
+    by_option, info = api.plan_layout_digest(tm, rows, n, nnz, entry_mode=2, strip_cost=800, entry_ordered=1)
+    assert info["entry_mode"] == 2 and info["strip_cost"] == 800 and info["entry_ordered"] == 1
+    monkeypatch.setenv("TILESPMV_WAVE_COO", "2"); monkeypatch.setenv("TILESPMV_STRIP_COST", "800"); monkeypatch.setenv("TILESPMV_COO_ORDERED", "1")
+    by_env, _ = api.plan_layout_digest(tm, rows, n, nnz)
+    assert by_env == by_option
+    over, info2 = api.plan_layout_digest(tm, rows, n, nnz, entry_mode=0, strip_cost=400)   # an option beats the environment
+    assert info2["entry_mode"] == 0 and info2["strip_cost"] == 400 and over != by_env
+    api.Tile_destroy(tm)
+
+
+def test_two_threads_build_differently_tuned_layouts():
+    """No setenv / unsetenv inside the library any more: concurrent builds with different knobs match the serial ones."""
+    tm, rows, n, nnz = _tm("powerlaw200k")
+    knobs = [dict(entry_mode=i % 3, strip_cost=200 + 250 * i, entry_ordered=i & 1) for i in range(6)]
+    serial = [api.plan_layout_digest(tm, rows, n, nnz, **k)[0] for k in knobs]
+    out = [None] * len(knobs)
+
+    def work(ids):
+        for i in ids:
+            out[i] = api.plan_layout_digest(tm, rows, n, nnz, **knobs[i])[0]
+    ts = [threading.Thread(target=work, args=(range(j, len(knobs), 3),)) for j in range(3)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert out == serial
+    api.Tile_destroy(tm)
+
+
+def test_columns_beyond_2_to_28_keep_their_bits():
+    """the round-2 lists kept row bits in the column word's top four bits, so a matrix with more than 2^28
+    columns gathered from the wrong x.  Packed records carry (column - chunk base); the builder's decode check covers it."""
+    rows, cols = 4096, (1 << 28) + 1000
+    rng = np.random.default_rng(3)
+    ri = np.repeat(np.arange(rows), 6)
+    ci = np.concatenate([rng.integers(0, cols, rows * 3), rng.integers(1 << 28, cols, rows * 3)])
+    m, n, rp, cidx = G.from_coo(rows, cols, ri, ci)
+    nnz = len(cidx)
+    tm = api.Tile_create(rows, cols, nnz, rp, cidx, G.compat_values(nnz))
+    d, info = api.plan_layout_digest(tm, rows, cols, nnz, coo_mode=api.COO_FALLBACK)    # tilen > 2^24: first-generation kernel + fallback lists
+    assert info["kernel"] == api.KERNEL_DIRECT and info["fallback_nnz"] > 0
+    with pytest.raises(RuntimeError):                                                     # the unit stream keeps column blocks in 24 bits: refused, not wrong
+        api.plan_layout_digest(tm, rows, cols, nnz, kernel=api.KERNEL_STREAM)
+    api.Tile_destroy(tm)
+    # and just below the unit stream's limit, with the merged lists of entry modes 1 and 2 (columns up to 2^28 - 1)
+    cols = 1 << 28
+    ci = np.concatenate([rng.integers(0, cols, rows * 3), rng.integers(cols - 5000, cols, rows * 3)])
+    m, n, rp, cidx = G.from_coo(rows, cols, ri, ci)
+    nnz = len(cidx)
+    tm = api.Tile_create(rows, cols, nnz, rp, cidx, G.compat_values(nnz))
+    for em in (1, 2):
+        d, info = api.plan_layout_digest(tm, rows, cols, nnz, kernel=api.KERNEL_STREAM, entry_mode=em)
+        assert info["entry_mode"] == em
+    api.Tile_destroy(tm)

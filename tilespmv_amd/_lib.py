@@ -20,14 +20,37 @@ INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode"
               "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us", "entry_mode", "entry_ordered", "strip_cost"]
 
 
+KNOB_DEFAULT = -1
+# tuning knobs of tilespmv_plan_options (include/tilespmv.h), in struct order after `autotune`
+KNOB_NAMES = ["entry_mode", "entry_ordered", "strip_cost", "split_above", "split_cap", "xcd_remap", "xcd_chunk", "csr_split", "fix_inline",
+              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "mv_native", "mv_xcd_chunk"]
+
+
 class PlanOptions(C.Structure):
-    _fields_ = [("coo_mode", C.c_int), ("dense_mode", C.c_int), ("kernel", C.c_int),
-                ("tilerow_begin", C.c_int), ("tilerow_end", C.c_int), ("reserved", C.c_int * 3)]
+    """Mirror of the versioned tilespmv_plan_options: `size` first, unset knobs = KNOB_DEFAULT."""
+    _fields_ = ([("size", C.c_uint), ("coo_mode", C.c_int), ("dense_mode", C.c_int), ("kernel", C.c_int),
+                 ("tilerow_begin", C.c_int), ("tilerow_end", C.c_int), ("autotune", C.c_int)] +
+                [(k, C.c_int) for k in KNOB_NAMES] + [("reserved", C.c_int * 8)])
+
+    def __init__(self, coo_mode=0, dense_mode=0, kernel=0, tilerow_begin=0, tilerow_end=0, autotune=False, **knobs):
+        super().__init__()
+        self.size = C.sizeof(PlanOptions)
+        self.coo_mode, self.dense_mode, self.kernel = coo_mode, dense_mode, kernel
+        self.tilerow_begin, self.tilerow_end, self.autotune = tilerow_begin, tilerow_end, 1 if autotune else 0
+        for k in KNOB_NAMES:
+            setattr(self, k, KNOB_DEFAULT)
+        for i in range(8):
+            self.reserved[i] = KNOB_DEFAULT
+        for k, v in knobs.items():
+            if k not in KNOB_NAMES:
+                raise TypeError("unknown plan knob %r (known: %s)" % (k, ", ".join(KNOB_NAMES)))
+            setattr(self, k, int(v))
 
 
 def lib_path(dtype):
     suf = "f64" if np.dtype(dtype) == np.float64 else "f32"
-    return os.path.join(_ROOT, "lib", "libtilespmv_%s.so" % suf)
+    # TILESPMV_LIB_VARIANT: diagnostic builds made with `make VARIANT=... libs` (timing-only ablations; never the product)
+    return os.path.join(_ROOT, "lib", "libtilespmv_%s%s.so" % (suf, os.environ.get("TILESPMV_LIB_VARIANT", "")))
 
 
 def build(verbose=False):
@@ -77,6 +100,10 @@ def load(dtype=np.float64):
     lib.tilespmv_plan_time_spmm.restype = C.c_double
     lib.tilespmv_plan_create.argtypes = [C.POINTER(C.c_void_p), TP, C.c_int, C.c_int, C.c_int, C.POINTER(PlanOptions)]
     lib.tilespmv_plan_create.restype = C.c_int
+    lib.tilespmv_plan_options_init.argtypes = [C.POINTER(PlanOptions)]
+    lib.tilespmv_plan_options_init.restype = None
+    lib.tilespmv_plan_layout_digest.argtypes = [TP, C.c_int, C.c_int, C.c_int, C.POINTER(PlanOptions), C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong)]
+    lib.tilespmv_plan_layout_digest.restype = C.c_int
     lib.tilespmv_plan_destroy.argtypes = [C.c_void_p]
     lib.tilespmv_plan_destroy.restype = None
     lib.tilespmv_plan_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -109,4 +136,4 @@ DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_c
                     "tilespmv_plan_create", "tilespmv_plan_destroy", "tilespmv_plan_spmv", "tilespmv_plan_info",
                     "tilespmv_plan_time", "tilespmv_partition_tilerows", "tilespmv_sizeof_value", "tilespmv_version",
                     "tilespmv_device_count", "tilespmv_matrix_save", "tilespmv_matrix_load", "tilespmv_plan_spmv_n",
-                    "call_tilespmv_hip_multi", "tilespmv_plan_spmm", "tilespmv_plan_time_spmm"]
+                    "call_tilespmv_hip_multi", "tilespmv_plan_spmm", "tilespmv_plan_time_spmm", "tilespmv_plan_options_init", "tilespmv_plan_layout_digest"]

@@ -138,14 +138,26 @@ def partition_tilerows(tm, nparts):
     return b
 
 
+def plan_layout_digest(tm, rowA, colA, nnzA, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, **knobs):
+    """Host-only build of the plan layout (no GPU needed): returns (FNV-1a-64 digest of every stream, plan facts)."""
+    opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, False, **knobs)
+    d = C.c_ulonglong(0)
+    out = (C.c_longlong * 16)()
+    rc = tm._lib.tilespmv_plan_layout_digest(C.byref(tm), rowA, colA, nnzA, C.byref(opts), C.byref(d), out)
+    if rc != 0:
+        raise RuntimeError("tilespmv_plan_layout_digest failed (%d)" % rc)
+    return d.value, {k: int(out[i]) for i, k in enumerate(_lib.INFO_NAMES)}
+
+
 class Plan:
     """Device-resident tiled matrix (or one tile-row shard of it)."""
 
-    def __init__(self, tm, rowA, colA, nnzA, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, autotune=False):
+    def __init__(self, tm, rowA, colA, nnzA, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, autotune=False, **knobs):
+        """``knobs``: the tuning fields of ``tilespmv_plan_options`` (``entry_mode=2, strip_cost=800, xcd_chunk=8, ...``;
+        ``_lib.KNOB_NAMES``).  An unset knob falls back to its TILESPMV_* environment variable, then to the built-in default."""
         self.lib = tm._lib
         self.rowA, self.colA, self.nnzA = rowA, colA, nnzA
-        opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end)
-        opts.reserved[0] = 1 if autotune else 0
+        opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, autotune, **knobs)
         h = C.c_void_p()
         rc = self.lib.tilespmv_plan_create(C.byref(h), C.byref(tm), rowA, colA, nnzA, C.byref(opts))
         if rc != 0 or not h:

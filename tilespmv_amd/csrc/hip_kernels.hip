@@ -316,66 +316,99 @@ typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 #define UNITS_MIN_WAVES 8  // waves per SIMD asked of the register allocator (64 VGPRs)
 #endif
 
+// ---- packed entry records (hip_plan.h ERec): value + (column - chunk base) << dest_bits | destination
+__device__ __forceinline__ val_t erec_val(const ERec &r)
+{
+#if defined(TILESPMV_F32)
+    return __uint_as_float(r.v);
+#else
+    return __hiloint2double((int)r.hi, (int)r.lo);
+#endif
+}
+
 // ---- wave-cooperative entry phase of k_units<.., 1>: the COO entry lists of the wavefront's four strips, merged and ordered
 // by column at plan time, are walked by all 64 lanes; products go to the owning strip's slab of the wavefront's part of
-// s_y with ds_add (column word = global column | strip-in-wavefront << 28).  A wavefront's time follows its TOTAL entry
+// s_y with ds_add (destination = strip-in-wavefront << 7 | row byte).  A wavefront's time follows its TOTAL entry
 // count, not its longest strip; every load is a full 64-lane access; neighbouring lanes of a gather read the same or
 // adjacent x lines, and the four wavefronts of a workgroup sweep the columns side by side, so they find each other's lines
 // in the CU's L1.  Only this wavefront adds into its slabs: the order of the additions is fixed by the plan (bit-
-// reproducible).  CT x 64 entries per trip: every load of a trip, then its gathers, then the adds.
+// reproducible).  CT x 64 entries per trip: every record load of a trip (one 12-/8-byte lane load each; the chunk's column
+// base comes through the scalar cache), then its gathers, then the adds.
 template <int CT>
-__device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t *__restrict__ x, val_t *swave, int lane, int gb, int ge)
+__device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t *__restrict__ x, val_t *swave, int lane, int gb, int ge, int chunk0, int cfirst)
 {
-    const bool coo_nt = S.coo_nt != 0;
-    for (int e0 = gb; e0 < ge; e0 += 64 * CT) {
-        int cc[CT]; unsigned rb[CT]; val_t cv[CT], xx[CT];
+    const int db = S.dest_bits;
+    const unsigned dmask = (1u << db) - 1u;
+    const int clast = chunk0 + ((ge - 1 - gb) >> 6);
+    for (int e0 = gb + 64 * cfirst; e0 < ge; e0 += 64 * CT) {
+        ERec rr[CT]; unsigned cb[CT]; val_t xx[CT];
 #pragma unroll
         for (int q = 0; q < CT; q++) {
-            const int e = min(e0 + 64 * q + lane, ge - 1);
-            // the entry streams are read once: the nontemporal hint is meant to keep them out of the CU's 32 KB L1 (measured neutral)
-            rb[q] = stream_load(S.grow + e, coo_nt); cc[q] = stream_load(S.gcol + e, coo_nt); cv[q] = stream_load(S.gval + e, coo_nt);
+            rr[q] = S.grec[min(e0 + 64 * q + lane, ge - 1)];
+            cb[q] = S.gbase[__builtin_amdgcn_readfirstlane(min(chunk0 + ((e0 - gb) >> 6) + q, clast))];
         }
 #pragma unroll
-        for (int q = 0; q < CT; q++) xx[q] = x[cc[q] & 0x0FFFFFFF];
+        for (int q = 0; q < CT; q++) xx[q] = x[(size_t)(cb[q] + (rr[q].w >> db))];
 #pragma unroll
         for (int q = 0; q < CT; q++)
-            if (e0 + 64 * q + lane < ge) atomicAdd(&swave[((unsigned)cc[q] >> 28) * (STRIP_MAX_ROWS * 16) + rb[q]], cv[q] * xx[q]);
+            if (e0 + 64 * q + lane < ge) atomicAdd(&swave[rr[q].w & dmask], erec_val(rr[q]) * xx[q]);
     }
 }
 
-// ---- workgroup-cooperative entry phase of k_units<.., 2>: the entries of the workgroup's 16 strips, merged and ordered by
-// column at plan time, walked by all 256 lanes.  Neighbouring lanes of a gather then read the same or adjacent x lines: on
-// power-law matrices the number of distinct x lines per batch drops from 0.48 per entry (one strip at a time) to 0.15
-// (64 tile-rows at a time), and the CU's L1 -> L2 request rate is what bounds those matrices.
-template <int CT>
-__device__ __forceinline__ void wg_entry_trips(const val_t *__restrict__ gval, const int *__restrict__ gcol, const unsigned char *__restrict__ grow,
-                                               bool coo_nt, bool ordered, const val_t *__restrict__ x, val_t *sy, int tid, int gb, int ge)
+// ---- workgroup-cooperative entry phase of k_units<.., 2> (and of the fallback kernel): the entries of the workgroup's 16 or
+// 32 strips, merged and ordered by column at plan time, walked by all NT lanes.  Neighbouring lanes of a gather then read
+// the same or adjacent x lines: on power-law matrices the number of distinct x lines per batch drops from 0.48 per entry (one
+// strip at a time) to 0.15 (64 tile-rows at a time), and the CU's L1 -> L2 request rate is what bounds those matrices.
+template <int CT, int NT>
+__device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, const unsigned *__restrict__ base, int chunk0, int db, bool ordered,
+                                               const val_t *__restrict__ x, val_t *sy, int tid, int gb, int ge)
 {
-    for (int e0 = gb; e0 < ge; e0 += 256 * CT) {
-        int cc[CT]; unsigned rb[CT]; val_t cv[CT], xx[CT];
+    const unsigned dmask = (1u << db) - 1u;
+    const int wave = tid >> 6;
+    const int clast = chunk0 + ((ge - 1 - gb) >> 6);
+#ifdef TILESPMV_ABL
+    // Diagnostic builds only (scripts/ablate_entries.sh; results are wrong by construction, timing only):
+    //   1 no LDS adds   2 contiguous instead of gathered x   5 one extra 2-byte stream load per entry
+    val_t abl_acc = 0;
+#endif
+    for (int e0 = gb; e0 < ge; e0 += NT * CT) {
+        ERec rr[CT]; unsigned cb[CT]; val_t xx[CT];
 #pragma unroll
         for (int q = 0; q < CT; q++) {
-            const int e = min(e0 + 256 * q + tid, ge - 1);
-            rb[q] = stream_load(grow + e, coo_nt); cc[q] = stream_load(gcol + e, coo_nt); cv[q] = stream_load(gval + e, coo_nt);
+            rr[q] = rec[min(e0 + NT * q + tid, ge - 1)];
+            cb[q] = base[__builtin_amdgcn_readfirstlane(min(chunk0 + ((e0 - gb) >> 6) + (NT / 64) * q + wave, clast))];   // a wavefront's 64 records are one chunk
+#if defined(TILESPMV_ABL) && TILESPMV_ABL == 5
+            rr[q].w += reinterpret_cast<const unsigned short *>(base)[min(e0 + NT * q + tid, ge - 1)] & 1u;
+#endif
         }
 #pragma unroll
-        for (int q = 0; q < CT; q++) xx[q] = x[cc[q] & 0x0FFFFFFF];
+        for (int q = 0; q < CT; q++) xx[q] = x[(size_t)(cb[q] + (rr[q].w >> db))];
+#if defined(TILESPMV_ABL) && TILESPMV_ABL == 2
+#pragma unroll
+        for (int q = 0; q < CT; q++) xx[q] = x[(e0 + NT * q + tid) & 0xFFFFF];
+#endif
+#if defined(TILESPMV_ABL) && TILESPMV_ABL == 1
+#pragma unroll
+        for (int q = 0; q < CT; q++) abl_acc += erec_val(rr[q]) * xx[q] + (val_t)(rr[q].w & dmask);
+        if (e0 + NT * CT >= ge) atomicAdd(&sy[tid], abl_acc);
+        continue;
+#endif
         if (ordered) {
-            // the four wavefronts add in turn: the order of the additions into one y element is then fixed by the plan (entry
-            // order inside a wavefront instruction, instruction order inside a wavefront, wavefront 0..3 inside a trip), not by
-            // timing, and two launches give the same bits (the reference's atomicAdd, src/tilespmv_cuda.h:784-790, does not)
-            for (int w = 0; w < 4; w++) {
-                if ((tid >> 6) == w) {
+            // the wavefronts add in turn: the order of the additions into one y element is then fixed by the plan (entry
+            // order inside a wavefront instruction, instruction order inside a wavefront, wavefront 0..NT/64-1 inside a trip), not
+            // by timing, and two launches give the same bits (the reference's atomicAdd, src/tilespmv_cuda.h:784-790, does not)
+            for (int w = 0; w < NT / 64; w++) {
+                if (wave == w) {
 #pragma unroll
                     for (int q = 0; q < CT; q++)
-                        if (e0 + 256 * q + tid < ge) atomicAdd(&sy[((unsigned)cc[q] >> 28) * (STRIP_MAX_ROWS * 16) + rb[q]], cv[q] * xx[q]);
+                        if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], erec_val(rr[q]) * xx[q]);
                 }
                 __syncthreads();
             }
         } else {
 #pragma unroll
             for (int q = 0; q < CT; q++)
-                if (e0 + 256 * q + tid < ge) atomicAdd(&sy[((unsigned)cc[q] >> 28) * (STRIP_MAX_ROWS * 16) + rb[q]], cv[q] * xx[q]);
+                if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], erec_val(rr[q]) * xx[q]);
         }
     }
 }
@@ -396,7 +429,7 @@ __global__ __launch_bounds__(256) void k_fallback_entries(DevPlan P, const val_t
     const int nrows = b.y < 0 ? 1 : b.y;
     for (int i = tid; i < nrows; i += 256) s_acc[i] = 0;
     __syncthreads();
-    wg_entry_trips<6>(P.f_val, P.f_col, P.f_row, false, P.f_ordered != 0, x, s_acc, tid, b.z, b.w);
+    wg_entry_trips<6, 256>(P.f_rec, P.f_base, b.z >> 6, FB_DEST_BITS, P.f_ordered != 0, x, s_acc, tid, b.z, b.w);   // a block's list starts on a chunk boundary
     __syncthreads();
     if (b.y < 0) {
         if (tid == 0) atomicAdd(&y[(long long)P.f_row0 + b.x], s_acc[0]);
@@ -428,14 +461,22 @@ hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream
 
 // ECOO: how the COO entry lists are executed — 0 per 16-lane strip (regular matrices: a handful of entries per strip),
 // 1 per wavefront (the four strips' lists concatenated), 2 per workgroup (merged + column-ordered list, see above).
-template <int UB, int XCD_REMAP, int ECOO>
-__global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+// GPB: strips (16-lane groups) per workgroup — 16 (256 threads) or, for the workgroup entry mode on large entry-heavy shards, 32
+// (512 threads: twice as many tile-rows share one column-ordered list, so fewer distinct x lines per entry; same waves per SIMD).
+template <int UB, int XCD_REMAP, int ECOO, int GPB>
+__global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
+    static_assert(GPB == 16 || (GPB == 32 && ECOO == 2), "512-thread workgroups exist for the workgroup entry mode only");
+    constexpr int GROUPS_PER_BLOCK = GPB;
     constexpr bool NT = false;  // nontemporal value loads: measured neutral
     __shared__ val_t s_y[GROUPS_PER_BLOCK][STRIP_MAX_ROWS][16];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
+#ifdef TILESPMV_ABL_LDS_PAD   // diagnostic builds only: extra LDS per workgroup, to measure what fewer resident workgroups cost
+    __shared__ unsigned s_pad[TILESPMV_ABL_LDS_PAD / 4];
+    if (rowA < 0) s_pad[threadIdx.x] = 1u, y[0] = (val_t)s_pad[(threadIdx.x * 7) % (TILESPMV_ABL_LDS_PAD / 4)];
+#endif
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), each
     // with a private L2; XCD_REMAP = 2 gives every XCD runs of xcd_chunk consecutive workgroups inside
@@ -506,7 +547,7 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
     };
 
     if constexpr (ECOO == 2) {
-        const int2 wr = S.wg_coo[bid];
+        const int4 wr = S.wg_coo[bid];
         TSPMV_STAMP_WAIT(1);   // task and list range have arrived
         if (wr.y > wr.x) {  // workgroup-uniform
             if (side) for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
@@ -515,7 +556,7 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
         unit_prologue();
         TSPMV_STAMP_WAIT(2);   // prologue has arrived (the entry loads are inside the trips)
         if (wr.y > wr.x) {
-            wg_entry_trips<WCOO_HEAVY_CT>(S.gval, S.gcol, S.grow, S.coo_nt != 0, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y);
+            wg_entry_trips<WCOO_HEAVY_CT, 16 * GPB>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y);
             __syncthreads();
         }
         TSPMV_STAMP_WAIT(3);   // entry phase done
@@ -526,18 +567,20 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
         // (4 waves/SIMD asked of the allocator).
         constexpr int CT = 6;
         const int lane = tid & 63;
-        const int2 wr = S.wg_coo[(long long)bid * (GROUPS_PER_BLOCK / 4) + (g >> 2)];  // this wavefront's merged list
+        const int4 wr = S.wg_coo[(long long)bid * (GROUPS_PER_BLOCK / 4) + (g >> 2)];  // this wavefront's merged list
         const int tot = wr.y - wr.x;
         val_t *swave = &s_y[g & ~3][0][0];  // the wavefront's four slabs of STRIP_MAX_ROWS x 16 values
         TSPMV_STAMP_WAIT(1);   // task and list range have arrived
         unit_prologue();
-        int cc[CT]; unsigned rb[CT]; val_t cv[CT], xx[CT];
+        ERec rr[CT]; unsigned cbase[CT]; val_t xx[CT];
+        const int db = S.dest_bits;
         if (tot > 0) {
             if (side) for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
+            const int clast = wr.z + ((tot - 1) >> 6);
 #pragma unroll
             for (int q = 0; q < CT; q++) {
-                const int e = min(wr.x + 64 * q + lane, wr.y - 1);
-                rb[q] = S.grow[e]; cc[q] = S.gcol[e]; cv[q] = S.gval[e];
+                rr[q] = S.grec[min(wr.x + 64 * q + lane, wr.y - 1)];
+                cbase[q] = S.gbase[__builtin_amdgcn_readfirstlane(min(wr.z + q, clast))];
             }
         }
         if (have_units) {  // waits for the descriptor chunk only (older than the entry loads)
@@ -547,12 +590,13 @@ __global__ __launch_bounds__(256, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : 
         } else if (tot > 0) wave_lds_fence();
         TSPMV_STAMP_WAIT(2);   // prologue + entry loads (and the first unit batch's gathers) have arrived
         if (tot > 0) {
+            const unsigned dmask = (1u << db) - 1u;
 #pragma unroll
-            for (int q = 0; q < CT; q++) xx[q] = x[cc[q] & 0x0FFFFFFF];
+            for (int q = 0; q < CT; q++) xx[q] = x[(size_t)(cbase[q] + (rr[q].w >> db))];
 #pragma unroll
             for (int q = 0; q < CT; q++)
-                if (wr.x + 64 * q + lane < wr.y) atomicAdd(&swave[((unsigned)cc[q] >> 28) * (STRIP_MAX_ROWS * 16) + rb[q]], cv[q] * xx[q]);
-            if (tot > 64 * CT) wave_entry_trips<CT>(S, x, swave, lane, wr.x + 64 * CT, wr.y);
+                if (wr.x + 64 * q + lane < wr.y) atomicAdd(&swave[rr[q].w & dmask], erec_val(rr[q]) * xx[q]);
+            if (tot > 64 * CT) wave_entry_trips<CT>(S, x, swave, lane, wr.x, wr.y, wr.z, CT);
             wave_lds_fence();
         }
         TSPMV_STAMP_WAIT(3);   // entry phase done
@@ -1160,13 +1204,12 @@ hipError_t launch_columns_to_rows(const val_t *YT, int nvec, long long row0, lon
     return hipGetLastError();
 }
 
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int xcd_remap, int xcd_chunk,
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st)
 {
     if (S.ntasks > 0) {
-        const dim3 grid((unsigned)((S.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), blk(256);
-#define TSPMV_L2(X, W) hipLaunchKernelGGL((k_units<4, X, W>), grid, blk, 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
-#define TSPMV_L1(X) do { if (entry_mode == 2) TSPMV_L2(X, 2); else if (entry_mode == 1) TSPMV_L2(X, 1); else TSPMV_L2(X, 0); } while (0)
+#define TSPMV_L2(X, W, B) hipLaunchKernelGGL((k_units<4, X, W, B>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_L1(X) do { if (entry_mode == 2 && wg_strips == 32) TSPMV_L2(X, 2, 32); else if (entry_mode == 2) TSPMV_L2(X, 2, 16); else if (entry_mode == 1) TSPMV_L2(X, 1, 16); else TSPMV_L2(X, 0, 16); } while (0)
         if (xcd_remap == 2) TSPMV_L1(2); else TSPMV_L1(0);
 #undef TSPMV_L1
 #undef TSPMV_L2

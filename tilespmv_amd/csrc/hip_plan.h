@@ -26,6 +26,23 @@ constexpr unsigned DESC_EOR = 8u;         // last tile of its tile-row
 constexpr int DESC_P1_SHIFT = 4;          // 8 bits: CSR nnz | COO count | ELL/HYB width | #dense rows/cols
 constexpr int DESC_P2_SHIFT = 12;         // 8 bits: HYB remainder count
 
+// ---- packed entry record (merged, column-ordered entry lists of the wavefront / workgroup entry modes and of the fallback):
+// value + one index word = (column - chunk base) << dest_bits | destination row of the group.  One lane load per entry
+// (global_load_dwordx3 in fp64, dwordx2 in fp32) instead of three stream loads (value, column, row byte): 12 B instead of
+// 13 B per entry in fp64, 8 instead of 9 in fp32, and — what the ablations of round 3 showed to matter as much as the
+// bytes — one vector-memory instruction per 64 entries instead of three (profiles/r03_entry_ablations.txt).  The column
+// base is one 32-bit word per chunk of 64 consecutive records of a list (a wavefront's share of one sub-trip), fetched
+// with a scalar load.  A chunk whose columns span more than 2^(32 - dest_bits) is cut short and padded with null records
+// (value 0, offset 0, destination 0).  Columns are full 32-bit numbers again (the round-2 lists kept the strip in the
+// column word's top four bits, which limited them to matrices of < 2^28 columns).
+#if defined(TILESPMV_F32)
+struct ERec { unsigned v, w; };            // 8 bytes
+#else
+struct ERec { unsigned lo, hi, w; };       // 12 bytes, 4-byte aligned
+#endif
+constexpr int ECHUNK = 64;                 // records per column-base chunk
+constexpr int FB_DEST_BITS = 11;           // fallback row blocks: <= 2048 rows
+
 struct Task {
     int tile_begin, tile_end;  // range in desc[]
     long long val_off;         // element offset of tile_begin's payload in val[]
@@ -49,12 +66,11 @@ struct DevPlan {
     const FixRow *fix_late; // split tile-rows with pieces outside the unit kernel: summed by k_fixup_split after all passes
     int nfix_late;
     // very-sparse fallback (the extracted matrix of the shard's rows, deferredcoo_*): row blocks of <= FB_ROWS rows and
-    // <= FB_CAP nonzeros, one workgroup each, the block's nonzeros ordered by column (same list form as the workgroup
-    // entry mode of the unit kernel: column word = column | (row-in-block >> 7) << 28, row byte = row-in-block & 127)
-    const int4 *f_blk;      // per block: first local row, #rows (-1: one piece of a single row longer than FB_CAP -> atomic add), [begin, end) in f_val / f_col / f_row
-    const val_t *f_val;
-    const int *f_col;
-    const unsigned char *f_row;
+    // <= FB_CAP nonzeros, one workgroup each, the block's nonzeros ordered by column and stored as packed entry records
+    // (ERec below; destination = row-in-block, FB_DEST_BITS bits); a block's list starts on a chunk boundary
+    const int4 *f_blk;      // per block: first local row, #rows (-1: one piece of a single row longer than FB_CAP -> atomic add), [begin, end) in f_rec
+    const ERec *f_rec;
+    const unsigned *f_base; // column base per 64-record chunk (chunk of record i = i >> 6)
     int f_nblk;
     int f_ordered;          // wavefronts add in turn (bit-reproducible sums)
     int f_row0;             // first global row of the shard
@@ -101,15 +117,14 @@ struct DevStream {
     const STask *task;
     int ntasks;
     int coo_heavy_min;                    // entry mode 0: strips with more COO entries than this run their entry list before the unit pipeline
-    int coo_nt;                           // entry streams loaded with the nontemporal hint
     int coo_ordered;                      // workgroup entry mode: wavefronts add in turn (bit-reproducible sums)
-    // entry modes 1 / 2 (k_units<.., 1 | 2>): the entries of the 4 strips of one wavefront / the 16 strips of one workgroup,
-    // merged and ordered by column, so that the lanes of one gather share x lines; column word = global column |
-    // strip-in-group << 28, row byte as in crow
-    const int2 *wg_coo;                   // per group (wavefront or workgroup): [begin, end) in gval / gcol / grow
-    const val_t *gval;
-    const int *gcol;
-    const unsigned char *grow;
+    // entry modes 1 / 2 (k_units<.., 1 | 2>): the entries of the 4 strips of one wavefront / the 16 or 32 strips of one
+    // workgroup, merged and ordered by column, so that the lanes of one gather share x lines; packed records (ERec),
+    // destination = strip-in-group << 7 | row-in-strip << 4 | row = the index into the group's slabs of s_y
+    const int4 *wg_coo;                   // per group (wavefront or workgroup): [begin, end) in grec, first chunk in gbase, 0
+    const ERec *grec;
+    const unsigned *gbase;                // column base per chunk of ECHUNK records, chunks counted from the list's begin
+    int dest_bits;                        // 9 (wavefront lists), 11 (16 strips per workgroup) or 12 (32 strips)
     // split tile-rows whose pieces all live in the unit kernel are summed in that kernel by the piece that
     // finishes last (fixed slot order): ifix[i] describes row i, ifix_count[i] counts finished pieces
     const FixRow *ifix;

@@ -17,7 +17,7 @@
 namespace tilespmv {
 
 hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulate, bool fixup, const val_t *x, val_t *y, hipStream_t st);
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int xcd_remap, int xcd_chunk,
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, const val_t *X, val_t *Y,
@@ -48,6 +48,64 @@ static int env_int(const char *name, int dflt)
     return (e && *e) ? atoi(e) : dflt;
 }
 
+// Every tuning knob of one plan build, resolved ONCE at the API boundary (tilespmv_plan_create): option field if set, else the
+// environment variable (getenv only — the library never writes the environment), else the built-in default.  The builder and
+// the autotuner pass this struct around; nothing below the boundary reads the environment.
+struct Knobs {
+    int coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, autotune;
+    int entry_mode;      // -1 = chosen from the shard
+    int entry_ordered;   // -1 = chosen from the grid size
+    int strip_cost;      // <= 0 = chosen from the shard
+    int split_above, split_cap, xcd_remap, xcd_chunk, csr_split, fix_inline, coo_cost, coo_heavy_min;
+    int coo_piece;       // <= 0 = derived from the piece size
+    int strip_even;
+    int wg_strips;       // -1 = chosen from the shard
+    int x_window;        // -1 = default
+    int mv_native;       // -1 = by nvec
+    int mv_xcd_chunk;    // -1 = the plan's XCD chunk
+    bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
+    bool dry;            // tilespmv_plan_layout_digest: build the layout on the host only, hash instead of upload
+    const char *autotune_log;
+};
+
+static Knobs resolve_knobs(const tilespmv_plan_options *opts)
+{
+    tilespmv_plan_options o;
+    tilespmv_plan_options_init(&o);
+    if (opts && opts->size >= sizeof(unsigned)) memcpy(&o, opts, std::min<size_t>(opts->size, sizeof(o)));
+    o.size = (unsigned)sizeof(o);
+    auto pick = [](int opt, const char *env, int dflt) { return opt != TILESPMV_KNOB_DEFAULT ? opt : env_int(env, dflt); };
+    auto pinned = [](int opt, const char *env) { return opt != TILESPMV_KNOB_DEFAULT || getenv(env) != nullptr; };
+    Knobs k{};
+    k.coo_mode = o.coo_mode > 0 ? o.coo_mode : env_int("TILESPMV_COO_MODE", 0);
+    k.dense_mode = o.dense_mode > 0 ? o.dense_mode : env_int("TILESPMV_DENSE_MODE", 0);
+    k.kernel = o.kernel > 0 ? o.kernel : env_int("TILESPMV_KERNEL", 0);
+    k.tilerow_begin = o.tilerow_begin; k.tilerow_end = o.tilerow_end;
+    k.autotune = (o.autotune > 0 || env_int("TILESPMV_AUTOTUNE", 0) != 0) ? 1 : 0;
+    k.entry_mode = pick(o.entry_mode, "TILESPMV_WAVE_COO", -1);
+    k.entry_ordered = pick(o.entry_ordered, "TILESPMV_COO_ORDERED", -1);
+    k.strip_cost = pick(o.strip_cost, "TILESPMV_STRIP_COST", 0);
+    k.split_above = pick(o.split_above, "TILESPMV_SPLIT_ABOVE", 2400);
+    k.split_cap = pick(o.split_cap, "TILESPMV_SPLIT_CAP", 4800);
+    k.xcd_remap = pick(o.xcd_remap, "TILESPMV_XCD_REMAP", 2) ? 2 : 0;
+    k.xcd_chunk = std::max(1, pick(o.xcd_chunk, "TILESPMV_XCD_CHUNK", 32));
+    k.csr_split = pick(o.csr_split, "TILESPMV_CSR_SPLIT", 1);
+    k.fix_inline = pick(o.fix_inline, "TILESPMV_FIX_INLINE", 1);
+    k.coo_cost = pick(o.coo_cost, "TILESPMV_COO_COST", 4);
+    k.coo_heavy_min = std::max(0, pick(o.coo_heavy_min, "TILESPMV_COO_HEAVY_MIN", 32));
+    k.coo_piece = pick(o.coo_piece, "TILESPMV_COO_PIECE", 0);
+    k.strip_even = pick(o.strip_even, "TILESPMV_STRIP_EVEN", 4);
+    k.wg_strips = pick(o.wg_strips, "TILESPMV_WG_STRIPS", -1);
+    k.x_window = pick(o.x_window, "TILESPMV_X_WINDOW", -1);
+    k.mv_native = pick(o.mv_native, "TILESPMV_MV_NATIVE", -1);
+    k.mv_xcd_chunk = pick(o.mv_xcd_chunk, "TILESPMV_MV_XCD_CHUNK", -1);
+    k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
+    k.entry_from_caller = pinned(o.entry_mode, "TILESPMV_WAVE_COO");
+    k.strip_from_caller = o.strip_cost > 0 || env_int("TILESPMV_STRIP_COST", 0) > 0;
+    k.autotune_log = getenv("TILESPMV_AUTOTUNE_LOG");
+    return k;
+}
+
 }  // namespace tilespmv
 
 using namespace tilespmv;
@@ -60,14 +118,27 @@ struct tilespmv_plan {
     val_t *mv_x = nullptr, *mv_y = nullptr;  // plans without a native multi-vector kernel: X / Y as mv_nvec contiguous vectors (allocated at the first such call)
     int mv_nvec = 0;
     bool mv_by_columns = false;              // ... and plans whose work is mostly COO entries (the multi-vector kernel walks them per 16-lane strip)
+    int mv_native = -1, mv_xcd_chunk = -1;   // knobs of tilespmv_plan_spmm (Knobs)
     int entry_mode = 0;                 // COO entry lists walked per 16-lane strip (0), per wavefront (1) or per workgroup, column-ordered (2)
     std::vector<void *> allocs;
     long long info[TILESPMV_INFO_COUNT] = {0};
     int coo_mode = 0, dense_mode = 0, kernel = 0;
     int device = 0;
+    int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
+    bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
+    unsigned long long digest = 1469598103934665603ull;
     template <class T>
     int upload(const T *host, size_t n, const T **out)
     {
+        if (dry) {   // FNV-1a-64 over (element count, bytes) of every stream, in upload order
+            auto mix = [&](const unsigned char *p, size_t len) { for (size_t i = 0; i < len; i++) { digest ^= p[i]; digest *= 1099511628211ull; } };
+            const unsigned long long cnt = n;
+            mix((const unsigned char *)&cnt, 8);
+            mix((const unsigned char *)host, n * sizeof(T));
+            info[TILESPMV_INFO_DEVICE_BYTES] += (long long)(n * sizeof(T));
+            *out = nullptr;
+            return 0;
+        }
         const double t0 = now_us();
         void *d = nullptr;
         HIP_TRY(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T) + 256));  // slack: masked tail lanes never fault
@@ -180,6 +251,61 @@ void repack_tile(const Tile_matrix *T, int t, const Emit &e, int rowlen, int col
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// One entry of a merged list before packing.
+struct PEnt { unsigned col, dest; val_t val; };
+
+inline ERec make_erec(val_t v, unsigned w)
+{
+    ERec r;
+#if defined(TILESPMV_F32)
+    memcpy(&r.v, &v, 4);
+#else
+    unsigned b[2]; memcpy(b, &v, 8); r.lo = b[0]; r.hi = b[1];
+#endif
+    r.w = w;
+    return r;
+}
+
+// Packs one list (entries already in their final order: by column, ties in list order) into records and per-chunk column
+// bases (hip_plan.h ERec).  Chunk k of the list = its records [64k, 64k + 64); base = column of the chunk's first entry;
+// an entry whose column is 2^(32 - dest_bits) or more above the base closes the chunk, which is filled up with null
+// records (value 0, offset 0, destination 0: adds 0 * x[base] to the group's first row).  Returns false if the packed list
+// does not decode back to the input (checked in layout-digest builds).
+inline bool pack_list(const std::vector<PEnt> &ents, int dest_bits, std::vector<ERec> &rec, std::vector<unsigned> &base, bool verify)
+{
+    const unsigned long long span = 1ull << (32 - dest_bits);
+    const size_t rec0 = rec.size(), base0 = base.size();
+    size_t i = 0;
+    while (i < ents.size()) {
+        const unsigned b = ents[i].col;
+        base.push_back(b);
+        int n = 0;
+        while (i < ents.size() && n < ECHUNK && (unsigned long long)ents[i].col - b < span) {
+            rec.push_back(make_erec(ents[i].val, ((ents[i].col - b) << dest_bits) | ents[i].dest));
+            i++; n++;
+        }
+        if (i < ents.size()) for (; n < ECHUNK; n++) rec.push_back(make_erec((val_t)0, 0u));   // interior chunks are always full
+    }
+    if (!verify) return true;
+    size_t j = 0;
+    for (size_t q = rec0; q < rec.size(); q++) {
+        const ERec &r = rec[q];
+        const unsigned bq = base[base0 + (q - rec0) / ECHUNK];
+        val_t v;
+#if defined(TILESPMV_F32)
+        memcpy(&v, &r.v, 4);
+#else
+        unsigned bb[2] = {r.lo, r.hi}; memcpy(&v, bb, 8);
+#endif
+        if (r.w == 0u && v == (val_t)0 && (j >= ents.size() || ents[j].col != bq || ents[j].dest != 0u || ents[j].val != (val_t)0)) continue;   // null padding
+        if (j >= ents.size()) return false;
+        const unsigned col = bq + (r.w >> dest_bits), dest = r.w & ((1u << dest_bits) - 1u);
+        if (col != ents[j].col || dest != ents[j].dest || memcmp(&v, &ents[j].val, sizeof(val_t)) != 0) return false;
+        j++;
+    }
+    return j == ents.size() && base.size() - base0 == (rec.size() - rec0 + ECHUNK - 1) / ECHUNK;
+}
+
 struct RowCount { int nunits, ncoo, nheavy, ndense; long long hval, hidx; long long cost; };
 
 // A CSR tile is executed as w ELL-style units (the first w entries of every row) plus the rest of
@@ -201,9 +327,8 @@ inline int csr_split_width(const unsigned char *ptr, int rowlen, int nnz, int *r
     return best_w;
 }
 
-inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, bool csr_split)
+inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, bool csr_split, int coo_cost)
 {
-    const int coo_cost = env_int("TILESPMV_COO_COST", 4);
     RowCount c{0, 0, 0, 0, 0, 0, 0};
     for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
         const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
@@ -230,14 +355,16 @@ inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, i
 
 }  // namespace
 
-static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,
-                        bool dense_mfma, bool csr_split, const std::vector<long long> &hyb_off, int target_in, int split_above_in,
+static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,
+                        bool dense_mfma, const std::vector<long long> &hyb_off,
                         std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes)
 {
+    const bool csr_split = K.csr_split != 0;
+    const int target_in = K.strip_cost, split_above_in = K.split_above;
     const int tilem = T->tilem, tilen = T->tilen, ntr = std::max(0, tr1 - tr0), sv = (int)sizeof(val_t);
     std::vector<RowCount> rc_((size_t)ntr);
     parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
-        for (int64_t i = b; i < e; i++) rc_[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, csr_split);
+        for (int64_t i = b; i < e; i++) rc_[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, csr_split, K.coo_cost);
     });
     std::vector<long long> pu((size_t)ntr + 1, 0), pc((size_t)ntr + 1, 0), ph((size_t)ntr + 1, 0), phv((size_t)ntr + 1, 0), phi((size_t)ntr + 1, 0);
     std::vector<long long> pd((size_t)ntr + 1, 0);
@@ -258,7 +385,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     std::vector<STask> tasks;
     std::vector<Task> htasks;
     std::vector<FixRow> ifix, fix_late;   // split rows summed inside the unit kernel / by k_fixup_split after all passes
-    const bool fix_inline_on = env_int("TILESPMV_FIX_INLINE", 1) != 0;
+    const bool fix_inline_on = K.fix_inline != 0;
     // How the COO entry lists run (TILESPMV_WAVE_COO = 0 / 1 / 2 overrides):
     //   0  per 16-lane strip — regular matrices (a handful of entries per strip);
     //   1  per wavefront, the four strips' lists merged and ordered by column — entry-heavy but small grids, where the
@@ -274,7 +401,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     for (int i = 0; i < ntr; i++) total_cost += rc_[i].cost;
     // tilespmv_plan_spmm: k_units_mv walks a strip's entries with its 16 lanes, tile-row by tile-row; where entries are most
     // of the work (webbase-like: nvec 2 took 0.11 ms against 0.013 ms for one SpMV) one SpMV per right-hand side is faster
-    const bool entry_dominated = (long long)env_int("TILESPMV_COO_COST", 4) * NC * 2 > total_cost;
+    const bool entry_dominated = (long long)K.coo_cost * NC * 2 > total_cost;
     int target = target_in;
     if (target <= 0) {
         target = 400;
@@ -291,15 +418,19 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     }
     target = std::max(32, target);
     const long long est_wgs = total_cost / (16LL * target) + 1;
-    const int wave_coo_env = env_int("TILESPMV_WAVE_COO", -1);
+    const int wave_coo_env = K.entry_mode;
     const int entry_mode = wave_coo_env >= 0 ? std::min(2, wave_coo_env) : (!entry_heavy ? 0 : est_wgs < 768 ? 1 : 2);
     const bool wave_coo = entry_mode != 0;
     plan->entry_mode = entry_mode;
+    // strips per workgroup: 32 (512 threads) only with the workgroup entry mode — twice as many tile-rows share one column-ordered
+    // list (power-law 8 M rows: 0.204 -> 0.152 distinct 128-B x lines per entry), same 6 waves per SIMD
+    const int wg_strips = entry_mode == 2 ? (K.wg_strips == 32 ? 32 : K.wg_strips == 16 ? 16 : (est_wgs >= 4096 ? 32 : 16)) : 16;
+    plan->wg_strips = wg_strips;
     // Workgroup mode: the four wavefronts add into shared slabs.  Taking turns (4 barriers per trip) fixes the order of the
     // additions -> bit-reproducible sums; free or a gain on large grids (fewer LDS conflicts: power-law 8 M rows 0.122 ->
     // 0.118 ms), +8 % on mid-size ones (webbase-like 14.2 -> 15.3 us), which therefore add unordered unless
     // TILESPMV_COO_ORDERED=1 asks for reproducible bits.  Modes 0 and 1 are always ordered (one wavefront per slab).
-    const int ordered_env = env_int("TILESPMV_COO_ORDERED", -1);
+    const int ordered_env = K.entry_ordered;
     const bool coo_ordered = ordered_env >= 0 ? ordered_env != 0 : est_wgs >= 2048;
     std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
     const int npartial0 = npartial;
@@ -307,12 +438,12 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         // rows above this cost are cut into pieces.  With the wavefront / workgroup entry modes a long row is no longer one strip's
         // private burden, but an unsplit one still makes its workgroup the last to finish: the threshold stops growing with the
         // strip size there (R-MAT scale 20 at strip size 3200: 0.099 ms with rows of up to 19,200 cost units kept whole)
-        const int split_cap = env_int("TILESPMV_SPLIT_CAP", 4800);
+        const int split_cap = K.split_cap;
         const int split_above = wave_coo ? std::max(split_above_in, std::min(6 * target, split_cap)) : std::max(6 * target, split_above_in);
         const int piece = std::max(wave_coo ? std::min(2 * target, 1600) : 2 * target, split_above / 3);
         tasks.clear(); htasks.clear(); ifix.clear(); fix_late.clear(); fix.clear(); drows.clear(); npartial = npartial0;
         std::fill(row_k.begin(), row_k.end(), 0); std::fill(row_split.begin(), row_split.end(), 0);
-        const int strip_even = env_int("TILESPMV_STRIP_EVEN", 4);  // 0 off, 1 = value group, n > 1 = multiples of n units
+        const int strip_even = K.strip_even;  // 0 off, 1 = value group, n > 1 = multiples of n units
         auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
         auto is_heavy = [&](int t) {
             const int fmt = T->Format[t];
@@ -332,7 +463,7 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
                 row_split[i] = 1;
                 FixRow f{tr0 + i, npartial, 0, 0};
                 // entry pieces: four consecutive pieces share a wavefront, which walks their lists together (4 x 192 = 2 trips of 6 x 64)
-                const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, env_int("TILESPMV_COO_PIECE", entry_mode == 1 ? 192 : piece / std::max(1, env_int("TILESPMV_COO_COST", 4))));
+                const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, K.coo_piece > 0 ? K.coo_piece : (entry_mode == 1 ? 192 : piece / std::max(1, K.coo_cost)));
                 for (long long u = pu[i]; u < pu[i + 1]; u += pu_) {
                     STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
                     k.unit_begin = (int)u; k.unit_end = (int)std::min(pu[i + 1], u + pu_);
@@ -588,46 +719,57 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
         rc |= plan->upload(paired, (size_t)NUP * 16, &S.uval);
         free(paired);
     }
-    S.wg_coo = nullptr; S.gval = nullptr; S.gcol = nullptr; S.grow = nullptr;
+    S.wg_coo = nullptr; S.grec = nullptr; S.gbase = nullptr; S.dest_bits = 11;
+    long long n_rec = 0, n_chunk = 0, n_groups = 0;
     if (entry_mode != 0) {
-        const size_t GS = entry_mode == 2 ? 16 : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
+        const size_t GS = entry_mode == 2 ? (size_t)wg_strips : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
+        const int dest_bits = entry_mode == 2 ? (wg_strips == 32 ? 12 : 11) : 9;   // strip-in-group | row-in-strip (3) | row (4)
+        S.dest_bits = dest_bits;
         const size_t nwg = (tasks.size() + GS - 1) / GS;
-        std::vector<int2> wg((size_t)nwg);
-        long long at = 0;
-        for (size_t w = 0; w < nwg; w++) {
-            long long n = 0;
-            for (size_t t = GS * w; t < std::min(tasks.size(), GS * w + GS); t++) n += tasks[t].coo_end - tasks[t].coo_begin;
-            wg[w] = make_int2((int)at, (int)(at + n));
-            at += n;
-        }
-        val_t *g_val = zalloc<val_t>((size_t)NC);
-        std::vector<int> g_col((size_t)NC);
-        std::vector<unsigned char> g_row((size_t)NC);
+        std::vector<std::vector<ERec>> grp_rec(nwg);
+        std::vector<std::vector<unsigned>> grp_base(nwg);
+        std::atomic<int> bad(0);
         parallel_chunks((int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
-            std::vector<std::pair<unsigned long long, int>> key;
+            std::vector<std::pair<unsigned long long, unsigned>> key;   // (column << 32 | position in strip / list order, destination)
+            std::vector<int> src;
+            std::vector<PEnt> ents;
             for (int64_t w = b; w < e; w++) {
-                key.clear();
+                key.clear(); src.clear();
                 for (size_t t = GS * (size_t)w; t < std::min(tasks.size(), GS * (size_t)w + GS); t++)
-                    for (int q = tasks[t].coo_begin; q < tasks[t].coo_end; q++)   // column-major order; ties keep strip / list order
-                        key.push_back({((unsigned long long)(unsigned)h_ccol[(size_t)q] << 32) | (unsigned long long)key.size(), (int)((t & (GS - 1)) << 28)});
-                // remember the source position next to the key: rebuild it from the running index
-                std::vector<int> src; src.reserve(key.size());
-                for (size_t t = GS * (size_t)w; t < std::min(tasks.size(), GS * (size_t)w + GS); t++)
-                    for (int q = tasks[t].coo_begin; q < tasks[t].coo_end; q++) src.push_back(q);
+                    for (int q = tasks[t].coo_begin; q < tasks[t].coo_end; q++) {   // column-major order; ties keep strip / list order
+                        key.push_back({((unsigned long long)(unsigned)h_ccol[(size_t)q] << 32) | (unsigned long long)key.size(),
+                                       (unsigned)((t & (GS - 1)) << 7) | (unsigned)h_crow[(size_t)q]});
+                        src.push_back(q);
+                    }
                 std::sort(key.begin(), key.end());
-                long long o = wg[(size_t)w].x;
-                for (const auto &k : key) {
-                    const int q = src[(size_t)(k.first & 0xFFFFFFFFull)];
-                    g_val[o] = h_cval[q]; g_col[(size_t)o] = h_ccol[(size_t)q] | k.second; g_row[(size_t)o] = h_crow[(size_t)q];
-                    o++;
+                ents.resize(key.size());
+                for (size_t i = 0; i < key.size(); i++) {
+                    const int q = src[(size_t)(key[i].first & 0xFFFFFFFFull)];
+                    ents[i] = PEnt{(unsigned)h_ccol[(size_t)q], key[i].second, h_cval[q]};
                 }
+                if (!pack_list(ents, dest_bits, grp_rec[(size_t)w], grp_base[(size_t)w], plan->dry)) bad++;
             }
         });
+        if (bad.load()) { fprintf(stderr, "tilespmv: internal error: %d packed entry lists do not decode to their entries\n", bad.load()); rc = -6; }
+        std::vector<int4> wg((size_t)nwg);
+        for (size_t w = 0; w < nwg; w++) {
+            wg[w] = make_int4((int)n_rec, (int)(n_rec + (long long)grp_rec[w].size()), (int)n_chunk, 0);
+            n_rec += (long long)grp_rec[w].size(); n_chunk += (long long)grp_base[w].size();
+        }
+        if (n_rec > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit entry ids\n"); rc = -2; n_rec = 0; }
+        std::vector<ERec> g_rec((size_t)n_rec);
+        std::vector<unsigned> g_base((size_t)n_chunk);
+        if (rc == 0)
+            parallel_chunks((int64_t)nwg, 256, [&](int64_t b, int64_t e, int) {
+                for (int64_t w = b; w < e; w++) {
+                    if (!grp_rec[(size_t)w].empty()) memcpy(&g_rec[(size_t)wg[(size_t)w].x], grp_rec[(size_t)w].data(), grp_rec[(size_t)w].size() * sizeof(ERec));
+                    if (!grp_base[(size_t)w].empty()) memcpy(&g_base[(size_t)wg[(size_t)w].z], grp_base[(size_t)w].data(), grp_base[(size_t)w].size() * sizeof(unsigned));
+                }
+            });
+        n_groups = (long long)nwg;
         rc |= plan->upload(wg.data(), wg.size(), &S.wg_coo);
-        rc |= plan->upload(g_val, (size_t)NC, &S.gval);
-        rc |= plan->upload(g_col.data(), (size_t)NC, &S.gcol);
-        rc |= plan->upload(g_row.data(), (size_t)NC, &S.grow);
-        free(g_val);
+        rc |= plan->upload(g_rec.data(), g_rec.size(), &S.grec);
+        rc |= plan->upload(g_base.data(), g_base.size(), &S.gbase);
     }
     rc |= plan->upload(h_cval, (size_t)NC, &S.cval);
     rc |= plan->upload(h_ccol.data(), (size_t)NC, &S.ccol);
@@ -663,15 +805,14 @@ static int build_stream(tilespmv_plan *plan, const Tile_matrix *T, int rowA, int
     plan->dev.nfix_late = (int)fix_late.size();
     // entry mode 0 only: strips with more entries than this run their list before the unit pipeline (32: swept on KKT fp64 / scircuit /
     // webbase stand-ins in round 1, best or within 1 %)
-    S.coo_heavy_min = std::max(0, env_int("TILESPMV_COO_HEAVY_MIN", 32));
-    S.coo_nt = env_int("TILESPMV_COO_NT", 0);
+    S.coo_heavy_min = K.coo_heavy_min;
     S.coo_ordered = coo_ordered ? 1 : 0;
     plan->info[TILESPMV_INFO_ENTRY_MODE] = entry_mode;
     plan->info[TILESPMV_INFO_ENTRY_ORDERED] = (entry_mode != 2 || coo_ordered) ? 1 : 0;
     plan->info[TILESPMV_INFO_STRIP_COST] = target;
     plan->mv_by_columns = entry_dominated && target >= 800;   // (small strips hold few entries each: scircuit-like 18 / 22 / 32 us native against 22 / 41 / 78 us)
     n_tasks = (long long)tasks.size();
-    model_bytes = NUP * (12 + 16LL * sv) + NC * (sv + 5LL) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
+    model_bytes = NUP * (12 + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
                   ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
     return rc;
@@ -710,23 +851,29 @@ void tilespmv_plan_destroy(tilespmv_plan *plan)
     delete plan;
 }
 
-static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA,
-                           const tilespmv_plan_options *opts);
+static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const Knobs &K);
 
-// Measured selection (execution side): when opts->reserved[0] != 0 or TILESPMV_AUTOTUNE=1, the
-// choices that AUTO otherwise makes from byte models — COO tiles in-tile vs CSR fallback, dense tiles on the
-// matrix cores vs as streamed units — are decided by timing each candidate plan on this device.
+void tilespmv_plan_options_init(tilespmv_plan_options *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->size = (unsigned)sizeof(*o);
+    int *knob = &o->entry_mode;   // every field from entry_mode on is a knob
+    const int n = (int)((sizeof(*o) - offsetof(tilespmv_plan_options, entry_mode)) / sizeof(int));
+    for (int i = 0; i < n; i++) knob[i] = TILESPMV_KNOB_DEFAULT;
+}
+
+// Measured selection (execution side): with opts->autotune (or TILESPMV_AUTOTUNE=1) the choices that AUTO
+// otherwise makes from byte models — COO tiles in-tile vs CSR fallback, dense tiles on the matrix cores vs as streamed
+// units, entry mode, strip size, workgroup -> XCD map — are decided by timing each candidate plan on this device.  A
+// candidate is a copy of the caller's Knobs with some fields replaced: nothing travels through the environment.
 int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA,
                          const tilespmv_plan_options *opts)
 {
-    tilespmv_plan_options o{};
-    if (opts) o = *opts;
-    const bool tune = o.reserved[0] != 0 || env_int("TILESPMV_AUTOTUNE", 0) != 0;
-    o.reserved[0] = 0;
-    if (!tune) return plan_create_one(out, T, rowA, colA, nnzA, &o);
+    const Knobs K0 = resolve_knobs(opts);
+    if (!K0.autotune) return plan_create_one(out, T, rowA, colA, nnzA, K0);
     *out = nullptr;
     const int tilem = T->tilem;
-    const int tr0 = std::max(0, o.tilerow_begin), tr1 = (o.tilerow_end <= 0 || o.tilerow_end > tilem) ? tilem : o.tilerow_end;
+    const int tr0 = std::max(0, K0.tilerow_begin), tr1 = (K0.tilerow_end <= 0 || K0.tilerow_end > tilem) ? tilem : K0.tilerow_end;
     bool has_dense = false;
     for (int t = T->tile_ptr[tr0]; t < T->tile_ptr[tr1] && !has_dense; t++) has_dense = T->Format[t] == TILESPMV_FMT_DNS;
     const bool has_extracted = T->new_coocount[T->tile_ptr[tr1]] > T->new_coocount[T->tile_ptr[tr0]];
@@ -742,19 +889,9 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     std::string log = "{\"rows\": " + std::to_string(rowA) + ", \"cols\": " + std::to_string(colA) + ", \"nnz\": " + std::to_string((long long)nnzA) +
                       ", \"value_bytes\": " + std::to_string(sizeof(val_t)) + ", \"candidates\": [";
     bool first = true;
-    // env knobs a candidate overrides for the duration of its build (the builder reads them at plan creation)
-    struct EnvSet { const char *name; std::string val; };
-    auto with_env = [&](const std::vector<EnvSet> &es, auto &&fn) {
-        std::vector<std::pair<std::string, std::string>> saved;
-        for (const EnvSet &e : es) { const char *o = getenv(e.name); saved.push_back({e.name, o ? o : "\x01"}); setenv(e.name, e.val.c_str(), 1); }
-        fn();
-        for (auto &sv : saved) { if (sv.second == "\x01") unsetenv(sv.first.c_str()); else setenv(sv.first.c_str(), sv.second.c_str(), 1); }
-    };
-    auto try_one = [&](tilespmv_plan_options cand, const std::vector<EnvSet> &es, const char *label) {
+    auto try_one = [&](const Knobs &cand, const char *label) {
         tilespmv_plan *p = nullptr;
-        int rc1 = 0;
-        with_env(es, [&]() { rc1 = plan_create_one(&p, T, rowA, colA, nnzA, &cand); });
-        if (rc1 != 0 || !p) return;
+        if (plan_create_one(&p, T, rowA, colA, nnzA, cand) != 0 || !p) return;
         const double ms = tilespmv_plan_time(p, dx, dy, nullptr, 3, 12);
         char buf[512];
         snprintf(buf, sizeof(buf), "%s{\"label\": \"%s\", \"coo_mode\": %d, \"dense_mode\": %d, \"entry_mode\": %d, \"ordered\": %lld, \"strip_cost\": %lld, \"tasks\": %lld, \"ms\": %.5f}",
@@ -765,44 +902,45 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
         else tilespmv_plan_destroy(p);
     };
     const int coo_cands[2] = {TILESPMV_COO_IN_TILE, TILESPMV_COO_FALLBACK}, dns_cands[2] = {TILESPMV_DENSE_MFMA, TILESPMV_DENSE_VALU};
-    try_one(o, {}, "default");   // what AUTO picks from its byte models: stays unless something is clearly faster
+    try_one(K0, "default");   // what AUTO picks from its byte models: stays unless something is clearly faster
     const tilespmv_plan *dflt = best;
     const int d_coo = dflt ? dflt->coo_mode : 0, d_dns = dflt ? dflt->dense_mode : 0, d_entry = dflt ? dflt->entry_mode : 0;
     const long long d_cost = dflt ? dflt->info[TILESPMV_INFO_STRIP_COST] : 400, d_ord = dflt ? dflt->info[TILESPMV_INFO_ENTRY_ORDERED] : 1;  // (copies: `best` may be replaced)
-    for (int ci = 0; ci < ((o.coo_mode == TILESPMV_COO_AUTO && has_extracted) ? 2 : 1); ci++)
-        for (int di = 0; di < ((o.dense_mode == TILESPMV_DENSE_AUTO && has_dense) ? 2 : 1); di++) {
-            tilespmv_plan_options cand = o;
-            if (o.coo_mode == TILESPMV_COO_AUTO && has_extracted) cand.coo_mode = coo_cands[ci];
-            if (o.dense_mode == TILESPMV_DENSE_AUTO && has_dense) cand.dense_mode = dns_cands[di];
-            const bool coo_var = o.coo_mode == TILESPMV_COO_AUTO && has_extracted, dns_var = o.dense_mode == TILESPMV_DENSE_AUTO && has_dense;
+    const bool coo_var = K0.coo_mode == TILESPMV_COO_AUTO && has_extracted, dns_var = K0.dense_mode == TILESPMV_DENSE_AUTO && has_dense;
+    for (int ci = 0; ci < (coo_var ? 2 : 1); ci++)
+        for (int di = 0; di < (dns_var ? 2 : 1); di++) {
+            Knobs cand = K0;
+            if (coo_var) cand.coo_mode = coo_cands[ci];
+            if (dns_var) cand.dense_mode = dns_cands[di];
             if ((!coo_var || cand.coo_mode == d_coo) && (!dns_var || cand.dense_mode == d_dns)) continue;   // that is the default, already timed
-            try_one(cand, {}, "coo/dense mode");
+            try_one(cand, "coo/dense mode");
         }
     // how the entry lists run and how large the strips are (generation 2, in-tile entries): the other entry modes at the
     // default strip size, then the winning mode at half and twice the size.  Unordered workgroup adds are only a candidate
-    // when the caller has not asked for reproducible sums (TILESPMV_COO_ORDERED=1).
-    if (best && best->kernel == TILESPMV_KERNEL_STREAM && best->coo_mode == TILESPMV_COO_IN_TILE && !getenv("TILESPMV_WAVE_COO") && !getenv("TILESPMV_STRIP_COST")) {
-        tilespmv_plan_options cand = o;
+    // when the caller has not asked for reproducible sums (entry_ordered = 1).
+    if (best && best->kernel == TILESPMV_KERNEL_STREAM && best->coo_mode == TILESPMV_COO_IN_TILE && !K0.entry_from_caller && !K0.strip_from_caller) {
+        Knobs cand = K0;
         cand.coo_mode = best->coo_mode; cand.dense_mode = best->dense_mode;
-        const bool may_unorder = env_int("TILESPMV_COO_ORDERED", -1) != 1;
+        const bool may_unorder = K0.entry_ordered != 1;
         for (int em = 0; em <= 2; em++) {
             if (em == d_entry && !(em == 2)) continue;
+            Knobs c2 = cand; c2.entry_mode = em;
             if (em == 2) {
-                if (d_entry != 2 || d_ord == 0) try_one(cand, {{"TILESPMV_WAVE_COO", "2"}, {"TILESPMV_COO_ORDERED", "1"}}, "entry mode 2, ordered");
-                if (may_unorder && (d_entry != 2 || d_ord == 1)) try_one(cand, {{"TILESPMV_WAVE_COO", "2"}, {"TILESPMV_COO_ORDERED", "0"}}, "entry mode 2, unordered");
-            } else try_one(cand, {{"TILESPMV_WAVE_COO", std::to_string(em)}}, em == 0 ? "entry mode 0" : "entry mode 1");
+                if (d_entry != 2 || d_ord == 0) { c2.entry_ordered = 1; try_one(c2, "entry mode 2, ordered"); }
+                if (may_unorder && (d_entry != 2 || d_ord == 1)) { c2.entry_ordered = 0; try_one(c2, "entry mode 2, unordered"); }
+            } else try_one(c2, em == 0 ? "entry mode 0" : "entry mode 1");
         }
         const int w_entry = best->entry_mode; const long long w_ord = best->info[TILESPMV_INFO_ENTRY_ORDERED], w_cost = best->info[TILESPMV_INFO_STRIP_COST];
         for (long long c : {w_cost / 2, w_cost * 2}) {
             if (c < 100 || c > 3200 || c == d_cost) continue;
-            std::vector<EnvSet> es = {{"TILESPMV_WAVE_COO", std::to_string(w_entry)}, {"TILESPMV_STRIP_COST", std::to_string(c)}};
-            if (w_entry == 2) es.push_back({"TILESPMV_COO_ORDERED", w_ord ? "1" : "0"});
-            try_one(cand, es, "strip size");
+            Knobs c2 = cand; c2.entry_mode = w_entry; c2.strip_cost = (int)c;
+            if (w_entry == 2) c2.entry_ordered = w_ord ? 1 : 0;
+            try_one(c2, "strip size");
         }
     }
     log += "], \"xcd_maps\": [";
     // the workgroup -> XCD mapping is a launch parameter: time the alternatives on the winning plan
-    if (best && best->kernel == TILESPMV_KERNEL_STREAM && !getenv("TILESPMV_XCD_REMAP") && !getenv("TILESPMV_XCD_CHUNK")) {
+    if (best && best->kernel == TILESPMV_KERNEL_STREAM && !K0.xcd_from_caller) {
         const int maps[3][2] = {{best->xcd_remap, best->xcd_chunk}, {0, best->xcd_chunk}, {2, 8}};
         int pick = 0;
         double pick_ms = 0;
@@ -822,8 +960,8 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
         snprintf(buf, sizeof(buf), "], \"choice\": {\"coo_mode\": %d, \"dense_mode\": %d, \"entry_mode\": %d, \"ordered\": %lld, \"strip_cost\": %lld, \"xcd_remap\": %d, \"xcd_chunk\": %d, \"ms\": %.5f}}",
                  best->coo_mode, best->dense_mode, best->entry_mode, best->info[TILESPMV_INFO_ENTRY_ORDERED], best->info[TILESPMV_INFO_STRIP_COST], best->xcd_remap, best->xcd_chunk, best_ms);
         log += buf;
-        if (const char *path = getenv("TILESPMV_AUTOTUNE_LOG")) {   // one JSON line per tuned plan
-            if (FILE *f = fopen(path, "a")) { fprintf(f, "%s\n", log.c_str()); fclose(f); }
+        if (K0.autotune_log) {   // one JSON line per tuned plan
+            if (FILE *f = fopen(K0.autotune_log, "a")) { fprintf(f, "%s\n", log.c_str()); fclose(f); }
         }
     }
     (void)hipFree(dx); (void)hipFree(dy);
@@ -832,25 +970,24 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     return 0;
 }
 
-static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA,
-                           const tilespmv_plan_options *opts)
+static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const Knobs &K)
 {
     (void)nnzA;
     *out = nullptr;
     const double t_create0 = now_us();
-    if (tilespmv_device_count() <= 0) {
+    if (!K.dry && tilespmv_device_count() <= 0) {
         fprintf(stderr, "tilespmv: no HIP device visible — the GPU path has no CPU fallback\n");
         return -1;
     }
-    tilespmv_plan_options o{};
-    if (opts) o = *opts;
+    const Knobs &o = K;
     const int tilem = T->tilem, tilen = T->tilen;
     const int tr0 = std::max(0, o.tilerow_begin), tr1 = (o.tilerow_end <= 0 || o.tilerow_end > tilem) ? tilem : o.tilerow_end;
     const int ntr = std::max(0, tr1 - tr0);
     const int sv = (int)sizeof(val_t);
 
     auto *plan = new tilespmv_plan();
-    if (hipGetDevice(&plan->device) != hipSuccess) { fprintf(stderr, "tilespmv: hipGetDevice failed\n"); delete plan; return -1; }
+    plan->dry = K.dry;
+    if (!K.dry && hipGetDevice(&plan->device) != hipSuccess) { fprintf(stderr, "tilespmv: hipGetDevice failed\n"); delete plan; return -1; }
 
     // ---- how are COO tiles executed?  (bytes model)
     const int t_begin = T->tile_ptr[tr0], t_end = T->tile_ptr[tr1];
@@ -859,9 +996,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     for (int t = t_begin; t < t_end; t++)
         if (T->Format[t] == TILESPMV_FMT_COO) { ncoo_tiles++; ncoo_vals += T->blknnz[t + 1] - T->blknnz[t]; }
     const long long extracted = T->new_coocount[t_end] - T->new_coocount[t_begin];
-    int coo_mode = o.coo_mode ? o.coo_mode : env_int("TILESPMV_COO_MODE", 0);
-    int dense_mode = o.dense_mode ? o.dense_mode : env_int("TILESPMV_DENSE_MODE", 0);
-    int kernel = o.kernel ? o.kernel : env_int("TILESPMV_KERNEL", 0);
+    int coo_mode = o.coo_mode, dense_mode = o.dense_mode, kernel = o.kernel;
     if (kernel == TILESPMV_KERNEL_AUTO)  // the unit descriptor keeps the column block in 24 bits
         kernel = tilen <= (1 << UNIT_FLAG_SHIFT) ? TILESPMV_KERNEL_STREAM : TILESPMV_KERNEL_DIRECT;
     if (coo_mode == TILESPMV_COO_AUTO) {
@@ -917,11 +1052,12 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     }
 
     plan->kernel = kernel;
-    plan->xcd_remap = env_int("TILESPMV_XCD_REMAP", 2) ? 2 : 0;  // 0 = round-robin, 2 = windows of 8 x xcd_chunk workgroups
-    plan->xcd_chunk = std::max(1, env_int("TILESPMV_XCD_CHUNK", 32));
+    plan->xcd_remap = K.xcd_remap;  // 0 = round-robin, 2 = windows of 8 x xcd_chunk workgroups
+    plan->xcd_chunk = K.xcd_chunk;
+    plan->mv_native = K.mv_native; plan->mv_xcd_chunk = K.mv_xcd_chunk;
     // Strip size: ~400 cost units (20 units) amortises the per-strip round trips; measured flat between 200
     // and 800 on large matrices and neutral on small (cache-resident) ones, where launch latency dominates.
-    const int target_env = env_int("TILESPMV_STRIP_COST", 0), split_env = env_int("TILESPMV_SPLIT_ABOVE", 2400);
+    const int target_env = K.strip_cost, split_env = K.split_above;
     int target = target_env;    // generation 1 below; the unit-stream builder picks its own default (build_stream)
     if (target <= 0) target = 192;
     target = std::max(32, target);
@@ -932,9 +1068,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     int rc = 0;
     DevPlan &D = plan->dev;
     if (kernel == TILESPMV_KERNEL_STREAM) {
-        const bool csr_split = env_int("TILESPMV_CSR_SPLIT", 1) != 0;
-        rc = build_stream(plan, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mode == TILESPMV_DENSE_MFMA, csr_split, hyb_off, target_env, split_env,
-                          fix, npartial, n_tasks, model_bytes);
+        rc = build_stream(plan, K, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mode == TILESPMV_DENSE_MFMA, hyb_off, fix, npartial, n_tasks, model_bytes);
     } else {
     // ---- pass 1: stream sizes per tile-row
     std::vector<long long> row_tile((size_t)ntr + 1, 0), row_val((size_t)ntr + 1, 0), row_idx((size_t)ntr + 1, 0);
@@ -1030,9 +1164,8 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     std::vector<int4> f_blk;
     long long f_nnz = 0;
     const int row0 = tr0 * 16, rows = (int)shard_rows;
-    val_t *f_val = nullptr;
-    std::vector<int> f_col;
-    std::vector<unsigned char> f_row;
+    std::vector<ERec> f_rec;
+    std::vector<unsigned> f_base;
     if (!coo_in_tile && extracted > 0) {
         const int *P0 = T->deferredcoo_ptr + row0;
         const int base = P0[0];
@@ -1040,7 +1173,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         // block size: FB_CAP nonzeros when there is enough work for ~3 workgroups per CU, smaller blocks (down to one trip) otherwise
         const int cap = (int)std::max<long long>(1536, std::min<long long>(FB_CAP, f_nnz / (3 * 256)));
         int r = 0;
-        while (r < rows) {
+        while (r < rows) {   // .z / .w: source range in the extracted matrix for now, record range after packing
             const int nr = P0[r + 1] - P0[r];
             if (nr == 0) { r++; continue; }   // runs of empty rows are not covered at all
             if (nr > FB_CAP) {
@@ -1054,10 +1187,12 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
             f_blk.push_back(make_int4(r, e - r, P0[r] - base, P0[e] - base));
             r = e;
         }
-        f_val = zalloc<val_t>((size_t)f_nnz);
-        f_col.resize((size_t)f_nnz); f_row.resize((size_t)f_nnz);
+        std::vector<std::vector<ERec>> blk_rec(f_blk.size());
+        std::vector<std::vector<unsigned>> blk_base(f_blk.size());
+        std::atomic<int> bad(0);
         parallel_chunks((int64_t)f_blk.size(), 16, [&](int64_t b0, int64_t b1, int) {
             std::vector<std::pair<unsigned long long, int>> key;
+            std::vector<PEnt> ents;
             for (int64_t b = b0; b < b1; b++) {
                 const int4 k = f_blk[(size_t)b];
                 key.clear();
@@ -1069,34 +1204,50 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
                             key.push_back({((unsigned long long)(unsigned)T->deferredcoo_colidx[base + q] << 32) | (unsigned)(q - k.z), rr - k.x});
                 }
                 std::sort(key.begin(), key.end());   // by column; ties keep the extracted matrix's order
+                ents.resize(key.size());
                 for (size_t i = 0; i < key.size(); i++) {
-                    const int q = k.z + (int)(key[i].first & 0xFFFFFFFFull), dest = key[i].second;
-                    f_val[(size_t)k.z + i] = T->deferredcoo_val[base + q];
-                    f_col[(size_t)k.z + i] = (int)((unsigned)T->deferredcoo_colidx[base + q] | ((unsigned)(dest >> 7) << 28));
-                    f_row[(size_t)k.z + i] = (unsigned char)(dest & 127);
+                    const int q = k.z + (int)(key[i].first & 0xFFFFFFFFull);
+                    ents[i] = PEnt{(unsigned)T->deferredcoo_colidx[base + q], (unsigned)key[i].second, T->deferredcoo_val[base + q]};
                 }
+                if (!pack_list(ents, FB_DEST_BITS, blk_rec[(size_t)b], blk_base[(size_t)b], K.dry)) bad++;
             }
         });
+        if (bad.load()) { fprintf(stderr, "tilespmv: internal error: %d packed fallback lists do not decode to their entries\n", bad.load()); rc = -6; }
+        long long at = 0;   // every block's list starts on a chunk boundary: chunk of record i = i >> 6
+        for (size_t b = 0; b < f_blk.size(); b++) {
+            f_blk[b].z = (int)at; f_blk[b].w = (int)(at + (long long)blk_rec[b].size());
+            at = (at + (long long)blk_rec[b].size() + ECHUNK - 1) / ECHUNK * ECHUNK;
+            if (at > INT32_MAX - ECHUNK) { fprintf(stderr, "tilespmv: shard too large for 32-bit entry ids\n"); rc = -2; break; }
+        }
+        if (rc == 0) {
+            f_rec.assign((size_t)at, make_erec((val_t)0, 0u));
+            f_base.assign((size_t)(at / ECHUNK), 0u);
+            parallel_chunks((int64_t)f_blk.size(), 64, [&](int64_t b0, int64_t b1, int) {
+                for (int64_t b = b0; b < b1; b++) {
+                    if (!blk_rec[(size_t)b].empty()) memcpy(&f_rec[(size_t)f_blk[(size_t)b].z], blk_rec[(size_t)b].data(), blk_rec[(size_t)b].size() * sizeof(ERec));
+                    if (!blk_base[(size_t)b].empty()) memcpy(&f_base[(size_t)(f_blk[(size_t)b].z / ECHUNK)], blk_base[(size_t)b].data(), blk_base[(size_t)b].size() * sizeof(unsigned));
+                }
+            });
+        }
     }
 
     // ---- upload the rest
     rc |= plan->upload(fix.data(), fix.size(), &D.fix);
     if (npartial > 0) {
         void *p = nullptr;
-        if (hipMalloc(&p, (size_t)npartial * 16 * sizeof(val_t) * TILESPMV_MAX_NVEC) != hipSuccess) rc = -3;  // slots are nvec wide in tilespmv_plan_spmm
+        if (K.dry) { }
+        else if (hipMalloc(&p, (size_t)npartial * 16 * sizeof(val_t) * TILESPMV_MAX_NVEC) != hipSuccess) rc = -3;  // slots are nvec wide in tilespmv_plan_spmm
         else { plan->allocs.push_back(p); D.partial = (val_t *)p; }
     }
     if (!f_blk.empty()) {
-        rc |= plan->upload(f_val, (size_t)f_nnz, &D.f_val);
-        rc |= plan->upload(f_col.data(), (size_t)f_nnz, &D.f_col);
-        rc |= plan->upload(f_row.data(), (size_t)f_nnz, &D.f_row);
+        rc |= plan->upload(f_rec.data(), f_rec.size(), &D.f_rec);
+        rc |= plan->upload(f_base.data(), f_base.size(), &D.f_base);
         rc |= plan->upload(f_blk.data(), f_blk.size(), &D.f_blk);
         D.f_nblk = (int)f_blk.size();
         // taking turns costs latency on small grids and nothing on large ones (as in the unit kernel's workgroup entry mode)
-        const int ordered_env = env_int("TILESPMV_COO_ORDERED", -1);
+        const int ordered_env = K.entry_ordered;
         D.f_ordered = ordered_env >= 0 ? ordered_env != 0 : f_blk.size() >= 2048;
     }
-    free(f_val);
     if (rc) { tilespmv_plan_destroy(plan); return rc; }
     D.nfix = (int)fix.size();
     D.rowA = std::min<long long>(rowA, (long long)tr1 * 16); D.colA = colA;
@@ -1113,8 +1264,22 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     I[TILESPMV_INFO_BUILD_US] = (long long)(now_us() - t_create0) - I[TILESPMV_INFO_UPLOAD_US];
     // bytes one SpMV has to move at least: the three streams + tasks + x once + y once (+ fallback)
     I[TILESPMV_INFO_STREAM_BYTES] = model_bytes + (long long)colA * sv + (long long)rows * sv +
-                                    (f_nnz ? f_nnz * (sv + 5) + 2LL * sv * rows + (long long)f_blk.size() * 16 : 0);   // the fallback re-reads and re-writes its rows of y
+                                    (f_nnz ? (long long)f_rec.size() * (long long)sizeof(ERec) + (long long)f_base.size() * 4 + 2LL * sv * rows + (long long)f_blk.size() * 16 : 0);   // the fallback re-reads and re-writes its rows of y
     *out = plan;
+    return 0;
+}
+
+int tilespmv_plan_layout_digest(const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const tilespmv_plan_options *opts,
+                                unsigned long long *digest, long long *info)
+{
+    Knobs K = resolve_knobs(opts);
+    K.dry = true; K.autotune = 0;
+    tilespmv_plan *p = nullptr;
+    const int rc = plan_create_one(&p, T, rowA, colA, nnzA, K);
+    if (rc != 0 || !p) return rc ? rc : -4;
+    if (digest) *digest = p->digest;
+    if (info) memcpy(info, p->info, sizeof(p->info));
+    tilespmv_plan_destroy(p);
     return 0;
 }
 
@@ -1122,7 +1287,7 @@ int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYP
 {
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = plan->dense_mode == TILESPMV_DENSE_MFMA;
-    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, plan->dn, mfma, plan->entry_mode, plan->xcd_remap, plan->xcd_chunk, d_x, d_y, st)
+    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, plan->dn, mfma, plan->entry_mode, plan->wg_strips, plan->xcd_remap, plan->xcd_chunk, d_x, d_y, st)
                                                           : launch_tiles_direct(plan->dev, mfma, false, true, d_x, d_y, st);
     if (e != hipSuccess) return (int)e;
     return (int)launch_fallback(plan->dev, d_x, d_y, st);
@@ -1135,7 +1300,7 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
     if (((uintptr_t)d_X | (uintptr_t)d_Y) & 15u) return (int)hipErrorInvalidValue;  // rows of X / Y travel as 16-B vectors
     // native multi-vector kernels: unit-stream plans whose COO entries run in-tile and whose CSR tiles were split into units
     // (the defaults).  Generation-1 plans, whole-tile passes and the CSR fallback go one right-hand side at a time.
-    static const int mv_native = env_int("TILESPMV_MV_NATIVE", -1);   // 1 / 0: force the multi-vector kernel / the one-at-a-time path on entry-dominated plans
+    const int mv_native = plan->mv_native;   // 1 / 0: force the multi-vector kernel / the one-at-a-time path on entry-dominated plans
     const bool has_native = plan->kernel == TILESPMV_KERNEL_STREAM && plan->dev.ntasks == 0 && plan->dev.f_nblk == 0;
     // entry-dominated plans: the multi-vector kernel only pays from 8 right-hand sides on (webbase-like: 38 / 77 / 154 us one
     // at a time against 110 / 125 / 142 us for nvec 2 / 4 / 8)
@@ -1159,7 +1324,7 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
         e = launch_columns_to_rows(plan->mv_y, nvec, row0, rows, ldy, d_Y, st);
         return (int)e;
     }
-    static const int mv_chunk = env_int("TILESPMV_MV_XCD_CHUNK", -1);
+    const int mv_chunk = plan->mv_xcd_chunk;
     return (int)launch_tiles_stream_mv(plan->dev, plan->st, plan->dn, nvec, mv_chunk >= 0 ? mv_chunk : (plan->xcd_remap >= 2 ? plan->xcd_chunk : 0), d_X, d_Y, (hipStream_t)stream);
 }
 

@@ -97,7 +97,7 @@ extern "C" void call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int
         CK(hipSetDevice(s.device));
         CK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         tilespmv_plan_options o;
-        memset(&o, 0, sizeof(o));
+        tilespmv_plan_options_init(&o);
         o.tilerow_begin = s.tr0; o.tilerow_end = s.tr1;
         if (s.tr1 > s.tr0) CK(tilespmv_plan_create(&s.plan, matrix, rowA, colA, nnzA, &o));
         CK(hipMalloc((void **)&s.d_x, ((size_t)colA + 16) * sizeof(val_t)));
