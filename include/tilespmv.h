@@ -152,6 +152,29 @@ int mmio_allinone(int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric, MAT_PTR_T
 int tilespmv_matrix_save(const Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA, const char *path);
 int tilespmv_matrix_load(Tile_matrix *matrix, int *rowA, int *colA, MAT_PTR_TYPE *nnzA, const char *path);
 
+/* Parse once (new): binary cache of what mmio_allinone returns.  The reference re-tokenises the text on
+ * every run (src/mmio_highlevel.h:648-682; nlpkkt160 is ~4 GB of it).  save: 0, -1 cannot open, -3 short write (the partial
+ * file is removed).  load: arrays are malloc'd like mmio_allinone's (caller frees); 0, -1 cannot open, -2 not a CSR cache,
+ * -3 read error, -5 other value type, -6 corrupt (length, FNV-1a-64 checksum, row pointer, column range all checked), -7
+ * stale: `source_mtx` (may be NULL = do not check) no longer has the size and modification time recorded at save time. */
+int tilespmv_csr_save(const char *path, int m, int n, MAT_PTR_TYPE nnz, int isSymmetric,
+                      const MAT_PTR_TYPE *csrRowPtr, const int *csrColIdx, const MAT_VAL_TYPE *csrVal,
+                      const char *source_mtx);
+int tilespmv_csr_load(const char *path, int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric,
+                      MAT_PTR_TYPE **csrRowPtr, int **csrColIdx, MAT_VAL_TYPE **csrVal,
+                      const char *source_mtx);
+/* mmio_allinone with the cache beside it: reads `cache_path` when it is fresh for `filename`, else parses the text and
+ * (re)writes the cache.  *from_cache (may be NULL): 1 read from the cache, 0 parsed and saved, -1 parsed, cache not
+ * writable.  Return codes of mmio_allinone.  The CLI's `--cache[=prefix]` and bench.py's `--cache DIR` go through this. */
+int mmio_allinone_cached(int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric, MAT_PTR_TYPE **csrRowPtr,
+                         int **csrColIdx, MAT_VAL_TYPE **csrVal, char *filename, const char *cache_path,
+                         int *from_cache);
+/* Writes a general coordinate Matrix Market file in CSR order (the reference's counterpart: mm_write_mtx_crd,
+ * src/mmio.h:605-645), formatted by all host threads; csrVal == NULL writes a pattern file.  0, -1 cannot open, -3 short
+ * write. */
+int tilespmv_mtx_write(const char *path, int m, int n, MAT_PTR_TYPE nnz, const MAT_PTR_TYPE *csrRowPtr,
+                       const int *csrColIdx, const MAT_VAL_TYPE *csrVal);
+
 /* ------------------------------------------------------------------------------------------
  * GPU hot path.
  * ---------------------------------------------------------------------------------------- */
@@ -250,9 +273,11 @@ typedef struct {
     int strip_even;     /* strips end on multiples of this many units                                        TILESPMV_STRIP_EVEN */
     int wg_strips;      /* workgroup entry mode: 16 (256-thread workgroups) or 32 (512 threads) strips per workgroup  TILESPMV_WG_STRIPS */
     int x_window;       /* stencil-like shards: 1 = workgroups own bricks of the grid and stage their x window in LDS, 0 = off   TILESPMV_X_WINDOW */
+    int x_stride1;      /* ... tile-rows per grid line (0 / unset: detected from the shard)                  TILESPMV_X_STRIDE1 */
+    int x_stride2;      /* ... tile-rows per grid plane (0 / unset: detected; none for 2-D problems)         TILESPMV_X_STRIDE2 */
     int mv_native;      /* tilespmv_plan_spmm on entry-dominated plans: 1 multi-vector kernel, 0 one vector at a time           TILESPMV_MV_NATIVE */
     int mv_xcd_chunk;   /* XCD window of the multi-vector kernel                                             TILESPMV_MV_XCD_CHUNK */
-    int reserved[8];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
+    int reserved[6];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
 
@@ -291,6 +316,12 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
                        void *stream);
 double tilespmv_plan_time_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y,
                                int nvec, void *stream, int warmup, int reps);
+/* Plans without a native multi-vector kernel (and entry-dominated plans below nvec 8) run one right-hand side at a time
+ * on transposed copies of X and Y that live with the plan.  tilespmv_plan_reserve_spmm allocates them for up to `nvec`
+ * right-hand sides (hipMalloc: synchronises) so that tilespmv_plan_spmm itself never allocates — call it before capturing
+ * tilespmv_plan_spmm into a hipGraph.  Without it the first such tilespmv_plan_spmm call allocates (and would fail under
+ * stream capture).  Returns a hipError_t value. */
+int tilespmv_plan_reserve_spmm(tilespmv_plan *plan, int nvec);
 
 /* Test / diagnostic entry (new): builds the plan's device layout ON THE HOST ONLY — no HIP call, works without a GPU — with
  * exactly the code tilespmv_plan_create runs, hashes every stream it would upload (FNV-1a-64 over element counts and bytes,
@@ -319,7 +350,10 @@ enum {
     TILESPMV_INFO_ENTRY_MODE = 13,    /* COO entry lists run per strip (0), per wavefront (1), per workgroup (2) */
     TILESPMV_INFO_ENTRY_ORDERED = 14, /* 1: the order of the additions is fixed by the plan (bit-reproducible y) */
     TILESPMV_INFO_STRIP_COST = 15,    /* strip size target the plan was cut with */
-    TILESPMV_INFO_COUNT = 16
+    TILESPMV_INFO_WG_STRIPS = 16,     /* strips per workgroup of the unit kernel (16 or 32) */
+    TILESPMV_INFO_X_WINDOW_SLOTS = 17,    /* x-window plans: column blocks of the largest workgroup window (0 = no windows) */
+    TILESPMV_INFO_X_WINDOW_SEGMENTS = 18, /* ... and of all windows together: x segments (16 values each) loaded per SpMV */
+    TILESPMV_INFO_COUNT = 20
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
 
@@ -328,6 +362,12 @@ void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_I
  * error.  Used by bench.py for the live per-launch figure. */
 double tilespmv_plan_time(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y,
                           void *stream, int warmup, int reps);
+
+/* The reference's own timing protocol as a C loop (src/tilespmv_cuda.h:1112-1137): wall clock (gettimeofday) around one
+ * launch + stream synchronize, averaged over `reps`; milliseconds per SpMV, negative on error.  call_tilespmv_hip prints
+ * this number in the reference's "CUDA SpMV runtime" line; bench.py reports it as reference_style_timing. */
+double tilespmv_plan_time_reference_style(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y,
+                                          void *stream, int reps);
 
 /* Multi-GPU helper: nnz-balanced contiguous tile-row partition (new; the reference is
  * single-GPU, src/main.cu:74).  Writes nparts+1 tile-row boundaries. */

@@ -13,7 +13,7 @@
 // build never launches anything, so the driver supplies empty stand-ins for the linker (test scaffolding, not product code).
 namespace tilespmv {
 hipError_t launch_tiles_direct(const DevPlan &, bool, bool, bool, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_tiles_stream(const DevPlan &, const DevStream &, const DevDense &, bool, int, int, int, int, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_tiles_stream(const DevPlan &, const DevStream &, const DevDense &, bool, int, int, int, int, int, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_fallback(const DevPlan &, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_tiles_stream_mv(const DevPlan &, const DevStream &, const DevDense &, int, int, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_rows_to_columns(const val_t *, int, long long, long long, val_t *, hipStream_t) { return hipErrorNotSupported; }
@@ -46,6 +46,7 @@ int main()
             tilespmv_plan_options_init(&o);
             o.entry_mode = i % 3; o.strip_cost = 200 + 300 * i; o.entry_ordered = i & 1; o.wg_strips = (i & 2) ? 32 : 16;
             if (i == 3) o.coo_mode = TILESPMV_COO_FALLBACK;
+            if (i == 2) o.x_window = 1;
             if (tilespmv_plan_layout_digest(&T, rows, cols, (int)ci.size(), &o, out + i, nullptr) != 0) out[i] = 0;
         };
         for (int i = 0; i < 4; i++) build(i, serial);

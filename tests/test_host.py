@@ -10,7 +10,7 @@ from hypothesis import given, settings, strategies as st
 
 from cases import SMALL, MEDIUM, truncated_rows, values_for
 from oracle.oracle import CpuImpl
-from tilespmv_amd import api, generators as G
+from tilespmv_amd import _lib, api, generators as G
 from tilespmv_amd.tile_matrix import to_dict
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -284,6 +284,80 @@ def test_matrix_cache_rejects_damaged_files(tmp_path):
     tl, r2, c2, z2 = load_bytes(raw)                            # and the intact bytes still load
     assert (r2, c2, z2) == (rowA, n, nnz)
     api.Tile_destroy(tl)
+
+
+def test_csr_cache_parse_once(tmp_path):
+    """mmio_allinone_cached (new): first call parses the text and writes the cache, second call reads it (same
+    arrays, bit for bit, as the oracle's reader); a touched / rewritten .mtx makes the cache stale; damaged caches are refused."""
+    import ctypes as C
+    m, n, rp, ci = G.powerlaw(3000, seed=5)
+    vals = np.random.default_rng(1).standard_normal(len(ci))
+    mtx = str(tmp_path / "a.mtx"); cache = str(tmp_path / "a.csr_f64")
+    api.mtx_write(mtx, m, n, rp, ci, vals)
+    want = CpuImpl("oracle", np.float64).mmio(mtx)
+    first = api.mmio_allinone(mtx, cache=cache)
+    assert first["rc"] == 0 and first["from_cache"] == 0 and os.path.exists(cache)
+    second = api.mmio_allinone(mtx, cache=cache)
+    assert second["from_cache"] == 1
+    for r in (first, second):
+        assert (r["m"], r["n"], r["nnz"], r["sym"]) == (want["m"], want["n"], want["nnz"], want["sym"])
+        for k in ("rowptr", "colidx", "val"):
+            assert np.array_equal(r[k], want[k]), k
+    # fp32 library refuses the fp64 cache (and re-parses into its own)
+    r32 = api.mmio_allinone(mtx, np.float32, cache=cache)
+    assert r32["rc"] == 0 and r32["from_cache"] == 0 and r32["val"].dtype == np.float32
+    assert api.mmio_allinone(mtx, cache=cache)["from_cache"] == 0      # ... which replaced it: stale for fp64 again, rewritten
+    assert api.mmio_allinone(mtx, cache=cache)["from_cache"] == 1
+    # the text changes -> stale -> parsed again
+    vals2 = vals.copy(); vals2[0] = 42.0
+    os.utime(mtx, ns=(1, 1))
+    api.mtx_write(mtx, m, n, rp, ci, vals2)
+    third = api.mmio_allinone(mtx, cache=cache)
+    assert third["from_cache"] == 0 and third["val"][0] == 42.0
+    assert api.mmio_allinone(mtx, cache=cache)["from_cache"] == 1
+    # damaged cache: flipped payload byte, truncated, junk
+    lib = _lib.load(np.float64)
+    blob = bytearray(open(cache, "rb").read())
+
+    def load(path, src=None):
+        mm, nn, zz, ss = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        a, b, c = _lib._I(), _lib._I(), C.POINTER(C.c_double)()
+        rc = lib.tilespmv_csr_load(path.encode(), C.byref(mm), C.byref(nn), C.byref(zz), C.byref(ss), C.byref(a), C.byref(b), C.byref(c), src.encode() if src else None)
+        if rc == 0:
+            for q in (a, b, c):
+                lib._free(C.cast(q, C.c_void_p))
+        return rc
+    assert load(cache) == 0 and load(cache, mtx) == 0
+    bad = str(tmp_path / "bad.csr")
+    flipped = bytearray(blob); flipped[len(flipped) // 2] ^= 0x40
+    open(bad, "wb").write(flipped); assert load(bad) == -6
+    open(bad, "wb").write(blob[:len(blob) - 9]); assert load(bad) == -6
+    open(bad, "wb").write(b"not a cache at all"); assert load(bad) == -2
+    assert load(str(tmp_path / "missing.csr")) == -1
+    os.utime(mtx, ns=(5, 5)); assert load(cache, mtx) == -7           # stale: source mtime changed
+    # an unwritable cache path does not break the load
+    r = api.mmio_allinone(mtx, cache=str(tmp_path / "no_such_dir" / "x.csr"))
+    assert r["rc"] == 0 and r["from_cache"] == -1
+
+
+def test_mtx_writer_round_trip(tmp_path):
+    """tilespmv_mtx_write: threaded writer; integers as integers, everything else %.17g (exact); pattern files."""
+    rng = np.random.default_rng(9)
+    m, n, rp, ci = G.random_uniform(70000, 300, 0.002, 4)    # more than one block of 65,536 rows
+    vals = rng.standard_normal(len(ci)) * 10.0 ** rng.integers(-30, 30, len(ci))
+    vals[::3] = rng.integers(-5000, 5000, len(vals[::3]))
+    p = str(tmp_path / "w.mtx")
+    api.mtx_write(p, m, n, rp, ci, vals)
+    r = api.mmio_allinone(p)
+    assert r["rc"] == 0 and (r["m"], r["n"], r["nnz"]) == (m, n, len(ci))
+    assert np.array_equal(r["rowptr"], rp) and np.array_equal(r["colidx"], ci) and np.array_equal(r["val"], vals)
+    a = CpuImpl("oracle", np.float64).mmio(p)
+    assert np.array_equal(a["val"], vals) and np.array_equal(a["colidx"], ci)
+    api.mtx_write(p, m, n, rp, ci, None)
+    r = api.mmio_allinone(p)
+    assert r["nnz"] == len(ci) and np.all(r["val"] == 1.0) and np.array_equal(r["colidx"], ci)
+    G.write_mtx(p, m, n, rp, ci, vals)                        # the generators' helper goes through the same writer
+    assert np.array_equal(api.mmio_allinone(p)["val"], vals)
 
 
 def test_partition_tilerows_balanced():

@@ -17,20 +17,21 @@ _U = C.POINTER(C.c_uint)
 _CACHE = {}
 
 INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel",
-              "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us", "entry_mode", "entry_ordered", "strip_cost"]
+              "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us", "entry_mode", "entry_ordered", "strip_cost",
+              "wg_strips", "x_window_slots", "x_window_segments", "reserved19"]
 
 
 KNOB_DEFAULT = -1
 # tuning knobs of tilespmv_plan_options (include/tilespmv.h), in struct order after `autotune`
 KNOB_NAMES = ["entry_mode", "entry_ordered", "strip_cost", "split_above", "split_cap", "xcd_remap", "xcd_chunk", "csr_split", "fix_inline",
-              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "mv_native", "mv_xcd_chunk"]
+              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "x_stride1", "x_stride2", "mv_native", "mv_xcd_chunk"]
 
 
 class PlanOptions(C.Structure):
     """Mirror of the versioned tilespmv_plan_options: `size` first, unset knobs = KNOB_DEFAULT."""
     _fields_ = ([("size", C.c_uint), ("coo_mode", C.c_int), ("dense_mode", C.c_int), ("kernel", C.c_int),
                  ("tilerow_begin", C.c_int), ("tilerow_end", C.c_int), ("autotune", C.c_int)] +
-                [(k, C.c_int) for k in KNOB_NAMES] + [("reserved", C.c_int * 8)])
+                [(k, C.c_int) for k in KNOB_NAMES] + [("reserved", C.c_int * 6)])
 
     def __init__(self, coo_mode=0, dense_mode=0, kernel=0, tilerow_begin=0, tilerow_end=0, autotune=False, **knobs):
         super().__init__()
@@ -39,7 +40,7 @@ class PlanOptions(C.Structure):
         self.tilerow_begin, self.tilerow_end, self.autotune = tilerow_begin, tilerow_end, 1 if autotune else 0
         for k in KNOB_NAMES:
             setattr(self, k, KNOB_DEFAULT)
-        for i in range(8):
+        for i in range(6):
             self.reserved[i] = KNOB_DEFAULT
         for k, v in knobs.items():
             if k not in KNOB_NAMES:
@@ -114,12 +115,24 @@ def load(dtype=np.float64):
     lib.tilespmv_plan_info.restype = None
     lib.tilespmv_plan_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.tilespmv_plan_time.restype = C.c_double
+    lib.tilespmv_plan_time_reference_style.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.tilespmv_plan_time_reference_style.restype = C.c_double
+    lib.tilespmv_plan_reserve_spmm.argtypes = [C.c_void_p, C.c_int]
+    lib.tilespmv_plan_reserve_spmm.restype = C.c_int
     lib.tilespmv_partition_tilerows.argtypes = [TP, C.c_int, _I]
     lib.tilespmv_partition_tilerows.restype = None
     lib.tilespmv_matrix_save.argtypes = [TP, C.c_int, C.c_int, C.c_int, C.c_char_p]
     lib.tilespmv_matrix_save.restype = C.c_int
     lib.tilespmv_matrix_load.argtypes = [TP, _I, _I, _I, C.c_char_p]
     lib.tilespmv_matrix_load.restype = C.c_int
+    lib.tilespmv_csr_save.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _I, _I, VP, C.c_char_p]
+    lib.tilespmv_csr_save.restype = C.c_int
+    lib.tilespmv_csr_load.argtypes = [C.c_char_p, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(VP), C.c_char_p]
+    lib.tilespmv_csr_load.restype = C.c_int
+    lib.mmio_allinone_cached.argtypes = [_I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(VP), C.c_char_p, C.c_char_p, _I]
+    lib.mmio_allinone_cached.restype = C.c_int
+    lib.tilespmv_mtx_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, _I, _I, VP]
+    lib.tilespmv_mtx_write.restype = C.c_int
     lib.tilespmv_device_count.restype = C.c_int
     lib.tilespmv_version.restype = C.c_char_p
     libc = C.CDLL(None)
@@ -136,4 +149,6 @@ DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_c
                     "tilespmv_plan_create", "tilespmv_plan_destroy", "tilespmv_plan_spmv", "tilespmv_plan_info",
                     "tilespmv_plan_time", "tilespmv_partition_tilerows", "tilespmv_sizeof_value", "tilespmv_version",
                     "tilespmv_device_count", "tilespmv_matrix_save", "tilespmv_matrix_load", "tilespmv_plan_spmv_n",
-                    "call_tilespmv_hip_multi", "tilespmv_plan_spmm", "tilespmv_plan_time_spmm", "tilespmv_plan_options_init", "tilespmv_plan_layout_digest"]
+                    "call_tilespmv_hip_multi", "tilespmv_plan_spmm", "tilespmv_plan_time_spmm", "tilespmv_plan_options_init", "tilespmv_plan_layout_digest",
+                    "tilespmv_csr_save", "tilespmv_csr_load", "mmio_allinone_cached", "tilespmv_mtx_write",
+                    "tilespmv_plan_time_reference_style", "tilespmv_plan_reserve_spmm"]

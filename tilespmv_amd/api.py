@@ -73,17 +73,38 @@ def tilespmv_cpu(tm, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, x, y_gol
             "errcount": int(np.count_nonzero(y[:rowA] != yg[:rowA]))}
 
 
-def mmio_allinone(filename, dtype=np.float64):
+def mmio_allinone(filename, dtype=np.float64, cache=None):
+    """``cache``: path of the binary CSR cache kept beside the text (``mmio_allinone_cached``): read when it is fresh for
+    ``filename`` (size and mtime), otherwise the text is parsed and the cache (re)written.  The result then carries
+    ``from_cache`` (1 read, 0 parsed and saved, -1 parsed, cache not writable)."""
     lib = _lib.load(dtype)
     VP = C.POINTER(lib._vt)
-    m, n, nnz, sym = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    m, n, nnz, sym, hit = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int(0)
     rp, ci, cv = _I(), _I(), VP()
-    rc = lib.mmio_allinone(C.byref(m), C.byref(n), C.byref(nnz), C.byref(sym), C.byref(rp), C.byref(ci), C.byref(cv), filename.encode())
+    if cache is None:
+        rc = lib.mmio_allinone(C.byref(m), C.byref(n), C.byref(nnz), C.byref(sym), C.byref(rp), C.byref(ci), C.byref(cv), filename.encode())
+    else:
+        rc = lib.mmio_allinone_cached(C.byref(m), C.byref(n), C.byref(nnz), C.byref(sym), C.byref(rp), C.byref(ci), C.byref(cv), filename.encode(),
+                                      cache.encode(), C.byref(hit))
     if rc != 0:
         return {"rc": rc}
-    return {"rc": 0, "m": m.value, "n": n.value, "nnz": nnz.value, "sym": sym.value,
-            "rowptr": _take(lib, rp, m.value + 1, np.int32), "colidx": _take(lib, ci, nnz.value, np.int32),
-            "val": _take(lib, cv, nnz.value, lib._dtype)}
+    out = {"rc": 0, "m": m.value, "n": n.value, "nnz": nnz.value, "sym": sym.value,
+           "rowptr": _take(lib, rp, m.value + 1, np.int32), "colidx": _take(lib, ci, nnz.value, np.int32),
+           "val": _take(lib, cv, nnz.value, lib._dtype)}
+    if cache is not None:
+        out["from_cache"] = hit.value
+    return out
+
+
+def mtx_write(path, rows, cols, rowptr, colidx, vals=None, dtype=np.float64):
+    """General coordinate Matrix Market file in CSR order, written by the library's threaded writer (GBs in seconds);
+    ``vals=None`` writes a pattern file."""
+    lib = _lib.load(dtype)
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32); ci = np.ascontiguousarray(colidx, dtype=np.int32)
+    v = None if vals is None else np.ascontiguousarray(vals, dtype=lib._dtype)
+    rc = lib.tilespmv_mtx_write(path.encode(), rows, cols, len(ci), _p(rp, C.c_int), _p(ci, C.c_int), None if v is None else _p(v, lib._vt))
+    if rc != 0:
+        raise OSError("tilespmv_mtx_write(%s) failed: %d" % (path, rc))
 
 
 Y_SHARDED, Y_ALLGATHER, Y_ALLREDUCE = 0, 1, 2
@@ -142,7 +163,7 @@ def plan_layout_digest(tm, rowA, colA, nnzA, coo_mode=COO_AUTO, dense_mode=DENSE
     """Host-only build of the plan layout (no GPU needed): returns (FNV-1a-64 digest of every stream, plan facts)."""
     opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, False, **knobs)
     d = C.c_ulonglong(0)
-    out = (C.c_longlong * 16)()
+    out = (C.c_longlong * len(_lib.INFO_NAMES))()
     rc = tm._lib.tilespmv_plan_layout_digest(C.byref(tm), rowA, colA, nnzA, C.byref(opts), C.byref(d), out)
     if rc != 0:
         raise RuntimeError("tilespmv_plan_layout_digest failed (%d)" % rc)
@@ -194,8 +215,20 @@ class Plan:
             raise RuntimeError("tilespmv_plan_time failed")
         return ms
 
+    def time_reference_style(self, d_x, d_y, stream=0, reps=100):
+        """Mean ms per SpMV by the reference's protocol: wall clock around one launch + synchronize (a C loop)."""
+        ms = self.lib.tilespmv_plan_time_reference_style(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream), reps)
+        if ms < 0:
+            raise RuntimeError("tilespmv_plan_time_reference_style failed")
+        return ms
+
+    def reserve_spmm(self, nvec):
+        rc = self.lib.tilespmv_plan_reserve_spmm(self.h, nvec)
+        if rc != 0:
+            raise RuntimeError("tilespmv_plan_reserve_spmm: HIP error %d" % rc)
+
     def info(self):
-        out = (C.c_longlong * 16)()
+        out = (C.c_longlong * len(_lib.INFO_NAMES))()
         self.lib.tilespmv_plan_info(self.h, out)
         return {k: int(out[i]) for i, k in enumerate(_lib.INFO_NAMES)}
 

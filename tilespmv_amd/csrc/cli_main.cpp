@@ -8,6 +8,10 @@
 // Extension that leaves `-d <int>` untouched: `-d 0,1,2,3` shards the matrix by
 // tile-rows over the listed devices (call_tilespmv_hip_multi); an optional 4th argument
 // `--combine=none|allgather|allreduce` (default allgather) says what happens to y afterwards.
+// `--cache[=prefix]` (4th or 5th argument; default prefix = the .mtx path): parse once — the parsed CSR is kept as
+// <prefix>.csr_f64|f32 and the created Tile_matrix as <prefix>.tile_f64|f32; a later run whose .mtx is unchanged (size and
+// mtime) reads those instead of tokenising the text and re-tiling (the reference re-parses every time,
+// src/mmio_highlevel.h:648-682).  The stdout lines of the reference stay, in order; one "  cache: ..." line is added after each of the two steps.
 #include <hip/hip_runtime.h>
 #include <sys/time.h>
 
@@ -16,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <string>
 
 #include "../../include/tilespmv.h"
 
@@ -38,11 +43,15 @@ int main(int argc, char **argv)
         }
     if (ndev > 0) device_id = devices[0];
     int combine = TILESPMV_Y_ALLGATHER;
-    if (argc > 4) {
-        if (strcmp(argv[4], "--combine=none") == 0) combine = TILESPMV_Y_SHARDED;
-        else if (strcmp(argv[4], "--combine=allgather") == 0) combine = TILESPMV_Y_ALLGATHER;
-        else if (strcmp(argv[4], "--combine=allreduce") == 0) combine = TILESPMV_Y_ALLREDUCE;
-        else { fprintf(stderr, "unknown option %s (expected --combine=none|allgather|allreduce)\n", argv[4]); return 1; }
+    bool use_cache = false;
+    std::string cache_prefix;
+    for (int a = 4; a < argc; a++) {
+        if (strcmp(argv[a], "--combine=none") == 0) combine = TILESPMV_Y_SHARDED;
+        else if (strcmp(argv[a], "--combine=allgather") == 0) combine = TILESPMV_Y_ALLGATHER;
+        else if (strcmp(argv[a], "--combine=allreduce") == 0) combine = TILESPMV_Y_ALLREDUCE;
+        else if (strcmp(argv[a], "--cache") == 0) use_cache = true;
+        else if (strncmp(argv[a], "--cache=", 8) == 0) { use_cache = true; cache_prefix = argv[a] + 8; }
+        else { fprintf(stderr, "unknown option %s (expected --combine=none|allgather|allreduce or --cache[=prefix])\n", argv[a]); return 1; }
     }
     printf("device_id = %i\n", device_id);
     if (argc < 4) { fprintf(stderr, "usage: %s -d <device_id> <matrix.mtx>\n", argv[0]); return 1; }
@@ -54,11 +63,17 @@ int main(int argc, char **argv)
     MAT_PTR_TYPE *csrRowPtrA = NULL; int *csrColIdxA = NULL; MAT_VAL_TYPE *csrValA = NULL;
     timeval t1, t2;
     gettimeofday(&t1, NULL);
-    int rc = mmio_allinone(&rowA, &colA, &nnzA, &isSymmetricA, &csrRowPtrA, &csrColIdxA, &csrValA, filename);
+    const char *suffix = sizeof(MAT_VAL_TYPE) == 8 ? "f64" : "f32";
+    if (use_cache && cache_prefix.empty()) cache_prefix = filename;
+    const std::string csr_cache = cache_prefix + ".csr_" + suffix, tile_cache = cache_prefix + ".tile_" + suffix;
+    int from_cache = 0;
+    int rc = use_cache ? mmio_allinone_cached(&rowA, &colA, &nnzA, &isSymmetricA, &csrRowPtrA, &csrColIdxA, &csrValA, filename, csr_cache.c_str(), &from_cache)
+                       : mmio_allinone(&rowA, &colA, &nnzA, &isSymmetricA, &csrRowPtrA, &csrColIdxA, &csrValA, filename);
     gettimeofday(&t2, NULL);
     if (rc != 0) { fprintf(stderr, "cannot read %s (mmio_allinone returned %d)\n", filename, rc); return 1; }
     double time_loadmat = (t2.tv_sec - t1.tv_sec) * 1000.0 + (t2.tv_usec - t1.tv_usec) / 1000.0;
     printf("  input matrix A: ( %i, %i ) nnz = %i\n  loadfile time    = %4.5f sec\n", rowA, colA, nnzA, time_loadmat / 1000.0);
+    if (use_cache) printf("  cache: CSR %s %s\n", from_cache == 1 ? "read from" : from_cache == 0 ? "parsed from the text and saved to" : "parsed from the text; could not write", csr_cache.c_str());
 
     for (int i = 0; i < nnzA; i++) csrValA[i] = i % 10;
     rowA = (rowA / TILESPMV_BLOCK_SIZE) * TILESPMV_BLOCK_SIZE;
@@ -70,7 +85,29 @@ int main(int argc, char **argv)
     printf("Device [ %i ] %s @ %4.2f MHz\n", device_id, prop.name[0] ? prop.name : prop.gcnArchName, prop.clockRate * 1e-3f);  // marketing name can be empty in containers
 
     Tile_matrix *matrixA = (Tile_matrix *)malloc(sizeof(Tile_matrix));
-    Tile_create(matrixA, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA);
+    bool tiles_from_cache = false;
+    if (use_cache && from_cache == 1) {   // a tile cache is only trusted next to a fresh CSR cache of the same file, and for this very shape
+        int r2 = 0, c2 = 0; MAT_PTR_TYPE z2 = 0;
+        gettimeofday(&t1, NULL);
+        if (tilespmv_matrix_load(matrixA, &r2, &c2, &z2, tile_cache.c_str()) == 0) {
+            if (r2 == rowA && c2 == colA && z2 == nnzA) tiles_from_cache = true;
+            else Tile_destroy(matrixA);
+        }
+        gettimeofday(&t2, NULL);
+    }
+    if (tiles_from_cache) {
+        printf("\n  The number of tile = %i\n", matrixA->tilenum);   // the line Tile_create prints (reference src/csr2tile.h:661)
+        printf("  cache: Tile_matrix read from %s in %4.5f sec\n", tile_cache.c_str(), ((t2.tv_sec - t1.tv_sec) * 1000.0 + (t2.tv_usec - t1.tv_usec) / 1000.0) / 1000.0);
+    } else {
+        gettimeofday(&t1, NULL);
+        Tile_create(matrixA, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA);
+        gettimeofday(&t2, NULL);
+        if (use_cache) {
+            const int src = tilespmv_matrix_save(matrixA, rowA, colA, nnzA, tile_cache.c_str());
+            printf("  cache: Tile_matrix created in %4.5f sec and %s %s\n", ((t2.tv_sec - t1.tv_sec) * 1000.0 + (t2.tv_usec - t1.tv_usec) / 1000.0) / 1000.0,
+                   src == 0 ? "saved to" : "could not be written to", tile_cache.c_str());
+        }
+    }
 
     MAT_VAL_TYPE *x = (MAT_VAL_TYPE *)malloc(sizeof(MAT_VAL_TYPE) * colA);
     for (int i = 0; i < colA; i++) x[i] = i % 10;

@@ -359,6 +359,9 @@ __device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t
 // 32 strips, merged and ordered by column at plan time, walked by all NT lanes.  Neighbouring lanes of a gather then read
 // the same or adjacent x lines: on power-law matrices the number of distinct x lines per batch drops from 0.48 per entry (one
 // strip at a time) to 0.15 (64 tile-rows at a time), and the CU's L1 -> L2 request rate is what bounds those matrices.
+#ifndef WG_TRIP_PIPE
+#define WG_TRIP_PIPE 0   // 1: the next trip's records are requested behind the current trip's gathers.  Measured (profiles/r03_entry_ablations.txt): power-law 8 M 0.1039 -> 0.1065 ms, KKT fp64 0.427 -> 0.435, webbase 13.1 -> 12.9 us at 4 x 256 per trip; 6 x 256 spills.  Off.
+#endif
 template <int CT, int NT>
 __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, const unsigned *__restrict__ base, int chunk0, int db, bool ordered,
                                                const val_t *__restrict__ x, val_t *sy, int tid, int gb, int ge)
@@ -371,28 +374,36 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
     //   1 no LDS adds   2 contiguous instead of gathered x   5 one extra 2-byte stream load per entry
     val_t abl_acc = 0;
 #endif
-    for (int e0 = gb; e0 < ge; e0 += NT * CT) {
-        ERec rr[CT]; unsigned cb[CT]; val_t xx[CT];
+    ERec rr[CT]; unsigned cb[CT];
+    auto load_trip = [&](int e0, ERec (&r)[CT], unsigned (&c)[CT]) {   // unconditional, clamped: exact vmcnt
 #pragma unroll
         for (int q = 0; q < CT; q++) {
-            rr[q] = rec[min(e0 + NT * q + tid, ge - 1)];
-            cb[q] = base[__builtin_amdgcn_readfirstlane(min(chunk0 + ((e0 - gb) >> 6) + (NT / 64) * q + wave, clast))];   // a wavefront's 64 records are one chunk
+            r[q] = rec[min(e0 + NT * q + tid, ge - 1)];
+            c[q] = base[__builtin_amdgcn_readfirstlane(min(chunk0 + ((e0 - gb) >> 6) + (NT / 64) * q + wave, clast))];   // a wavefront's 64 records are one chunk
 #if defined(TILESPMV_ABL) && TILESPMV_ABL == 5
-            rr[q].w += reinterpret_cast<const unsigned short *>(base)[min(e0 + NT * q + tid, ge - 1)] & 1u;
+            r[q].w += reinterpret_cast<const unsigned short *>(base)[min(e0 + NT * q + tid, ge - 1)] & 1u;
 #endif
         }
+    };
+    if (gb < ge) load_trip(gb, rr, cb);
+    for (int e0 = gb; e0 < ge; e0 += NT * CT) {
+        val_t xx[CT];
+        if (!WG_TRIP_PIPE && e0 > gb) load_trip(e0, rr, cb);
 #pragma unroll
         for (int q = 0; q < CT; q++) xx[q] = x[(size_t)(cb[q] + (rr[q].w >> db))];
 #if defined(TILESPMV_ABL) && TILESPMV_ABL == 2
 #pragma unroll
         for (int q = 0; q < CT; q++) xx[q] = x[(e0 + NT * q + tid) & 0xFFFFF];
 #endif
+        // the next trip's records go in flight behind this trip's gathers (loads return in issue order: the gathers are waited
+        // for with the prefetch still outstanding); the last trip re-requests its own (clamped) records, which costs nothing
+        ERec rn[CT]; unsigned cn[CT];
+        if (WG_TRIP_PIPE) load_trip(min(e0 + NT * CT, gb + (ge - 1 - gb) / (NT * CT) * (NT * CT)), rn, cn);
 #if defined(TILESPMV_ABL) && TILESPMV_ABL == 1
 #pragma unroll
         for (int q = 0; q < CT; q++) abl_acc += erec_val(rr[q]) * xx[q] + (val_t)(rr[q].w & dmask);
         if (e0 + NT * CT >= ge) atomicAdd(&sy[tid], abl_acc);
-        continue;
-#endif
+#else
         if (ordered) {
             // the wavefronts add in turn: the order of the additions into one y element is then fixed by the plan (entry
             // order inside a wavefront instruction, instruction order inside a wavefront, wavefront 0..NT/64-1 inside a trip), not
@@ -409,6 +420,11 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
 #pragma unroll
             for (int q = 0; q < CT; q++)
                 if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], erec_val(rr[q]) * xx[q]);
+        }
+#endif
+        if (WG_TRIP_PIPE) {
+#pragma unroll
+            for (int q = 0; q < CT; q++) { rr[q] = rn[q]; cb[q] = cn[q]; }
         }
     }
 }
@@ -463,16 +479,23 @@ hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream
 // 1 per wavefront (the four strips' lists concatenated), 2 per workgroup (merged + column-ordered list, see above).
 // GPB: strips (16-lane groups) per workgroup — 16 (256 threads) or, for the workgroup entry mode on large entry-heavy shards, 32
 // (512 threads: twice as many tile-rows share one column-ordered list, so fewer distinct x lines per entry; same waves per SIMD).
-template <int UB, int XCD_REMAP, int ECOO, int GPB>
+// XWIN: x-window plans (hip_plan.h) — the workgroup's strips form a brick of the grid, the x segments (column blocks) their
+// units touch are loaded ONCE per workgroup into LDS (dynamic shared memory, sized by the plan) and the units read x from there;
+// the descriptor's low 24 bits then hold the window slot.  Strips of such plans have at most XWIN_STRIP_ROWS tile-rows.
+extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN>
 __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
     static_assert(GPB == 16 || (GPB == 32 && ECOO == 2), "512-thread workgroups exist for the workgroup entry mode only");
+    static_assert(!XWIN || (GPB == 16 && ECOO != 1), "x windows: 256-thread workgroups, per-strip or per-workgroup entries");
     constexpr int GROUPS_PER_BLOCK = GPB;
+    constexpr int SROWS = XWIN ? XWIN_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
     constexpr bool NT = false;  // nontemporal value loads: measured neutral
-    __shared__ val_t s_y[GROUPS_PER_BLOCK][STRIP_MAX_ROWS][16];
+    __shared__ val_t s_y[GROUPS_PER_BLOCK][SROWS][16];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
+    val_t *s_xw = reinterpret_cast<val_t *>(s_dyn);   // [window slot][16]
 #ifdef TILESPMV_ABL_LDS_PAD   // diagnostic builds only: extra LDS per workgroup, to measure what fewer resident workgroups cost
     __shared__ unsigned s_pad[TILESPMV_ABL_LDS_PAD / 4];
     if (rowA < 0) s_pad[threadIdx.x] = 1u, y[0] = (val_t)s_pad[(threadIdx.x * 7) % (TILESPMV_ABL_LDS_PAD / 4)];
@@ -495,7 +518,7 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAV
     const bool have = task_id < S.ntasks;
     constexpr bool WCOO = ECOO == 1;
     if (ECOO == 1) { if ((long long)bid * GROUPS_PER_BLOCK + (g & ~3) >= S.ntasks) return; }  // whole wavefronts leave together (wave-cooperative entry phase)
-    else if (ECOO == 0 && !have) return;                                                      // ECOO == 2: every wavefront reaches the two barriers
+    else if (ECOO == 0 && !XWIN && !have) return;                                             // ECOO == 2 / XWIN: every wavefront reaches the barriers
     int4 t0 = make_int4(0, 0, 0, 0), t1 = make_int4(0, -1, 0, 0);
     if (have) {
         t0 = reinterpret_cast<const int4 *>(S.task)[task_id * 2];
@@ -516,6 +539,16 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAV
     const bool have_units = unit_begin < unit_end;
     const long long xlast = (long long)colA - 1;  // row units of a partial last column block: zero payload, clamped x index
     const int ncoo = coo_end - coo_begin;
+    // ---- x window of this workgroup: wcount segments of 16 x values, lane group g loads segments g, g + 16, ...
+    int wcount = 0;
+    if constexpr (XWIN) {
+        const int2 ww = S.wg_win[bid];
+        wcount = ww.y;
+        for (int i = g; i < wcount; i += GROUPS_PER_BLOCK) {
+            const long long xi = (long long)S.win_cb[ww.x + i] * 16 + r;
+            s_xw[i * 16 + r] = x[min(xi, xlast)];
+        }
+    }
     uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
     val_t v[UB];
     auto unit_prologue = [&]() {  // descriptor chunks 0 and 1, first value batch: in flight across the entry phase
@@ -542,7 +575,8 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAV
         for (int k = 0; k < UB; k++) {
             const unsigned fl = d[k].x >> 24;
             const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
-            xv[k] = x[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast)];
+            if (XWIN && wcount > 0) xv[k] = s_xw[(d[k].x & 0xFFFFFFu) * 16 + nib];   // workgroup-uniform: a windowed workgroup's descriptors hold slots
+            else xv[k] = x[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast)];
         }
     };
 
@@ -668,6 +702,7 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAV
             acc = 0;
         }
     };
+    if constexpr (XWIN) __syncthreads();   // the workgroup's x window is complete (every wavefront of an x-window kernel gets here)
     if (have_units) {  // phase 2: units, value loads software-pipelined by one batch
         if (ECOO != 1) {  // (entry mode 1 parked the first chunk and fetched the first batch before its entry phase)
             s_d[g][r] = dcur;
@@ -917,8 +952,8 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
     val_t v[UB];
     if (have_units) {
-        dcur = load_udesc(S.udesc, min(unit_begin + r, last));
-        dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
+        dcur = load_udesc(S.udesc_cb, min(unit_begin + r, last));
+        dnext = load_udesc(S.udesc_cb, min(unit_begin + DCHUNK + r, last));
         load_grp(unit_begin, v);
     }
     if (ncoo > 0) {
@@ -1021,7 +1056,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
                 s_d[g][r] = dnext;
                 wave_lds_fence();
                 chunk_end += DCHUNK;
-                dnext = load_udesc(S.udesc, min(chunk_end + r, last));
+                dnext = load_udesc(S.udesc_cb, min(chunk_end + r, last));
             }
             const int j0 = u - (chunk_end - DCHUNK);
             uint2 d[UB];
@@ -1204,12 +1239,14 @@ hipError_t launch_columns_to_rows(const val_t *YT, int nvec, long long row0, lon
     return hipGetLastError();
 }
 
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xcd_remap, int xcd_chunk,
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xwin_lds_bytes, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st)
 {
     if (S.ntasks > 0) {
-#define TSPMV_L2(X, W, B) hipLaunchKernelGGL((k_units<4, X, W, B>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
-#define TSPMV_L1(X) do { if (entry_mode == 2 && wg_strips == 32) TSPMV_L2(X, 2, 32); else if (entry_mode == 2) TSPMV_L2(X, 2, 16); else if (entry_mode == 1) TSPMV_L2(X, 1, 16); else TSPMV_L2(X, 0, 16); } while (0)
+#define TSPMV_L2(X, W, B, XW) hipLaunchKernelGGL((k_units<4, X, W, B, XW>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), XW ? (size_t)xwin_lds_bytes : 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L2(X, 2, 16, true); else if (xwin_lds_bytes > 0) TSPMV_L2(X, 0, 16, true); \
+        else if (entry_mode == 2 && wg_strips == 32) TSPMV_L2(X, 2, 32, false); else if (entry_mode == 2) TSPMV_L2(X, 2, 16, false); \
+        else if (entry_mode == 1) TSPMV_L2(X, 1, 16, false); else TSPMV_L2(X, 0, 16, false); } while (0)
         if (xcd_remap == 2) TSPMV_L1(2); else TSPMV_L1(0);
 #undef TSPMV_L1
 #undef TSPMV_L2

@@ -89,6 +89,8 @@ struct DevPlan {
 constexpr int FB_ROWS = 2048;             // fallback row block: rows (= 16 x 128: the entry lists' 4 + 7 destination bits) ...
 constexpr int FB_CAP = 6144;              // ... and nonzeros (4 trips of 6 x 256)
 constexpr int STRIP_MAX_ROWS = 8;         // tile-rows per strip (3 bits of row-in-strip)
+constexpr int XWIN_STRIP_ROWS = 4;        // ... in x-window plans (the LDS the y slabs give up goes to the window)
+constexpr int XWIN_MAX_SLOTS = 224;       // column blocks (16 x values each) a workgroup's window may hold: 28 KB fp64 / 14 KB fp32
 constexpr unsigned UNIT_EOR = 1u;         // unit flag bit 0: last unit of its tile-row -> write y
 constexpr int UNIT_ROW_SHIFT = 1;         // unit flag bits 1-3: tile-row inside the strip
 constexpr unsigned UNIT_ROWUNIT = 16u;    // unit flag bit 4: "row unit" = 16 values of ONE tile row (dense-row tiles);
@@ -125,6 +127,13 @@ struct DevStream {
     const ERec *grec;
     const unsigned *gbase;                // column base per chunk of ECHUNK records, chunks counted from the list's begin
     int dest_bits;                        // 9 (wavefront lists), 11 (16 strips per workgroup) or 12 (32 strips)
+    // x-window plans (stencil-like shards): the 16 strips of a workgroup are a brick of the grid — chosen at plan time
+    // from the dominant tile-row distances of the shard — and the column blocks their units touch are loaded once per workgroup
+    // into LDS.  Descriptors of a windowed workgroup carry the window slot in their low 24 bits; a workgroup whose units touch
+    // more than XWIN_MAX_SLOTS column blocks keeps column blocks and reads x from global memory (window count 0).
+    const int2 *wg_win;                   // per workgroup: [begin, count) in win_cb
+    const int *win_cb;                    // column block of every window slot
+    const UDesc *udesc_cb;                // descriptors with column blocks for the multi-vector kernel (== udesc when there is no window)
     // split tile-rows whose pieces all live in the unit kernel are summed in that kernel by the piece that
     // finishes last (fixed slot order): ifix[i] describes row i, ifix_count[i] counts finished pieces
     const FixRow *ifix;

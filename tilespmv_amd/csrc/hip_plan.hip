@@ -9,15 +9,17 @@
 #include <hip/hip_runtime.h>
 #include <sys/time.h>
 
+#include <climits>
 #include <cmath>
 #include <string>
+#include <unordered_map>
 
 #include "hip_plan.h"
 
 namespace tilespmv {
 
 hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulate, bool fixup, const val_t *x, val_t *y, hipStream_t st);
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xcd_remap, int xcd_chunk,
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xwin_lds_bytes, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, const val_t *X, val_t *Y,
@@ -61,6 +63,7 @@ struct Knobs {
     int strip_even;
     int wg_strips;       // -1 = chosen from the shard
     int x_window;        // -1 = default
+    int x_stride1, x_stride2;   // tile-rows per grid line / plane for the x windows; 0 = detected from the shard
     int mv_native;       // -1 = by nvec
     int mv_xcd_chunk;    // -1 = the plan's XCD chunk
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
@@ -97,6 +100,8 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.strip_even = pick(o.strip_even, "TILESPMV_STRIP_EVEN", 4);
     k.wg_strips = pick(o.wg_strips, "TILESPMV_WG_STRIPS", -1);
     k.x_window = pick(o.x_window, "TILESPMV_X_WINDOW", -1);
+    k.x_stride1 = pick(o.x_stride1, "TILESPMV_X_STRIDE1", 0);
+    k.x_stride2 = pick(o.x_stride2, "TILESPMV_X_STRIDE2", 0);
     k.mv_native = pick(o.mv_native, "TILESPMV_MV_NATIVE", -1);
     k.mv_xcd_chunk = pick(o.mv_xcd_chunk, "TILESPMV_MV_XCD_CHUNK", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
@@ -125,6 +130,7 @@ struct tilespmv_plan {
     int coo_mode = 0, dense_mode = 0, kernel = 0;
     int device = 0;
     int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
+    int xwin_lds_bytes = 0;             // x-window plans: dynamic LDS of the unit kernel (largest window of the plan); 0 = no windows
     bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
     unsigned long long digest = 1469598103934665603ull;
     template <class T>
@@ -353,6 +359,48 @@ inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, i
     return c;
 }
 
+
+// Dominant tile-row distances of a stencil-like shard: d = column block - tile-row over the tiles that become units.  s1 = the
+// smallest distance >= 2 that most tile-rows have (tile-rows per grid line), s2 = the middle of the next cluster of distances
+// (tile-rows per grid plane; 0 for 2-D problems).  0 / 0 when the shard has no such structure.
+inline void detect_strides(const Tile_matrix *T, int tr0, int tr1, bool csr_split, bool dense_mfma, int *s1, int *s2)
+{
+    *s1 = *s2 = 0;
+    const int ntr = tr1 - tr0;
+    if (ntr < 64) return;
+    const int step = std::max(1, ntr / 32768);
+    std::vector<long long> ds;
+    long long sampled = 0;
+    for (int bi = tr0; bi < tr1; bi += step) {
+        sampled++;
+        long long last = LLONG_MIN;
+        for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+            const int fmt = T->Format[t];
+            const bool units = fmt == TILESPMV_FMT_ELL || fmt == TILESPMV_FMT_HYB || fmt == TILESPMV_FMT_DNSCOL || fmt == TILESPMV_FMT_DNSROW ||
+                               (fmt == TILESPMV_FMT_DNS && !dense_mfma) || (fmt == TILESPMV_FMT_CSR && csr_split);
+            const long long d = (long long)T->tile_columnidx[t] - bi;
+            if (units && d >= 2 && d != last) { ds.push_back(d); last = d; }
+        }
+    }
+    std::sort(ds.begin(), ds.end());
+    std::vector<long long> dom;   // distances that at least a quarter of the sampled tile-rows have
+    for (size_t i = 0; i < ds.size();) {
+        size_t j = i;
+        while (j < ds.size() && ds[j] == ds[i]) j++;
+        if ((long long)(j - i) * 4 >= sampled) dom.push_back(ds[i]);
+        i = j;
+    }
+    if (dom.empty() || dom[0] > (1 << 20)) return;
+    *s1 = (int)dom[0];
+    size_t a = 1;
+    while (a < dom.size() && dom[a] <= dom[0] + 1) a++;
+    if (a >= dom.size()) return;
+    size_t b = a;
+    while (b + 1 < dom.size() && dom[b + 1] - dom[b] <= dom[0] + 1) b++;   // {s2 - s1, s2, s2 + s1} of a 27-point stencil
+    const long long mid = dom[(a + b) / 2];
+    if (mid % dom[0] == 0 && mid / dom[0] >= 2 && mid < (1ll << 30)) *s2 = (int)mid;
+}
+
 }  // namespace
 
 static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,
@@ -422,9 +470,10 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     const int entry_mode = wave_coo_env >= 0 ? std::min(2, wave_coo_env) : (!entry_heavy ? 0 : est_wgs < 768 ? 1 : 2);
     const bool wave_coo = entry_mode != 0;
     plan->entry_mode = entry_mode;
-    // strips per workgroup: 32 (512 threads) only with the workgroup entry mode — twice as many tile-rows share one column-ordered
-    // list (power-law 8 M rows: 0.204 -> 0.152 distinct 128-B x lines per entry), same 6 waves per SIMD
-    const int wg_strips = entry_mode == 2 ? (K.wg_strips == 32 ? 32 : K.wg_strips == 16 ? 16 : (est_wgs >= 4096 ? 32 : 16)) : 16;
+    // strips per workgroup: 32 (512 threads) only on request and only with the workgroup entry mode — twice as many tile-rows share
+    // one column-ordered list (power-law 8 M rows: 0.204 -> 0.152 distinct 128-B x lines per entry) at the same 6 waves per SIMD, but
+    // it measures slower everywhere (power-law 8 M 0.1038 -> 0.1072 ms, webbase-like 13.1 -> 13.9 us, KKT fp64 equal): default 16
+    const int wg_strips = (entry_mode == 2 && K.wg_strips == 32) ? 32 : 16;
     plan->wg_strips = wg_strips;
     // Workgroup mode: the four wavefronts add into shared slabs.  Taking turns (4 barriers per trip) fixes the order of the
     // additions -> bit-reproducible sums; free or a gain on large grids (fewer LDS conflicts: power-law 8 M rows 0.122 ->
@@ -432,6 +481,13 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     // TILESPMV_COO_ORDERED=1 asks for reproducible bits.  Modes 0 and 1 are always ordered (one wavefront per slab).
     const int ordered_env = K.entry_ordered;
     const bool coo_ordered = ordered_env >= 0 ? ordered_env != 0 : est_wgs >= 2048;
+    // ---- x windows (stencil-like shards): strips stay inside one grid line and have at most XWIN_STRIP_ROWS tile-rows; after the
+    // cut the strips are regrouped so that the 16 strips of a workgroup form a brick of the grid (below)
+    int xs1 = K.x_stride1 > 0 ? K.x_stride1 : 0, xs2 = K.x_stride2 > 0 ? K.x_stride2 : 0;
+    bool xwin = K.x_window > 0 && entry_mode != 1 && wg_strips == 16;
+    if (xwin && xs1 == 0) detect_strides(T, tr0, tr1, csr_split, dense_mfma, &xs1, &xs2);
+    if (xs1 < 2) xwin = false;
+    const int max_strip_rows = xwin ? XWIN_STRIP_ROWS : STRIP_MAX_ROWS;
     std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
     const int npartial0 = npartial;
     auto cut = [&](int target) {
@@ -510,7 +566,8 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
             int jend = i;
             {
                 long long cc = 0;
-                while (jend < ntr && jend - i < STRIP_MAX_ROWS && !must_split(jend)) {
+                while (jend < ntr && jend - i < max_strip_rows && !must_split(jend)) {
+                    if (xwin && jend > i && (tr0 + jend) % xs1 == 0) break;   // x-window plans: a strip stays inside one grid line
                     const long long nc = cc + rc_[jend].cost;
                     // entry-heavy shards round to the nearest strip size (rows cost 100-400 each there: "never above the target"
                     // would leave most strips half empty and double the number of wavefronts)
@@ -522,7 +579,7 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
                 auto pad = [&](int e) { return (int)((quantum - (pu[e] - pu[i]) % quantum) % quantum); };
                 if (strip_even && pad(jend) > 0) {
                     int best = jend;
-                    if (jend < ntr && jend - i < STRIP_MAX_ROWS && !must_split(jend) && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
+                    if (jend < ntr && jend - i < max_strip_rows && !(xwin && (tr0 + jend) % xs1 == 0) && !must_split(jend) && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
                     if (best == jend && jend - i >= 3 && pad(jend - 1) < pad(best)) best = jend - 1;
                     jend = best;
                 }
@@ -681,6 +738,96 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
 
     int rc = 0;
     DevStream &S = plan->st;
+    // ---- x windows: brick order of the strips, then one window of column blocks per workgroup
+    std::vector<uint4> h_udesc_cb;   // the descriptors with column blocks (multi-vector kernel), when windows put slots into h_udesc
+    std::vector<int2> h_wg_win;
+    std::vector<int> h_win_cb;
+    int xwin_slots_max = 0;
+    long long xwin_segments = 0, xwin_wgs = 0;
+    if (xwin && !tasks.empty()) {
+        const size_t nt = tasks.size();
+        // grid coordinates of every strip: position in its line (ordinal of the strip), line in its plane, plane
+        std::vector<int> sx(nt), ly(nt), lz(nt);
+        {
+            long long prev_line = -1; int ord = 0;
+            for (size_t i = 0; i < nt; i++) {
+                const long long line = tasks[i].row / xs1;
+                ord = line == prev_line ? ord + 1 : 0;
+                prev_line = line;
+                sx[i] = ord;
+                ly[i] = xs2 ? (int)(line % (xs2 / xs1)) : (int)line;
+                lz[i] = xs2 ? tasks[i].row / xs2 : 0;
+            }
+        }
+        auto blocks_of = [&](const STask &k, std::vector<int> &out) {
+            for (int u = k.unit_begin; u < k.unit_end; u++) out.push_back((int)(h_udesc[(size_t)u].x & 0xFFFFFFu));
+        };
+        struct Shape { int px, py, pz; };
+        const Shape shapes3[] = {{1, 4, 4}, {2, 2, 4}, {2, 4, 2}, {4, 2, 2}, {1, 2, 8}, {1, 8, 2}, {4, 4, 1}, {2, 8, 1}, {1, 16, 1}, {16, 1, 1}};
+        const Shape shapes2[] = {{4, 4, 1}, {2, 8, 1}, {8, 2, 1}, {1, 16, 1}, {16, 1, 1}};
+        const Shape *shapes = xs2 ? shapes3 : shapes2;
+        const int nshapes = xs2 ? 10 : 5;
+        std::vector<unsigned> order(nt), best_order;
+        double best_avg = 1e30;
+        Shape best_shape{16, 1, 1};
+        auto sort_for = [&](const Shape &sh) {
+            for (size_t i = 0; i < nt; i++) order[i] = (unsigned)i;
+            std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) {
+                const int ka[6] = {lz[a] / sh.pz, ly[a] / sh.py, sx[a] / sh.px, lz[a] % sh.pz, ly[a] % sh.py, sx[a] % sh.px};
+                const int kb[6] = {lz[b] / sh.pz, ly[b] / sh.py, sx[b] / sh.px, lz[b] % sh.pz, ly[b] % sh.py, sx[b] % sh.px};
+                for (int q = 0; q < 6; q++) if (ka[q] != kb[q]) return ka[q] < kb[q];
+                return a < b;
+            });
+        };
+        const size_t nwg = (nt + 15) / 16;
+        std::vector<int> tmp;
+        for (int si = 0; si < nshapes; si++) {   // the brick shape that needs the fewest window slots on a sample of workgroups
+            sort_for(shapes[si]);
+            long long slots = 0, wgs = 0;
+            for (size_t w = nwg / 128; w < nwg; w += std::max<size_t>(1, nwg / 64)) {
+                tmp.clear();
+                for (size_t t = 16 * w; t < std::min(nt, 16 * w + 16); t++) blocks_of(tasks[order[t]], tmp);
+                std::sort(tmp.begin(), tmp.end());
+                slots += (long long)(std::unique(tmp.begin(), tmp.end()) - tmp.begin()); wgs++;
+            }
+            const double avg = wgs ? (double)slots / (double)wgs : 1e30;
+            if (avg < best_avg * 0.98) { best_avg = avg; best_order = order; best_shape = shapes[si]; }
+        }
+        {
+            std::vector<STask> permuted(nt);
+            for (size_t i = 0; i < nt; i++) permuted[i] = tasks[best_order[i]];
+            tasks.swap(permuted);
+        }
+        h_udesc_cb = h_udesc;
+        h_wg_win.assign(nwg, make_int2(0, 0));
+        std::vector<std::vector<int>> wg_blocks(nwg);
+        parallel_chunks((int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
+            for (int64_t w = b; w < e; w++) {
+                std::vector<int> &bl = wg_blocks[(size_t)w];
+                for (size_t t = 16 * (size_t)w; t < std::min(nt, 16 * (size_t)w + 16); t++) blocks_of(tasks[t], bl);
+                std::sort(bl.begin(), bl.end());
+                bl.erase(std::unique(bl.begin(), bl.end()), bl.end());
+                if (bl.size() > (size_t)XWIN_MAX_SLOTS) { bl.clear(); continue; }   // this workgroup reads x from global memory
+                for (size_t t = 16 * (size_t)w; t < std::min(nt, 16 * (size_t)w + 16); t++)
+                    for (int u = tasks[t].unit_begin; u < tasks[t].unit_end; u++) {
+                        uint4 &d = h_udesc[(size_t)u];
+                        const unsigned slot = (unsigned)(std::lower_bound(bl.begin(), bl.end(), (int)(d.x & 0xFFFFFFu)) - bl.begin());
+                        d.x = (d.x & 0xFF000000u) | slot; d.z = d.x;
+                    }
+            }
+        });
+        for (size_t w = 0; w < nwg; w++) {
+            h_wg_win[w] = make_int2((int)h_win_cb.size(), (int)wg_blocks[w].size());
+            h_win_cb.insert(h_win_cb.end(), wg_blocks[w].begin(), wg_blocks[w].end());
+            xwin_slots_max = std::max(xwin_slots_max, (int)wg_blocks[w].size());
+            xwin_segments += (long long)wg_blocks[w].size(); xwin_wgs += !wg_blocks[w].empty();
+        }
+        if (xwin_slots_max == 0) { xwin = false; h_udesc_cb.clear(); }
+        else if (getenv("TILESPMV_PLAN_VERBOSE"))
+            fprintf(stderr, "tilespmv: x windows: strides %d / %d tile-rows, brick %d x %d x %d strips, %lld of %zu workgroups windowed, %.1f slots on average, %d at most\n",
+                    xs1, xs2, best_shape.px, best_shape.py, best_shape.pz, xwin_wgs, nwg, xwin_wgs ? (double)xwin_segments / (double)xwin_wgs : 0.0, xwin_slots_max);
+    } else xwin = false;
+    plan->xwin_lds_bytes = xwin ? xwin_slots_max * 16 * (int)sizeof(val_t) : 0;
     // ---- final HBM form of the unit streams.  Descriptors: 12 B (the duplicate of word 0 is dropped).  Values: the
     // units of one task are stored in GROUPS of G = 16 / sizeof(value) units (2 in fp64, 4 in fp32) — the values of
     // the G units interleaved per row, so that a lane fetches G units with one 16-byte load (row r of the group at
@@ -698,7 +845,8 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     {
         std::vector<UDesc> packed((size_t)NUP, UDesc{0u, 0u, 0u});
         val_t *paired = zalloc<val_t>((size_t)NUP * 16);
-        std::vector<long long> new_begin(tasks.size());
+        std::vector<long long> new_begin(tasks.size()), old_begin(tasks.size());
+        for (size_t i = 0; i < tasks.size(); i++) old_begin[i] = tasks[i].unit_begin;
         long long at = 0;
         for (size_t i = 0; i < tasks.size(); i++) { new_begin[i] = at; at += padded(tasks[i].unit_end - tasks[i].unit_begin); }
         parallel_chunks((int64_t)tasks.size(), 512, [&](int64_t b, int64_t e, int) {
@@ -718,12 +866,29 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
         rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc);
         rc |= plan->upload(paired, (size_t)NUP * 16, &S.uval);
         free(paired);
+        S.udesc_cb = S.udesc;
+        if (xwin) {   // the multi-vector kernel keeps reading x from global memory: its descriptors carry column blocks
+            std::fill(packed.begin(), packed.end(), UDesc{0u, 0u, 0u});
+            parallel_chunks((int64_t)tasks.size(), 512, [&](int64_t b, int64_t e, int) {
+                for (int64_t i = b; i < e; i++) {
+                    const STask &k = tasks[(size_t)i];   // (unit_begin already points into the packed numbering)
+                    for (long long j = 0; j < k.unit_end - k.unit_begin; j++) {
+                        const uint4 d = h_udesc_cb[(size_t)(old_begin[(size_t)i] + j)];
+                        packed[(size_t)(k.unit_begin + j)] = UDesc{d.x, d.y, d.w};
+                    }
+                }
+            });
+            rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc_cb);
+            rc |= plan->upload(h_wg_win.data(), h_wg_win.size(), &S.wg_win);
+            rc |= plan->upload(h_win_cb.data(), h_win_cb.size(), &S.win_cb);
+        } else { S.wg_win = nullptr; S.win_cb = nullptr; }
     }
     S.wg_coo = nullptr; S.grec = nullptr; S.gbase = nullptr; S.dest_bits = 11;
     long long n_rec = 0, n_chunk = 0, n_groups = 0;
     if (entry_mode != 0) {
         const size_t GS = entry_mode == 2 ? (size_t)wg_strips : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
-        const int dest_bits = entry_mode == 2 ? (wg_strips == 32 ? 12 : 11) : 9;   // strip-in-group | row-in-strip (3) | row (4)
+        const int slab_shift = xwin ? 6 : 7;   // a strip's slab of s_y: XWIN_STRIP_ROWS x 16 values in x-window plans, STRIP_MAX_ROWS x 16 otherwise
+        const int dest_bits = entry_mode == 2 ? (wg_strips == 32 ? 12 : 4 + slab_shift) : 9;   // strip-in-group | row-in-strip | row (4)
         S.dest_bits = dest_bits;
         const size_t nwg = (tasks.size() + GS - 1) / GS;
         std::vector<std::vector<ERec>> grp_rec(nwg);
@@ -738,7 +903,7 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
                 for (size_t t = GS * (size_t)w; t < std::min(tasks.size(), GS * (size_t)w + GS); t++)
                     for (int q = tasks[t].coo_begin; q < tasks[t].coo_end; q++) {   // column-major order; ties keep strip / list order
                         key.push_back({((unsigned long long)(unsigned)h_ccol[(size_t)q] << 32) | (unsigned long long)key.size(),
-                                       (unsigned)((t & (GS - 1)) << 7) | (unsigned)h_crow[(size_t)q]});
+                                       (unsigned)((t & (GS - 1)) << slab_shift) | (unsigned)h_crow[(size_t)q]});
                         src.push_back(q);
                     }
                 std::sort(key.begin(), key.end());
@@ -810,6 +975,9 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     plan->info[TILESPMV_INFO_ENTRY_MODE] = entry_mode;
     plan->info[TILESPMV_INFO_ENTRY_ORDERED] = (entry_mode != 2 || coo_ordered) ? 1 : 0;
     plan->info[TILESPMV_INFO_STRIP_COST] = target;
+    plan->info[TILESPMV_INFO_WG_STRIPS] = wg_strips;
+    plan->info[TILESPMV_INFO_X_WINDOW_SLOTS] = xwin ? xwin_slots_max : 0;
+    plan->info[TILESPMV_INFO_X_WINDOW_SEGMENTS] = xwin ? xwin_segments : 0;
     plan->mv_by_columns = entry_dominated && target >= 800;   // (small strips hold few entries each: scircuit-like 18 / 22 / 32 us native against 22 / 41 / 78 us)
     n_tasks = (long long)tasks.size();
     model_bytes = NUP * (12 + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
@@ -1287,10 +1455,25 @@ int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYP
 {
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = plan->dense_mode == TILESPMV_DENSE_MFMA;
-    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, plan->dn, mfma, plan->entry_mode, plan->wg_strips, plan->xcd_remap, plan->xcd_chunk, d_x, d_y, st)
+    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, plan->dn, mfma, plan->entry_mode, plan->wg_strips, plan->xwin_lds_bytes, plan->xcd_remap, plan->xcd_chunk, d_x, d_y, st)
                                                           : launch_tiles_direct(plan->dev, mfma, false, true, d_x, d_y, st);
     if (e != hipSuccess) return (int)e;
     return (int)launch_fallback(plan->dev, d_x, d_y, st);
+}
+
+int tilespmv_plan_reserve_spmm(tilespmv_plan *plan, int nvec)
+{
+    if (nvec < 1 || nvec > TILESPMV_MAX_NVEC) return (int)hipErrorInvalidValue;
+    if (plan->mv_nvec >= nvec) return 0;
+    const long long rows = plan->dev.f_rows, ldx = ((long long)plan->dev.colA + 16 + 15) / 16 * 16, ldy = (rows + 16 + 15) / 16 * 16;
+    void *px = nullptr, *py = nullptr;
+    if (hipMalloc(&px, (size_t)ldx * nvec * sizeof(val_t)) != hipSuccess) return (int)hipErrorOutOfMemory;
+    if (hipMalloc(&py, (size_t)ldy * nvec * sizeof(val_t)) != hipSuccess) { (void)hipFree(px); return (int)hipErrorOutOfMemory; }
+    for (void *old : {(void *)plan->mv_x, (void *)plan->mv_y})   // a narrower pair from an earlier call goes back
+        if (old) { (void)hipFree(old); plan->allocs.erase(std::find(plan->allocs.begin(), plan->allocs.end(), old)); }
+    plan->allocs.push_back(px); plan->allocs.push_back(py);
+    plan->mv_x = (val_t *)px; plan->mv_y = (val_t *)py; plan->mv_nvec = nvec;
+    return 0;
 }
 
 int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y, int nvec, void *stream)
@@ -1307,13 +1490,12 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
     const bool one_at_a_time = !has_native || (plan->mv_by_columns && (mv_native >= 0 ? mv_native == 0 : nvec < 8));
     if (one_at_a_time) {
         hipStream_t st = (hipStream_t)stream;
-        const long long row0 = plan->dev.f_row0, rows = plan->dev.f_rows, ldx = (long long)plan->dev.colA + 16, ldy = rows + 16;
-        if (plan->mv_nvec < nvec) {   // first call (or a wider one): the transposed copies of X and Y live with the plan
-            void *px = nullptr, *py = nullptr;
-            if (hipMalloc(&px, (size_t)ldx * nvec * sizeof(val_t)) != hipSuccess) return (int)hipErrorOutOfMemory;
-            if (hipMalloc(&py, (size_t)ldy * nvec * sizeof(val_t)) != hipSuccess) { (void)hipFree(px); return (int)hipErrorOutOfMemory; }
-            plan->allocs.push_back(px); plan->allocs.push_back(py);   // (an earlier, narrower pair stays allocated until the plan goes)
-            plan->mv_x = (val_t *)px; plan->mv_y = (val_t *)py; plan->mv_nvec = nvec;
+        // leading dimensions of the column copies: multiples of 16 elements, so that every column of X / Y starts 64- / 128-byte
+        // aligned whatever rowA is (the SpMV kernels store y with 16-byte lane stores)
+        const long long row0 = plan->dev.f_row0, rows = plan->dev.f_rows, ldx = ((long long)plan->dev.colA + 16 + 15) / 16 * 16, ldy = (rows + 16 + 15) / 16 * 16;
+        if (plan->mv_nvec < nvec) {   // not reserved (tilespmv_plan_reserve_spmm): allocate now — synchronises, and fails under stream capture
+            const int rc = tilespmv_plan_reserve_spmm(plan, nvec);
+            if (rc) return rc;
         }
         hipError_t e = launch_rows_to_columns(d_X, nvec, plan->dev.colA, ldx, plan->mv_x, st);
         if (e != hipSuccess) return (int)e;
@@ -1389,6 +1571,23 @@ double tilespmv_plan_time(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_
     return reps > 0 ? (double)ms / reps : 0.0;
 }
 
+double tilespmv_plan_time_reference_style(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYPE *d_y, void *stream, int reps)
+{
+    // the reference's protocol (src/tilespmv_cuda.h:1112-1137): gettimeofday around ONE launch + synchronize, summed over the repeats
+    hipStream_t st = (hipStream_t)stream;
+    if (hipStreamSynchronize(st) != hipSuccess) return -1.0;
+    double wall_ms = 0;
+    for (int i = 0; i < reps; i++) {
+        timeval t1, t2;
+        gettimeofday(&t1, NULL);
+        if (tilespmv_plan_spmv(plan, d_x, d_y, stream) != 0) return -1.0;
+        if (hipStreamSynchronize(st) != hipSuccess) return -1.0;
+        gettimeofday(&t2, NULL);
+        wall_ms += (t2.tv_sec - t1.tv_sec) * 1000.0 + (t2.tv_usec - t1.tv_usec) / 1000.0;
+    }
+    return reps > 0 ? wall_ms / reps : 0.0;
+}
+
 void call_tilespmv_hip(char *filename, Tile_matrix *matrix, int *ptroffset1, int *ptroffset2, int rowblkblock,
                        unsigned int *blkcoostylerowidx, int *blkcoostylerowidx_colstart, int *blkcoostylerowidx_colstop,
                        int rowA, int colA, MAT_PTR_TYPE nnzA, MAT_PTR_TYPE *csrRowPtrA, int *csrColIdxA,
@@ -1412,16 +1611,8 @@ void call_tilespmv_hip(char *filename, Tile_matrix *matrix, int *ptroffset1, int
     if ((rc = hipDeviceSynchronize())) die("hipDeviceSynchronize", rc);
 
     // reference-style number: wall clock around launch + sync, one SpMV at a time (src/tilespmv_cuda.h:1112-1137)
-    double wall_ms = 0;
-    for (int i = 0; i < reps; i++) {
-        timeval t1, t2;
-        gettimeofday(&t1, NULL);
-        if ((rc = tilespmv_plan_spmv(plan, d_x, d_y, nullptr))) die("launch", rc);
-        if ((rc = hipDeviceSynchronize())) die("hipDeviceSynchronize", rc);
-        gettimeofday(&t2, NULL);
-        wall_ms += (t2.tv_sec - t1.tv_sec) * 1000.0 + (t2.tv_usec - t1.tv_usec) / 1000.0;
-    }
-    wall_ms /= reps;
+    const double wall_ms = tilespmv_plan_time_reference_style(plan, d_x, d_y, nullptr, reps);
+    if (wall_ms < 0) die("timed launch", 1);
     const double gflops = 2 * (double)nnzA * 1.0e-6 / wall_ms;
     printf("  CUDA SpMV runtime %4.2f ms, %4.2f GFlops\n\n", wall_ms, gflops);
 

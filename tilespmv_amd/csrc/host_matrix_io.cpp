@@ -141,3 +141,106 @@ extern "C" int tilespmv_matrix_load(Tile_matrix *matrix, int *rowA, int *colA, M
     *rowA = head[1]; *colA = head[2]; *nnzA = head[3];
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// CSR cache of a parsed .mtx (new): the reference re-parses the text on every run (src/mmio_highlevel.h:648-682); here the
+// result of mmio_allinone is written once as a flat binary — magic, value size, m, n, nnz, symmetry flag, size and mtime of
+// the source file, FNV-1a-64 of the three arrays — and later runs read three arrays instead of tokenising gigabytes.
+// ------------------------------------------------------------------------------------------------
+#include <sys/stat.h>
+
+namespace {
+
+const char CSR_MAGIC[8] = {'T', 'S', 'C', 'S', 'R', '0', '0', '1'};
+
+struct SourceId { long long size, mtime_s, mtime_ns; };
+
+bool source_id(const char *path, SourceId *id)
+{
+    struct stat sb;
+    if (!path || stat(path, &sb) != 0) return false;
+    id->size = (long long)sb.st_size; id->mtime_s = (long long)sb.st_mtim.tv_sec; id->mtime_ns = (long long)sb.st_mtim.tv_nsec;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int tilespmv_csr_save(const char *path, int m, int n, MAT_PTR_TYPE nnz, int isSymmetric, const MAT_PTR_TYPE *rowptr,
+                                 const int *colidx, const MAT_VAL_TYPE *val, const char *source_mtx)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    int head[5] = {(int)sizeof(tilespmv::val_t), m, n, nnz, isSymmetric};
+    SourceId id{0, 0, 0};
+    (void)source_id(source_mtx, &id);
+    unsigned long long h = 0xCBF29CE484222325ull;
+    h = fnv1a(head, sizeof(head), h);
+    h = fnv1a(rowptr, sizeof(MAT_PTR_TYPE) * ((size_t)m + 1), h);
+    h = fnv1a(colidx, sizeof(int) * (size_t)nnz, h);
+    h = fnv1a(val, sizeof(tilespmv::val_t) * (size_t)nnz, h);
+    bool ok = fwrite(CSR_MAGIC, 1, 8, f) == 8 && fwrite(head, sizeof(int), 5, f) == 5 && fwrite(&id, sizeof(id), 1, f) == 1 &&
+              fwrite(&h, sizeof(h), 1, f) == 1;
+    ok = ok && fwrite(rowptr, sizeof(MAT_PTR_TYPE), (size_t)m + 1, f) == (size_t)m + 1;
+    ok = ok && (nnz == 0 || fwrite(colidx, sizeof(int), (size_t)nnz, f) == (size_t)nnz);
+    ok = ok && (nnz == 0 || fwrite(val, sizeof(tilespmv::val_t), (size_t)nnz, f) == (size_t)nnz);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) remove(path);   // never leave half a cache behind
+    return ok ? 0 : -3;
+}
+
+extern "C" int tilespmv_csr_load(const char *path, int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric, MAT_PTR_TYPE **rowptr,
+                                 int **colidx, MAT_VAL_TYPE **val, const char *source_mtx)
+{
+    *rowptr = nullptr; *colidx = nullptr; *val = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    char magic[8]; int head[5]; SourceId id; unsigned long long want = 0;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, CSR_MAGIC, 8) != 0) { fclose(f); return -2; }
+    if (fread(head, sizeof(int), 5, f) != 5 || fread(&id, sizeof(id), 1, f) != 1 || fread(&want, sizeof(want), 1, f) != 1) { fclose(f); return -3; }
+    if (head[0] != (int)sizeof(tilespmv::val_t)) { fclose(f); return -5; }
+    if (source_mtx) {   // stale: the text file changed (or vanished) since the cache was written
+        SourceId now;
+        if (!source_id(source_mtx, &now) || now.size != id.size || now.mtime_s != id.mtime_s || now.mtime_ns != id.mtime_ns) { fclose(f); return -7; }
+    }
+    const long long M = head[1], N = head[2], NZ = head[3];
+    const long here = ftell(f);
+    const unsigned long long bytes = (unsigned long long)(M + 1) * sizeof(MAT_PTR_TYPE) + (unsigned long long)NZ * (sizeof(int) + sizeof(tilespmv::val_t));
+    bool sane = M >= 0 && N >= 0 && NZ >= 0 && fseek(f, 0, SEEK_END) == 0 && (unsigned long long)(ftell(f) - here) == bytes && fseek(f, here, SEEK_SET) == 0;
+    if (!sane) { fclose(f); return -6; }
+    MAT_PTR_TYPE *rp = (MAT_PTR_TYPE *)malloc(sizeof(MAT_PTR_TYPE) * ((size_t)M + 1));
+    int *ci = (int *)malloc(sizeof(int) * (size_t)std::max<long long>(NZ, 1));
+    tilespmv::val_t *v = (tilespmv::val_t *)malloc(sizeof(tilespmv::val_t) * (size_t)std::max<long long>(NZ, 1));
+    bool ok = rp && ci && v && fread(rp, sizeof(MAT_PTR_TYPE), (size_t)M + 1, f) == (size_t)M + 1 &&
+              (NZ == 0 || (fread(ci, sizeof(int), (size_t)NZ, f) == (size_t)NZ && fread(v, sizeof(tilespmv::val_t), (size_t)NZ, f) == (size_t)NZ));
+    fclose(f);
+    if (ok) {
+        unsigned long long h = 0xCBF29CE484222325ull;
+        h = fnv1a(head, sizeof(head), h);
+        h = fnv1a(rp, sizeof(MAT_PTR_TYPE) * ((size_t)M + 1), h);
+        h = fnv1a(ci, sizeof(int) * (size_t)NZ, h);
+        h = fnv1a(v, sizeof(tilespmv::val_t) * (size_t)NZ, h);
+        sane = h == want && monotone(rp, M + 1, NZ);
+        for (long long i = 0; i < NZ && sane; i++) sane = ci[i] >= 0 && ci[i] < N;
+    }
+    if (!ok || !sane) { free(rp); free(ci); free(v); return ok ? -6 : -3; }
+    *m = (int)M; *n = (int)N; *nnz = (MAT_PTR_TYPE)NZ; *isSymmetric = head[4];
+    *rowptr = rp; *colidx = ci; *val = v;
+    return 0;
+}
+
+// mmio_allinone with a cache beside it: `cache_path` fresh (written from this very file: size and mtime match) -> read it;
+// otherwise parse the text and (re)write the cache, best effort.  *from_cache: 1 read from the cache, 0 parsed (and saved),
+// -1 parsed but the cache could not be written.  Return codes of mmio_allinone.
+extern "C" int mmio_allinone_cached(int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric, MAT_PTR_TYPE **csrRowPtr, int **csrColIdx,
+                                    MAT_VAL_TYPE **csrVal, char *filename, const char *cache_path, int *from_cache)
+{
+    if (from_cache) *from_cache = 0;
+    if (cache_path && tilespmv_csr_load(cache_path, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, csrVal, filename) == 0) {
+        if (from_cache) *from_cache = 1;
+        return 0;
+    }
+    const int rc = mmio_allinone(m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, csrVal, filename);
+    if (rc != 0 || !cache_path) return rc;
+    if (tilespmv_csr_save(cache_path, *m, *n, *nnz, *isSymmetric, *csrRowPtr, *csrColIdx, *csrVal, filename) != 0 && from_cache) *from_cache = -1;
+    return 0;
+}

@@ -297,3 +297,64 @@ extern "C" int mmio_allinone(int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric
     *csrRowPtr = rowptr; *csrColIdx = cols; *csrVal = vals;
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Writer (the reference's counterpart is mm_write_mtx_crd, src/mmio.h:605-645: one fprintf per entry): a general coordinate
+// file in CSR (row-major) order, "real" with shortest-exact values ("%.17g", integers as integers) or "pattern".  Rows are
+// formatted by all host threads into per-chunk buffers that are written out in order, so that a multi-GB file (the
+// nlpkkt160 stand-in is ~4 GB of text) takes seconds.  Returns 0, -1 (cannot open), -3 (short write).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+inline char *put_uint(char *p, unsigned long long v)
+{
+    char tmp[24]; int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+}  // namespace
+
+extern "C" int tilespmv_mtx_write(const char *path, int m, int n, MAT_PTR_TYPE nnz, const MAT_PTR_TYPE *rowptr, const int *colidx,
+                                  const MAT_VAL_TYPE *val /* NULL: pattern */)
+{
+    using namespace tilespmv;
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    bool ok = fprintf(f, "%%%%MatrixMarket matrix coordinate %s general\n%d %d %d\n", val ? "real" : "pattern", m, n, (int)nnz) > 0;
+    const int64_t rows_per = 1 << 16;
+    const int64_t nblk = ((int64_t)m + rows_per - 1) / rows_per;
+    const int wave = std::max(1, host_threads());   // blocks formatted together, then written in order
+    std::vector<std::vector<char>> buf((size_t)wave);
+    for (int64_t b0 = 0; b0 < nblk && ok; b0 += wave) {
+        const int64_t b1 = std::min(nblk, b0 + wave);
+        parallel_chunks(b1 - b0, 1, [&](int64_t k0, int64_t k1, int) {
+            for (int64_t k = k0; k < k1; k++) {
+                const int64_t r0 = (b0 + k) * rows_per, r1 = std::min<int64_t>(m, r0 + rows_per);
+                std::vector<char> &o = buf[(size_t)k];
+                o.resize((size_t)(rowptr[r1] - rowptr[r0]) * 48 + 64);
+                char *p = o.data();
+                for (int64_t r = r0; r < r1; r++)
+                    for (int j = rowptr[r]; j < rowptr[r + 1]; j++) {
+                        p = put_uint(p, (unsigned long long)r + 1); *p++ = ' ';
+                        p = put_uint(p, (unsigned long long)colidx[j] + 1);
+                        if (val) {
+                            *p++ = ' ';
+                            const double v = (double)val[j];
+                            if (v == (double)(long long)v && v > -1e15 && v < 1e15) {
+                                long long iv = (long long)v;
+                                if (iv < 0) { *p++ = '-'; iv = -iv; }
+                                p = put_uint(p, (unsigned long long)iv);
+                            } else p += snprintf(p, 32, "%.17g", v);
+                        }
+                        *p++ = '\n';
+                    }
+                o.resize((size_t)(p - o.data()));
+            }
+        });
+        for (int64_t k = 0; k < b1 - b0 && ok; k++) ok = buf[(size_t)k].empty() || fwrite(buf[(size_t)k].data(), 1, buf[(size_t)k].size(), f) == buf[(size_t)k].size();
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 0 : -3;
+}
