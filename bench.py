@@ -14,8 +14,12 @@ Workloads (synthetic stand-ins unless $TILESPMV_MATRIX_DIR/<name>.mtx exists; SU
   nlpkkt160      KKT-like, 8,345,600 rows, 229,518,112 nnz, fp32 by default (config 5)
 Multi-GPU: contiguous nnz-balanced tile-row blocks, one rank per GPU, x replicated, y left
 sharded (the SpMV needs no collective: SURVEY.md §8e) => "scaling": "strong" on the fixed matrix;
---combine allgather|allreduce adds the RCCL y combine to every step, and the default run also
-reports both combine variants beside the headline value when N > 1.
+--combine allgather|allreduce adds the RCCL y combine to every step, --combine halo runs the sharded-x form
+(HaloSpMV: only the halo of x travels); the default run also reports all three beside the headline value when N > 1.
+Every rank generates (or reads) and preprocesses ONLY its own row block where the workload has a row-block generator
+(the stencil workloads, incl. the headline) — `generated` in the line says which.
+--data real: vals, x ~ U(-1, 1), seed 12345 (SURVEY.md S8(d) data mode ii), whole-y tolerance check instead of the exact one.
+--cache DIR: parse / tile once — .mtx files through the CSR cache (mmio_allinone_cached), Tile_matrix through tilespmv_matrix_save/load.
 """
 import argparse
 import json
@@ -31,13 +35,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def build_matrix(name):
+def build_matrix(name, cache_dir=None):
     from tilespmv_amd import api, generators as G
     d = os.environ.get("TILESPMV_MATRIX_DIR")
     real = {"laplacian4096": None, "scircuit": "scircuit", "webbase": "webbase-1M", "nlpkkt160": "nlpkkt160"}.get(name)
     if d and real and os.path.exists(os.path.join(d, real + ".mtx")):
-        r = api.mmio_allinone(os.path.join(d, real + ".mtx"))
-        return r["m"], r["n"], r["rowptr"], r["colidx"], "file:" + real + ".mtx"
+        path = os.path.join(d, real + ".mtx")
+        cache = os.path.join(cache_dir, real + ".csr_f64") if cache_dir else None   # parse once
+        r = api.mmio_allinone(path, cache=cache)
+        how = "" if cache is None else (" (CSR cache hit)" if r.get("from_cache") == 1 else " (parsed; CSR cache written)")
+        return r["m"], r["n"], r["rowptr"], r["colidx"], "file:" + real + ".mtx" + how
     if name == "laplacian4096":
         return G.laplacian5pt(4096) + ("synthetic 5-pt Laplacian 4096^2",)
     if name.startswith("lap3d"):
@@ -57,6 +64,53 @@ def build_matrix(name):
     if name == "nlpkkt160":
         return G.nlpkkt_like(160) + ("synthetic KKT stand-in for nlpkkt160, same rows / nnz",)
     raise SystemExit("unknown workload " + name)
+
+
+def build_block(name, rank, world, cache_dir=None):
+    """This rank's row block of the workload: (rows, cols, bounds, rowptr_block, colidx_block, first_nnz, nnz_total, source, how).
+    Stencil workloads (incl. the headline) have row-block generators: the cheap row pointer is computed by everyone, the
+    nnz-balanced partition cut from it, and only rows [r0, r1) are ever materialised.  Everything else is generated / read
+    whole and sliced (`how` says which)."""
+    from tilespmv_amd import generators as G
+    from tilespmv_amd.dist import partition_rows, shard_csr
+    gen = None
+    if name.startswith("laplacian") and name[len("laplacian"):].isdigit() and not os.environ.get("TILESPMV_MATRIX_DIR"):
+        n = int(name[len("laplacian"):]); gen = (G.laplacian5pt, G.laplacian5pt_rowptr, n, "synthetic 5-pt Laplacian %d^2" % n)
+    elif name.startswith("lap3d"):
+        n = int(name[5:]); gen = (G.laplacian7pt, G.laplacian7pt_rowptr, n, "synthetic 7-pt Laplacian on a cube")
+    if gen is not None:
+        full_rp = gen[1](gen[2])
+        m = len(full_rp) - 1
+        rows = (m // 16) * 16
+        bounds = partition_rows(full_rp, rows, world)
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        _, cols, rp, ci = gen[0](gen[2], rows=(r0, r1))
+        return rows, cols, bounds, rp, ci, int(full_rp[r0]), int(full_rp[rows]), gen[3], "own row block only"
+    m, n, rowptr, colidx, source = build_matrix(name, cache_dir)
+    rows = (m // 16) * 16
+    bounds = partition_rows(rowptr, rows, world)
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    rp, ci, _ = shard_csr(rowptr, colidx, colidx, r0, r1)
+    return rows, n, bounds, rp, np.ascontiguousarray(ci), int(rowptr[r0]), int(rowptr[rows]), source, "whole matrix, then sliced"
+
+
+def usable_cores():
+    """Cores this process may really run on: affinity mask, capped by the cgroup CPU quota (a GPU box hands out a share of
+    the host — omp_get_max_threads() still reports every hardware thread)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except Exception:
+            pass
+    return max(1, n)
 
 
 def cpu_baseline(rows, cols, rowptr, colidx, vals, x, dtype):
@@ -125,10 +179,22 @@ def cpu_baseline(rows, cols, rowptr, colidx, vals, x, dtype):
             for q in (a, b, c):
                 O.free(C.cast(q, C.c_void_p))
         t_sched = med(_sched, warm=1, runs=3)
+        # all-cores figure: as many threads as this process may really use (affinity + cgroup quota), spread over the cores
+        # (proc_bind(spread) clause in the loop), x and y in buffers first touched by those threads
         fo = O.lib.oracle_tilespmv_cpu_omp
         fo.argtypes = [C.POINTER(O.TM), C.c_int, C.c_int, VP, VP]; fo.restype = C.c_int
+        O.lib.oracle_set_omp_threads.argtypes = [C.c_int]; O.lib.oracle_set_omp_threads.restype = None
+        O.lib.oracle_alloc_first_touch.argtypes = [C.c_size_t]; O.lib.oracle_alloc_first_touch.restype = C.c_void_p
+        ncores = usable_cores()
+        O.lib.oracle_set_omp_threads(ncores)
+        isz = np.dtype(dtype).itemsize
+        px, py = O.lib.oracle_alloc_first_touch((cols + 16) * isz), O.lib.oracle_alloc_first_touch((rows + 16) * isz)
+        C.memmove(px, xs.ctypes.data, cols * isz)
         nthr = []
-        t_omp = med(lambda: nthr.append(fo(tmO, rows, cols, xs.ctypes.data_as(VP), y.ctypes.data_as(VP))))
+        t_omp = med(lambda: nthr.append(fo(tmO, rows, cols, C.cast(px, VP), C.cast(py, VP))))
+        omp_ok = bool(np.array_equal(np.frombuffer((C.c_char * (rows * isz)).from_address(py), dtype=dtype), ygs[:rows]))
+        O.free(C.c_void_p(px)); O.free(C.c_void_p(py))
+        O.lib.oracle_set_omp_threads(0)
         api.Tile_destroy(tm)
     finally:
         C.CDLL(None).fflush(None)   # the checkers print through C stdio: drain it into /dev/null before stdout comes back
@@ -145,7 +211,10 @@ def cpu_baseline(rows, cols, rowptr, colidx, vals, x, dtype):
             "sample": "the full workload (%d rows, %d nnz); %s; 2 warm-ups, median of 10" % (
                 rows, nz, "one tilespmv_cpu call = schedule + serial format loop + self-check" if t_ref is not None else "serial format loop of the restatement"),
             "format_loop_only": {"kind": "port", "serial_1_core": {"value": gf(t_loop), "seconds": round(t_loop, 6), "errcount": int(errs[-1])},
-                                 "all_host_cores": {"value": gf(t_omp), "seconds": round(t_omp, 6), "cores": int(nthr[-1])},
+                                 "all_host_cores": {"value": gf(t_omp), "seconds": round(t_omp, 6), "cores": int(nthr[-1]), "threads": int(nthr[-1]),
+                                                    "usable_cores": ncores, "binding": "proc_bind(spread) on the loop; x, y first touched by the worker threads",
+                                                    "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
+                                                    "y_equals_csr_golden": omp_ok},
                                  "schedule_construction_seconds": round(t_sched, 6), "unit": "GFLOP/s"},
             "reference_y_equals_csr_golden": (ref_ok if t_ref is not None else None),
             "host_cpu": cpu, "host_logical_cores": os.cpu_count()}
@@ -188,13 +257,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="laplacian4096")
     ap.add_argument("--dtype", default=None, choices=[None, "f64", "f32"])
-    ap.add_argument("--combine", default="none", choices=["none", "allgather", "allreduce"])
+    ap.add_argument("--combine", default="none", choices=["none", "allgather", "allreduce", "halo"])
+    ap.add_argument("--data", default="compat", choices=["compat", "real"],
+                    help="compat: the reference driver's val[i] = i %% 10, x[i] = i %% 10 (exact check); real: U(-1, 1), seed 12345 (tolerance check)")
+    ap.add_argument("--cache", default=None, metavar="DIR", help="parse / tile once: CSR cache of .mtx inputs and Tile_matrix cache of this rank's block live here")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--setup-launches", type=int, default=200,
-                    help="untimed SpMVs issued during setup, before the --warmup steps (the reference warms up with 200 launches, "
-                         "src/tilespmv_cuda.h:1059-1082): clocks and caches are at steady state even when the driver asks for few steps")
+                    help="untimed SpMVs issued before the steady-state measurement (the reference warms up with 200 launches, "
+                         "src/tilespmv_cuda.h:1059-1082).  The plain protocol (W warm-ups, K steps, nothing else) is measured FIRST and reported beside it")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo only to rehearse the N>1 path on a single GPU")
     args = ap.parse_args()
@@ -222,25 +294,43 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.cache:
+        os.makedirs(args.cache, exist_ok=True)
 
     dtype = np.dtype(np.float32 if (args.dtype == "f32" or (args.dtype is None and args.workload == "nlpkkt160")) else np.float64)
     tdtype = torch.float64 if dtype == np.float64 else torch.float32
+    dname = "f64" if dtype == np.float64 else "f32"
     t0 = time.time()
-    m, n, rowptr, colidx, source = build_matrix(args.workload)
-    rows = (m // 16) * 16                      # the driver rule of the reference (src/main.cu:71)
-    nnz = int(rowptr[rows])
-    vals, x = G.compat_values(len(colidx), dtype), G.compat_x(n, dtype)   # reference's synthetic data (src/main.cu:68-69,:93-97)
+    rows, n, bounds, rp_b, ci_b, first_nnz, nnz, source, generated = build_block(args.workload, rank, world, args.cache)
+    if args.data == "real":   # one global U(-1, 1) stream: this rank's slice of the values, the whole x
+        vals_b, x = G.real_values(len(ci_b), dtype, first=first_nnz), G.real_x(n, nnz, dtype)
+    else:                     # reference's synthetic data (src/main.cu:68-69,:93-97), i = global nonzero index
+        vals_b, x = G.compat_values(len(ci_b), dtype, first=first_nnz), G.compat_x(n, dtype)
     t_gen = time.time() - t0
 
     t0 = time.time()
-    sh = ShardedSpMV(rank, world, rows, n, rowptr, colidx, vals, dtype)
+    tile_cache = os.path.join(args.cache, "%s_%s_%s_rank%dof%d.tile_%s" % (args.workload, args.data, dname, rank, world, dname)) if args.cache else None
+    sh = ShardedSpMV(rank, world, rows, n, rp_b, ci_b, vals_b, dtype, bounds=bounds, tile_cache=tile_cache)
     t_prep = time.time() - t0
     info = sh.local.info()
     stream = torch.cuda.current_stream()
     xd = torch.from_numpy(x).cuda()
     yd = torch.zeros(rows + 16, dtype=tdtype, device="cuda")
+    halo = None
+
+    def make_halo():
+        from tilespmv_amd.halo import HaloSpMV
+        if rows != n:
+            raise SystemExit("--combine halo needs a square matrix whose size is a multiple of 16 (x is sharded like y)")
+        h = HaloSpMV(rank, world, rows, rp_b, ci_b, vals_b, dtype, bounds=bounds)
+        h.x_own.copy_(xd[h.r0:h.r1])
+        h.y_own = h.new_vector()
+        return h
 
     def step(combine):
+        if combine == "halo":
+            halo.matvec(halo.x_own, halo.y_own)
+            return
         sh.spmv(xd, yd, stream.cuda_stream)
         if combine != "none":
             sh.combine(yd, combine)
@@ -283,60 +373,78 @@ def main():
         timed.per_rank = per_rank
         return wall, dev_ms
 
-    # parity spot check of the resident plan before timing (exact: integer-valued data)
+    # parity of the resident plan before timing, on this rank's WHOLE row block: exact for the reference's integer-valued
+    # data; for real-valued data |y - y_ref| <= tol * sum_j |a_ij x_j| with tol 1e-12 (fp64) / 1e-5 (fp32) (SURVEY S8(d) ii;
+    # the reference's own GPU check is 1 % relative, src/main.cu:186-197)
+    import scipy.sparse as sp
+    A64 = sp.csr_matrix((vals_b.astype(np.float64), ci_b, rp_b), shape=(sh.r1 - sh.r0, n)) if not args.no_check else None
+
+    def check_rows(got, what):
+        want = A64 @ x.astype(np.float64)
+        if args.data == "compat":
+            ok = bool(np.array_equal(got.astype(np.float64), want))
+        else:
+            bound = (1e-12 if dtype == np.float64 else 1e-5) * (abs(A64) @ np.abs(x.astype(np.float64)))
+            ok = bool(np.all(np.abs(got.astype(np.float64) - want) <= bound))
+        if not ok:
+            raise SystemExit("bench.py: HIP result (%s) differs from the CSR golden on rank %d" % (what, rank))
+        return "pass"
+
     check = "skipped"
     if not args.no_check:
         step("none"); torch.cuda.synchronize()
-        rs = np.unique(np.concatenate([np.arange(sh.r0, min(sh.r0 + 4096, sh.r1)), np.random.default_rng(rank).integers(sh.r0, max(sh.r1, sh.r0 + 1), 20000)]))
-        rs = rs[rs < sh.r1]
-        got = yd[torch.from_numpy(rs).cuda()].cpu().numpy()
-        want = np.array([np.dot(vals[rowptr[r]:rowptr[r + 1]].astype(np.float64), x[colidx[rowptr[r]:rowptr[r + 1]]].astype(np.float64)) for r in rs[:6000]])
-        ok = np.array_equal(got[:len(want)].astype(np.float64), want)
-        check = "pass" if ok else "FAIL"
-        if not ok:
-            raise SystemExit("bench.py: HIP result differs from the CSR golden on sampled rows")
+        check = check_rows(yd[sh.r0:sh.r1].cpu().numpy(), "sharded SpMV")
+    if args.combine == "halo":
+        halo = make_halo()
+        if not args.no_check:
+            step("halo"); torch.cuda.synchronize()
+            check_rows(halo.y_own[:halo.nloc].cpu().numpy(), "halo SpMV")
 
-    if args.setup_launches > 0:   # setup, not part of the W warm-up steps nor of the K timed ones; reported as `setup_launches`
+    # 1) the plain protocol: W warm-up steps, K timed steps, nothing else before them (what the round-end driver asks for)
+    wall0, dev_ms0 = timed(args.combine, args.steps, args.warmup)
+    # 2) steady state: `setup_launches` untimed SpMVs first (reference: 200 warm-up launches), then the same W + K
+    if args.setup_launches > 0:
         run("none", args.setup_launches)
         sync_all()
-    wall, dev_ms = timed(args.combine, args.steps, args.warmup)
+        wall, dev_ms = timed(args.combine, args.steps, args.warmup)
+    else:
+        wall, dev_ms = wall0, dev_ms0
     ms_per_step = wall * 1e3 / args.steps
     flops = 2.0 * nnz
     b_alg_total = api.algorithmic_bytes(nnz, rows, n, dtype.itemsize)
     value = flops / (wall / args.steps) * 1e-9
 
-    # roofline of the dominant kernel (k_tiles_direct): algorithmic bytes of THIS rank's launch
-    # divided by its average duration, from HIP events on the launch stream over the timed region.
+    # roofline of the dominant kernel (k_units): algorithmic bytes of THIS rank's launch divided by its average duration,
+    # from HIP events on the launch stream over the timed region.
     b_alg_launch = api.algorithmic_bytes(sh.local_nnz, sh.local_rows, n, dtype.itemsize)
     kernel_ms = dev_ms / args.steps
     achieved = b_alg_launch / (kernel_ms * 1e-3) * 1e-9
     main_per_rank = timed.per_rank
     # HBM traffic of one launch: PMC counters cannot be read inside this process (rocprofv3 wraps the command, and a
-    # --pmc pass serialises the kernels), so the figure comes from the committed summary of scripts/profile_round.sh
-    # for this workload/dtype and is labelled with its source; null when no such pass has been committed.
+    # --pmc pass serialises the kernels), so the figure comes from the committed summary of scripts/profile_traffic.sh
+    # for this workload/dtype — and only if that pass saw THIS plan: the summary carries a fingerprint of the plan it
+    # measured (entry mode, strip cost, tasks, stream bytes); on a mismatch traffic is null and marked stale.
     traffic, traffic_source = None, None
-    tj = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, "f64" if dtype == np.float64 else "f32"))
+    fingerprint = {k: info[k] for k in ("entry_mode", "strip_cost", "num_tasks", "stream_bytes", "x_window_slots")}
+    tj = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, dname))
     if world == 1 and os.path.exists(tj):
         tjd = json.load(open(tj))
-        traffic = tjd.get("hbm_bytes_per_launch")
-        traffic_source = {"file": os.path.relpath(tj, ROOT), "measured": tjd.get("measured", "round 1"), "kernel": tjd.get("kernel"),
+        fresh = tjd.get("plan_fingerprint") == fingerprint
+        traffic = tjd.get("hbm_bytes_per_launch") if fresh else None
+        traffic_source = {"file": os.path.relpath(tj, ROOT), "measured": tjd.get("measured"), "kernel": tjd.get("kernel"),
                           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this command; FETCH_SIZE x2 (gfx950 correction, calibrated)",
-                          "live": False}
-    # the reference's own timing protocol (src/tilespmv_cuda.h:1112-1137): wall clock around launch + sync, one SpMV at a time
-    # (its cudaMemset of y is not needed: the kernel overwrites y)
+                          "live": False, "plan_fingerprint_matches": fresh}
+        if not fresh:
+            traffic_source["stale"] = "the committed pass measured another plan: %s" % json.dumps(tjd.get("plan_fingerprint"))
+    # the reference's own timing protocol (src/tilespmv_cuda.h:1112-1137): wall clock around launch + synchronize, one SpMV at
+    # a time, as a C loop (tilespmv_plan_time_reference_style); its cudaMemset of y is not needed: the kernel overwrites y
     nref = min(1000, max(args.steps, 50))
     sync_all()
-    tr = []
-    for _ in range(nref):
-        t1 = time.perf_counter()
-        sh.spmv(xd, yd, stream.cuda_stream)
-        torch.cuda.synchronize()
-        tr.append(time.perf_counter() - t1)
-    ref_style_ms = float(np.mean(tr)) * 1e3
+    ref_style_ms = sh.local.time_reference_style(xd.data_ptr(), yd.data_ptr() + sh.r0 * yd.element_size(), stream.cuda_stream, nref)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "k_units" if info["kernel"] == 2 else "k_tiles_direct", "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_launch": int(b_alg_launch),
-                "plan_stream_bytes_per_launch": info["stream_bytes"], "timing": "hip events on the launch stream, timed region"}
+                "plan_stream_bytes_per_launch": info["stream_bytes"], "plan_fingerprint": fingerprint, "timing": "hip events on the launch stream, timed region"}
 
     # measured device ceilings beside the 8 TB/s spec figure: read-only and copy streams of 1 GiB buffers
     if rank == 0 and world == 1:
@@ -358,40 +466,79 @@ def main():
 
     extra = {}
     if world > 1 and args.combine == "none":
-        for mode in ("allgather", "allreduce"):
-            w2, _ = timed(mode, max(5, args.steps // 10), 3)
-            extra[mode] = {"ms_per_step": round(w2 * 1e3 / max(5, args.steps // 10), 5), "gflops": round(flops / (w2 / max(5, args.steps // 10)) * 1e-9, 2)}
-            if not args.no_check:  # after the combine every rank holds the whole y: sampled rows of ALL shards, exact
-                ra = np.unique(np.random.default_rng(100 + rank).integers(0, rows, 3000))
-                got = yd[torch.from_numpy(ra).cuda()].cpu().numpy().astype(np.float64)
-                want = np.array([np.dot(vals[rowptr[r]:rowptr[r + 1]].astype(np.float64), x[colidx[rowptr[r]:rowptr[r + 1]]].astype(np.float64)) for r in ra])
-                okc = torch.tensor([1.0 if np.array_equal(got, want) else 0.0], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-                dist.all_reduce(okc, op=dist.ReduceOp.MIN)
-                extra[mode]["check_full_y_on_every_rank"] = "pass" if float(okc[0]) == 1.0 else "FAIL"
+        ksteps = max(5, args.steps // 10)
+        for mode in ("allgather", "allreduce", "halo"):
+            try:
+                if mode == "halo":
+                    halo = make_halo()
+                w2, _ = timed(mode, ksteps, 3)
+                extra[mode] = {"ms_per_step": round(w2 * 1e3 / ksteps, 5), "gflops": round(flops / (w2 / ksteps) * 1e-9, 2)}
+                if mode == "halo":
+                    extra[mode]["halo_bytes_per_rank"] = int(halo.halo_bytes())
+                    extra[mode]["note"] = "x sharded like y: one all_to_all_single of the halo per SpMV, no full-length vector anywhere"
+                if not args.no_check:
+                    if mode == "halo":   # every rank: its own rows, whole block
+                        okv = 1.0
+                        try:
+                            check_rows(halo.y_own[:halo.nloc].cpu().numpy(), "halo SpMV")
+                        except SystemExit:
+                            okv = 0.0
+                        key = "check_own_rows_on_every_rank"
+                    else:                # after the combine every rank holds the whole y: its own block again + the neighbours' first rows
+                        nb = (rank + 1) % world
+                        ra = np.arange(int(bounds[nb]), min(int(bounds[nb]) + 2048, int(bounds[nb + 1])))
+                        mine_ok = check_rows(yd[sh.r0:sh.r1].cpu().numpy(), mode) == "pass"
+                        # rows of the next rank as that rank computed them before the combine: all-gathered reference values
+                        ref_rows = yd[torch.from_numpy(ra).cuda()].clone()
+                        sh.spmv(xd, yd, stream.cuda_stream); sh.combine(yd, mode); torch.cuda.synchronize()
+                        okv = 1.0 if (mine_ok and bool(torch.equal(ref_rows, yd[torch.from_numpy(ra).cuda()]))) else 0.0
+                        key = "check_full_y_on_every_rank"
+                    okc = torch.tensor([okv], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+                    dist.all_reduce(okc, op=dist.ReduceOp.MIN)
+                    extra[mode][key] = "pass" if float(okc[0]) == 1.0 else "FAIL"
+            except Exception as e:   # a combine variant never breaks the headline line
+                extra[mode] = {"error": repr(e)}
 
+    # per-rank preprocessing seconds (every rank prepares only its own block)
+    prep_mine = dict({"generate": round(t_gen, 3), "total_tile_create_plus_plan": round(t_prep, 3)}, **{k: round(v, 3) for k, v in sh.seconds.items()})
+    if getattr(sh, "tile_cache", None):
+        prep_mine["tile_cache"] = sh.tile_cache
+    prep_all = [prep_mine]
+    if world > 1:
+        prep_all = [None] * world
+        dist.all_gather_object(prep_all, prep_mine)
+
+    value_plain = flops / (wall0 / args.steps) * 1e-9
     out = {
         "metric": "fp%d SpMV GFLOP/s (y = A*x, tiled format)" % (dtype.itemsize * 8), "value": round(value, 2), "unit": "GFLOP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-        "setup_launches": args.setup_launches, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64" if dtype == np.float64 else "f32", "data": "synthetic (reference driver data: val[i]=i%10, x[i]=i%10)",
-        "config": {"workload": args.workload, "source": source, "rows": rows, "cols": n, "nnz": nnz,
+        "setup_launches": args.setup_launches,
+        "value_without_setup_launches": round(value_plain, 2), "ms_per_step_without_setup_launches": round(wall0 * 1e3 / args.steps, 5),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": dname,
+        "data": "synthetic (reference driver data: val[i]=i%10, x[i]=i%10)" if args.data == "compat" else "synthetic (vals, x ~ U(-1,1), seed 12345; SURVEY S8(d) data mode ii)",
+        "config": {"workload": args.workload, "source": source, "generated": generated, "rows": rows, "cols": n, "nnz": nnz,
                    "partition": "tile-row blocks, nnz-balanced, %d rank(s)" % world, "y_combine": args.combine, "backend": args.backend if world > 1 else None,
-                   "tiles": info["tiles"], "tasks": info["num_tasks"], "coo_mode": info["coo_mode"], "dense_mode": info["dense_mode"],
-                   "entry_mode": info["entry_mode"], "sums_bit_reproducible": bool(info["entry_ordered"]), "strip_cost": info["strip_cost"]},
+                   "tiles": getattr(sh, "tiles", None), "tasks": info["num_tasks"], "coo_mode": info["coo_mode"], "dense_mode": info["dense_mode"],
+                   "entry_mode": info["entry_mode"], "sums_bit_reproducible": bool(info["entry_ordered"]), "strip_cost": info["strip_cost"],
+                   "x_window_slots": info["x_window_slots"]},
         "hbm_gbps_algorithmic": round(b_alg_total / (wall / args.steps) * 1e-9, 1),
         "hbm_roofline_frac": round(b_alg_total / (wall / args.steps) * 1e-9 / (HBM_PEAK_GBPS * world), 4),
-        "roofline": roofline, "check": check,
+        "roofline": roofline,
+        "check": check if check == "skipped" else ("pass: whole row block of every rank, %s" % ("exact" if args.data == "compat" else "|y - y_ref| <= %g * sum|a_ij x_j|" % (1e-12 if dtype == np.float64 else 1e-5))),
         "ranks": (dist.get_world_size() if world > 1 else 1), "devices": [int(r[0]) for r in main_per_rank], "backend": (args.backend if world > 1 else None),
         "per_rank_ms_per_step": {"wall": [round(r[1], 5) for r in main_per_rank], "device": [round(r[2], 5) for r in main_per_rank],
                                  "min": round(min(r[1] for r in main_per_rank), 5), "max": round(max(r[1] for r in main_per_rank), 5)},
         "launched_by": "self (child torch.distributed.run)" if os.environ.get("TILESPMV_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "direct"),
-        "reference_style_timing": {"ms_per_spmv": round(ref_style_ms, 5), "gflops": round(flops / (ref_style_ms * 1e-3) * 1e-9, 2), "reps": nref,
-                                   "protocol": "wall clock around launch + synchronize, one SpMV at a time (reference src/tilespmv_cuda.h:1112-1137), this rank's shard"},
-        "prep_seconds": dict({"generate": round(t_gen, 3), "total_tile_create_plus_plan": round(t_prep, 3)},
-                             **{k: round(v, 3) for k, v in sh.seconds.items()}),
+        "reference_style_timing": {"ms_per_spmv": round(ref_style_ms, 5), "gflops": round(2.0 * sh.local_nnz / (ref_style_ms * 1e-3) * 1e-9, 2), "reps": nref,
+                                   "protocol": "C loop: gettimeofday around one launch + stream synchronize (reference src/tilespmv_cuda.h:1112-1137), this rank's shard"},
+        "prep_seconds": prep_mine, "prep_seconds_per_rank": prep_all,
     }
     if extra:
         out["with_y_combine"] = extra
+    if args.combine == "halo" and halo is not None:
+        out["halo_bytes_per_rank"] = int(halo.halo_bytes())
+    vals, rowptr, colidx = vals_b, rp_b, ci_b   # (world == 1 below: the block is the whole matrix)
     # the other BASELINE configs (stand-ins) at one GPU, reported beside the headline; never `value`:
     # configs 2-3 are cache-resident (launch/latency-bound), config 5 is the fp32 HBM-roofline case
     if rank == 0 and world == 1 and args.workload == "laplacian4096" and not args.no_extras:
@@ -423,19 +570,34 @@ def main():
                     p2 = api.Plan(tm2, r2, n2, nz2, coo_mode=coo)
                     yd2 = torch.zeros(r2 + 16, dtype=td2, device="cuda")
                     ms2 = p2.time(xd2.data_ptr(), yd2.data_ptr(), stream.cuda_stream, warmup=20, reps=200 if small else 50)
+                    fp2 = {k: p2.info()[k] for k in ("entry_mode", "strip_cost", "num_tasks", "stream_bytes", "x_window_slots")}
                     ok2 = bool(np.array_equal(yd2.cpu().numpy()[:r2].astype(np.float64), ref2))
                     rec[label] = {"ms_per_spmv": round(ms2, 5), "gflops": round(2.0 * nz2 / ms2 * 1e-6, 1),
                                   "hbm_gbps_algorithmic": round(b2 / ms2 * 1e-6, 1), "frac_of_8TBps": round(b2 / ms2 * 1e-6 / HBM_PEAK_GBPS, 4),
                                   "check": "pass" if ok2 else "FAIL", "fallback_nnz": p2.info()["fallback_nnz"],
                                   "entry_mode": p2.info()["entry_mode"], "sums_bit_reproducible": bool(p2.info()["entry_ordered"]),
                                   "strip_cost": p2.info()["strip_cost"], "tasks": p2.info()["num_tasks"]}
+                    if label in ("coo_in_tile", "default_plan"):   # the same plan on real-valued data: the time does not depend on the values
+                        vr, xr = G.real_values(len(ci2), dt2), G.real_x(n2, len(ci2), dt2)
+                        tmr = api.Tile_create(r2, n2, nz2, rp2, ci2, vr, dtype=dt2, hyb=(wl == "scircuit"))
+                        pr = api.Plan(tmr, r2, n2, nz2, coo_mode=coo)
+                        xdr = torch.from_numpy(xr).cuda()
+                        msr = pr.time(xdr.data_ptr(), yd2.data_ptr(), stream.cuda_stream, warmup=20, reps=200 if small else 50)
+                        Ar = sp.csr_matrix((vr[:nz2].astype(np.float64), ci2[:nz2], rp2[:r2 + 1]), shape=(r2, n2))
+                        wantr = Ar @ xr.astype(np.float64)
+                        tol = (1e-12 if dt2 == np.float64 else 1e-5) * (abs(Ar) @ np.abs(xr.astype(np.float64)))
+                        okr = bool(np.all(np.abs(yd2.cpu().numpy()[:r2].astype(np.float64) - wantr) <= tol))
+                        rec[label]["real_valued_data"] = {"ms_per_spmv": round(msr, 5), "check_whole_y_within_tolerance": "pass" if okr else "FAIL"}
+                        pr.close(); api.Tile_destroy(tmr)
+                        del xdr, vr, xr, Ar, wantr, tol
                     p2.close()
                     del yd2
                 tj2 = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (wl, "f64" if dt2 == np.float64 else "f32"))
                 if os.path.exists(tj2):   # HBM-side bytes per launch of the default plan, from the committed counter passes (not live)
                     t2 = json.load(open(tj2))
-                    rec["traffic"] = {"hbm_bytes_per_launch": t2.get("hbm_bytes_per_launch"), "kernel": t2.get("kernel"), "measured": t2.get("measured"),
-                                      "file": os.path.relpath(tj2, ROOT), "live": False}
+                    fresh2 = t2.get("plan_fingerprint") == fp2
+                    rec["traffic"] = {"hbm_bytes_per_launch": t2.get("hbm_bytes_per_launch") if fresh2 else None, "kernel": t2.get("kernel"), "measured": t2.get("measured"),
+                                      "file": os.path.relpath(tj2, ROOT), "live": False, "plan_fingerprint_matches": fresh2}
                 out["other_workloads"][wl] = rec
                 api.Tile_destroy(tm2)
                 del m2, n2, rp2, ci2, v2, x2, ref2, xd2

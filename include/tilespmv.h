@@ -117,6 +117,11 @@ void Tile_create(Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA,
  * TILESPMV_CREATE_QUIET suppresses the stdout line. */
 #define TILESPMV_CREATE_HYB 1u
 #define TILESPMV_CREATE_QUIET 2u
+/* TILESPMV_CREATE_CDNA4 (opt-in; default off = the reference's selection, byte-identical Tile_matrix): per-tile format chosen by
+ * the bytes THIS engine moves for it (16-value units + entries) instead of the reference's thresholds (dense at 75 % fill, COO up
+ * to 12 entries, ELL at row-length variation <= 0.2: src/csr2tile.h:150,159,267-270; COO_NNZ_TH src/common.h:45-47).  The result is
+ * still a valid Tile_matrix for tilespmv_cpu and every plan; profiles/r03_selection_cdna4.txt has what it changes. */
+#define TILESPMV_CREATE_CDNA4 4u
 void Tile_create_ex(Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA,
                     const MAT_PTR_TYPE *csrRowPtrA, const int *csrColIdxA,
                     const MAT_VAL_TYPE *csrValA, unsigned flags);
@@ -277,7 +282,8 @@ typedef struct {
     int x_stride2;      /* ... tile-rows per grid plane (0 / unset: detected; none for 2-D problems)         TILESPMV_X_STRIDE2 */
     int mv_native;      /* tilespmv_plan_spmm on entry-dominated plans: 1 multi-vector kernel, 0 one vector at a time           TILESPMV_MV_NATIVE */
     int mv_xcd_chunk;   /* XCD window of the multi-vector kernel                                             TILESPMV_MV_XCD_CHUNK */
-    int reserved[6];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
+    int lds_pad;        /* bytes of unused LDS added to every unit-kernel workgroup: fewer resident workgroups per CU  TILESPMV_LDS_PAD */
+    int reserved[5];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
 

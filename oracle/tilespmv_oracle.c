@@ -586,6 +586,26 @@ int oracle_tilespmv_cpu(const Tile_matrix *T, int *ptroffset1, int *ptroffset2, 
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+static int omp_threads_wanted = 0;   /* 0 = omp_get_max_threads() */
+/* Thread count of the all-cores baseline (bench.py passes the cores this process may really use: affinity mask and cgroup
+ * quota — omp_get_max_threads() reports every hardware thread of the host, 8x more than a 16-core share allows). */
+void oracle_set_omp_threads(int n) { omp_threads_wanted = n > 0 ? n : 0; }
+
+/* Buffer whose pages are first touched by the threads of the baseline, spread over the cores (proc_bind(spread)): a vector
+ * allocated and filled by one Python thread sits on one NUMA node and every other node reads it remotely. */
+void *oracle_alloc_first_touch(size_t bytes)
+{
+    char *p = (char *)malloc(bytes ? bytes : 1);
+    if (!p) return NULL;
+    const long long pages = (long long)((bytes + 4095) / 4096);
+#ifdef _OPENMP
+    const int nt = omp_threads_wanted > 0 ? omp_threads_wanted : omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(nt) proc_bind(spread)
+#endif
+    for (long long i = 0; i < pages; i++) memset(p + (size_t)i * 4096, 0, (size_t)((i + 1) * 4096 <= (long long)bytes ? 4096 : bytes - (size_t)i * 4096));
+    return p;
+}
+
 int oracle_tilespmv_cpu_omp(const Tile_matrix *T, int rowA, int colA, const val_t *x, val_t *y)
 {
     const int tilem = T->tilem, tilen = T->tilen;
@@ -604,8 +624,8 @@ int oracle_tilespmv_cpu_omp(const Tile_matrix *T, int rowA, int colA, const val_
     }
     int nthreads = 1;
 #ifdef _OPENMP
-    nthreads = omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic, 256)
+    nthreads = omp_threads_wanted > 0 ? omp_threads_wanted : omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads) proc_bind(spread)
 #endif
     for (int bi = 0; bi < tilem; bi++) {
         const int rowlen = (bi == tilem - 1) ? rowA - (tilem - 1) * BS : BS;

@@ -1,0 +1,41 @@
+"""Selection-side f3: the reference's per-tile format thresholds vs TILESPMV_CREATE_CDNA4 (formats chosen by this
+engine's byte costs), on the bench workloads: format histogram, plan stream bytes, ms per SpMV (min of 5 x 20), exact check.
+    python scripts/selection_sweep.py out.txt [workload ...]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import scipy.sparse as sp
+from tilespmv_amd import api, generators as G
+from tilespmv_amd.tile_matrix import field_array
+
+out = sys.argv[1]
+wls = sys.argv[2:] or ["laplacian4096", "lap3d256", "nlpkkt160:f32", "nlpkkt160:f64", "band40_2000000", "powerlaw8000000", "webbase", "scircuit"]
+sys.argv = sys.argv[:1]
+import bench
+lines = ["%-18s %-5s %-9s %-46s %12s %10s %6s" % ("workload", "dtype", "selection", "tiles [csr,coo,ell,hyb,dns,dnsrow,dnscol]", "stream MB", "ms/SpMV", "exact")]
+for spec in wls:
+    wl, _, dt = spec.partition(":")
+    dtype = np.float32 if dt == "f32" else np.float64
+    m, n, rp, ci, src = bench.build_matrix(wl)
+    rows = (m // 16) * 16; nnz = int(rp[rows])
+    vals, x = G.compat_values(len(ci), dtype), G.compat_x(n, dtype)
+    want = sp.csr_matrix((vals[:nnz].astype(np.float64), ci[:nnz], rp[:rows + 1]), shape=(rows, n)) @ x.astype(np.float64)
+    xd = torch.from_numpy(x).cuda(); yd = torch.zeros(rows + 16, dtype=xd.dtype, device="cuda")
+    res = {}
+    for label, flag in (("reference", False), ("cdna4", True)):
+        tm = api.Tile_create(rows, n, nnz, rp, ci, vals, dtype=dtype, cdna4=flag)
+        hist = np.bincount(field_array(tm, "Format", tm.tilenum), minlength=7).tolist()
+        p = api.Plan(tm, rows, n, nnz)
+        yd.fill_(-1); p.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize()
+        ok = bool(np.array_equal(yd.cpu().numpy()[:rows].astype(np.float64), want))
+        res[label] = (tm, p, hist, ok, [])
+    for rnd in range(5):
+        for label in res:
+            res[label][4].append(res[label][1].time(xd.data_ptr(), yd.data_ptr(), warmup=3, reps=20))
+    for label, (tm, p, hist, ok, ts) in res.items():
+        lines.append("%-18s %-5s %-9s %-46s %12.1f %10.5f %6s" % (wl, "f32" if dtype == np.float32 else "f64", label, hist, p.info()["stream_bytes"] / 1e6, min(ts), ok))
+        p.close(); api.Tile_destroy(tm)
+    print("\n".join(lines[-2:]), flush=True)
+    del xd, yd, want
+open(out, "w").write("\n".join(lines) + "\n")

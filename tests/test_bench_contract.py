@@ -27,7 +27,7 @@ def test_single_gpu_line():
     d = _last_json(r.stdout)
     for k in REQUIRED:
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["check"] == "pass"
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["check"].startswith("pass: whole row block")
     assert d["config"]["workload"] == "laplacian512" and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
@@ -35,8 +35,29 @@ def test_single_gpu_line():
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
     assert cb["sample"].startswith("the full workload") and cb["format_loop_only"]["serial_1_core"]["errcount"] == 0
     assert d["ranks"] == 1 and d["devices"] == [0] and d["reference_style_timing"]["ms_per_spmv"] > 0 and d["setup_launches"] == 200
-    assert {"tile_create", "plan_build", "plan_upload"} <= set(d["prep_seconds"])
+    assert {"tile_create", "plan_build", "plan_upload"} <= set(d["prep_seconds"]) and len(d["prep_seconds_per_rank"]) == 1
+    assert d["value_without_setup_launches"] > 0 and d["ms_per_step_without_setup_launches"] > 0      # the plain W + K protocol, measured first
+    assert d["config"]["generated"] == "own row block only"
+    allc = cb["format_loop_only"]["all_host_cores"]
+    assert allc["threads"] == allc["usable_cores"] >= 1 and allc["y_equals_csr_golden"] is True
+    assert "C loop" in d["reference_style_timing"]["protocol"]
+    fp = rf["plan_fingerprint"]
+    assert fp["num_tasks"] == d["config"]["tasks"] and (rf["traffic"] is None or rf["traffic_source"]["plan_fingerprint_matches"])
     assert abs(d["value"] - 2 * d["config"]["nnz"] / (d["ms_per_step"] * 1e-3) * 1e-9) / d["value"] < 0.02
+
+
+def test_single_gpu_line_real_valued_data(tmp_path):
+    """--data real: U(-1, 1) values and x (seed 12345), whole-y tolerance check; --cache: the second run reads the Tile_matrix cache."""
+    cmd = [sys.executable, "bench.py", "--workload", "laplacian512", "--steps", "10", "--warmup", "3", "--data", "real", "--no-cpu-baseline",
+           "--no-extras", "--cache", str(tmp_path)]
+    lines = []
+    for _ in range(2):
+        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append(_last_json(r.stdout))
+    assert "U(-1,1)" in lines[0]["data"] and "<=" in lines[0]["check"] and lines[0]["check"].startswith("pass")
+    assert lines[0]["prep_seconds"]["tile_cache"] == "miss" and lines[1]["prep_seconds"]["tile_cache"] == "hit"
+    assert lines[1]["check"].startswith("pass")
 
 
 def test_two_rank_rehearsal_over_gloo():
@@ -46,8 +67,20 @@ def test_two_rank_rehearsal_over_gloo():
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["check"] == "pass" and d["scaling"] == "strong"
+    assert d["n_gpus"] == 2 and d["check"].startswith("pass") and d["scaling"] == "strong"
     assert d["ranks"] == 2 and len(d["devices"]) == 2 and d["backend"] == "gloo" and d["launched_by"].startswith("self")
     assert len(d["per_rank_ms_per_step"]["wall"]) == 2 and d["per_rank_ms_per_step"]["max"] >= d["per_rank_ms_per_step"]["min"] > 0
-    assert set(d["with_y_combine"]) == {"allgather", "allreduce"} and d["cpu_baseline"] is None
-    assert all(v["check_full_y_on_every_rank"] == "pass" for v in d["with_y_combine"].values())
+    assert set(d["with_y_combine"]) == {"allgather", "allreduce", "halo"} and d["cpu_baseline"] is None
+    assert all(v["check_full_y_on_every_rank"] == "pass" for k, v in d["with_y_combine"].items() if k != "halo"), d["with_y_combine"]
+    assert d["with_y_combine"]["halo"]["check_own_rows_on_every_rank"] == "pass" and d["with_y_combine"]["halo"]["halo_bytes_per_rank"] > 0
+    assert len(d["prep_seconds_per_rank"]) == 2 and d["config"]["generated"] == "own row block only"      # each rank built only its rows
+
+
+def test_two_rank_halo_mode_over_gloo():
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo", "--workload", "laplacian512", "--combine", "halo",
+           "--data", "real"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["config"]["y_combine"] == "halo" and d["halo_bytes_per_rank"] > 0 and d["check"].startswith("pass") and d["value"] > 0

@@ -607,3 +607,132 @@ def test_inline_fixup_of_split_rows_is_stable_across_launches(torch_cuda, monkey
             p.spmv(xd.data_ptr(), yd.data_ptr()); p.spmv(xd.data_ptr(), yd.data_ptr())
             assert torch.equal(yd[:m], want), (env, it)
         p.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
+    """Round 3: packed entry records in every entry mode, 512-thread workgroups, x windows (brick task order + LDS-staged x
+    segments, strides detected from the matrix) and the resident-workgroup cap — all passed as plan options, none through the
+    environment — give the oracle's y bit for bit on the stencil / KKT / irregular test matrices."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    O = CpuImpl("oracle", dtype)
+    mats = {"kkt12": MEDIUM["kkt12"], "lap256": MEDIUM["lap256"], "powerlaw200k": MEDIUM["powerlaw200k"],
+            "lap3d40": lambda: G.laplacian7pt(40), "kkt_like24": lambda: G.nlpkkt_like(24, target_nnz=None), "allfmt": SMALL["allfmt"]}
+    knob_sets = [dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, entry_ordered=1), dict(entry_mode=2, entry_ordered=0),
+                 dict(entry_mode=2, wg_strips=32, entry_ordered=1), dict(x_window=1), dict(x_window=1, entry_mode=0), dict(x_window=1, entry_mode=2),
+                 dict(x_window=1, entry_mode=2, strip_cost=200), dict(x_window=1, x_stride1=3), dict(lds_pad=12288, xcd_remap=0),
+                 dict(x_window=1, strip_cost=64, split_above=200)]
+    windowed = 0
+    for name, gen in mats.items():
+        m, n, rp, ci = gen()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, x = values_for(name, nnz, n, dtype)
+        want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, x)["y"]
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=True)
+        for kw in knob_sets:
+            y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, **kw)
+            assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
+            if "entry_mode" in kw and not kw.get("x_window"):
+                assert info["entry_mode"] == kw["entry_mode"]
+            windowed += info["x_window_slots"] > 0
+        # multi-vector product on an x-window plan: its kernel reads the column-block descriptors kept beside the slotted ones
+        plan = api.Plan(tp, rowA, n, nnz, x_window=1, entry_mode=0)
+        X = (np.arange(n * 4, dtype=np.int64) % 7).astype(dtype).reshape(n, 4)
+        Xd = torch_cuda.from_numpy(X).cuda(); Yd = torch_cuda.zeros((rowA + 16, 4), dtype=Xd.dtype, device="cuda")
+        plan.spmm(Xd.data_ptr(), Yd.data_ptr(), 4); torch_cuda.cuda.synchronize()
+        for j in range(4):
+            wj = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"]
+            assert np.array_equal(Yd.cpu().numpy()[:rowA, j], wj), (name, "spmm on an x-window plan", j)
+        plan.close()
+        api.Tile_destroy(tp)
+    assert windowed >= 12      # the stencil / KKT matrices really took the windowed kernel
+
+
+def test_matrix_cache_to_plan_matches_oracle(torch_cuda, tmp_path):
+    """f2 end to end on the GPU: .mtx -> (parse, CSR cache) -> Tile_create -> save -> load -> Plan -> whole y == oracle, and
+    the second pass touches neither the text nor Tile_create."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    m, n, rp, ci = MEDIUM["circuit60k"]()
+    mtx = str(tmp_path / "c.mtx")
+    api.mtx_write(mtx, m, n, rp, ci, np.ones(len(ci)))
+    for dtype in (np.float64, np.float32):
+        suf = "f64" if dtype == np.float64 else "f32"
+        O = CpuImpl("oracle", dtype)
+        for attempt in range(2):
+            r = api.mmio_allinone(mtx, dtype, cache=str(tmp_path / ("c.csr_" + suf)))
+            assert r["rc"] == 0 and r["from_cache"] == attempt
+            rowA, nnz = truncated_rows(r["m"]), int(r["rowptr"][truncated_rows(r["m"])])
+            vals, x = values_for("circuit60k", r["nnz"], r["n"], dtype)
+            tile_path = str(tmp_path / ("c.tile_" + suf))
+            if attempt == 0:
+                tp = api.Tile_create(rowA, r["n"], nnz, r["rowptr"], r["colidx"], vals, dtype=dtype)
+                api.matrix_save(tp, rowA, r["n"], nnz, tile_path)
+                api.Tile_destroy(tp)
+            tl, r2, c2, z2 = api.matrix_load(tile_path, dtype)
+            assert (r2, c2, z2) == (rowA, r["n"], nnz)
+            want = O.spmv(O.tile_create(rowA, r["n"], nnz, r["rowptr"], r["colidx"], vals), rowA, r["n"], nnz, r["rowptr"], r["colidx"], vals, x)["y"]
+            y, _ = _gpu_y(torch_cuda, tl, rowA, r["n"], nnz, x)
+            assert np.array_equal(y, want), (suf, attempt)
+            api.Tile_destroy(tl)
+
+
+def test_cli_cache_option(torch_cuda, tmp_path):
+    """`./test -d 0 A.mtx --cache`: first run parses and saves both caches, second run reads them; same lines, PASS both times."""
+    import shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tilespmv_amd", "bin", "test_f64")
+    mtx = str(tmp_path / "t.mtx")
+    shutil.copy(os.path.join(root, "tests", "golden", "test.mtx"), mtx)
+    env = dict(os.environ, TILESPMV_WARMUP="2", TILESPMV_BENCH_REPEAT="5")
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([exe, "-d", "0", mtx, "--cache"], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout)
+    assert "cache: CSR parsed from the text and saved to" in outs[0] and "cache: Tile_matrix created" in outs[0]
+    assert "cache: CSR read from" in outs[1] and "cache: Tile_matrix read from" in outs[1]
+    for o in outs:
+        pos = -1
+        for w in ["input matrix A: ( 192, 192 ) nnz = 6845", "loadfile time", "The number of tile = ", "Run CPU TileSpMV, errcount = 0", "CUDA SpMV runtime", "Check... PASS!"]:
+            nxt = o.find(w, pos + 1)
+            assert nxt > pos, (w, o)
+            pos = nxt
+    tiles = [l for o in outs for l in o.splitlines() if "The number of tile" in l]
+    assert tiles[0] == tiles[1]
+    r = subprocess.run([exe, "-d", "0", mtx, "--cache=" + str(tmp_path / "elsewhere"), "--combine=none"], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and os.path.exists(str(tmp_path / "elsewhere.csr_f64")) and os.path.exists(str(tmp_path / "elsewhere.tile_f64"))
+
+
+def test_rccl_collectives_on_the_real_y_world_size_one():
+    """The y combine through RCCL itself (backend "nccl", one rank — all this box has): all_reduce and all_gather_into_tensor on
+    the device vector the plan wrote (ShardedSpMV.combine(force=True)), in a child process so that the process group never
+    meets the other tests' state.  y must come back bit-identical."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import os, sys, numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        from tilespmv_amd import generators as G
+        from tilespmv_amd.dist import ShardedSpMV
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        assert dist.get_backend() == "nccl"
+        m, n, rp, ci = G.laplacian5pt(256)
+        vals, x = G.compat_values(len(ci)), G.compat_x(n)
+        sh = ShardedSpMV(0, 1, m, n, rp, ci, vals, np.float64)
+        xd = torch.from_numpy(x).cuda(); yd = torch.zeros(m + 16, dtype=torch.float64, device="cuda")
+        sh.spmv(xd, yd, torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+        want = yd.clone()
+        for mode in ("allreduce", "allgather"):
+            sh.combine(yd, mode, force=True); torch.cuda.synchronize()
+            assert torch.equal(yd, want), mode
+        import scipy.sparse as sp
+        assert np.array_equal(yd.cpu().numpy()[:m], sp.csr_matrix((vals, ci, rp), shape=(m, n)) @ x)
+        dist.destroy_process_group()
+        print("RCCL-OK")
+    """ % root)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

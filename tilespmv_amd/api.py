@@ -18,7 +18,7 @@ _I, _U = _lib._I, _lib._U
 COO_AUTO, COO_IN_TILE, COO_FALLBACK = 0, 1, 2
 DENSE_AUTO, DENSE_MFMA, DENSE_VALU = 0, 1, 2
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_STREAM = 0, 1, 2
-CREATE_HYB, CREATE_QUIET = 1, 2
+CREATE_HYB, CREATE_QUIET, CREATE_CDNA4 = 1, 2, 4
 
 
 def _p(a, t):
@@ -39,12 +39,12 @@ def _csr(lib, rowptr, colidx, vals):
             np.ascontiguousarray(vals, dtype=lib._dtype))
 
 
-def Tile_create(rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, hyb=False, quiet=True):
+def Tile_create(rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, hyb=False, quiet=True, cdna4=False):
     dtype = np.dtype(dtype or np.asarray(csrValA).dtype)
     lib = _lib.load(dtype)
     rp, ci, v = _csr(lib, csrRowPtrA, csrColIdxA, csrValA)
     tm = lib._TM()
-    flags = (CREATE_HYB if hyb else 0) | (CREATE_QUIET if quiet else 0)
+    flags = (CREATE_HYB if hyb else 0) | (CREATE_QUIET if quiet else 0) | (CREATE_CDNA4 if cdna4 else 0)
     lib.Tile_create_ex(C.byref(tm), rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int), _p(v, lib._vt), flags)
     tm._keep = (rp, ci, v)
     tm._lib = lib

@@ -481,10 +481,11 @@ hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream
 // (512 threads: twice as many tile-rows share one column-ordered list, so fewer distinct x lines per entry; same waves per SIMD).
 // XWIN: x-window plans (hip_plan.h) — the workgroup's strips form a brick of the grid, the x segments (column blocks) their
 // units touch are loaded ONCE per workgroup into LDS (dynamic shared memory, sized by the plan) and the units read x from there;
-// the descriptor's low 24 bits then hold the window slot.  Strips of such plans have at most XWIN_STRIP_ROWS tile-rows.
+// the descriptor's low 24 bits then hold the window slot.  Strips of such plans have at most XWIN_STRIP_ROWS tile-rows.  (The window
+// leaves room for 4-5 workgroups per CU, so the workgroup-entry form is built for 4 waves per SIMD: at 6 it spills 20 bytes.)
 extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
 template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN>
-__global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+__global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
@@ -1239,11 +1240,11 @@ hipError_t launch_columns_to_rows(const val_t *YT, int nvec, long long row0, lon
     return hipGetLastError();
 }
 
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xwin_lds_bytes, int xcd_remap, int xcd_chunk,
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xwin_lds_bytes, int lds_pad_bytes, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st)
 {
     if (S.ntasks > 0) {
-#define TSPMV_L2(X, W, B, XW) hipLaunchKernelGGL((k_units<4, X, W, B, XW>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), XW ? (size_t)xwin_lds_bytes : 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_L2(X, W, B, XW) hipLaunchKernelGGL((k_units<4, X, W, B, XW>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
 #define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L2(X, 2, 16, true); else if (xwin_lds_bytes > 0) TSPMV_L2(X, 0, 16, true); \
         else if (entry_mode == 2 && wg_strips == 32) TSPMV_L2(X, 2, 32, false); else if (entry_mode == 2) TSPMV_L2(X, 2, 16, false); \
         else if (entry_mode == 1) TSPMV_L2(X, 1, 16, false); else TSPMV_L2(X, 0, 16, false); } while (0)

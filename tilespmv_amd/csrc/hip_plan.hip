@@ -19,7 +19,7 @@
 namespace tilespmv {
 
 hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulate, bool fixup, const val_t *x, val_t *y, hipStream_t st);
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xwin_lds_bytes, int xcd_remap, int xcd_chunk,
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xwin_lds_bytes, int lds_pad_bytes, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, const val_t *X, val_t *Y,
@@ -64,6 +64,7 @@ struct Knobs {
     int wg_strips;       // -1 = chosen from the shard
     int x_window;        // -1 = default
     int x_stride1, x_stride2;   // tile-rows per grid line / plane for the x windows; 0 = detected from the shard
+    int lds_pad;         // bytes of unused LDS added to every unit-kernel workgroup (fewer resident workgroups per CU); -1 = chosen from the shard
     int mv_native;       // -1 = by nvec
     int mv_xcd_chunk;    // -1 = the plan's XCD chunk
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
@@ -102,6 +103,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.x_window = pick(o.x_window, "TILESPMV_X_WINDOW", -1);
     k.x_stride1 = pick(o.x_stride1, "TILESPMV_X_STRIDE1", 0);
     k.x_stride2 = pick(o.x_stride2, "TILESPMV_X_STRIDE2", 0);
+    k.lds_pad = pick(o.lds_pad, "TILESPMV_LDS_PAD", -1);
     k.mv_native = pick(o.mv_native, "TILESPMV_MV_NATIVE", -1);
     k.mv_xcd_chunk = pick(o.mv_xcd_chunk, "TILESPMV_MV_XCD_CHUNK", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
@@ -130,6 +132,7 @@ struct tilespmv_plan {
     int coo_mode = 0, dense_mode = 0, kernel = 0;
     int device = 0;
     int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
+    int lds_pad_bytes = 0;              // extra (unused) dynamic LDS per workgroup of the unit kernel: caps the workgroups resident on a CU (knob lds_pad)
     int xwin_lds_bytes = 0;             // x-window plans: dynamic LDS of the unit kernel (largest window of the plan); 0 = no windows
     bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
     unsigned long long digest = 1469598103934665603ull;
@@ -1223,6 +1226,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     plan->xcd_remap = K.xcd_remap;  // 0 = round-robin, 2 = windows of 8 x xcd_chunk workgroups
     plan->xcd_chunk = K.xcd_chunk;
     plan->mv_native = K.mv_native; plan->mv_xcd_chunk = K.mv_xcd_chunk;
+    plan->lds_pad_bytes = K.lds_pad > 0 ? std::min(K.lds_pad, 40 * 1024) : 0;
     // Strip size: ~400 cost units (20 units) amortises the per-strip round trips; measured flat between 200
     // and 800 on large matrices and neutral on small (cache-resident) ones, where launch latency dominates.
     const int target_env = K.strip_cost, split_env = K.split_above;
@@ -1455,7 +1459,7 @@ int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYP
 {
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = plan->dense_mode == TILESPMV_DENSE_MFMA;
-    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, plan->dn, mfma, plan->entry_mode, plan->wg_strips, plan->xwin_lds_bytes, plan->xcd_remap, plan->xcd_chunk, d_x, d_y, st)
+    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, plan->dn, mfma, plan->entry_mode, plan->wg_strips, plan->xwin_lds_bytes, plan->lds_pad_bytes, plan->xcd_remap, plan->xcd_chunk, d_x, d_y, st)
                                                           : launch_tiles_direct(plan->dev, mfma, false, true, d_x, d_y, st);
     if (e != hipSuccess) return (int)e;
     return (int)launch_fallback(plan->dev, d_x, d_y, st);

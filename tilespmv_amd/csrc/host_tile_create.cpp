@@ -19,9 +19,37 @@ namespace {
 struct Choice { int fmt = 0, stored = 0, width = 0, ndr = 0, ndc = 0, hybcoo = 0, extracted = 0, csrptr = 0; };
 
 // One tile.  cnt_row[r]: entries in local row r.  lrc: (row<<4|col) byte of each entry.
-Choice select_format(int nnz, int rowlen, int collen, const uint8_t *cnt_row, const uint8_t *lrc, bool allow_hyb)
+Choice select_format(int nnz, int rowlen, int collen, const uint8_t *cnt_row, const uint8_t *lrc, bool allow_hyb, bool cdna4)
 {
     Choice c;
+    if (cdna4) {
+        // TILESPMV_CREATE_CDNA4 (opt-in; SURVEY S8 f3, selection side): the reference's thresholds (dense at 75 % fill, COO up to
+        // COO_NNZ_TH entries, ELL at a row-length variation of 0.2: src/csr2tile.h:150,159,267-270) were tuned for the byte costs of
+        // its 32-lane kernels.  Here every format runs as 16-value units (12-byte descriptor + 16 values) plus 13- / 9-byte entries,
+        // so the choice is made by those bytes: w = the unit width that minimises units + remainder entries; w = 0 -> COO (while it
+        // fits the reference's COO tile), w = widest row -> ELL, in between CSR (which the plan splits at that very w); dense when
+        // 16 whole columns are cheaper than that.  Whole-row / whole-column tiles keep the reference rule (exact patterns only).
+        const int sv = (int)sizeof(val_t);
+        const long long unit_b = 12 + 16LL * sv, entry_b = sv + 5;
+        int widest = 0;
+        for (int r = 0; r < rowlen; r++) widest = std::max<int>(widest, cnt_row[r]);
+        int best_w = 0; long long best = entry_b * nnz;
+        for (int w = 1; w <= widest; w++) {
+            int rem = 0;
+            for (int r = 0; r < rowlen; r++) rem += std::max(0, (int)cnt_row[r] - w);
+            const long long b = unit_b * w + entry_b * rem;
+            if (b < best) { best = b; best_w = w; }
+        }
+        if ((long long)collen * unit_b <= best) { c.fmt = TILESPMV_FMT_DNS; c.stored = rowlen * collen; return c; }
+        if (nnz % collen == 0 || nnz % rowlen == 0) {
+            Choice r = select_format(nnz, rowlen, collen, cnt_row, lrc, false, false);
+            if (r.fmt == TILESPMV_FMT_DNSROW || r.fmt == TILESPMV_FMT_DNSCOL) return r;
+        }
+        if (best_w == 0 && nnz <= TILESPMV_COO_NNZ_TH) { c.fmt = TILESPMV_FMT_COO; c.stored = nnz; c.extracted = nnz; return c; }
+        if (best_w == widest && widest > 0) { c.fmt = TILESPMV_FMT_ELL; c.width = widest; c.stored = widest * rowlen; return c; }
+        c.fmt = TILESPMV_FMT_CSR; c.stored = nnz; c.csrptr = rowlen;
+        return c;
+    }
     if (nnz >= (int)(rowlen * collen * 0.75)) {  // near-dense tile stored dense (src/csr2tile.h:150-158)
         c.fmt = TILESPMV_FMT_DNS; c.stored = rowlen * collen; return c;
     }
@@ -111,7 +139,7 @@ void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *ro
                       const val_t *vals, unsigned flags)
 {
     memset(T, 0, sizeof(*T));
-    const bool allow_hyb = flags & TILESPMV_CREATE_HYB;
+    const bool allow_hyb = flags & TILESPMV_CREATE_HYB, cdna4 = flags & TILESPMV_CREATE_CDNA4;
     const int tilem = (rowA + BS - 1) / BS, tilen = (colA + BS - 1) / BS;
     T->tilem = tilem; T->tilen = tilen;
     T->tile_ptr = zalloc<int>((size_t)tilem + 1);
@@ -206,7 +234,7 @@ void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *ro
             for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
                 const int collen = tile_collen(T->tile_columnidx[t], tilen, colA);
                 const int n = T->tile_nnz[t + 1] - T->tile_nnz[t];
-                Choice c = select_format(n, rowlen, collen, cnt_row + (size_t)t * BS, lrc + T->tile_nnz[t], allow_hyb);
+                Choice c = select_format(n, rowlen, collen, cnt_row + (size_t)t * BS, lrc + T->tile_nnz[t], allow_hyb, cdna4);
                 T->Format[t] = (char)c.fmt;
                 T->blknnz[t] = c.stored;
                 T->blknnznnz[t] = (unsigned char)c.stored;

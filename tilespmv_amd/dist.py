@@ -46,13 +46,23 @@ class ShardedSpMV:
     exercised without a GPU.
     """
 
-    def __init__(self, rank, world, rows, cols, rowptr, colidx, vals, dtype=np.float64, make_local=None, **plan_kw):
+    def __init__(self, rank, world, rows, cols, rowptr, colidx, vals, dtype=np.float64, make_local=None, bounds=None, tile_cache=None, **plan_kw):
+        """``bounds`` given: ``rowptr / colidx / vals`` are THIS RANK'S row block only (row pointer rebased to 0, global
+        column ids) and ``bounds`` the row partition everybody agreed on — a rank then never holds the whole matrix.
+        ``tile_cache``: path of a Tile_matrix cache for this rank's block (read when present and of the right shape, written
+        otherwise: api.matrix_load / matrix_save)."""
         from . import api
         self.rank, self.world, self.rows, self.cols = rank, world, rows, cols
         self.dtype = np.dtype(dtype)
-        self.bounds = partition_rows(rowptr, rows, world)
-        self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
-        rp, ci, v = shard_csr(rowptr, colidx, vals, self.r0, self.r1)
+        if bounds is None:
+            self.bounds = partition_rows(rowptr, rows, world)
+            self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
+            rp, ci, v = shard_csr(rowptr, colidx, vals, self.r0, self.r1)
+        else:
+            self.bounds = np.asarray(bounds, dtype=np.int64)
+            self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
+            rp, ci, v = rowptr, colidx, vals
+            assert len(rp) == self.r1 - self.r0 + 1 and int(rp[0]) == 0
         self.local_rows, self.local_nnz = self.r1 - self.r0, int(rp[-1])
         self.seconds = {}
         if make_local is not None:
@@ -61,7 +71,26 @@ class ShardedSpMV:
         else:
             import time
             t0 = time.perf_counter()
-            self.tm = api.Tile_create(self.local_rows, cols, self.local_nnz, rp, ci, v, dtype=self.dtype)
+            self.tm, self.tile_cache = None, None
+            if tile_cache is not None:
+                import os
+                self.tile_cache = "miss"
+                if os.path.exists(tile_cache):
+                    try:
+                        tm, r2, c2, z2 = api.matrix_load(tile_cache, self.dtype)
+                        if (r2, c2, z2) == (self.local_rows, cols, self.local_nnz):
+                            self.tm, self.tile_cache = tm, "hit"
+                        else:
+                            api.Tile_destroy(tm)
+                    except OSError:
+                        pass
+            if self.tm is None:
+                self.tm = api.Tile_create(self.local_rows, cols, self.local_nnz, rp, ci, v, dtype=self.dtype)
+                if tile_cache is not None:
+                    try:
+                        api.matrix_save(self.tm, self.local_rows, cols, self.local_nnz, tile_cache)
+                    except OSError:
+                        self.tile_cache = "miss, not writable"
             t1 = time.perf_counter()
             self.local = api.Plan(self.tm, self.local_rows, cols, self.local_nnz, **plan_kw)
             t2 = time.perf_counter()
@@ -85,10 +114,12 @@ class ShardedSpMV:
         else:
             self.local.spmv_n(x.data_ptr(), yp, stream, count)
 
-    def combine(self, y_full, mode):
+    def combine(self, y_full, mode, force=False):
+        """``force``: run the collective even in a 1-rank group (a no-op numerically) — lets a single-GPU box push the real y
+        through RCCL's all_reduce / all_gather_into_tensor (tests/test_gpu_parity.py)."""
         import torch
         import torch.distributed as dist
-        if self.world == 1 or mode == "none":
+        if mode == "none" or (self.world == 1 and not force):
             return
         if mode == "allreduce":
             if self.r0 > 0:

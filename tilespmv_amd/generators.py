@@ -11,12 +11,31 @@ the caller: ``compat_values`` reproduces the reference driver's synthetic data
 import numpy as np
 
 
-def compat_values(nnz, dtype=np.float64):
-    return (np.arange(nnz, dtype=np.int64) % 10).astype(dtype)
+def compat_values(nnz, dtype=np.float64, first=0):
+    """val[i] = i % 10 over the GLOBAL nonzero index i; ``first`` = index of this block's first nonzero."""
+    return ((np.arange(nnz, dtype=np.int64) + int(first)) % 10).astype(dtype)
 
 
 def compat_x(n, dtype=np.float64):
     return (np.arange(n, dtype=np.int64) % 10).astype(dtype)
+
+
+REAL_SEED = 12345
+
+
+def real_values(nnz, dtype=np.float64, first=0):
+    """SURVEY.md S8(d) data mode (ii): vals ~ U(-1, 1), seed 12345 — nonzeros [first, first + nnz) of ONE global stream
+    (PCG64 advanced to ``first``: a rank generates only its own block and still sees the values a one-rank run would)."""
+    bg = np.random.PCG64(REAL_SEED)
+    bg.advance(int(first))
+    return np.random.Generator(bg).uniform(-1.0, 1.0, int(nnz)).astype(dtype)
+
+
+def real_x(n, nnz_total, dtype=np.float64):
+    """x ~ U(-1, 1) from the same stream, right behind the ``nnz_total`` values (the order tests/cases.values_for uses)."""
+    bg = np.random.PCG64(REAL_SEED)
+    bg.advance(int(nnz_total))
+    return np.random.Generator(bg).uniform(-1.0, 1.0, int(n)).astype(dtype)
 
 
 def _from_mask(cand, mask):
@@ -29,27 +48,52 @@ def _from_mask(cand, mask):
     return rowptr.astype(np.int32), colidx
 
 
-def laplacian5pt(n):
+def _block(cand_fn, N, rows):
+    """Rows [r0, r1) of a stencil matrix: (N, N, rowptr rebased to 0, colidx) — only that block is ever materialised."""
+    r0, r1 = (0, N) if rows is None else (int(rows[0]), int(rows[1]))
+    idx = np.arange(r0, r1, dtype=np.int64)
+    cand, mask = cand_fn(idx)
+    rowptr, colidx = _from_mask(cand, mask)
+    return N, N, rowptr, colidx
+
+
+def laplacian5pt(n, rows=None):
     """5-point stencil on an n x n row-major grid; per-row order up,left,centre,right,down
-    (SURVEY.md §8c known-answer generator; BASELINE config 4 is n=4096)."""
-    N = n * n
-    idx = np.arange(N, dtype=np.int64)
+    (SURVEY.md §8c known-answer generator; BASELINE config 4 is n=4096).  ``rows=(r0, r1)``: only that row block
+    (global column ids, row pointer rebased) — what one rank of a sharded run generates."""
+    def cand_fn(idx):
+        i, j = idx // n, idx % n
+        return (np.stack([idx - n, idx - 1, idx, idx + 1, idx + n], axis=1),
+                np.stack([i > 0, j > 0, np.ones(idx.size, bool), j < n - 1, i < n - 1], axis=1))
+    return _block(cand_fn, n * n, rows)
+
+
+def laplacian5pt_rowptr(n):
+    """Row pointer of laplacian5pt(n) alone (int64): cheap, lets every rank cut the same nnz-balanced partition."""
+    idx = np.arange(n * n, dtype=np.int64)
     i, j = idx // n, idx % n
-    cand = np.stack([idx - n, idx - 1, idx, idx + 1, idx + n], axis=1)
-    mask = np.stack([i > 0, j > 0, np.ones(N, bool), j < n - 1, i < n - 1], axis=1)
-    rowptr, colidx = _from_mask(cand, mask)
-    return N, N, rowptr, colidx
+    deg = 5 - (i == 0) - (i == n - 1) - (j == 0) - (j == n - 1)
+    rp = np.zeros(n * n + 1, dtype=np.int64)
+    np.cumsum(deg, out=rp[1:])
+    return rp
 
 
-def laplacian7pt(n):
-    """7-point stencil on an n^3 grid (row-major), per-row order by ascending column."""
-    N = n * n * n
-    idx = np.arange(N, dtype=np.int64)
+def laplacian7pt(n, rows=None):
+    """7-point stencil on an n^3 grid (row-major), per-row order by ascending column.  ``rows``: see laplacian5pt."""
+    def cand_fn(idx):
+        k, j, i = idx // (n * n), (idx // n) % n, idx % n
+        return (np.stack([idx - n * n, idx - n, idx - 1, idx, idx + 1, idx + n, idx + n * n], axis=1),
+                np.stack([k > 0, j > 0, i > 0, np.ones(idx.size, bool), i < n - 1, j < n - 1, k < n - 1], axis=1))
+    return _block(cand_fn, n * n * n, rows)
+
+
+def laplacian7pt_rowptr(n):
+    idx = np.arange(n * n * n, dtype=np.int64)
     k, j, i = idx // (n * n), (idx // n) % n, idx % n
-    cand = np.stack([idx - n * n, idx - n, idx - 1, idx, idx + 1, idx + n, idx + n * n], axis=1)
-    mask = np.stack([k > 0, j > 0, i > 0, np.ones(N, bool), i < n - 1, j < n - 1, k < n - 1], axis=1)
-    rowptr, colidx = _from_mask(cand, mask)
-    return N, N, rowptr, colidx
+    deg = 7 - (k == 0) - (k == n - 1) - (j == 0) - (j == n - 1) - (i == 0) - (i == n - 1)
+    rp = np.zeros(n * n * n + 1, dtype=np.int64)
+    np.cumsum(deg, out=rp[1:])
+    return rp
 
 
 def band(n, hbw, ncols=None):

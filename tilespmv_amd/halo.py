@@ -32,7 +32,7 @@ class HaloSpMV:
     """
 
     def __init__(self, rank, world, n, rowptr, colidx, vals, dtype=np.float64, make_local=None, device="cuda",
-                 overlap=True, group=None, **plan_kw):
+                 overlap=True, group=None, bounds=None, **plan_kw):
         import torch
         import torch.distributed as dist
         from . import api
@@ -42,10 +42,15 @@ class HaloSpMV:
         self.dtype = np.dtype(dtype)
         self.tdtype = torch.float64 if self.dtype == np.float64 else torch.float32
         self.device = torch.device(device)
-        self.bounds = partition_rows(rowptr, n, world)
-        self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
+        if bounds is None:
+            self.bounds = partition_rows(rowptr, n, world)
+            self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
+            rp, ci, v = shard_csr(rowptr, colidx, vals, self.r0, self.r1)
+        else:   # rowptr / colidx / vals are this rank's row block only (rebased row pointer, global columns): see ShardedSpMV
+            self.bounds = np.asarray(bounds, dtype=np.int64)
+            self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
+            rp, ci, v = rowptr, colidx, vals
         self.nloc = self.r1 - self.r0
-        rp, ci, v = shard_csr(rowptr, colidx, vals, self.r0, self.r1)
         ci = np.asarray(ci, dtype=np.int64)
 
         # ---- columns -> [own | halo] index space
