@@ -277,7 +277,8 @@ typedef struct {
     int coo_piece;      /* entries per piece of a split tile-row                                             TILESPMV_COO_PIECE */
     int strip_even;     /* strips end on multiples of this many units                                        TILESPMV_STRIP_EVEN */
     int wg_strips;      /* workgroup entry mode: 16 (256-thread workgroups) or 32 (512 threads) strips per workgroup  TILESPMV_WG_STRIPS */
-    int x_window;       /* stencil-like shards: 1 = workgroups own bricks of the grid and stage their x window in LDS, 0 = off   TILESPMV_X_WINDOW */
+    int x_window;       /* stencil-like shards: -1 / unset = brick task order on large 3-D shards, 0 = off, 2 = brick order wherever grid strides are
+                           found, 1 = brick order + the workgroup's x segments staged in LDS (measured slower; opt-in)          TILESPMV_X_WINDOW */
     int x_stride1;      /* ... tile-rows per grid line (0 / unset: detected from the shard)                  TILESPMV_X_STRIDE1 */
     int x_stride2;      /* ... tile-rows per grid plane (0 / unset: detected; none for 2-D problems)         TILESPMV_X_STRIDE2 */
     int mv_native;      /* tilespmv_plan_spmm on entry-dominated plans: 1 multi-vector kernel, 0 one vector at a time           TILESPMV_MV_NATIVE */
@@ -359,6 +360,7 @@ enum {
     TILESPMV_INFO_WG_STRIPS = 16,     /* strips per workgroup of the unit kernel (16 or 32) */
     TILESPMV_INFO_X_WINDOW_SLOTS = 17,    /* x-window plans: column blocks of the largest workgroup window (0 = no windows) */
     TILESPMV_INFO_X_WINDOW_SEGMENTS = 18, /* ... and of all windows together: x segments (16 values each) loaded per SpMV */
+    TILESPMV_INFO_BRICK_ORDER = 19,       /* 1: the strips were regrouped into bricks of the grid (stencil-like shard) */
     TILESPMV_INFO_COUNT = 20
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);

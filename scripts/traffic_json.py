@@ -38,7 +38,9 @@ bench = None
 for line in open(os.path.join(d, "bench_under_trace.json")):
     if line.startswith("{"):
         bench = json.loads(line)
-out = {"workload": wl, "dtype": dt, "kernel": dom, "measured": time.strftime("round 2, %Y-%m-%d"),
+out = {"workload": wl, "dtype": dt, "kernel": dom, "measured": time.strftime("round 3, %Y-%m-%d"),
+       # the plan these passes measured: bench.py reports `traffic` only while its live plan has the same fingerprint
+       "plan_fingerprint": None if bench is None else (bench.get("roofline") or {}).get("plan_fingerprint"),
        "FETCH_SIZE_kb": per.get(dom, {}).get("FETCH_SIZE_kb"), "WRITE_SIZE_kb": per.get(dom, {}).get("WRITE_SIZE_kb"),
        "fetch_correction": factor, "hbm_bytes_per_launch": per.get(dom, {}).get("bytes_per_launch"),
        "all_kernels_bytes_per_launch": {k: t["bytes_per_launch"] for k, t in per.items()},

@@ -51,6 +51,25 @@ def test_every_entry_mode_packs_and_decodes(name, dtype):
     api.Tile_destroy(tm)
 
 
+def test_brick_order_is_detected_on_3d_grids_only():
+    """Stride detection + brick order: 3-D stencils (7-point cube, the KKT stand-in) get it by default once they are large,
+    2-D stencils and irregular matrices do not; x_window=0 switches it off; the layout stays deterministic."""
+    cases_ = {"lap3d96": (G.laplacian7pt(96), True), "kkt48": (G.nlpkkt_like(48, target_nnz=None), True),
+              "lap2d1024": (G.laplacian5pt(1024), False), "powerlaw200k": (cases.MEDIUM["powerlaw200k"](), False)}
+    for name, ((m, n, rp, ci), want3d) in cases_.items():
+        rows = cases.truncated_rows(m); nnz = int(rp[rows])
+        tm = api.Tile_create(rows, n, nnz, rp, ci, G.compat_values(len(ci)))
+        d_auto, i_auto = api.plan_layout_digest(tm, rows, n, nnz, strip_cost=100)          # (small strips: enough workgroups to count as large)
+        d_off, i_off = api.plan_layout_digest(tm, rows, n, nnz, strip_cost=100, x_window=0)
+        d_on, i_on = api.plan_layout_digest(tm, rows, n, nnz, strip_cost=100, x_window=2)
+        assert i_off["brick_order"] == 0
+        assert i_auto["brick_order"] == (1 if want3d else 0), name
+        assert i_on["brick_order"] == (1 if name != "powerlaw200k" else 0), name             # forced: wherever strides exist (2-D too)
+        assert (d_auto != d_off) == want3d
+        assert api.plan_layout_digest(tm, rows, n, nnz, strip_cost=100)[0] == d_auto
+        api.Tile_destroy(tm)
+
+
 def test_environment_is_only_a_default(monkeypatch):
     tm, rows, n, nnz = _tm("powerlaw20k")
     by_option, info = api.plan_layout_digest(tm, rows, n, nnz, entry_mode=2, strip_cost=800, entry_ordered=1)

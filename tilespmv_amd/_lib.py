@@ -18,7 +18,7 @@ _CACHE = {}
 
 INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel",
               "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us", "entry_mode", "entry_ordered", "strip_cost",
-              "wg_strips", "x_window_slots", "x_window_segments", "reserved19"]
+              "wg_strips", "x_window_slots", "x_window_segments", "brick_order"]
 
 
 KNOB_DEFAULT = -1

@@ -65,6 +65,7 @@ struct Knobs {
     int x_window;        // -1 = default
     int x_stride1, x_stride2;   // tile-rows per grid line / plane for the x windows; 0 = detected from the shard
     int lds_pad;         // bytes of unused LDS added to every unit-kernel workgroup (fewer resident workgroups per CU); -1 = chosen from the shard
+    int brick_rows;      // brick order: tile-rows per strip at most (experiment knob, environment only)
     int mv_native;       // -1 = by nvec
     int mv_xcd_chunk;    // -1 = the plan's XCD chunk
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
@@ -104,6 +105,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.x_stride1 = pick(o.x_stride1, "TILESPMV_X_STRIDE1", 0);
     k.x_stride2 = pick(o.x_stride2, "TILESPMV_X_STRIDE2", 0);
     k.lds_pad = pick(o.lds_pad, "TILESPMV_LDS_PAD", -1);
+    k.brick_rows = env_int("TILESPMV_BRICK_ROWS", 0);
     k.mv_native = pick(o.mv_native, "TILESPMV_MV_NATIVE", -1);
     k.mv_xcd_chunk = pick(o.mv_xcd_chunk, "TILESPMV_MV_XCD_CHUNK", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
@@ -134,6 +136,7 @@ struct tilespmv_plan {
     int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
     int lds_pad_bytes = 0;              // extra (unused) dynamic LDS per workgroup of the unit kernel: caps the workgroups resident on a CU (knob lds_pad)
     int xwin_lds_bytes = 0;             // x-window plans: dynamic LDS of the unit kernel (largest window of the plan); 0 = no windows
+    char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20;   // bump allocator of upload()
     bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
     unsigned long long digest = 1469598103934665603ull;
     template <class T>
@@ -150,8 +153,18 @@ struct tilespmv_plan {
         }
         const double t0 = now_us();
         void *d = nullptr;
-        HIP_TRY(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T) + 256));  // slack: masked tail lanes never fault
-        allocs.push_back(d);
+        // Streams are carved out of a few large device blocks (bump allocation, 256-byte aligned + 256 bytes of slack so that
+        // masked tail lanes never fault) instead of one hipMalloc each: a plan is ~20 streams, and large blocks get large
+        // page-table fragments whatever state the allocator is in (fewer hipMalloc calls, too).
+        const size_t need = (std::max<size_t>(n, 1) * sizeof(T) + 256 + 255) / 256 * 256;
+        if (need > arena_left) {
+            const size_t blk = std::max<size_t>(need, arena_block);
+            void *b = nullptr;
+            HIP_TRY(hipMalloc(&b, blk));
+            allocs.push_back(b);
+            arena_at = (char *)b; arena_left = blk;
+        }
+        d = arena_at; arena_at += need; arena_left -= need;
         if (n) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
         info[TILESPMV_INFO_DEVICE_BYTES] += (long long)(n * sizeof(T));
         info[TILESPMV_INFO_UPLOAD_US] += (long long)(now_us() - t0);
@@ -484,13 +497,22 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     // TILESPMV_COO_ORDERED=1 asks for reproducible bits.  Modes 0 and 1 are always ordered (one wavefront per slab).
     const int ordered_env = K.entry_ordered;
     const bool coo_ordered = ordered_env >= 0 ? ordered_env != 0 : est_wgs >= 2048;
-    // ---- x windows (stencil-like shards): strips stay inside one grid line and have at most XWIN_STRIP_ROWS tile-rows; after the
-    // cut the strips are regrouped so that the 16 strips of a workgroup form a brick of the grid (below)
+    // ---- brick order (stencil-like shards): the grid strides of the shard are detected from its tile pattern, strips stay inside
+    // one grid line, and after the cut the strips are regrouped so that the 16 strips of a workgroup — and the neighbouring
+    // workgroups of an XCD window — form a brick of the grid instead of a run of one grid line: the x segments a tile-row shares
+    // with its neighbours in the other two directions are then wanted at about the same time by one CU / one XCD, and hit in L1 /
+    // L2 instead of being fetched again (nlpkkt160 stand-in fp64: 3.07 -> 2.64 GB per launch at the fabric, 0.464 -> 0.410 ms).
+    //   x_window  -1 (default): brick order on large 3-D shards   0: off   2: brick order wherever strides are found
+    //              1: brick order + the workgroup's x segments staged once in LDS ("x windows": strips of at most XWIN_STRIP_ROWS
+    //                 tile-rows; cuts another ~0.4 GB but runs 25 % slower — profiles/r03_xwindow_and_map.txt; opt-in only)
     int xs1 = K.x_stride1 > 0 ? K.x_stride1 : 0, xs2 = K.x_stride2 > 0 ? K.x_stride2 : 0;
-    bool xwin = K.x_window > 0 && entry_mode != 1 && wg_strips == 16;
-    if (xwin && xs1 == 0) detect_strides(T, tr0, tr1, csr_split, dense_mfma, &xs1, &xs2);
-    if (xs1 < 2) xwin = false;
-    const int max_strip_rows = xwin ? XWIN_STRIP_ROWS : STRIP_MAX_ROWS;
+    bool brick = K.x_window != 0 && entry_mode != 1 && wg_strips == 16 && (K.x_window > 0 || est_wgs >= 2048);
+    if (brick && xs1 == 0) detect_strides(T, tr0, tr1, csr_split, dense_mfma, &xs1, &xs2);
+    if (xs1 < 2 || (K.x_window < 0 && xs2 == 0)) brick = false;   // (2-D grids: measured neutral on the 5-point 4096^2 case)
+    bool xwin = brick && K.x_window == 1;
+    // (strips of at most 4 tile-rows in brick plans: nlpkkt160 stand-in fp64 0.418 -> 0.414 ms, fp32 0.252 -> 0.250; 2 rows: KKT 0.408 but 7-pt 256^3 +5 %)
+    const int max_strip_rows = xwin ? XWIN_STRIP_ROWS : brick ? (K.brick_rows > 0 ? std::min(K.brick_rows, STRIP_MAX_ROWS) : 4) : STRIP_MAX_ROWS;
+    if (brick && !K.xcd_from_caller) plan->xcd_chunk = 8;   // bricks are compact: smaller XCD windows keep an XCD's resident set together
     std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
     const int npartial0 = npartial;
     auto cut = [&](int target) {
@@ -570,7 +592,7 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
             {
                 long long cc = 0;
                 while (jend < ntr && jend - i < max_strip_rows && !must_split(jend)) {
-                    if (xwin && jend > i && (tr0 + jend) % xs1 == 0) break;   // x-window plans: a strip stays inside one grid line
+                    if (brick && jend > i && (tr0 + jend) % xs1 == 0) break;   // brick order: a strip stays inside one grid line
                     const long long nc = cc + rc_[jend].cost;
                     // entry-heavy shards round to the nearest strip size (rows cost 100-400 each there: "never above the target"
                     // would leave most strips half empty and double the number of wavefronts)
@@ -582,7 +604,7 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
                 auto pad = [&](int e) { return (int)((quantum - (pu[e] - pu[i]) % quantum) % quantum); };
                 if (strip_even && pad(jend) > 0) {
                     int best = jend;
-                    if (jend < ntr && jend - i < max_strip_rows && !(xwin && (tr0 + jend) % xs1 == 0) && !must_split(jend) && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
+                    if (jend < ntr && jend - i < max_strip_rows && !(brick && (tr0 + jend) % xs1 == 0) && !must_split(jend) && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
                     if (best == jend && jend - i >= 3 && pad(jend - 1) < pad(best)) best = jend - 1;
                     jend = best;
                 }
@@ -747,7 +769,7 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     std::vector<int> h_win_cb;
     int xwin_slots_max = 0;
     long long xwin_segments = 0, xwin_wgs = 0;
-    if (xwin && !tasks.empty()) {
+    if (brick && !tasks.empty()) {
         const size_t nt = tasks.size();
         // grid coordinates of every strip: position in its line (ordinal of the strip), line in its plane, plane
         std::vector<int> sx(nt), ly(nt), lz(nt);
@@ -804,7 +826,8 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
         h_udesc_cb = h_udesc;
         h_wg_win.assign(nwg, make_int2(0, 0));
         std::vector<std::vector<int>> wg_blocks(nwg);
-        parallel_chunks((int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
+        const bool order_only = !xwin;   // brick order alone: x is still gathered from global memory (through L1 / L2)
+        parallel_chunks(order_only ? 0 : (int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
             for (int64_t w = b; w < e; w++) {
                 std::vector<int> &bl = wg_blocks[(size_t)w];
                 for (size_t t = 16 * (size_t)w; t < std::min(nt, 16 * (size_t)w + 16); t++) blocks_of(tasks[t], bl);
@@ -826,10 +849,11 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
             xwin_segments += (long long)wg_blocks[w].size(); xwin_wgs += !wg_blocks[w].empty();
         }
         if (xwin_slots_max == 0) { xwin = false; h_udesc_cb.clear(); }
-        else if (getenv("TILESPMV_PLAN_VERBOSE"))
-            fprintf(stderr, "tilespmv: x windows: strides %d / %d tile-rows, brick %d x %d x %d strips, %lld of %zu workgroups windowed, %.1f slots on average, %d at most\n",
-                    xs1, xs2, best_shape.px, best_shape.py, best_shape.pz, xwin_wgs, nwg, xwin_wgs ? (double)xwin_segments / (double)xwin_wgs : 0.0, xwin_slots_max);
-    } else xwin = false;
+        if (getenv("TILESPMV_PLAN_VERBOSE"))
+            fprintf(stderr, "tilespmv: brick order: strides %d / %d tile-rows, brick %d x %d x %d strips, %.1f distinct column blocks per workgroup on the sample; x windows: %lld of %zu workgroups, %d slots at most\n",
+                    xs1, xs2, best_shape.px, best_shape.py, best_shape.pz, best_avg, xwin_wgs, nwg, xwin_slots_max);
+    } else { xwin = false; brick = false; }
+    plan->info[TILESPMV_INFO_BRICK_ORDER] = brick ? 1 : 0;
     plan->xwin_lds_bytes = xwin ? xwin_slots_max * 16 * (int)sizeof(val_t) : 0;
     // ---- final HBM form of the unit streams.  Descriptors: 12 B (the duplicate of word 0 is dropped).  Values: the
     // units of one task are stored in GROUPS of G = 16 / sizeof(value) units (2 in fp64, 4 in fp32) — the values of
@@ -1158,6 +1182,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
 
     auto *plan = new tilespmv_plan();
     plan->dry = K.dry;
+    if (const char *ab = getenv("TILESPMV_ARENA_MB")) plan->arena_block = (size_t)std::max(0, atoi(ab)) << 20;   // (experiment knob; 0 = one hipMalloc per stream)
     if (!K.dry && hipGetDevice(&plan->device) != hipSuccess) { fprintf(stderr, "tilespmv: hipGetDevice failed\n"); delete plan; return -1; }
 
     // ---- how are COO tiles executed?  (bytes model)
