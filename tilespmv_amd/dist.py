@@ -46,7 +46,7 @@ class ShardedSpMV:
     exercised without a GPU.
     """
 
-    def __init__(self, rank, world, rows, cols, rowptr, colidx, vals, dtype=np.float64, make_local=None, bounds=None, tile_cache=None, **plan_kw):
+    def __init__(self, rank, world, rows, cols, rowptr, colidx, vals, dtype=np.float64, make_local=None, bounds=None, tile_cache=None, hyb=False, **plan_kw):
         """``bounds`` given: ``rowptr / colidx / vals`` are THIS RANK'S row block only (row pointer rebased to 0, global
         column ids) and ``bounds`` the row partition everybody agreed on — a rank then never holds the whole matrix.
         ``tile_cache``: path of a Tile_matrix cache for this rank's block (read when present and of the right shape, written
@@ -85,7 +85,7 @@ class ShardedSpMV:
                     except OSError:
                         pass
             if self.tm is None:
-                self.tm = api.Tile_create(self.local_rows, cols, self.local_nnz, rp, ci, v, dtype=self.dtype)
+                self.tm = api.Tile_create(self.local_rows, cols, self.local_nnz, rp, ci, v, dtype=self.dtype, hyb=hyb)
                 if tile_cache is not None:
                     try:
                         api.matrix_save(self.tm, self.local_rows, cols, self.local_nnz, tile_cache)
