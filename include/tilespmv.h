@@ -210,11 +210,12 @@ void call_tilespmv_hip(char *filename, Tile_matrix *matrix, int *ptroffset1, int
  * Prints the reference's runtime line for the sharded SpMV plus one "  HIP ..." line that also
  * carries the SpMV+combine time, appends results.csv, returns y on the host (in the combine modes
  * taken from the last device's full-length copy).  A device id may be repeated (several shards on
- * one device) except in all-reduce mode.  Aborts with a message and exit status 3 on any error. */
+ * one device) except in all-reduce mode.  Returns 0, or — after a message on stderr and after releasing every device resource it
+ * had created — a non-zero status on any error (bad arguments, no such device, HIP / RCCL failure): it never exits the process. */
 #define TILESPMV_Y_SHARDED 0
 #define TILESPMV_Y_ALLGATHER 1
 #define TILESPMV_Y_ALLREDUCE 2
-void call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int *ptroffset1, int *ptroffset2,
+int call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int *ptroffset1, int *ptroffset2,
                              int rowblkblock, unsigned int *blkcoostylerowidx,
                              int *blkcoostylerowidx_colstart, int *blkcoostylerowidx_colstop,
                              int rowA, int colA, MAT_PTR_TYPE nnzA, MAT_PTR_TYPE *csrRowPtrA,

@@ -738,3 +738,23 @@ def test_rccl_collectives_on_the_real_y_world_size_one():
     """ % root)
     r = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_call_tilespmv_hip_multi_returns_a_status(torch_cuda, tmp_path, monkeypatch, capfd):
+    """Round 3: the multi-device entry reports errors as a return value (message on stderr, device resources released) instead
+    of exiting the caller's process; the process goes on and a correct call afterwards still works."""
+    from tilespmv_amd import api
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("TILESPMV_WARMUP", "1"); monkeypatch.setenv("TILESPMV_BENCH_REPEAT", "2"); monkeypatch.setenv("TILESPMV_COMBINE_REPEAT", "1")
+    m, n, rp, ci = SMALL["lap64"]()
+    nnz, rowA = len(ci), truncated_rows(m)
+    vals, x = values_for("lap64", nnz, n, np.float64)
+    tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
+    for ids, mode in (([99], api.Y_SHARDED), ([0, 99], api.Y_ALLGATHER), ([0], 7)):      # no such device (first / second shard) / bad mode
+        with pytest.raises(RuntimeError):
+            api.call_tilespmv_hip("x.mtx", tp, None, rowA, n, nnz, rp, ci, vals, x, device_ids=ids, y_combine_mode=mode)
+    assert "call_tilespmv_hip_multi:" in capfd.readouterr().err
+    y = api.call_tilespmv_hip("x.mtx", tp, None, rowA, n, nnz, rp, ci, vals, x, device_ids=[0, 0], y_combine_mode=api.Y_ALLGATHER)
+    import scipy.sparse as sp
+    assert np.array_equal(y, sp.csr_matrix((vals[:int(rp[rowA])], ci[:int(rp[rowA])], rp[:rowA + 1]), shape=(rowA, n)) @ x)
+    api.Tile_destroy(tp)

@@ -94,7 +94,7 @@ def load(dtype=np.float64):
     lib.call_tilespmv_hip.restype = None
     lib.call_tilespmv_hip_multi.argtypes = [C.c_char_p, TP, _I, _I, C.c_int, _U, _I, _I, C.c_int, C.c_int, C.c_int, _I, _I, VP,
                                             vt, VP, VP, VP, C.c_int, _I, C.c_int]
-    lib.call_tilespmv_hip_multi.restype = None
+    lib.call_tilespmv_hip_multi.restype = C.c_int
     lib.tilespmv_plan_spmm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.tilespmv_plan_spmm.restype = C.c_int
     lib.tilespmv_plan_time_spmm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]

@@ -131,7 +131,9 @@ def call_tilespmv_hip(filename, tm, sched, rowA, colA, nnzA, csrRowPtrA, csrColI
         lib.call_tilespmv_hip(*args)
     else:
         ids = np.ascontiguousarray(device_ids, dtype=np.int32)
-        lib.call_tilespmv_hip_multi(*args, len(ids), _p(ids, C.c_int), int(y_combine_mode))
+        rc = lib.call_tilespmv_hip_multi(*args, len(ids), _p(ids, C.c_int), int(y_combine_mode))
+        if rc != 0:
+            raise RuntimeError("call_tilespmv_hip_multi failed (%d): see stderr" % rc)
     return y[:rowA].copy()
 
 

@@ -128,11 +128,12 @@ int main(int argc, char **argv)
 
     MAT_VAL_TYPE alpha = 1.0;
     memset(y, 0, sizeof(MAT_VAL_TYPE) * rowA);
-    if (ndev > 0)
-        call_tilespmv_hip_multi(filename, matrixA, ptroffset1, ptroffset2, rowblkblock, blkcoostylerowidx,
+    if (ndev > 0) {
+        const int mrc = call_tilespmv_hip_multi(filename, matrixA, ptroffset1, ptroffset2, rowblkblock, blkcoostylerowidx,
                                 blkcoostylerowidx_colstart, blkcoostylerowidx_colstop, rowA, colA, nnzA, csrRowPtrA,
                                 csrColIdxA, csrValA, alpha, x, y, y_golden, ndev, devices, combine);
-    else
+        if (mrc != 0) return 3;   // (message already on stderr)
+    } else
         call_tilespmv_hip(filename, matrixA, ptroffset1, ptroffset2, rowblkblock, blkcoostylerowidx, blkcoostylerowidx_colstart,
                           blkcoostylerowidx_colstop, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, alpha, x, y, y_golden);
 

@@ -25,11 +25,10 @@ int env_int(const char *name, int dflt)
     return e && *e ? atoi(e) : dflt;
 }
 
-[[noreturn]] void die(const char *what, int code)
-{
-    fprintf(stderr, "call_tilespmv_hip_multi: %s failed (%d)\n", what, code);
-    exit(3);
-}
+// Errors travel as an exception to the C entry point, which prints the message, releases every device resource it holds
+// and RETURNS a status (the reference's void signatures cannot fail; this new entry can, and must not take the caller's process down).
+struct Fail { const char *what; int code; };
+[[noreturn]] void die(const char *what, int code) { throw Fail{what, code}; }
 
 #define CK(call) do { int rc_ = (int)(call); if (rc_) die(#call, rc_); } while (0)
 
@@ -67,7 +66,10 @@ struct Shard {
 
 }  // namespace
 
-extern "C" void call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int *ptroffset1, int *ptroffset2, int rowblkblock,
+static void run_multi(std::vector<Shard> &S, Rccl &rccl, std::vector<void *> &comms, char *filename, Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA,
+                      MAT_VAL_TYPE *x, MAT_VAL_TYPE *y, int ngpus, const int *device_ids, int y_combine_mode);
+
+extern "C" int call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int *ptroffset1, int *ptroffset2, int rowblkblock,
                                         unsigned int *blkcoostylerowidx, int *blkcoostylerowidx_colstart,
                                         int *blkcoostylerowidx_colstop, int rowA, int colA, MAT_PTR_TYPE nnzA,
                                         MAT_PTR_TYPE *csrRowPtrA, int *csrColIdxA, MAT_VAL_TYPE *csrValA, MAT_VAL_TYPE alpha,
@@ -76,18 +78,42 @@ extern "C" void call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int
 {
     (void)ptroffset1; (void)ptroffset2; (void)rowblkblock; (void)blkcoostylerowidx; (void)blkcoostylerowidx_colstart;
     (void)blkcoostylerowidx_colstop; (void)csrRowPtrA; (void)csrColIdxA; (void)csrValA; (void)alpha; (void)y_golden;
+    int prev_device = 0;
+    (void)hipGetDevice(&prev_device);
+    std::vector<Shard> S;
+    Rccl rccl;
+    std::vector<void *> comms;
+    int status = 0;
+    try {
+        run_multi(S, rccl, comms, filename, matrix, rowA, colA, nnzA, x, y, ngpus, device_ids, y_combine_mode);
+    } catch (const Fail &f) {
+        fprintf(stderr, "call_tilespmv_hip_multi: %s failed (%d)\n", f.what, f.code);
+        status = 3;
+    }
+    for (size_t g = 0; g < comms.size(); g++) if (comms[g] && rccl.CommDestroy) (void)rccl.CommDestroy(comms[g]);
+    for (Shard &s : S) {   // (also after a failure: whatever was created is released)
+        (void)hipSetDevice(s.device);
+        if (s.plan) tilespmv_plan_destroy(s.plan);
+        if (s.d_x) (void)hipFree(s.d_x);
+        if (s.d_y) (void)hipFree(s.d_y);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    (void)hipSetDevice(prev_device);
+    return status;
+}
+
+static void run_multi(std::vector<Shard> &S, Rccl &rccl, std::vector<void *> &comms, char *filename, Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA,
+                      MAT_VAL_TYPE *x, MAT_VAL_TYPE *y, int ngpus, const int *device_ids, int y_combine_mode)
+{
     if (ngpus < 1 || !device_ids) die("argument check (ngpus >= 1, device_ids != NULL)", ngpus);
     if (y_combine_mode < TILESPMV_Y_SHARDED || y_combine_mode > TILESPMV_Y_ALLREDUCE) die("argument check (y_combine_mode)", y_combine_mode);
     const int visible = tilespmv_device_count();
     for (int g = 0; g < ngpus; g++)
         if (device_ids[g] < 0 || device_ids[g] >= visible) die("device id check (no such HIP device)", device_ids[g]);
-    int prev_device = 0;
-    CK(hipGetDevice(&prev_device));
-
     // ---- shards: nnz-balanced whole tile-rows, one plan + stream + x copy + full-length y per device
     std::vector<int> bounds((size_t)ngpus + 1);
     tilespmv_partition_tilerows(matrix, ngpus, bounds.data());
-    std::vector<Shard> S((size_t)ngpus);
+    S.assign((size_t)ngpus, Shard());
     const size_t ybytes = ((size_t)rowA + 16) * sizeof(val_t);
     for (int g = 0; g < ngpus; g++) {
         Shard &s = S[g];
@@ -118,11 +144,9 @@ extern "C" void call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) die("hipDeviceEnablePeerAccess", (int)e);
                 (void)hipGetLastError();
             }
-    Rccl rccl;
-    std::vector<void *> comms;
     if (y_combine_mode == TILESPMV_Y_ALLREDUCE) {
         if (!rccl.load()) die("dlopen(librccl.so) for the all-reduce y combine", 1);
-        comms.resize((size_t)ngpus);
+        comms.assign((size_t)ngpus, nullptr);
         CK(rccl.CommInitAll(comms.data(), ngpus, device_ids));  // refuses duplicate devices
     }
 
@@ -218,12 +242,4 @@ extern "C" void call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int
         CK(hipSetDevice(s.device));
         CK(hipMemcpy(y, s.d_y, (size_t)rowA * sizeof(val_t), hipMemcpyDeviceToHost));
     }
-    for (size_t g = 0; g < comms.size(); g++) (void)rccl.CommDestroy(comms[g]);
-    for (Shard &s : S) {
-        CK(hipSetDevice(s.device));
-        if (s.plan) tilespmv_plan_destroy(s.plan);
-        (void)hipFree(s.d_x); (void)hipFree(s.d_y);
-        (void)hipStreamDestroy(s.stream);
-    }
-    (void)hipSetDevice(prev_device);
 }
