@@ -1,5 +1,6 @@
 """Randomised GPU parity fuzz (manual tool, uses the oracle): python tests/gpu_fuzz.py [seeds] [first_seed]
-Every seed builds a matrix from random ingredients (blocks of every tile format, bands, long rows, empty
+Every seed builds a matrix from random ingredients (every fourth seed: a 3-D stencil plus random extras, so that the brick order and
+the x windows of round 3 engage) (blocks of every tile format, bands, long rows, empty
 tile-rows, single entries, duplicate-free scatter), odd column counts, then checks SpMV (both kernels, both COO
 modes, both dense modes, HYB on/off, with tiny strip / split thresholds) and SpMM (2/4/8) bit-exactly against
 the oracle's CSR golden on small-integer data, fp64 and fp32."""
@@ -59,8 +60,34 @@ def random_matrix(seed):
     return G.from_coo(rows, cols, r, c)
 
 
+def stencil_matrix(seed):
+    """Round 3: a 3-D stencil (7- or 27-point on g x g x gz cells, g a multiple of 16 so that grid lines are whole tile-rows) plus
+    random scatter, a few dense blocks and long rows: grid strides exist, so the brick task order and the LDS x windows engage."""
+    rng = np.random.default_rng(seed)
+    g = 16 * int(rng.integers(1, 4)); gy = int(rng.integers(4, 11)); gz = int(rng.integers(4, 11))
+    N = g * gy * gz
+    idx = np.arange(N, dtype=np.int64); k, j, i = idx // (g * gy), (idx // g) % gy, idx % g
+    R, Cc = [], []
+    full = rng.random() < 0.5
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if not full and abs(dz) + abs(dy) + abs(dx) > 1: continue
+                ok = (k + dz >= 0) & (k + dz < gz) & (j + dy >= 0) & (j + dy < gy) & (i + dx >= 0) & (i + dx < g)
+                R.append(idx[ok]); Cc.append(idx[ok] + (dz * gy + dy) * g + dx)
+    ns = int(rng.integers(0, 400)); R.append(rng.integers(0, N, ns)); Cc.append(rng.integers(0, N, ns))
+    for _ in range(int(rng.integers(0, 4))):
+        br, bc = 16 * int(rng.integers(0, N // 16)), 16 * int(rng.integers(0, N // 16))
+        rr, cc = np.meshgrid(np.arange(16), np.arange(16), indexing="ij"); R.append((br + rr).ravel()); Cc.append((bc + cc).ravel())
+    if rng.random() < 0.3:
+        r = int(rng.integers(0, N)); kk = int(rng.integers(1, N)); R.append(np.full(kk, r)); Cc.append(rng.choice(N, kk, replace=False))
+    r = np.concatenate(R); c = np.concatenate(Cc)
+    key = np.unique(r.astype(np.int64) * N + c)
+    return G.from_coo(N, N, key // N, key % N)
+
+
 def check(seed):
-    m, n, rp, ci = random_matrix(seed)
+    m, n, rp, ci = stencil_matrix(seed) if seed % 4 == 1 else random_matrix(seed)
     nnz = len(ci)
     bad = 0
     rng = np.random.default_rng(seed + 7)
@@ -72,6 +99,10 @@ def check(seed):
     env.update([{}, {"TILESPMV_WAVE_COO": "0"}, {"TILESPMV_WAVE_COO": "1"}, {"TILESPMV_WAVE_COO": "2", "TILESPMV_COO_ORDERED": "1"},
                 {"TILESPMV_WAVE_COO": "2", "TILESPMV_COO_ORDERED": "0"}][seed % 5 if seed % 2 else (seed // 2) % 5])
     if seed % 11 == 0: env["TILESPMV_STRIP_COST"] = "1600"
+    # round 3: brick task order / LDS x windows on the stencil seeds, 512-thread workgroups, resident-workgroup cap
+    if seed % 4 == 1: env["TILESPMV_X_WINDOW"] = str([1, 2, 1, -1][(seed // 4) % 4])
+    if seed % 6 == 3 and env.get("TILESPMV_WAVE_COO") == "2": env["TILESPMV_WG_STRIPS"] = "32"
+    if seed % 9 == 5: env["TILESPMV_LDS_PAD"] = "8192"
     os.environ.update(env)
     for dt in (np.float64, np.float32):
         vals = rng.integers(1, 4, nnz).astype(dt)

@@ -758,3 +758,38 @@ def test_call_tilespmv_hip_multi_returns_a_status(torch_cuda, tmp_path, monkeypa
     import scipy.sparse as sp
     assert np.array_equal(y, sp.csr_matrix((vals[:int(rp[rowA])], ci[:int(rp[rowA])], rp[:rowA + 1]), shape=(rowA, n)) @ x)
     api.Tile_destroy(tp)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_spmm_one_at_a_time_scratch_is_reserved_and_aligned(torch_cuda, dtype):
+    """plans without a native multi-vector kernel (CSR fallback, first-generation kernel) transpose X / Y into
+    column copies.  With rowA % 16 != 0 (and colA % 16 != 0) the copies' strides must still leave every column 16-byte aligned
+    (the SpMV kernels store y with 16-byte lane stores), and tilespmv_plan_reserve_spmm allocates the scratch up front so that the
+    launch path itself never allocates (graph capture).  Per-column results == the oracle."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api
+    m, n, rp, ci = SMALL["allfmt_pad5"]()
+    nnz = len(ci)
+    vals, _ = values_for("allfmt_pad5", nnz, n, dtype)
+    O = CpuImpl("oracle", dtype)
+    for rowA in (187, 178, 33):
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=True)
+        to = O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True)
+        for kw in (dict(coo_mode=api.COO_FALLBACK), dict(kernel=api.KERNEL_DIRECT), dict(csr_split=0)):
+            plan = api.Plan(tp, rowA, n, nnz, **kw)
+            plan.reserve_spmm(8)
+            for nv in (2, 4, 8):
+                X = (np.arange(n * nv, dtype=np.int64) % 5).astype(dtype).reshape(n, nv)
+                Xd = torch_cuda.from_numpy(X).cuda()
+                Yd = torch_cuda.full((rowA + 16, nv), -3.0, dtype=Xd.dtype, device="cuda")
+                stream = torch_cuda.cuda.Stream()
+                with torch_cuda.cuda.stream(stream):     # a non-default stream: nothing in the launch path may synchronise the device
+                    plan.spmm(Xd.data_ptr(), Yd.data_ptr(), nv, stream.cuda_stream)
+                stream.synchronize()
+                Y = Yd.cpu().numpy()
+                for j in range(nv):
+                    want = O.spmv(to, rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"]
+                    assert np.array_equal(Y[:rowA, j], want), (rowA, kw, nv, j)
+                assert (Y[rowA:] == -3.0).all()
+            plan.close()
+        api.Tile_destroy(tp)

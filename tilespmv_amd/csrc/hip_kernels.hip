@@ -590,6 +590,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         }
         // (issuing the unit prologue after the entry phase instead frees 16 VGPRs — 8 waves per SIMD at 6 x 256 per trip, or 8 x 256 at
         // 6 waves — and changes nothing: power-law 8 M 0.1026-0.1034 ms either way, profiles/r03_entry_ablations.txt: bytes in flight are not the limit)
+        // pipelined trips on top of that (78 VGPRs at 6 x 256, no spill): 0.1050-0.1062 against 0.1031-0.1046 — slightly worse
         unit_prologue();
         TSPMV_STAMP_WAIT(2);   // prologue has arrived (the entry loads are inside the trips)
         if (wr.y > wr.x) {

@@ -383,7 +383,7 @@ inline void detect_strides(const Tile_matrix *T, int tr0, int tr1, bool csr_spli
 {
     *s1 = *s2 = 0;
     const int ntr = tr1 - tr0;
-    if (ntr < 64) return;
+    if (ntr < 32) return;
     const int step = std::max(1, ntr / 32768);
     std::vector<long long> ds;
     long long sampled = 0;
@@ -506,10 +506,10 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     //              1: brick order + the workgroup's x segments staged once in LDS ("x windows": strips of at most XWIN_STRIP_ROWS
     //                 tile-rows; cuts another ~0.4 GB but runs 25 % slower — profiles/r03_xwindow_and_map.txt; opt-in only)
     int xs1 = K.x_stride1 > 0 ? K.x_stride1 : 0, xs2 = K.x_stride2 > 0 ? K.x_stride2 : 0;
-    bool brick = K.x_window != 0 && entry_mode != 1 && wg_strips == 16 && (K.x_window > 0 || est_wgs >= 2048);
+    bool brick = K.x_window != 0 && wg_strips == 16 && (K.x_window > 0 || est_wgs >= 2048);
     if (brick && xs1 == 0) detect_strides(T, tr0, tr1, csr_split, dense_mfma, &xs1, &xs2);
     if (xs1 < 2 || (K.x_window < 0 && xs2 == 0)) brick = false;   // (2-D grids: measured neutral on the 5-point 4096^2 case)
-    bool xwin = brick && K.x_window == 1;
+    bool xwin = brick && K.x_window == 1 && entry_mode != 1;   // (the windowed kernel exists for entry modes 0 and 2)
     // (strips of at most 4 tile-rows in brick plans: nlpkkt160 stand-in fp64 0.418 -> 0.414 ms, fp32 0.252 -> 0.250; 2 rows: KKT 0.408 but 7-pt 256^3 +5 %)
     const int max_strip_rows = xwin ? XWIN_STRIP_ROWS : brick ? (K.brick_rows > 0 ? std::min(K.brick_rows, STRIP_MAX_ROWS) : 4) : STRIP_MAX_ROWS;
     if (brick && !K.xcd_from_caller) plan->xcd_chunk = 8;   // bricks are compact: smaller XCD windows keep an XCD's resident set together
