@@ -1,4 +1,4 @@
-"""Run the measured plan selection (tilespmv_plan_options.reserved[0] / TILESPMV_AUTOTUNE) on the BASELINE workloads and a few
+"""Run the measured plan selection (tilespmv_plan_options.autotune / TILESPMV_AUTOTUNE) on the BASELINE workloads and a few
 more, and keep what it saw: candidates, times, choice — profiles/autotune_rNN.json.  python scripts/autotune_receipts.py out.json"""
 import json, os, sys, tempfile
 import numpy as np

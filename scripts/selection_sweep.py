@@ -23,19 +23,29 @@ for spec in wls:
     want = sp.csr_matrix((vals[:nnz].astype(np.float64), ci[:nnz], rp[:rows + 1]), shape=(rows, n)) @ x.astype(np.float64)
     xd = torch.from_numpy(x).cuda(); yd = torch.zeros(rows + 16, dtype=xd.dtype, device="cuda")
     res = {}
-    for label, flag in (("reference", False), ("cdna4", True)):
-        tm = api.Tile_create(rows, n, nnz, rp, ci, vals, dtype=dtype, cdna4=flag)
-        hist = np.bincount(field_array(tm, "Format", tm.tilenum), minlength=7).tolist()
-        p = api.Plan(tm, rows, n, nnz)
-        yd.fill_(-1); p.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize()
-        ok = bool(np.array_equal(yd.cpu().numpy()[:rows].astype(np.float64), want))
-        res[label] = (tm, p, hist, ok, [])
+    # two plan instances per selection, interleaved (ref, cdna4, ref, cdna4): instances of one plan can differ by several per cent on the
+    # KKT matrices (DESIGN S6.13), so a single pair proves nothing there; the table gives the min over both instances
+    tms = {label: api.Tile_create(rows, n, nnz, rp, ci, vals, dtype=dtype, cdna4=flag) for label, flag in (("reference", False), ("cdna4", True))}
+    for inst in range(2):
+        for label in ("reference", "cdna4"):
+            tm = tms[label]
+            hist = np.bincount(field_array(tm, "Format", tm.tilenum), minlength=7).tolist()
+            p = api.Plan(tm, rows, n, nnz)
+            yd.fill_(-1); p.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize()
+            ok = bool(np.array_equal(yd.cpu().numpy()[:rows].astype(np.float64), want))
+            res[(label, inst)] = (p, hist, ok, [])
     for rnd in range(5):
-        for label in res:
-            res[label][4].append(res[label][1].time(xd.data_ptr(), yd.data_ptr(), warmup=3, reps=20))
-    for label, (tm, p, hist, ok, ts) in res.items():
-        lines.append("%-18s %-5s %-9s %-46s %12.1f %10.5f %6s" % (wl, "f32" if dtype == np.float32 else "f64", label, hist, p.info()["stream_bytes"] / 1e6, min(ts), ok))
-        p.close(); api.Tile_destroy(tm)
+        for key in res:
+            res[key][3].append(res[key][0].time(xd.data_ptr(), yd.data_ptr(), warmup=5, reps=20))
+    for label in ("reference", "cdna4"):
+        p, hist, ok, _ = res[(label, 0)]
+        best = [min(res[(label, i)][3]) for i in range(2)]
+        lines.append("%-18s %-5s %-9s %-46s %12.1f %10.5f %6s   instances: %s" % (wl, "f32" if dtype == np.float32 else "f64", label, hist, p.info()["stream_bytes"] / 1e6, min(best),
+                                                                              ok and res[(label, 1)][2], " ".join("%.5f" % b for b in best)))
+    for key in res:
+        res[key][0].close()
+    for tm in tms.values():
+        api.Tile_destroy(tm)
     print("\n".join(lines[-2:]), flush=True)
     del xd, yd, want
 open(out, "w").write("\n".join(lines) + "\n")
