@@ -282,7 +282,8 @@ typedef struct {
                            found, 1 = brick order + the workgroup's x segments staged in LDS (measured slower; opt-in)          TILESPMV_X_WINDOW */
     int x_stride1;      /* ... tile-rows per grid line (0 / unset: detected from the shard)                  TILESPMV_X_STRIDE1 */
     int x_stride2;      /* ... tile-rows per grid plane (0 / unset: detected; none for 2-D problems)         TILESPMV_X_STRIDE2 */
-    int mv_native;      /* tilespmv_plan_spmm on entry-dominated plans: 1 multi-vector kernel, 0 one vector at a time           TILESPMV_MV_NATIVE */
+    int mv_native;      /* tilespmv_plan_spmm: 0 one vector at a time, 1 multi-vector kernel with per-strip entries, 2 multi-vector kernel +
+                           entry pass over the merged lists (entry mode 2); unset: by plan and nvec                        TILESPMV_MV_NATIVE */
     int mv_xcd_chunk;   /* XCD window of the multi-vector kernel                                             TILESPMV_MV_XCD_CHUNK */
     int lds_pad;        /* bytes of unused LDS added to every unit-kernel workgroup: fewer resident workgroups per CU  TILESPMV_LDS_PAD */
     int reserved[5];    /* must be TILESPMV_KNOB_DEFAULT or 0 */

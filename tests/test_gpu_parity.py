@@ -793,3 +793,35 @@ def test_spmm_one_at_a_time_scratch_is_reserved_and_aligned(torch_cuda, dtype):
                 assert (Y[rowA:] == -3.0).all()
             plan.close()
         api.Tile_destroy(tp)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_spmm_entry_pass_on_entry_dominated_plans(torch_cuda, dtype):
+    """Round 3: entry-dominated plans with the workgroup entry mode multiply their merged, column-ordered lists in a multi-vector
+    pass of their own (k_entries_mv: Y += A_entries X after k_units_mv) instead of going one right-hand side at a time — also with
+    split tile-rows (pieces add atomically) and with unordered adds.  Every column == the oracle, exactly (integer data)."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api
+    O = CpuImpl("oracle", dtype)
+    for name in ("powerlaw200k", "one_long_row", "circuit8k", "allfmt"):
+        m, n, rp, ci = (SMALL.get(name) or MEDIUM[name])()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, _ = values_for(name, nnz, n, dtype)
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=True)
+        to = O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True)
+        X8 = (np.arange(n * 8, dtype=np.int64) % 5).astype(dtype).reshape(n, 8)
+        want = [O.spmv(to, rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X8[:, j]))["y"] for j in range(8)]
+        for kw in (dict(entry_mode=2, strip_cost=1600, mv_native=2), dict(entry_mode=2, strip_cost=1600, entry_ordered=0, mv_native=2),
+                   dict(entry_mode=2, strip_cost=800, split_above=300, split_cap=300, mv_native=2), dict(entry_mode=2, strip_cost=1600), dict(entry_mode=2, strip_cost=1600, mv_native=1)):
+            plan = api.Plan(tp, rowA, n, nnz, **kw)
+            for nv in (2, 4, 8):
+                Xd = torch_cuda.from_numpy(np.ascontiguousarray(X8[:, :nv])).cuda()
+                Yd = torch_cuda.full((rowA + 16, nv), -7.0, dtype=Xd.dtype, device="cuda")
+                plan.spmm(Xd.data_ptr(), Yd.data_ptr(), nv); plan.spmm(Xd.data_ptr(), Yd.data_ptr(), nv)   # twice: Y is overwritten, not accumulated
+                torch_cuda.cuda.synchronize()
+                Y = Yd.cpu().numpy()
+                for j in range(nv):
+                    assert np.array_equal(Y[:rowA, j], want[j]), (name, kw, nv, j, int(np.count_nonzero(Y[:rowA, j] != want[j])))
+                assert (Y[rowA:] == -7.0).all()
+            plan.close()
+        api.Tile_destroy(tp)

@@ -900,8 +900,10 @@ struct alignas(NV * sizeof(val_t) >= 16 ? 16 : NV * sizeof(val_t)) MVec { val_t 
 // wavefront work on the SAME strip with different slices of the NV vectors, so a wide NV costs no extra
 // registers, the stores of one Y row (NV values) come from Q lanes of one store instruction, and a
 // wavefront sees the store latency of one strip instead of four (stores retire in order with the loads).
+// skip_entries: the plan's merged, column-ordered entry lists are multiplied by k_entries_mv afterwards (entry-dominated plans with the
+// workgroup entry mode); this kernel then handles units only and stores zeros for the rows without units.
 template <int NVT>
-__global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+__global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int rowA, int colA, int xcd_chunk, int skip_entries, val_t *__restrict__ partial,
                                                   const val_t *__restrict__ X, val_t *__restrict__ Y)
 {
     constexpr int NV = NVT < 2 ? NVT : 2;   // vectors per lane
@@ -925,7 +927,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     const int unit_begin = t0.x, unit_end = t0.y, coo_begin = t0.z, coo_end = t0.w;
     const int row0 = t1.x, part = t1.y;
     const unsigned nounit = (unsigned)t1.z;
-    const int ncoo = coo_end - coo_begin;
+    const int ncoo = skip_entries ? 0 : coo_end - coo_begin;
     typedef val_t grp_t __attribute__((ext_vector_type(UNIT_GROUP)));
     const grp_t *__restrict__ ugrp = reinterpret_cast<const grp_t *>(S.uval) + r;  // group layout (hip_plan.hip): one 16-byte load = UNIT_GROUP units
     const vec_t *__restrict__ Xv = reinterpret_cast<const vec_t *>(X) + q;   // row i, slice q: Xv[i * Q]
@@ -1115,6 +1117,87 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-vector entry pass (round 3): Y[rows][NVT] += A_entries * X for plans whose COO entries run per workgroup (entry mode 2, 16 strips):
+// the same merged, column-ordered, packed lists k_units<.., 2> walks, two right-hand sides per pass (one 16-byte gather per entry and lane
+// in fp64), NVT / 2 passes over the workgroup's list (the list of a workgroup is ~80 KB: the later passes find it in L2).  Row sums of
+// a pass are accumulated in LDS (2,048 rows x 2 values) exactly like the single-vector kernel does, then added to Y, which k_units_mv
+// (skip_entries) has written before.  Pieces of split tile-rows add their sums atomically.  Entry-dominated plans used to run one
+// right-hand side at a time below nvec 8 (webbase-like: 40 / 83 us for nvec 2 / 4).
+// ------------------------------------------------------------------------------------------------
+template <int NVT>
+__global__ __launch_bounds__(256) void k_entries_mv(DevStream S, int rowA, const val_t *__restrict__ X, val_t *__restrict__ Y)
+{
+    constexpr int NP = NVT / 2, CT = 4;
+    typedef MVec<2> vec_t;
+    __shared__ val_t s_acc[GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16][2];
+    const int tid = threadIdx.x, r = tid & 15, g = tid >> 4, wave = tid >> 6;
+    const unsigned bid = blockIdx.x;
+    const int4 wr = S.wg_coo[bid];
+    if (wr.y <= wr.x) return;   // workgroup-uniform
+    const long long task_id = (long long)bid * GROUPS_PER_BLOCK + g;
+    int4 t0 = make_int4(0, 0, 0, 0), t1 = make_int4(0, -1, 0, 0);
+    if (task_id < S.ntasks) {
+        t0 = reinterpret_cast<const int4 *>(S.task)[task_id * 2];
+        t1 = reinterpret_cast<const int4 *>(S.task)[task_id * 2 + 1];
+    }
+    const bool side = t0.w > t0.z;
+    const int row0 = t1.x, part = t1.y, nrows = t1.w;
+    const int db = S.dest_bits, gb = wr.x, ge = wr.y;
+    const unsigned dmask = (1u << db) - 1u;
+    const int clast = wr.z + ((ge - 1 - gb) >> 6);
+    const bool ordered = S.coo_ordered != 0;
+    const vec_t *__restrict__ X2 = reinterpret_cast<const vec_t *>(X);
+    vec_t *__restrict__ Y2 = reinterpret_cast<vec_t *>(Y);
+    for (int p = 0; p < NP; p++) {
+        for (int i = tid; i < GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16; i += 256) { s_acc[i][0] = 0; s_acc[i][1] = 0; }
+        __syncthreads();
+        for (int e0 = gb; e0 < ge; e0 += 256 * CT) {
+            ERec rr[CT]; unsigned cb[CT]; vec_t xx[CT];
+#pragma unroll
+            for (int q = 0; q < CT; q++) {
+                rr[q] = S.grec[min(e0 + 256 * q + tid, ge - 1)];
+                cb[q] = S.gbase[__builtin_amdgcn_readfirstlane(min(wr.z + ((e0 - gb) >> 6) + 4 * q + wave, clast))];
+            }
+#pragma unroll
+            for (int q = 0; q < CT; q++) xx[q] = X2[(size_t)(cb[q] + (rr[q].w >> db)) * NP + p];
+            auto adds = [&]() {
+#pragma unroll
+                for (int q = 0; q < CT; q++)
+                    if (e0 + 256 * q + tid < ge) {
+                        const val_t v = erec_val(rr[q]);
+                        atomicAdd(&s_acc[rr[q].w & dmask][0], v * xx[q].v[0]);
+                        atomicAdd(&s_acc[rr[q].w & dmask][1], v * xx[q].v[1]);
+                    }
+            };
+            if (ordered) {   // wavefronts add in turn: plan-fixed order of the additions, as in k_units<.., 2>
+                for (int w = 0; w < 4; w++) { if (wave == w) adds(); __syncthreads(); }
+            } else adds();
+        }
+        __syncthreads();
+        if (side) {
+            if (part >= 0) {   // piece of a split tile-row: k_fixup_split_mv has written the row; the piece's entry sums are added atomically
+                const long long yi = (long long)row0 * 16 + r;
+                if (yi < rowA) {
+                    atomicAdd(&Y[(yi * NP + p) * 2 + 0], s_acc[g * (STRIP_MAX_ROWS * 16) + r][0]);
+                    atomicAdd(&Y[(yi * NP + p) * 2 + 1], s_acc[g * (STRIP_MAX_ROWS * 16) + r][1]);
+                }
+            } else {
+                for (int k = 0; k < nrows; k++) {
+                    const long long yi = ((long long)row0 + k) * 16 + r;
+                    if (yi < rowA) {
+                        vec_t o = Y2[yi * NP + p];
+                        o.v[0] += s_acc[g * (STRIP_MAX_ROWS * 16) + k * 16 + r][0];
+                        o.v[1] += s_acc[g * (STRIP_MAX_ROWS * 16) + k * 16 + r][1];
+                        Y2[yi * NP + p] = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void k_fixup_split_mv(DevPlan P, val_t *__restrict__ Y)
 {
@@ -1188,30 +1271,32 @@ __global__ __launch_bounds__(256) void k_dense_mfma_mv(DevDense D, int rowA, int
 }
 
 template <int NV>
-static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int xcd_chunk, const val_t *X, val_t *Y, hipStream_t st)
+static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int xcd_chunk, bool entries_pass, const val_t *X, val_t *Y, hipStream_t st)
 {
     if (S.ntasks > 0)
     {
         constexpr int strips = GROUPS_PER_BLOCK / (NV < 2 ? 1 : NV / 2);  // per workgroup (k_units_mv: Q lane groups per strip)
         hipLaunchKernelGGL((k_units_mv<NV>), dim3((unsigned)((S.ntasks + strips - 1) / strips)), dim3(256), 0, st,
-                           S, P.rowA, P.colA, xcd_chunk, P.partial, X, Y);
+                           S, P.rowA, P.colA, xcd_chunk, entries_pass ? 1 : 0, P.partial, X, Y);
     }
     if (DN.nrows > 0)
         hipLaunchKernelGGL((k_dense_mfma_mv<NV>), dim3((DN.nrows + 3) / 4), dim3(256), 0, st, DN, P.rowA, P.colA, P.partial, X, Y);
     if (P.nfix > 0)
         hipLaunchKernelGGL((k_fixup_split_mv<NV>), dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, Y);
+    if (entries_pass && S.ntasks > 0)   // Y += entries (after the units, the dense pass and the split-row sums have written Y)
+        hipLaunchKernelGGL((k_entries_mv<NV>), dim3((unsigned)((S.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), dim3(256), 0, st, S, P.rowA, X, Y);
     return hipGetLastError();
 }
 
 // nvec in {2, 4, 8}.  The plan must be a unit-stream plan without whole-tile passes and without the CSR
 // fallback (the defaults); the caller checks that (hip_plan.hip).
-hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, const val_t *X, val_t *Y,
+hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, bool entries_pass, const val_t *X, val_t *Y,
                                   hipStream_t st)
 {
     switch (nvec) {
-    case 2: return launch_mv<2>(P, S, DN, xcd_chunk, X, Y, st);
-    case 4: return launch_mv<4>(P, S, DN, xcd_chunk, X, Y, st);
-    case 8: return launch_mv<8>(P, S, DN, xcd_chunk, X, Y, st);
+    case 2: return launch_mv<2>(P, S, DN, xcd_chunk, entries_pass, X, Y, st);
+    case 4: return launch_mv<4>(P, S, DN, xcd_chunk, entries_pass, X, Y, st);
+    case 8: return launch_mv<8>(P, S, DN, xcd_chunk, entries_pass, X, Y, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -22,7 +22,7 @@ hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulat
 hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xwin_lds_bytes, int lds_pad_bytes, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
-hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, const val_t *X, val_t *Y,
+hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, bool entries_pass, const val_t *X, val_t *Y,
                                   hipStream_t st);
 hipError_t launch_rows_to_columns(const val_t *X, int nvec, long long n, long long ld, val_t *XT, hipStream_t st);
 hipError_t launch_columns_to_rows(const val_t *YT, int nvec, long long row0, long long rows, long long ld, val_t *Y, hipStream_t st);
@@ -1516,7 +1516,13 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
     const bool has_native = plan->kernel == TILESPMV_KERNEL_STREAM && plan->dev.ntasks == 0 && plan->dev.f_nblk == 0;
     // entry-dominated plans: the multi-vector kernel only pays from 8 right-hand sides on (webbase-like: 38 / 77 / 154 us one
     // at a time against 110 / 125 / 142 us for nvec 2 / 4 / 8)
-    const bool one_at_a_time = !has_native || (plan->mv_by_columns && (mv_native >= 0 ? mv_native == 0 : nvec < 8));
+    // entry-dominated plans: with the workgroup entry mode (16 strips, no x windows) the merged lists get their own multi-vector pass
+    // (k_entries_mv, round 3); the others still go one right-hand side at a time below nvec 8 (webbase-like, per-strip entries in the
+    // multi-vector kernel: 38 / 77 / 154 us one at a time against 110 / 125 / 142 us for nvec 2 / 4 / 8)
+    // mv_native: -1 by rule, 0 one right-hand side at a time, 1 the multi-vector kernel with its per-strip entry walk, 2 the multi-vector kernel + entry pass
+    const bool can_pass = has_native && plan->entry_mode == 2 && plan->wg_strips == 16 && plan->xwin_lds_bytes == 0;
+    const bool entries_pass = can_pass && (mv_native == 2 || (mv_native < 0 && plan->mv_by_columns && nvec < 8));
+    const bool one_at_a_time = !has_native || mv_native == 0 || (mv_native < 0 && plan->mv_by_columns && !entries_pass && nvec < 8);
     if (one_at_a_time) {
         hipStream_t st = (hipStream_t)stream;
         // leading dimensions of the column copies: multiples of 16 elements, so that every column of X / Y starts 64- / 128-byte
@@ -1536,7 +1542,7 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
         return (int)e;
     }
     const int mv_chunk = plan->mv_xcd_chunk;
-    return (int)launch_tiles_stream_mv(plan->dev, plan->st, plan->dn, nvec, mv_chunk >= 0 ? mv_chunk : (plan->xcd_remap >= 2 ? plan->xcd_chunk : 0), d_X, d_Y, (hipStream_t)stream);
+    return (int)launch_tiles_stream_mv(plan->dev, plan->st, plan->dn, nvec, mv_chunk >= 0 ? mv_chunk : (plan->xcd_remap >= 2 ? plan->xcd_chunk : 0), entries_pass, d_X, d_Y, (hipStream_t)stream);
 }
 
 double tilespmv_plan_time_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y, int nvec, void *stream, int warmup, int reps)
