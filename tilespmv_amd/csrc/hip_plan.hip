@@ -1075,7 +1075,7 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     val_t *dx = nullptr, *dy = nullptr;
     if (hipMalloc((void **)&dx, ((size_t)colA + 16) * sizeof(val_t)) != hipSuccess) return -3;
     if (hipMalloc((void **)&dy, ((size_t)rowA + 16) * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); return -3; }
-    {   // x = 1: an all-zero x would make every product zero, and the fallback kernel skips rows whose sum is exactly zero
+    {   // x = 1 (not zero: candidates are timed on data that makes every product count)
         std::vector<val_t> ones((size_t)colA + 16, (val_t)1);
         (void)hipMemcpy(dx, ones.data(), ones.size() * sizeof(val_t), hipMemcpyHostToDevice);
     }
