@@ -136,7 +136,7 @@ struct tilespmv_plan {
     int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
     int lds_pad_bytes = 0;              // extra (unused) dynamic LDS per workgroup of the unit kernel: caps the workgroups resident on a CU (knob lds_pad)
     int xwin_lds_bytes = 0;             // x-window plans: dynamic LDS of the unit kernel (largest window of the plan); 0 = no windows
-    char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20;   // bump allocator of upload()
+    char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20, arena_next = (size_t)1 << 20, size_hint = 0;   // bump allocator of upload(); size_hint = the builder's estimate of the plan's bytes
     bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
     unsigned long long digest = 1469598103934665603ull;
     template <class T>
@@ -157,8 +157,10 @@ struct tilespmv_plan {
         // masked tail lanes never fault) instead of one hipMalloc each: a plan is ~20 streams, and large blocks get large
         // page-table fragments whatever state the allocator is in (fewer hipMalloc calls, too).
         const size_t need = (std::max<size_t>(n, 1) * sizeof(T) + 256 + 255) / 256 * 256;
-        if (need > arena_left) {
-            const size_t blk = std::max<size_t>(need, arena_block);
+        if (need > arena_left) {   // blocks of arena_block bytes (256 MB) for plans of that size and more; a smaller plan gets one block of about its own size (size_hint)
+            const size_t want = size_hint >= arena_block ? arena_block : std::max<size_t>(arena_next, size_hint + size_hint / 4 + ((size_t)1 << 20));
+            const size_t blk = std::max<size_t>(need, std::min(want, arena_block));
+            arena_next = std::min<size_t>(arena_next * 4, std::max<size_t>(arena_block, 1));
             void *b = nullptr;
             HIP_TRY(hipMalloc(&b, blk));
             allocs.push_back(b);
@@ -855,6 +857,7 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     } else { xwin = false; brick = false; }
     plan->info[TILESPMV_INFO_BRICK_ORDER] = brick ? 1 : 0;
     plan->xwin_lds_bytes = xwin ? xwin_slots_max * 16 * (int)sizeof(val_t) : 0;
+    plan->size_hint = (size_t)(NU * (12 + 16LL * sv) + NC * (2LL * sv + 13) + NHV * sv + NHI + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);   // estimate of the plan's bytes: picks the block size of upload()
     // ---- final HBM form of the unit streams.  Descriptors: 12 B (the duplicate of word 0 is dropped).  Values: the
     // units of one task are stored in GROUPS of G = 16 / sizeof(value) units (2 in fp64, 4 in fp32) — the values of
     // the G units interleaved per row, so that a lane fetches G units with one 16-byte load (row r of the group at
