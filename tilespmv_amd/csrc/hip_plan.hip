@@ -503,7 +503,8 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     // one grid line, and after the cut the strips are regrouped so that the 16 strips of a workgroup — and the neighbouring
     // workgroups of an XCD window — form a brick of the grid instead of a run of one grid line: the x segments a tile-row shares
     // with its neighbours in the other two directions are then wanted at about the same time by one CU / one XCD, and hit in L1 /
-    // L2 instead of being fetched again (nlpkkt160 stand-in fp64: 3.07 -> 2.64 GB per launch at the fabric, 0.464 -> 0.410 ms).
+    // L2 instead of being fetched again (nlpkkt160 stand-in: 3.07 -> 2.6-2.7 GB per launch at the fabric in fp64, 1.81 -> 1.56 GB in fp32;
+    // time -2.5 ... -6 % in fp32, inside the matrix's 10 % placement spread in fp64: DESIGN.md S6.9).
     //   x_window  -1 (default): brick order on large 3-D shards   0: off   2: brick order wherever strides are found
     //              1: brick order + the workgroup's x segments staged once in LDS ("x windows": strips of at most XWIN_STRIP_ROWS
     //                 tile-rows; cuts another ~0.4 GB but runs 25 % slower — profiles/r03_xwindow_and_map.txt; opt-in only)
@@ -512,7 +513,7 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     if (brick && xs1 == 0) detect_strides(T, tr0, tr1, csr_split, dense_mfma, &xs1, &xs2);
     if (xs1 < 2 || (K.x_window < 0 && xs2 == 0)) brick = false;   // (2-D grids: measured neutral on the 5-point 4096^2 case)
     bool xwin = brick && K.x_window == 1 && entry_mode != 1;   // (the windowed kernel exists for entry modes 0 and 2)
-    // (strips of at most 4 tile-rows in brick plans: nlpkkt160 stand-in fp64 0.418 -> 0.414 ms, fp32 0.252 -> 0.250; 2 rows: KKT 0.408 but 7-pt 256^3 +5 %)
+    // (strips of at most 4 tile-rows in brick plans: nlpkkt160 stand-in fp64 0.418 -> 0.414 ms, fp32 0.252 -> 0.250 in one process; 2 rows: KKT 0.408 but 7-pt 256^3 +5 %)
     const int max_strip_rows = xwin ? XWIN_STRIP_ROWS : brick ? (K.brick_rows > 0 ? std::min(K.brick_rows, STRIP_MAX_ROWS) : 4) : STRIP_MAX_ROWS;
     if (brick && !K.xcd_from_caller) plan->xcd_chunk = 8;   // bricks are compact: smaller XCD windows keep an XCD's resident set together
     std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
