@@ -8,7 +8,10 @@ cd $root/tilespmv_amd/csrc
 for f in host_tile_create host_tilespmv_cpu host_mmio host_matrix_io; do
   g++ -O1 -g -fPIC -std=c++17 -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -DMAT_VAL_TYPE=double -c $f.cpp -o $out/$f.o
 done
-g++ -shared -fsanitize=address,undefined -pthread $out/*.o -o $out/libhost_asan.so
+# the plan layout builder, host-only (plain g++; libamdhip64 only satisfies the linker: tilespmv_plan_layout_digest makes no HIP call)
+g++ -O1 -g -fPIC -std=c++17 -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -DMAT_VAL_TYPE=double -Wno-unused-result -x c++ -c hip_plan.hip -o $out/hip_plan.o
+g++ -O1 -g -fPIC -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -DMAT_VAL_TYPE=double -c $root/scripts/host_stubs.cpp -o $out/host_stubs.o
+g++ -shared -fsanitize=address,undefined -pthread $out/*.o -o $out/libhost_asan.so -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 cd $out
 LD_PRELOAD=$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 \
   TILESPMV_NUM_THREADS=4 python $root/scripts/asan_host_drive.py > $out/out.txt 2> $out/err.txt

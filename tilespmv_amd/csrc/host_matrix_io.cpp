@@ -151,7 +151,7 @@ extern "C" int tilespmv_matrix_load(Tile_matrix *matrix, int *rowA, int *colA, M
 
 namespace {
 
-const char CSR_MAGIC[8] = {'T', 'S', 'C', 'S', 'R', '0', '0', '1'};
+const char CSR_MAGIC[8] = {'T', 'S', 'C', 'S', 'R', '0', '0', '2'};
 
 struct SourceId { long long size, mtime_s, mtime_ns; };
 
@@ -175,6 +175,7 @@ extern "C" int tilespmv_csr_save(const char *path, int m, int n, MAT_PTR_TYPE nn
     (void)source_id(source_mtx, &id);
     unsigned long long h = 0xCBF29CE484222325ull;
     h = fnv1a(head, sizeof(head), h);
+    h = fnv1a(&id, sizeof(id), h);
     h = fnv1a(rowptr, sizeof(MAT_PTR_TYPE) * ((size_t)m + 1), h);
     h = fnv1a(colidx, sizeof(int) * (size_t)nnz, h);
     h = fnv1a(val, sizeof(tilespmv::val_t) * (size_t)nnz, h);
@@ -216,6 +217,7 @@ extern "C" int tilespmv_csr_load(const char *path, int *m, int *n, MAT_PTR_TYPE 
     if (ok) {
         unsigned long long h = 0xCBF29CE484222325ull;
         h = fnv1a(head, sizeof(head), h);
+        h = fnv1a(&id, sizeof(id), h);
         h = fnv1a(rp, sizeof(MAT_PTR_TYPE) * ((size_t)M + 1), h);
         h = fnv1a(ci, sizeof(int) * (size_t)NZ, h);
         h = fnv1a(v, sizeof(tilespmv::val_t) * (size_t)NZ, h);
