@@ -286,7 +286,8 @@ typedef struct {
                            entry pass over the merged lists (entry mode 2); unset: by plan and nvec                        TILESPMV_MV_NATIVE */
     int mv_xcd_chunk;   /* XCD window of the multi-vector kernel                                             TILESPMV_MV_XCD_CHUNK */
     int lds_pad;        /* bytes of unused LDS added to every unit-kernel workgroup: fewer resident workgroups per CU  TILESPMV_LDS_PAD */
-    int reserved[5];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
+    int y_store;        /* y stores: 1 streaming (nontemporal), 0 plain; unset: streaming where y is >= 5 % of the launch's bytes  TILESPMV_Y_STORE */
+    int reserved[4];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
 

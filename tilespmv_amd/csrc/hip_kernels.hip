@@ -301,7 +301,7 @@ constexpr int DCHUNK = 16;  // units per descriptor chunk
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 #ifndef NT_Y
-#define NT_Y 1  // y is written once and not re-read by this kernel: streaming (nontemporal) stores keep it from displacing x in L2 (+1-2 %)
+#define NT_Y 1  // y is written once and not re-read by this kernel: streaming (nontemporal) stores keep it from displacing x in L2 (+1-2 %; per plan: DevStream::y_streaming)
 #endif
 #ifndef WCOO_HEAVY_CT
 #define WCOO_HEAVY_CT 6  // sub-chunks (of 64 / 256 entries) per trip of the wavefront / workgroup entry phase
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         const long long ybase = (long long)row0 * 16;
         for (int i = r * VEC; i < 16 * nrows; i += 16 * VEC) {
             if (ybase + i + VEC <= rowA) {
-                if (NT_Y) __builtin_nontemporal_store(*reinterpret_cast<const v4u_t *>(res + i), reinterpret_cast<v4u_t *>(y + ybase + i));
+                if (NT_Y && S.y_streaming) __builtin_nontemporal_store(*reinterpret_cast<const v4u_t *>(res + i), reinterpret_cast<v4u_t *>(y + ybase + i));
                 else *reinterpret_cast<uint4 *>(y + ybase + i) = *reinterpret_cast<const uint4 *>(res + i);
             } else {
 #pragma unroll

@@ -66,6 +66,7 @@ struct Knobs {
     int x_stride1, x_stride2;   // tile-rows per grid line / plane for the x windows; 0 = detected from the shard
     int lds_pad;         // bytes of unused LDS added to every unit-kernel workgroup (fewer resident workgroups per CU); -1 = chosen from the shard
     int brick_rows;      // brick order: tile-rows per strip at most (experiment knob, environment only)
+    int y_store;         // -1 by rule, 0 plain y stores, 1 streaming (nontemporal) y stores
     int mv_native;       // -1 = by nvec
     int mv_xcd_chunk;    // -1 = the plan's XCD chunk
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
@@ -106,6 +107,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.x_stride2 = pick(o.x_stride2, "TILESPMV_X_STRIDE2", 0);
     k.lds_pad = pick(o.lds_pad, "TILESPMV_LDS_PAD", -1);
     k.brick_rows = env_int("TILESPMV_BRICK_ROWS", 0);
+    k.y_store = pick(o.y_store, "TILESPMV_Y_STORE", -1);
     k.mv_native = pick(o.mv_native, "TILESPMV_MV_NATIVE", -1);
     k.mv_xcd_chunk = pick(o.mv_xcd_chunk, "TILESPMV_MV_XCD_CHUNK", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
@@ -1003,6 +1005,13 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     // webbase stand-ins in round 1, best or within 1 %)
     S.coo_heavy_min = K.coo_heavy_min;
     S.coo_ordered = coo_ordered ? 1 : 0;
+    // y stores: streaming (nontemporal) where y is a real share of what the launch moves — they keep y from displacing x in L2: config 4 0.1946 -> 0.1845 ms,
+    // 7-pt 256^3 0.2533 -> 0.2432, power-law 8 M 0.1078 -> 0.1043 — plain where it is a few per cent: there the streaming form buys nothing and makes the time
+    // depend on where the CALLER's y happens to sit (nlpkkt160 stand-in fp64: 0.413 or 0.459 ms by the copy of y; plain: 0.408-0.411 with every copy)
+    {
+        const long long stream_b = NU * (12 + 16LL * sv) + NC * (sv + 4LL), y_b = 16LL * ntr * sv;
+        S.y_streaming = K.y_store >= 0 ? (K.y_store != 0) : (y_b * 20 >= stream_b);   // >= 5 %
+    }
     plan->info[TILESPMV_INFO_ENTRY_MODE] = entry_mode;
     plan->info[TILESPMV_INFO_ENTRY_ORDERED] = (entry_mode != 2 || coo_ordered) ? 1 : 0;
     plan->info[TILESPMV_INFO_STRIP_COST] = target;
