@@ -910,6 +910,10 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     constexpr int STRIPS = GROUPS_PER_BLOCK / Q;
     typedef MVec<NV> vec_t;
     constexpr int UB = UNIT_GROUP;          // one 16-byte value load per batch (2 units fp64, 4 units fp32)
+    // the next descriptor chunk is prefetched into registers (4 VGPRs) except in the fp64 nvec 4 / 8 variants: there the
+    // prefetch pushed the kernel 12 bytes into scratch at 80 VGPRs, and loading the chunk at the switch is 3.4-4.3 % faster
+    // (profiles/r03_spmm.txt)
+    constexpr bool MV_PREFETCH_DESC = !(sizeof(val_t) == 8 && NVT >= 4);
     __shared__ val_t s_c[GROUPS_PER_BLOCK][16][NV];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
@@ -958,7 +962,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     val_t v[UB];
     if (have_units) {
         dcur = load_udesc(S.udesc_cb, min(unit_begin + r, last));
-        dnext = load_udesc(S.udesc_cb, min(unit_begin + DCHUNK + r, last));
+        if (MV_PREFETCH_DESC) dnext = load_udesc(S.udesc_cb, min(unit_begin + DCHUNK + r, last));
         load_grp(unit_begin, v);
     }
     if (ncoo > 0) {
@@ -1058,10 +1062,10 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
         for (int u = unit_begin; u < unit_end; u += UB) {
             if (u == chunk_end) {
                 wave_lds_fence();
-                s_d[g][r] = dnext;
+                s_d[g][r] = MV_PREFETCH_DESC ? dnext : load_udesc(S.udesc_cb, min(chunk_end + r, last));
                 wave_lds_fence();
                 chunk_end += DCHUNK;
-                dnext = load_udesc(S.udesc_cb, min(chunk_end + r, last));
+                if (MV_PREFETCH_DESC) dnext = load_udesc(S.udesc_cb, min(chunk_end + r, last));
             }
             const int j0 = u - (chunk_end - DCHUNK);
             uint2 d[UB];
