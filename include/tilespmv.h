@@ -287,7 +287,9 @@ typedef struct {
     int mv_xcd_chunk;   /* XCD window of the multi-vector kernel                                             TILESPMV_MV_XCD_CHUNK */
     int lds_pad;        /* bytes of unused LDS added to every unit-kernel workgroup: fewer resident workgroups per CU  TILESPMV_LDS_PAD */
     int y_store;        /* y stores: 1 streaming (nontemporal), 0 plain; unset: streaming where y is >= 5 % of the launch's bytes  TILESPMV_Y_STORE */
-    int reserved[4];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
+    int desc_dict;      /* unit descriptors: 1 / unset = 4 B per unit + a dictionary of column patterns where the shard's units use few
+                           distinct patterns (stencil-like shards), 0 = always the 12-B form                                  TILESPMV_DESC_DICT */
+    int reserved[3];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
 
@@ -364,7 +366,8 @@ enum {
     TILESPMV_INFO_X_WINDOW_SLOTS = 17,    /* x-window plans: column blocks of the largest workgroup window (0 = no windows) */
     TILESPMV_INFO_X_WINDOW_SEGMENTS = 18, /* ... and of all windows together: x segments (16 values each) loaded per SpMV */
     TILESPMV_INFO_BRICK_ORDER = 19,       /* 1: the strips were regrouped into bricks of the grid (stencil-like shard) */
-    TILESPMV_INFO_COUNT = 20
+    TILESPMV_INFO_DESC_BYTES = 20,        /* bytes per unit descriptor in HBM: 12, or 4 (column-pattern dictionary) */
+    TILESPMV_INFO_COUNT = 21
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
 

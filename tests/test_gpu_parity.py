@@ -622,8 +622,10 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
     knob_sets = [dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, entry_ordered=1), dict(entry_mode=2, entry_ordered=0),
                  dict(entry_mode=2, wg_strips=32, entry_ordered=1), dict(x_window=1), dict(x_window=1, entry_mode=0), dict(x_window=1, entry_mode=2),
                  dict(x_window=1, entry_mode=2, strip_cost=200), dict(x_window=1, x_stride1=3), dict(lds_pad=12288, xcd_remap=0),
-                 dict(x_window=1, strip_cost=64, split_above=200), dict(x_window=2), dict(x_window=2, entry_mode=2, xcd_chunk=4), dict(x_window=0)]
+                 dict(x_window=1, strip_cost=64, split_above=200), dict(x_window=2), dict(x_window=2, entry_mode=2, xcd_chunk=4), dict(x_window=0),
+                 dict(desc_dict=0), dict(desc_dict=0, entry_mode=2), dict(desc_dict=0, entry_mode=1), dict(desc_dict=1, entry_mode=1, strip_cost=100)]
     windowed = bricks = 0
+    desc = {4: 0, 12: 0}
     for name, gen in mats.items():
         m, n, rp, ci = gen()
         nnz, rowA = len(ci), truncated_rows(m)
@@ -637,6 +639,8 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
                 assert info["entry_mode"] == kw["entry_mode"]
             windowed += info["x_window_slots"] > 0
             bricks += info["brick_order"] == 1
+            desc[info["desc_bytes"]] += 1
+            assert info["desc_bytes"] == 12 or (kw.get("desc_dict") != 0 and info["x_window_slots"] == 0)
             assert not (kw.get("x_window") == 0 and info["brick_order"])
         # multi-vector product on an x-window plan: its kernel reads the column-block descriptors kept beside the slotted ones
         plan = api.Plan(tp, rowA, n, nnz, x_window=1, entry_mode=0)
@@ -649,6 +653,7 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
         plan.close()
         api.Tile_destroy(tp)
     assert windowed >= 12 and bricks >= 20     # the stencil / KKT matrices really took the windowed kernel / the brick order
+    assert desc[4] >= 30 and desc[12] >= 18    # both descriptor forms ran (4 B + pattern dictionary is the default wherever the patterns are few)
 
 
 def test_matrix_cache_to_plan_matches_oracle(torch_cuda, tmp_path):

@@ -70,6 +70,31 @@ def test_brick_order_is_detected_on_3d_grids_only():
         api.Tile_destroy(tm)
 
 
+def test_dictionary_descriptors_where_patterns_are_few():
+    """4-B unit descriptors + a dictionary of column patterns (stencils: a handful of patterns); 12 B when the knob says so,
+    when the patterns do not fit the dictionary, and on x-window plans (their descriptors hold window slots)."""
+    m, n, rp, ci = G.laplacian7pt(48)
+    rows = cases.truncated_rows(m); nnz = int(rp[rows])
+    tm = api.Tile_create(rows, n, nnz, rp, ci, G.compat_values(len(ci)))
+    d4, i4 = api.plan_layout_digest(tm, rows, n, nnz)
+    d12, i12 = api.plan_layout_digest(tm, rows, n, nnz, desc_dict=0)
+    _, iw = api.plan_layout_digest(tm, rows, n, nnz, x_window=1, entry_mode=0)
+    assert (i4["desc_bytes"], i12["desc_bytes"]) == (4, 12) and d4 != d12
+    assert iw["x_window_slots"] == 0 or iw["desc_bytes"] == 12
+    assert i12["stream_bytes"] - i4["stream_bytes"] >= 8 * (nnz // 16) * 0.9      # 8 bytes per unit less to read
+    api.Tile_destroy(tm)
+    # thousands of distinct patterns (random columns inside ELL / CSR-as-units tiles): the dictionary is refused, 12 B stay
+    rng = np.random.default_rng(11)
+    rows_, cols_ = 16 * 1200, 16 * 1200
+    ri = np.repeat(np.arange(rows_), 6)
+    cj = (ri // 16) * 16 + rng.integers(0, 16, len(ri))          # six random columns of the diagonal tile per row
+    m2, n2, rp2, ci2 = G.from_coo(rows_, cols_, ri, cj)
+    tm = api.Tile_create(rows_, cols_, len(ci2), rp2, ci2, G.compat_values(len(ci2)))
+    _, info = api.plan_layout_digest(tm, rows_, cols_, len(ci2))
+    assert info["desc_bytes"] == 12
+    api.Tile_destroy(tm)
+
+
 def test_environment_is_only_a_default(monkeypatch):
     tm, rows, n, nnz = _tm("powerlaw20k")
     by_option, info = api.plan_layout_digest(tm, rows, n, nnz, entry_mode=2, strip_cost=800, entry_ordered=1)

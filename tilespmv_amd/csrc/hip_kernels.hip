@@ -287,6 +287,16 @@ __device__ __forceinline__ uint4 load_udesc(const UDesc *__restrict__ d, int i)
     return make_uint4(u.w0, u.n0, u.w0, u.n1);
 }
 
+// Dictionary plans (DevStream::cb_bits > 0; hip_plan.hip): 4 B per unit in HBM — column block | pattern id << cb_bits |
+// flags << 27 — and the unit's column pattern (the two nibble words) in a small dictionary that stays in the vector L1.
+// A lane expands its unit's descriptor to the 16-B LDS form when the chunk is parked.
+__device__ __forceinline__ uint2 udict_of(const DevStream &S, unsigned w) { return S.udict[(w << 5) >> (5 + S.cb_bits)]; }
+__device__ __forceinline__ uint4 udesc_expand(const DevStream &S, unsigned w, uint2 pat)
+{
+    const unsigned w0 = (w & ((1u << S.cb_bits) - 1u)) | ((w >> 27) << UNIT_FLAG_SHIFT);
+    return make_uint4(w0, pat.x, w0, pat.y);
+}
+
 // Descriptor word layout in LDS (16 B per unit, two identical-purpose halves so that a lane reads 8 B; HBM holds the
 // 12-B form without the duplicate word, UDesc):
 //   word 0 / word 2 : column block (24 bits) | flags << 24   (flag bit 0 = end of tile-row, bits 1-3 = row in strip,
@@ -483,13 +493,16 @@ hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream
 // the descriptor's low 24 bits then hold the window slot.  Strips of such plans have at most XWIN_STRIP_ROWS tile-rows.  (The window
 // leaves room for 4-5 workgroups per CU, so the workgroup-entry form is built for 4 waves per SIMD: at 6 it spills 20 bytes.)
 extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN>
+// CD: dictionary plans (4-B descriptors, above).  The descriptor words are loaded two chunks ahead, the pattern of a chunk is
+// gathered from the dictionary one chunk ahead (when its word has arrived), so neither hop is waited for in the unit loop.
+template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD>
 __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
     static_assert(GPB == 16 || (GPB == 32 && ECOO == 2), "512-thread workgroups exist for the workgroup entry mode only");
     static_assert(!XWIN || (GPB == 16 && ECOO != 1), "x windows: 256-thread workgroups, per-strip or per-workgroup entries");
+    static_assert(!(XWIN && CD), "x-window plans keep 12-B descriptors (their low bits hold window slots)");
     constexpr int GROUPS_PER_BLOCK = GPB;
     constexpr int SROWS = XWIN ? XWIN_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
     constexpr bool NT = false;  // nontemporal value loads: measured neutral
@@ -550,11 +563,18 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         }
     }
     uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
+    unsigned wnn = 0;   // CD: descriptor word of the chunk after `dnext`
+    const unsigned *__restrict__ udw = reinterpret_cast<const unsigned *>(S.udesc);
     val_t v[UB];
     auto unit_prologue = [&]() {  // descriptor chunks 0 and 1, first value batch: in flight across the entry phase
         if (have_units) {
-            dcur = load_udesc(S.udesc, min(unit_begin + r, last));
-            dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
+            if constexpr (CD) {
+                dcur.x = udw[min(unit_begin + r, last)];
+                dnext.x = udw[min(unit_begin + DCHUNK + r, last)];
+            } else {
+                dcur = load_udesc(S.udesc, min(unit_begin + r, last));
+                dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
+            }
 #pragma unroll
             for (int k = 0; k < UB; k += G) {
                 const grp_t pv = stream_load(ugrp + (long long)min(unit_begin + k, last_grp) * (16 / G), NT);
@@ -568,6 +588,14 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     const uint2 *sd = reinterpret_cast<const uint2 *>(&s_d[g][0]) + (r >> 3);  // this lane's 8-B half of a descriptor
     uint2 d[UB];
     val_t xv[UB];
+    auto park_first = [&]() {   // chunk 0 into LDS (CD: the patterns of chunks 0 and 1 are gathered here, the word of chunk 2 loaded)
+        if constexpr (CD) {
+            const uint2 p0 = udict_of(S, dcur.x), p1 = udict_of(S, dnext.x);
+            wnn = udw[min(unit_begin + 2 * DCHUNK + r, last)];
+            dnext.y = p1.x; dnext.w = p1.y;
+            s_d[g][r] = udesc_expand(S, dcur.x, p0);
+        } else s_d[g][r] = dcur;
+    };
     auto fetch_batch = [&](int j0) {
 #pragma unroll
         for (int k = 0; k < UB; k++) d[k] = sd[2 * (j0 + k)];
@@ -621,7 +649,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             }
         }
         if (have_units) {  // waits for the descriptor chunk only (older than the entry loads)
-            s_d[g][r] = dcur;
+            park_first();
             wave_lds_fence();
             fetch_batch(0);
         } else if (tot > 0) wave_lds_fence();
@@ -708,17 +736,22 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     if constexpr (XWIN) __syncthreads();   // the workgroup's x window is complete (every wavefront of an x-window kernel gets here)
     if (have_units) {  // phase 2: units, value loads software-pipelined by one batch
         if (ECOO != 1) {  // (entry mode 1 parked the first chunk and fetched the first batch before its entry phase)
-            s_d[g][r] = dcur;
+            park_first();
             wave_lds_fence();
         }
         int chunk_end = unit_begin + DCHUNK;  // first unit NOT described by the chunk in LDS
         for (int u = unit_begin; u < unit_end; u += UB) {
             if (u == chunk_end) {  // next descriptor chunk: already in registers, fetch the one after it
                 wave_lds_fence();
-                s_d[g][r] = dnext;
+                if constexpr (CD) s_d[g][r] = udesc_expand(S, dnext.x, make_uint2(dnext.y, dnext.w));
+                else s_d[g][r] = dnext;
                 wave_lds_fence();
                 chunk_end += DCHUNK;
-                dnext = load_udesc(S.udesc, min(chunk_end + r, last));
+                if constexpr (CD) {
+                    const uint2 p = udict_of(S, wnn);   // (its word was loaded a chunk ago)
+                    dnext = make_uint4(wnn, p.x, 0u, p.y);
+                    wnn = udw[min(chunk_end + DCHUNK + r, last)];
+                } else dnext = load_udesc(S.udesc, min(chunk_end + r, last));
             }
             if (!(ECOO == 1 && u == unit_begin)) fetch_batch(u - (chunk_end - DCHUNK));
             val_t vn[UB];
@@ -901,7 +934,8 @@ struct alignas(NV * sizeof(val_t) >= 16 ? 16 : NV * sizeof(val_t)) MVec { val_t 
 // wavefront sees the store latency of one strip instead of four (stores retire in order with the loads).
 // skip_entries: the plan's merged, column-ordered entry lists are multiplied by k_entries_mv afterwards (entry-dominated plans with the
 // workgroup entry mode); this kernel then handles units only and stores zeros for the rows without units.
-template <int NVT>
+// CD: dictionary plans (4-B descriptors): the next chunk's words are prefetched (one register), its patterns gathered at the switch.
+template <int NVT, bool CD>
 __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int rowA, int colA, int xcd_chunk, int skip_entries, val_t *__restrict__ partial,
                                                   const val_t *__restrict__ X, val_t *__restrict__ Y)
 {
@@ -959,10 +993,16 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
         for (int j = 0; j < NV; j++) p0.v[j] = cv * xx.v[j];
     }
     uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
+    const unsigned *__restrict__ udw = reinterpret_cast<const unsigned *>(S.udesc_cb);
     val_t v[UB];
     if (have_units) {
-        dcur = load_udesc(S.udesc_cb, min(unit_begin + r, last));
-        if (MV_PREFETCH_DESC) dnext = load_udesc(S.udesc_cb, min(unit_begin + DCHUNK + r, last));
+        if constexpr (CD) {
+            dcur.x = udw[min(unit_begin + r, last)];
+            if (MV_PREFETCH_DESC) dnext.x = udw[min(unit_begin + DCHUNK + r, last)];
+        } else {
+            dcur = load_udesc(S.udesc_cb, min(unit_begin + r, last));
+            if (MV_PREFETCH_DESC) dnext = load_udesc(S.udesc_cb, min(unit_begin + DCHUNK + r, last));
+        }
         load_grp(unit_begin, v);
     }
     if (ncoo > 0) {
@@ -1056,16 +1096,21 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
 
     if (have_units) {
         const uint2 *sd = reinterpret_cast<const uint2 *>(&s_d[g][0]) + (r >> 3);
-        s_d[g][r] = dcur;
+        if constexpr (CD) s_d[g][r] = udesc_expand(S, dcur.x, udict_of(S, dcur.x));
+        else s_d[g][r] = dcur;
         wave_lds_fence();
         int chunk_end = unit_begin + DCHUNK;
         for (int u = unit_begin; u < unit_end; u += UB) {
             if (u == chunk_end) {
                 wave_lds_fence();
-                s_d[g][r] = MV_PREFETCH_DESC ? dnext : load_udesc(S.udesc_cb, min(chunk_end + r, last));
+                if constexpr (CD) {
+                    const unsigned w = MV_PREFETCH_DESC ? dnext.x : udw[min(chunk_end + r, last)];
+                    s_d[g][r] = udesc_expand(S, w, udict_of(S, w));
+                } else s_d[g][r] = MV_PREFETCH_DESC ? dnext : load_udesc(S.udesc_cb, min(chunk_end + r, last));
                 wave_lds_fence();
                 chunk_end += DCHUNK;
-                if (MV_PREFETCH_DESC) dnext = load_udesc(S.udesc_cb, min(chunk_end + r, last));
+                if constexpr (CD) { if (MV_PREFETCH_DESC) dnext.x = udw[min(chunk_end + r, last)]; }
+                else if (MV_PREFETCH_DESC) dnext = load_udesc(S.udesc_cb, min(chunk_end + r, last));
             }
             const int j0 = u - (chunk_end - DCHUNK);
             uint2 d[UB];
@@ -1279,8 +1324,12 @@ static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense
     if (S.ntasks > 0)
     {
         constexpr int strips = GROUPS_PER_BLOCK / (NV < 2 ? 1 : NV / 2);  // per workgroup (k_units_mv: Q lane groups per strip)
-        hipLaunchKernelGGL((k_units_mv<NV>), dim3((unsigned)((S.ntasks + strips - 1) / strips)), dim3(256), 0, st,
-                           S, P.rowA, P.colA, xcd_chunk, entries_pass ? 1 : 0, P.partial, X, Y);
+        if (S.cb_bits > 0)
+            hipLaunchKernelGGL((k_units_mv<NV, true>), dim3((unsigned)((S.ntasks + strips - 1) / strips)), dim3(256), 0, st,
+                               S, P.rowA, P.colA, xcd_chunk, entries_pass ? 1 : 0, P.partial, X, Y);
+        else
+            hipLaunchKernelGGL((k_units_mv<NV, false>), dim3((unsigned)((S.ntasks + strips - 1) / strips)), dim3(256), 0, st,
+                               S, P.rowA, P.colA, xcd_chunk, entries_pass ? 1 : 0, P.partial, X, Y);
     }
     if (DN.nrows > 0)
         hipLaunchKernelGGL((k_dense_mfma_mv<NV>), dim3((DN.nrows + 3) / 4), dim3(256), 0, st, DN, P.rowA, P.colA, P.partial, X, Y);
@@ -1335,13 +1384,15 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
                                const val_t *x, val_t *y, hipStream_t st)
 {
     if (S.ntasks > 0) {
-#define TSPMV_L2(X, W, B, XW) hipLaunchKernelGGL((k_units<4, X, W, B, XW>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
-#define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L2(X, 2, 16, true); else if (xwin_lds_bytes > 0) TSPMV_L2(X, 0, 16, true); \
-        else if (entry_mode == 2 && wg_strips == 32) TSPMV_L2(X, 2, 32, false); else if (entry_mode == 2) TSPMV_L2(X, 2, 16, false); \
-        else if (entry_mode == 1) TSPMV_L2(X, 1, 16, false); else TSPMV_L2(X, 0, 16, false); } while (0)
+#define TSPMV_L3(X, W, B, XW, CD) hipLaunchKernelGGL((k_units<4, X, W, B, XW, CD>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_L2(X, W, B) do { if (S.cb_bits > 0) TSPMV_L3(X, W, B, false, true); else TSPMV_L3(X, W, B, false, false); } while (0)
+#define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L3(X, 2, 16, true, false); else if (xwin_lds_bytes > 0) TSPMV_L3(X, 0, 16, true, false); \
+        else if (entry_mode == 2 && wg_strips == 32) TSPMV_L2(X, 2, 32); else if (entry_mode == 2) TSPMV_L2(X, 2, 16); \
+        else if (entry_mode == 1) TSPMV_L2(X, 1, 16); else TSPMV_L2(X, 0, 16); } while (0)
         if (xcd_remap == 2) TSPMV_L1(2); else TSPMV_L1(0);
 #undef TSPMV_L1
 #undef TSPMV_L2
+#undef TSPMV_L3
     }
     // whole-tile passes (y += ...): CSR tiles kept as tiles, dense tiles on the matrix cores; then the split-row fix-up
     hipError_t e = launch_tiles_direct(P, dense_mfma, /*accumulate=*/true, /*fixup=*/false, x, y, st);

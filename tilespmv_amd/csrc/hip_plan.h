@@ -96,6 +96,7 @@ constexpr int UNIT_ROW_SHIFT = 1;         // unit flag bits 1-3: tile-row inside
 constexpr unsigned UNIT_ROWUNIT = 16u;    // unit flag bit 4: "row unit" = 16 values of ONE tile row (dense-row tiles);
                                           //   lane = column, word 1/3 hold the target row, result needs a 16-lane reduction
 constexpr int UNIT_GROUP = 16 / (int)sizeof(val_t);  // units whose values share one 16-byte lane load (2 in fp64, 4 in fp32)
+constexpr int DICT_MAX_BITS = 10;         // dictionary plans: at most 1024 column patterns (8 KB: stays in the vector L1)
 constexpr int UNIT_FLAG_SHIFT = 24;       // flags live above the 24-bit column block in words 0 and 2
 
 struct UDesc { unsigned w0, n0, n1; };    // 12 bytes in HBM; lanes expand it to (w0, n0, w0, n1) in LDS so that a lane reads one 8-B half
@@ -111,7 +112,7 @@ struct STask {                            // 32 bytes
 };
 
 struct DevStream {
-    const UDesc *udesc;                   // per unit, 12 B: column block | flags << 24, column nibbles of rows 0-7, of rows 8-15
+    const UDesc *udesc;                   // per unit, 12 B: column block | flags << 24, column nibbles of rows 0-7, of rows 8-15 (dictionary plans: 4-B words, see cb_bits)
     const val_t *uval;                    // 16 values per unit, stored in groups of UNIT_GROUP units of one task, interleaved per row
     const val_t *cval;                    // COO entry list: value, global column, (row-in-strip << 4) | row
     const int *ccol;
@@ -134,6 +135,8 @@ struct DevStream {
     // more than XWIN_MAX_SLOTS column blocks keeps column blocks and reads x from global memory (window count 0).
     const int2 *wg_win;                   // per workgroup: [begin, count) in win_cb
     const int *win_cb;                    // column block of every window slot
+    const uint2 *udict;                   // dictionary plans: the column patterns (nibbles of rows 0-7, of rows 8-15); udesc / udesc_cb then hold 4-B words
+    int cb_bits;                          // ... column block (cb_bits) | pattern id | flags << 27;  0 = 12-B descriptors
     const UDesc *udesc_cb;                // descriptors with column blocks for the multi-vector kernel (== udesc when there is no window)
     // split tile-rows whose pieces all live in the unit kernel are summed in that kernel by the piece that
     // finishes last (fixed slot order): ifix[i] describes row i, ifix_count[i] counts finished pieces

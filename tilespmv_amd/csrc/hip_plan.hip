@@ -13,6 +13,7 @@
 #include <cmath>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 
 #include "hip_plan.h"
 
@@ -69,6 +70,7 @@ struct Knobs {
     int y_store;         // -1 by rule, 0 plain y stores, 1 streaming (nontemporal) y stores
     int mv_native;       // -1 = by nvec
     int mv_xcd_chunk;    // -1 = the plan's XCD chunk
+    int desc_dict;       // 0 = always 12-B unit descriptors; otherwise 4-B descriptors + pattern dictionary where the shard allows
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
     bool dry;            // tilespmv_plan_layout_digest: build the layout on the host only, hash instead of upload
     const char *autotune_log;
@@ -110,6 +112,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.y_store = pick(o.y_store, "TILESPMV_Y_STORE", -1);
     k.mv_native = pick(o.mv_native, "TILESPMV_MV_NATIVE", -1);
     k.mv_xcd_chunk = pick(o.mv_xcd_chunk, "TILESPMV_MV_XCD_CHUNK", -1);
+    k.desc_dict = pick(o.desc_dict, "TILESPMV_DESC_DICT", 1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
     k.entry_from_caller = pinned(o.entry_mode, "TILESPMV_WAVE_COO");
     k.strip_from_caller = o.strip_cost > 0 || env_int("TILESPMV_STRIP_COST", 0) > 0;
@@ -896,7 +899,55 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
                 if (n > 0) { k.unit_begin = (int)nb; k.unit_end = (int)(nb + n); }
             }
         });
-        rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc);
+        // ---- 4-B descriptors where the units of the shard use few distinct column patterns (stencil-like shards: 4 patterns in the
+        // 5- and 7-point grids, 36 in the KKT stand-in): column block | pattern id << cb_bits | flags << 27, the patterns (the
+        // two nibble words) in a dictionary the kernels gather from.  Not for x-window plans (their descriptors hold slots).
+        S.udict = nullptr; S.cb_bits = 0;
+        std::vector<uint2> dict;
+        std::vector<unsigned> compact;
+        if (K.desc_dict != 0 && !xwin && NUP > 0) {
+            const int cb_bits = std::max(1, 32 - __builtin_clz((unsigned)std::max(1, T->tilen - 1)));
+            const int pid_bits = std::min(DICT_MAX_BITS, 27 - cb_bits);
+            if (pid_bits >= 1) {
+                const size_t cap = (size_t)1 << pid_bits;
+                std::vector<std::unordered_set<unsigned long long>> local((size_t)host_threads());
+                std::atomic<int> over(0);
+                parallel_chunks((int64_t)NUP, 1 << 16, [&](int64_t b, int64_t e, int th) {
+                    if (over.load(std::memory_order_relaxed)) return;
+                    std::unordered_set<unsigned long long> &L = local[(size_t)th];
+                    for (int64_t u = b; u < e; u++) {
+                        L.insert(((unsigned long long)packed[(size_t)u].n0 << 32) | packed[(size_t)u].n1);
+                        if (L.size() > cap) { over.store(1); return; }
+                    }
+                });
+                std::vector<unsigned long long> all;
+                if (!over.load()) {
+                    for (auto &L : local) all.insert(all.end(), L.begin(), L.end());
+                    std::sort(all.begin(), all.end());
+                    all.erase(std::unique(all.begin(), all.end()), all.end());
+                }
+                if (!over.load() && all.size() <= cap) {
+                    dict.resize(all.size());
+                    for (size_t i = 0; i < all.size(); i++) dict[i] = make_uint2((unsigned)(all[i] >> 32), (unsigned)(all[i] & 0xffffffffull));
+                    compact.resize((size_t)NUP);
+                    const unsigned cbmask = (1u << cb_bits) - 1u;
+                    parallel_chunks((int64_t)NUP, 1 << 16, [&](int64_t b, int64_t e, int) {
+                        for (int64_t u = b; u < e; u++) {
+                            const UDesc &d = packed[(size_t)u];
+                            const unsigned long long key = ((unsigned long long)d.n0 << 32) | d.n1;
+                            const unsigned pid = (unsigned)(std::lower_bound(all.begin(), all.end(), key) - all.begin());
+                            compact[(size_t)u] = (d.w0 & cbmask) | (pid << cb_bits) | ((d.w0 >> UNIT_FLAG_SHIFT) << 27);
+                        }
+                    });
+                    S.cb_bits = cb_bits;
+                }
+            }
+        }
+        if (S.cb_bits > 0) {
+            rc |= plan->upload(compact.data(), compact.size(), reinterpret_cast<const unsigned **>(&S.udesc));
+            rc |= plan->upload(dict.data(), dict.size(), &S.udict);
+        } else rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc);
+        plan->info[TILESPMV_INFO_DESC_BYTES] = S.cb_bits > 0 ? 4 : 12;
         rc |= plan->upload(paired, (size_t)NUP * 16, &S.uval);
         free(paired);
         S.udesc_cb = S.udesc;
@@ -1009,7 +1060,7 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     // 7-pt 256^3 0.2533 -> 0.2432, power-law 8 M 0.1078 -> 0.1043 — plain where it is a few per cent: there the streaming form buys nothing and makes the time
     // depend on where the CALLER's y happens to sit (nlpkkt160 stand-in fp64: 0.413 or 0.459 ms by the copy of y; plain: 0.408-0.411 with every copy)
     {
-        const long long stream_b = NU * (12 + 16LL * sv) + NC * (sv + 4LL), y_b = 16LL * ntr * sv;
+        const long long stream_b = NU * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + NC * (sv + 4LL), y_b = 16LL * ntr * sv;
         S.y_streaming = K.y_store >= 0 ? (K.y_store != 0) : (y_b * 20 >= stream_b);   // >= 5 %
     }
     plan->info[TILESPMV_INFO_ENTRY_MODE] = entry_mode;
@@ -1020,7 +1071,7 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     plan->info[TILESPMV_INFO_X_WINDOW_SEGMENTS] = xwin ? xwin_segments : 0;
     plan->mv_by_columns = entry_dominated && target >= 800;   // (small strips hold few entries each: scircuit-like 18 / 22 / 32 us native against 22 / 41 / 78 us)
     n_tasks = (long long)tasks.size();
-    model_bytes = NUP * (12 + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
+    model_bytes = NUP * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
                   ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
     return rc;
