@@ -289,7 +289,9 @@ typedef struct {
     int y_store;        /* y stores: 1 streaming (nontemporal), 0 plain; unset: streaming where y is >= 5 % of the launch's bytes  TILESPMV_Y_STORE */
     int desc_dict;      /* unit descriptors: 1 / unset = 4 B per unit + a dictionary of column patterns where the shard's units use few
                            distinct patterns (stencil-like shards), 0 = always the 12-B form                                  TILESPMV_DESC_DICT */
-    int reserved[3];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
+    int nt_stream;      /* value / entry-record loads: 1 nontemporal, 0 default cache policy; unset: nontemporal where one SpMV moves more
+                           than 400 MB (about 1.6 x the Infinity Cache)                                                             TILESPMV_NT_STREAM */
+    int reserved[2];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
 
@@ -367,7 +369,8 @@ enum {
     TILESPMV_INFO_X_WINDOW_SEGMENTS = 18, /* ... and of all windows together: x segments (16 values each) loaded per SpMV */
     TILESPMV_INFO_BRICK_ORDER = 19,       /* 1: the strips were regrouped into bricks of the grid (stencil-like shard) */
     TILESPMV_INFO_DESC_BYTES = 20,        /* bytes per unit descriptor in HBM: 12, or 4 (column-pattern dictionary) */
-    TILESPMV_INFO_COUNT = 21
+    TILESPMV_INFO_NT_STREAM = 21,         /* 1: the unit kernel reads the value / entry-record streams with nontemporal loads */
+    TILESPMV_INFO_COUNT = 22
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
 

@@ -103,6 +103,7 @@ def check(seed):
     if seed % 4 == 1: env["TILESPMV_X_WINDOW"] = str([1, 2, 1, -1][(seed // 4) % 4])
     if seed % 6 == 3 and env.get("TILESPMV_WAVE_COO") == "2": env["TILESPMV_WG_STRIPS"] = "32"
     if seed % 9 == 5: env["TILESPMV_LDS_PAD"] = "8192"
+    if seed % 4 == 2: env["TILESPMV_NT_STREAM"] = "1"   # nontemporal value / entry-record loads (by rule only on launches above 400 MB)
     if seed % 3 == 1: env["TILESPMV_DESC_DICT"] = "0"   # 12-B unit descriptors (the default takes the 4-B dictionary form wherever the patterns are few)
     os.environ.update(env)
     for dt in (np.float64, np.float32):

@@ -623,7 +623,8 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
                  dict(entry_mode=2, wg_strips=32, entry_ordered=1), dict(x_window=1), dict(x_window=1, entry_mode=0), dict(x_window=1, entry_mode=2),
                  dict(x_window=1, entry_mode=2, strip_cost=200), dict(x_window=1, x_stride1=3), dict(lds_pad=12288, xcd_remap=0),
                  dict(x_window=1, strip_cost=64, split_above=200), dict(x_window=2), dict(x_window=2, entry_mode=2, xcd_chunk=4), dict(x_window=0),
-                 dict(desc_dict=0), dict(desc_dict=0, entry_mode=2), dict(desc_dict=0, entry_mode=1), dict(desc_dict=1, entry_mode=1, strip_cost=100)]
+                 dict(desc_dict=0), dict(desc_dict=0, entry_mode=2), dict(desc_dict=0, entry_mode=1), dict(desc_dict=1, entry_mode=1, strip_cost=100),
+                 dict(nt_stream=1), dict(nt_stream=1, entry_mode=2, entry_ordered=1), dict(nt_stream=1, desc_dict=0, entry_mode=0), dict(nt_stream=0)]
     windowed = bricks = 0
     desc = {4: 0, 12: 0}
     for name, gen in mats.items():
@@ -640,6 +641,7 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
             windowed += info["x_window_slots"] > 0
             bricks += info["brick_order"] == 1
             desc[info["desc_bytes"]] += 1
+            assert info["nt_stream"] == (1 if kw.get("nt_stream") == 1 and kw.get("entry_mode") != 1 and not info["x_window_slots"] else 0)   # (small test matrices: off by rule)
             assert info["desc_bytes"] == 12 or (kw.get("desc_dict") != 0 and info["x_window_slots"] == 0)
             assert not (kw.get("x_window") == 0 and info["brick_order"])
         # multi-vector product on an x-window plan: its kernel reads the column-block descriptors kept beside the slotted ones

@@ -80,6 +80,7 @@ def test_dictionary_descriptors_where_patterns_are_few():
     d12, i12 = api.plan_layout_digest(tm, rows, n, nnz, desc_dict=0)
     _, iw = api.plan_layout_digest(tm, rows, n, nnz, x_window=1, entry_mode=0)
     assert (i4["desc_bytes"], i12["desc_bytes"]) == (4, 12) and d4 != d12
+    assert i4["nt_stream"] == 0 and api.plan_layout_digest(tm, rows, n, nnz, nt_stream=1)[1]["nt_stream"] == 1    # small launch: default cache policy unless asked
     assert iw["x_window_slots"] == 0 or iw["desc_bytes"] == 12
     assert i12["stream_bytes"] - i4["stream_bytes"] >= 8 * (nnz // 16) * 0.9      # 8 bytes per unit less to read
     api.Tile_destroy(tm)

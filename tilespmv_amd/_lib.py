@@ -18,20 +18,20 @@ _CACHE = {}
 
 INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel",
               "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us", "entry_mode", "entry_ordered", "strip_cost",
-              "wg_strips", "x_window_slots", "x_window_segments", "brick_order", "desc_bytes"]
+              "wg_strips", "x_window_slots", "x_window_segments", "brick_order", "desc_bytes", "nt_stream"]
 
 
 KNOB_DEFAULT = -1
 # tuning knobs of tilespmv_plan_options (include/tilespmv.h), in struct order after `autotune`
 KNOB_NAMES = ["entry_mode", "entry_ordered", "strip_cost", "split_above", "split_cap", "xcd_remap", "xcd_chunk", "csr_split", "fix_inline",
-              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "x_stride1", "x_stride2", "lds_pad", "y_store", "mv_native", "mv_xcd_chunk", "desc_dict"]
+              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "x_stride1", "x_stride2", "lds_pad", "y_store", "mv_native", "mv_xcd_chunk", "desc_dict", "nt_stream"]
 
 
 class PlanOptions(C.Structure):
     """Mirror of the versioned tilespmv_plan_options: `size` first, unset knobs = KNOB_DEFAULT."""
     _fields_ = ([("size", C.c_uint), ("coo_mode", C.c_int), ("dense_mode", C.c_int), ("kernel", C.c_int),
                  ("tilerow_begin", C.c_int), ("tilerow_end", C.c_int), ("autotune", C.c_int)] +
-                [(k, C.c_int) for k in KNOB_NAMES] + [("reserved", C.c_int * 3)])
+                [(k, C.c_int) for k in KNOB_NAMES] + [("reserved", C.c_int * 2)])
 
     def __init__(self, coo_mode=0, dense_mode=0, kernel=0, tilerow_begin=0, tilerow_end=0, autotune=False, **knobs):
         super().__init__()
@@ -40,7 +40,7 @@ class PlanOptions(C.Structure):
         self.tilerow_begin, self.tilerow_end, self.autotune = tilerow_begin, tilerow_end, 1 if autotune else 0
         for k in KNOB_NAMES:
             setattr(self, k, KNOB_DEFAULT)
-        for i in range(3):
+        for i in range(2):
             self.reserved[i] = KNOB_DEFAULT
         for k, v in knobs.items():
             if k not in KNOB_NAMES:

@@ -274,10 +274,11 @@ hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulat
 // ================================================================================================
 namespace tilespmv {
 
-template <class T>
-__device__ __forceinline__ T stream_load(const T *p, bool nt)
+template <bool NT, class T>
+__device__ __forceinline__ T stream_load(const T *p)
 {
-    return nt ? __builtin_nontemporal_load(p) : *p;
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
 
 // 12-B descriptor in HBM -> the 16-B form the strip parks in LDS (both halves carry word 0)
@@ -372,7 +373,9 @@ __device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t
 #ifndef WG_TRIP_PIPE
 #define WG_TRIP_PIPE 0   // 1: the next trip's records are requested behind the current trip's gathers.  Measured (profiles/r03_entry_ablations.txt): power-law 8 M 0.1039 -> 0.1065 ms, KKT fp64 0.427 -> 0.435, webbase 13.1 -> 12.9 us at 4 x 256 per trip; 6 x 256 spills.  Off.
 #endif
-template <int CT, int NT>
+// NTL: the records are read with nontemporal loads (plans whose streams do not fit the Infinity Cache: the once-read stream
+// then does not displace x in the L2s; DevStream::nt_stream).
+template <int CT, int NT, bool NTL>
 __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, const unsigned *__restrict__ base, int chunk0, int db, bool ordered,
                                                const val_t *__restrict__ x, val_t *sy, int tid, int gb, int ge)
 {
@@ -388,7 +391,12 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
     auto load_trip = [&](int e0, ERec (&r)[CT], unsigned (&c)[CT]) {   // unconditional, clamped: exact vmcnt
 #pragma unroll
         for (int q = 0; q < CT; q++) {
-            r[q] = rec[min(e0 + NT * q + tid, ge - 1)];
+            if constexpr (NTL) {   // (the adjacent nontemporal dword loads become one global_load_dwordx3 / dwordx2 nt)
+                const unsigned *pw = reinterpret_cast<const unsigned *>(&rec[min(e0 + NT * q + tid, ge - 1)]);
+                unsigned *rw = reinterpret_cast<unsigned *>(&r[q]);
+#pragma unroll
+                for (int z = 0; z < (int)(sizeof(ERec) / 4); z++) rw[z] = __builtin_nontemporal_load(pw + z);
+            } else r[q] = rec[min(e0 + NT * q + tid, ge - 1)];
             c[q] = base[__builtin_amdgcn_readfirstlane(min(chunk0 + ((e0 - gb) >> 6) + (NT / 64) * q + wave, clast))];   // a wavefront's 64 records are one chunk
 #if defined(TILESPMV_ABL) && TILESPMV_ABL == 5
             r[q].w += reinterpret_cast<const unsigned short *>(base)[min(e0 + NT * q + tid, ge - 1)] & 1u;
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(256) void k_fallback_entries(DevPlan P, const val_t
     const int nrows = b.y < 0 ? 1 : b.y;
     for (int i = tid; i < nrows; i += 256) s_acc[i] = 0;
     __syncthreads();
-    wg_entry_trips<6, 256>(P.f_rec, P.f_base, b.z >> 6, FB_DEST_BITS, P.f_ordered != 0, x, s_acc, tid, b.z, b.w);   // a block's list starts on a chunk boundary
+    wg_entry_trips<6, 256, false>(P.f_rec, P.f_base, b.z >> 6, FB_DEST_BITS, P.f_ordered != 0, x, s_acc, tid, b.z, b.w);   // a block's list starts on a chunk boundary
     __syncthreads();
     if (b.y < 0) {
         if (tid == 0) atomicAdd(&y[(long long)P.f_row0 + b.x], s_acc[0]);
@@ -495,7 +503,8 @@ hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream
 extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
 // CD: dictionary plans (4-B descriptors, above).  The descriptor words are loaded two chunks ahead, the pattern of a chunk is
 // gathered from the dictionary one chunk ahead (when its word has arrived), so neither hop is waited for in the unit loop.
-template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD>
+// NTS: value and entry-record loads are nontemporal (plans larger than the Infinity Cache, DevStream::nt_stream).
+template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD, bool NTS>
 __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
@@ -503,9 +512,17 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     static_assert(GPB == 16 || (GPB == 32 && ECOO == 2), "512-thread workgroups exist for the workgroup entry mode only");
     static_assert(!XWIN || (GPB == 16 && ECOO != 1), "x windows: 256-thread workgroups, per-strip or per-workgroup entries");
     static_assert(!(XWIN && CD), "x-window plans keep 12-B descriptors (their low bits hold window slots)");
+    static_assert(!(NTS && (XWIN || ECOO == 1)), "nontemporal streams: large plans only (entry mode 1 = small grids; x windows are an opt-in experiment)");
     constexpr int GROUPS_PER_BLOCK = GPB;
     constexpr int SROWS = XWIN ? XWIN_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
-    constexpr bool NT = false;  // nontemporal value loads: measured neutral
+    constexpr bool NT = NTS;  // nontemporal value loads
+#ifndef TILESPMV_NT_DESC
+#define TILESPMV_NT_DESC 0
+#endif
+#ifndef TILESPMV_NT_COO0
+#define TILESPMV_NT_COO0 0
+#endif
+    constexpr bool NT_DESC = NTS && TILESPMV_NT_DESC, NT_COO0 = NTS && TILESPMV_NT_COO0;
     __shared__ val_t s_y[GROUPS_PER_BLOCK][SROWS][16];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     val_t *s_xw = reinterpret_cast<val_t *>(s_dyn);   // [window slot][16]
@@ -569,15 +586,15 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     auto unit_prologue = [&]() {  // descriptor chunks 0 and 1, first value batch: in flight across the entry phase
         if (have_units) {
             if constexpr (CD) {
-                dcur.x = udw[min(unit_begin + r, last)];
-                dnext.x = udw[min(unit_begin + DCHUNK + r, last)];
+                dcur.x = stream_load<NT_DESC>(udw + min(unit_begin + r, last));
+                dnext.x = stream_load<NT_DESC>(udw + min(unit_begin + DCHUNK + r, last));
             } else {
                 dcur = load_udesc(S.udesc, min(unit_begin + r, last));
                 dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
             }
 #pragma unroll
             for (int k = 0; k < UB; k += G) {
-                const grp_t pv = stream_load(ugrp + (long long)min(unit_begin + k, last_grp) * (16 / G), NT);
+                const grp_t pv = stream_load<NT>(ugrp + (long long)min(unit_begin + k, last_grp) * (16 / G));
 #pragma unroll
                 for (int q = 0; q < G; q++) v[k + q] = pv[q];
             }
@@ -591,7 +608,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     auto park_first = [&]() {   // chunk 0 into LDS (CD: the patterns of chunks 0 and 1 are gathered here, the word of chunk 2 loaded)
         if constexpr (CD) {
             const uint2 p0 = udict_of(S, dcur.x), p1 = udict_of(S, dnext.x);
-            wnn = udw[min(unit_begin + 2 * DCHUNK + r, last)];
+            wnn = stream_load<NT_DESC>(udw + min(unit_begin + 2 * DCHUNK + r, last));
             dnext.y = p1.x; dnext.w = p1.y;
             s_d[g][r] = udesc_expand(S, dcur.x, p0);
         } else s_d[g][r] = dcur;
@@ -621,7 +638,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         unit_prologue();
         TSPMV_STAMP_WAIT(2);   // prologue has arrived (the entry loads are inside the trips)
         if (wr.y > wr.x) {
-            wg_entry_trips<WCOO_HEAVY_CT, 16 * GPB>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y);
+            wg_entry_trips<WCOO_HEAVY_CT, 16 * GPB, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y);
             __syncthreads();
         }
         TSPMV_STAMP_WAIT(3);   // entry phase done
@@ -694,7 +711,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     }
     unsigned rb0 = 0; int cc0 = 0; val_t cv0 = 0;
     const bool coo0 = side && !coo_heavy && (coo_begin + r < coo_end);
-    if (coo0) { rb0 = S.crow[coo_begin + r]; cc0 = S.ccol[coo_begin + r]; cv0 = S.cval[coo_begin + r]; }
+    if (coo0) { rb0 = stream_load<NT_COO0>(S.crow + coo_begin + r); cc0 = stream_load<NT_COO0>(S.ccol + coo_begin + r); cv0 = stream_load<NT_COO0>(S.cval + coo_begin + r); }
     unit_prologue();
     if (side && !coo_heavy) {  // up to coo_heavy_min entries: 16 with the prologue loads, the rest 4 x 16 per trip
         if (coo0) atomicAdd(&s_y[g][rb0 >> 4][rb0 & 15u], cv0 * x[cc0]);
@@ -750,14 +767,14 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
                 if constexpr (CD) {
                     const uint2 p = udict_of(S, wnn);   // (its word was loaded a chunk ago)
                     dnext = make_uint4(wnn, p.x, 0u, p.y);
-                    wnn = udw[min(chunk_end + DCHUNK + r, last)];
+                    wnn = stream_load<NT_DESC>(udw + min(chunk_end + DCHUNK + r, last));
                 } else dnext = load_udesc(S.udesc, min(chunk_end + r, last));
             }
             if (!(ECOO == 1 && u == unit_begin)) fetch_batch(u - (chunk_end - DCHUNK));
             val_t vn[UB];
 #pragma unroll
             for (int k = 0; k < UB; k += G) {  // unconditional (clamped to the task's last group): exact vmcnt
-                const grp_t pv = stream_load(ugrp + (long long)min(u + UB + k, last_grp) * (16 / G), NT);
+                const grp_t pv = stream_load<NT>(ugrp + (long long)min(u + UB + k, last_grp) * (16 / G));
 #pragma unroll
                 for (int q = 0; q < G; q++) vn[k + q] = pv[q];
             }
@@ -935,7 +952,7 @@ struct alignas(NV * sizeof(val_t) >= 16 ? 16 : NV * sizeof(val_t)) MVec { val_t 
 // skip_entries: the plan's merged, column-ordered entry lists are multiplied by k_entries_mv afterwards (entry-dominated plans with the
 // workgroup entry mode); this kernel then handles units only and stores zeros for the rows without units.
 // CD: dictionary plans (4-B descriptors): the next chunk's words are prefetched (one register), its patterns gathered at the switch.
-template <int NVT, bool CD>
+template <int NVT, bool CD, bool NTS>
 __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int rowA, int colA, int xcd_chunk, int skip_entries, val_t *__restrict__ partial,
                                                   const val_t *__restrict__ X, val_t *__restrict__ Y)
 {
@@ -972,7 +989,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     const int last = unit_end - 1;
     const int last_grp = unit_begin + (unit_end - 1 - unit_begin) / UNIT_GROUP * UNIT_GROUP;
     auto load_grp = [&](int u, val_t (&out)[UB]) {
-        const grp_t pv = ugrp[(long long)min(u, last_grp) * (16 / UNIT_GROUP)];
+        const grp_t pv = stream_load<NTS>(ugrp + (long long)min(u, last_grp) * (16 / UNIT_GROUP));
 #pragma unroll
         for (int k = 0; k < UB; k++) out[k] = pv[k];
     };
@@ -1324,12 +1341,11 @@ static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense
     if (S.ntasks > 0)
     {
         constexpr int strips = GROUPS_PER_BLOCK / (NV < 2 ? 1 : NV / 2);  // per workgroup (k_units_mv: Q lane groups per strip)
-        if (S.cb_bits > 0)
-            hipLaunchKernelGGL((k_units_mv<NV, true>), dim3((unsigned)((S.ntasks + strips - 1) / strips)), dim3(256), 0, st,
-                               S, P.rowA, P.colA, xcd_chunk, entries_pass ? 1 : 0, P.partial, X, Y);
-        else
-            hipLaunchKernelGGL((k_units_mv<NV, false>), dim3((unsigned)((S.ntasks + strips - 1) / strips)), dim3(256), 0, st,
-                               S, P.rowA, P.colA, xcd_chunk, entries_pass ? 1 : 0, P.partial, X, Y);
+#define TSPMV_MV(CD, NTS) hipLaunchKernelGGL((k_units_mv<NV, CD, NTS>), dim3((unsigned)((S.ntasks + strips - 1) / strips)), dim3(256), 0, st, \
+                                             S, P.rowA, P.colA, xcd_chunk, entries_pass ? 1 : 0, P.partial, X, Y)
+        if (S.cb_bits > 0) { if (S.nt_stream) TSPMV_MV(true, true); else TSPMV_MV(true, false); }
+        else { if (S.nt_stream) TSPMV_MV(false, true); else TSPMV_MV(false, false); }
+#undef TSPMV_MV
     }
     if (DN.nrows > 0)
         hipLaunchKernelGGL((k_dense_mfma_mv<NV>), dim3((DN.nrows + 3) / 4), dim3(256), 0, st, DN, P.rowA, P.colA, P.partial, X, Y);
@@ -1384,15 +1400,17 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
                                const val_t *x, val_t *y, hipStream_t st)
 {
     if (S.ntasks > 0) {
-#define TSPMV_L3(X, W, B, XW, CD) hipLaunchKernelGGL((k_units<4, X, W, B, XW, CD>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
-#define TSPMV_L2(X, W, B) do { if (S.cb_bits > 0) TSPMV_L3(X, W, B, false, true); else TSPMV_L3(X, W, B, false, false); } while (0)
-#define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L3(X, 2, 16, true, false); else if (xwin_lds_bytes > 0) TSPMV_L3(X, 0, 16, true, false); \
+#define TSPMV_L4(X, W, B, XW, CD, NTS) hipLaunchKernelGGL((k_units<4, X, W, B, XW, CD, NTS>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_L3(X, W, B, CD) do { if (S.nt_stream) TSPMV_L4(X, W, B, false, CD, true); else TSPMV_L4(X, W, B, false, CD, false); } while (0)
+#define TSPMV_L2(X, W, B) do { if (S.cb_bits > 0) TSPMV_L3(X, W, B, true); else TSPMV_L3(X, W, B, false); } while (0)
+#define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L4(X, 2, 16, true, false, false); else if (xwin_lds_bytes > 0) TSPMV_L4(X, 0, 16, true, false, false); \
         else if (entry_mode == 2 && wg_strips == 32) TSPMV_L2(X, 2, 32); else if (entry_mode == 2) TSPMV_L2(X, 2, 16); \
-        else if (entry_mode == 1) TSPMV_L2(X, 1, 16); else TSPMV_L2(X, 0, 16); } while (0)
+        else if (entry_mode == 1) { if (S.cb_bits > 0) TSPMV_L4(X, 1, 16, false, true, false); else TSPMV_L4(X, 1, 16, false, false, false); } else TSPMV_L2(X, 0, 16); } while (0)
         if (xcd_remap == 2) TSPMV_L1(2); else TSPMV_L1(0);
 #undef TSPMV_L1
 #undef TSPMV_L2
 #undef TSPMV_L3
+#undef TSPMV_L4
     }
     // whole-tile passes (y += ...): CSR tiles kept as tiles, dense tiles on the matrix cores; then the split-row fix-up
     hipError_t e = launch_tiles_direct(P, dense_mfma, /*accumulate=*/true, /*fixup=*/false, x, y, st);

@@ -96,6 +96,7 @@ constexpr int UNIT_ROW_SHIFT = 1;         // unit flag bits 1-3: tile-row inside
 constexpr unsigned UNIT_ROWUNIT = 16u;    // unit flag bit 4: "row unit" = 16 values of ONE tile row (dense-row tiles);
                                           //   lane = column, word 1/3 hold the target row, result needs a 16-lane reduction
 constexpr int UNIT_GROUP = 16 / (int)sizeof(val_t);  // units whose values share one 16-byte lane load (2 in fp64, 4 in fp32)
+constexpr long long NT_STREAM_MIN_BYTES = 400ll << 20;   // launches that move more than this (about 1.6 x the 256 MB Infinity Cache) read their once-read streams nontemporally
 constexpr int DICT_MAX_BITS = 10;         // dictionary plans: at most 1024 column patterns (8 KB: stays in the vector L1)
 constexpr int UNIT_FLAG_SHIFT = 24;       // flags live above the 24-bit column block in words 0 and 2
 
@@ -137,6 +138,7 @@ struct DevStream {
     const int *win_cb;                    // column block of every window slot
     const uint2 *udict;                   // dictionary plans: the column patterns (nibbles of rows 0-7, of rows 8-15); udesc / udesc_cb then hold 4-B words
     int cb_bits;                          // ... column block (cb_bits) | pattern id | flags << 27;  0 = 12-B descriptors
+    int nt_stream;                        // 1: value / entry-record loads are nontemporal (the plan's streams do not fit the Infinity Cache)
     const UDesc *udesc_cb;                // descriptors with column blocks for the multi-vector kernel (== udesc when there is no window)
     // split tile-rows whose pieces all live in the unit kernel are summed in that kernel by the piece that
     // finishes last (fixed slot order): ifix[i] describes row i, ifix_count[i] counts finished pieces

@@ -70,6 +70,7 @@ struct Knobs {
     int y_store;         // -1 by rule, 0 plain y stores, 1 streaming (nontemporal) y stores
     int mv_native;       // -1 = by nvec
     int mv_xcd_chunk;    // -1 = the plan's XCD chunk
+    int nt_stream;       // -1 by size, 0 plain, 1 nontemporal loads of the value / entry-record streams
     int desc_dict;       // 0 = always 12-B unit descriptors; otherwise 4-B descriptors + pattern dictionary where the shard allows
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
     bool dry;            // tilespmv_plan_layout_digest: build the layout on the host only, hash instead of upload
@@ -113,6 +114,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.mv_native = pick(o.mv_native, "TILESPMV_MV_NATIVE", -1);
     k.mv_xcd_chunk = pick(o.mv_xcd_chunk, "TILESPMV_MV_XCD_CHUNK", -1);
     k.desc_dict = pick(o.desc_dict, "TILESPMV_DESC_DICT", 1);
+    k.nt_stream = pick(o.nt_stream, "TILESPMV_NT_STREAM", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
     k.entry_from_caller = pinned(o.entry_mode, "TILESPMV_WAVE_COO");
     k.strip_from_caller = o.strip_cost > 0 || env_int("TILESPMV_STRIP_COST", 0) > 0;
@@ -1074,6 +1076,17 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     model_bytes = NUP * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
                   ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
+    // The once-read streams (values, entry records) are loaded nontemporally when the launch moves clearly more than the Infinity Cache holds: they then do
+    // not displace x in the L2s / the Infinity Cache — config 4 0.182 -> 0.164-0.166 ms, 7-pt 256^3 0.231 -> 0.211, KKT fp32 0.253 -> 0.236-0.243, power-law
+    // 8 M 0.103 -> 0.095 — while a plan that (nearly) fits keeps the default policy, because its streams come back from the Infinity Cache on the next SpMV:
+    // nontemporal loses 2 % at 340 MB (5-pt 2400^2), 15 % at 180-300 MB (power-law 3-5 M rows), 6-8 % on webbase-1M; it wins from 500 MB up (5-pt 2896^2 +4 %,
+    // power-law 8 M +8 %, 5-pt 3400^2 +10 %).  Descriptors, tasks and per-strip entry lists stay on the default policy (nontemporal: config 4 0.164 -> 0.170-0.173).
+    // profiles/r03_nontemporal_streams.txt.  Entry mode 1 = small grids; x-window plans are an opt-in experiment.
+    {
+        const long long launch_b = model_bytes + ((long long)colA + 16LL * ntr) * sv;
+        S.nt_stream = (entry_mode != 1 && !xwin && (K.nt_stream >= 0 ? K.nt_stream != 0 : launch_b > NT_STREAM_MIN_BYTES)) ? 1 : 0;
+    }
+    plan->info[TILESPMV_INFO_NT_STREAM] = S.nt_stream;
     return rc;
 }
 
