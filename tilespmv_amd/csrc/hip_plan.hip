@@ -487,6 +487,10 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
             const bool balanced = ntr > 0 && max_cost * ntr <= 4 * total_cost;
             const long long cap = (entry_dominated && balanced) ? 3200 : 1600;
             target = (int)std::min<long long>(cap, std::max<long long>(400, total_cost / (3 * 256 * 16)));
+        } else if (total_cost / (16LL * 800) >= 4096) {
+            // large regular shards: strips of up to 8 tile-rows once that still leaves >= 4096 workgroups (config 4: 0.1644-0.1665 -> 0.1606-0.1608 ms with the
+            // nontemporal value stream, 5-pt 2896^2 0.0864 -> 0.0854; a 1024^2 grid would lose 17 % — 512 workgroups — and keeps 400)
+            target = 800;
         }
     }
     target = std::max(32, target);
