@@ -641,7 +641,7 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
             windowed += info["x_window_slots"] > 0
             bricks += info["brick_order"] == 1
             desc[info["desc_bytes"]] += 1
-            assert info["nt_stream"] == (1 if kw.get("nt_stream") == 1 and kw.get("entry_mode") != 1 and not info["x_window_slots"] else 0)   # (small test matrices: off by rule)
+            assert info["nt_stream"] == (1 if kw.get("nt_stream") == 1 and info["entry_mode"] != 1 and not info["x_window_slots"] else 0)   # (small test matrices: off by rule)
             assert info["desc_bytes"] == 12 or (kw.get("desc_dict") != 0 and info["x_window_slots"] == 0)
             assert not (kw.get("x_window") == 0 and info["brick_order"])
         # multi-vector product on an x-window plan: its kernel reads the column-block descriptors kept beside the slotted ones
