@@ -883,7 +883,8 @@ __global__ __launch_bounds__(256) void k_dense_mfma(DevDense D, int rowA, int co
         const long long xb = (long long)cb * 16 + 4 * kq;
         const val_t *tv = D.val + (long long)min(t, last) * 256 + (16 * kq + rr0) * 4;  // operand order: 4 contiguous values per lane
 #pragma unroll
-        for (int s = 0; s < 4; s++) a[s] = tv[s];
+        for (int s = 0; s < 4; s++) a[s] = tv[s];   // (default cache policy also on plans whose unit kernel reads its streams nontemporally: a lane's 32 bytes are two loads that
+                                                    //  each touch half of every line, and the hint makes the second one fetch the line again — band hbw 40: 0.265 -> 0.301 ms)
         if (xb + 3 <= xlast) {
 #pragma unroll
             for (int s = 0; s < 4; s++) b[s] = x[xb + s];   // contiguous: merged into 16-B loads
