@@ -143,6 +143,7 @@ struct tilespmv_plan {
     int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
     int lds_pad_bytes = 0;              // extra (unused) dynamic LDS per workgroup of the unit kernel: caps the workgroups resident on a CU (knob lds_pad)
     int xwin_lds_bytes = 0;             // x-window plans: dynamic LDS of the unit kernel (largest window of the plan); 0 = no windows
+    int arena_flags = 0;
     char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20, arena_next = (size_t)1 << 20, size_hint = 0;   // bump allocator of upload(); size_hint = the builder's estimate of the plan's bytes
     bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
     unsigned long long digest = 1469598103934665603ull;
@@ -169,7 +170,8 @@ struct tilespmv_plan {
             const size_t blk = std::max<size_t>(need, std::min(want, arena_block));
             arena_next = std::min<size_t>(arena_next * 4, std::max<size_t>(arena_block, 1));
             void *b = nullptr;
-            HIP_TRY(hipMalloc(&b, blk));
+            if (arena_flags) HIP_TRY(hipExtMallocWithFlags(&b, blk, (unsigned)arena_flags));   // experiment knob TILESPMV_ARENA_FLAGS (4 = physically contiguous)
+            else HIP_TRY(hipMalloc(&b, blk));
             allocs.push_back(b);
             arena_at = (char *)b; arena_left = blk;
         }
@@ -1263,6 +1265,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
 
     auto *plan = new tilespmv_plan();
     plan->dry = K.dry;
+    if (const char *af = getenv("TILESPMV_ARENA_FLAGS")) plan->arena_flags = atoi(af);
     if (const char *ab = getenv("TILESPMV_ARENA_MB")) plan->arena_block = (size_t)std::max(0, atoi(ab)) << 20;   // (experiment knob; 0 = one hipMalloc per stream)
     if (!K.dry && hipGetDevice(&plan->device) != hipSuccess) { fprintf(stderr, "tilespmv: hipGetDevice failed\n"); delete plan; return -1; }
 
