@@ -143,7 +143,7 @@ struct tilespmv_plan {
     int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
     int lds_pad_bytes = 0;              // extra (unused) dynamic LDS per workgroup of the unit kernel: caps the workgroups resident on a CU (knob lds_pad)
     int xwin_lds_bytes = 0;             // x-window plans: dynamic LDS of the unit kernel (largest window of the plan); 0 = no windows
-    int arena_flags = 0;
+    int arena_flags = 0; size_t arena_skew = 0;
     char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20, arena_next = (size_t)1 << 20, size_hint = 0;   // bump allocator of upload(); size_hint = the builder's estimate of the plan's bytes
     bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
     unsigned long long digest = 1469598103934665603ull;
@@ -164,7 +164,7 @@ struct tilespmv_plan {
         // Streams are carved out of a few large device blocks (bump allocation, 256-byte aligned + 256 bytes of slack so that
         // masked tail lanes never fault) instead of one hipMalloc each: a plan is ~20 streams, and large blocks get large
         // page-table fragments whatever state the allocator is in (fewer hipMalloc calls, too).
-        const size_t need = (std::max<size_t>(n, 1) * sizeof(T) + 256 + 255) / 256 * 256;
+        const size_t need = (std::max<size_t>(n, 1) * sizeof(T) + 256 + 255) / 256 * 256 + arena_skew;   // (arena_skew: experiment knob, bytes left unused behind every stream)
         if (need > arena_left) {   // blocks of arena_block bytes (256 MB) for plans of that size and more; a smaller plan gets one block of about its own size (size_hint)
             const size_t want = size_hint >= arena_block ? arena_block : std::max<size_t>(arena_next, size_hint + size_hint / 4 + ((size_t)1 << 20));
             const size_t blk = std::max<size_t>(need, std::min(want, arena_block));
@@ -1266,6 +1266,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     auto *plan = new tilespmv_plan();
     plan->dry = K.dry;
     if (const char *af = getenv("TILESPMV_ARENA_FLAGS")) plan->arena_flags = atoi(af);
+    if (const char *as = getenv("TILESPMV_ARENA_SKEW")) plan->arena_skew = (size_t)std::max(0ll, atoll(as)) / 256 * 256;
     if (const char *ab = getenv("TILESPMV_ARENA_MB")) plan->arena_block = (size_t)std::max(0, atoi(ab)) << 20;   // (experiment knob; 0 = one hipMalloc per stream)
     if (!K.dry && hipGetDevice(&plan->device) != hipSuccess) { fprintf(stderr, "tilespmv: hipGetDevice failed\n"); delete plan; return -1; }
 
