@@ -953,6 +953,14 @@ struct alignas(NV * sizeof(val_t) >= 16 ? 16 : NV * sizeof(val_t)) MVec { val_t 
 // skip_entries: the plan's merged, column-ordered entry lists are multiplied by k_entries_mv afterwards (entry-dominated plans with the
 // workgroup entry mode); this kernel then handles units only and stores zeros for the rows without units.
 // CD: dictionary plans (4-B descriptors): the next chunk's words are prefetched (one register), its patterns gathered at the switch.
+#ifndef MV_NT_Y
+#define MV_NT_Y 1   // streaming stores of Y (as y in k_units)
+#endif
+#if MV_NT_Y
+#define MV_STORE16(w, p) __builtin_nontemporal_store(w, p)
+#else
+#define MV_STORE16(w, p) (*(p) = (w))
+#endif
 template <int NVT, bool CD, bool NTS>
 __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int rowA, int colA, int xcd_chunk, int skip_entries, val_t *__restrict__ partial,
                                                   const val_t *__restrict__ X, val_t *__restrict__ Y)
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
         if (yi < rowA) {
             if constexpr (sizeof(vec_t) == 16) {
                 v4u_t w; __builtin_memcpy(&w, &o, 16);
-                __builtin_nontemporal_store(w, reinterpret_cast<v4u_t *>(&Yv[yi * Q]));
+                MV_STORE16(w, reinterpret_cast<v4u_t *>(&Yv[yi * Q]));
             } else if constexpr (sizeof(vec_t) == 8) {
                 v2u_t w; __builtin_memcpy(&w, &o, 8);
                 __builtin_nontemporal_store(w, reinterpret_cast<v2u_t *>(&Yv[yi * Q]));
@@ -1100,7 +1108,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
             for (int j = 0; j < NV; j++) o.v[j] = acc[j];
             if constexpr (sizeof(vec_t) == 16) {  // streaming stores, as in k_units
                 v4u_t w; __builtin_memcpy(&w, &o, 16);
-                __builtin_nontemporal_store(w, reinterpret_cast<v4u_t *>(&Yv[yi * Q]));
+                MV_STORE16(w, reinterpret_cast<v4u_t *>(&Yv[yi * Q]));
             } else if constexpr (sizeof(vec_t) == 8) {
                 v2u_t w; __builtin_memcpy(&w, &o, 8);
                 __builtin_nontemporal_store(w, reinterpret_cast<v2u_t *>(&Yv[yi * Q]));
