@@ -96,6 +96,22 @@ def test_dictionary_descriptors_where_patterns_are_few():
     api.Tile_destroy(tm)
 
 
+def test_rules_that_depend_on_the_size_of_the_launch():
+    """Nontemporal value / entry streams above 400 MB per launch, strips of 8 tile-rows (cost target 800) once that leaves >= 4096 workgroups;
+    neither on a grid that fits the Infinity Cache."""
+    for n, want_nt, want_cost in ((3456, 1, 800), (1024, 0, 400)):
+        m, cols, rp, ci = G.laplacian5pt(n)
+        rows = cases.truncated_rows(m); nnz = int(rp[rows])
+        tm = api.Tile_create(rows, cols, nnz, rp, ci, G.compat_values(len(ci)))
+        _, info = api.plan_layout_digest(tm, rows, cols, nnz)
+        assert (info["nt_stream"], info["strip_cost"], info["desc_bytes"]) == (want_nt, want_cost, 4), (n, info)
+        assert (info["stream_bytes"] > (400 << 20)) == bool(want_nt)
+        _, off = api.plan_layout_digest(tm, rows, cols, nnz, nt_stream=0, strip_cost=400)
+        assert (off["nt_stream"], off["strip_cost"]) == (0, 400)
+        api.Tile_destroy(tm)
+        del rp, ci
+
+
 def test_environment_is_only_a_default(monkeypatch):
     tm, rows, n, nnz = _tm("powerlaw20k")
     by_option, info = api.plan_layout_digest(tm, rows, n, nnz, entry_mode=2, strip_cost=800, entry_ordered=1)
