@@ -323,6 +323,9 @@ typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 #ifndef ECOO2_MIN_WAVES
 #define ECOO2_MIN_WAVES 6  // workgroup entry mode: 80 VGPRs
 #endif
+#ifndef TILESPMV_UB
+#define TILESPMV_UB 4   // units per batch of the unit loop (diagnostic builds: 8 with UNITS_MIN_WAVES=6 measured below)
+#endif
 #ifndef UNITS_MIN_WAVES
 #define UNITS_MIN_WAVES 8  // waves per SIMD asked of the register allocator (64 VGPRs)
 #endif
@@ -1409,7 +1412,7 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
                                const val_t *x, val_t *y, hipStream_t st)
 {
     if (S.ntasks > 0) {
-#define TSPMV_L4(X, W, B, XW, CD, NTS) hipLaunchKernelGGL((k_units<4, X, W, B, XW, CD, NTS>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_L4(X, W, B, XW, CD, NTS) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, B, XW, CD, NTS>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
 #define TSPMV_L3(X, W, B, CD) do { if (S.nt_stream) TSPMV_L4(X, W, B, false, CD, true); else TSPMV_L4(X, W, B, false, CD, false); } while (0)
 #define TSPMV_L2(X, W, B) do { if (S.cb_bits > 0) TSPMV_L3(X, W, B, true); else TSPMV_L3(X, W, B, false); } while (0)
 #define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L4(X, 2, 16, true, false, false); else if (xwin_lds_bytes > 0) TSPMV_L4(X, 0, 16, true, false, false); \
