@@ -471,7 +471,7 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     // on large matrices.  Entry-heavy shards want MANY tile-rows per workgroup (power-law 8 M rows: 0.149 ms at 400,
     // 0.120 ms at 1600) but still about 3 workgroups per CU on small matrices (webbase-like: 12.9-13.1 us at ~760
     // workgroups, 13.6-14.3 at 1000, 15.4 at 570; scircuit-like flat 7.2-7.8 us from 250 to 670 workgroups).
-    const bool entry_heavy = NC >= 6LL * ntr;
+    const bool entry_heavy = NC >= 5LL * ntr;   // (5 since round 3: an unaligned 7-point grid — 6 one-entry COO tiles per tile-row — runs 5 % faster with the workgroup entry mode; 4 per tile-row, the unaligned 5-point grid, does not)
     long long total_cost = 0;
     for (int i = 0; i < ntr; i++) total_cost += rc_[i].cost;
     // tilespmv_plan_spmm: k_units_mv walks a strip's entries with its 16 lanes, tile-row by tile-row; where entries are most
@@ -489,9 +489,10 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
             const bool balanced = ntr > 0 && max_cost * ntr <= 4 * total_cost;
             const long long cap = (entry_dominated && balanced) ? 3200 : 1600;
             target = (int)std::min<long long>(cap, std::max<long long>(400, total_cost / (3 * 256 * 16)));
-        } else if (total_cost / (16LL * 800) >= 4096) {
+        } else if (total_cost / (16LL * 800) >= 4096 && NC <= 2LL * ntr) {
             // large regular shards: strips of up to 8 tile-rows once that still leaves >= 4096 workgroups (config 4: 0.1644-0.1665 -> 0.1606-0.1608 ms with the
-            // nontemporal value stream, 5-pt 2896^2 0.0864 -> 0.0854; a 1024^2 grid would lose 17 % — 512 workgroups — and keeps 400)
+            // nontemporal value stream, 5-pt 2896^2 0.0864 -> 0.0854; a 1024^2 grid would lose 17 % — 512 workgroups — and keeps 400) — and only while the
+            // 8 tile-rows bring at most the 16 entries that travel with the unit prologue (4 entries per tile-row, the 4095^2 grid: 0.1875 ms at 800, 0.1770 at 400)
             target = 800;
         }
     }
