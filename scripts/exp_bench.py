@@ -11,7 +11,7 @@ def main():
     sys.argv = sys.argv[:1]
     import bench
     m, n, rp, ci, src = bench.build_matrix(wl)
-    dtype = np.float32 if (wl == "nlpkkt160" and not os.environ.get("EXP_F64")) else np.float64
+    dtype = np.float32 if ((wl == "nlpkkt160" and not os.environ.get("EXP_F64")) or os.environ.get("EXP_F32")) else np.float64
     rows = (m // 16) * 16; nnz = int(rp[rows])
     vals, x = G.compat_values(len(ci), dtype), G.compat_x(n, dtype)
     tm = api.Tile_create(rows, n, nnz, rp, ci, vals, dtype=dtype)

@@ -29,6 +29,13 @@
 
 namespace tilespmv {
 
+// LDS scatter accumulators are fp64 in BOTH builds: on gfx950 a wavefront's ds_add_f32 takes about 170 cycles whatever the address
+// pattern, its ds_add_f64 7-18 (scripts/micro/lds_atomic_rate.hip: 203 against 1860-4670 G adds/s) — the fp32 build's entry phase
+// spent 0.108 ms of a 0.166 ms SpMV (power-law 8 M rows) in them.  Products are formed in the value type and widened for the add;
+// sums of integer-valued data stay exact, real-valued sums get closer to the exact result than a float chain would.
+typedef double lacc_t;
+
+
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -106,7 +113,7 @@ template <bool DENSE_MFMA, bool ACCUM>
 __global__ __launch_bounds__(256) void k_tiles_direct(DevPlan P, const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     __shared__ val_t s_x[GROUPS_PER_BLOCK][16];    // x segment of the strip's current tile
-    __shared__ val_t s_acc[GROUPS_PER_BLOCK][16];  // scatter accumulator (COO / HYB remainder)
+    __shared__ lacc_t s_acc[GROUPS_PER_BLOCK][16]; // scatter accumulator (COO / HYB remainder)
     __shared__ val_t s_t[4][16];                   // MFMA result hand-off, one per wave
 
     const int tid = threadIdx.x, lane = tid & 63, r = tid & 15, g = tid >> 4, wave = tid >> 6;
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256) void k_tiles_direct(DevPlan P, const val_t *__
             case TILESPMV_FMT_COO: {
                 if (r < p1) {
                     const unsigned b = ix[r];
-                    atomicAdd(&s_acc[g][b >> 4], v[r] * xs[b & 15u]);
+                    atomicAdd(&s_acc[g][b >> 4], (lacc_t)(v[r] * xs[b & 15u]));
                 }
                 dirty = true; nv = p1; ni = p1;
                 break;
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void k_tiles_direct(DevPlan P, const val_t *__
                 for (int s = 0; s < p1; s++) acc += v[16 * s + r] * xs[nibble_of(ix, 16 * s + r)];
                 if (r < p2) {
                     const unsigned b = ix[8 * p1 + r];
-                    atomicAdd(&s_acc[g][b >> 4], v[16 * p1 + r] * xs[b & 15u]);
+                    atomicAdd(&s_acc[g][b >> 4], (lacc_t)(v[16 * p1 + r] * xs[b & 15u]));
                 }
                 dirty = true; nv = 16 * p1 + p2; ni = 8 * p1 + p2;
                 break;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256) void k_tiles_direct(DevPlan P, const val_t *__
             if ((meta & DESC_EOR) && tk.partial < 0) {  // tile-row finished: write its 16 results
                 wave_lds_fence();
                 val_t out = acc;
-                if (dirty) { out += s_acc[g][r]; s_acc[g][r] = 0; dirty = false; }
+                if (dirty) { out = (val_t)((lacc_t)out + s_acc[g][r]); s_acc[g][r] = 0; dirty = false; }
                 const long long yi = (long long)row * 16 + r;
                 if (yi < P.rowA) { if (ACCUM) y[yi] += out; else y[yi] = out; }
                 acc = 0; row++;
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256) void k_tiles_direct(DevPlan P, const val_t *__
     }
     if (have && tk.partial >= 0) {  // piece of a split tile-row: combined later in a fixed order
         val_t out = acc;
-        if (dirty) out += s_acc[g][r];
+        if (dirty) out = (val_t)((lacc_t)out + s_acc[g][r]);
         P.partial[(long long)tk.partial * 16 + r] = out;
     }
 }
@@ -349,7 +356,7 @@ __device__ __forceinline__ val_t erec_val(const ERec &r)
 // reproducible).  CT x 64 entries per trip: every record load of a trip (one 12-/8-byte lane load each; the chunk's column
 // base comes through the scalar cache), then its gathers, then the adds.
 template <int CT>
-__device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t *__restrict__ x, val_t *swave, int lane, int gb, int ge, int chunk0, int cfirst)
+__device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t *__restrict__ x, lacc_t *swave, int lane, int gb, int ge, int chunk0, int cfirst)
 {
     const int db = S.dest_bits;
     const unsigned dmask = (1u << db) - 1u;
@@ -365,7 +372,7 @@ __device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t
         for (int q = 0; q < CT; q++) xx[q] = x[(size_t)(cb[q] + (rr[q].w >> db))];
 #pragma unroll
         for (int q = 0; q < CT; q++)
-            if (e0 + 64 * q + lane < ge) atomicAdd(&swave[rr[q].w & dmask], erec_val(rr[q]) * xx[q]);
+            if (e0 + 64 * q + lane < ge) atomicAdd(&swave[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
     }
 }
 
@@ -380,7 +387,7 @@ __device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t
 // then does not displace x in the L2s; DevStream::nt_stream).
 template <int CT, int NT, bool NTL>
 __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, const unsigned *__restrict__ base, int chunk0, int db, bool ordered,
-                                               const val_t *__restrict__ x, val_t *sy, int tid, int gb, int ge)
+                                               const val_t *__restrict__ x, lacc_t *sy, int tid, int gb, int ge)
 {
     const unsigned dmask = (1u << db) - 1u;
     const int wave = tid >> 6;
@@ -423,7 +430,7 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
 #if defined(TILESPMV_ABL) && TILESPMV_ABL == 1
 #pragma unroll
         for (int q = 0; q < CT; q++) abl_acc += erec_val(rr[q]) * xx[q] + (val_t)(rr[q].w & dmask);
-        if (e0 + NT * CT >= ge) atomicAdd(&sy[tid], abl_acc);
+        if (e0 + NT * CT >= ge) atomicAdd(&sy[tid], (lacc_t)abl_acc);
 #else
         if (ordered) {
             // the wavefronts add in turn: the order of the additions into one y element is then fixed by the plan (entry
@@ -433,14 +440,14 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
                 if (wave == w) {
 #pragma unroll
                     for (int q = 0; q < CT; q++)
-                        if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], erec_val(rr[q]) * xx[q]);
+                        if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
                 }
                 __syncthreads();
             }
         } else {
 #pragma unroll
             for (int q = 0; q < CT; q++)
-                if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], erec_val(rr[q]) * xx[q]);
+                if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
         }
 #endif
         if (WG_TRIP_PIPE) {
@@ -460,7 +467,7 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
 // ================================================================================================
 __global__ __launch_bounds__(256) void k_fallback_entries(DevPlan P, const val_t *__restrict__ x, val_t *__restrict__ y)
 {
-    __shared__ val_t s_acc[FB_ROWS];
+    __shared__ lacc_t s_acc[FB_ROWS];
     const int tid = threadIdx.x;
     const int4 b = P.f_blk[blockIdx.x];
     const int nrows = b.y < 0 ? 1 : b.y;
@@ -469,11 +476,11 @@ __global__ __launch_bounds__(256) void k_fallback_entries(DevPlan P, const val_t
     wg_entry_trips<6, 256, false>(P.f_rec, P.f_base, b.z >> 6, FB_DEST_BITS, P.f_ordered != 0, x, s_acc, tid, b.z, b.w);   // a block's list starts on a chunk boundary
     __syncthreads();
     if (b.y < 0) {
-        if (tid == 0) atomicAdd(&y[(long long)P.f_row0 + b.x], s_acc[0]);
+        if (tid == 0) atomicAdd(&y[(long long)P.f_row0 + b.x], (val_t)s_acc[0]);
     } else {
         // every row of the block is updated, also those whose sum is zero: the kernel's time must not depend on the values (round 2 skipped
         // exact zeros, which made an all-zero x look 20-30 % faster to the autotuner)
-        for (int i = tid; i < nrows; i += 256) y[(long long)P.f_row0 + b.x + i] += s_acc[i];
+        for (int i = tid; i < nrows; i += 256) y[(long long)P.f_row0 + b.x + i] = (val_t)((lacc_t)y[(long long)P.f_row0 + b.x + i] + s_acc[i]);
     }
 }
 
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
 #define TILESPMV_NT_COO0 0
 #endif
     constexpr bool NT_DESC = NTS && TILESPMV_NT_DESC, NT_COO0 = NTS && TILESPMV_NT_COO0;
-    __shared__ val_t s_y[GROUPS_PER_BLOCK][SROWS][16];
+    __shared__ lacc_t s_y[GROUPS_PER_BLOCK][SROWS][16];   // (lacc_t: fp64 in both builds, see its typedef)
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     val_t *s_xw = reinterpret_cast<val_t *>(s_dyn);   // [window slot][16]
 #ifdef TILESPMV_ABL_LDS_PAD   // diagnostic builds only: extra LDS per workgroup, to measure what fewer resident workgroups cost
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         const int lane = tid & 63;
         const int4 wr = S.wg_coo[(long long)bid * (GROUPS_PER_BLOCK / 4) + (g >> 2)];  // this wavefront's merged list
         const int tot = wr.y - wr.x;
-        val_t *swave = &s_y[g & ~3][0][0];  // the wavefront's four slabs of STRIP_MAX_ROWS x 16 values
+        lacc_t *swave = &s_y[g & ~3][0][0];  // the wavefront's four slabs of STRIP_MAX_ROWS x 16 values
         TSPMV_STAMP_WAIT(1);   // task and list range have arrived
         unit_prologue();
         ERec rr[CT]; unsigned cbase[CT]; val_t xx[CT];
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             for (int q = 0; q < CT; q++) xx[q] = x[(size_t)(cbase[q] + (rr[q].w >> db))];
 #pragma unroll
             for (int q = 0; q < CT; q++)
-                if (wr.x + 64 * q + lane < wr.y) atomicAdd(&swave[rr[q].w & dmask], erec_val(rr[q]) * xx[q]);
+                if (wr.x + 64 * q + lane < wr.y) atomicAdd(&swave[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
             if (tot > 64 * CT) wave_entry_trips<CT>(S, x, swave, lane, wr.x, wr.y, wr.z, CT);
             wave_lds_fence();
         }
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             for (int q = 0; q < CT; q++) xx[q] = x[cc[q]];
 #pragma unroll
             for (int q = 0; q < CT; q++)
-                if (e0 + 16 * q + r < coo_end) atomicAdd(&s_y[g][rb[q] >> 4][rb[q] & 15u], cv[q] * xx[q]);
+                if (e0 + 16 * q + r < coo_end) atomicAdd(&s_y[g][rb[q] >> 4][rb[q] & 15u], (lacc_t)(cv[q] * xx[q]));
         }
         wave_lds_fence();
     }
@@ -717,7 +724,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     if (coo0) { rb0 = stream_load<NT_COO0>(S.crow + coo_begin + r); cc0 = stream_load<NT_COO0>(S.ccol + coo_begin + r); cv0 = stream_load<NT_COO0>(S.cval + coo_begin + r); }
     unit_prologue();
     if (side && !coo_heavy) {  // up to coo_heavy_min entries: 16 with the prologue loads, the rest 4 x 16 per trip
-        if (coo0) atomicAdd(&s_y[g][rb0 >> 4][rb0 & 15u], cv0 * x[cc0]);
+        if (coo0) atomicAdd(&s_y[g][rb0 >> 4][rb0 & 15u], (lacc_t)(cv0 * x[cc0]));
         for (int e0 = coo_begin + 16; e0 < coo_end; e0 += 64) {
             unsigned rb[4]; int cc[4]; val_t cv[4], xx[4];
 #pragma unroll
@@ -729,7 +736,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             for (int q = 0; q < 4; q++) xx[q] = x[cc[q]];
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (e0 + 16 * q + r < coo_end) atomicAdd(&s_y[g][rb[q] >> 4][rb[q] & 15u], cv[q] * xx[q]);
+                if (e0 + 16 * q + r < coo_end) atomicAdd(&s_y[g][rb[q] >> 4][rb[q] & 15u], (lacc_t)(cv[q] * xx[q]));
         }
         wave_lds_fence();
     }
@@ -747,7 +754,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         acc += prod;
         if (flags & UNIT_EOR) {
             const int kr = (int)((flags >> UNIT_ROW_SHIFT) & 7u);
-            val_t out = acc;
+            lacc_t out = acc;
             if (side) out += s_y[g][kr][r];
             s_y[g][kr][r] = out;
             acc = 0;
@@ -791,7 +798,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     TSPMV_STAMP_WAIT(4);       // unit loop done
     if (part >= 0) {
         val_t out = acc;
-        if (side) out += s_y[g][0][r];
+        if (side) out = (val_t)((lacc_t)acc + s_y[g][0][r]);
         if (S.ifix_count == nullptr || nounit == 0xFFFFFFFFu) {
             partial[(long long)part * 16 + r] = out;  // k_fixup_split adds the slots up after all passes
         } else {
@@ -829,15 +836,19 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         }
         wave_lds_fence();
         constexpr int VEC = 16 / (int)sizeof(val_t);  // values per 16-B lane store
-        const val_t *res = &s_y[g][0][0];
+        const lacc_t *res = &s_y[g][0][0];
         const long long ybase = (long long)row0 * 16;
         for (int i = r * VEC; i < 16 * nrows; i += 16 * VEC) {
+            val_t o[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; q++) o[q] = (val_t)res[i + q];   // (fp64: the 16 bytes as they are; fp32: four results narrowed)
             if (ybase + i + VEC <= rowA) {
-                if (NT_Y && S.y_streaming) __builtin_nontemporal_store(*reinterpret_cast<const v4u_t *>(res + i), reinterpret_cast<v4u_t *>(y + ybase + i));
-                else *reinterpret_cast<uint4 *>(y + ybase + i) = *reinterpret_cast<const uint4 *>(res + i);
+                v4u_t w; __builtin_memcpy(&w, o, 16);
+                if (NT_Y && S.y_streaming) __builtin_nontemporal_store(w, reinterpret_cast<v4u_t *>(y + ybase + i));
+                else *reinterpret_cast<v4u_t *>(y + ybase + i) = w;
             } else {
 #pragma unroll
-                for (int q = 0; q < VEC; q++) if (ybase + i + q < rowA) y[ybase + i + q] = res[i + q];
+                for (int q = 0; q < VEC; q++) if (ybase + i + q < rowA) y[ybase + i + q] = o[q];
             }
         }
     }
@@ -977,7 +988,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     // prefetch pushed the kernel 12 bytes into scratch at 80 VGPRs, and loading the chunk at the switch is 3.4-4.3 % faster
     // (profiles/r03_spmm.txt)
     constexpr bool MV_PREFETCH_DESC = !(sizeof(val_t) == 8 && NVT >= 4);
-    __shared__ val_t s_c[GROUPS_PER_BLOCK][16][NV];
+    __shared__ lacc_t s_c[GROUPS_PER_BLOCK][16][NV];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
     unsigned bid = blockIdx.x;
@@ -1051,7 +1062,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
         if (ncoo == 0) return;
         if ((rb0 >> 4) == (unsigned)kr) {
 #pragma unroll
-            for (int j = 0; j < NV; j++) atomicAdd(&s_c[g][rb0 & 15u][j], p0.v[j]);
+            for (int j = 0; j < NV; j++) atomicAdd(&s_c[g][rb0 & 15u][j], (lacc_t)p0.v[j]);
         }
         for (int e0 = in_order ? scan_from : coo_begin + 16; e0 < coo_end; e0 += 16) {
             unsigned rb = 0xFFFFFFFFu;
@@ -1061,7 +1072,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
                     const val_t cv = S.cval[e0 + r];
                     const vec_t xx = Xv[(long long)S.ccol[e0 + r] * Q];
 #pragma unroll
-                    for (int j = 0; j < NV; j++) atomicAdd(&s_c[g][rb & 15u][j], cv * xx.v[j]);
+                    for (int j = 0; j < NV; j++) atomicAdd(&s_c[g][rb & 15u][j], (lacc_t)(cv * xx.v[j]));
                 }
             }
             if (in_order) {
@@ -1072,7 +1083,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
         }
         wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < NV; j++) { acc[j] += s_c[g][r][j]; s_c[g][r][j] = 0; }
+        for (int j = 0; j < NV; j++) { acc[j] = (val_t)((lacc_t)acc[j] + s_c[g][r][j]); s_c[g][r][j] = 0; }
         wave_lds_fence();
     };
     // Stores count in the same in-order vmcnt queue as loads: a store issued at the end of a batch makes the next batch's wait
@@ -1207,7 +1218,7 @@ __global__ __launch_bounds__(256) void k_entries_mv(DevStream S, int rowA, const
 {
     constexpr int NP = NVT / 2, CT = 4;
     typedef MVec<2> vec_t;
-    __shared__ val_t s_acc[GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16][2];
+    __shared__ lacc_t s_acc[GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16][2];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4, wave = tid >> 6;
     const unsigned bid = blockIdx.x;
     const int4 wr = S.wg_coo[bid];
@@ -1243,8 +1254,8 @@ __global__ __launch_bounds__(256) void k_entries_mv(DevStream S, int rowA, const
                 for (int q = 0; q < CT; q++)
                     if (e0 + 256 * q + tid < ge) {
                         const val_t v = erec_val(rr[q]);
-                        atomicAdd(&s_acc[rr[q].w & dmask][0], v * xx[q].v[0]);
-                        atomicAdd(&s_acc[rr[q].w & dmask][1], v * xx[q].v[1]);
+                        atomicAdd(&s_acc[rr[q].w & dmask][0], (lacc_t)(v * xx[q].v[0]));
+                        atomicAdd(&s_acc[rr[q].w & dmask][1], (lacc_t)(v * xx[q].v[1]));
                     }
             };
             if (ordered) {   // wavefronts add in turn: plan-fixed order of the additions, as in k_units<.., 2>
@@ -1256,16 +1267,16 @@ __global__ __launch_bounds__(256) void k_entries_mv(DevStream S, int rowA, const
             if (part >= 0) {   // piece of a split tile-row: k_fixup_split_mv has written the row; the piece's entry sums are added atomically
                 const long long yi = (long long)row0 * 16 + r;
                 if (yi < rowA) {
-                    atomicAdd(&Y[(yi * NP + p) * 2 + 0], s_acc[g * (STRIP_MAX_ROWS * 16) + r][0]);
-                    atomicAdd(&Y[(yi * NP + p) * 2 + 1], s_acc[g * (STRIP_MAX_ROWS * 16) + r][1]);
+                    atomicAdd(&Y[(yi * NP + p) * 2 + 0], (val_t)s_acc[g * (STRIP_MAX_ROWS * 16) + r][0]);
+                    atomicAdd(&Y[(yi * NP + p) * 2 + 1], (val_t)s_acc[g * (STRIP_MAX_ROWS * 16) + r][1]);
                 }
             } else {
                 for (int k = 0; k < nrows; k++) {
                     const long long yi = ((long long)row0 + k) * 16 + r;
                     if (yi < rowA) {
                         vec_t o = Y2[yi * NP + p];
-                        o.v[0] += s_acc[g * (STRIP_MAX_ROWS * 16) + k * 16 + r][0];
-                        o.v[1] += s_acc[g * (STRIP_MAX_ROWS * 16) + k * 16 + r][1];
+                        o.v[0] = (val_t)((lacc_t)o.v[0] + s_acc[g * (STRIP_MAX_ROWS * 16) + k * 16 + r][0]);
+                        o.v[1] = (val_t)((lacc_t)o.v[1] + s_acc[g * (STRIP_MAX_ROWS * 16) + k * 16 + r][1]);
                         Y2[yi * NP + p] = o;
                     }
                 }
