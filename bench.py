@@ -51,6 +51,8 @@ def build_matrix(name, cache_dir=None):
         return G.laplacian7pt(int(name[5:])) + ("synthetic 7-pt Laplacian on a cube",)
     if name.startswith("powerlaw"):
         return G.powerlaw(int(name[8:]), seed=2) + ("synthetic power-law",)
+    if name.startswith("circuit") and name[7:].isdigit():
+        return G.circuit_like(int(name[7:]), seed=1) + ("synthetic circuit-like",)
     if name.startswith("laplacian"):
         return G.laplacian5pt(int(name[len("laplacian"):])) + ("synthetic 5-pt Laplacian",)
     if name.startswith("band"):  # e.g. band40_2000000: full band, half-bandwidth 40 (dense-tile dominated)
