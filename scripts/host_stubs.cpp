@@ -8,7 +8,7 @@ namespace tilespmv {
 hipError_t launch_tiles_direct(const DevPlan &, bool, bool, bool, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_tiles_stream(const DevPlan &, const DevStream &, const DevDense &, bool, int, int, int, int, int, int, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_fallback(const DevPlan &, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_tiles_stream_mv(const DevPlan &, const DevStream &, const DevDense &, int, int, bool, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_tiles_stream_mv(const DevPlan &, const DevStream &, const DevDense &, int, int, bool, int, const val_t *, val_t *, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_rows_to_columns(const val_t *, int, long long, long long, val_t *, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_columns_to_rows(const val_t *, int, long long, long long, long long, val_t *, hipStream_t) { return hipErrorNotSupported; }
 }

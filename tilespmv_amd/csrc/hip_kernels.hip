@@ -976,7 +976,7 @@ struct alignas(NV * sizeof(val_t) >= 16 ? 16 : NV * sizeof(val_t)) MVec { val_t 
 #define MV_STORE16(w, p) (*(p) = (w))
 #endif
 template <int NVT, bool CD, bool NTS>
-__global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int rowA, int colA, int xcd_chunk, int skip_entries, val_t *__restrict__ partial,
+__global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int rowA, int colA, int xcd_chunk, int skip_entries, int slab_rows, val_t *__restrict__ partial,
                                                   const val_t *__restrict__ X, val_t *__restrict__ Y)
 {
     constexpr int NV = NVT < 2 ? NVT : 2;   // vectors per lane
@@ -1002,9 +1002,14 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     const int4 t0 = reinterpret_cast<const int4 *>(S.task)[task_id * 2];
     const int4 t1 = reinterpret_cast<const int4 *>(S.task)[task_id * 2 + 1];
     const int unit_begin = t0.x, unit_end = t0.y, coo_begin = t0.z, coo_end = t0.w;
-    const int row0 = t1.x, part = t1.y;
+    const int row0 = t1.x, part = t1.y, nrows = t1.w;
     const unsigned nounit = (unsigned)t1.z;
     const int ncoo = skip_entries ? 0 : coo_end - coo_begin;
+    // Entry slab (plans with more than a handful of entries per tile-row, slab_rows > 0; dynamic LDS [lane group][slab_rows][16][NV]): a strip whose list does not fit the 16 entries that
+    // travel with the prologue scatters ALL its entries up front, 4 x 16 per trip with every load of a trip in flight, and a retiring tile-row just reads its 16 sums — instead of walking the
+    // list once per tile-row through three dependent loads (KKT stand-in fp32, nvec 8: 1.07 -> see profiles/r03_spmm.txt).
+    const bool epre = slab_rows > 0 && ncoo > 16;
+    lacc_t (*s_e)[NV] = reinterpret_cast<lacc_t (*)[NV]>(s_dyn) + (size_t)g * slab_rows * 16;
     typedef val_t grp_t __attribute__((ext_vector_type(UNIT_GROUP)));
     const grp_t *__restrict__ ugrp = reinterpret_cast<const grp_t *>(S.uval) + r;  // group layout (hip_plan.hip): one 16-byte load = UNIT_GROUP units
     const vec_t *__restrict__ Xv = reinterpret_cast<const vec_t *>(X) + q;   // row i, slice q: Xv[i * Q]
@@ -1024,7 +1029,31 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     vec_t p0;
 #pragma unroll
     for (int j = 0; j < NV; j++) p0.v[j] = 0;
-    if (r < ncoo) {
+    if (epre) {
+        for (int k = 0; k < nrows; k++) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) s_e[k * 16 + r][j] = 0;
+        }
+        wave_lds_fence();
+        constexpr int ECT = 4;
+        for (int e0 = coo_begin; e0 < coo_end; e0 += 16 * ECT) {
+            unsigned rb[ECT]; int cc[ECT]; val_t cv[ECT]; vec_t xx[ECT];
+#pragma unroll
+            for (int k = 0; k < ECT; k++) {
+                const int e = min(e0 + 16 * k + r, coo_end - 1);
+                rb[k] = S.crow[e]; cc[k] = S.ccol[e]; cv[k] = S.cval[e];
+            }
+#pragma unroll
+            for (int k = 0; k < ECT; k++) xx[k] = Xv[(long long)cc[k] * Q];
+#pragma unroll
+            for (int k = 0; k < ECT; k++)
+                if (e0 + 16 * k + r < coo_end) {
+#pragma unroll
+                    for (int j = 0; j < NV; j++) atomicAdd(&s_e[(rb[k] >> 4) * 16 + (rb[k] & 15u)][j], (lacc_t)(cv[k] * xx[k].v[j]));
+                }
+        }
+        wave_lds_fence();
+    } else if (r < ncoo) {
         rb0 = S.crow[coo_begin + r];
         const int cc = S.ccol[coo_begin + r];
         const val_t cv = S.cval[coo_begin + r];
@@ -1045,7 +1074,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
         }
         load_grp(unit_begin, v);
     }
-    if (ncoo > 0) {
+    if (ncoo > 0 && !epre) {
 #pragma unroll
         for (int j = 0; j < NV; j++) s_c[g][r][j] = 0;
         wave_lds_fence();
@@ -1060,6 +1089,11 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     int scan_from = coo_begin + 16;
     auto coo_add = [&](int kr, bool in_order) {
         if (ncoo == 0) return;
+        if (epre) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) acc[j] = (val_t)((lacc_t)acc[j] + s_e[kr * 16 + r][j]);
+            return;
+        }
         if ((rb0 >> 4) == (unsigned)kr) {
 #pragma unroll
             for (int j = 0; j < NV; j++) atomicAdd(&s_c[g][rb0 & 15u][j], (lacc_t)p0.v[j]);
@@ -1359,13 +1393,15 @@ __global__ __launch_bounds__(256) void k_dense_mfma_mv(DevDense D, int rowA, int
 }
 
 template <int NV>
-static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int xcd_chunk, bool entries_pass, const val_t *X, val_t *Y, hipStream_t st)
+static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int xcd_chunk, bool entries_pass, int slab_rows, const val_t *X, val_t *Y, hipStream_t st)
 {
     if (S.ntasks > 0)
     {
         constexpr int strips = GROUPS_PER_BLOCK / (NV < 2 ? 1 : NV / 2);  // per workgroup (k_units_mv: Q lane groups per strip)
-#define TSPMV_MV(CD, NTS) hipLaunchKernelGGL((k_units_mv<NV, CD, NTS>), dim3((unsigned)((S.ntasks + strips - 1) / strips)), dim3(256), 0, st, \
-                                             S, P.rowA, P.colA, xcd_chunk, entries_pass ? 1 : 0, P.partial, X, Y)
+        const int slab = entries_pass ? 0 : slab_rows;   // (the entry pass multiplies the lists itself)
+        const size_t slab_bytes = (size_t)GROUPS_PER_BLOCK * slab * 16 * (NV < 2 ? NV : 2) * sizeof(lacc_t);
+#define TSPMV_MV(CD, NTS) hipLaunchKernelGGL((k_units_mv<NV, CD, NTS>), dim3((unsigned)((S.ntasks + strips - 1) / strips)), dim3(256), slab_bytes, st, \
+                                             S, P.rowA, P.colA, xcd_chunk, entries_pass ? 1 : 0, slab, P.partial, X, Y)
         if (S.cb_bits > 0) { if (S.nt_stream) TSPMV_MV(true, true); else TSPMV_MV(true, false); }
         else { if (S.nt_stream) TSPMV_MV(false, true); else TSPMV_MV(false, false); }
 #undef TSPMV_MV
@@ -1381,13 +1417,13 @@ static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense
 
 // nvec in {2, 4, 8}.  The plan must be a unit-stream plan without whole-tile passes and without the CSR
 // fallback (the defaults); the caller checks that (hip_plan.hip).
-hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, bool entries_pass, const val_t *X, val_t *Y,
+hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, bool entries_pass, int slab_rows, const val_t *X, val_t *Y,
                                   hipStream_t st)
 {
     switch (nvec) {
-    case 2: return launch_mv<2>(P, S, DN, xcd_chunk, entries_pass, X, Y, st);
-    case 4: return launch_mv<4>(P, S, DN, xcd_chunk, entries_pass, X, Y, st);
-    case 8: return launch_mv<8>(P, S, DN, xcd_chunk, entries_pass, X, Y, st);
+    case 2: return launch_mv<2>(P, S, DN, xcd_chunk, entries_pass, slab_rows, X, Y, st);
+    case 4: return launch_mv<4>(P, S, DN, xcd_chunk, entries_pass, slab_rows, X, Y, st);
+    case 8: return launch_mv<8>(P, S, DN, xcd_chunk, entries_pass, slab_rows, X, Y, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -23,7 +23,7 @@ hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulat
 hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xwin_lds_bytes, int lds_pad_bytes, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
-hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, bool entries_pass, const val_t *X, val_t *Y,
+hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, bool entries_pass, int slab_rows, const val_t *X, val_t *Y,
                                   hipStream_t st);
 hipError_t launch_rows_to_columns(const val_t *X, int nvec, long long n, long long ld, val_t *XT, hipStream_t st);
 hipError_t launch_columns_to_rows(const val_t *YT, int nvec, long long row0, long long rows, long long ld, val_t *Y, hipStream_t st);
@@ -135,6 +135,7 @@ struct tilespmv_plan {
     int mv_nvec = 0;
     bool mv_by_columns = false;              // ... and plans whose work is mostly COO entries (the multi-vector kernel walks them per 16-lane strip)
     int mv_native = -1, mv_xcd_chunk = -1;   // knobs of tilespmv_plan_spmm (Knobs)
+    int mv_slab_rows = 0;                    // > 0: the multi-vector kernel scatters a strip's entries up front into an LDS slab of this many tile-rows per lane group
     int entry_mode = 0;                 // COO entry lists walked per 16-lane strip (0), per wavefront (1) or per workgroup, column-ordered (2)
     std::vector<void *> allocs;
     long long info[TILESPMV_INFO_COUNT] = {0};
@@ -1078,6 +1079,12 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
     plan->info[TILESPMV_INFO_WG_STRIPS] = wg_strips;
     plan->info[TILESPMV_INFO_X_WINDOW_SLOTS] = xwin ? xwin_slots_max : 0;
     plan->info[TILESPMV_INFO_X_WINDOW_SEGMENTS] = xwin ? xwin_segments : 0;
+    {   // entry slab of the multi-vector kernel: shards with >= 3 entries per tile-row (strips then regularly hold more than the 16 entries that travel with the prologue)
+        int used = 1;
+        for (const STask &k : tasks) used = std::max(used, k.nrows);
+        const int slab_env = env_int("TILESPMV_MV_SLAB", -1);   // (experiment knob: 0 off, 1 on wherever entries exist)
+        plan->mv_slab_rows = (slab_env == 0 || NC == 0) ? 0 : (slab_env > 0 || NC >= 3LL * ntr) ? used : 0;
+    }
     plan->mv_by_columns = entry_dominated && target >= 800;   // (small strips hold few entries each: scircuit-like 18 / 22 / 32 us native against 22 / 41 / 78 us)
     n_tasks = (long long)tasks.size();
     model_bytes = NUP * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
@@ -1628,7 +1635,7 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
         return (int)e;
     }
     const int mv_chunk = plan->mv_xcd_chunk;
-    return (int)launch_tiles_stream_mv(plan->dev, plan->st, plan->dn, nvec, mv_chunk >= 0 ? mv_chunk : (plan->xcd_remap >= 2 ? plan->xcd_chunk : 0), entries_pass, d_X, d_Y, (hipStream_t)stream);
+    return (int)launch_tiles_stream_mv(plan->dev, plan->st, plan->dn, nvec, mv_chunk >= 0 ? mv_chunk : (plan->xcd_remap >= 2 ? plan->xcd_chunk : 0), entries_pass, plan->mv_slab_rows, d_X, d_Y, (hipStream_t)stream);
 }
 
 double tilespmv_plan_time_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y, int nvec, void *stream, int warmup, int reps)
