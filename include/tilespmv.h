@@ -331,7 +331,7 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
                        void *stream);
 double tilespmv_plan_time_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYPE *d_Y,
                                int nvec, void *stream, int warmup, int reps);
-/* Plans without a native multi-vector kernel (and entry-dominated plans below nvec 8) run one right-hand side at a time
+/* Plans without a native multi-vector kernel (CSR fallback, first-generation kernel, whole CSR tiles; or mv_native = 0) run one right-hand side at a time
  * on transposed copies of X and Y that live with the plan.  tilespmv_plan_reserve_spmm allocates them for up to `nvec`
  * right-hand sides (hipMalloc: synchronises) so that tilespmv_plan_spmm itself never allocates — call it before capturing
  * tilespmv_plan_spmm into a hipGraph.  Without it the first such tilespmv_plan_spmm call allocates (and would fail under
