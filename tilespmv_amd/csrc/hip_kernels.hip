@@ -983,7 +983,10 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     constexpr int Q = NVT / NV;             // lane groups per strip
     constexpr int STRIPS = GROUPS_PER_BLOCK / Q;
     typedef MVec<NV> vec_t;
-    constexpr int UB = UNIT_GROUP;          // one 16-byte value load per batch (2 units fp64, 4 units fp32)
+#ifndef MV_UBX
+#define MV_UBX 1   // value groups per batch of the multi-vector unit loop (diagnostic builds: 2 = twice the units in flight per wavefront, needs MV_MIN_WAVES <= 5)
+#endif
+    constexpr int UB = UNIT_GROUP * MV_UBX; // MV_UBX 16-byte value loads per batch (2 units fp64, 4 units fp32 each)
     // the next descriptor chunk is prefetched into registers (4 VGPRs) except in the fp64 nvec 4 / 8 variants: there the
     // prefetch pushed the kernel 12 bytes into scratch at 80 VGPRs, and loading the chunk at the switch is 3.4-4.3 % faster
     // (profiles/r03_spmm.txt)
@@ -1017,9 +1020,12 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     const int last = unit_end - 1;
     const int last_grp = unit_begin + (unit_end - 1 - unit_begin) / UNIT_GROUP * UNIT_GROUP;
     auto load_grp = [&](int u, val_t (&out)[UB]) {
-        const grp_t pv = stream_load<NTS>(ugrp + (long long)min(u, last_grp) * (16 / UNIT_GROUP));
 #pragma unroll
-        for (int k = 0; k < UB; k++) out[k] = pv[k];
+        for (int gk = 0; gk < UB; gk += UNIT_GROUP) {
+            const grp_t pv = stream_load<NTS>(ugrp + (long long)min(u + gk, last_grp) * (16 / UNIT_GROUP));
+#pragma unroll
+            for (int k = 0; k < UNIT_GROUP; k++) out[gk + k] = pv[k];
+        }
     };
     const bool have_units = unit_begin < unit_end;
     const long long xlast = (long long)colA - 1;
