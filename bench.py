@@ -222,6 +222,54 @@ def cpu_baseline(rows, cols, rowptr, colidx, vals, x, dtype):
             "host_cpu": cpu, "host_logical_cores": os.cpu_count()}
 
 
+def device_state_under_load(run_async, sync, samples=6, gap=0.04):
+    """Clocks / power of the card while the SpMV runs (sysfs reads only, no child process): tells a slow box from a slow kernel.
+    `run_async` queues ~0.3 s of back-to-back SpMVs, `sync` waits for them.  None when the files are not readable."""
+    import glob
+    cards = [d for d in sorted(glob.glob("/sys/class/drm/card*/device")) if os.path.exists(os.path.join(d, "pp_dpm_sclk"))]
+    if not cards:
+        return None
+
+    def busy(c):
+        try:
+            return int(open(os.path.join(c, "gpu_busy_percent")).read())
+        except (OSError, ValueError):
+            return -1
+    d = cards[0]
+
+    def starred(name):
+        try:
+            for line in open(os.path.join(d, name)):
+                if line.rstrip().endswith("*"):
+                    return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    def hw(name, scale):
+        for f in glob.glob(os.path.join(d, "hwmon", "*", name)):
+            try:
+                return round(int(open(f).read()) * scale, 1)
+            except (OSError, ValueError):
+                pass
+        return None
+    out = {"sclk_mhz": [], "mclk_mhz": [], "fclk_mhz": [], "power_w": []}
+    run_async()
+    if len(cards) > 1:       # several cards visible in sysfs: ours is the busy one
+        time.sleep(gap)
+        d = max(cards, key=busy)
+    out["card"] = os.path.basename(os.path.dirname(d))
+    for _ in range(samples):
+        time.sleep(gap)
+        out["sclk_mhz"].append(starred("pp_dpm_sclk")); out["mclk_mhz"].append(starred("pp_dpm_mclk")); out["fclk_mhz"].append(starred("pp_dpm_fclk"))
+        out["power_w"].append(hw("power1_input", 1e-6))
+    sync()
+    out["temp_junction_c"] = hw("temp2_input", 1e-3)
+    out["power_cap_w"] = hw("power1_cap", 1e-6)
+    out["note"] = "sampled from sysfs while ~0.3 s of back-to-back SpMVs run after the timed region"
+    return out
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -457,6 +505,14 @@ def main():
         roofline["note"] = ("frac > 1: the kernel finishes sooner than 8 TB/s could move the CSR-model bytes, because the plan's streams are %.0f %% of them; "
                             "see plan_bytes_gbps / frac_by_plan_bytes and, when present, actual_traffic_gbps (counter bytes)" % (100.0 * info["stream_bytes"] / b_alg_launch))
 
+    device_state = None
+    if rank == 0 and world == 1:
+        try:
+            n_load = max(200, int(0.3 / max(kernel_ms * 1e-3, 1e-6)))
+            device_state = device_state_under_load(lambda: sh.spmv(xd, yd, stream.cuda_stream, count=n_load), sync_all)
+        except Exception as e:  # a diagnostic must never break the line
+            device_state = {"error": repr(e)}
+
     # measured device ceilings beside the 8 TB/s spec figure: read-only and copy streams of 1 GiB buffers
     if rank == 0 and world == 1:
         try:
@@ -536,6 +592,7 @@ def main():
         "hbm_gbps_algorithmic": round(b_alg_total / (wall / args.steps) * 1e-9, 1),
         "hbm_roofline_frac": round(b_alg_total / (wall / args.steps) * 1e-9 / (HBM_PEAK_GBPS * world), 4),
         "roofline": roofline,
+        "device_state_under_load": device_state,
         "check": check if check == "skipped" else ("pass: whole row block of every rank, %s" % ("exact" if args.data == "compat" else "|y - y_ref| <= %g * sum|a_ij x_j|" % (1e-12 if dtype == np.float64 else 1e-5))),
         "ranks": (dist.get_world_size() if world > 1 else 1), "devices": [int(r[0]) for r in main_per_rank], "backend": (args.backend if world > 1 else None),
         "per_rank_ms_per_step": {"wall": [round(r[1], 5) for r in main_per_rank], "device": [round(r[2], 5) for r in main_per_rank],

@@ -839,16 +839,26 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         const lacc_t *res = &s_y[g][0][0];
         const long long ybase = (long long)row0 * 16;
         for (int i = r * VEC; i < 16 * nrows; i += 16 * VEC) {
-            val_t o[VEC];
+            if constexpr (sizeof(val_t) == sizeof(lacc_t)) {   // fp64: the 16 bytes go out as they sit in LDS (one ds_read_b128, one store)
+                if (ybase + i + VEC <= rowA) {
+                    if (NT_Y && S.y_streaming) __builtin_nontemporal_store(*reinterpret_cast<const v4u_t *>(res + i), reinterpret_cast<v4u_t *>(y + ybase + i));
+                    else *reinterpret_cast<uint4 *>(y + ybase + i) = *reinterpret_cast<const uint4 *>(res + i);
+                } else {
 #pragma unroll
-            for (int q = 0; q < VEC; q++) o[q] = (val_t)res[i + q];   // (fp64: the 16 bytes as they are; fp32: four results narrowed)
-            if (ybase + i + VEC <= rowA) {
-                v4u_t w; __builtin_memcpy(&w, o, 16);
-                if (NT_Y && S.y_streaming) __builtin_nontemporal_store(w, reinterpret_cast<v4u_t *>(y + ybase + i));
-                else *reinterpret_cast<v4u_t *>(y + ybase + i) = w;
-            } else {
+                    for (int q = 0; q < VEC; q++) if (ybase + i + q < rowA) y[ybase + i + q] = (val_t)res[i + q];
+                }
+            } else {                                           // fp32: four fp64 sums narrowed into one 16-byte store
+                val_t o[VEC];
 #pragma unroll
-                for (int q = 0; q < VEC; q++) if (ybase + i + q < rowA) y[ybase + i + q] = o[q];
+                for (int q = 0; q < VEC; q++) o[q] = (val_t)res[i + q];
+                if (ybase + i + VEC <= rowA) {
+                    v4u_t w; __builtin_memcpy(&w, o, 16);
+                    if (NT_Y && S.y_streaming) __builtin_nontemporal_store(w, reinterpret_cast<v4u_t *>(y + ybase + i));
+                    else *reinterpret_cast<v4u_t *>(y + ybase + i) = w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < VEC; q++) if (ybase + i + q < rowA) y[ybase + i + q] = o[q];
+                }
             }
         }
     }
