@@ -288,8 +288,9 @@ typedef struct {
     int mv_xcd_chunk;   /* XCD window of the multi-vector kernel                                             TILESPMV_MV_XCD_CHUNK */
     int lds_pad;        /* bytes of unused LDS added to every unit-kernel workgroup: fewer resident workgroups per CU  TILESPMV_LDS_PAD */
     int y_store;        /* y stores: 1 streaming (nontemporal), 0 plain; unset: streaming where y is >= 5 % of the launch's bytes  TILESPMV_Y_STORE */
-    int desc_dict;      /* unit descriptors: 1 / unset = 4 B per unit + a dictionary of column patterns where the shard's units use few
-                           distinct patterns (stencil-like shards), 0 = always the 12-B form                                  TILESPMV_DESC_DICT */
+    int desc_dict;      /* unit descriptors: unset = 4 B per unit + a dictionary of column patterns where the shard's units use few distinct
+                           patterns AND the 8 bytes per unit are >= 2 % of the streams (stencil-like shards); 1 = wherever the patterns
+                           are few; 0 = always the 12-B form                                                                   TILESPMV_DESC_DICT */
     int nt_stream;      /* value / entry-record loads: 1 nontemporal, 0 default cache policy; unset: nontemporal where one SpMV moves more
                            than 400 MB (about 1.6 x the Infinity Cache)                                                             TILESPMV_NT_STREAM */
     int reserved[2];    /* must be TILESPMV_KNOB_DEFAULT or 0 */

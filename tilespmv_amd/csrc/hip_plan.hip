@@ -71,7 +71,7 @@ struct Knobs {
     int mv_native;       // -1 = by nvec
     int mv_xcd_chunk;    // -1 = the plan's XCD chunk
     int nt_stream;       // -1 by size, 0 plain, 1 nontemporal loads of the value / entry-record streams
-    int desc_dict;       // 0 = always 12-B unit descriptors; otherwise 4-B descriptors + pattern dictionary where the shard allows
+    int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
     bool dry;            // tilespmv_plan_layout_digest: build the layout on the host only, hash instead of upload
     const char *autotune_log;
@@ -113,7 +113,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.y_store = pick(o.y_store, "TILESPMV_Y_STORE", -1);
     k.mv_native = pick(o.mv_native, "TILESPMV_MV_NATIVE", -1);
     k.mv_xcd_chunk = pick(o.mv_xcd_chunk, "TILESPMV_MV_XCD_CHUNK", -1);
-    k.desc_dict = pick(o.desc_dict, "TILESPMV_DESC_DICT", 1);
+    k.desc_dict = pick(o.desc_dict, "TILESPMV_DESC_DICT", -1);
     k.nt_stream = pick(o.nt_stream, "TILESPMV_NT_STREAM", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
     k.entry_from_caller = pinned(o.entry_mode, "TILESPMV_WAVE_COO");
@@ -915,7 +915,10 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
         S.udict = nullptr; S.cb_bits = 0;
         std::vector<uint2> dict;
         std::vector<unsigned> compact;
-        if (K.desc_dict != 0 && !xwin && NUP > 0) {
+        // ... and only where it pays: 8 bytes per unit must be at least 2 % of the streams (an entry-dominated plan with a handful of units would only buy the dictionary
+        // hop at the start of every strip: webbase-1M stand-in 13.2 -> 13.6 us); desc_dict = 1 asks for it wherever it is possible
+        const bool dict_pays = K.desc_dict > 0 ? true : 8LL * NUP * 50 >= NUP * (12 + 16LL * sv) + NC * (sv + 4LL);
+        if (K.desc_dict != 0 && dict_pays && !xwin && NUP > 0) {
             const int cb_bits = std::max(1, 32 - __builtin_clz((unsigned)std::max(1, T->tilen - 1)));
             const int pid_bits = std::min(DICT_MAX_BITS, 27 - cb_bits);
             if (pid_bits >= 1) {
