@@ -84,6 +84,12 @@ def test_dictionary_descriptors_where_patterns_are_few():
     assert iw["x_window_slots"] == 0 or iw["desc_bytes"] == 12
     assert i12["stream_bytes"] - i4["stream_bytes"] >= 8 * (nnz // 16) * 0.9      # 8 bytes per unit less to read
     api.Tile_destroy(tm)
+    # an entry-dominated shard with a handful of units: the dictionary would save < 2 % of the streams and is not taken by default (desc_dict=1 asks for it anyway)
+    tm, rows, n, nnz = _tm("powerlaw200k")
+    _, i_def = api.plan_layout_digest(tm, rows, n, nnz)
+    _, i_ask = api.plan_layout_digest(tm, rows, n, nnz, desc_dict=1)
+    assert i_def["desc_bytes"] == 12 and i_ask["desc_bytes"] == 4
+    api.Tile_destroy(tm)
     # thousands of distinct patterns (random columns inside ELL / CSR-as-units tiles): the dictionary is refused, 12 B stay
     rng = np.random.default_rng(11)
     rows_, cols_ = 16 * 1200, 16 * 1200
