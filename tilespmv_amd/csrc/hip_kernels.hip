@@ -754,9 +754,18 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         acc += prod;
         if (flags & UNIT_EOR) {
             const int kr = (int)((flags >> UNIT_ROW_SHIFT) & 7u);
-            lacc_t out = acc;
-            if (side) out += s_y[g][kr][r];
-            s_y[g][kr][r] = out;
+            if constexpr (sizeof(val_t) == sizeof(lacc_t)) {
+                lacc_t out = acc;
+                if (side) out += s_y[g][kr][r];
+                s_y[g][kr][r] = out;
+            } else {
+                // fp32 build: the row's entry sums (fp64, complete: the entry phase is over) are read and the 16 FINAL results go back as floats into the head of the
+                // row's 128 bytes — lane r's 4 bytes overlap the doubles of lanes r/2, which every lane of the strip has read one instruction earlier — so that
+                // the y store at the end reads 16 bytes per lane as in the fp64 build instead of narrowing four doubles
+                val_t out = acc;
+                if (side) out = (val_t)((lacc_t)acc + s_y[g][kr][r]);
+                reinterpret_cast<val_t *>(&s_y[g][kr][0])[r] = out;
+            }
             acc = 0;
         }
     };
@@ -830,9 +839,18 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             }
         }
     } else {
-        if (!side) {  // rows without any unit and no COO contribution are zero
+        if constexpr (sizeof(val_t) == sizeof(lacc_t)) {
+            if (!side) {  // rows without any unit and no COO contribution are zero
+                unsigned m = nounit;
+                while (m) { const int kr = __ffs((int)m) - 1; m &= m - 1; s_y[g][kr][r] = 0; }
+            }
+        } else {          // fp32 build: rows without units hold fp64 entry sums (or nothing): into the float form of the retired rows
             unsigned m = nounit;
-            while (m) { const int kr = __ffs((int)m) - 1; m &= m - 1; s_y[g][kr][r] = 0; }
+            while (m) {
+                const int kr = __ffs((int)m) - 1; m &= m - 1;
+                const val_t o = side ? (val_t)s_y[g][kr][r] : (val_t)0;
+                reinterpret_cast<val_t *>(&s_y[g][kr][0])[r] = o;
+            }
         }
         wave_lds_fence();
         constexpr int VEC = 16 / (int)sizeof(val_t);  // values per 16-B lane store
@@ -847,17 +865,14 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
 #pragma unroll
                     for (int q = 0; q < VEC; q++) if (ybase + i + q < rowA) y[ybase + i + q] = (val_t)res[i + q];
                 }
-            } else {                                           // fp32: four fp64 sums narrowed into one 16-byte store
-                val_t o[VEC];
-#pragma unroll
-                for (int q = 0; q < VEC; q++) o[q] = (val_t)res[i + q];
+            } else {                                           // fp32: the rows hold 16 floats each at the head of their 128 bytes (retire / flush above)
+                const val_t *rf = reinterpret_cast<const val_t *>(res) + (i >> 4) * 32 + (i & 15);
                 if (ybase + i + VEC <= rowA) {
-                    v4u_t w; __builtin_memcpy(&w, o, 16);
-                    if (NT_Y && S.y_streaming) __builtin_nontemporal_store(w, reinterpret_cast<v4u_t *>(y + ybase + i));
-                    else *reinterpret_cast<v4u_t *>(y + ybase + i) = w;
+                    if (NT_Y && S.y_streaming) __builtin_nontemporal_store(*reinterpret_cast<const v4u_t *>(rf), reinterpret_cast<v4u_t *>(y + ybase + i));
+                    else *reinterpret_cast<uint4 *>(y + ybase + i) = *reinterpret_cast<const uint4 *>(rf);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < VEC; q++) if (ybase + i + q < rowA) y[ybase + i + q] = o[q];
+                    for (int q = 0; q < VEC; q++) if (ybase + i + q < rowA) y[ybase + i + q] = rf[q];
                 }
             }
         }
