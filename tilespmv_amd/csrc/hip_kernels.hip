@@ -896,6 +896,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
 // n dense tiles costs 4n MFMAs and one 16-value update of y at the end; summation order is fixed.
 // Loads of the next tile are issued before the MFMAs of the current one (unconditionally, clamped).
 // ------------------------------------------------------------------------------------------------
+template <bool NTS>   // NTS: the tile values (read once) are loaded nontemporally — plans above 400 MB per launch, as in k_units
 __global__ __launch_bounds__(256) void k_dense_mfma(DevDense D, int rowA, int colA, val_t *__restrict__ partial,
                                                     const val_t *__restrict__ x, val_t *__restrict__ y)
 {
@@ -920,10 +921,9 @@ __global__ __launch_bounds__(256) void k_dense_mfma(DevDense D, int rowA, int co
     auto load_tile = [&](int t, val_t (&a)[4], val_t (&b)[4]) {
         const int cb = __builtin_amdgcn_readlane(cbv, __builtin_amdgcn_readfirstlane(min(t, last) - t0));
         const long long xb = (long long)cb * 16 + 4 * kq;
-        const val_t *tv = D.val + (long long)min(t, last) * 256 + (16 * kq + rr0) * 4;  // operand order: 4 contiguous values per lane
+        const val_t *tv = D.val + (long long)min(t, last) * 256;   // operand order (dense_slot): fp32 one 16-byte load per lane, fp64 two, each covering whole lines
 #pragma unroll
-        for (int s = 0; s < 4; s++) a[s] = tv[s];   // (default cache policy also on plans whose unit kernel reads its streams nontemporally: a lane's 32 bytes are two loads that
-                                                    //  each touch half of every line, and the hint makes the second one fetch the line again — band hbw 40: 0.265 -> 0.301 ms)
+        for (int s = 0; s < 4; s++) a[s] = stream_load<NTS>(tv + dense_slot(rr0, 4 * kq + s));
         if (xb + 3 <= xlast) {
 #pragma unroll
             for (int s = 0; s < 4; s++) b[s] = x[xb + s];   // contiguous: merged into 16-B loads
@@ -969,9 +969,12 @@ __global__ __launch_bounds__(256) void k_dense_mfma(DevDense D, int rowA, int co
     }
 }
 
-hipError_t launch_dense_mfma(const DevDense &D, int rowA, int colA, val_t *partial, const val_t *x, val_t *y, hipStream_t st)
+hipError_t launch_dense_mfma(const DevDense &D, bool nt_stream, int rowA, int colA, val_t *partial, const val_t *x, val_t *y, hipStream_t st)
 {
-    if (D.nrows > 0) hipLaunchKernelGGL(k_dense_mfma, dim3((D.nrows + 3) / 4), dim3(256), 0, st, D, rowA, colA, partial, x, y);
+    if (D.nrows > 0) {
+        if (nt_stream) hipLaunchKernelGGL(k_dense_mfma<true>, dim3((D.nrows + 3) / 4), dim3(256), 0, st, D, rowA, colA, partial, x, y);
+        else hipLaunchKernelGGL(k_dense_mfma<false>, dim3((D.nrows + 3) / 4), dim3(256), 0, st, D, rowA, colA, partial, x, y);
+    }
     return hipGetLastError();
 }
 
@@ -1391,10 +1394,10 @@ __global__ __launch_bounds__(256) void k_dense_mfma_mv(DevDense D, int rowA, int
     for (int t = t0; t < t1; t++) {
         const int cb = __builtin_amdgcn_readlane(cbv, __builtin_amdgcn_readfirstlane(t - t0));
         const long long xb = (long long)cb * 16 + 4 * kq;
-        const val_t *tv = D.val + (long long)t * 256 + (16 * kq + n) * 4;
+        const val_t *tv = D.val + (long long)t * 256;
         val_t a[4], b[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) a[s] = tv[s];
+        for (int s = 0; s < 4; s++) a[s] = tv[dense_slot(n, 4 * kq + s)];
 #pragma unroll
         for (int s = 0; s < 4; s++) b[s] = n < NV ? X[min(xb + s, xlast) * NV + n] : (val_t)0;
 #pragma unroll
@@ -1505,7 +1508,7 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
     // whole-tile passes (y += ...): CSR tiles kept as tiles, dense tiles on the matrix cores; then the split-row fix-up
     hipError_t e = launch_tiles_direct(P, dense_mfma, /*accumulate=*/true, /*fixup=*/false, x, y, st);
     if (e != hipSuccess) return e;
-    e = launch_dense_mfma(DN, P.rowA, P.colA, P.partial, x, y, st);
+    e = launch_dense_mfma(DN, S.nt_stream != 0, P.rowA, P.colA, P.partial, x, y, st);
     if (e != hipSuccess) return e;
     if (P.nfix_late > 0) {  // split rows with pieces outside k_units (whole-tile / matrix-core passes)
         DevPlan Q = P;

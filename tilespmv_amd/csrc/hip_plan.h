@@ -151,9 +151,17 @@ struct DevStream {
 
 // Dense tiles on the matrix cores (generation 2): one wavefront per tile-row that owns dense tiles.
 struct DenseRow { int row, tile_begin, tile_end, partial; };  // partial: -1 -> y += result, else slot in partial[]
+// Where tile[r][c] of a dense tile sits among its 256 values (matrix-core pass).  Lane (q = c >> 2, r) needs columns 4q .. 4q+3 of row r.  fp32: its 16 bytes
+// contiguous — one load per lane, the wavefront's load covers whole lines.  fp64: two halves of 16 bytes, 1 KB apart, so that EACH of the lane's two loads covers whole
+// lines too (round 3: with the 32 bytes contiguous every load touched half of every line, which nontemporal loads then fetched twice — band hbw 40 0.265 -> 0.301 ms).
+__host__ __device__ constexpr int dense_slot(int r, int c)
+{
+    return sizeof(val_t) == 8 ? ((c & 3) >> 1) * 128 + ((c >> 2) * 16 + r) * 2 + (c & 1) : ((c >> 2) * 16 + r) * 4 + (c & 3);
+}
+
 struct DevDense {
     const int *cb;          // column block per dense tile
-    const val_t *val;       // 256 values per tile, zero padded, MFMA operand order: tile[r][c] at ((c >> 2) * 16 + r) * 4 + (c & 3)
+    const val_t *val;       // 256 values per tile, zero padded, MFMA operand order: tile[r][c] at dense_slot(r, c)
     const DenseRow *rows;
     int nrows;
 };

@@ -715,12 +715,11 @@ static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *
                         for (int q = 0; q < collen; q++) put_unit(cb, T->Blockdense_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)q);
                         break;
                     }
-                    {   // dense tile for the matrix cores: 256 values, zero padded, in MFMA operand order — lane (q, r) of
-                        // k_dense_mfma needs tile[r][4q .. 4q+3]; those four sit together: index (q*16 + r)*4 + s
+                    {   // dense tile for the matrix cores: 256 values, zero padded, in MFMA operand order (dense_slot, hip_plan.h)
                         const int off = T->dns_offset[t];
                         val_t *dst = h_dval + dq * 256;
                         for (int cc = 0; cc < collen; cc++)
-                            for (int r = 0; r < rowlen; r++) dst[((cc >> 2) * 16 + r) * 4 + (cc & 3)] = T->Blockdense_Val[off + cc * rowlen + r];
+                            for (int r = 0; r < rowlen; r++) dst[dense_slot(r, cc)] = T->Blockdense_Val[off + cc * rowlen + r];
                         h_dcb[(size_t)dq] = cb;
                         dq++;
                     }
