@@ -291,7 +291,7 @@ typedef struct {
     int desc_dict;      /* unit descriptors: unset = 4 B per unit + a dictionary of column patterns where the shard's units use few distinct
                            patterns AND the 8 bytes per unit are >= 2 % of the streams (stencil-like shards); 1 = wherever the patterns
                            are few; 0 = always the 12-B form                                                                   TILESPMV_DESC_DICT */
-    int nt_stream;      /* value / entry-record loads: 1 nontemporal, 0 default cache policy; unset: nontemporal where one SpMV moves more
+    int nt_stream;      /* value / entry-record / dense-tile loads: 1 nontemporal, 0 default cache policy; unset: nontemporal where one SpMV moves more
                            than 400 MB (about 1.6 x the Infinity Cache)                                                             TILESPMV_NT_STREAM */
     int reserved[2];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
