@@ -631,6 +631,9 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             const unsigned fl = d[k].x >> 24;
             const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
             if (XWIN && wcount > 0) xv[k] = s_xw[(d[k].x & 0xFFFFFFu) * 16 + nib];   // workgroup-uniform: a windowed workgroup's descriptors hold slots
+#if defined(TILESPMV_ABL) && TILESPMV_ABL == 7   // timing only: a unit whose column block equals the previous unit's skips its gather (what sharing the x segment would save)
+            else if (k > 0 && ((d[k].x ^ d[k - 1].x) & 0xFFFFFFu) == 0) xv[k] = xv[k - 1];
+#endif
             else xv[k] = x[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast)];
         }
     };
