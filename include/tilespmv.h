@@ -262,7 +262,7 @@ typedef struct {
     int kernel;         /* TILESPMV_KERNEL_* (0 = AUTO; env TILESPMV_KERNEL)     */
     int tilerow_begin;  /* shard: first tile-row (0 for the whole matrix) */
     int tilerow_end;    /* shard: one past the last tile-row (<=0 means tilem) */
-    int autotune;       /* != 0 (or env TILESPMV_AUTOTUNE=1): decide the AUTO modes, entry mode, strip size and XCD map by timing candidates
+    int autotune;       /* != 0 (or env TILESPMV_AUTOTUNE=1): decide the AUTO modes, entry mode, strip size, XCD map and stream cache policy by timing candidates
                            (one candidate plan is resident beside the best one so far: peak device memory = two plans + x + y) */
     /* ---- knobs (TILESPMV_KNOB_DEFAULT = unset) */
     int entry_mode;     /* COO entry lists per 16-lane strip (0), per wavefront (1), per workgroup (2)      TILESPMV_WAVE_COO */

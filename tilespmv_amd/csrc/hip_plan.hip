@@ -1243,10 +1243,28 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
         best->xcd_remap = maps[pick][0]; best->xcd_chunk = maps[pick][1];
         best_ms = std::min(best_ms, pick_ms);
     }
+    // cache policy of the once-read streams: the size rule (nontemporal above 400 MB per launch) switches somewhere between 340 and 500 MB; a measured selection
+    // just times both (the kernels differ by a template flag only: nothing is rebuilt).  Entry mode 1 and x-window plans have no nontemporal form.
+    log += "], \"stream_policy\": [";
+    if (best && best->kernel == TILESPMV_KERNEL_STREAM && K0.nt_stream < 0 && best->entry_mode != 1 && best->xwin_lds_bytes == 0) {
+        const int rule = best->st.nt_stream;
+        double ms2[2] = {0, 0};
+        for (int k = 0; k < 2; k++) {
+            best->st.nt_stream = k ? 1 - rule : rule;
+            ms2[k] = tilespmv_plan_time(best, dx, dy, nullptr, 3, 20);
+            char buf[96];
+            snprintf(buf, sizeof(buf), "%s{\"nontemporal\": %d, \"ms\": %.5f}", k ? ", " : "", best->st.nt_stream, ms2[k]);
+            log += buf;
+        }
+        const bool flip = ms2[1] > 0 && ms2[1] < ms2[0] * 0.985;   // leave the rule unless clearly better
+        best->st.nt_stream = flip ? 1 - rule : rule;
+        best->info[TILESPMV_INFO_NT_STREAM] = best->st.nt_stream;
+        if (ms2[flip ? 1 : 0] > 0) best_ms = std::min(best_ms, ms2[flip ? 1 : 0]);
+    }
     if (best) {
         char buf[512];
-        snprintf(buf, sizeof(buf), "], \"choice\": {\"coo_mode\": %d, \"dense_mode\": %d, \"entry_mode\": %d, \"ordered\": %lld, \"strip_cost\": %lld, \"xcd_remap\": %d, \"xcd_chunk\": %d, \"ms\": %.5f}}",
-                 best->coo_mode, best->dense_mode, best->entry_mode, best->info[TILESPMV_INFO_ENTRY_ORDERED], best->info[TILESPMV_INFO_STRIP_COST], best->xcd_remap, best->xcd_chunk, best_ms);
+        snprintf(buf, sizeof(buf), "], \"choice\": {\"coo_mode\": %d, \"dense_mode\": %d, \"entry_mode\": %d, \"ordered\": %lld, \"strip_cost\": %lld, \"xcd_remap\": %d, \"xcd_chunk\": %d, \"nontemporal\": %d, \"ms\": %.5f}}",
+                 best->coo_mode, best->dense_mode, best->entry_mode, best->info[TILESPMV_INFO_ENTRY_ORDERED], best->info[TILESPMV_INFO_STRIP_COST], best->xcd_remap, best->xcd_chunk, best->st.nt_stream, best_ms);
         log += buf;
         if (K0.autotune_log) {   // one JSON line per tuned plan
             if (FILE *f = fopen(K0.autotune_log, "a")) { fprintf(f, "%s\n", log.c_str()); fclose(f); }
