@@ -296,6 +296,9 @@ typedef struct {
     int reserved[2];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
+/* "name:offset,..." of every field above as the library was built: lets a binding that mirrors the struct by hand verify
+ * its field order (the Python mirror once had four knobs permuted and nothing noticed). */
+const char *tilespmv_plan_options_layout(void);
 
 /* Returns 0 on success, non-zero (message on stderr) when no HIP device / extension is
  * usable — there is no CPU fallback behind this entry point. */

@@ -34,6 +34,23 @@ def test_options_struct_is_versioned_and_mirrored():
         _lib.PlanOptions(no_such_knob=1)
 
 
+def test_options_mirror_has_the_field_order_of_the_header():
+    """the ctypes mirror had mv_native / mv_xcd_chunk / lds_pad / y_store permuted; size and all-defaults checks cannot see that.
+    The library reports name:offset of every field as it was compiled; the mirror must agree field by field, and a distinct value written
+    through every Python attribute must arrive in the C field of the same name (read back at the C offset)."""
+    for dtype in (np.float64, np.float32):
+        lib = _lib.load(dtype)
+        layout = [kv.split(":") for kv in lib.tilespmv_plan_options_layout().decode().split(",")]
+        c_off = {k: int(v) for k, v in layout}
+        py_off = {name: getattr(_lib.PlanOptions, name).offset for name, _ in _lib.PlanOptions._fields_}
+        assert [k for k, _ in layout] == [name for name, _ in _lib.PlanOptions._fields_]
+        assert c_off == py_off
+        o = _lib.PlanOptions(**{k: 1000 + i for i, k in enumerate(_lib.KNOB_NAMES)})
+        raw = (C.c_int * (C.sizeof(o) // 4)).from_buffer_copy(o)
+        for i, k in enumerate(_lib.KNOB_NAMES):
+            assert raw[c_off[k] // 4] == 1000 + i, k
+
+
 @pytest.mark.parametrize("name", ["allfmt", "powerlaw20k", "circuit8k", "one_long_row", "lap64", "kkt12"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_every_entry_mode_packs_and_decodes(name, dtype):

@@ -24,7 +24,7 @@ INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode"
 KNOB_DEFAULT = -1
 # tuning knobs of tilespmv_plan_options (include/tilespmv.h), in struct order after `autotune`
 KNOB_NAMES = ["entry_mode", "entry_ordered", "strip_cost", "split_above", "split_cap", "xcd_remap", "xcd_chunk", "csr_split", "fix_inline",
-              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "x_stride1", "x_stride2", "lds_pad", "y_store", "mv_native", "mv_xcd_chunk", "desc_dict", "nt_stream"]
+              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "x_stride1", "x_stride2", "mv_native", "mv_xcd_chunk", "lds_pad", "y_store", "desc_dict", "nt_stream"]
 
 
 class PlanOptions(C.Structure):
@@ -134,6 +134,7 @@ def load(dtype=np.float64):
     lib.tilespmv_mtx_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, _I, _I, VP]
     lib.tilespmv_mtx_write.restype = C.c_int
     lib.tilespmv_device_count.restype = C.c_int
+    lib.tilespmv_plan_options_layout.restype = C.c_char_p
     lib.tilespmv_version.restype = C.c_char_p
     libc = C.CDLL(None)
     libc.free.argtypes = [C.c_void_p]
@@ -151,4 +152,4 @@ DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_c
                     "tilespmv_device_count", "tilespmv_matrix_save", "tilespmv_matrix_load", "tilespmv_plan_spmv_n",
                     "call_tilespmv_hip_multi", "tilespmv_plan_spmm", "tilespmv_plan_time_spmm", "tilespmv_plan_options_init", "tilespmv_plan_layout_digest",
                     "tilespmv_csr_save", "tilespmv_csr_load", "mmio_allinone_cached", "tilespmv_mtx_write",
-                    "tilespmv_plan_time_reference_style", "tilespmv_plan_reserve_spmm"]
+                    "tilespmv_plan_time_reference_style", "tilespmv_plan_reserve_spmm", "tilespmv_plan_options_layout"]

@@ -1150,6 +1150,24 @@ void tilespmv_plan_options_init(tilespmv_plan_options *o)
     for (int i = 0; i < n; i++) knob[i] = TILESPMV_KNOB_DEFAULT;
 }
 
+// "name:offset,name:offset,..." of every field of tilespmv_plan_options as THIS build lays it out: what a binding that mirrors the
+// struct by hand (tilespmv_amd/_lib.py) is checked against (tests/test_plan_layout.py) — a permuted mirror used to go unnoticed.
+const char *tilespmv_plan_options_layout(void)
+{
+    static const std::string s = [] {
+        std::string o;
+#define TSPMV_F(f) o += std::string(o.empty() ? "" : ",") + #f + ":" + std::to_string(offsetof(tilespmv_plan_options, f));
+        TSPMV_F(size) TSPMV_F(coo_mode) TSPMV_F(dense_mode) TSPMV_F(kernel) TSPMV_F(tilerow_begin) TSPMV_F(tilerow_end) TSPMV_F(autotune)
+        TSPMV_F(entry_mode) TSPMV_F(entry_ordered) TSPMV_F(strip_cost) TSPMV_F(split_above) TSPMV_F(split_cap) TSPMV_F(xcd_remap) TSPMV_F(xcd_chunk)
+        TSPMV_F(csr_split) TSPMV_F(fix_inline) TSPMV_F(coo_cost) TSPMV_F(coo_heavy_min) TSPMV_F(coo_piece) TSPMV_F(strip_even) TSPMV_F(wg_strips)
+        TSPMV_F(x_window) TSPMV_F(x_stride1) TSPMV_F(x_stride2) TSPMV_F(mv_native) TSPMV_F(mv_xcd_chunk) TSPMV_F(lds_pad) TSPMV_F(y_store)
+        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(reserved)
+#undef TSPMV_F
+        return o;
+    }();
+    return s.c_str();
+}
+
 // Measured selection (execution side): with opts->autotune (or TILESPMV_AUTOTUNE=1) the choices that AUTO
 // otherwise makes from byte models — COO tiles in-tile vs CSR fallback, dense tiles on the matrix cores vs as streamed
 // units, entry mode, strip size, workgroup -> XCD map — are decided by timing each candidate plan on this device.  A
