@@ -55,6 +55,19 @@ def build_matrix(name, cache_dir=None):
         return G.circuit_like(int(name[7:]), seed=1) + ("synthetic circuit-like",)
     if name.startswith("laplacian"):
         return G.laplacian5pt(int(name[len("laplacian"):])) + ("synthetic 5-pt Laplacian",)
+    # the HBM-resident irregular / mixed class: bandrand<hbw>x<extra>_<rows>, uniform<per_row>_<rows>[x<cols>], rmat<scale>x<edge factor>
+    if name.startswith("bandrand"):
+        a, nn = name[8:].split("_"); hbw, extra = a.split("x")
+        return G.band_plus_random(int(nn), int(hbw), int(extra), 5) + ("synthetic band hbw=%s + %s random entries per row" % (hbw, extra),)
+    if name.startswith("uniform"):
+        k, nn = name[7:].split("_"); rr, _, cc = nn.partition("x")
+        return G.uniform_per_row(int(rr), int(cc or rr), int(k), 1) + ("synthetic uniform random, %s per row" % k,)
+    if name.startswith("rmat"):
+        sc, ef = name[4:].split("x")
+        return G.rmat(int(sc), int(ef), 3) + ("synthetic R-MAT scale %s, %s edges per vertex" % (sc, ef),)
+    if name.startswith("blockdiag"):   # blockdiag<bs>x<extra>_<blocks>
+        a, nb = name[9:].split("_"); bs, extra = a.split("x")
+        return G.block_diag_plus_sparse(int(nb), int(bs), int(extra), 6) + ("synthetic block-diagonal %sx%s (60 %%) + %s random per row" % (bs, bs, extra),)
     if name.startswith("band"):  # e.g. band40_2000000: full band, half-bandwidth 40 (dense-tile dominated)
         hbw, nn = name[4:].split("_")
         return G.band(int(nn), int(hbw)) + ("synthetic full band hbw=%s" % hbw,)

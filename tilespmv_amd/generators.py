@@ -147,6 +147,49 @@ def random_uniform(rows, cols, density, seed):
     return from_coo(rows, cols, rng.integers(0, rows, nnz), rng.integers(0, cols, nnz))
 
 
+def uniform_per_row(rows, cols, per_row, seed):
+    """``per_row`` uniformly random columns in every row (duplicates removed): the fully irregular end of the HBM-resident
+    test population (the authors' 2,757-matrix sweep is dominated by irregular matrices)."""
+    rng = np.random.default_rng(seed)
+    ri = np.repeat(np.arange(rows, dtype=np.int64), per_row)
+    return from_coo(rows, cols, ri, rng.integers(0, cols, ri.size))
+
+
+def band_plus_random(n, hbw, extra, seed):
+    """Full band of half-bandwidth ``hbw`` plus ``extra`` uniformly random entries per row on average: a regular part
+    (units) with scattered fill (one-entry COO tiles) — what many "structured + coupling" SuiteSparse matrices look like."""
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(n, dtype=np.int64), 2 * hbw + 1)
+    c = r + np.tile(np.arange(-hbw, hbw + 1, dtype=np.int64), n)
+    ok = (c >= 0) & (c < n)
+    rr = rng.integers(0, n, extra * n); cc = rng.integers(0, n, extra * n)
+    return from_coo(n, n, np.concatenate([r[ok], rr]), np.concatenate([c[ok], cc]))
+
+
+def rmat(scale, edge_factor, seed, a=0.57, b=0.19, c=0.19):
+    """R-MAT (Graph500 parameters) with 2^scale vertices and edge_factor * 2^scale edges before duplicate removal."""
+    rng = np.random.default_rng(seed)
+    n = 1 << scale
+    m = edge_factor * n
+    ri = np.zeros(m, np.int64); ci = np.zeros(m, np.int64)
+    for _ in range(scale):
+        u = rng.random(m)
+        rbit = (u >= a + b).astype(np.int64)
+        cbit = (((u >= a) & (u < a + b)) | (u >= a + b + c)).astype(np.int64)
+        ri = (ri << 1) | rbit; ci = (ci << 1) | cbit
+    return from_coo(n, n, ri, ci)
+
+
+def block_diag_plus_sparse(nb, bs, extra, seed, fill=0.6):
+    """``nb`` diagonal blocks of ``bs`` x ``bs`` at ``fill`` density + ``extra`` random entries per row."""
+    rng = np.random.default_rng(seed)
+    n = nb * bs
+    keep = rng.random((nb, bs, bs)) < fill
+    b, i, j = np.nonzero(keep)
+    rr = rng.integers(0, n, extra * n); cc = rng.integers(0, n, extra * n)
+    return from_coo(n, n, np.concatenate([b * bs + i, rr]), np.concatenate([b * bs + j, cc]))
+
+
 def all_formats(nblk=12, seed=7, cols_pad=0):
     """Small matrix whose 16x16 tiles are built on purpose to hit every selection rule of
     reference src/csr2tile.h:143-325: dense, COO, dense-row, dense-col, ELL, CSR and (only when
