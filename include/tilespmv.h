@@ -351,6 +351,23 @@ int tilespmv_plan_layout_digest(const Tile_matrix *matrix, int rowA, int colA, M
                                 const tilespmv_plan_options *opts, unsigned long long *digest,
                                 long long *info /* [TILESPMV_INFO_COUNT] or NULL */);
 
+/* Same host-only build, one digest per STAGE of the unit-stream layout builder (hip_plan_stream.hip), so that a test can say which
+ * knob is allowed to change which stage (`stage_digests` = TILESPMV_STAGE_COUNT values; all 0 for first-generation plans). */
+enum {
+    TILESPMV_STAGE_COUNT_ROWS = 0,    /* per tile-row: units / entries / whole tiles / dense tiles, cost */
+    TILESPMV_STAGE_CHOOSE = 1,        /* strip size, entry mode, strips per workgroup, ordered adds, brick order */
+    TILESPMV_STAGE_CUT = 2,           /* strips and pieces -> task records */
+    TILESPMV_STAGE_EMIT = 3,          /* unit descriptors + values, entry triples, whole-tile and dense payload (tile order) */
+    TILESPMV_STAGE_ORDER = 4,         /* task order: linear / brick (+ x windows) */
+    TILESPMV_STAGE_ENCODE = 5,        /* value groups per task, 12-B descriptors or 4-B words + dictionary */
+    TILESPMV_STAGE_ENTRIES = 6,       /* merged, column-ordered, packed entry lists */
+    TILESPMV_STAGE_FINISH = 7,        /* byte model and cache-policy flags */
+    TILESPMV_STAGE_COUNT = 8
+};
+int tilespmv_plan_layout_stages(const Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA,
+                                const tilespmv_plan_options *opts, unsigned long long *stage_digests,
+                                long long *info /* [TILESPMV_INFO_COUNT] or NULL */);
+
 /* Plan facts for reports: index into `out` by TILESPMV_INFO_*. */
 enum {
     TILESPMV_INFO_DEVICE_BYTES = 0,   /* bytes of the resident plan */

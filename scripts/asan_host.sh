@@ -9,7 +9,9 @@ for f in host_tile_create host_tilespmv_cpu host_mmio host_matrix_io; do
   g++ -O1 -g -fPIC -std=c++17 -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -DMAT_VAL_TYPE=double -c $f.cpp -o $out/$f.o
 done
 # the plan layout builder, host-only (plain g++; libamdhip64 only satisfies the linker: tilespmv_plan_layout_digest makes no HIP call)
-g++ -O1 -g -fPIC -std=c++17 -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -DMAT_VAL_TYPE=double -Wno-unused-result -x c++ -c hip_plan.hip -o $out/hip_plan.o
+for f in hip_plan hip_plan_stream; do
+  g++ -O1 -g -fPIC -std=c++17 -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -DMAT_VAL_TYPE=double -Wno-unused-result -x c++ -c $f.hip -o $out/$f.o
+done
 g++ -O1 -g -fPIC -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -DMAT_VAL_TYPE=double -c $root/scripts/host_stubs.cpp -o $out/host_stubs.o
 g++ -shared -fsanitize=address,undefined -pthread $out/*.o -o $out/libhost_asan.so -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 cd $out

@@ -1,0 +1,119 @@
+"""The unit-stream layout builder runs in stages (tilespmv_amd/csrc/hip_plan_stream.hip: count, choose, cut, emit, order, encode, entries, finish);
+tilespmv_plan_layout_stages hashes what each stage produced (host only, no GPU).  These tests pin WHICH stage a knob may change — a knob that
+leaks into an earlier stage than it should shows up here, not as a slow or wrong plan on the device."""
+import numpy as np
+import pytest
+
+import cases
+from tilespmv_amd import api, generators as G
+
+ALL = api.STAGE_NAMES
+
+
+def _tm(gen, dtype=np.float64, hyb=False):
+    m, n, rp, ci = gen
+    rows = cases.truncated_rows(m); nnz = int(rp[rows])
+    return api.Tile_create(rows, n, nnz, rp, ci, G.compat_values(len(ci), dtype), dtype=dtype, hyb=hyb), rows, n, nnz
+
+
+def _changed(a, b):
+    return [k for k in ALL if a[k] != b[k]]
+
+
+@pytest.fixture(scope="module")
+def mats():
+    out = {"lap3d": _tm(G.laplacian7pt(48)), "powerlaw": _tm(G.powerlaw(60000, seed=2)), "allfmt": _tm(G.all_formats(12, 7), hyb=True),
+           "bandrand": _tm(G.band_plus_random(40000, 4, 3, 5)), "band40": _tm(G.band(30000, 40))}
+    yield out
+    for tm, *_ in out.values():
+        api.Tile_destroy(tm)
+
+
+def test_stages_are_deterministic_and_all_present(mats):
+    for name, (tm, rows, n, nnz) in mats.items():
+        a, info = api.plan_layout_stages(tm, rows, n, nnz)
+        b, _ = api.plan_layout_stages(tm, rows, n, nnz)
+        assert a == b, name
+        assert all(a[k] != 0 for k in ALL), (name, a)
+        assert len(set(a.values())) == len(ALL)
+
+
+def test_first_generation_plans_have_no_stages(mats):
+    tm, rows, n, nnz = mats["allfmt"]
+    a, _ = api.plan_layout_stages(tm, rows, n, nnz, kernel=api.KERNEL_DIRECT)
+    assert all(v == 0 for v in a.values())
+
+
+def test_descriptor_form_touches_the_encoding_and_the_byte_model_only(mats):
+    tm, rows, n, nnz = mats["lap3d"]
+    d4, i4 = api.plan_layout_stages(tm, rows, n, nnz)
+    d12, i12 = api.plan_layout_stages(tm, rows, n, nnz, desc_dict=0)
+    assert (i4["desc_bytes"], i12["desc_bytes"]) == (4, 12)
+    assert _changed(d4, d12) == ["encode", "finish"]
+
+
+def test_cache_policy_and_store_knobs_touch_only_the_last_stage(mats):
+    tm, rows, n, nnz = mats["lap3d"]
+    base, _ = api.plan_layout_stages(tm, rows, n, nnz)
+    for kw in ({"nt_stream": 1}, {"y_store": 0}, {"coo_heavy_min": 7}):
+        other, _ = api.plan_layout_stages(tm, rows, n, nnz, **kw)
+        assert _changed(base, other) == ["finish"], kw
+    for kw in ({"xcd_chunk": 8}, {"xcd_remap": 0}, {"lds_pad": 4096}, {"mv_native": 1}):   # launch parameters: no stage at all
+        other, _ = api.plan_layout_stages(tm, rows, n, nnz, **kw)
+        assert _changed(base, other) == [], kw
+
+
+def test_ordered_adds_are_a_flag_not_a_layout(mats):
+    tm, rows, n, nnz = mats["powerlaw"]
+    a, ia = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, entry_ordered=1)
+    b, ib = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, entry_ordered=0)
+    assert (ia["entry_ordered"], ib["entry_ordered"]) == (1, 0)
+    assert _changed(a, b) == ["choose", "finish"]
+
+
+def test_strips_per_workgroup_only_regroup_the_entry_lists(mats):
+    tm, rows, n, nnz = mats["powerlaw"]
+    a, _ = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, wg_strips=16, strip_cost=800)
+    b, _ = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, wg_strips=32, strip_cost=800)
+    assert _changed(a, b) == ["choose", "entries", "finish"]
+
+
+def test_entry_modes_share_counts_and_differ_in_the_lists(mats):
+    tm, rows, n, nnz = mats["bandrand"]
+    st = {m: api.plan_layout_stages(tm, rows, n, nnz, entry_mode=m, strip_cost=800, split_above=100000)[0] for m in (0, 1, 2)}
+    assert st[0]["count"] == st[1]["count"] == st[2]["count"]
+    assert st[1]["cut"] == st[2]["cut"] and st[1]["emit"] == st[2]["emit"] and st[1]["encode"] == st[2]["encode"]   # same strips, same units: only the merged lists differ
+    assert st[1]["entries"] != st[2]["entries"] != st[0]["entries"]
+
+
+def test_brick_order_permutes_tasks_but_emits_the_same_units(mats):
+    tm, rows, n, nnz = mats["lap3d"]
+    kw = dict(strip_cost=100)
+    lin, il = api.plan_layout_stages(tm, rows, n, nnz, x_window=0, **kw)
+    brk, ib = api.plan_layout_stages(tm, rows, n, nnz, x_window=2, **kw)
+    assert (il["brick_order"], ib["brick_order"]) == (0, 1)
+    assert lin["count"] == brk["count"]
+    assert lin["order"] != brk["order"] and lin["encode"] != brk["encode"]
+    win, iw = api.plan_layout_stages(tm, rows, n, nnz, x_window=1, entry_mode=0, **kw)
+    assert iw["x_window_slots"] > 0 and win["order"] != brk["order"]
+
+
+def test_dense_tiles_as_units_or_for_the_matrix_cores(mats):
+    tm, rows, n, nnz = mats["band40"]
+    u, iu = api.plan_layout_stages(tm, rows, n, nnz, dense_mode=api.DENSE_VALU)
+    m, im = api.plan_layout_stages(tm, rows, n, nnz, dense_mode=api.DENSE_MFMA)
+    assert u["count"] != m["count"] and u["emit"] != m["emit"]
+    assert im["stream_bytes"] < iu["stream_bytes"]      # 256 values + 4 B per dense tile against 16 units of 16 values + descriptor
+
+
+def test_byte_model_follows_the_streams(mats):
+    """stream_bytes (the plan's own model of one SpMV) recomputed from the plan facts for the two simplest layouts."""
+    tm, rows, n, nnz = mats["lap3d"]          # units only (7-point grid aligned to 16: no entries), 4-B descriptors, no padding units beyond the value groups
+    _, i = api.plan_layout_stages(tm, rows, n, nnz, desc_dict=0, strip_even=0)
+    units = nnz // 16 if nnz % 16 == 0 else None
+    assert i["stream_bytes"] >= nnz * 8 + 12 * (nnz // 16) + i["num_tasks"] * 32 + 8 * (rows + n)
+    assert i["stream_bytes"] <= 1.1 * (nnz * 8 + 12 * (nnz // 16) + i["num_tasks"] * 32 + 8 * (rows + n))
+    tm, rows, n, nnz = mats["powerlaw"]       # entry-dominated, per-strip lists: value + column + row byte per entry
+    _, i0 = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=0)
+    _, i2 = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2)
+    assert i0["stream_bytes"] >= 13 * int(0.8 * nnz) and i2["stream_bytes"] < i0["stream_bytes"]     # packed 12-B records against 13-B triples

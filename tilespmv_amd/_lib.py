@@ -105,6 +105,8 @@ def load(dtype=np.float64):
     lib.tilespmv_plan_options_init.restype = None
     lib.tilespmv_plan_layout_digest.argtypes = [TP, C.c_int, C.c_int, C.c_int, C.POINTER(PlanOptions), C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong)]
     lib.tilespmv_plan_layout_digest.restype = C.c_int
+    lib.tilespmv_plan_layout_stages.argtypes = [TP, C.c_int, C.c_int, C.c_int, C.POINTER(PlanOptions), C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong)]
+    lib.tilespmv_plan_layout_stages.restype = C.c_int
     lib.tilespmv_plan_destroy.argtypes = [C.c_void_p]
     lib.tilespmv_plan_destroy.restype = None
     lib.tilespmv_plan_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -152,4 +154,4 @@ DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_c
                     "tilespmv_device_count", "tilespmv_matrix_save", "tilespmv_matrix_load", "tilespmv_plan_spmv_n",
                     "call_tilespmv_hip_multi", "tilespmv_plan_spmm", "tilespmv_plan_time_spmm", "tilespmv_plan_options_init", "tilespmv_plan_layout_digest",
                     "tilespmv_csr_save", "tilespmv_csr_load", "mmio_allinone_cached", "tilespmv_mtx_write",
-                    "tilespmv_plan_time_reference_style", "tilespmv_plan_reserve_spmm", "tilespmv_plan_options_layout"]
+                    "tilespmv_plan_time_reference_style", "tilespmv_plan_reserve_spmm", "tilespmv_plan_options_layout", "tilespmv_plan_layout_stages"]

@@ -172,6 +172,20 @@ def plan_layout_digest(tm, rowA, colA, nnzA, coo_mode=COO_AUTO, dense_mode=DENSE
     return d.value, {k: int(out[i]) for i, k in enumerate(_lib.INFO_NAMES)}
 
 
+STAGE_NAMES = ["count", "choose", "cut", "emit", "order", "encode", "entries", "finish"]
+
+
+def plan_layout_stages(tm, rowA, colA, nnzA, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, **knobs):
+    """Host-only build of the unit-stream layout, one digest per builder stage (``STAGE_NAMES``) + the plan facts."""
+    opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, False, **knobs)
+    st = (C.c_ulonglong * len(STAGE_NAMES))()
+    out = (C.c_longlong * len(_lib.INFO_NAMES))()
+    rc = tm._lib.tilespmv_plan_layout_stages(C.byref(tm), rowA, colA, nnzA, C.byref(opts), st, out)
+    if rc != 0:
+        raise RuntimeError("tilespmv_plan_layout_stages failed (%d)" % rc)
+    return {k: int(st[i]) for i, k in enumerate(STAGE_NAMES)}, {k: int(out[i]) for i, k in enumerate(_lib.INFO_NAMES)}
+
+
 class Plan:
     """Device-resident tiled matrix (or one tile-row shard of it)."""
 

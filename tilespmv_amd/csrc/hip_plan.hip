@@ -6,16 +6,7 @@
 // tile stream of generation 1) and uploaded; the chunk schedule that the reference derives inside
 // tilespmv_cpu (:68-118) and patches up with a one-off v5 launch (:1045-1056) is replaced by a
 // cost-balanced strip list built here.
-#include <hip/hip_runtime.h>
-#include <sys/time.h>
-
-#include <climits>
-#include <cmath>
-#include <string>
-#include <unordered_map>
-#include <unordered_set>
-
-#include "hip_plan.h"
+#include "hip_plan_internal.h"
 
 namespace tilespmv {
 
@@ -27,55 +18,6 @@ hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const De
                                   hipStream_t st);
 hipError_t launch_rows_to_columns(const val_t *X, int nvec, long long n, long long ld, val_t *XT, hipStream_t st);
 hipError_t launch_columns_to_rows(const val_t *YT, int nvec, long long row0, long long rows, long long ld, val_t *Y, hipStream_t st);
-
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess) {                                                                         \
-            fprintf(stderr, "tilespmv: HIP error %d (%s) at %s:%d: %s\n", (int)e_, hipGetErrorString(e_), \
-                    __FILE__, __LINE__, #expr);                                                         \
-            return (int)e_;                                                                             \
-        }                                                                                               \
-    } while (0)
-
-static double now_us()
-{
-    timeval t;
-    gettimeofday(&t, NULL);
-    return t.tv_sec * 1e6 + t.tv_usec;
-}
-
-static int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
-
-// Every tuning knob of one plan build, resolved ONCE at the API boundary (tilespmv_plan_create): option field if set, else the
-// environment variable (getenv only — the library never writes the environment), else the built-in default.  The builder and
-// the autotuner pass this struct around; nothing below the boundary reads the environment.
-struct Knobs {
-    int coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, autotune;
-    int entry_mode;      // -1 = chosen from the shard
-    int entry_ordered;   // -1 = chosen from the grid size
-    int strip_cost;      // <= 0 = chosen from the shard
-    int split_above, split_cap, xcd_remap, xcd_chunk, csr_split, fix_inline, coo_cost, coo_heavy_min;
-    int coo_piece;       // <= 0 = derived from the piece size
-    int strip_even;
-    int wg_strips;       // -1 = chosen from the shard
-    int x_window;        // -1 = default
-    int x_stride1, x_stride2;   // tile-rows per grid line / plane for the x windows; 0 = detected from the shard
-    int lds_pad;         // bytes of unused LDS added to every unit-kernel workgroup (fewer resident workgroups per CU); -1 = chosen from the shard
-    int brick_rows;      // brick order: tile-rows per strip at most (experiment knob, environment only)
-    int y_store;         // -1 by rule, 0 plain y stores, 1 streaming (nontemporal) y stores
-    int mv_native;       // -1 = by nvec
-    int mv_xcd_chunk;    // -1 = the plan's XCD chunk
-    int nt_stream;       // -1 by size, 0 plain, 1 nontemporal loads of the value / entry-record streams
-    int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows
-    bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
-    bool dry;            // tilespmv_plan_layout_digest: build the layout on the host only, hash instead of upload
-    const char *autotune_log;
-};
 
 static Knobs resolve_knobs(const tilespmv_plan_options *opts)
 {
@@ -125,986 +67,6 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
 }  // namespace tilespmv
 
 using namespace tilespmv;
-
-struct tilespmv_plan {
-    DevPlan dev{};
-    DevStream st{};
-    DevDense dn{};
-    int xcd_remap = 2, xcd_chunk = 32;  // windows of 8 x 32 workgroups: neighbouring strips share an XCD L2 (sweep 4..64: flat within 2.5 %, 32 best on 3 of 4 large matrices)
-    val_t *mv_x = nullptr, *mv_y = nullptr;  // plans without a native multi-vector kernel: X / Y as mv_nvec contiguous vectors (allocated at the first such call)
-    int mv_nvec = 0;
-    bool mv_by_columns = false;              // ... and plans whose work is mostly COO entries (the multi-vector kernel walks them per 16-lane strip)
-    int mv_native = -1, mv_xcd_chunk = -1;   // knobs of tilespmv_plan_spmm (Knobs)
-    int mv_slab_rows = 0;                    // > 0: the multi-vector kernel scatters a strip's entries up front into an LDS slab of this many tile-rows per lane group
-    int entry_mode = 0;                 // COO entry lists walked per 16-lane strip (0), per wavefront (1) or per workgroup, column-ordered (2)
-    std::vector<void *> allocs;
-    long long info[TILESPMV_INFO_COUNT] = {0};
-    int coo_mode = 0, dense_mode = 0, kernel = 0;
-    int device = 0;
-    int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
-    int lds_pad_bytes = 0;              // extra (unused) dynamic LDS per workgroup of the unit kernel: caps the workgroups resident on a CU (knob lds_pad)
-    int xwin_lds_bytes = 0;             // x-window plans: dynamic LDS of the unit kernel (largest window of the plan); 0 = no windows
-    int arena_flags = 0; size_t arena_skew = 0;
-    char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20, arena_next = (size_t)1 << 20, size_hint = 0;   // bump allocator of upload(); size_hint = the builder's estimate of the plan's bytes
-    bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
-    unsigned long long digest = 1469598103934665603ull;
-    template <class T>
-    int upload(const T *host, size_t n, const T **out)
-    {
-        if (dry) {   // FNV-1a-64 over (element count, bytes) of every stream, in upload order
-            auto mix = [&](const unsigned char *p, size_t len) { for (size_t i = 0; i < len; i++) { digest ^= p[i]; digest *= 1099511628211ull; } };
-            const unsigned long long cnt = n;
-            mix((const unsigned char *)&cnt, 8);
-            mix((const unsigned char *)host, n * sizeof(T));
-            info[TILESPMV_INFO_DEVICE_BYTES] += (long long)(n * sizeof(T));
-            *out = nullptr;
-            return 0;
-        }
-        const double t0 = now_us();
-        void *d = nullptr;
-        // Streams are carved out of a few large device blocks (bump allocation, 256-byte aligned + 256 bytes of slack so that
-        // masked tail lanes never fault) instead of one hipMalloc each: a plan is ~20 streams, and large blocks get large
-        // page-table fragments whatever state the allocator is in (fewer hipMalloc calls, too).
-        const size_t need = (std::max<size_t>(n, 1) * sizeof(T) + 256 + 255) / 256 * 256 + arena_skew;   // (arena_skew: experiment knob, bytes left unused behind every stream)
-        if (need > arena_left) {   // blocks of arena_block bytes (256 MB) for plans of that size and more; a smaller plan gets one block of about its own size (size_hint)
-            const size_t want = size_hint >= arena_block ? arena_block : std::max<size_t>(arena_next, size_hint + size_hint / 4 + ((size_t)1 << 20));
-            const size_t blk = std::max<size_t>(need, std::min(want, arena_block));
-            arena_next = std::min<size_t>(arena_next * 4, std::max<size_t>(arena_block, 1));
-            void *b = nullptr;
-            if (arena_flags) HIP_TRY(hipExtMallocWithFlags(&b, blk, (unsigned)arena_flags));   // experiment knob TILESPMV_ARENA_FLAGS (4 = physically contiguous)
-            else HIP_TRY(hipMalloc(&b, blk));
-            allocs.push_back(b);
-            arena_at = (char *)b; arena_left = blk;
-        }
-        d = arena_at; arena_at += need; arena_left -= need;
-        if (n) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
-        info[TILESPMV_INFO_DEVICE_BYTES] += (long long)(n * sizeof(T));
-        info[TILESPMV_INFO_UPLOAD_US] += (long long)(now_us() - t0);
-        *out = (const T *)d;
-        return 0;
-    }
-};
-
-namespace {
-
-inline int nib(const unsigned char *s, long long p) { return (p & 1) ? (s[p >> 1] & 15) : (s[p >> 1] >> 4); }
-inline void put_nib(unsigned char *s, int p, int v) { if (p & 1) s[p >> 1] |= (unsigned char)v; else s[p >> 1] |= (unsigned char)(v << 4); }
-
-// What one source tile becomes in the streams.
-struct Emit { int fmt, p1, p2, nv, ni; };
-
-inline Emit emit_of(const Tile_matrix *T, int t, int rowlen, bool coo_in_tile)
-{
-    Emit e{DESC_FMT_NOP, 0, 0, 0, 0};
-    const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
-    switch (fmt) {
-    case TILESPMV_FMT_CSR: e.fmt = fmt; e.p1 = stored; break;
-    case TILESPMV_FMT_COO: if (!coo_in_tile) return e; e.fmt = fmt; e.p1 = stored; break;
-    case TILESPMV_FMT_ELL: e.fmt = fmt; e.p1 = w; break;
-    case TILESPMV_FMT_HYB: e.fmt = fmt; e.p1 = w; e.p2 = coo_in_tile ? stored - w * rowlen : 0; break;
-    case TILESPMV_FMT_DNS: e.fmt = fmt; break;
-    case TILESPMV_FMT_DNSROW: e.fmt = fmt; e.p1 = T->dnsrowptr[t + 1] - T->dnsrowptr[t]; break;
-    case TILESPMV_FMT_DNSCOL: e.fmt = fmt; e.p1 = T->dnscolptr[t + 1] - T->dnscolptr[t]; break;
-    }
-    tile_stream_sizes(e.fmt, e.p1, e.p2, &e.nv, &e.ni);
-    return e;
-}
-
-// Copy one tile's payload into the streams, converting to row stride 16 / tile-local packing.
-void repack_tile(const Tile_matrix *T, int t, const Emit &e, int rowlen, int collen, long long hyb_idx_off,
-                 val_t *v, unsigned char *ix)
-{
-    switch (e.fmt) {
-    case TILESPMV_FMT_CSR: {
-        const int off = T->csr_offset[t], poff = T->csrptr_offset[t];
-        memcpy(v, T->Blockcsr_Val + off, sizeof(val_t) * (size_t)e.p1);
-        for (int r = 0; r < 16; r++) ix[r] = (unsigned char)(r < rowlen ? T->Blockcsr_Ptr[poff + r] : e.p1);
-        for (int k = 0; k < e.p1; k++) put_nib(ix + 16, k, nib(T->csr_compressedIdx, (long long)off + k));
-        break;
-    }
-    case TILESPMV_FMT_COO: {
-        const int off = T->coo_offset[t];
-        memcpy(v, T->Blockcoo_Val + off, sizeof(val_t) * (size_t)e.p1);
-        memcpy(ix, T->coo_compressed_Idx + off, (size_t)e.p1);
-        break;
-    }
-    case TILESPMV_FMT_ELL: {
-        const int off = T->ell_offset[t];
-        for (int s = 0; s < e.p1; s++)
-            for (int r = 0; r < rowlen; r++) {
-                v[16 * s + r] = T->Blockell_Val[off + s * rowlen + r];
-                put_nib(ix, 16 * s + r, nib(T->ell_compressedIdx, (long long)off + s * rowlen + r));
-            }
-        break;
-    }
-    case TILESPMV_FMT_HYB: {
-        const int off = T->hyb_offset[t], nell = e.p1 * rowlen;
-        const unsigned char *src = T->hybIdx + hyb_idx_off;
-        for (int s = 0; s < e.p1; s++)
-            for (int r = 0; r < rowlen; r++) {
-                v[16 * s + r] = T->Blockhyb_Val[off + s * rowlen + r];
-                put_nib(ix, 16 * s + r, nib(src, s * rowlen + r));
-            }
-        for (int i = 0; i < e.p2; i++) {
-            v[16 * e.p1 + i] = T->Blockhyb_Val[off + nell + i];
-            ix[8 * e.p1 + i] = src[(nell + 1) / 2 + i];
-        }
-        break;
-    }
-    case TILESPMV_FMT_DNS: {
-        const int off = T->dns_offset[t];
-        for (int c = 0; c < collen; c++)
-            for (int r = 0; r < rowlen; r++) v[16 * c + r] = T->Blockdense_Val[off + c * rowlen + r];
-        break;
-    }
-    case TILESPMV_FMT_DNSROW: {
-        const int off = T->dnsrow_offset[t], ro = T->dnsrowptr[t];
-        for (int k = 0; k < e.p1; k++) {
-            for (int c = 0; c < collen; c++) v[16 * k + c] = T->Blockdenserow_Val[off + k * collen + c];
-            ix[k] = (unsigned char)T->denserowid[ro + k];
-        }
-        break;
-    }
-    case TILESPMV_FMT_DNSCOL: {
-        const int off = T->dnscol_offset[t], co = T->dnscolptr[t];
-        for (int k = 0; k < e.p1; k++) {
-            for (int r = 0; r < rowlen; r++) v[16 * k + r] = T->Blockdensecol_Val[off + k * rowlen + r];
-            ix[k] = (unsigned char)T->densecolid[co + k];
-        }
-        break;
-    }
-    default: break;
-    }
-}
-
-}  // namespace
-
-
-// ------------------------------------------------------------------------------------------------
-// Second-generation layout builder (hip_plan.h "unit stream").
-// ------------------------------------------------------------------------------------------------
-namespace {
-
-// One entry of a merged list before packing.
-struct PEnt { unsigned col, dest; val_t val; };
-
-inline ERec make_erec(val_t v, unsigned w)
-{
-    ERec r;
-#if defined(TILESPMV_F32)
-    memcpy(&r.v, &v, 4);
-#else
-    unsigned b[2]; memcpy(b, &v, 8); r.lo = b[0]; r.hi = b[1];
-#endif
-    r.w = w;
-    return r;
-}
-
-// Packs one list (entries already in their final order: by column, ties in list order) into records and per-chunk column
-// bases (hip_plan.h ERec).  Chunk k of the list = its records [64k, 64k + 64); base = column of the chunk's first entry;
-// an entry whose column is 2^(32 - dest_bits) or more above the base closes the chunk, which is filled up with null
-// records (value 0, offset 0, destination 0: adds 0 * x[base] to the group's first row).  Returns false if the packed list
-// does not decode back to the input (checked in layout-digest builds).
-inline bool pack_list(const std::vector<PEnt> &ents, int dest_bits, std::vector<ERec> &rec, std::vector<unsigned> &base, bool verify)
-{
-    const unsigned long long span = 1ull << (32 - dest_bits);
-    const size_t rec0 = rec.size(), base0 = base.size();
-    size_t i = 0;
-    while (i < ents.size()) {
-        const unsigned b = ents[i].col;
-        base.push_back(b);
-        int n = 0;
-        while (i < ents.size() && n < ECHUNK && (unsigned long long)ents[i].col - b < span) {
-            rec.push_back(make_erec(ents[i].val, ((ents[i].col - b) << dest_bits) | ents[i].dest));
-            i++; n++;
-        }
-        if (i < ents.size()) for (; n < ECHUNK; n++) rec.push_back(make_erec((val_t)0, 0u));   // interior chunks are always full
-    }
-    if (!verify) return true;
-    size_t j = 0;
-    for (size_t q = rec0; q < rec.size(); q++) {
-        const ERec &r = rec[q];
-        const unsigned bq = base[base0 + (q - rec0) / ECHUNK];
-        val_t v;
-#if defined(TILESPMV_F32)
-        memcpy(&v, &r.v, 4);
-#else
-        unsigned bb[2] = {r.lo, r.hi}; memcpy(&v, bb, 8);
-#endif
-        if (r.w == 0u && v == (val_t)0 && (j >= ents.size() || ents[j].col != bq || ents[j].dest != 0u || ents[j].val != (val_t)0)) continue;   // null padding
-        if (j >= ents.size()) return false;
-        const unsigned col = bq + (r.w >> dest_bits), dest = r.w & ((1u << dest_bits) - 1u);
-        if (col != ents[j].col || dest != ents[j].dest || memcmp(&v, &ents[j].val, sizeof(val_t)) != 0) return false;
-        j++;
-    }
-    return j == ents.size() && base.size() - base0 == (rec.size() - rec0 + ECHUNK - 1) / ECHUNK;
-}
-
-struct RowCount { int nunits, ncoo, nheavy, ndense; long long hval, hidx; long long cost; };
-
-// A CSR tile is executed as w ELL-style units (the first w entries of every row) plus the rest of
-// its entries on the strip's COO list; w minimises the bytes moved (HYB's idea, src/csr2tile.h:279-306,
-// with this kernel's byte costs).  Returns w and the number of remainder entries.
-inline int csr_split_width(const unsigned char *ptr, int rowlen, int nnz, int *remainder)
-{
-    const long long unit_b = 16 + 16 * (long long)sizeof(val_t), entry_b = (long long)sizeof(val_t) + 5;
-    int len[16], wmax = 0;
-    for (int r = 0; r < 16; r++) { len[r] = r < rowlen ? ((r == rowlen - 1 ? nnz : ptr[r + 1]) - ptr[r]) : 0; wmax = std::max(wmax, len[r]); }
-    int best_w = 0, best_rem = nnz; long long best = entry_b * nnz;
-    for (int w = 1; w <= wmax; w++) {
-        int rem = 0;
-        for (int r = 0; r < 16; r++) rem += std::max(0, len[r] - w);
-        const long long b = unit_b * w + entry_b * rem;
-        if (b < best) { best = b; best_w = w; best_rem = rem; }
-    }
-    *remainder = best_rem;
-    return best_w;
-}
-
-inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, bool csr_split, int coo_cost)
-{
-    RowCount c{0, 0, 0, 0, 0, 0, 0};
-    for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
-        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
-        switch (fmt) {
-        case TILESPMV_FMT_ELL: c.nunits += w; break;
-        case TILESPMV_FMT_HYB: c.nunits += w; if (coo_in_tile) c.ncoo += stored - w * rowlen; break;
-        case TILESPMV_FMT_DNSCOL: c.nunits += T->dnscolptr[t + 1] - T->dnscolptr[t]; break;
-        case TILESPMV_FMT_DNS:
-            if (dense_mfma) c.ndense++;
-            else c.nunits += tile_collen(T->tile_columnidx[t], tilen, colA);
-            break;
-        case TILESPMV_FMT_COO: if (coo_in_tile) c.ncoo += stored; break;
-        case TILESPMV_FMT_CSR:
-            if (csr_split) { int rem; c.nunits += csr_split_width(T->Blockcsr_Ptr + T->csrptr_offset[t], rowlen, stored, &rem); c.ncoo += rem; }
-            else { c.nheavy++; c.hval += stored; c.hidx += 16 + (stored + 1) / 2; }
-            break;
-        case TILESPMV_FMT_DNSROW: c.nunits += T->dnsrowptr[t + 1] - T->dnsrowptr[t]; break;  // one row unit per dense row
-        }
-    }
-    // heavy tiles are latency-bound (one tile at a time): weigh them so that long lists get split
-    c.cost = 16LL * c.nunits + (long long)coo_cost * c.ncoo + c.hval + 256LL * c.nheavy + 64LL * c.ndense + 8;
-    return c;
-}
-
-
-// Dominant tile-row distances of a stencil-like shard: d = column block - tile-row over the tiles that become units.  s1 = the
-// smallest distance >= 2 that most tile-rows have (tile-rows per grid line), s2 = the middle of the next cluster of distances
-// (tile-rows per grid plane; 0 for 2-D problems).  0 / 0 when the shard has no such structure.
-inline void detect_strides(const Tile_matrix *T, int tr0, int tr1, bool csr_split, bool dense_mfma, int *s1, int *s2)
-{
-    *s1 = *s2 = 0;
-    const int ntr = tr1 - tr0;
-    if (ntr < 32) return;
-    const int step = std::max(1, ntr / 32768);
-    std::vector<long long> ds;
-    long long sampled = 0;
-    for (int bi = tr0; bi < tr1; bi += step) {
-        sampled++;
-        long long last = LLONG_MIN;
-        for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
-            const int fmt = T->Format[t];
-            const bool units = fmt == TILESPMV_FMT_ELL || fmt == TILESPMV_FMT_HYB || fmt == TILESPMV_FMT_DNSCOL || fmt == TILESPMV_FMT_DNSROW ||
-                               (fmt == TILESPMV_FMT_DNS && !dense_mfma) || (fmt == TILESPMV_FMT_CSR && csr_split);
-            const long long d = (long long)T->tile_columnidx[t] - bi;
-            if (units && d >= 2 && d != last) { ds.push_back(d); last = d; }
-        }
-    }
-    std::sort(ds.begin(), ds.end());
-    std::vector<long long> dom;   // distances that at least a quarter of the sampled tile-rows have
-    for (size_t i = 0; i < ds.size();) {
-        size_t j = i;
-        while (j < ds.size() && ds[j] == ds[i]) j++;
-        if ((long long)(j - i) * 4 >= sampled) dom.push_back(ds[i]);
-        i = j;
-    }
-    if (dom.empty() || dom[0] > (1 << 20)) return;
-    *s1 = (int)dom[0];
-    size_t a = 1;
-    while (a < dom.size() && dom[a] <= dom[0] + 1) a++;
-    if (a >= dom.size()) return;
-    size_t b = a;
-    while (b + 1 < dom.size() && dom[b + 1] - dom[b] <= dom[0] + 1) b++;   // {s2 - s1, s2, s2 + s1} of a 27-point stencil
-    const long long mid = dom[(a + b) / 2];
-    if (mid % dom[0] == 0 && mid / dom[0] >= 2 && mid < (1ll << 30)) *s2 = (int)mid;
-}
-
-}  // namespace
-
-static int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,
-                        bool dense_mfma, const std::vector<long long> &hyb_off,
-                        std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes)
-{
-    const bool csr_split = K.csr_split != 0;
-    const int target_in = K.strip_cost, split_above_in = K.split_above;
-    const int tilem = T->tilem, tilen = T->tilen, ntr = std::max(0, tr1 - tr0), sv = (int)sizeof(val_t);
-    std::vector<RowCount> rc_((size_t)ntr);
-    parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
-        for (int64_t i = b; i < e; i++) rc_[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, csr_split, K.coo_cost);
-    });
-    std::vector<long long> pu((size_t)ntr + 1, 0), pc((size_t)ntr + 1, 0), ph((size_t)ntr + 1, 0), phv((size_t)ntr + 1, 0), phi((size_t)ntr + 1, 0);
-    std::vector<long long> pd((size_t)ntr + 1, 0);
-    for (int i = 0; i < ntr; i++) pd[i + 1] = pd[i] + rc_[i].ndense;
-    const long long ND = pd[ntr];
-    std::vector<DenseRow> drows;
-    for (int i = 0; i < ntr; i++) {
-        pu[i + 1] = pu[i] + rc_[i].nunits; pc[i + 1] = pc[i] + rc_[i].ncoo; ph[i + 1] = ph[i] + rc_[i].nheavy;
-        phv[i + 1] = phv[i] + rc_[i].hval; phi[i + 1] = phi[i] + rc_[i].hidx;
-    }
-    const long long NU = pu[ntr], NC = pc[ntr], NH = ph[ntr], NHV = phv[ntr], NHI = phi[ntr];
-    if (tilen > (1 << UNIT_FLAG_SHIFT)) { fprintf(stderr, "tilespmv: more than 2^24 column blocks: use TILESPMV_KERNEL=1\n"); return -2; }
-    if (NU > INT32_MAX || NC > INT32_MAX || NH > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit unit ids\n"); return -2; }
-
-    // ---- strips (<= STRIP_MAX_ROWS whole tile-rows up to the cost target) for the unit kernel, one
-    // heavy task per tile-row that owns heavy tiles, and pieces of very long tile-rows (all three
-    // kinds of pieces write partial[] slots that k_fixup_split adds up in a fixed order).
-    std::vector<STask> tasks;
-    std::vector<Task> htasks;
-    std::vector<FixRow> ifix, fix_late;   // split rows summed inside the unit kernel / by k_fixup_split after all passes
-    const bool fix_inline_on = K.fix_inline != 0;
-    // How the COO entry lists run (TILESPMV_WAVE_COO = 0 / 1 / 2 overrides):
-    //   0  per 16-lane strip — regular matrices (a handful of entries per strip);
-    //   1  per wavefront, the four strips' lists merged and ordered by column — entry-heavy but small grids, where the
-    //      kernel is a chain of round trips and a workgroup barrier costs more than shared x lines save;
-    //   2  per workgroup, the sixteen strips' lists merged and ordered by column — entry-heavy shards that fill the chip:
-    //      distinct x lines per batch drop 3x and the CU's L1 -> L2 request rate is what bounds those.
-    // Strip size.  Regular matrices: ~400 cost units (20 units) amortise the per-strip round trips; flat between 200 and 800
-    // on large matrices.  Entry-heavy shards want MANY tile-rows per workgroup (power-law 8 M rows: 0.149 ms at 400,
-    // 0.120 ms at 1600) but still about 3 workgroups per CU on small matrices (webbase-like: 12.9-13.1 us at ~760
-    // workgroups, 13.6-14.3 at 1000, 15.4 at 570; scircuit-like flat 7.2-7.8 us from 250 to 670 workgroups).
-    const bool entry_heavy = NC >= 5LL * ntr;   // (5 since round 3: an unaligned 7-point grid — 6 one-entry COO tiles per tile-row — runs 5 % faster with the workgroup entry mode; 4 per tile-row, the unaligned 5-point grid, does not)
-    long long total_cost = 0;
-    for (int i = 0; i < ntr; i++) total_cost += rc_[i].cost;
-    // tilespmv_plan_spmm: k_units_mv walks a strip's entries with its 16 lanes, tile-row by tile-row; where entries are most
-    // of the work (webbase-like: nvec 2 took 0.11 ms against 0.013 ms for one SpMV) one SpMV per right-hand side is faster
-    const bool entry_dominated = (long long)K.coo_cost * NC * 2 > total_cost;
-    int target = target_in;
-    if (target <= 0) {
-        target = 400;
-        if (entry_heavy) {
-            // balanced, entry-dominated shards (uniform random: 0.075 ms at 1600, 0.060 ms at 3200; band + random fill 0.126 -> 0.117)
-            // take strips of up to 3200; skewed ones (R-MAT scale 20: 0.054 ms at 1600, 0.076 ms at 3200) and unit-dominated ones
-            // (KKT-like 64^3: 0.022 ms at 967, 0.051 ms at 3200) stop at 1600
-            long long max_cost = 0;
-            for (int i = 0; i < ntr; i++) max_cost = std::max(max_cost, rc_[i].cost);
-            const bool balanced = ntr > 0 && max_cost * ntr <= 4 * total_cost;
-            const long long cap = (entry_dominated && balanced) ? 3200 : 1600;
-            target = (int)std::min<long long>(cap, std::max<long long>(400, total_cost / (3 * 256 * 16)));
-        } else if (total_cost / (16LL * 800) >= 4096 && NC <= 2LL * ntr) {
-            // large regular shards: strips of up to 8 tile-rows once that still leaves >= 4096 workgroups (config 4: 0.1644-0.1665 -> 0.1606-0.1608 ms with the
-            // nontemporal value stream, 5-pt 2896^2 0.0864 -> 0.0854; a 1024^2 grid would lose 17 % — 512 workgroups — and keeps 400) — and only while the
-            // 8 tile-rows bring at most the 16 entries that travel with the unit prologue (4 entries per tile-row, the 4095^2 grid: 0.1875 ms at 800, 0.1770 at 400)
-            target = 800;
-        }
-    }
-    target = std::max(32, target);
-    const long long est_wgs = total_cost / (16LL * target) + 1;
-    const int wave_coo_env = K.entry_mode;
-    const int entry_mode = wave_coo_env >= 0 ? std::min(2, wave_coo_env) : (!entry_heavy ? 0 : est_wgs < 768 ? 1 : 2);
-    const bool wave_coo = entry_mode != 0;
-    plan->entry_mode = entry_mode;
-    // strips per workgroup: 32 (512 threads) only on request and only with the workgroup entry mode — twice as many tile-rows share
-    // one column-ordered list (power-law 8 M rows: 0.204 -> 0.152 distinct 128-B x lines per entry) at the same 6 waves per SIMD, but
-    // it measures slower everywhere (power-law 8 M 0.1038 -> 0.1072 ms, webbase-like 13.1 -> 13.9 us, KKT fp64 equal): default 16
-    const int wg_strips = (entry_mode == 2 && K.wg_strips == 32) ? 32 : 16;
-    plan->wg_strips = wg_strips;
-    // Workgroup mode: the four wavefronts add into shared slabs.  Taking turns (4 barriers per trip) fixes the order of the
-    // additions -> bit-reproducible sums; free or a gain on large grids (fewer LDS conflicts: power-law 8 M rows 0.122 ->
-    // 0.118 ms), +8 % on mid-size ones (webbase-like 14.2 -> 15.3 us), which therefore add unordered unless
-    // TILESPMV_COO_ORDERED=1 asks for reproducible bits.  Modes 0 and 1 are always ordered (one wavefront per slab).
-    const int ordered_env = K.entry_ordered;
-    const bool coo_ordered = ordered_env >= 0 ? ordered_env != 0 : est_wgs >= 2048;
-    // ---- brick order (stencil-like shards): the grid strides of the shard are detected from its tile pattern, strips stay inside
-    // one grid line, and after the cut the strips are regrouped so that the 16 strips of a workgroup — and the neighbouring
-    // workgroups of an XCD window — form a brick of the grid instead of a run of one grid line: the x segments a tile-row shares
-    // with its neighbours in the other two directions are then wanted at about the same time by one CU / one XCD, and hit in L1 /
-    // L2 instead of being fetched again (nlpkkt160 stand-in: 3.07 -> 2.6-2.7 GB per launch at the fabric in fp64, 1.81 -> 1.56 GB in fp32;
-    // time -2.5 ... -6 % in fp32, inside the matrix's 10 % placement spread in fp64: DESIGN.md S6.9).
-    //   x_window  -1 (default): brick order on large 3-D shards   0: off   2: brick order wherever strides are found
-    //              1: brick order + the workgroup's x segments staged once in LDS ("x windows": strips of at most XWIN_STRIP_ROWS
-    //                 tile-rows; cuts another ~0.4 GB but runs 25 % slower — profiles/r03_xwindow_and_map.txt; opt-in only)
-    int xs1 = K.x_stride1 > 0 ? K.x_stride1 : 0, xs2 = K.x_stride2 > 0 ? K.x_stride2 : 0;
-    bool brick = K.x_window != 0 && wg_strips == 16 && (K.x_window > 0 || est_wgs >= 2048);
-    if (brick && xs1 == 0) detect_strides(T, tr0, tr1, csr_split, dense_mfma, &xs1, &xs2);
-    if (xs1 < 2 || (K.x_window < 0 && xs2 == 0)) brick = false;   // (2-D grids: measured neutral on the 5-point 4096^2 case)
-    bool xwin = brick && K.x_window == 1 && entry_mode != 1;   // (the windowed kernel exists for entry modes 0 and 2)
-    // (strips of at most 4 tile-rows in brick plans: nlpkkt160 stand-in fp64 0.418 -> 0.414 ms, fp32 0.252 -> 0.250 in one process; 2 rows: KKT 0.408 but 7-pt 256^3 +5 %)
-    const int max_strip_rows = xwin ? XWIN_STRIP_ROWS : brick ? (K.brick_rows > 0 ? std::min(K.brick_rows, STRIP_MAX_ROWS) : 4) : STRIP_MAX_ROWS;
-    if (brick && !K.xcd_from_caller) plan->xcd_chunk = 8;   // bricks are compact: smaller XCD windows keep an XCD's resident set together
-    std::vector<unsigned char> row_k((size_t)ntr, 0), row_split((size_t)ntr, 0);
-    const int npartial0 = npartial;
-    auto cut = [&](int target) {
-        // rows above this cost are cut into pieces.  With the wavefront / workgroup entry modes a long row is no longer one strip's
-        // private burden, but an unsplit one still makes its workgroup the last to finish: the threshold stops growing with the
-        // strip size there (R-MAT scale 20 at strip size 3200: 0.099 ms with rows of up to 19,200 cost units kept whole)
-        const int split_cap = K.split_cap;
-        const int split_above = wave_coo ? std::max(split_above_in, std::min(6 * target, split_cap)) : std::max(6 * target, split_above_in);
-        const int piece = std::max(wave_coo ? std::min(2 * target, 1600) : 2 * target, split_above / 3);
-        tasks.clear(); htasks.clear(); ifix.clear(); fix_late.clear(); fix.clear(); drows.clear(); npartial = npartial0;
-        std::fill(row_k.begin(), row_k.end(), 0); std::fill(row_split.begin(), row_split.end(), 0);
-        const int strip_even = K.strip_even;  // 0 off, 1 = value group, n > 1 = multiples of n units
-        auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
-        auto is_heavy = [&](int t) {
-            const int fmt = T->Format[t];
-            return fmt == TILESPMV_FMT_CSR && !csr_split;
-        };
-        auto heavy_sizes = [&](int t, int *nv, int *ni) {
-            const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t];
-            (void)fmt; *nv = stored; *ni = 16 + (stored + 1) / 2;
-        };
-        // k_dense_mfma broadcasts the column blocks of one DenseRow piece from a single 64-lane load: a piece holds at most
-        // 64 dense tiles.  Split rows cut their dense tiles into pieces of 32; an unsplit row is one piece, so a row with
-        // more dense tiles than that is always split, whatever the cost knobs say (TILESPMV_STRIP_COST / _SPLIT_ABOVE).
-        constexpr int DENSE_PIECE = 32;
-        auto must_split = [&](int i) { return rc_[i].cost > split_above || rc_[i].ndense > DENSE_PIECE; };
-        for (int i = 0; i < ntr;) {
-            if (must_split(i)) {
-                row_split[i] = 1;
-                FixRow f{tr0 + i, npartial, 0, 0};
-                // entry pieces: four consecutive pieces share a wavefront, which walks their lists together (4 x 192 = 2 trips of 6 x 64)
-                const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, K.coo_piece > 0 ? K.coo_piece : (entry_mode == 1 ? 192 : piece / std::max(1, K.coo_cost)));
-                for (long long u = pu[i]; u < pu[i + 1]; u += pu_) {
-                    STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
-                    k.unit_begin = (int)u; k.unit_end = (int)std::min(pu[i + 1], u + pu_);
-                    tasks.push_back(k); f.count++;
-                }
-                for (long long c = pc[i]; c < pc[i + 1]; c += pc_) {
-                    STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
-                    k.coo_begin = (int)c; k.coo_end = (int)std::min(pc[i + 1], c + pc_);
-                    tasks.push_back(k); f.count++;
-                }
-                const int stream_pieces = f.count;  // pieces executed by the unit kernel
-                long long h = ph[i], hv = phv[i], hi = phi[i];
-                int t = T->tile_ptr[tr0 + i];
-                while (h < ph[i + 1]) {  // heavy tiles of a split row: cut at tile boundaries by payload size
-                    Task k{(int)h, (int)h, hv, hi, tr0 + i, npartial++};
-                    long long c = 0;
-                    while (h < ph[i + 1] && (c == 0 || c < piece)) {
-                        while (!is_heavy(t)) t++;
-                        int nv, ni; heavy_sizes(t, &nv, &ni);
-                        hv += nv; hi += ni; c += nv + 256; h++; t++;
-                    }
-                    k.tile_end = (int)h;
-                    htasks.push_back(k); f.count++;
-                }
-                for (long long dq = pd[i]; dq < pd[i + 1]; dq += DENSE_PIECE) {  // dense tiles of a split row: 32 per piece
-                    drows.push_back(DenseRow{tr0 + i, (int)dq, (int)std::min(pd[i + 1], dq + DENSE_PIECE), npartial++});
-                    f.count++;
-                }
-                // all pieces inside the unit kernel -> the last one to finish adds the slots up there
-                const bool inline_fix = fix_inline_on && f.count == stream_pieces;
-                for (int q = 0; q < stream_pieces; q++) tasks[tasks.size() - 1 - (size_t)q].nounit_mask = inline_fix ? (unsigned)ifix.size() : 0xFFFFFFFFu;
-                if (inline_fix) ifix.push_back(f); else fix_late.push_back(f);
-                fix.push_back(f);
-                i++;
-                continue;
-            }
-            STask k = blank();
-            k.row = tr0 + i;
-            k.unit_begin = (int)pu[i]; k.coo_begin = (int)pc[i];
-            long long c = 0;
-            int j = i;
-            // how many tile-rows: up to the cost target, then nudged by one row either way if that leaves fewer padding
-            // units (the strip's values are stored in groups of UNIT_GROUP units, tail padded with zero units)
-            int jend = i;
-            {
-                long long cc = 0;
-                while (jend < ntr && jend - i < max_strip_rows && !must_split(jend)) {
-                    if (brick && jend > i && (tr0 + jend) % xs1 == 0) break;   // brick order: a strip stays inside one grid line
-                    const long long nc = cc + rc_[jend].cost;
-                    // entry-heavy shards round to the nearest strip size (rows cost 100-400 each there: "never above the target"
-                    // would leave most strips half empty and double the number of wavefronts)
-                    if (jend > i && nc > target && !(wave_coo && nc - target < target - cc && nc <= target + target / 2)) break;
-                    cc = nc; jend++;
-                }
-                // (whole batches of 4 units, which are also whole value groups: a half-empty last batch costs as much as a full one)
-                const int quantum = strip_even > 1 ? strip_even : UNIT_GROUP;
-                auto pad = [&](int e) { return (int)((quantum - (pu[e] - pu[i]) % quantum) % quantum); };
-                if (strip_even && pad(jend) > 0) {
-                    int best = jend;
-                    if (jend < ntr && jend - i < max_strip_rows && !(brick && (tr0 + jend) % xs1 == 0) && !must_split(jend) && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
-                    if (best == jend && jend - i >= 3 && pad(jend - 1) < pad(best)) best = jend - 1;
-                    jend = best;
-                }
-            }
-            while (j < jend) {
-                row_k[j] = (unsigned char)(j - i);
-                if (rc_[j].nunits == 0) k.nounit_mask |= 1u << (j - i);
-                if (rc_[j].nheavy > 0) htasks.push_back(Task{(int)ph[j], (int)ph[j + 1], phv[j], phi[j], tr0 + j, -1});
-                if (rc_[j].ndense > 0) drows.push_back(DenseRow{tr0 + j, (int)pd[j], (int)pd[j + 1], -1});
-                c += rc_[j].cost; j++;
-            }
-            k.nrows = j - i;
-            k.unit_end = (int)pu[j]; k.coo_end = (int)pc[j];
-            tasks.push_back(k);
-            i = j;
-        }
-
-    };
-    cut(target);
-    // ---- fill
-    std::vector<uint4> h_udesc((size_t)NU);
-    val_t *h_uval = zalloc<val_t>((size_t)NU * 16);
-    val_t *h_cval = zalloc<val_t>((size_t)NC);
-    std::vector<int> h_ccol((size_t)NC);
-    std::vector<unsigned char> h_crow((size_t)NC);
-    std::vector<uint2> h_hdesc((size_t)NH);
-    val_t *h_hval = zalloc<val_t>((size_t)NHV);
-    unsigned char *h_hidx = zalloc<unsigned char>((size_t)NHI + 16);
-    std::vector<int> h_dcb((size_t)ND);
-    val_t *h_dval = zalloc<val_t>((size_t)ND * 256);
-    parallel_chunks(ntr, 256, [&](int64_t b, int64_t e, int) {
-        for (int64_t i = b; i < e; i++) {
-            const int bi = tr0 + (int)i, rowlen = tile_rowlen(bi, tilem, rowA);
-            const unsigned kr = row_k[i];
-            long long u = pu[i], c = pc[i], h = ph[i], hv = phv[i], hi = phi[i], dq = pd[i];
-            auto put_unit = [&](int cb, const val_t *src, int stride_ok_rows, unsigned long long nibs) {
-                // src: rowlen consecutive values of this column; nibs: 16 nibbles, row 0 in the top nibble
-                for (int r = 0; r < stride_ok_rows; r++) h_uval[u * 16 + r] = src[r];
-                const unsigned w0 = (unsigned)cb | ((kr << UNIT_ROW_SHIFT) << UNIT_FLAG_SHIFT);
-                h_udesc[(size_t)u] = make_uint4(w0, (unsigned)(nibs >> 32), w0, (unsigned)(nibs & 0xffffffffull));
-                u++;
-            };
-            for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
-                const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
-                const int cb = T->tile_columnidx[t], collen = tile_collen(cb, tilen, colA);
-                switch (fmt) {
-                case TILESPMV_FMT_ELL: {
-                    const int off = T->ell_offset[t];
-                    for (int s = 0; s < w; s++) {
-                        unsigned long long nibs = 0;
-                        for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib(T->ell_compressedIdx, (long long)off + s * rowlen + r) << (60 - 4 * r);
-                        put_unit(cb, T->Blockell_Val + off + s * rowlen, rowlen, nibs);
-                    }
-                    break;
-                }
-                case TILESPMV_FMT_HYB: {
-                    const int off = T->hyb_offset[t], nell = w * rowlen;
-                    const unsigned char *src = T->hybIdx + hyb_off[t];
-                    for (int s = 0; s < w; s++) {
-                        unsigned long long nibs = 0;
-                        for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib(src, s * rowlen + r) << (60 - 4 * r);
-                        put_unit(cb, T->Blockhyb_Val + off + s * rowlen, rowlen, nibs);
-                    }
-                    if (coo_in_tile)
-                        for (int q = 0; q < stored - nell; q++) {
-                            const unsigned char rcb = src[(nell + 1) / 2 + q];
-                            h_cval[c] = T->Blockhyb_Val[off + nell + q]; h_ccol[(size_t)c] = cb * 16 + (rcb & 15);
-                            h_crow[(size_t)c] = (unsigned char)((kr << 4) | (rcb >> 4)); c++;
-                        }
-                    break;
-                }
-                case TILESPMV_FMT_DNSCOL: {
-                    const int off = T->dnscol_offset[t], co = T->dnscolptr[t], k = T->dnscolptr[t + 1] - co;
-                    for (int q = 0; q < k; q++) put_unit(cb, T->Blockdensecol_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)(T->densecolid[co + q] & 15));
-                    break;
-                }
-                case TILESPMV_FMT_COO:
-                    if (coo_in_tile) {
-                        const int off = T->coo_offset[t];
-                        for (int q = 0; q < stored; q++) {
-                            const unsigned char rcb = T->coo_compressed_Idx[off + q];
-                            h_cval[c] = T->Blockcoo_Val[off + q]; h_ccol[(size_t)c] = cb * 16 + (rcb & 15);
-                            h_crow[(size_t)c] = (unsigned char)((kr << 4) | (rcb >> 4)); c++;
-                        }
-                    }
-                    break;
-                case TILESPMV_FMT_DNS:
-                    if (!dense_mfma) {
-                        const int off = T->dns_offset[t];
-                        for (int q = 0; q < collen; q++) put_unit(cb, T->Blockdense_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)q);
-                        break;
-                    }
-                    {   // dense tile for the matrix cores: 256 values, zero padded, in MFMA operand order (dense_slot, hip_plan.h)
-                        const int off = T->dns_offset[t];
-                        val_t *dst = h_dval + dq * 256;
-                        for (int cc = 0; cc < collen; cc++)
-                            for (int r = 0; r < rowlen; r++) dst[dense_slot(r, cc)] = T->Blockdense_Val[off + cc * rowlen + r];
-                        h_dcb[(size_t)dq] = cb;
-                        dq++;
-                    }
-                    break;
-                case TILESPMV_FMT_DNSROW: {
-                    const int off = T->dnsrow_offset[t], ro = T->dnsrowptr[t], k = T->dnsrowptr[t + 1] - ro;
-                    for (int q = 0; q < k; q++) {
-                        for (int cc = 0; cc < collen; cc++) h_uval[u * 16 + cc] = T->Blockdenserow_Val[off + q * collen + cc];
-                        const unsigned w0 = (unsigned)cb | (((kr << UNIT_ROW_SHIFT) | UNIT_ROWUNIT) << UNIT_FLAG_SHIFT);
-                        const unsigned rid = (unsigned)(T->denserowid[ro + q] & 15);
-                        h_udesc[(size_t)u] = make_uint4(w0, rid, w0, rid);
-                        u++;
-                    }
-                    break;
-                }
-                case TILESPMV_FMT_CSR:
-                    if (csr_split) {
-                        const int off = T->csr_offset[t];
-                        const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
-                        int rem;
-                        const int w = csr_split_width(ptr, rowlen, stored, &rem);
-                        const long long u0 = u;
-                        for (int sidx = 0; sidx < w; sidx++) {  // descriptors first (zero nibbles), payload below
-                            const unsigned w0 = (unsigned)cb | ((kr << UNIT_ROW_SHIFT) << UNIT_FLAG_SHIFT);
-                            h_udesc[(size_t)u] = make_uint4(w0, 0u, w0, 0u);
-                            u++;
-                        }
-                        for (int r = 0; r < rowlen; r++) {
-                            const int k0 = ptr[r], k1 = (r == rowlen - 1) ? stored : ptr[r + 1];
-                            for (int kk = k0; kk < k1; kk++) {
-                                const int lc = nib(T->csr_compressedIdx, (long long)off + kk), sidx = kk - k0;
-                                if (sidx < w) {
-                                    h_uval[(u0 + sidx) * 16 + r] = T->Blockcsr_Val[off + kk];
-                                    if (r < 8) h_udesc[(size_t)(u0 + sidx)].y |= (unsigned)lc << (28 - 4 * r);
-                                    else h_udesc[(size_t)(u0 + sidx)].w |= (unsigned)lc << (28 - 4 * (r - 8));
-                                } else {
-                                    h_cval[c] = T->Blockcsr_Val[off + kk]; h_ccol[(size_t)c] = cb * 16 + lc;
-                                    h_crow[(size_t)c] = (unsigned char)((kr << 4) | r); c++;
-                                }
-                            }
-                        }
-                        break;
-                    }
-                    // fallthrough: CSR tile as a heavy (whole) tile
-                {
-                    Emit em = emit_of(T, t, rowlen, true);
-                    repack_tile(T, t, em, rowlen, collen, 0, h_hval + hv, h_hidx + hi);
-                    h_hdesc[(size_t)h] = make_uint2((unsigned)cb, (unsigned)em.fmt | ((unsigned)em.p1 << DESC_P1_SHIFT));
-                    h++; hv += em.nv; hi += em.ni;
-                    break;
-                }
-                }
-            }
-            if (!row_split[i] && u > pu[i]) { h_udesc[(size_t)u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; h_udesc[(size_t)u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
-            if (h > ph[i]) h_hdesc[(size_t)h - 1].y |= DESC_EOR;
-        }
-    });
-
-    int rc = 0;
-    DevStream &S = plan->st;
-    // ---- x windows: brick order of the strips, then one window of column blocks per workgroup
-    std::vector<uint4> h_udesc_cb;   // the descriptors with column blocks (multi-vector kernel), when windows put slots into h_udesc
-    std::vector<int2> h_wg_win;
-    std::vector<int> h_win_cb;
-    int xwin_slots_max = 0;
-    long long xwin_segments = 0, xwin_wgs = 0;
-    if (brick && !tasks.empty()) {
-        const size_t nt = tasks.size();
-        // grid coordinates of every strip: position in its line (ordinal of the strip), line in its plane, plane
-        std::vector<int> sx(nt), ly(nt), lz(nt);
-        {
-            long long prev_line = -1; int ord = 0;
-            for (size_t i = 0; i < nt; i++) {
-                const long long line = tasks[i].row / xs1;
-                ord = line == prev_line ? ord + 1 : 0;
-                prev_line = line;
-                sx[i] = ord;
-                ly[i] = xs2 ? (int)(line % (xs2 / xs1)) : (int)line;
-                lz[i] = xs2 ? tasks[i].row / xs2 : 0;
-            }
-        }
-        auto blocks_of = [&](const STask &k, std::vector<int> &out) {
-            for (int u = k.unit_begin; u < k.unit_end; u++) out.push_back((int)(h_udesc[(size_t)u].x & 0xFFFFFFu));
-        };
-        struct Shape { int px, py, pz; };
-        const Shape shapes3[] = {{1, 4, 4}, {2, 2, 4}, {2, 4, 2}, {4, 2, 2}, {1, 2, 8}, {1, 8, 2}, {4, 4, 1}, {2, 8, 1}, {1, 16, 1}, {16, 1, 1}};
-        const Shape shapes2[] = {{4, 4, 1}, {2, 8, 1}, {8, 2, 1}, {1, 16, 1}, {16, 1, 1}};
-        const Shape *shapes = xs2 ? shapes3 : shapes2;
-        const int nshapes = xs2 ? 10 : 5;
-        std::vector<unsigned> order(nt), best_order;
-        double best_avg = 1e30;
-        Shape best_shape{16, 1, 1};
-        auto sort_for = [&](const Shape &sh) {
-            for (size_t i = 0; i < nt; i++) order[i] = (unsigned)i;
-            std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) {
-                const int ka[6] = {lz[a] / sh.pz, ly[a] / sh.py, sx[a] / sh.px, lz[a] % sh.pz, ly[a] % sh.py, sx[a] % sh.px};
-                const int kb[6] = {lz[b] / sh.pz, ly[b] / sh.py, sx[b] / sh.px, lz[b] % sh.pz, ly[b] % sh.py, sx[b] % sh.px};
-                for (int q = 0; q < 6; q++) if (ka[q] != kb[q]) return ka[q] < kb[q];
-                return a < b;
-            });
-        };
-        const size_t nwg = (nt + 15) / 16;
-        std::vector<int> tmp;
-        for (int si = 0; si < nshapes; si++) {   // the brick shape that needs the fewest window slots on a sample of workgroups
-            sort_for(shapes[si]);
-            long long slots = 0, wgs = 0;
-            for (size_t w = nwg / 128; w < nwg; w += std::max<size_t>(1, nwg / 64)) {
-                tmp.clear();
-                for (size_t t = 16 * w; t < std::min(nt, 16 * w + 16); t++) blocks_of(tasks[order[t]], tmp);
-                std::sort(tmp.begin(), tmp.end());
-                slots += (long long)(std::unique(tmp.begin(), tmp.end()) - tmp.begin()); wgs++;
-            }
-            const double avg = wgs ? (double)slots / (double)wgs : 1e30;
-            if (avg < best_avg * 0.98) { best_avg = avg; best_order = order; best_shape = shapes[si]; }
-        }
-        {
-            std::vector<STask> permuted(nt);
-            for (size_t i = 0; i < nt; i++) permuted[i] = tasks[best_order[i]];
-            tasks.swap(permuted);
-        }
-        h_udesc_cb = h_udesc;
-        h_wg_win.assign(nwg, make_int2(0, 0));
-        std::vector<std::vector<int>> wg_blocks(nwg);
-        const bool order_only = !xwin;   // brick order alone: x is still gathered from global memory (through L1 / L2)
-        parallel_chunks(order_only ? 0 : (int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
-            for (int64_t w = b; w < e; w++) {
-                std::vector<int> &bl = wg_blocks[(size_t)w];
-                for (size_t t = 16 * (size_t)w; t < std::min(nt, 16 * (size_t)w + 16); t++) blocks_of(tasks[t], bl);
-                std::sort(bl.begin(), bl.end());
-                bl.erase(std::unique(bl.begin(), bl.end()), bl.end());
-                if (bl.size() > (size_t)XWIN_MAX_SLOTS) { bl.clear(); continue; }   // this workgroup reads x from global memory
-                for (size_t t = 16 * (size_t)w; t < std::min(nt, 16 * (size_t)w + 16); t++)
-                    for (int u = tasks[t].unit_begin; u < tasks[t].unit_end; u++) {
-                        uint4 &d = h_udesc[(size_t)u];
-                        const unsigned slot = (unsigned)(std::lower_bound(bl.begin(), bl.end(), (int)(d.x & 0xFFFFFFu)) - bl.begin());
-                        d.x = (d.x & 0xFF000000u) | slot; d.z = d.x;
-                    }
-            }
-        });
-        for (size_t w = 0; w < nwg; w++) {
-            h_wg_win[w] = make_int2((int)h_win_cb.size(), (int)wg_blocks[w].size());
-            h_win_cb.insert(h_win_cb.end(), wg_blocks[w].begin(), wg_blocks[w].end());
-            xwin_slots_max = std::max(xwin_slots_max, (int)wg_blocks[w].size());
-            xwin_segments += (long long)wg_blocks[w].size(); xwin_wgs += !wg_blocks[w].empty();
-        }
-        if (xwin_slots_max == 0) { xwin = false; h_udesc_cb.clear(); }
-        if (getenv("TILESPMV_PLAN_VERBOSE"))
-            fprintf(stderr, "tilespmv: brick order: strides %d / %d tile-rows, brick %d x %d x %d strips, %.1f distinct column blocks per workgroup on the sample; x windows: %lld of %zu workgroups, %d slots at most\n",
-                    xs1, xs2, best_shape.px, best_shape.py, best_shape.pz, best_avg, xwin_wgs, nwg, xwin_slots_max);
-    } else { xwin = false; brick = false; }
-    plan->info[TILESPMV_INFO_BRICK_ORDER] = brick ? 1 : 0;
-    plan->xwin_lds_bytes = xwin ? xwin_slots_max * 16 * (int)sizeof(val_t) : 0;
-    plan->size_hint = (size_t)(NU * (12 + 16LL * sv) + NC * (2LL * sv + 13) + NHV * sv + NHI + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);   // estimate of the plan's bytes: picks the block size of upload()
-    // ---- final HBM form of the unit streams.  Descriptors: 12 B (the duplicate of word 0 is dropped).  Values: the
-    // units of one task are stored in GROUPS of G = 16 / sizeof(value) units (2 in fp64, 4 in fp32) — the values of
-    // the G units interleaved per row, so that a lane fetches G units with one 16-byte load (row r of the group at
-    // +16 r bytes).  A task whose unit count is not a multiple of G gets padding units (zero values, never executed:
-    // unit_end excludes them) so that its last group exists.
-    constexpr long long G = UNIT_GROUP;
-    auto padded = [&](long long n) { return (n + G - 1) / G * G; };
-    long long NUP = 0;
-    for (const STask &k : tasks) NUP += padded(k.unit_end - k.unit_begin);
-    if (NUP > INT32_MAX) {
-        fprintf(stderr, "tilespmv: shard too large for 32-bit unit ids\n");
-        free(h_uval); free(h_cval); free(h_hval); free(h_hidx); free(h_dval);
-        return -2;
-    }
-    {
-        std::vector<UDesc> packed((size_t)NUP, UDesc{0u, 0u, 0u});
-        val_t *paired = zalloc<val_t>((size_t)NUP * 16);
-        std::vector<long long> new_begin(tasks.size()), old_begin(tasks.size());
-        for (size_t i = 0; i < tasks.size(); i++) old_begin[i] = tasks[i].unit_begin;
-        long long at = 0;
-        for (size_t i = 0; i < tasks.size(); i++) { new_begin[i] = at; at += padded(tasks[i].unit_end - tasks[i].unit_begin); }
-        parallel_chunks((int64_t)tasks.size(), 512, [&](int64_t b, int64_t e, int) {
-            for (int64_t i = b; i < e; i++) {
-                STask &k = tasks[(size_t)i];
-                const long long ub = k.unit_begin, n = k.unit_end - ub, nb = new_begin[(size_t)i];
-                for (long long j = 0; j < n; j++) {
-                    const uint4 d = h_udesc[(size_t)(ub + j)];
-                    packed[(size_t)(nb + j)] = UDesc{d.x, d.y, d.w};
-                    const val_t *src = h_uval + (ub + j) * 16;
-                    val_t *dst = paired + (nb + j / G * G) * 16 + (j % G);
-                    for (int r = 0; r < 16; r++) dst[G * r] = src[r];
-                }
-                if (n > 0) { k.unit_begin = (int)nb; k.unit_end = (int)(nb + n); }
-            }
-        });
-        // ---- 4-B descriptors where the units of the shard use few distinct column patterns (stencil-like shards: 4 patterns in the
-        // 5- and 7-point grids, 36 in the KKT stand-in): column block | pattern id << cb_bits | flags << 27, the patterns (the
-        // two nibble words) in a dictionary the kernels gather from.  Not for x-window plans (their descriptors hold slots).
-        S.udict = nullptr; S.cb_bits = 0;
-        std::vector<uint2> dict;
-        std::vector<unsigned> compact;
-        // ... and only where it pays: 8 bytes per unit must be at least 2 % of the streams (an entry-dominated plan with a handful of units would only buy the dictionary
-        // hop at the start of every strip: webbase-1M stand-in 13.2 -> 13.6 us); desc_dict = 1 asks for it wherever it is possible
-        const bool dict_pays = K.desc_dict > 0 ? true : 8LL * NUP * 50 >= NUP * (12 + 16LL * sv) + NC * (sv + 4LL);
-        if (K.desc_dict != 0 && dict_pays && !xwin && NUP > 0) {
-            const int cb_bits = std::max(1, 32 - __builtin_clz((unsigned)std::max(1, T->tilen - 1)));
-            const int pid_bits = std::min(DICT_MAX_BITS, 27 - cb_bits);
-            if (pid_bits >= 1) {
-                const size_t cap = (size_t)1 << pid_bits;
-                std::vector<std::unordered_set<unsigned long long>> local((size_t)host_threads());
-                std::atomic<int> over(0);
-                parallel_chunks((int64_t)NUP, 1 << 16, [&](int64_t b, int64_t e, int th) {
-                    if (over.load(std::memory_order_relaxed)) return;
-                    std::unordered_set<unsigned long long> &L = local[(size_t)th];
-                    for (int64_t u = b; u < e; u++) {
-                        L.insert(((unsigned long long)packed[(size_t)u].n0 << 32) | packed[(size_t)u].n1);
-                        if (L.size() > cap) { over.store(1); return; }
-                    }
-                });
-                std::vector<unsigned long long> all;
-                if (!over.load()) {
-                    for (auto &L : local) all.insert(all.end(), L.begin(), L.end());
-                    std::sort(all.begin(), all.end());
-                    all.erase(std::unique(all.begin(), all.end()), all.end());
-                }
-                if (!over.load() && all.size() <= cap) {
-                    dict.resize(all.size());
-                    for (size_t i = 0; i < all.size(); i++) dict[i] = make_uint2((unsigned)(all[i] >> 32), (unsigned)(all[i] & 0xffffffffull));
-                    compact.resize((size_t)NUP);
-                    const unsigned cbmask = (1u << cb_bits) - 1u;
-                    parallel_chunks((int64_t)NUP, 1 << 16, [&](int64_t b, int64_t e, int) {
-                        for (int64_t u = b; u < e; u++) {
-                            const UDesc &d = packed[(size_t)u];
-                            const unsigned long long key = ((unsigned long long)d.n0 << 32) | d.n1;
-                            const unsigned pid = (unsigned)(std::lower_bound(all.begin(), all.end(), key) - all.begin());
-                            compact[(size_t)u] = (d.w0 & cbmask) | (pid << cb_bits) | ((d.w0 >> UNIT_FLAG_SHIFT) << 27);
-                        }
-                    });
-                    S.cb_bits = cb_bits;
-                }
-            }
-        }
-        if (S.cb_bits > 0) {
-            rc |= plan->upload(compact.data(), compact.size(), reinterpret_cast<const unsigned **>(&S.udesc));
-            rc |= plan->upload(dict.data(), dict.size(), &S.udict);
-        } else rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc);
-        plan->info[TILESPMV_INFO_DESC_BYTES] = S.cb_bits > 0 ? 4 : 12;
-        rc |= plan->upload(paired, (size_t)NUP * 16, &S.uval);
-        free(paired);
-        S.udesc_cb = S.udesc;
-        if (xwin) {   // the multi-vector kernel keeps reading x from global memory: its descriptors carry column blocks
-            std::fill(packed.begin(), packed.end(), UDesc{0u, 0u, 0u});
-            parallel_chunks((int64_t)tasks.size(), 512, [&](int64_t b, int64_t e, int) {
-                for (int64_t i = b; i < e; i++) {
-                    const STask &k = tasks[(size_t)i];   // (unit_begin already points into the packed numbering)
-                    for (long long j = 0; j < k.unit_end - k.unit_begin; j++) {
-                        const uint4 d = h_udesc_cb[(size_t)(old_begin[(size_t)i] + j)];
-                        packed[(size_t)(k.unit_begin + j)] = UDesc{d.x, d.y, d.w};
-                    }
-                }
-            });
-            rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc_cb);
-            rc |= plan->upload(h_wg_win.data(), h_wg_win.size(), &S.wg_win);
-            rc |= plan->upload(h_win_cb.data(), h_win_cb.size(), &S.win_cb);
-        } else { S.wg_win = nullptr; S.win_cb = nullptr; }
-    }
-    S.wg_coo = nullptr; S.grec = nullptr; S.gbase = nullptr; S.dest_bits = 11;
-    long long n_rec = 0, n_chunk = 0, n_groups = 0;
-    if (entry_mode != 0) {
-        const size_t GS = entry_mode == 2 ? (size_t)wg_strips : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
-        const int slab_shift = xwin ? 6 : 7;   // a strip's slab of s_y: XWIN_STRIP_ROWS x 16 values in x-window plans, STRIP_MAX_ROWS x 16 otherwise
-        const int dest_bits = entry_mode == 2 ? (wg_strips == 32 ? 12 : 4 + slab_shift) : 9;   // strip-in-group | row-in-strip | row (4)
-        S.dest_bits = dest_bits;
-        const size_t nwg = (tasks.size() + GS - 1) / GS;
-        std::vector<std::vector<ERec>> grp_rec(nwg);
-        std::vector<std::vector<unsigned>> grp_base(nwg);
-        std::atomic<int> bad(0);
-        parallel_chunks((int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
-            std::vector<std::pair<unsigned long long, unsigned>> key;   // (column << 32 | position in strip / list order, destination)
-            std::vector<int> src;
-            std::vector<PEnt> ents;
-            for (int64_t w = b; w < e; w++) {
-                key.clear(); src.clear();
-                for (size_t t = GS * (size_t)w; t < std::min(tasks.size(), GS * (size_t)w + GS); t++)
-                    for (int q = tasks[t].coo_begin; q < tasks[t].coo_end; q++) {   // column-major order; ties keep strip / list order
-                        key.push_back({((unsigned long long)(unsigned)h_ccol[(size_t)q] << 32) | (unsigned long long)key.size(),
-                                       (unsigned)((t & (GS - 1)) << slab_shift) | (unsigned)h_crow[(size_t)q]});
-                        src.push_back(q);
-                    }
-                std::sort(key.begin(), key.end());
-                ents.resize(key.size());
-                for (size_t i = 0; i < key.size(); i++) {
-                    const int q = src[(size_t)(key[i].first & 0xFFFFFFFFull)];
-                    ents[i] = PEnt{(unsigned)h_ccol[(size_t)q], key[i].second, h_cval[q]};
-                }
-                if (!pack_list(ents, dest_bits, grp_rec[(size_t)w], grp_base[(size_t)w], plan->dry)) bad++;
-            }
-        });
-        if (bad.load()) { fprintf(stderr, "tilespmv: internal error: %d packed entry lists do not decode to their entries\n", bad.load()); rc = -6; }
-        std::vector<int4> wg((size_t)nwg);
-        for (size_t w = 0; w < nwg; w++) {
-            wg[w] = make_int4((int)n_rec, (int)(n_rec + (long long)grp_rec[w].size()), (int)n_chunk, 0);
-            n_rec += (long long)grp_rec[w].size(); n_chunk += (long long)grp_base[w].size();
-        }
-        if (n_rec > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit entry ids\n"); rc = -2; n_rec = 0; }
-        std::vector<ERec> g_rec((size_t)n_rec);
-        std::vector<unsigned> g_base((size_t)n_chunk);
-        if (rc == 0)
-            parallel_chunks((int64_t)nwg, 256, [&](int64_t b, int64_t e, int) {
-                for (int64_t w = b; w < e; w++) {
-                    if (!grp_rec[(size_t)w].empty()) memcpy(&g_rec[(size_t)wg[(size_t)w].x], grp_rec[(size_t)w].data(), grp_rec[(size_t)w].size() * sizeof(ERec));
-                    if (!grp_base[(size_t)w].empty()) memcpy(&g_base[(size_t)wg[(size_t)w].z], grp_base[(size_t)w].data(), grp_base[(size_t)w].size() * sizeof(unsigned));
-                }
-            });
-        n_groups = (long long)nwg;
-        rc |= plan->upload(wg.data(), wg.size(), &S.wg_coo);
-        rc |= plan->upload(g_rec.data(), g_rec.size(), &S.grec);
-        rc |= plan->upload(g_base.data(), g_base.size(), &S.gbase);
-    }
-    rc |= plan->upload(h_cval, (size_t)NC, &S.cval);
-    rc |= plan->upload(h_ccol.data(), (size_t)NC, &S.ccol);
-    rc |= plan->upload(h_crow.data(), (size_t)NC, &S.crow);
-    DevPlan &D = plan->dev;  // heavy tiles reuse the first-generation streams + kernel (accumulate mode)
-    rc |= plan->upload(h_hdesc.data(), (size_t)NH, &D.desc);
-    rc |= plan->upload(h_hval, (size_t)NHV, &D.val);
-    rc |= plan->upload(h_hidx, (size_t)NHI, &D.idx);
-    rc |= plan->upload(htasks.data(), htasks.size(), &D.task);
-    D.ntasks = (int)htasks.size();
-    rc |= plan->upload(tasks.data(), tasks.size(), &S.task);
-    rc |= plan->upload(h_dcb.data(), (size_t)ND, &plan->dn.cb);
-    rc |= plan->upload(h_dval, (size_t)ND * 256, &plan->dn.val);
-    rc |= plan->upload(drows.data(), drows.size(), &plan->dn.rows);
-    plan->dn.nrows = (int)drows.size();
-    for (const DenseRow &dr : drows)
-        if (dr.tile_end - dr.tile_begin > 64) { fprintf(stderr, "tilespmv: internal error: dense piece of %d tiles\n", dr.tile_end - dr.tile_begin); rc = -6; }
-    free(h_uval); free(h_cval); free(h_hval); free(h_hidx); free(h_dval);
-    S.ntasks = (int)tasks.size();
-#ifdef TILESPMV_STAMPS
-    { void *sp = nullptr; const size_t nst = ((tasks.size() + 15) / 16) * 4 * 8;
-      if (hipMalloc(&sp, nst * 8 + 64) == hipSuccess) { (void)hipMemset(sp, 0, nst * 8 + 64); plan->allocs.push_back(sp); } S.stamps = (unsigned long long *)sp; }
-#endif
-    S.ifix = nullptr; S.ifix_count = nullptr;
-    if (!ifix.empty()) {
-        rc |= plan->upload(ifix.data(), ifix.size(), &S.ifix);
-        std::vector<unsigned> zeros(ifix.size(), 0u);
-        const unsigned *cnt = nullptr;
-        rc |= plan->upload(zeros.data(), zeros.size(), &cnt);
-        S.ifix_count = const_cast<unsigned *>(cnt);
-    }
-    rc |= plan->upload(fix_late.data(), fix_late.size(), &plan->dev.fix_late);
-    plan->dev.nfix_late = (int)fix_late.size();
-    // entry mode 0 only: strips with more entries than this run their list before the unit pipeline (32: swept on KKT fp64 / scircuit /
-    // webbase stand-ins in round 1, best or within 1 %)
-    S.coo_heavy_min = K.coo_heavy_min;
-    S.coo_ordered = coo_ordered ? 1 : 0;
-    // y stores: streaming (nontemporal) where y is a real share of what the launch moves — they keep y from displacing x in L2: config 4 0.1946 -> 0.1845 ms,
-    // 7-pt 256^3 0.2533 -> 0.2432, power-law 8 M 0.1078 -> 0.1043 — plain where it is a few per cent: there the streaming form buys nothing and makes the time
-    // depend on where the CALLER's y happens to sit (nlpkkt160 stand-in fp64: 0.413 or 0.459 ms by the copy of y; plain: 0.408-0.411 with every copy)
-    {
-        const long long stream_b = NU * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + NC * (sv + 4LL), y_b = 16LL * ntr * sv;
-        S.y_streaming = K.y_store >= 0 ? (K.y_store != 0) : (y_b * 20 >= stream_b);   // >= 5 %
-    }
-    plan->info[TILESPMV_INFO_ENTRY_MODE] = entry_mode;
-    plan->info[TILESPMV_INFO_ENTRY_ORDERED] = (entry_mode != 2 || coo_ordered) ? 1 : 0;
-    plan->info[TILESPMV_INFO_STRIP_COST] = target;
-    plan->info[TILESPMV_INFO_WG_STRIPS] = wg_strips;
-    plan->info[TILESPMV_INFO_X_WINDOW_SLOTS] = xwin ? xwin_slots_max : 0;
-    plan->info[TILESPMV_INFO_X_WINDOW_SEGMENTS] = xwin ? xwin_segments : 0;
-    {   // entry slab of the multi-vector kernel: shards with >= 3 entries per tile-row (strips then regularly hold more than the 16 entries that travel with the prologue)
-        int used = 1;
-        for (const STask &k : tasks) used = std::max(used, k.nrows);
-        const int slab_env = env_int("TILESPMV_MV_SLAB", -1);   // (experiment knob: 0 off, 1 on wherever entries exist)
-        plan->mv_slab_rows = (slab_env == 0 || NC == 0) ? 0 : (slab_env > 0 || NC >= 3LL * ntr) ? used : 0;
-    }
-    plan->mv_by_columns = entry_dominated && target >= 800;   // (small strips hold few entries each: scircuit-like 18 / 22 / 32 us native against 22 / 41 / 78 us)
-    n_tasks = (long long)tasks.size();
-    model_bytes = NUP * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
-                  (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
-                  ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
-    // The once-read streams (values, entry records) are loaded nontemporally when the launch moves clearly more than the Infinity Cache holds: they then do
-    // not displace x in the L2s / the Infinity Cache — config 4 0.182 -> 0.164-0.166 ms, 7-pt 256^3 0.231 -> 0.211, KKT fp32 0.253 -> 0.236-0.243, power-law
-    // 8 M 0.103 -> 0.095 — while a plan that (nearly) fits keeps the default policy, because its streams come back from the Infinity Cache on the next SpMV:
-    // nontemporal loses 2 % at 340 MB (5-pt 2400^2), 15 % at 180-300 MB (power-law 3-5 M rows), 6-8 % on webbase-1M; it wins from 500 MB up (5-pt 2896^2 +4 %,
-    // power-law 8 M +8 %, 5-pt 3400^2 +10 %).  Descriptors, tasks and per-strip entry lists stay on the default policy (nontemporal: config 4 0.164 -> 0.170-0.173).
-    // profiles/r03_nontemporal_streams.txt.  Entry mode 1 = small grids; x-window plans are an opt-in experiment.
-    {
-        const long long launch_b = model_bytes + ((long long)colA + 16LL * ntr) * sv;
-        S.nt_stream = (entry_mode != 1 && !xwin && (K.nt_stream >= 0 ? K.nt_stream != 0 : launch_b > NT_STREAM_MIN_BYTES)) ? 1 : 0;
-    }
-    plan->info[TILESPMV_INFO_NT_STREAM] = S.nt_stream;
-    return rc;
-}
 
 extern "C" {
 
@@ -1606,6 +568,20 @@ int tilespmv_plan_layout_digest(const Tile_matrix *T, int rowA, int colA, MAT_PT
     const int rc = plan_create_one(&p, T, rowA, colA, nnzA, K);
     if (rc != 0 || !p) return rc ? rc : -4;
     if (digest) *digest = p->digest;
+    if (info) memcpy(info, p->info, sizeof(p->info));
+    tilespmv_plan_destroy(p);
+    return 0;
+}
+
+int tilespmv_plan_layout_stages(const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const tilespmv_plan_options *opts,
+                                unsigned long long *stage_digests, long long *info)
+{
+    Knobs K = resolve_knobs(opts);
+    K.dry = true; K.autotune = 0;
+    tilespmv_plan *p = nullptr;
+    const int rc = plan_create_one(&p, T, rowA, colA, nnzA, K);
+    if (rc != 0 || !p) return rc ? rc : -4;
+    if (stage_digests) memcpy(stage_digests, p->stage_digest, sizeof(p->stage_digest));
     if (info) memcpy(info, p->info, sizeof(p->info));
     tilespmv_plan_destroy(p);
     return 0;

@@ -1,0 +1,284 @@
+// hip_plan_internal.h — what the plan's translation units share: the resolved knobs, the plan object with its device arena, and the
+// per-tile repacking helpers.  hip_plan.hip holds the C ABI, the first-generation layout, the fallback lists and the measured
+// selection; hip_plan_stream.hip holds the second-generation ("unit stream") layout builder, in stages.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <sys/time.h>
+
+#include <climits>
+#include <cmath>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "hip_plan.h"
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            fprintf(stderr, "tilespmv: HIP error %d (%s) at %s:%d: %s\n", (int)e_, hipGetErrorString(e_), \
+                    __FILE__, __LINE__, #expr);                                                         \
+            return (int)e_;                                                                             \
+        }                                                                                               \
+    } while (0)
+
+namespace tilespmv {
+
+inline double now_us()
+{
+    timeval t;
+    gettimeofday(&t, NULL);
+    return t.tv_sec * 1e6 + t.tv_usec;
+}
+
+inline int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+// Every tuning knob of one plan build, resolved ONCE at the API boundary (tilespmv_plan_create): option field if set, else the
+// environment variable (getenv only — the library never writes the environment), else the built-in default.  The builder and
+// the autotuner pass this struct around; nothing below the boundary reads the environment.
+struct Knobs {
+    int coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, autotune;
+    int entry_mode;      // -1 = chosen from the shard
+    int entry_ordered;   // -1 = chosen from the grid size
+    int strip_cost;      // <= 0 = chosen from the shard
+    int split_above, split_cap, xcd_remap, xcd_chunk, csr_split, fix_inline, coo_cost, coo_heavy_min;
+    int coo_piece;       // <= 0 = derived from the piece size
+    int strip_even;
+    int wg_strips;       // -1 = chosen from the shard
+    int x_window;        // -1 = default
+    int x_stride1, x_stride2;   // tile-rows per grid line / plane for the x windows; 0 = detected from the shard
+    int lds_pad;         // bytes of unused LDS added to every unit-kernel workgroup (fewer resident workgroups per CU); -1 = chosen from the shard
+    int brick_rows;      // brick order: tile-rows per strip at most (experiment knob, environment only)
+    int y_store;         // -1 by rule, 0 plain y stores, 1 streaming (nontemporal) y stores
+    int mv_native;       // -1 = by nvec
+    int mv_xcd_chunk;    // -1 = the plan's XCD chunk
+    int nt_stream;       // -1 by size, 0 plain, 1 nontemporal loads of the value / entry-record streams
+    int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows
+    bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
+    bool dry;            // tilespmv_plan_layout_digest: build the layout on the host only, hash instead of upload
+    const char *autotune_log;
+};
+
+}  // namespace tilespmv
+
+using namespace tilespmv;
+
+struct tilespmv_plan {
+    DevPlan dev{};
+    DevStream st{};
+    DevDense dn{};
+    int xcd_remap = 2, xcd_chunk = 32;  // windows of 8 x 32 workgroups: neighbouring strips share an XCD L2 (sweep 4..64: flat within 2.5 %, 32 best on 3 of 4 large matrices)
+    val_t *mv_x = nullptr, *mv_y = nullptr;  // plans without a native multi-vector kernel: X / Y as mv_nvec contiguous vectors (allocated at the first such call)
+    int mv_nvec = 0;
+    bool mv_by_columns = false;              // ... and plans whose work is mostly COO entries (the multi-vector kernel walks them per 16-lane strip)
+    int mv_native = -1, mv_xcd_chunk = -1;   // knobs of tilespmv_plan_spmm (Knobs)
+    int mv_slab_rows = 0;                    // > 0: the multi-vector kernel scatters a strip's entries up front into an LDS slab of this many tile-rows per lane group
+    int entry_mode = 0;                 // COO entry lists walked per 16-lane strip (0), per wavefront (1) or per workgroup, column-ordered (2)
+    std::vector<void *> allocs;
+    long long info[TILESPMV_INFO_COUNT] = {0};
+    int coo_mode = 0, dense_mode = 0, kernel = 0;
+    int device = 0;
+    int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
+    int lds_pad_bytes = 0;              // extra (unused) dynamic LDS per workgroup of the unit kernel: caps the workgroups resident on a CU (knob lds_pad)
+    int xwin_lds_bytes = 0;             // x-window plans: dynamic LDS of the unit kernel (largest window of the plan); 0 = no windows
+    int arena_flags = 0; size_t arena_skew = 0;
+    char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20, arena_next = (size_t)1 << 20, size_hint = 0;   // bump allocator of upload(); size_hint = the builder's estimate of the plan's bytes
+    bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
+    unsigned long long digest = 1469598103934665603ull;
+    unsigned long long stage_digest[TILESPMV_STAGE_COUNT] = {0};   // layout-digest builds: one hash per stage of the unit-stream builder (hip_plan_stream.hip)
+    template <class T>
+    int upload(const T *host, size_t n, const T **out)
+    {
+        if (dry) {   // FNV-1a-64 over (element count, bytes) of every stream, in upload order
+            auto mix = [&](const unsigned char *p, size_t len) { for (size_t i = 0; i < len; i++) { digest ^= p[i]; digest *= 1099511628211ull; } };
+            const unsigned long long cnt = n;
+            mix((const unsigned char *)&cnt, 8);
+            mix((const unsigned char *)host, n * sizeof(T));
+            info[TILESPMV_INFO_DEVICE_BYTES] += (long long)(n * sizeof(T));
+            *out = nullptr;
+            return 0;
+        }
+        const double t0 = now_us();
+        void *d = nullptr;
+        // Streams are carved out of a few large device blocks (bump allocation, 256-byte aligned + 256 bytes of slack so that
+        // masked tail lanes never fault) instead of one hipMalloc each: a plan is ~20 streams, and large blocks get large
+        // page-table fragments whatever state the allocator is in (fewer hipMalloc calls, too).
+        const size_t need = (std::max<size_t>(n, 1) * sizeof(T) + 256 + 255) / 256 * 256 + arena_skew;   // (arena_skew: experiment knob, bytes left unused behind every stream)
+        if (need > arena_left) {   // blocks of arena_block bytes (256 MB) for plans of that size and more; a smaller plan gets one block of about its own size (size_hint)
+            const size_t want = size_hint >= arena_block ? arena_block : std::max<size_t>(arena_next, size_hint + size_hint / 4 + ((size_t)1 << 20));
+            const size_t blk = std::max<size_t>(need, std::min(want, arena_block));
+            arena_next = std::min<size_t>(arena_next * 4, std::max<size_t>(arena_block, 1));
+            void *b = nullptr;
+            if (arena_flags) HIP_TRY(hipExtMallocWithFlags(&b, blk, (unsigned)arena_flags));   // experiment knob TILESPMV_ARENA_FLAGS (4 = physically contiguous)
+            else HIP_TRY(hipMalloc(&b, blk));
+            allocs.push_back(b);
+            arena_at = (char *)b; arena_left = blk;
+        }
+        d = arena_at; arena_at += need; arena_left -= need;
+        if (n) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+        info[TILESPMV_INFO_DEVICE_BYTES] += (long long)(n * sizeof(T));
+        info[TILESPMV_INFO_UPLOAD_US] += (long long)(now_us() - t0);
+        *out = (const T *)d;
+        return 0;
+    }
+};
+
+namespace tilespmv {
+
+inline int nib(const unsigned char *s, long long p) { return (p & 1) ? (s[p >> 1] & 15) : (s[p >> 1] >> 4); }
+inline void put_nib(unsigned char *s, int p, int v) { if (p & 1) s[p >> 1] |= (unsigned char)v; else s[p >> 1] |= (unsigned char)(v << 4); }
+
+// What one source tile becomes in the streams.
+struct Emit { int fmt, p1, p2, nv, ni; };
+
+inline Emit emit_of(const Tile_matrix *T, int t, int rowlen, bool coo_in_tile)
+{
+    Emit e{DESC_FMT_NOP, 0, 0, 0, 0};
+    const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
+    switch (fmt) {
+    case TILESPMV_FMT_CSR: e.fmt = fmt; e.p1 = stored; break;
+    case TILESPMV_FMT_COO: if (!coo_in_tile) return e; e.fmt = fmt; e.p1 = stored; break;
+    case TILESPMV_FMT_ELL: e.fmt = fmt; e.p1 = w; break;
+    case TILESPMV_FMT_HYB: e.fmt = fmt; e.p1 = w; e.p2 = coo_in_tile ? stored - w * rowlen : 0; break;
+    case TILESPMV_FMT_DNS: e.fmt = fmt; break;
+    case TILESPMV_FMT_DNSROW: e.fmt = fmt; e.p1 = T->dnsrowptr[t + 1] - T->dnsrowptr[t]; break;
+    case TILESPMV_FMT_DNSCOL: e.fmt = fmt; e.p1 = T->dnscolptr[t + 1] - T->dnscolptr[t]; break;
+    }
+    tile_stream_sizes(e.fmt, e.p1, e.p2, &e.nv, &e.ni);
+    return e;
+}
+
+// Copy one tile's payload into the streams, converting to row stride 16 / tile-local packing.
+inline void repack_tile(const Tile_matrix *T, int t, const Emit &e, int rowlen, int collen, long long hyb_idx_off,
+                 val_t *v, unsigned char *ix)
+{
+    switch (e.fmt) {
+    case TILESPMV_FMT_CSR: {
+        const int off = T->csr_offset[t], poff = T->csrptr_offset[t];
+        memcpy(v, T->Blockcsr_Val + off, sizeof(val_t) * (size_t)e.p1);
+        for (int r = 0; r < 16; r++) ix[r] = (unsigned char)(r < rowlen ? T->Blockcsr_Ptr[poff + r] : e.p1);
+        for (int k = 0; k < e.p1; k++) put_nib(ix + 16, k, nib(T->csr_compressedIdx, (long long)off + k));
+        break;
+    }
+    case TILESPMV_FMT_COO: {
+        const int off = T->coo_offset[t];
+        memcpy(v, T->Blockcoo_Val + off, sizeof(val_t) * (size_t)e.p1);
+        memcpy(ix, T->coo_compressed_Idx + off, (size_t)e.p1);
+        break;
+    }
+    case TILESPMV_FMT_ELL: {
+        const int off = T->ell_offset[t];
+        for (int s = 0; s < e.p1; s++)
+            for (int r = 0; r < rowlen; r++) {
+                v[16 * s + r] = T->Blockell_Val[off + s * rowlen + r];
+                put_nib(ix, 16 * s + r, nib(T->ell_compressedIdx, (long long)off + s * rowlen + r));
+            }
+        break;
+    }
+    case TILESPMV_FMT_HYB: {
+        const int off = T->hyb_offset[t], nell = e.p1 * rowlen;
+        const unsigned char *src = T->hybIdx + hyb_idx_off;
+        for (int s = 0; s < e.p1; s++)
+            for (int r = 0; r < rowlen; r++) {
+                v[16 * s + r] = T->Blockhyb_Val[off + s * rowlen + r];
+                put_nib(ix, 16 * s + r, nib(src, s * rowlen + r));
+            }
+        for (int i = 0; i < e.p2; i++) {
+            v[16 * e.p1 + i] = T->Blockhyb_Val[off + nell + i];
+            ix[8 * e.p1 + i] = src[(nell + 1) / 2 + i];
+        }
+        break;
+    }
+    case TILESPMV_FMT_DNS: {
+        const int off = T->dns_offset[t];
+        for (int c = 0; c < collen; c++)
+            for (int r = 0; r < rowlen; r++) v[16 * c + r] = T->Blockdense_Val[off + c * rowlen + r];
+        break;
+    }
+    case TILESPMV_FMT_DNSROW: {
+        const int off = T->dnsrow_offset[t], ro = T->dnsrowptr[t];
+        for (int k = 0; k < e.p1; k++) {
+            for (int c = 0; c < collen; c++) v[16 * k + c] = T->Blockdenserow_Val[off + k * collen + c];
+            ix[k] = (unsigned char)T->denserowid[ro + k];
+        }
+        break;
+    }
+    case TILESPMV_FMT_DNSCOL: {
+        const int off = T->dnscol_offset[t], co = T->dnscolptr[t];
+        for (int k = 0; k < e.p1; k++) {
+            for (int r = 0; r < rowlen; r++) v[16 * k + r] = T->Blockdensecol_Val[off + k * rowlen + r];
+            ix[k] = (unsigned char)T->densecolid[co + k];
+        }
+        break;
+    }
+    default: break;
+    }
+}
+
+
+// One entry of a merged list before packing.
+struct PEnt { unsigned col, dest; val_t val; };
+
+inline ERec make_erec(val_t v, unsigned w)
+{
+    ERec r;
+#if defined(TILESPMV_F32)
+    memcpy(&r.v, &v, 4);
+#else
+    unsigned b[2]; memcpy(b, &v, 8); r.lo = b[0]; r.hi = b[1];
+#endif
+    r.w = w;
+    return r;
+}
+
+// Packs one list (entries already in their final order: by column, ties in list order) into records and per-chunk column
+// bases (hip_plan.h ERec).  Chunk k of the list = its records [64k, 64k + 64); base = column of the chunk's first entry;
+// an entry whose column is 2^(32 - dest_bits) or more above the base closes the chunk, which is filled up with null
+// records (value 0, offset 0, destination 0: adds 0 * x[base] to the group's first row).  Returns false if the packed list
+// does not decode back to the input (checked in layout-digest builds).
+inline bool pack_list(const std::vector<PEnt> &ents, int dest_bits, std::vector<ERec> &rec, std::vector<unsigned> &base, bool verify)
+{
+    const unsigned long long span = 1ull << (32 - dest_bits);
+    const size_t rec0 = rec.size(), base0 = base.size();
+    size_t i = 0;
+    while (i < ents.size()) {
+        const unsigned b = ents[i].col;
+        base.push_back(b);
+        int n = 0;
+        while (i < ents.size() && n < ECHUNK && (unsigned long long)ents[i].col - b < span) {
+            rec.push_back(make_erec(ents[i].val, ((ents[i].col - b) << dest_bits) | ents[i].dest));
+            i++; n++;
+        }
+        if (i < ents.size()) for (; n < ECHUNK; n++) rec.push_back(make_erec((val_t)0, 0u));   // interior chunks are always full
+    }
+    if (!verify) return true;
+    size_t j = 0;
+    for (size_t q = rec0; q < rec.size(); q++) {
+        const ERec &r = rec[q];
+        const unsigned bq = base[base0 + (q - rec0) / ECHUNK];
+        val_t v;
+#if defined(TILESPMV_F32)
+        memcpy(&v, &r.v, 4);
+#else
+        unsigned bb[2] = {r.lo, r.hi}; memcpy(&v, bb, 8);
+#endif
+        if (r.w == 0u && v == (val_t)0 && (j >= ents.size() || ents[j].col != bq || ents[j].dest != 0u || ents[j].val != (val_t)0)) continue;   // null padding
+        if (j >= ents.size()) return false;
+        const unsigned col = bq + (r.w >> dest_bits), dest = r.w & ((1u << dest_bits) - 1u);
+        if (col != ents[j].col || dest != ents[j].dest || memcmp(&v, &ents[j].val, sizeof(val_t)) != 0) return false;
+        j++;
+    }
+    return j == ents.size() && base.size() - base0 == (rec.size() - rec0 + ECHUNK - 1) / ECHUNK;
+}
+
+// Second-generation layout (hip_plan_stream.hip): fills plan->st / plan->dn / the whole-tile pass of plan->dev for tile-rows [tr0, tr1).
+int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,
+                 bool dense_mfma, const std::vector<long long> &hyb_off,
+                 std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes);
+
+}  // namespace tilespmv

@@ -1,0 +1,904 @@
+// hip_plan_stream.hip — second-generation ("unit stream") layout builder of the plan (hip_plan.h), in stages.
+#include "hip_plan_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// Second-generation layout builder (hip_plan.h "unit stream").
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct RowCount { int nunits, ncoo, nheavy, ndense; long long hval, hidx; long long cost; };
+
+// A CSR tile is executed as w ELL-style units (the first w entries of every row) plus the rest of
+// its entries on the strip's COO list; w minimises the bytes moved (HYB's idea, src/csr2tile.h:279-306,
+// with this kernel's byte costs).  Returns w and the number of remainder entries.
+inline int csr_split_width(const unsigned char *ptr, int rowlen, int nnz, int *remainder)
+{
+    const long long unit_b = 16 + 16 * (long long)sizeof(val_t), entry_b = (long long)sizeof(val_t) + 5;
+    int len[16], wmax = 0;
+    for (int r = 0; r < 16; r++) { len[r] = r < rowlen ? ((r == rowlen - 1 ? nnz : ptr[r + 1]) - ptr[r]) : 0; wmax = std::max(wmax, len[r]); }
+    int best_w = 0, best_rem = nnz; long long best = entry_b * nnz;
+    for (int w = 1; w <= wmax; w++) {
+        int rem = 0;
+        for (int r = 0; r < 16; r++) rem += std::max(0, len[r] - w);
+        const long long b = unit_b * w + entry_b * rem;
+        if (b < best) { best = b; best_w = w; best_rem = rem; }
+    }
+    *remainder = best_rem;
+    return best_w;
+}
+
+inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, bool csr_split, int coo_cost)
+{
+    RowCount c{0, 0, 0, 0, 0, 0, 0};
+    for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
+        switch (fmt) {
+        case TILESPMV_FMT_ELL: c.nunits += w; break;
+        case TILESPMV_FMT_HYB: c.nunits += w; if (coo_in_tile) c.ncoo += stored - w * rowlen; break;
+        case TILESPMV_FMT_DNSCOL: c.nunits += T->dnscolptr[t + 1] - T->dnscolptr[t]; break;
+        case TILESPMV_FMT_DNS:
+            if (dense_mfma) c.ndense++;
+            else c.nunits += tile_collen(T->tile_columnidx[t], tilen, colA);
+            break;
+        case TILESPMV_FMT_COO: if (coo_in_tile) c.ncoo += stored; break;
+        case TILESPMV_FMT_CSR:
+            if (csr_split) { int rem; c.nunits += csr_split_width(T->Blockcsr_Ptr + T->csrptr_offset[t], rowlen, stored, &rem); c.ncoo += rem; }
+            else { c.nheavy++; c.hval += stored; c.hidx += 16 + (stored + 1) / 2; }
+            break;
+        case TILESPMV_FMT_DNSROW: c.nunits += T->dnsrowptr[t + 1] - T->dnsrowptr[t]; break;  // one row unit per dense row
+        }
+    }
+    // heavy tiles are latency-bound (one tile at a time): weigh them so that long lists get split
+    c.cost = 16LL * c.nunits + (long long)coo_cost * c.ncoo + c.hval + 256LL * c.nheavy + 64LL * c.ndense + 8;
+    return c;
+}
+
+
+// Dominant tile-row distances of a stencil-like shard: d = column block - tile-row over the tiles that become units.  s1 = the
+// smallest distance >= 2 that most tile-rows have (tile-rows per grid line), s2 = the middle of the next cluster of distances
+// (tile-rows per grid plane; 0 for 2-D problems).  0 / 0 when the shard has no such structure.
+inline void detect_strides(const Tile_matrix *T, int tr0, int tr1, bool csr_split, bool dense_mfma, int *s1, int *s2)
+{
+    *s1 = *s2 = 0;
+    const int ntr = tr1 - tr0;
+    if (ntr < 32) return;
+    const int step = std::max(1, ntr / 32768);
+    std::vector<long long> ds;
+    long long sampled = 0;
+    for (int bi = tr0; bi < tr1; bi += step) {
+        sampled++;
+        long long last = LLONG_MIN;
+        for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+            const int fmt = T->Format[t];
+            const bool units = fmt == TILESPMV_FMT_ELL || fmt == TILESPMV_FMT_HYB || fmt == TILESPMV_FMT_DNSCOL || fmt == TILESPMV_FMT_DNSROW ||
+                               (fmt == TILESPMV_FMT_DNS && !dense_mfma) || (fmt == TILESPMV_FMT_CSR && csr_split);
+            const long long d = (long long)T->tile_columnidx[t] - bi;
+            if (units && d >= 2 && d != last) { ds.push_back(d); last = d; }
+        }
+    }
+    std::sort(ds.begin(), ds.end());
+    std::vector<long long> dom;   // distances that at least a quarter of the sampled tile-rows have
+    for (size_t i = 0; i < ds.size();) {
+        size_t j = i;
+        while (j < ds.size() && ds[j] == ds[i]) j++;
+        if ((long long)(j - i) * 4 >= sampled) dom.push_back(ds[i]);
+        i = j;
+    }
+    if (dom.empty() || dom[0] > (1 << 20)) return;
+    *s1 = (int)dom[0];
+    size_t a = 1;
+    while (a < dom.size() && dom[a] <= dom[0] + 1) a++;
+    if (a >= dom.size()) return;
+    size_t b = a;
+    while (b + 1 < dom.size() && dom[b + 1] - dom[b] <= dom[0] + 1) b++;   // {s2 - s1, s2, s2 + s1} of a 27-point stencil
+    const long long mid = dom[(a + b) / 2];
+    if (mid % dom[0] == 0 && mid / dom[0] >= 2 && mid < (1ll << 30)) *s2 = (int)mid;
+}
+
+
+// The builder, one stage per method.  Every stage reads the members earlier stages filled and, in layout-digest builds
+// (plan->dry), hashes what it produced into plan->stage_digest[stage]: tests/test_plan_stages.py pins which knob may change which stage.
+//   COUNT    per tile-row: units / entries / whole tiles / dense tiles it will emit, cost; prefix sums
+//   CHOOSE   strip size, entry mode, strips per workgroup, ordered adds, brick order: pure function of the counts and the knobs
+//   CUT      strips of whole tile-rows and pieces of split tile-rows -> task records
+//   EMIT     unit descriptors + values, entry triples, whole-tile and dense-tile payload, in tile order
+//   ORDER    task order: linear, or brick order (stencil-like shards) + the workgroups' x windows
+//   ENCODE   final HBM form of the units: value groups per task, 12-B descriptors or 4-B words + pattern dictionary
+//   ENTRIES  merged, column-ordered, packed entry lists per wavefront / workgroup
+//   FINISH   remaining uploads, cache-policy flags, byte model
+struct StreamBuilder {
+    tilespmv_plan *plan; const Knobs &K; const Tile_matrix *T; const int rowA, colA, tr0, tr1; const bool coo_in_tile, dense_mfma;
+    const std::vector<long long> &hyb_off;
+    std::vector<FixRow> &fix; int &npartial;
+    DevStream &S;
+    int rc = 0;
+    // COUNT
+    bool csr_split = true; int target_in = 0, split_above_in = 0, tilem = 0, tilen = 0, ntr = 0, sv = 0;
+    std::vector<RowCount> rc_;
+    std::vector<long long> pu, pc, ph, phv, phi, pd;
+    long long NU = 0, NC = 0, NH = 0, NHV = 0, NHI = 0, ND = 0;
+    // CHOOSE
+    bool fix_inline_on = true, entry_heavy = false, entry_dominated = false, wave_coo = false, coo_ordered = false, brick = false, xwin = false;
+    long long total_cost = 0, est_wgs = 0;
+    int target = 0, entry_mode = 0, wg_strips = 16, xs1 = 0, xs2 = 0, max_strip_rows = STRIP_MAX_ROWS;
+    // CUT
+    std::vector<STask> tasks;
+    std::vector<Task> htasks;
+    std::vector<FixRow> ifix, fix_late;   // split rows summed inside the unit kernel / by k_fixup_split after all passes
+    std::vector<DenseRow> drows;
+    std::vector<unsigned char> row_k, row_split;
+    int npartial0 = 0;
+    // EMIT
+    std::vector<uint4> h_udesc;
+    val_t *h_uval = nullptr, *h_cval = nullptr, *h_hval = nullptr, *h_dval = nullptr;
+    unsigned char *h_hidx = nullptr;
+    std::vector<int> h_ccol, h_dcb;
+    std::vector<unsigned char> h_crow;
+    std::vector<uint2> h_hdesc;
+    // ORDER
+    std::vector<uint4> h_udesc_cb;
+    std::vector<int2> h_wg_win;
+    std::vector<int> h_win_cb;
+    int xwin_slots_max = 0;
+    long long xwin_segments = 0, xwin_wgs = 0;
+    // ENCODE / ENTRIES
+    long long NUP = 0, n_rec = 0, n_chunk = 0, n_groups = 0;
+    std::vector<long long> old_begin;
+
+    StreamBuilder(tilespmv_plan *plan_, const Knobs &K_, const Tile_matrix *T_, int rowA_, int colA_, int tr0_, int tr1_, bool coo_in_tile_, bool dense_mfma_,
+                  const std::vector<long long> &hyb_off_, std::vector<FixRow> &fix_, int &npartial_)
+        : plan(plan_), K(K_), T(T_), rowA(rowA_), colA(colA_), tr0(tr0_), tr1(tr1_), coo_in_tile(coo_in_tile_), dense_mfma(dense_mfma_), hyb_off(hyb_off_), fix(fix_), npartial(npartial_), S(plan_->st) {}
+    ~StreamBuilder() { release(); }
+    void release() { free(h_uval); free(h_cval); free(h_hval); free(h_hidx); free(h_dval); h_uval = h_cval = h_hval = h_dval = nullptr; h_hidx = nullptr; }
+
+    // ---- stage digests (layout-digest builds only): FNV-1a-64 over (element count, bytes) of what the stage produced
+    struct Hash {
+        unsigned long long h = 1469598103934665603ull;
+        void bytes(const void *p, size_t len) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < len; i++) { h ^= b[i]; h *= 1099511628211ull; } }
+        template <class V> void vec(const std::vector<V> &v) { arr(v.data(), v.size()); }
+        template <class V> void arr(const V *p, size_t n) { const unsigned long long cnt = n; bytes(&cnt, 8); if (n) bytes(p, n * sizeof(V)); }
+        void num(long long v) { bytes(&v, 8); }
+    };
+    bool hashing() const { return plan->dry; }
+    void stage_done(int stage, const Hash &h) { plan->stage_digest[stage] = h.h; }
+
+    void count();
+    void choose();
+    void cut();
+    void emit();
+    void order();
+    void encode();
+    void entries();
+    void finish(long long &n_tasks, long long &model_bytes);
+};
+
+void StreamBuilder::count()
+{
+    csr_split = K.csr_split != 0;
+    target_in = K.strip_cost; split_above_in = K.split_above;
+    tilem = T->tilem; tilen = T->tilen; ntr = std::max(0, tr1 - tr0); sv = (int)sizeof(val_t);
+    rc_.assign((size_t)ntr, RowCount{0, 0, 0, 0, 0, 0, 0});
+    parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; i++) rc_[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, csr_split, K.coo_cost);
+    });
+    for (std::vector<long long> *p : {&pu, &pc, &ph, &phv, &phi, &pd}) p->assign((size_t)ntr + 1, 0);
+    for (int i = 0; i < ntr; i++) pd[i + 1] = pd[i] + rc_[i].ndense;
+    ND = pd[ntr];
+    for (int i = 0; i < ntr; i++) {
+        pu[i + 1] = pu[i] + rc_[i].nunits; pc[i + 1] = pc[i] + rc_[i].ncoo; ph[i + 1] = ph[i] + rc_[i].nheavy;
+        phv[i + 1] = phv[i] + rc_[i].hval; phi[i + 1] = phi[i] + rc_[i].hidx;
+    }
+    NU = pu[ntr]; NC = pc[ntr]; NH = ph[ntr]; NHV = phv[ntr]; NHI = phi[ntr];
+    if (tilen > (1 << UNIT_FLAG_SHIFT)) { fprintf(stderr, "tilespmv: more than 2^24 column blocks: use TILESPMV_KERNEL=1\n"); rc = -2; return; }
+    if (NU > INT32_MAX || NC > INT32_MAX || NH > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit unit ids\n"); rc = -2; return; }
+    if (hashing()) { Hash h; h.vec(rc_); for (long long v : {NU, NC, NH, NHV, NHI, ND}) h.num(v); stage_done(TILESPMV_STAGE_COUNT_ROWS, h); }
+}
+
+void StreamBuilder::choose()
+{
+    // ---- strips (<= STRIP_MAX_ROWS whole tile-rows up to the cost target) for the unit kernel, one
+    // heavy task per tile-row that owns heavy tiles, and pieces of very long tile-rows (all three
+    // kinds of pieces write partial[] slots that k_fixup_split adds up in a fixed order).
+    fix_inline_on = K.fix_inline != 0;
+    // How the COO entry lists run (TILESPMV_WAVE_COO = 0 / 1 / 2 overrides):
+    //   0  per 16-lane strip — regular matrices (a handful of entries per strip);
+    //   1  per wavefront, the four strips' lists merged and ordered by column — entry-heavy but small grids, where the
+    //      kernel is a chain of round trips and a workgroup barrier costs more than shared x lines save;
+    //   2  per workgroup, the sixteen strips' lists merged and ordered by column — entry-heavy shards that fill the chip:
+    //      distinct x lines per batch drop 3x and the CU's L1 -> L2 request rate is what bounds those.
+    // Strip size.  Regular matrices: ~400 cost units (20 units) amortise the per-strip round trips; flat between 200 and 800
+    // on large matrices.  Entry-heavy shards want MANY tile-rows per workgroup (power-law 8 M rows: 0.149 ms at 400,
+    // 0.120 ms at 1600) but still about 3 workgroups per CU on small matrices (webbase-like: 12.9-13.1 us at ~760
+    // workgroups, 13.6-14.3 at 1000, 15.4 at 570; scircuit-like flat 7.2-7.8 us from 250 to 670 workgroups).
+    entry_heavy = NC >= 5LL * ntr;   // (5 since round 3: an unaligned 7-point grid — 6 one-entry COO tiles per tile-row — runs 5 % faster with the workgroup entry mode; 4 per tile-row, the unaligned 5-point grid, does not)
+    total_cost = 0;
+    for (int i = 0; i < ntr; i++) total_cost += rc_[i].cost;
+    // tilespmv_plan_spmm: k_units_mv walks a strip's entries with its 16 lanes, tile-row by tile-row; where entries are most
+    // of the work (webbase-like: nvec 2 took 0.11 ms against 0.013 ms for one SpMV) one SpMV per right-hand side is faster
+    entry_dominated = (long long)K.coo_cost * NC * 2 > total_cost;
+    target = target_in;
+    if (target <= 0) {
+        target = 400;
+        if (entry_heavy) {
+            // balanced, entry-dominated shards (uniform random: 0.075 ms at 1600, 0.060 ms at 3200; band + random fill 0.126 -> 0.117)
+            // take strips of up to 3200; skewed ones (R-MAT scale 20: 0.054 ms at 1600, 0.076 ms at 3200) and unit-dominated ones
+            // (KKT-like 64^3: 0.022 ms at 967, 0.051 ms at 3200) stop at 1600
+            long long max_cost = 0;
+            for (int i = 0; i < ntr; i++) max_cost = std::max(max_cost, rc_[i].cost);
+            const bool balanced = ntr > 0 && max_cost * ntr <= 4 * total_cost;
+            const long long cap = (entry_dominated && balanced) ? 3200 : 1600;
+            target = (int)std::min<long long>(cap, std::max<long long>(400, total_cost / (3 * 256 * 16)));
+        } else if (total_cost / (16LL * 800) >= 4096 && NC <= 2LL * ntr) {
+            // large regular shards: strips of up to 8 tile-rows once that still leaves >= 4096 workgroups (config 4: 0.1644-0.1665 -> 0.1606-0.1608 ms with the
+            // nontemporal value stream, 5-pt 2896^2 0.0864 -> 0.0854; a 1024^2 grid would lose 17 % — 512 workgroups — and keeps 400) — and only while the
+            // 8 tile-rows bring at most the 16 entries that travel with the unit prologue (4 entries per tile-row, the 4095^2 grid: 0.1875 ms at 800, 0.1770 at 400)
+            target = 800;
+        }
+    }
+    target = std::max(32, target);
+    est_wgs = total_cost / (16LL * target) + 1;
+    const int wave_coo_env = K.entry_mode;
+    entry_mode = wave_coo_env >= 0 ? std::min(2, wave_coo_env) : (!entry_heavy ? 0 : est_wgs < 768 ? 1 : 2);
+    wave_coo = entry_mode != 0;
+    plan->entry_mode = entry_mode;
+    // strips per workgroup: 32 (512 threads) only on request and only with the workgroup entry mode — twice as many tile-rows share
+    // one column-ordered list (power-law 8 M rows: 0.204 -> 0.152 distinct 128-B x lines per entry) at the same 6 waves per SIMD, but
+    // it measures slower everywhere (power-law 8 M 0.1038 -> 0.1072 ms, webbase-like 13.1 -> 13.9 us, KKT fp64 equal): default 16
+    wg_strips = (entry_mode == 2 && K.wg_strips == 32) ? 32 : 16;
+    plan->wg_strips = wg_strips;
+    // Workgroup mode: the four wavefronts add into shared slabs.  Taking turns (4 barriers per trip) fixes the order of the
+    // additions -> bit-reproducible sums; free or a gain on large grids (fewer LDS conflicts: power-law 8 M rows 0.122 ->
+    // 0.118 ms), +8 % on mid-size ones (webbase-like 14.2 -> 15.3 us), which therefore add unordered unless
+    // TILESPMV_COO_ORDERED=1 asks for reproducible bits.  Modes 0 and 1 are always ordered (one wavefront per slab).
+    const int ordered_env = K.entry_ordered;
+    coo_ordered = ordered_env >= 0 ? ordered_env != 0 : est_wgs >= 2048;
+    // ---- brick order (stencil-like shards): the grid strides of the shard are detected from its tile pattern, strips stay inside
+    // one grid line, and after the cut the strips are regrouped so that the 16 strips of a workgroup — and the neighbouring
+    // workgroups of an XCD window — form a brick of the grid instead of a run of one grid line: the x segments a tile-row shares
+    // with its neighbours in the other two directions are then wanted at about the same time by one CU / one XCD, and hit in L1 /
+    // L2 instead of being fetched again (nlpkkt160 stand-in: 3.07 -> 2.6-2.7 GB per launch at the fabric in fp64, 1.81 -> 1.56 GB in fp32;
+    // time -2.5 ... -6 % in fp32, inside the matrix's 10 % placement spread in fp64: DESIGN.md S6.9).
+    //   x_window  -1 (default): brick order on large 3-D shards   0: off   2: brick order wherever strides are found
+    //              1: brick order + the workgroup's x segments staged once in LDS ("x windows": strips of at most XWIN_STRIP_ROWS
+    //                 tile-rows; cuts another ~0.4 GB but runs 25 % slower — profiles/r03_xwindow_and_map.txt; opt-in only)
+    xs1 = K.x_stride1 > 0 ? K.x_stride1 : 0; xs2 = K.x_stride2 > 0 ? K.x_stride2 : 0;
+    brick = K.x_window != 0 && wg_strips == 16 && (K.x_window > 0 || est_wgs >= 2048);
+    if (brick && xs1 == 0) detect_strides(T, tr0, tr1, csr_split, dense_mfma, &xs1, &xs2);
+    if (xs1 < 2 || (K.x_window < 0 && xs2 == 0)) brick = false;   // (2-D grids: measured neutral on the 5-point 4096^2 case)
+    xwin = brick && K.x_window == 1 && entry_mode != 1;   // (the windowed kernel exists for entry modes 0 and 2)
+    // (strips of at most 4 tile-rows in brick plans: nlpkkt160 stand-in fp64 0.418 -> 0.414 ms, fp32 0.252 -> 0.250 in one process; 2 rows: KKT 0.408 but 7-pt 256^3 +5 %)
+    max_strip_rows = xwin ? XWIN_STRIP_ROWS : brick ? (K.brick_rows > 0 ? std::min(K.brick_rows, STRIP_MAX_ROWS) : 4) : STRIP_MAX_ROWS;
+    if (brick && !K.xcd_from_caller) plan->xcd_chunk = 8;   // bricks are compact: smaller XCD windows keep an XCD's resident set together
+    if (hashing()) {
+        Hash h;
+        for (long long v : {(long long)target, (long long)entry_mode, (long long)wg_strips, (long long)coo_ordered, (long long)xs1, (long long)xs2, (long long)brick, (long long)xwin, (long long)max_strip_rows}) h.num(v);
+        stage_done(TILESPMV_STAGE_CHOOSE, h);
+    }
+}
+
+void StreamBuilder::cut()
+{
+    row_k.assign((size_t)ntr, 0); row_split.assign((size_t)ntr, 0);
+    npartial0 = npartial;
+    {
+        // rows above this cost are cut into pieces.  With the wavefront / workgroup entry modes a long row is no longer one strip's
+        // private burden, but an unsplit one still makes its workgroup the last to finish: the threshold stops growing with the
+        // strip size there (R-MAT scale 20 at strip size 3200: 0.099 ms with rows of up to 19,200 cost units kept whole)
+        const int split_cap = K.split_cap;
+        const int split_above = wave_coo ? std::max(split_above_in, std::min(6 * target, split_cap)) : std::max(6 * target, split_above_in);
+        const int piece = std::max(wave_coo ? std::min(2 * target, 1600) : 2 * target, split_above / 3);
+        tasks.clear(); htasks.clear(); ifix.clear(); fix_late.clear(); fix.clear(); drows.clear(); npartial = npartial0;
+        std::fill(row_k.begin(), row_k.end(), 0); std::fill(row_split.begin(), row_split.end(), 0);
+        const int strip_even = K.strip_even;  // 0 off, 1 = value group, n > 1 = multiples of n units
+        auto blank = [&]() { STask k; memset(&k, 0, sizeof(k)); k.partial = -1; return k; };
+        auto is_heavy = [&](int t) {
+            const int fmt = T->Format[t];
+            return fmt == TILESPMV_FMT_CSR && !csr_split;
+        };
+        auto heavy_sizes = [&](int t, int *nv, int *ni) {
+            const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t];
+            (void)fmt; *nv = stored; *ni = 16 + (stored + 1) / 2;
+        };
+        // k_dense_mfma broadcasts the column blocks of one DenseRow piece from a single 64-lane load: a piece holds at most
+        // 64 dense tiles.  Split rows cut their dense tiles into pieces of 32; an unsplit row is one piece, so a row with
+        // more dense tiles than that is always split, whatever the cost knobs say (TILESPMV_STRIP_COST / _SPLIT_ABOVE).
+        constexpr int DENSE_PIECE = 32;
+        auto must_split = [&](int i) { return rc_[i].cost > split_above || rc_[i].ndense > DENSE_PIECE; };
+        for (int i = 0; i < ntr;) {
+            if (must_split(i)) {
+                row_split[i] = 1;
+                FixRow f{tr0 + i, npartial, 0, 0};
+                // entry pieces: four consecutive pieces share a wavefront, which walks their lists together (4 x 192 = 2 trips of 6 x 64)
+                const int pu_ = std::max(1, piece / 16), pc_ = std::max(16, K.coo_piece > 0 ? K.coo_piece : (entry_mode == 1 ? 192 : piece / std::max(1, K.coo_cost)));
+                for (long long u = pu[i]; u < pu[i + 1]; u += pu_) {
+                    STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
+                    k.unit_begin = (int)u; k.unit_end = (int)std::min(pu[i + 1], u + pu_);
+                    tasks.push_back(k); f.count++;
+                }
+                for (long long c = pc[i]; c < pc[i + 1]; c += pc_) {
+                    STask k = blank(); k.row = tr0 + i; k.nrows = 1; k.partial = npartial++;
+                    k.coo_begin = (int)c; k.coo_end = (int)std::min(pc[i + 1], c + pc_);
+                    tasks.push_back(k); f.count++;
+                }
+                const int stream_pieces = f.count;  // pieces executed by the unit kernel
+                long long h = ph[i], hv = phv[i], hi = phi[i];
+                int t = T->tile_ptr[tr0 + i];
+                while (h < ph[i + 1]) {  // heavy tiles of a split row: cut at tile boundaries by payload size
+                    Task k{(int)h, (int)h, hv, hi, tr0 + i, npartial++};
+                    long long c = 0;
+                    while (h < ph[i + 1] && (c == 0 || c < piece)) {
+                        while (!is_heavy(t)) t++;
+                        int nv, ni; heavy_sizes(t, &nv, &ni);
+                        hv += nv; hi += ni; c += nv + 256; h++; t++;
+                    }
+                    k.tile_end = (int)h;
+                    htasks.push_back(k); f.count++;
+                }
+                for (long long dq = pd[i]; dq < pd[i + 1]; dq += DENSE_PIECE) {  // dense tiles of a split row: 32 per piece
+                    drows.push_back(DenseRow{tr0 + i, (int)dq, (int)std::min(pd[i + 1], dq + DENSE_PIECE), npartial++});
+                    f.count++;
+                }
+                // all pieces inside the unit kernel -> the last one to finish adds the slots up there
+                const bool inline_fix = fix_inline_on && f.count == stream_pieces;
+                for (int q = 0; q < stream_pieces; q++) tasks[tasks.size() - 1 - (size_t)q].nounit_mask = inline_fix ? (unsigned)ifix.size() : 0xFFFFFFFFu;
+                if (inline_fix) ifix.push_back(f); else fix_late.push_back(f);
+                fix.push_back(f);
+                i++;
+                continue;
+            }
+            STask k = blank();
+            k.row = tr0 + i;
+            k.unit_begin = (int)pu[i]; k.coo_begin = (int)pc[i];
+            int j = i;
+            // how many tile-rows: up to the cost target, then nudged by one row either way if that leaves fewer padding
+            // units (the strip's values are stored in groups of UNIT_GROUP units, tail padded with zero units)
+            int jend = i;
+            {
+                long long cc = 0;
+                while (jend < ntr && jend - i < max_strip_rows && !must_split(jend)) {
+                    if (brick && jend > i && (tr0 + jend) % xs1 == 0) break;   // brick order: a strip stays inside one grid line
+                    const long long nc = cc + rc_[jend].cost;
+                    // entry-heavy shards round to the nearest strip size (rows cost 100-400 each there: "never above the target"
+                    // would leave most strips half empty and double the number of wavefronts)
+                    if (jend > i && nc > target && !(wave_coo && nc - target < target - cc && nc <= target + target / 2)) break;
+                    cc = nc; jend++;
+                }
+                // (whole batches of 4 units, which are also whole value groups: a half-empty last batch costs as much as a full one)
+                const int quantum = strip_even > 1 ? strip_even : UNIT_GROUP;
+                auto pad = [&](int e) { return (int)((quantum - (pu[e] - pu[i]) % quantum) % quantum); };
+                if (strip_even && pad(jend) > 0) {
+                    int best = jend;
+                    if (jend < ntr && jend - i < max_strip_rows && !(brick && (tr0 + jend) % xs1 == 0) && !must_split(jend) && cc + rc_[jend].cost <= target + target / 3 && pad(jend + 1) < pad(best)) best = jend + 1;
+                    if (best == jend && jend - i >= 3 && pad(jend - 1) < pad(best)) best = jend - 1;
+                    jend = best;
+                }
+            }
+            while (j < jend) {
+                row_k[j] = (unsigned char)(j - i);
+                if (rc_[j].nunits == 0) k.nounit_mask |= 1u << (j - i);
+                if (rc_[j].nheavy > 0) htasks.push_back(Task{(int)ph[j], (int)ph[j + 1], phv[j], phi[j], tr0 + j, -1});
+                if (rc_[j].ndense > 0) drows.push_back(DenseRow{tr0 + j, (int)pd[j], (int)pd[j + 1], -1});
+                j++;
+            }
+            k.nrows = j - i;
+            k.unit_end = (int)pu[j]; k.coo_end = (int)pc[j];
+            tasks.push_back(k);
+            i = j;
+        }
+
+    }
+    if (hashing()) { Hash h; h.vec(tasks); h.vec(htasks); h.vec(ifix); h.vec(fix_late); h.vec(drows); h.vec(row_k); h.vec(row_split); h.num(npartial); stage_done(TILESPMV_STAGE_CUT, h); }
+}
+
+void StreamBuilder::emit()
+{
+    // ---- fill
+    h_udesc.assign((size_t)NU, make_uint4(0u, 0u, 0u, 0u));
+    h_uval = zalloc<val_t>((size_t)NU * 16);
+    h_cval = zalloc<val_t>((size_t)NC);
+    h_ccol.assign((size_t)NC, 0);
+    h_crow.assign((size_t)NC, 0);
+    h_hdesc.assign((size_t)NH, make_uint2(0u, 0u));
+    h_hval = zalloc<val_t>((size_t)NHV);
+    h_hidx = zalloc<unsigned char>((size_t)NHI + 16);
+    h_dcb.assign((size_t)ND, 0);
+    h_dval = zalloc<val_t>((size_t)ND * 256);
+    parallel_chunks(ntr, 256, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; i++) {
+            const int bi = tr0 + (int)i, rowlen = tile_rowlen(bi, tilem, rowA);
+            const unsigned kr = row_k[i];
+            long long u = pu[i], c = pc[i], h = ph[i], hv = phv[i], hi = phi[i], dq = pd[i];
+            auto put_unit = [&](int cb, const val_t *src, int stride_ok_rows, unsigned long long nibs) {
+                // src: rowlen consecutive values of this column; nibs: 16 nibbles, row 0 in the top nibble
+                for (int r = 0; r < stride_ok_rows; r++) h_uval[u * 16 + r] = src[r];
+                const unsigned w0 = (unsigned)cb | ((kr << UNIT_ROW_SHIFT) << UNIT_FLAG_SHIFT);
+                h_udesc[(size_t)u] = make_uint4(w0, (unsigned)(nibs >> 32), w0, (unsigned)(nibs & 0xffffffffull));
+                u++;
+            };
+            for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+                const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
+                const int cb = T->tile_columnidx[t], collen = tile_collen(cb, tilen, colA);
+                switch (fmt) {
+                case TILESPMV_FMT_ELL: {
+                    const int off = T->ell_offset[t];
+                    for (int s = 0; s < w; s++) {
+                        unsigned long long nibs = 0;
+                        for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib(T->ell_compressedIdx, (long long)off + s * rowlen + r) << (60 - 4 * r);
+                        put_unit(cb, T->Blockell_Val + off + s * rowlen, rowlen, nibs);
+                    }
+                    break;
+                }
+                case TILESPMV_FMT_HYB: {
+                    const int off = T->hyb_offset[t], nell = w * rowlen;
+                    const unsigned char *src = T->hybIdx + hyb_off[t];
+                    for (int s = 0; s < w; s++) {
+                        unsigned long long nibs = 0;
+                        for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib(src, s * rowlen + r) << (60 - 4 * r);
+                        put_unit(cb, T->Blockhyb_Val + off + s * rowlen, rowlen, nibs);
+                    }
+                    if (coo_in_tile)
+                        for (int q = 0; q < stored - nell; q++) {
+                            const unsigned char rcb = src[(nell + 1) / 2 + q];
+                            h_cval[c] = T->Blockhyb_Val[off + nell + q]; h_ccol[(size_t)c] = cb * 16 + (rcb & 15);
+                            h_crow[(size_t)c] = (unsigned char)((kr << 4) | (rcb >> 4)); c++;
+                        }
+                    break;
+                }
+                case TILESPMV_FMT_DNSCOL: {
+                    const int off = T->dnscol_offset[t], co = T->dnscolptr[t], k = T->dnscolptr[t + 1] - co;
+                    for (int q = 0; q < k; q++) put_unit(cb, T->Blockdensecol_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)(T->densecolid[co + q] & 15));
+                    break;
+                }
+                case TILESPMV_FMT_COO:
+                    if (coo_in_tile) {
+                        const int off = T->coo_offset[t];
+                        for (int q = 0; q < stored; q++) {
+                            const unsigned char rcb = T->coo_compressed_Idx[off + q];
+                            h_cval[c] = T->Blockcoo_Val[off + q]; h_ccol[(size_t)c] = cb * 16 + (rcb & 15);
+                            h_crow[(size_t)c] = (unsigned char)((kr << 4) | (rcb >> 4)); c++;
+                        }
+                    }
+                    break;
+                case TILESPMV_FMT_DNS:
+                    if (!dense_mfma) {
+                        const int off = T->dns_offset[t];
+                        for (int q = 0; q < collen; q++) put_unit(cb, T->Blockdense_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)q);
+                        break;
+                    }
+                    {   // dense tile for the matrix cores: 256 values, zero padded, in MFMA operand order (dense_slot, hip_plan.h)
+                        const int off = T->dns_offset[t];
+                        val_t *dst = h_dval + dq * 256;
+                        for (int cc = 0; cc < collen; cc++)
+                            for (int r = 0; r < rowlen; r++) dst[dense_slot(r, cc)] = T->Blockdense_Val[off + cc * rowlen + r];
+                        h_dcb[(size_t)dq] = cb;
+                        dq++;
+                    }
+                    break;
+                case TILESPMV_FMT_DNSROW: {
+                    const int off = T->dnsrow_offset[t], ro = T->dnsrowptr[t], k = T->dnsrowptr[t + 1] - ro;
+                    for (int q = 0; q < k; q++) {
+                        for (int cc = 0; cc < collen; cc++) h_uval[u * 16 + cc] = T->Blockdenserow_Val[off + q * collen + cc];
+                        const unsigned w0 = (unsigned)cb | (((kr << UNIT_ROW_SHIFT) | UNIT_ROWUNIT) << UNIT_FLAG_SHIFT);
+                        const unsigned rid = (unsigned)(T->denserowid[ro + q] & 15);
+                        h_udesc[(size_t)u] = make_uint4(w0, rid, w0, rid);
+                        u++;
+                    }
+                    break;
+                }
+                case TILESPMV_FMT_CSR:
+                    if (csr_split) {
+                        const int off = T->csr_offset[t];
+                        const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
+                        int rem;
+                        const int w = csr_split_width(ptr, rowlen, stored, &rem);
+                        const long long u0 = u;
+                        for (int sidx = 0; sidx < w; sidx++) {  // descriptors first (zero nibbles), payload below
+                            const unsigned w0 = (unsigned)cb | ((kr << UNIT_ROW_SHIFT) << UNIT_FLAG_SHIFT);
+                            h_udesc[(size_t)u] = make_uint4(w0, 0u, w0, 0u);
+                            u++;
+                        }
+                        for (int r = 0; r < rowlen; r++) {
+                            const int k0 = ptr[r], k1 = (r == rowlen - 1) ? stored : ptr[r + 1];
+                            for (int kk = k0; kk < k1; kk++) {
+                                const int lc = nib(T->csr_compressedIdx, (long long)off + kk), sidx = kk - k0;
+                                if (sidx < w) {
+                                    h_uval[(u0 + sidx) * 16 + r] = T->Blockcsr_Val[off + kk];
+                                    if (r < 8) h_udesc[(size_t)(u0 + sidx)].y |= (unsigned)lc << (28 - 4 * r);
+                                    else h_udesc[(size_t)(u0 + sidx)].w |= (unsigned)lc << (28 - 4 * (r - 8));
+                                } else {
+                                    h_cval[c] = T->Blockcsr_Val[off + kk]; h_ccol[(size_t)c] = cb * 16 + lc;
+                                    h_crow[(size_t)c] = (unsigned char)((kr << 4) | r); c++;
+                                }
+                            }
+                        }
+                        break;
+                    }
+                    // fallthrough: CSR tile as a heavy (whole) tile
+                {
+                    Emit em = emit_of(T, t, rowlen, true);
+                    repack_tile(T, t, em, rowlen, collen, 0, h_hval + hv, h_hidx + hi);
+                    h_hdesc[(size_t)h] = make_uint2((unsigned)cb, (unsigned)em.fmt | ((unsigned)em.p1 << DESC_P1_SHIFT));
+                    h++; hv += em.nv; hi += em.ni;
+                    break;
+                }
+                }
+            }
+            if (!row_split[i] && u > pu[i]) { h_udesc[(size_t)u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; h_udesc[(size_t)u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
+            if (h > ph[i]) h_hdesc[(size_t)h - 1].y |= DESC_EOR;
+        }
+    });
+    if (hashing()) {
+        Hash h;
+        h.vec(h_udesc); h.arr(h_uval, (size_t)NU * 16); h.arr(h_cval, (size_t)NC); h.vec(h_ccol); h.vec(h_crow); h.vec(h_hdesc); h.arr(h_hval, (size_t)NHV); h.arr(h_hidx, (size_t)NHI);
+        h.vec(h_dcb); h.arr(h_dval, (size_t)ND * 256);
+        stage_done(TILESPMV_STAGE_EMIT, h);
+    }
+}
+
+void StreamBuilder::order()
+{
+    // ---- x windows: brick order of the strips, then one window of column blocks per workgroup
+    h_udesc_cb.clear();   // the descriptors with column blocks (multi-vector kernel), when windows put slots into h_udesc
+    xwin_slots_max = 0;
+    xwin_segments = 0; xwin_wgs = 0;
+    if (brick && !tasks.empty()) {
+        const size_t nt = tasks.size();
+        // grid coordinates of every strip: position in its line (ordinal of the strip), line in its plane, plane
+        std::vector<int> sx(nt), ly(nt), lz(nt);
+        {
+            long long prev_line = -1; int ord = 0;
+            for (size_t i = 0; i < nt; i++) {
+                const long long line = tasks[i].row / xs1;
+                ord = line == prev_line ? ord + 1 : 0;
+                prev_line = line;
+                sx[i] = ord;
+                ly[i] = xs2 ? (int)(line % (xs2 / xs1)) : (int)line;
+                lz[i] = xs2 ? tasks[i].row / xs2 : 0;
+            }
+        }
+        auto blocks_of = [&](const STask &k, std::vector<int> &out) {
+            for (int u = k.unit_begin; u < k.unit_end; u++) out.push_back((int)(h_udesc[(size_t)u].x & 0xFFFFFFu));
+        };
+        struct Shape { int px, py, pz; };
+        const Shape shapes3[] = {{1, 4, 4}, {2, 2, 4}, {2, 4, 2}, {4, 2, 2}, {1, 2, 8}, {1, 8, 2}, {4, 4, 1}, {2, 8, 1}, {1, 16, 1}, {16, 1, 1}};
+        const Shape shapes2[] = {{4, 4, 1}, {2, 8, 1}, {8, 2, 1}, {1, 16, 1}, {16, 1, 1}};
+        const Shape *shapes = xs2 ? shapes3 : shapes2;
+        const int nshapes = xs2 ? 10 : 5;
+        std::vector<unsigned> order(nt), best_order;
+        double best_avg = 1e30;
+        Shape best_shape{16, 1, 1};
+        auto sort_for = [&](const Shape &sh) {
+            for (size_t i = 0; i < nt; i++) order[i] = (unsigned)i;
+            std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) {
+                const int ka[6] = {lz[a] / sh.pz, ly[a] / sh.py, sx[a] / sh.px, lz[a] % sh.pz, ly[a] % sh.py, sx[a] % sh.px};
+                const int kb[6] = {lz[b] / sh.pz, ly[b] / sh.py, sx[b] / sh.px, lz[b] % sh.pz, ly[b] % sh.py, sx[b] % sh.px};
+                for (int q = 0; q < 6; q++) if (ka[q] != kb[q]) return ka[q] < kb[q];
+                return a < b;
+            });
+        };
+        const size_t nwg = (nt + 15) / 16;
+        std::vector<int> tmp;
+        for (int si = 0; si < nshapes; si++) {   // the brick shape that needs the fewest window slots on a sample of workgroups
+            sort_for(shapes[si]);
+            long long slots = 0, wgs = 0;
+            for (size_t w = nwg / 128; w < nwg; w += std::max<size_t>(1, nwg / 64)) {
+                tmp.clear();
+                for (size_t t = 16 * w; t < std::min(nt, 16 * w + 16); t++) blocks_of(tasks[order[t]], tmp);
+                std::sort(tmp.begin(), tmp.end());
+                slots += (long long)(std::unique(tmp.begin(), tmp.end()) - tmp.begin()); wgs++;
+            }
+            const double avg = wgs ? (double)slots / (double)wgs : 1e30;
+            if (avg < best_avg * 0.98) { best_avg = avg; best_order = order; best_shape = shapes[si]; }
+        }
+        {
+            std::vector<STask> permuted(nt);
+            for (size_t i = 0; i < nt; i++) permuted[i] = tasks[best_order[i]];
+            tasks.swap(permuted);
+        }
+        h_udesc_cb = h_udesc;
+        h_wg_win.assign(nwg, make_int2(0, 0));
+        std::vector<std::vector<int>> wg_blocks(nwg);
+        const bool order_only = !xwin;   // brick order alone: x is still gathered from global memory (through L1 / L2)
+        parallel_chunks(order_only ? 0 : (int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
+            for (int64_t w = b; w < e; w++) {
+                std::vector<int> &bl = wg_blocks[(size_t)w];
+                for (size_t t = 16 * (size_t)w; t < std::min(nt, 16 * (size_t)w + 16); t++) blocks_of(tasks[t], bl);
+                std::sort(bl.begin(), bl.end());
+                bl.erase(std::unique(bl.begin(), bl.end()), bl.end());
+                if (bl.size() > (size_t)XWIN_MAX_SLOTS) { bl.clear(); continue; }   // this workgroup reads x from global memory
+                for (size_t t = 16 * (size_t)w; t < std::min(nt, 16 * (size_t)w + 16); t++)
+                    for (int u = tasks[t].unit_begin; u < tasks[t].unit_end; u++) {
+                        uint4 &d = h_udesc[(size_t)u];
+                        const unsigned slot = (unsigned)(std::lower_bound(bl.begin(), bl.end(), (int)(d.x & 0xFFFFFFu)) - bl.begin());
+                        d.x = (d.x & 0xFF000000u) | slot; d.z = d.x;
+                    }
+            }
+        });
+        for (size_t w = 0; w < nwg; w++) {
+            h_wg_win[w] = make_int2((int)h_win_cb.size(), (int)wg_blocks[w].size());
+            h_win_cb.insert(h_win_cb.end(), wg_blocks[w].begin(), wg_blocks[w].end());
+            xwin_slots_max = std::max(xwin_slots_max, (int)wg_blocks[w].size());
+            xwin_segments += (long long)wg_blocks[w].size(); xwin_wgs += !wg_blocks[w].empty();
+        }
+        if (xwin_slots_max == 0) { xwin = false; h_udesc_cb.clear(); }
+        if (getenv("TILESPMV_PLAN_VERBOSE"))
+            fprintf(stderr, "tilespmv: brick order: strides %d / %d tile-rows, brick %d x %d x %d strips, %.1f distinct column blocks per workgroup on the sample; x windows: %lld of %zu workgroups, %d slots at most\n",
+                    xs1, xs2, best_shape.px, best_shape.py, best_shape.pz, best_avg, xwin_wgs, nwg, xwin_slots_max);
+    } else { xwin = false; brick = false; }
+    plan->info[TILESPMV_INFO_BRICK_ORDER] = brick ? 1 : 0;
+    plan->xwin_lds_bytes = xwin ? xwin_slots_max * 16 * (int)sizeof(val_t) : 0;
+    plan->size_hint = (size_t)(NU * (12 + 16LL * sv) + NC * (2LL * sv + 13) + NHV * sv + NHI + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);   // estimate of the plan's bytes: picks the block size of upload()
+    if (hashing()) { Hash h; h.vec(tasks); h.vec(h_wg_win); h.vec(h_win_cb); h.num(brick); h.num(xwin); stage_done(TILESPMV_STAGE_ORDER, h); }
+}
+
+void StreamBuilder::encode()
+{
+    const unsigned long long d0 = plan->digest;
+    // ---- final HBM form of the unit streams.  Descriptors: 12 B (the duplicate of word 0 is dropped).  Values: the
+    // units of one task are stored in GROUPS of G = 16 / sizeof(value) units (2 in fp64, 4 in fp32) — the values of
+    // the G units interleaved per row, so that a lane fetches G units with one 16-byte load (row r of the group at
+    // +16 r bytes).  A task whose unit count is not a multiple of G gets padding units (zero values, never executed:
+    // unit_end excludes them) so that its last group exists.
+    constexpr long long G = UNIT_GROUP;
+    auto padded = [&](long long n) { return (n + G - 1) / G * G; };
+    NUP = 0;
+    for (const STask &k : tasks) NUP += padded(k.unit_end - k.unit_begin);
+    if (NUP > INT32_MAX) {
+        fprintf(stderr, "tilespmv: shard too large for 32-bit unit ids\n");
+        rc = -2;
+        return;
+    }
+    {
+        std::vector<UDesc> packed((size_t)NUP, UDesc{0u, 0u, 0u});
+        val_t *paired = zalloc<val_t>((size_t)NUP * 16);
+        std::vector<long long> new_begin(tasks.size());
+        old_begin.assign(tasks.size(), 0);
+        for (size_t i = 0; i < tasks.size(); i++) old_begin[i] = tasks[i].unit_begin;
+        long long at = 0;
+        for (size_t i = 0; i < tasks.size(); i++) { new_begin[i] = at; at += padded(tasks[i].unit_end - tasks[i].unit_begin); }
+        parallel_chunks((int64_t)tasks.size(), 512, [&](int64_t b, int64_t e, int) {
+            for (int64_t i = b; i < e; i++) {
+                STask &k = tasks[(size_t)i];
+                const long long ub = k.unit_begin, n = k.unit_end - ub, nb = new_begin[(size_t)i];
+                for (long long j = 0; j < n; j++) {
+                    const uint4 d = h_udesc[(size_t)(ub + j)];
+                    packed[(size_t)(nb + j)] = UDesc{d.x, d.y, d.w};
+                    const val_t *src = h_uval + (ub + j) * 16;
+                    val_t *dst = paired + (nb + j / G * G) * 16 + (j % G);
+                    for (int r = 0; r < 16; r++) dst[G * r] = src[r];
+                }
+                if (n > 0) { k.unit_begin = (int)nb; k.unit_end = (int)(nb + n); }
+            }
+        });
+        // ---- 4-B descriptors where the units of the shard use few distinct column patterns (stencil-like shards: 4 patterns in the
+        // 5- and 7-point grids, 36 in the KKT stand-in): column block | pattern id << cb_bits | flags << 27, the patterns (the
+        // two nibble words) in a dictionary the kernels gather from.  Not for x-window plans (their descriptors hold slots).
+        S.udict = nullptr; S.cb_bits = 0;
+        std::vector<uint2> dict;
+        std::vector<unsigned> compact;
+        // ... and only where it pays: 8 bytes per unit must be at least 2 % of the streams (an entry-dominated plan with a handful of units would only buy the dictionary
+        // hop at the start of every strip: webbase-1M stand-in 13.2 -> 13.6 us); desc_dict = 1 asks for it wherever it is possible
+        const bool dict_pays = K.desc_dict > 0 ? true : 8LL * NUP * 50 >= NUP * (12 + 16LL * sv) + NC * (sv + 4LL);
+        if (K.desc_dict != 0 && dict_pays && !xwin && NUP > 0) {
+            const int cb_bits = std::max(1, 32 - __builtin_clz((unsigned)std::max(1, T->tilen - 1)));
+            const int pid_bits = std::min(DICT_MAX_BITS, 27 - cb_bits);
+            if (pid_bits >= 1) {
+                const size_t cap = (size_t)1 << pid_bits;
+                std::vector<std::unordered_set<unsigned long long>> local((size_t)host_threads());
+                std::atomic<int> over(0);
+                parallel_chunks((int64_t)NUP, 1 << 16, [&](int64_t b, int64_t e, int th) {
+                    if (over.load(std::memory_order_relaxed)) return;
+                    std::unordered_set<unsigned long long> &L = local[(size_t)th];
+                    for (int64_t u = b; u < e; u++) {
+                        L.insert(((unsigned long long)packed[(size_t)u].n0 << 32) | packed[(size_t)u].n1);
+                        if (L.size() > cap) { over.store(1); return; }
+                    }
+                });
+                std::vector<unsigned long long> all;
+                if (!over.load()) {
+                    for (auto &L : local) all.insert(all.end(), L.begin(), L.end());
+                    std::sort(all.begin(), all.end());
+                    all.erase(std::unique(all.begin(), all.end()), all.end());
+                }
+                if (!over.load() && all.size() <= cap) {
+                    dict.resize(all.size());
+                    for (size_t i = 0; i < all.size(); i++) dict[i] = make_uint2((unsigned)(all[i] >> 32), (unsigned)(all[i] & 0xffffffffull));
+                    compact.resize((size_t)NUP);
+                    const unsigned cbmask = (1u << cb_bits) - 1u;
+                    parallel_chunks((int64_t)NUP, 1 << 16, [&](int64_t b, int64_t e, int) {
+                        for (int64_t u = b; u < e; u++) {
+                            const UDesc &d = packed[(size_t)u];
+                            const unsigned long long key = ((unsigned long long)d.n0 << 32) | d.n1;
+                            const unsigned pid = (unsigned)(std::lower_bound(all.begin(), all.end(), key) - all.begin());
+                            compact[(size_t)u] = (d.w0 & cbmask) | (pid << cb_bits) | ((d.w0 >> UNIT_FLAG_SHIFT) << 27);
+                        }
+                    });
+                    S.cb_bits = cb_bits;
+                }
+            }
+        }
+        if (S.cb_bits > 0) {
+            rc |= plan->upload(compact.data(), compact.size(), reinterpret_cast<const unsigned **>(&S.udesc));
+            rc |= plan->upload(dict.data(), dict.size(), &S.udict);
+        } else rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc);
+        plan->info[TILESPMV_INFO_DESC_BYTES] = S.cb_bits > 0 ? 4 : 12;
+        rc |= plan->upload(paired, (size_t)NUP * 16, &S.uval);
+        free(paired);
+        S.udesc_cb = S.udesc;
+        if (xwin) {   // the multi-vector kernel keeps reading x from global memory: its descriptors carry column blocks
+            std::fill(packed.begin(), packed.end(), UDesc{0u, 0u, 0u});
+            parallel_chunks((int64_t)tasks.size(), 512, [&](int64_t b, int64_t e, int) {
+                for (int64_t i = b; i < e; i++) {
+                    const STask &k = tasks[(size_t)i];   // (unit_begin already points into the packed numbering)
+                    for (long long j = 0; j < k.unit_end - k.unit_begin; j++) {
+                        const uint4 d = h_udesc_cb[(size_t)(old_begin[(size_t)i] + j)];
+                        packed[(size_t)(k.unit_begin + j)] = UDesc{d.x, d.y, d.w};
+                    }
+                }
+            });
+            rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc_cb);
+            rc |= plan->upload(h_wg_win.data(), h_wg_win.size(), &S.wg_win);
+            rc |= plan->upload(h_win_cb.data(), h_win_cb.size(), &S.win_cb);
+        } else { S.wg_win = nullptr; S.win_cb = nullptr; }
+    }
+    if (hashing()) { Hash h; h.num((long long)(plan->digest ^ d0)); h.num(NUP); h.num(S.cb_bits); stage_done(TILESPMV_STAGE_ENCODE, h); }   // (everything this stage produces is uploaded: the running upload digest covers it)
+}
+
+void StreamBuilder::entries()
+{
+    const unsigned long long d0 = plan->digest;
+    S.wg_coo = nullptr; S.grec = nullptr; S.gbase = nullptr; S.dest_bits = 11;
+    n_rec = 0; n_chunk = 0; n_groups = 0;
+    if (entry_mode != 0) {
+        const size_t GS = entry_mode == 2 ? (size_t)wg_strips : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
+        const int slab_shift = xwin ? 6 : 7;   // a strip's slab of s_y: XWIN_STRIP_ROWS x 16 values in x-window plans, STRIP_MAX_ROWS x 16 otherwise
+        const int dest_bits = entry_mode == 2 ? (wg_strips == 32 ? 12 : 4 + slab_shift) : 9;   // strip-in-group | row-in-strip | row (4)
+        S.dest_bits = dest_bits;
+        const size_t nwg = (tasks.size() + GS - 1) / GS;
+        std::vector<std::vector<ERec>> grp_rec(nwg);
+        std::vector<std::vector<unsigned>> grp_base(nwg);
+        std::atomic<int> bad(0);
+        parallel_chunks((int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
+            std::vector<std::pair<unsigned long long, unsigned>> key;   // (column << 32 | position in strip / list order, destination)
+            std::vector<int> src;
+            std::vector<PEnt> ents;
+            for (int64_t w = b; w < e; w++) {
+                key.clear(); src.clear();
+                for (size_t t = GS * (size_t)w; t < std::min(tasks.size(), GS * (size_t)w + GS); t++)
+                    for (int q = tasks[t].coo_begin; q < tasks[t].coo_end; q++) {   // column-major order; ties keep strip / list order
+                        key.push_back({((unsigned long long)(unsigned)h_ccol[(size_t)q] << 32) | (unsigned long long)key.size(),
+                                       (unsigned)((t & (GS - 1)) << slab_shift) | (unsigned)h_crow[(size_t)q]});
+                        src.push_back(q);
+                    }
+                std::sort(key.begin(), key.end());
+                ents.resize(key.size());
+                for (size_t i = 0; i < key.size(); i++) {
+                    const int q = src[(size_t)(key[i].first & 0xFFFFFFFFull)];
+                    ents[i] = PEnt{(unsigned)h_ccol[(size_t)q], key[i].second, h_cval[q]};
+                }
+                if (!pack_list(ents, dest_bits, grp_rec[(size_t)w], grp_base[(size_t)w], plan->dry)) bad++;
+            }
+        });
+        if (bad.load()) { fprintf(stderr, "tilespmv: internal error: %d packed entry lists do not decode to their entries\n", bad.load()); rc = -6; }
+        std::vector<int4> wg((size_t)nwg);
+        for (size_t w = 0; w < nwg; w++) {
+            wg[w] = make_int4((int)n_rec, (int)(n_rec + (long long)grp_rec[w].size()), (int)n_chunk, 0);
+            n_rec += (long long)grp_rec[w].size(); n_chunk += (long long)grp_base[w].size();
+        }
+        if (n_rec > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit entry ids\n"); rc = -2; n_rec = 0; }
+        std::vector<ERec> g_rec((size_t)n_rec);
+        std::vector<unsigned> g_base((size_t)n_chunk);
+        if (rc == 0)
+            parallel_chunks((int64_t)nwg, 256, [&](int64_t b, int64_t e, int) {
+                for (int64_t w = b; w < e; w++) {
+                    if (!grp_rec[(size_t)w].empty()) memcpy(&g_rec[(size_t)wg[(size_t)w].x], grp_rec[(size_t)w].data(), grp_rec[(size_t)w].size() * sizeof(ERec));
+                    if (!grp_base[(size_t)w].empty()) memcpy(&g_base[(size_t)wg[(size_t)w].z], grp_base[(size_t)w].data(), grp_base[(size_t)w].size() * sizeof(unsigned));
+                }
+            });
+        n_groups = (long long)nwg;
+        rc |= plan->upload(wg.data(), wg.size(), &S.wg_coo);
+        rc |= plan->upload(g_rec.data(), g_rec.size(), &S.grec);
+        rc |= plan->upload(g_base.data(), g_base.size(), &S.gbase);
+    }
+    if (hashing()) { Hash h; h.num((long long)(plan->digest ^ d0)); h.num(n_rec); h.num(n_chunk); h.num(n_groups); h.num(S.dest_bits); stage_done(TILESPMV_STAGE_ENTRIES, h); }
+}
+
+void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
+{
+    rc |= plan->upload(h_cval, (size_t)NC, &S.cval);
+    rc |= plan->upload(h_ccol.data(), (size_t)NC, &S.ccol);
+    rc |= plan->upload(h_crow.data(), (size_t)NC, &S.crow);
+    DevPlan &D = plan->dev;  // heavy tiles reuse the first-generation streams + kernel (accumulate mode)
+    rc |= plan->upload(h_hdesc.data(), (size_t)NH, &D.desc);
+    rc |= plan->upload(h_hval, (size_t)NHV, &D.val);
+    rc |= plan->upload(h_hidx, (size_t)NHI, &D.idx);
+    rc |= plan->upload(htasks.data(), htasks.size(), &D.task);
+    D.ntasks = (int)htasks.size();
+    rc |= plan->upload(tasks.data(), tasks.size(), &S.task);
+    rc |= plan->upload(h_dcb.data(), (size_t)ND, &plan->dn.cb);
+    rc |= plan->upload(h_dval, (size_t)ND * 256, &plan->dn.val);
+    rc |= plan->upload(drows.data(), drows.size(), &plan->dn.rows);
+    plan->dn.nrows = (int)drows.size();
+    for (const DenseRow &dr : drows)
+        if (dr.tile_end - dr.tile_begin > 64) { fprintf(stderr, "tilespmv: internal error: dense piece of %d tiles\n", dr.tile_end - dr.tile_begin); rc = -6; }
+    release();
+    S.ntasks = (int)tasks.size();
+#ifdef TILESPMV_STAMPS
+    { void *sp = nullptr; const size_t nst = ((tasks.size() + 15) / 16) * 4 * 8;
+      if (hipMalloc(&sp, nst * 8 + 64) == hipSuccess) { (void)hipMemset(sp, 0, nst * 8 + 64); plan->allocs.push_back(sp); } S.stamps = (unsigned long long *)sp; }
+#endif
+    S.ifix = nullptr; S.ifix_count = nullptr;
+    if (!ifix.empty()) {
+        rc |= plan->upload(ifix.data(), ifix.size(), &S.ifix);
+        std::vector<unsigned> zeros(ifix.size(), 0u);
+        const unsigned *cnt = nullptr;
+        rc |= plan->upload(zeros.data(), zeros.size(), &cnt);
+        S.ifix_count = const_cast<unsigned *>(cnt);
+    }
+    rc |= plan->upload(fix_late.data(), fix_late.size(), &plan->dev.fix_late);
+    plan->dev.nfix_late = (int)fix_late.size();
+    // entry mode 0 only: strips with more entries than this run their list before the unit pipeline (32: swept on KKT fp64 / scircuit /
+    // webbase stand-ins in round 1, best or within 1 %)
+    S.coo_heavy_min = K.coo_heavy_min;
+    S.coo_ordered = coo_ordered ? 1 : 0;
+    // y stores: streaming (nontemporal) where y is a real share of what the launch moves — they keep y from displacing x in L2: config 4 0.1946 -> 0.1845 ms,
+    // 7-pt 256^3 0.2533 -> 0.2432, power-law 8 M 0.1078 -> 0.1043 — plain where it is a few per cent: there the streaming form buys nothing and makes the time
+    // depend on where the CALLER's y happens to sit (nlpkkt160 stand-in fp64: 0.413 or 0.459 ms by the copy of y; plain: 0.408-0.411 with every copy)
+    {
+        const long long stream_b = NU * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + NC * (sv + 4LL), y_b = 16LL * ntr * sv;
+        S.y_streaming = K.y_store >= 0 ? (K.y_store != 0) : (y_b * 20 >= stream_b);   // >= 5 %
+    }
+    plan->info[TILESPMV_INFO_ENTRY_MODE] = entry_mode;
+    plan->info[TILESPMV_INFO_ENTRY_ORDERED] = (entry_mode != 2 || coo_ordered) ? 1 : 0;
+    plan->info[TILESPMV_INFO_STRIP_COST] = target;
+    plan->info[TILESPMV_INFO_WG_STRIPS] = wg_strips;
+    plan->info[TILESPMV_INFO_X_WINDOW_SLOTS] = xwin ? xwin_slots_max : 0;
+    plan->info[TILESPMV_INFO_X_WINDOW_SEGMENTS] = xwin ? xwin_segments : 0;
+    {   // entry slab of the multi-vector kernel: shards with >= 3 entries per tile-row (strips then regularly hold more than the 16 entries that travel with the prologue)
+        int used = 1;
+        for (const STask &k : tasks) used = std::max(used, k.nrows);
+        const int slab_env = env_int("TILESPMV_MV_SLAB", -1);   // (experiment knob: 0 off, 1 on wherever entries exist)
+        plan->mv_slab_rows = (slab_env == 0 || NC == 0) ? 0 : (slab_env > 0 || NC >= 3LL * ntr) ? used : 0;
+    }
+    plan->mv_by_columns = entry_dominated && target >= 800;   // (small strips hold few entries each: scircuit-like 18 / 22 / 32 us native against 22 / 41 / 78 us)
+    n_tasks = (long long)tasks.size();
+    model_bytes = NUP * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
+                  (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
+                  ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
+    // The once-read streams (values, entry records) are loaded nontemporally when the launch moves clearly more than the Infinity Cache holds: they then do
+    // not displace x in the L2s / the Infinity Cache — config 4 0.182 -> 0.164-0.166 ms, 7-pt 256^3 0.231 -> 0.211, KKT fp32 0.253 -> 0.236-0.243, power-law
+    // 8 M 0.103 -> 0.095 — while a plan that (nearly) fits keeps the default policy, because its streams come back from the Infinity Cache on the next SpMV:
+    // nontemporal loses 2 % at 340 MB (5-pt 2400^2), 15 % at 180-300 MB (power-law 3-5 M rows), 6-8 % on webbase-1M; it wins from 500 MB up (5-pt 2896^2 +4 %,
+    // power-law 8 M +8 %, 5-pt 3400^2 +10 %).  Descriptors, tasks and per-strip entry lists stay on the default policy (nontemporal: config 4 0.164 -> 0.170-0.173).
+    // profiles/r03_nontemporal_streams.txt.  Entry mode 1 = small grids; x-window plans are an opt-in experiment.
+    {
+        const long long launch_b = model_bytes + ((long long)colA + 16LL * ntr) * sv;
+        S.nt_stream = (entry_mode != 1 && !xwin && (K.nt_stream >= 0 ? K.nt_stream != 0 : launch_b > NT_STREAM_MIN_BYTES)) ? 1 : 0;
+    }
+    plan->info[TILESPMV_INFO_NT_STREAM] = S.nt_stream;
+    if (hashing()) {
+        Hash h;
+        for (long long v : {model_bytes, n_tasks, (long long)S.y_streaming, (long long)S.nt_stream, (long long)S.coo_ordered, (long long)plan->mv_slab_rows, (long long)plan->mv_by_columns, (long long)S.coo_heavy_min}) h.num(v);
+        stage_done(TILESPMV_STAGE_FINISH, h);
+    }
+}
+
+}  // namespace
+
+int tilespmv::build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,
+                           bool dense_mfma, const std::vector<long long> &hyb_off,
+                           std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes)
+{
+    StreamBuilder B(plan, K, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mfma, hyb_off, fix, npartial);
+    B.count();
+    if (B.rc) return B.rc;
+    B.choose();
+    B.cut();
+    B.emit();
+    B.order();
+    B.encode();
+    if (B.rc == -2) return B.rc;   // (shard too large for 32-bit unit ids)
+    B.entries();
+    B.finish(n_tasks, model_bytes);
+    return B.rc;
+}
