@@ -610,6 +610,43 @@ def test_inline_fixup_of_split_rows_is_stable_across_launches(torch_cuda, monkey
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_slab_paced_entry_phase_bit_exact(torch_cuda, dtype):
+    """Round 4: the workgroup entry mode with slab pacing (teams of co-resident workgroups gather from the same few slabs of x at one time; pacing is
+    speed only).  Same lists, same adds: the oracle's y bit for bit — with slabs so small that the test matrices have hundreds, teams of one
+    workgroup up to more than the grid holds, windows of 1-3 slabs, ordered and unordered adds, no patience at all (every team gives up), and
+    launch after launch on one plan (the last wavefront of a team zeroes its counters)."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    O = CpuImpl("oracle", dtype)
+    mats = {"powerlaw200k": MEDIUM["powerlaw200k"], "bandrand60k": lambda: G.band_plus_random(60000, 4, 3, 5), "uniform40k": lambda: G.uniform_per_row(40000, 70001, 8, 1),
+            "allfmt": SMALL["allfmt"], "one_long_row": SMALL["one_long_row"], "empty_rows": SMALL["empty_rows"], "circuit60k": MEDIUM["circuit60k"]}
+    knob_sets = [dict(pace_slab_kb=1), dict(pace_slab_kb=1, pace_window=1, pace_team=1), dict(pace_slab_kb=2, pace_window=3, pace_team=3, entry_ordered=0),
+                 dict(pace_slab_kb=16, pace_team=192, entry_ordered=1), dict(pace_slab_kb=1, pace_spins=1, pace_team=2), dict(pace_slab_kb=4, nt_stream=1, desc_dict=0),
+                 dict(pace_slab_kb=1, strip_cost=64, split_above=200), dict(pace_slab_kb=8, xcd_remap=0, pace_team=2, strip_cost=100)]
+    paced = 0
+    for name, gen in mats.items():
+        m, n, rp, ci = gen()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, x = values_for(name, nnz, n, dtype)
+        want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, x)["y"]
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=True)
+        for kw in knob_sets:
+            y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, entry_mode=2, pace=1, **kw)
+            assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
+            paced += info["pace_slabs"] > 0
+            assert info["pace_slabs"] == 0 or info["pace_slabs"] == -(-n // max(256, kw["pace_slab_kb"] * 1024 // np.dtype(dtype).itemsize)), (name, kw, info["pace_slabs"])
+        # one plan, many launches: counters come back to zero every time (a stale counter would only cost speed, so look at the bits AND at the time of launch 50 vs launch 1)
+        plan = api.Plan(tp, rowA, n, nnz, entry_mode=2, pace=1, pace_slab_kb=1, pace_team=4)
+        xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda(); yd = torch_cuda.zeros(rowA + 16, dtype=xd.dtype, device="cuda")
+        for it in range(50):
+            yd.fill_(7.0); plan.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()
+            assert np.array_equal(yd.cpu().numpy()[:rowA], want), (name, "launch", it)
+        plan.close()
+        api.Tile_destroy(tp)
+    assert paced >= 40
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
     """Round 3: packed entry records in every entry mode, 512-thread workgroups, x windows (brick task order + LDS-staged x
     segments, strides detected from the matrix) and the resident-workgroup cap — all passed as plan options, none through the

@@ -457,6 +457,105 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
     }
 }
 
+// ---- slab-paced form of the workgroup entry phase (k_units<.., PACE = true>; DevStream::pace, hip_plan.h).  Same merged, column-ordered list, same
+// records, same adds in the same order; what changes is WHEN a wavefront issues the gathers of a 64-record chunk.  The columns are cut into slabs of
+// 2^pace_shift columns (about 1 MB of x).  The workgroups one XCD holds at one time are a team (blockIdx.x & 7 = the XCD under the round-robin
+// dispatch, (blockIdx.x >> 3) / pace_twg = the team's generation); fin[s] counts the team's wavefronts that have issued every gather of theirs
+// below slab s + 1.  A wavefront whose next chunk starts in slab `lo` first reports the slabs below `lo` as finished, then waits until slab
+// min(hi, lo + win - 1) is open — slab s is open once fin[s - win] has reached the team's wavefront count, i.e. nobody in the team is still below
+// slab s - win + 1.  The team's gathers therefore fall into `win` consecutive slabs at any time; those stay in the XCD's 4-MB L2, where today every
+// scattered gather of a large matrix pulls a 128-byte line across the fabric for 8 useful bytes (band + random fill, 2 M rows: 739 MB moved for a
+// 284 MB plan; uniform random 8 M rows: 7.7 GB for 0.9 GB — profiles/r04_pmc_*_before.json).  The wavefront that is furthest behind never waits
+// (its window is open by construction), so the team always advances; every wait is bounded all the same (pace_spins polls, then the team is
+// declared broken and everybody runs unpaced), and no result depends on a counter: pacing is speed only.  Counters are agent-scope atomics; the
+// last wavefront of a team to finish zeroes them for the next launch.
+template <int CT, bool NTL>
+__device__ __forceinline__ void wg_entry_paced(const DevStream &S, const ERec *__restrict__ rec, const unsigned *__restrict__ base, int chunk0, int db, bool ordered,
+                                               const val_t *__restrict__ x, lacc_t *sy, int tid, int gb, int ge, unsigned *__restrict__ team, unsigned team_waves)
+{
+    constexpr int NT = 256;
+    const unsigned dmask = (1u << db) - 1u;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int nslab = S.pace_nslab, shift = S.pace_shift, win = S.pace_win, max_spins = S.pace_spins;
+    const int nchunk = (ge - gb + 63) >> 6;              // chunks of this list; base[chunk0 + nchunk] = the list's last column (sentinel)
+    int passed = 0;                                      // slabs [0, passed) reported finished by this wavefront
+    int allowed = win - 1;                               // slabs <= allowed are known to be open
+    bool paced = true;
+    auto report = [&](int upto) {                        // wave-uniform
+        while (passed < upto) {
+            const int n = min(64, upto - passed);
+            if (lane < n) __hip_atomic_fetch_add(&team[passed + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            passed += n;
+        }
+    };
+    auto open_until = [&](int need) {                    // wave-uniform; returns once slab `need` is open or pacing has been given up
+        int spins = 0;
+        while (paced && allowed < need) {
+            // lane i < 63 looks at the counter that opens slab allowed + 1 + i, lane 63 at the team's broken flag: one load instruction per poll
+            const int sl = allowed + 1 + lane;
+            unsigned v = team_waves;
+            if (lane == 63) v = __hip_atomic_load(&team[nslab], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (sl < nslab) v = __hip_atomic_load(&team[sl - win], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long ok = __ballot(lane < 63 && v >= team_waves);
+            if (__builtin_amdgcn_readlane((int)v, 63) != 0) { paced = false; break; }
+            allowed += (int)__builtin_ctzll(~ok);        // leading lanes whose slab is open
+            if (allowed >= need) break;
+            if (++spins > max_spins) {                   // somebody of the team is not coming (not resident, or far behind): stop waiting, all of us
+                if (lane == 0) __hip_atomic_store(&team[nslab], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                paced = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    };
+    for (int e0 = gb; e0 < ge; e0 += NT * CT) {
+        ERec rr[CT]; unsigned cb[CT], cnext[CT]; val_t xx[CT];
+#pragma unroll
+        for (int q = 0; q < CT; q++) {                   // unconditional, clamped: exact vmcnt
+            if constexpr (NTL) {
+                const unsigned *pw = reinterpret_cast<const unsigned *>(&rec[min(e0 + NT * q + tid, ge - 1)]);
+                unsigned *rw = reinterpret_cast<unsigned *>(&rr[q]);
+#pragma unroll
+                for (int z = 0; z < (int)(sizeof(ERec) / 4); z++) rw[z] = __builtin_nontemporal_load(pw + z);
+            } else rr[q] = rec[min(e0 + NT * q + tid, ge - 1)];
+            const int c = __builtin_amdgcn_readfirstlane(min(((e0 - gb) >> 6) + (NT / 64) * q + wave, nchunk - 1));
+            cb[q] = base[chunk0 + c];
+            cnext[q] = base[chunk0 + c + 1];             // first column of the next chunk (>= every column of this one), or the sentinel
+        }
+#pragma unroll
+        for (int q = 0; q < CT; q++) {
+            if (paced && e0 + NT * q + 64 * wave < ge) { // this wavefront's chunk exists (wave-uniform)
+                const int lo = (int)(cb[q] >> shift), hi = (int)(cnext[q] >> shift);
+                report(lo);
+                open_until(min(hi, lo + win - 1));
+            }
+            xx[q] = x[(size_t)(cb[q] + (rr[q].w >> db))];
+        }
+        if (ordered) {
+            for (int w = 0; w < NT / 64; w++) {
+                if (wave == w) {
+#pragma unroll
+                    for (int q = 0; q < CT; q++)
+                        if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
+                }
+                __syncthreads();
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < CT; q++)
+                if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
+        }
+    }
+    // this wavefront is through: the remaining slabs count as finished, and the last wavefront of the team resets the counters for the next launch
+    report(nslab);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the adds above have been acknowledged before `done` is bumped)
+    unsigned prev = 0;
+    if (lane == 0) prev = __hip_atomic_fetch_add(&team[nslab + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
+    if (prev == team_waves - 1u)
+        for (int i = lane; i < nslab + 2; i += 64) __hip_atomic_store(&team[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ================================================================================================
 // Very-sparse fallback: y[row] += sum_j val[j] * x[col[j]] over the extracted matrix (the reference hands it to CSR5,
 // src/tilespmv_cuda.h:1011-1029,:1080; kernels src/external/CSR5_cuda/detail/cuda/csr5_spmv_cuda.h:277-420).
@@ -514,7 +613,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
 // CD: dictionary plans (4-B descriptors, above).  The descriptor words are loaded two chunks ahead, the pattern of a chunk is
 // gathered from the dictionary one chunk ahead (when its word has arrived), so neither hop is waited for in the unit loop.
 // NTS: value and entry-record loads are nontemporal (plans larger than the Infinity Cache, DevStream::nt_stream).
-template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD, bool NTS>
+// PACE: slab-paced workgroup entry phase (wg_entry_paced above; ECOO = 2, 256-thread workgroups, no x windows).
+template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD, bool NTS, bool PACE = false>
 __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
@@ -523,6 +623,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     static_assert(!XWIN || (GPB == 16 && ECOO != 1), "x windows: 256-thread workgroups, per-strip or per-workgroup entries");
     static_assert(!(XWIN && CD), "x-window plans keep 12-B descriptors (their low bits hold window slots)");
     static_assert(!(NTS && (XWIN || ECOO == 1)), "nontemporal streams: large plans only (entry mode 1 = small grids; x windows are an opt-in experiment)");
+    static_assert(!PACE || (ECOO == 2 && GPB == 16 && !XWIN), "slab pacing: workgroup entry mode, 256-thread workgroups, no x windows");
     constexpr int GROUPS_PER_BLOCK = GPB;
     constexpr int SROWS = XWIN ? XWIN_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
     constexpr bool NT = NTS;  // nontemporal value loads
@@ -650,7 +751,15 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         // pipelined trips on top of that (78 VGPRs at 6 x 256, no spill): 0.1050-0.1062 against 0.1031-0.1046 — slightly worse
         unit_prologue();
         TSPMV_STAMP_WAIT(2);   // prologue has arrived (the entry loads are inside the trips)
-        if (wr.y > wr.x) {
+        if constexpr (PACE) {
+            // every wavefront of every workgroup takes part (a workgroup without entries reports all slabs as finished right away)
+            const unsigned xcd = blockIdx.x & 7u, gen = (blockIdx.x >> 3) / (unsigned)S.pace_twg;
+            const unsigned on_xcd = (gridDim.x - xcd + 7u) >> 3;           // workgroups of this launch on this XCD
+            const unsigned team_wgs = min((unsigned)S.pace_twg, on_xcd - gen * (unsigned)S.pace_twg);
+            unsigned *team = S.pace + (size_t)(xcd * (unsigned)S.pace_ngen + gen) * (size_t)(S.pace_nslab + 2);
+            wg_entry_paced<WCOO_HEAVY_CT, NTS>(S, S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y, team, team_wgs * 4u);
+            if (wr.y > wr.x) __syncthreads();
+        } else if (wr.y > wr.x) {
             wg_entry_trips<WCOO_HEAVY_CT, 16 * GPB, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y);
             __syncthreads();
         }
@@ -1492,11 +1601,26 @@ hipError_t launch_columns_to_rows(const val_t *YT, int nvec, long long row0, lon
     return hipGetLastError();
 }
 
+int paced_team_workgroups(bool dict_desc, bool nt_stream, int xcd_remap, int lds_pad_bytes)
+{
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    hipError_t e;
+#define TSPMV_OCC(X, CD, NTS) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_units<TILESPMV_UB, X, 2, 16, false, CD, NTS, true>, 256, (size_t)lds_pad_bytes)
+    if (xcd_remap == 2) { if (dict_desc) { if (nt_stream) TSPMV_OCC(2, true, true); else TSPMV_OCC(2, true, false); } else { if (nt_stream) TSPMV_OCC(2, false, true); else TSPMV_OCC(2, false, false); } }
+    else { if (dict_desc) { if (nt_stream) TSPMV_OCC(0, true, true); else TSPMV_OCC(0, true, false); } else { if (nt_stream) TSPMV_OCC(0, false, true); else TSPMV_OCC(0, false, false); } }
+#undef TSPMV_OCC
+    if (e != hipSuccess || per_cu <= 0) return 0;
+    return per_cu * std::max(1, prop.multiProcessorCount / 8);   // 8 XCDs on gfx950
+}
+
 hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xwin_lds_bytes, int lds_pad_bytes, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st)
 {
     if (S.ntasks > 0) {
-#define TSPMV_L4(X, W, B, XW, CD, NTS) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, B, XW, CD, NTS>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_L5(X, W, B, XW, CD, NTS, PC) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, B, XW, CD, NTS, PC>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_L4(X, W, B, XW, CD, NTS) do { if ((W) == 2 && (B) == 16 && !(XW) && S.pace != nullptr) TSPMV_L5(X, W, B, XW, CD, NTS, ((W) == 2 && (B) == 16 && !(XW))); else TSPMV_L5(X, W, B, XW, CD, NTS, false); } while (0)
 #define TSPMV_L3(X, W, B, CD) do { if (S.nt_stream) TSPMV_L4(X, W, B, false, CD, true); else TSPMV_L4(X, W, B, false, CD, false); } while (0)
 #define TSPMV_L2(X, W, B) do { if (S.cb_bits > 0) TSPMV_L3(X, W, B, true); else TSPMV_L3(X, W, B, false); } while (0)
 #define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L4(X, 2, 16, true, false, false); else if (xwin_lds_bytes > 0) TSPMV_L4(X, 0, 16, true, false, false); \
@@ -1507,6 +1631,7 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
 #undef TSPMV_L2
 #undef TSPMV_L3
 #undef TSPMV_L4
+#undef TSPMV_L5
     }
     // whole-tile passes (y += ...): CSR tiles kept as tiles, dense tiles on the matrix cores; then the split-row fix-up
     hipError_t e = launch_tiles_direct(P, dense_mfma, /*accumulate=*/true, /*fixup=*/false, x, y, st);

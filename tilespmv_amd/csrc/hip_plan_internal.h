@@ -58,6 +58,8 @@ struct Knobs {
     int mv_native;       // -1 = by nvec
     int mv_xcd_chunk;    // -1 = the plan's XCD chunk
     int nt_stream;       // -1 by size, 0 plain, 1 nontemporal loads of the value / entry-record streams
+    int pace;            // slab pacing of the workgroup entry mode: -1 by rule, 0 off, 1 on
+    int pace_slab_kb, pace_window, pace_team, pace_spins;
     int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
     bool dry;            // tilespmv_plan_layout_digest: build the layout on the host only, hash instead of upload
@@ -275,6 +277,9 @@ inline bool pack_list(const std::vector<PEnt> &ents, int dest_bits, std::vector<
     }
     return j == ents.size() && base.size() - base0 == (rec.size() - rec0 + ECHUNK - 1) / ECHUNK;
 }
+
+// Workgroups of the slab-paced unit kernel one XCD holds at one time (occupancy query on the current device; hip_kernels.hip)
+int paced_team_workgroups(bool dict_desc, bool nt_stream, int xcd_remap, int lds_pad_bytes);
 
 // Second-generation layout (hip_plan_stream.hip): fills plan->st / plan->dn / the whole-tile pass of plan->dev for tile-rows [tr0, tr1).
 int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,

@@ -121,6 +121,7 @@ struct StreamBuilder {
     bool fix_inline_on = true, entry_heavy = false, entry_dominated = false, wave_coo = false, coo_ordered = false, brick = false, xwin = false;
     long long total_cost = 0, est_wgs = 0;
     int target = 0, entry_mode = 0, wg_strips = 16, xs1 = 0, xs2 = 0, max_strip_rows = STRIP_MAX_ROWS;
+    bool pace_on = false; int pace_shift = 0, pace_nslab = 0;   // slab-paced entry phase (hip_plan.h DevStream::pace)
     // CUT
     std::vector<STask> tasks;
     std::vector<Task> htasks;
@@ -269,8 +270,24 @@ void StreamBuilder::choose()
     // (strips of at most 4 tile-rows in brick plans: nlpkkt160 stand-in fp64 0.418 -> 0.414 ms, fp32 0.252 -> 0.250 in one process; 2 rows: KKT 0.408 but 7-pt 256^3 +5 %)
     max_strip_rows = xwin ? XWIN_STRIP_ROWS : brick ? (K.brick_rows > 0 ? std::min(K.brick_rows, STRIP_MAX_ROWS) : 4) : STRIP_MAX_ROWS;
     if (brick && !K.xcd_from_caller) plan->xcd_chunk = 8;   // bricks are compact: smaller XCD windows keep an XCD's resident set together
+    // ---- slab pacing of the workgroup entry mode (hip_plan.h DevStream::pace): worth it where scattered gathers miss the XCD's L2 — x clearly larger than
+    // an L2 — on shards that fill the chip (the teams are what one XCD holds at one time) with enough entries to pay for the bookkeeping
+    {
+        const long long x_bytes = (long long)colA * sv;
+        pace_on = entry_mode == 2 && wg_strips == 16 && !xwin && (K.pace > 0 || (K.pace < 0 && x_bytes >= (8ll << 20) && NC >= (4ll << 20) && est_wgs >= 1024));
+        if (pace_on) {
+            long long cols_per_slab = std::max<long long>(256, (long long)std::max(1, K.pace_slab_kb) * 1024 / sv);
+            pace_shift = 0;
+            while ((2ll << pace_shift) <= cols_per_slab) pace_shift++;
+            while ((((long long)colA - 1) >> pace_shift) + 1 > 4096) pace_shift++;          // a wavefront reports every slab it passes: keep their number bounded
+            pace_nslab = (int)((((long long)std::max(1, colA) - 1) >> pace_shift) + 1);
+            if (pace_nslab <= K.pace_window) pace_on = false;                               // everything is inside one window anyway
+        }
+        if (!pace_on) pace_shift = pace_nslab = 0;
+    }
     if (hashing()) {
         Hash h;
+        h.num(pace_on); h.num(pace_shift); h.num(pace_nslab);
         for (long long v : {(long long)target, (long long)entry_mode, (long long)wg_strips, (long long)coo_ordered, (long long)xs1, (long long)xs2, (long long)brick, (long long)xwin, (long long)max_strip_rows}) h.num(v);
         stage_done(TILESPMV_STAGE_CHOOSE, h);
     }
@@ -777,6 +794,7 @@ void StreamBuilder::entries()
                     ents[i] = PEnt{(unsigned)h_ccol[(size_t)q], key[i].second, h_cval[q]};
                 }
                 if (!pack_list(ents, dest_bits, grp_rec[(size_t)w], grp_base[(size_t)w], plan->dry)) bad++;
+                if (pace_on) grp_base[(size_t)w].push_back(ents.empty() ? 0u : ents.back().col);   // paced lists: one more base word = the list's last column (the "next chunk" of the last chunk)
             }
         });
         if (bad.load()) { fprintf(stderr, "tilespmv: internal error: %d packed entry lists do not decode to their entries\n", bad.load()); rc = -6; }
@@ -876,6 +894,20 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
         S.nt_stream = (entry_mode != 1 && !xwin && (K.nt_stream >= 0 ? K.nt_stream != 0 : launch_b > NT_STREAM_MIN_BYTES)) ? 1 : 0;
     }
     plan->info[TILESPMV_INFO_NT_STREAM] = S.nt_stream;
+    // ---- slab pacing: team counters (fin[nslab], broken, done per team; zero between launches)
+    S.pace = nullptr; S.pace_shift = 0; S.pace_nslab = 0; S.pace_win = 0; S.pace_twg = 0; S.pace_ngen = 0; S.pace_spins = 0;
+    if (pace_on && !tasks.empty()) {
+        const long long grid = ((long long)tasks.size() + 15) / 16, on_xcd0 = (grid + 7) / 8;
+        int twg = K.pace_team > 0 ? K.pace_team : (plan->dry ? 0 : paced_team_workgroups(S.cb_bits > 0, S.nt_stream != 0, plan->xcd_remap, plan->lds_pad_bytes));
+        if (twg <= 0) twg = 192;   // (6 workgroups on each of an XCD's 32 CUs: what the kernel is built for)
+        const long long ngen = (on_xcd0 + twg - 1) / twg;
+        std::vector<unsigned> zeros((size_t)(8 * ngen * (pace_nslab + 2)), 0u);
+        const unsigned *cnt = nullptr;
+        rc |= plan->upload(zeros.data(), zeros.size(), &cnt);
+        S.pace = const_cast<unsigned *>(cnt);
+        S.pace_shift = pace_shift; S.pace_nslab = pace_nslab; S.pace_win = K.pace_window; S.pace_twg = twg; S.pace_ngen = (int)ngen; S.pace_spins = K.pace_spins;
+        plan->info[TILESPMV_INFO_PACE_SLABS] = pace_nslab; plan->info[TILESPMV_INFO_PACE_TEAM] = twg;
+    }
     if (hashing()) {
         Hash h;
         for (long long v : {model_bytes, n_tasks, (long long)S.y_streaming, (long long)S.nt_stream, (long long)S.coo_ordered, (long long)plan->mv_slab_rows, (long long)plan->mv_by_columns, (long long)S.coo_heavy_min}) h.num(v);
