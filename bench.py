@@ -327,6 +327,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--extras", default=None, help="comma-separated keys of `other_workloads` to run (default: all)")
     ap.add_argument("--setup-launches", type=int, default=200,
                     help="untimed SpMVs issued before the steady-state measurement (the reference warms up with 200 launches, "
                          "src/tilespmv_cuda.h:1059-1082).  The plain protocol (W warm-ups, K steps, nothing else) is measured FIRST and reported beside it")
@@ -343,8 +344,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:  # one process per GPU shares the host cores: keep the preprocessing threads per rank modest
-        os.environ.setdefault("TILESPMV_NUM_THREADS", str(max(2, min(16, (os.cpu_count() or 16) // world))))
+    if world > 1:  # one process per GPU shares the host cores: this rank's share of what the job may really use (affinity mask and cgroup quota, not os.cpu_count())
+        os.environ.setdefault("TILESPMV_NUM_THREADS", str(max(1, min(16, usable_cores() // world))))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -512,11 +513,15 @@ def main():
                 "plan_stream_bytes_per_launch": info["stream_bytes"], "plan_fingerprint": fingerprint, "timing": "hip events on the launch stream, timed region"}
     # `achieved` is priced on the CSR-model bytes SURVEY S8(d) defines (nnz (s_v + 4) + 4 (m + 1) + s_v (n + m)); the tiled plan itself moves fewer
     # (4-bit tile-local columns, 4-B unit descriptors), so that rate can pass the pin bandwidth.  The same launch by the plan's own bytes:
+    # ... and by the bytes NO lossless format of this matrix can avoid: every value once, x once, y once (s_v nnz + s_v (n + m)) — a fraction that cannot pass 1
+    min_bytes_launch = dtype.itemsize * (sh.local_nnz + n + sh.local_rows)
+    roofline["min_bytes_per_launch"] = int(min_bytes_launch)
+    roofline["frac_min_bytes"] = round(min_bytes_launch / (kernel_ms * 1e-3) * 1e-9 / HBM_PEAK_GBPS, 4)
     roofline["plan_bytes_gbps"] = round(info["stream_bytes"] / (kernel_ms * 1e-3) * 1e-9, 1)
     roofline["frac_by_plan_bytes"] = round(info["stream_bytes"] / (kernel_ms * 1e-3) * 1e-9 / HBM_PEAK_GBPS, 4)
-    if achieved > HBM_PEAK_GBPS:
-        roofline["note"] = ("frac > 1: the kernel finishes sooner than 8 TB/s could move the CSR-model bytes, because the plan's streams are %.0f %% of them; "
-                            "see plan_bytes_gbps / frac_by_plan_bytes and, when present, actual_traffic_gbps (counter bytes)" % (100.0 * info["stream_bytes"] / b_alg_launch))
+    roofline["note"] = ("`frac` prices the launch on SURVEY S8(d)'s CSR-model bytes (kept for continuity); the tiled plan's streams are %.0f %% of them, so `frac` can pass 1. "
+                        "Read `frac_min_bytes` (values + x + y only: bounded by 1), `frac_by_plan_bytes` and, when present, actual_traffic_gbps (counter bytes) as efficiencies"
+                        % (100.0 * info["stream_bytes"] / b_alg_launch))
 
     device_state = None
     if rank == 0 and world == 1:
@@ -627,13 +632,29 @@ def main():
         del xd, yd
         torch.cuda.empty_cache()
         out["other_workloads"] = {}
-        for wl, dt2 in (("scircuit", dtype), ("webbase", dtype), ("nlpkkt160", np.dtype(np.float32))):
+        f32_, f64_ = np.dtype(np.float32), np.dtype(np.float64)
+        # key, bench workload, dtype, class ("small": cache-resident BASELINE configs, both COO modes; "large": HBM-bound), also on real-valued data?
+        # configs 2, 3, 5 first; then what the north star names beside them — synthetic banded / power-law matrices — and the >= 10 M-nnz irregular / mixed class
+        specs = [("scircuit", "scircuit", dtype, "small", True), ("webbase", "webbase", dtype, "small", True), ("nlpkkt160", "nlpkkt160", f32_, "large", True),
+                 ("nlpkkt160_f64", "nlpkkt160", f64_, "large", False), ("lap3d256", "lap3d256", f64_, "large", False), ("band40_2m", "band40_2000000", f64_, "large", False),
+                 ("powerlaw8m", "powerlaw8000000", f64_, "large", False), ("bandrand4x3_2m", "bandrand4x3_2000000", f64_, "large", False),
+                 ("uniform8_4m", "uniform8_4000000", f64_, "large", False)]
+        if args.extras:
+            keep = set(args.extras.split(","))
+            specs = [sp_ for sp_ in specs if sp_[0] in keep]
+        built = {}
+        t_extras = time.time()
+        for key, wl, dt2, klass, also_real in specs:
             try:
                 from tilespmv_amd.tile_matrix import field_array
                 import scipy.sparse as sp
-                small = wl != "nlpkkt160"
+                t_wl = time.time()
+                small = klass == "small"
                 td2 = torch.float64 if dt2 == np.float64 else torch.float32
-                m2, n2, rp2, ci2, src2 = build_matrix(wl)
+                if wl not in built:
+                    built.clear()           # (one structure at a time: the KKT stand-in serves its fp32 and fp64 entries)
+                    built[wl] = build_matrix(wl)
+                m2, n2, rp2, ci2, src2 = built[wl]
                 r2 = (m2 // 16) * 16; nz2 = int(rp2[r2])
                 v2, x2 = G.compat_values(len(ci2), dt2), G.compat_x(n2, dt2)
                 # config 2 must exercise all seven tile formats: HYB is only reachable with the opt-in rule
@@ -641,8 +662,10 @@ def main():
                 hist = np.bincount(field_array(tm2, "Format", tm2.tilenum), minlength=7).tolist()
                 ref2 = sp.csr_matrix((v2[:nz2], ci2[:nz2], rp2[:r2 + 1]), shape=(r2, n2)).astype(np.float64) @ x2.astype(np.float64)
                 b2 = api.algorithmic_bytes(nz2, r2, n2, dt2.itemsize)
-                rec = {"source": src2, "dtype": "f64" if dt2 == np.float64 else "f32", "rows": r2, "nnz": nz2,
+                bmin2 = dt2.itemsize * (nz2 + n2 + r2)          # values + x + y: what no lossless format can avoid
+                rec = {"workload": wl, "source": src2, "stand_in": not src2.startswith("file:"), "dtype": "f64" if dt2 == np.float64 else "f32", "rows": r2, "nnz": nz2,
                        "tile_format_histogram[csr,coo,ell,hyb,dns,dnsrow,dnscol]": hist,
+                       "algorithmic_bytes": int(b2), "min_bytes": int(bmin2),
                        "note": ("cache-resident: launch/latency-bound, roofline time %.1f us" % (b2 / 8e12 * 1e6)) if small
                                else "HBM-bound; integer-valued data, checked exactly against scipy CSR"}
                 xd2 = torch.from_numpy(x2).cuda()
@@ -651,15 +674,18 @@ def main():
                     p2 = api.Plan(tm2, r2, n2, nz2, coo_mode=coo)
                     yd2 = torch.zeros(r2 + 16, dtype=td2, device="cuda")
                     ms2 = p2.time(xd2.data_ptr(), yd2.data_ptr(), stream.cuda_stream, warmup=20, reps=200 if small else 50)
+                    i2 = p2.info()
                     if label != "coo_csr_fallback":   # the plan the committed counter passes of this workload measured
-                        fp2 = {k: p2.info()[k] for k in FP_KEYS}
+                        fp2 = {k: i2[k] for k in FP_KEYS}
                     ok2 = bool(np.array_equal(yd2.cpu().numpy()[:r2].astype(np.float64), ref2))
                     rec[label] = {"ms_per_spmv": round(ms2, 5), "gflops": round(2.0 * nz2 / ms2 * 1e-6, 1),
                                   "hbm_gbps_algorithmic": round(b2 / ms2 * 1e-6, 1), "frac_of_8TBps": round(b2 / ms2 * 1e-6 / HBM_PEAK_GBPS, 4),
-                                  "check": "pass" if ok2 else "FAIL", "fallback_nnz": p2.info()["fallback_nnz"],
-                                  "entry_mode": p2.info()["entry_mode"], "sums_bit_reproducible": bool(p2.info()["entry_ordered"]),
-                                  "strip_cost": p2.info()["strip_cost"], "tasks": p2.info()["num_tasks"]}
-                    if label in ("coo_in_tile", "default_plan"):   # the same plan on real-valued data: the time does not depend on the values
+                                  "frac_min_bytes": round(bmin2 / ms2 * 1e-6 / HBM_PEAK_GBPS, 4), "frac_by_plan_bytes": round(i2["stream_bytes"] / ms2 * 1e-6 / HBM_PEAK_GBPS, 4),
+                                  "check": "pass" if ok2 else "FAIL", "fallback_nnz": i2["fallback_nnz"],
+                                  "entry_mode": i2["entry_mode"], "sums_bit_reproducible": bool(i2["entry_ordered"]),
+                                  "strip_cost": i2["strip_cost"], "tasks": i2["num_tasks"], "pace_slabs": i2["pace_slabs"], "nt_stream": i2["nt_stream"],
+                                  "placement_tries": i2["placement_tries"]}
+                    if also_real and label in ("coo_in_tile", "default_plan"):   # the same plan on real-valued data: the time does not depend on the values
                         vr, xr = G.real_values(len(ci2), dt2), G.real_x(n2, len(ci2), dt2)
                         tmr = api.Tile_create(r2, n2, nz2, rp2, ci2, vr, dtype=dt2, hyb=(wl == "scircuit"))
                         pr = api.Plan(tmr, r2, n2, nz2, coo_mode=coo)
@@ -680,11 +706,16 @@ def main():
                     fresh2 = t2.get("plan_fingerprint") == fp2
                     rec["traffic"] = {"hbm_bytes_per_launch": t2.get("hbm_bytes_per_launch") if fresh2 else None, "kernel": t2.get("kernel"), "measured": t2.get("measured"),
                                       "file": os.path.relpath(tj2, ROOT), "live": False, "plan_fingerprint_matches": fresh2}
-                out["other_workloads"][wl] = rec
+                else:
+                    rec["traffic"] = None
+                rec["seconds"] = round(time.time() - t_wl, 1)
+                out["other_workloads"][key] = rec
                 api.Tile_destroy(tm2)
                 del m2, n2, rp2, ci2, v2, x2, ref2, xd2
             except Exception as e:  # never let an extra break the headline line
-                out["other_workloads"][wl] = {"error": repr(e)}
+                out["other_workloads"][key] = {"error": repr(e)}
+        built.clear()
+        out["other_workloads_seconds"] = round(time.time() - t_extras, 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rows, n, rowptr, colidx, vals, x, dtype)
     elif rank == 0:

@@ -293,13 +293,14 @@ typedef struct {
                            are few; 0 = always the 12-B form                                                                   TILESPMV_DESC_DICT */
     int nt_stream;      /* value / entry-record / dense-tile loads: 1 nontemporal, 0 default cache policy; unset: nontemporal where one SpMV moves more
                            than 400 MB (about 1.6 x the Infinity Cache)                                                             TILESPMV_NT_STREAM */
-    int pace;           /* slab pacing of the workgroup entry mode (round 4): the workgroups one XCD holds at one time gather from the same few ~1-MB slabs
-                           of x at the same time, so that scattered gathers hit the XCD's L2; 1 on, 0 off, unset: on for entry-heavy shards whose x does
-                           not fit an L2 and whose grid fills the chip several times over                                         TILESPMV_PACE */
+    int pace;           /* slab pacing of the workgroup entry mode (round 4): the workgroups one XCD holds at one time sweep x by a common timetable, so that
+                           their scattered gathers fall into the same few ~1-MB slabs, which stay in the XCD's L2; 1 on, 0 off, unset: tried on entry-heavy
+                           shards whose x does not fit an L2 (and kept only if the calibration finds it faster)                    TILESPMV_PACE */
     int pace_slab_kb;   /* ... KB of x per slab (power of two; unset: 1024)                                   TILESPMV_PACE_SLAB_KB */
-    int pace_window;    /* ... slabs a team may be spread over (unset: 2)                                     TILESPMV_PACE_WINDOW */
+    int pace_window;    /* ... slabs a wavefront may be ahead of the timetable, plus one (unset: 2)           TILESPMV_PACE_WINDOW */
     int pace_team;      /* ... workgroups per team and XCD (unset: what the occupancy query says one XCD holds)  TILESPMV_PACE_TEAM */
-    int pace_spins;     /* ... polls a wavefront waits for a slab before the team gives pacing up (unset: 200)  TILESPMV_PACE_SPINS */
+    int pace_period_us; /* ... microseconds one team's sweep over x is given (the timetable's length); unset: calibrated by timing at plan creation — and a
+                           plan that does not get faster is launched unpaced; 0: nobody waits                        TILESPMV_PACE_PERIOD_US */
     int reserved[2];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
@@ -402,7 +403,8 @@ enum {
     TILESPMV_INFO_PACE_SLABS = 22,        /* slab-paced entry phase: slabs of x the columns are cut into (0 = not paced) */
     TILESPMV_INFO_PACE_TEAM = 23,         /* ... workgroups per team and XCD */
     TILESPMV_INFO_PLACEMENT_TRIES = 24,   /* arena placements timed at plan creation (large plans; 0 / 1 = the first one was kept) */
-    TILESPMV_INFO_COUNT = 25
+    TILESPMV_INFO_PACE_PERIOD_US = 25,    /* ... microseconds of one team's timetable (0 = not paced) */
+    TILESPMV_INFO_COUNT = 26
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
 

@@ -106,10 +106,10 @@ def check(seed):
     if seed % 4 == 2: env["TILESPMV_NT_STREAM"] = "1"   # nontemporal value / entry-record loads (by rule only on launches above 400 MB)
     if seed % 3 == 1: env["TILESPMV_DESC_DICT"] = "0"   # 12-B unit descriptors (the default takes the 4-B dictionary form wherever the patterns are few)
     # round 4: slab-paced workgroup entry phase — tiny slabs (128 ... 2048 columns) so that the small fuzz matrices have many, teams of 1 ... 192 workgroups
-    # (a team larger than the grid is clamped), windows of 1-3 slabs, and sometimes next to no patience (the team then gives pacing up mid-launch)
+    # (a team larger than the grid is clamped), leads of 0-2 slabs, timetables of 0 (nobody waits), 20 and 200 microseconds
     if env.get("TILESPMV_WAVE_COO") == "2" and env.get("TILESPMV_WG_STRIPS") != "32" and seed % 3 != 2:
         env.update({"TILESPMV_PACE": "1", "TILESPMV_PACE_SLAB_KB": str([1, 2, 16, 4][(seed // 3) % 4]), "TILESPMV_PACE_WINDOW": str(1 + (seed // 5) % 3),
-                    "TILESPMV_PACE_TEAM": str([1, 2, 5, 192][(seed // 7) % 4]), "TILESPMV_PACE_SPINS": str([200, 1, 50][(seed // 11) % 3])})
+                    "TILESPMV_PACE_TEAM": str([1, 2, 5, 192][(seed // 7) % 4]), "TILESPMV_PACE_PERIOD_US": str([20, 0, 200][(seed // 11) % 3])})
     os.environ.update(env)
     for dt in (np.float64, np.float32):
         vals = rng.integers(1, 4, nnz).astype(dt)

@@ -457,59 +457,53 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
     }
 }
 
-// ---- slab-paced form of the workgroup entry phase (k_units<.., PACE = true>; DevStream::pace, hip_plan.h).  Same merged, column-ordered list, same
-// records, same adds in the same order; what changes is WHEN a wavefront issues the gathers of a 64-record chunk.  The columns are cut into slabs of
-// 2^pace_shift columns (about 1 MB of x).  The workgroups one XCD holds at one time are a team (blockIdx.x & 7 = the XCD under the round-robin
-// dispatch, (blockIdx.x >> 3) / pace_twg = the team's generation); fin[s] counts the team's wavefronts that have issued every gather of theirs
-// below slab s + 1.  A wavefront whose next chunk starts in slab `lo` first reports the slabs below `lo` as finished, then waits until slab
-// min(hi, lo + win - 1) is open — slab s is open once fin[s - win] has reached the team's wavefront count, i.e. nobody in the team is still below
-// slab s - win + 1.  The team's gathers therefore fall into `win` consecutive slabs at any time; those stay in the XCD's 4-MB L2, where today every
-// scattered gather of a large matrix pulls a 128-byte line across the fabric for 8 useful bytes (band + random fill, 2 M rows: 739 MB moved for a
-// 284 MB plan; uniform random 8 M rows: 7.7 GB for 0.9 GB — profiles/r04_pmc_*_before.json).  The wavefront that is furthest behind never waits
-// (its window is open by construction), so the team always advances; every wait is bounded all the same (pace_spins polls, then the team is
-// declared broken and everybody runs unpaced), and no result depends on a counter: pacing is speed only.  Counters are agent-scope atomics; the
-// last wavefront of a team to finish zeroes them for the next launch.
+// ---- slab-paced form of the workgroup entry phase (k_units<.., PACE = true>; DevStream::pace, hip_plan.h).  Same records, same adds in the same order as
+// wg_entry_trips; what changes is WHEN a wavefront issues the gathers of a 64-record chunk.  Why: on the large irregular matrices every scattered x gather
+// misses the XCD's 4-MB L2 and pulls a 128-byte line across the fabric for 8 useful bytes — band + random fill, 2 M rows: 739 MB moved for a 284-MB plan;
+// uniform random, 8 M rows: 7.7 GB for 0.9 GB, both at the fabric's 7 TB/s (profiles/r04_pmc_*_before.json) — while the same gathers run 4.5x faster when
+// x fits the L2 (profiles/r04_gather_locality.txt).  The lists are in column order, so every workgroup sweeps x from left to right; if the workgroups one
+// XCD holds at one time sweep TOGETHER, the x lines they want are the same few hundred KB at any moment and stay in that L2.
+// How: the columns are cut into slabs of 2^pace_shift columns (about 1 MB of x).  The workgroups an XCD holds at one time form a team (blockIdx.x & 7 = the
+// XCD under the round-robin dispatch, (blockIdx.x >> 3) / pace_twg = the team's generation).  A workgroup's list holds its LOCAL entries first (columns
+// around its own rows: shared with the neighbouring workgroups anyway; never paced), then the remote ones in column order.  The team follows a timetable:
+// slab s opens pace_sched[s] / 2^24 of pace_period after the team's start, where pace_sched is the share of the shard's remote entries left of slab s
+// (a slot as long as the slab has work) and the team's start is the constant 100-MHz clock (s_memrealtime) at which its first wavefront finished its
+// local entries (one compare-and-swap per wavefront).  A wavefront that is ahead of the timetable sleeps until the slab of its next chunk — less
+// pace_win - 1 slabs of lead — opens; one that is behind just goes on.  No counters are polled and nobody waits for anybody: a first version that counted
+// finished wavefronts per slab spent its time in the polls (every wait is a round trip to the memory side — atomics do not execute in the L2 on this
+// part — and hundreds of wavefronts polled one line: band + random 0.107 -> 1.33 ms).  pace_period is calibrated at plan creation by timing
+// (hip_plan.hip): a plan that does not get faster is launched unpaced.  Speed only: no result depends on the clock; every wait ends when its slot opens,
+// at the latest pace_period after the team's start.
+__device__ __forceinline__ unsigned pace_clock()
+{
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return (unsigned)t;
+}
+
 template <int CT, bool NTL>
 __device__ __forceinline__ void wg_entry_paced(const DevStream &S, const ERec *__restrict__ rec, const unsigned *__restrict__ base, int chunk0, int db, bool ordered,
-                                               const val_t *__restrict__ x, lacc_t *sy, int tid, int gb, int ge, unsigned *__restrict__ team, unsigned team_waves)
+                                               const val_t *__restrict__ x, lacc_t *sy, int tid, int gb, int ge, int remote_from, unsigned *__restrict__ team, unsigned team_waves)
 {
     constexpr int NT = 256;
     const unsigned dmask = (1u << db) - 1u;
     const int wave = tid >> 6, lane = tid & 63;
-    const int nslab = S.pace_nslab, shift = S.pace_shift, win = S.pace_win, max_spins = S.pace_spins;
+    const int shift = S.pace_shift, lead = S.pace_win - 1;
+    const unsigned period = S.pace_period;
     const int nchunk = (ge - gb + 63) >> 6;              // chunks of this list; base[chunk0 + nchunk] = the list's last column (sentinel)
-    int passed = 0;                                      // slabs [0, passed) reported finished by this wavefront
-    int allowed = win - 1;                               // slabs <= allowed are known to be open
-    bool paced = true;
-    auto report = [&](int upto) {                        // wave-uniform
-        while (passed < upto) {
-            const int n = min(64, upto - passed);
-            if (lane < n) __hip_atomic_fetch_add(&team[passed + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            passed += n;
+    unsigned t0 = 0;                                     // the team's start on the 100-MHz clock (0 = not asked yet)
+    auto team_start = [&]() {                            // wave-uniform; first caller of the team sets the start
+        unsigned now = pace_clock() | 1u, old = 0;
+        if (lane == 0) {
+            unsigned expect = 0u;
+            __hip_atomic_compare_exchange_strong(&team[0], &expect, now, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = expect;                                // 0: this wavefront set it
         }
-    };
-    auto open_until = [&](int need) {                    // wave-uniform; returns once slab `need` is open or pacing has been given up
-        int spins = 0;
-        while (paced && allowed < need) {
-            // lane i < 63 looks at the counter that opens slab allowed + 1 + i, lane 63 at the team's broken flag: one load instruction per poll
-            const int sl = allowed + 1 + lane;
-            unsigned v = team_waves;
-            if (lane == 63) v = __hip_atomic_load(&team[nslab], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else if (sl < nslab) v = __hip_atomic_load(&team[sl - win], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long ok = __ballot(lane < 63 && v >= team_waves);
-            if (__builtin_amdgcn_readlane((int)v, 63) != 0) { paced = false; break; }
-            allowed += (int)__builtin_ctzll(~ok);        // leading lanes whose slab is open
-            if (allowed >= need) break;
-            if (++spins > max_spins) {                   // somebody of the team is not coming (not resident, or far behind): stop waiting, all of us
-                if (lane == 0) __hip_atomic_store(&team[nslab], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                paced = false;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(16);
-        }
+        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+        t0 = old ? old : now;
     };
     for (int e0 = gb; e0 < ge; e0 += NT * CT) {
-        ERec rr[CT]; unsigned cb[CT], cnext[CT]; val_t xx[CT];
+        ERec rr[CT]; unsigned cb[CT]; val_t xx[CT];
 #pragma unroll
         for (int q = 0; q < CT; q++) {                   // unconditional, clamped: exact vmcnt
             if constexpr (NTL) {
@@ -518,16 +512,21 @@ __device__ __forceinline__ void wg_entry_paced(const DevStream &S, const ERec *_
 #pragma unroll
                 for (int z = 0; z < (int)(sizeof(ERec) / 4); z++) rw[z] = __builtin_nontemporal_load(pw + z);
             } else rr[q] = rec[min(e0 + NT * q + tid, ge - 1)];
-            const int c = __builtin_amdgcn_readfirstlane(min(((e0 - gb) >> 6) + (NT / 64) * q + wave, nchunk - 1));
-            cb[q] = base[chunk0 + c];
-            cnext[q] = base[chunk0 + c + 1];             // first column of the next chunk (>= every column of this one), or the sentinel
+            cb[q] = base[chunk0 + __builtin_amdgcn_readfirstlane(min(((e0 - gb) >> 6) + (NT / 64) * q + wave, nchunk - 1))];
         }
 #pragma unroll
         for (int q = 0; q < CT; q++) {
-            if (paced && e0 + NT * q + 64 * wave < ge) { // this wavefront's chunk exists (wave-uniform)
-                const int lo = (int)(cb[q] >> shift), hi = (int)(cnext[q] >> shift);
-                report(lo);
-                open_until(min(hi, lo + win - 1));
+            const int ebeg = e0 + NT * q + 64 * wave;    // this wavefront's chunk (wave-uniform)
+            if (period != 0u && ebeg < ge && ebeg >= remote_from) {
+                if (t0 == 0u) team_start();
+                const int slab = max(0, (int)(cb[q] >> shift) - lead);
+                const unsigned open_at = (unsigned)(((unsigned long long)S.pace_sched[slab] * period) >> 24);
+                unsigned el = pace_clock() - t0;         // (a stale or garbled start reads as "long ago": no wait)
+                while (el < open_at) {
+                    const unsigned left = open_at - el;                 // 10-ns ticks; s_sleep n = 64 n cycles, about 27 n ns
+                    if (left > 400u) __builtin_amdgcn_s_sleep(127); else if (left > 60u) __builtin_amdgcn_s_sleep(20); else __builtin_amdgcn_s_sleep(2);
+                    el = pace_clock() - t0;
+                }
             }
             xx[q] = x[(size_t)(cb[q] + (rr[q].w >> db))];
         }
@@ -546,14 +545,11 @@ __device__ __forceinline__ void wg_entry_paced(const DevStream &S, const ERec *_
                 if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
         }
     }
-    // this wavefront is through: the remaining slabs count as finished, and the last wavefront of the team resets the counters for the next launch
-    report(nslab);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the adds above have been acknowledged before `done` is bumped)
+    // the last wavefront of the team to get here clears the team's start for the next launch
     unsigned prev = 0;
-    if (lane == 0) prev = __hip_atomic_fetch_add(&team[nslab + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) prev = __hip_atomic_fetch_add(&team[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
-    if (prev == team_waves - 1u)
-        for (int i = lane; i < nslab + 2; i += 64) __hip_atomic_store(&team[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == team_waves - 1u && lane < 2) __hip_atomic_store(&team[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ================================================================================================
@@ -756,8 +752,8 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             const unsigned xcd = blockIdx.x & 7u, gen = (blockIdx.x >> 3) / (unsigned)S.pace_twg;
             const unsigned on_xcd = (gridDim.x - xcd + 7u) >> 3;           // workgroups of this launch on this XCD
             const unsigned team_wgs = min((unsigned)S.pace_twg, on_xcd - gen * (unsigned)S.pace_twg);
-            unsigned *team = S.pace + (size_t)(xcd * (unsigned)S.pace_ngen + gen) * (size_t)(S.pace_nslab + 2);
-            wg_entry_paced<WCOO_HEAVY_CT, NTS>(S, S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y, team, team_wgs * 4u);
+            unsigned *team = S.pace + (size_t)(xcd * (unsigned)S.pace_ngen + gen) * 2u;   // {start on the 100-MHz clock, wavefronts done}
+            wg_entry_paced<WCOO_HEAVY_CT, NTS>(S, S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y, wr.x + wr.w, team, team_wgs * 4u);
             if (wr.y > wr.x) __syncthreads();
         } else if (wr.y > wr.x) {
             wg_entry_trips<WCOO_HEAVY_CT, 16 * GPB, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y);

@@ -140,15 +140,16 @@ struct DevStream {
     int cb_bits;                          // ... column block (cb_bits) | pattern id | flags << 27;  0 = 12-B descriptors
     int nt_stream;                        // 1: value / entry-record loads are nontemporal (the plan's streams do not fit the Infinity Cache)
     // slab pacing of the workgroup entry mode (round 4; hip_kernels.hip wg_entry_paced): the columns are cut into slabs of 2^pace_shift columns (about
-    // 1 MB of x), the workgroups one XCD holds at one time form a team, and a wavefront gathers from slab s only once every wavefront of its team has
-    // finished the slabs below s - pace_win + 1 — the team's gathers then fall into pace_win consecutive slabs that stay in the XCD's L2 instead of
-    // every gather pulling a 128-byte line across the fabric (profiles/r04_gather_locality.txt).  Counters per team: fin[pace_nslab], broken, done.
-    // Speed only: the spins are bounded and no result depends on a counter.  The merged lists are already in column order = slab order.
-    unsigned *pace;                       // nullptr: no pacing
+    // 1 MB of x), the workgroups one XCD holds at one time form a team, and the team sweeps the slabs by a timetable on the constant 100-MHz clock, so
+    // that its scattered gathers fall into the same few slabs — which stay in the XCD's L2 — instead of each pulling a 128-byte line across the fabric
+    // (profiles/r04_gather_locality.txt).  Lists of paced plans: the workgroup's local entries first (wg_coo.w = their record count, a multiple of 64),
+    // then the remote ones in column order, one more base word per list (its last column).  Speed only: no result depends on the clock.
+    unsigned *pace;                       // per team {start clock, wavefronts done}; nullptr: no pacing
+    const unsigned *pace_sched;           // [pace_nslab + 1]: share of the shard's remote entries left of slab s, in 1 / 2^24
+    unsigned pace_period;                 // 10-ns ticks one team's sweep is given (calibrated at plan creation; 0: nobody waits)
     int pace_shift, pace_nslab, pace_win;
     int pace_twg;                         // workgroups per team = workgroups of this kernel one XCD holds at one time
     int pace_ngen;                        // teams per XCD
-    int pace_spins;                       // polls a wavefront waits for a slab before it declares the team broken (everybody then runs unpaced)
     const UDesc *udesc_cb;                // descriptors with column blocks for the multi-vector kernel (== udesc when there is no window)
     // split tile-rows whose pieces all live in the unit kernel are summed in that kernel by the piece that
     // finishes last (fixed slot order): ifix[i] describes row i, ifix_count[i] counts finished pieces

@@ -61,7 +61,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.pace_slab_kb = pick(o.pace_slab_kb, "TILESPMV_PACE_SLAB_KB", 1024);
     k.pace_window = std::max(1, pick(o.pace_window, "TILESPMV_PACE_WINDOW", 2));
     k.pace_team = pick(o.pace_team, "TILESPMV_PACE_TEAM", 0);
-    k.pace_spins = std::max(1, pick(o.pace_spins, "TILESPMV_PACE_SPINS", 200));
+    k.pace_period_us = pick(o.pace_period_us, "TILESPMV_PACE_PERIOD_US", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
     k.entry_from_caller = pinned(o.entry_mode, "TILESPMV_WAVE_COO");
     k.strip_from_caller = o.strip_cost > 0 || env_int("TILESPMV_STRIP_COST", 0) > 0;
@@ -128,7 +128,7 @@ const char *tilespmv_plan_options_layout(void)
         TSPMV_F(entry_mode) TSPMV_F(entry_ordered) TSPMV_F(strip_cost) TSPMV_F(split_above) TSPMV_F(split_cap) TSPMV_F(xcd_remap) TSPMV_F(xcd_chunk)
         TSPMV_F(csr_split) TSPMV_F(fix_inline) TSPMV_F(coo_cost) TSPMV_F(coo_heavy_min) TSPMV_F(coo_piece) TSPMV_F(strip_even) TSPMV_F(wg_strips)
         TSPMV_F(x_window) TSPMV_F(x_stride1) TSPMV_F(x_stride2) TSPMV_F(mv_native) TSPMV_F(mv_xcd_chunk) TSPMV_F(lds_pad) TSPMV_F(y_store)
-        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_spins) TSPMV_F(reserved)
+        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(reserved)
 #undef TSPMV_F
         return o;
     }();
@@ -259,6 +259,48 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     if (!best) return -4;
     *out = best;
     return 0;
+}
+
+// Slab-paced plans (DevStream::pace): how long one team's timetable is, found by timing.  The unpaced launch first; then timetables of 0.1 ... 1.2 of
+// (unpaced time / generations of teams), the best one refined once.  Pacing is kept only when it is at least 3 % faster than the unpaced launch of the
+// same plan — otherwise the plan is launched unpaced (S.pace = nullptr) and says so in its facts.  TILESPMV_PLAN_VERBOSE prints the candidates.
+static void calibrate_pace(tilespmv_plan *plan)
+{
+    DevStream &S = plan->st;
+    const bool verbose = getenv("TILESPMV_PLAN_VERBOSE") != nullptr;
+    val_t *dx = nullptr, *dy = nullptr;
+    const size_t nx = (size_t)plan->dev.colA + 16, ny = (size_t)plan->dev.rowA + 16;
+    unsigned *const pace = S.pace;
+    auto give_up = [&]() { S.pace = nullptr; S.pace_period = 0; plan->info[TILESPMV_INFO_PACE_SLABS] = 0; plan->info[TILESPMV_INFO_PACE_PERIOD_US] = 0; };
+    if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) { give_up(); return; }
+    if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); give_up(); return; }
+    {
+        std::vector<val_t> ones(nx, (val_t)1);
+        (void)hipMemcpy(dx, ones.data(), nx * sizeof(val_t), hipMemcpyHostToDevice);
+    }
+    S.pace = nullptr;
+    const double t_base = tilespmv_plan_time(plan, dx, dy, nullptr, 3, 10);
+    S.pace = pace;
+    const double grid = ((double)S.ntasks + 15) / 16, gens = std::max(1.0, grid / 8.0 / std::max(1, S.pace_twg));
+    double best = t_base, best_ticks = 0;
+    auto try_ticks = [&](double ticks) {
+        if (ticks < 100 || ticks > (double)(1u << 30)) return;
+        S.pace_period = (unsigned)ticks;
+        const double t = tilespmv_plan_time(plan, dx, dy, nullptr, 2, 8);
+        if (verbose) fprintf(stderr, "tilespmv: pace calibration: timetable %.1f us per team -> %.4f ms (unpaced %.4f)\n", ticks / 100.0, t, t_base);
+        if (t > 0 && t < best) { best = t; best_ticks = ticks; }
+    };
+    if (t_base > 0) {
+        const double unit = t_base * 1e5 / gens;     // ms -> 10-ns ticks, per generation
+        for (double f : {0.1, 0.17, 0.27, 0.4, 0.6, 0.85, 1.2}) try_ticks(unit * f);
+        if (best_ticks > 0) { const double c = best_ticks; try_ticks(c * 0.8); try_ticks(c * 1.25); }
+    }
+    (void)hipFree(dx); (void)hipFree(dy);
+    if (best_ticks > 0 && best < 0.97 * t_base) {
+        S.pace_period = (unsigned)best_ticks;
+        plan->info[TILESPMV_INFO_PACE_PERIOD_US] = (long long)(best_ticks / 100.0 + 0.5);
+    } else give_up();
+    if (verbose) fprintf(stderr, "tilespmv: pace calibration: %s (unpaced %.4f ms, best paced %.4f ms at %.1f us)\n", S.pace ? "kept" : "dropped", t_base, best, best_ticks / 100.0);
 }
 
 static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const Knobs &K)
@@ -560,6 +602,11 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     // bytes one SpMV has to move at least: the three streams + tasks + x once + y once (+ fallback)
     I[TILESPMV_INFO_STREAM_BYTES] = model_bytes + (long long)colA * sv + (long long)rows * sv +
                                     (f_nnz ? (long long)f_rec.size() * (long long)sizeof(ERec) + (long long)f_base.size() * 4 + 2LL * sv * rows + (long long)f_blk.size() * 16 : 0);   // the fallback re-reads and re-writes its rows of y
+    if (!K.dry && plan->pace_calibrate && plan->st.pace != nullptr) {
+        const double t0c = now_us();
+        calibrate_pace(plan);
+        I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0c);
+    }
     *out = plan;
     return 0;
 }

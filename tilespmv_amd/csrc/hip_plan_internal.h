@@ -59,7 +59,7 @@ struct Knobs {
     int mv_xcd_chunk;    // -1 = the plan's XCD chunk
     int nt_stream;       // -1 by size, 0 plain, 1 nontemporal loads of the value / entry-record streams
     int pace;            // slab pacing of the workgroup entry mode: -1 by rule, 0 off, 1 on
-    int pace_slab_kb, pace_window, pace_team, pace_spins;
+    int pace_slab_kb, pace_window, pace_team, pace_period_us;   // pace_period_us < 0: calibrate at plan creation
     int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
     bool dry;            // tilespmv_plan_layout_digest: build the layout on the host only, hash instead of upload
@@ -91,6 +91,7 @@ struct tilespmv_plan {
     int arena_flags = 0; size_t arena_skew = 0;
     char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20, arena_next = (size_t)1 << 20, size_hint = 0;   // bump allocator of upload(); size_hint = the builder's estimate of the plan's bytes
     bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
+    bool pace_calibrate = false;        // slab-paced plan whose timetable length is still to be found by timing (plan_create_one)
     unsigned long long digest = 1469598103934665603ull;
     unsigned long long stage_digest[TILESPMV_STAGE_COUNT] = {0};   // layout-digest builds: one hash per stage of the unit-stream builder (hip_plan_stream.hip)
     template <class T>

@@ -1,4 +1,6 @@
 // hip_plan_stream.hip — second-generation ("unit stream") layout builder of the plan (hip_plan.h), in stages.
+#include <mutex>
+
 #include "hip_plan_internal.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -122,6 +124,7 @@ struct StreamBuilder {
     long long total_cost = 0, est_wgs = 0;
     int target = 0, entry_mode = 0, wg_strips = 16, xs1 = 0, xs2 = 0, max_strip_rows = STRIP_MAX_ROWS;
     bool pace_on = false; int pace_shift = 0, pace_nslab = 0;   // slab-paced entry phase (hip_plan.h DevStream::pace)
+    std::vector<long long> pace_hist;                           // ... remote entries per slab, whole shard (-> the teams' timetable)
     // CUT
     std::vector<STask> tasks;
     std::vector<Task> htasks;
@@ -774,33 +777,59 @@ void StreamBuilder::entries()
         const size_t nwg = (tasks.size() + GS - 1) / GS;
         std::vector<std::vector<ERec>> grp_rec(nwg);
         std::vector<std::vector<unsigned>> grp_base(nwg);
+        std::vector<int> wg_local(nwg, 0);      // paced lists: records of the local part (whole chunks)
+        std::mutex hist_mutex;
+        pace_hist.assign(pace_on ? (size_t)pace_nslab : 0, 0);
         std::atomic<int> bad(0);
         parallel_chunks((int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
             std::vector<std::pair<unsigned long long, unsigned>> key;   // (column << 32 | position in strip / list order, destination)
             std::vector<int> src;
-            std::vector<PEnt> ents;
+            std::vector<PEnt> ents, local;
+            std::vector<long long> hist(pace_on ? (size_t)pace_nslab : 0, 0);
             for (int64_t w = b; w < e; w++) {
                 key.clear(); src.clear();
-                for (size_t t = GS * (size_t)w; t < std::min(tasks.size(), GS * (size_t)w + GS); t++)
+                long long own_lo = LLONG_MAX, own_hi = LLONG_MIN;   // columns "around the group's own rows" (paced plans): [16 first tile-row - margin, 16 (last tile-row + 1) + margin)
+                for (size_t t = GS * (size_t)w; t < std::min(tasks.size(), GS * (size_t)w + GS); t++) {
+                    own_lo = std::min<long long>(own_lo, 16LL * tasks[t].row); own_hi = std::max<long long>(own_hi, 16LL * (tasks[t].row + std::max(1, tasks[t].nrows)));
                     for (int q = tasks[t].coo_begin; q < tasks[t].coo_end; q++) {   // column-major order; ties keep strip / list order
                         key.push_back({((unsigned long long)(unsigned)h_ccol[(size_t)q] << 32) | (unsigned long long)key.size(),
                                        (unsigned)((t & (GS - 1)) << slab_shift) | (unsigned)h_crow[(size_t)q]});
                         src.push_back(q);
                     }
+                }
                 std::sort(key.begin(), key.end());
                 ents.resize(key.size());
                 for (size_t i = 0; i < key.size(); i++) {
                     const int q = src[(size_t)(key[i].first & 0xFFFFFFFFull)];
                     ents[i] = PEnt{(unsigned)h_ccol[(size_t)q], key[i].second, h_cval[q]};
                 }
+                wg_local[(size_t)w] = 0;
+                if (pace_on) {
+                    // paced lists: the local entries first (columns around the group's own rows — the neighbouring workgroups want the same x lines anyway; never paced),
+                    // padded to whole chunks, then the remote entries in column order = slab order (the part the team sweeps by its timetable)
+                    constexpr long long MARGIN = 2048;
+                    local.clear();
+                    size_t nrem = 0;
+                    for (const PEnt &en : ents) {
+                        if ((long long)en.col >= own_lo - MARGIN && (long long)en.col < own_hi + MARGIN) local.push_back(en);
+                        else { ents[nrem++] = en; hist[(size_t)(en.col >> pace_shift)]++; }
+                    }
+                    ents.resize(nrem);
+                    if (!local.empty()) {
+                        if (!pack_list(local, dest_bits, grp_rec[(size_t)w], grp_base[(size_t)w], plan->dry)) bad++;
+                        if (!ents.empty()) while (grp_rec[(size_t)w].size() % ECHUNK) grp_rec[(size_t)w].push_back(make_erec((val_t)0, 0u));
+                        wg_local[(size_t)w] = (int)grp_rec[(size_t)w].size();
+                    }
+                }
                 if (!pack_list(ents, dest_bits, grp_rec[(size_t)w], grp_base[(size_t)w], plan->dry)) bad++;
-                if (pace_on) grp_base[(size_t)w].push_back(ents.empty() ? 0u : ents.back().col);   // paced lists: one more base word = the list's last column (the "next chunk" of the last chunk)
+                if (pace_on) grp_base[(size_t)w].push_back(ents.empty() ? (local.empty() ? 0u : local.back().col) : ents.back().col);   // one more base word: the list's last column
             }
+            if (pace_on) { std::lock_guard<std::mutex> lk(hist_mutex); for (size_t i2 = 0; i2 < hist.size(); i2++) pace_hist[i2] += hist[i2]; }
         });
         if (bad.load()) { fprintf(stderr, "tilespmv: internal error: %d packed entry lists do not decode to their entries\n", bad.load()); rc = -6; }
         std::vector<int4> wg((size_t)nwg);
         for (size_t w = 0; w < nwg; w++) {
-            wg[w] = make_int4((int)n_rec, (int)(n_rec + (long long)grp_rec[w].size()), (int)n_chunk, 0);
+            wg[w] = make_int4((int)n_rec, (int)(n_rec + (long long)grp_rec[w].size()), (int)n_chunk, wg_local[w]);
             n_rec += (long long)grp_rec[w].size(); n_chunk += (long long)grp_base[w].size();
         }
         if (n_rec > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit entry ids\n"); rc = -2; n_rec = 0; }
@@ -894,19 +923,30 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
         S.nt_stream = (entry_mode != 1 && !xwin && (K.nt_stream >= 0 ? K.nt_stream != 0 : launch_b > NT_STREAM_MIN_BYTES)) ? 1 : 0;
     }
     plan->info[TILESPMV_INFO_NT_STREAM] = S.nt_stream;
-    // ---- slab pacing: team counters (fin[nslab], broken, done per team; zero between launches)
-    S.pace = nullptr; S.pace_shift = 0; S.pace_nslab = 0; S.pace_win = 0; S.pace_twg = 0; S.pace_ngen = 0; S.pace_spins = 0;
+    // ---- slab pacing: the teams' timetable and their two words of state ({start clock, wavefronts done}; zero between launches)
+    S.pace = nullptr; S.pace_sched = nullptr; S.pace_period = 0; S.pace_shift = 0; S.pace_nslab = 0; S.pace_win = 0; S.pace_twg = 0; S.pace_ngen = 0;
     if (pace_on && !tasks.empty()) {
         const long long grid = ((long long)tasks.size() + 15) / 16, on_xcd0 = (grid + 7) / 8;
         int twg = K.pace_team > 0 ? K.pace_team : (plan->dry ? 0 : paced_team_workgroups(S.cb_bits > 0, S.nt_stream != 0, plan->xcd_remap, plan->lds_pad_bytes));
         if (twg <= 0) twg = 192;   // (6 workgroups on each of an XCD's 32 CUs: what the kernel is built for)
         const long long ngen = (on_xcd0 + twg - 1) / twg;
-        std::vector<unsigned> zeros((size_t)(8 * ngen * (pace_nslab + 2)), 0u);
+        long long total = 0;
+        for (long long v : pace_hist) total += v;
+        std::vector<unsigned> sched((size_t)pace_nslab + 1, 0u);   // slab s opens when the share of the remote entries left of it has gone by
+        long long run = 0;
+        for (int sl = 0; sl <= pace_nslab; sl++) {
+            sched[(size_t)sl] = total > 0 ? (unsigned)(((__int128)run << 24) / total) : 0u;
+            if (sl < pace_nslab) run += pace_hist[(size_t)sl];
+        }
+        std::vector<unsigned> zeros((size_t)(8 * ngen * 2), 0u);
         const unsigned *cnt = nullptr;
+        rc |= plan->upload(sched.data(), sched.size(), &S.pace_sched);
         rc |= plan->upload(zeros.data(), zeros.size(), &cnt);
         S.pace = const_cast<unsigned *>(cnt);
-        S.pace_shift = pace_shift; S.pace_nslab = pace_nslab; S.pace_win = K.pace_window; S.pace_twg = twg; S.pace_ngen = (int)ngen; S.pace_spins = K.pace_spins;
-        plan->info[TILESPMV_INFO_PACE_SLABS] = pace_nslab; plan->info[TILESPMV_INFO_PACE_TEAM] = twg;
+        S.pace_shift = pace_shift; S.pace_nslab = pace_nslab; S.pace_win = K.pace_window; S.pace_twg = twg; S.pace_ngen = (int)ngen;
+        S.pace_period = K.pace_period_us > 0 ? (unsigned)std::min<long long>(100LL * K.pace_period_us, 1LL << 30) : 0u;   // 10-ns ticks; unset: calibrated by plan_create_one
+        plan->pace_calibrate = K.pace_period_us < 0;
+        plan->info[TILESPMV_INFO_PACE_SLABS] = pace_nslab; plan->info[TILESPMV_INFO_PACE_TEAM] = twg; plan->info[TILESPMV_INFO_PACE_PERIOD_US] = S.pace_period / 100;
     }
     if (hashing()) {
         Hash h;

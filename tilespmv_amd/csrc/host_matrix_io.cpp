@@ -4,6 +4,10 @@
 // lengths, the payload byte count and an FNV-1a-64 of the payload, then every member array in declaration order with
 // the element counts of SURVEY.md Appendix A (derived from the scalars).  A load checks all of it before returning a
 // matrix: counts, file length, checksum, and the prefix arrays the plan builder and tilespmv_cpu index with.
+#include <unistd.h>
+
+#include <string>
+
 #include "host_util.h"
 
 namespace {
@@ -168,7 +172,10 @@ bool source_id(const char *path, SourceId *id)
 extern "C" int tilespmv_csr_save(const char *path, int m, int n, MAT_PTR_TYPE nnz, int isSymmetric, const MAT_PTR_TYPE *rowptr,
                                  const int *colidx, const MAT_VAL_TYPE *val, const char *source_mtx)
 {
-    FILE *f = fopen(path, "wb");
+    // written under a name of its own and renamed into place: N ranks that all miss the cache write the same file at the same time (bench.py --cache),
+    // and a truncating fopen / a remove() on `path` itself could destroy another rank's finished cache
+    const std::string tmp = std::string(path) + "." + std::to_string((long long)getpid()) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return -1;
     int head[5] = {(int)sizeof(tilespmv::val_t), m, n, nnz, isSymmetric};
     SourceId id{0, 0, 0};
@@ -185,7 +192,8 @@ extern "C" int tilespmv_csr_save(const char *path, int m, int n, MAT_PTR_TYPE nn
     ok = ok && (nnz == 0 || fwrite(colidx, sizeof(int), (size_t)nnz, f) == (size_t)nnz);
     ok = ok && (nnz == 0 || fwrite(val, sizeof(tilespmv::val_t), (size_t)nnz, f) == (size_t)nnz);
     ok = (fclose(f) == 0) && ok;
-    if (!ok) remove(path);   // never leave half a cache behind
+    ok = ok && rename(tmp.c_str(), path) == 0;
+    if (!ok) remove(tmp.c_str());   // never leave half a cache behind — and never touch a finished one
     return ok ? 0 : -3;
 }
 

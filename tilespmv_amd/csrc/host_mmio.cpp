@@ -15,6 +15,8 @@
 #include <cctype>
 #include <string>
 
+#include <cmath>
+
 #include "host_util.h"
 
 namespace {
@@ -342,7 +344,8 @@ extern "C" int tilespmv_mtx_write(const char *path, int m, int n, MAT_PTR_TYPE n
                         if (val) {
                             *p++ = ' ';
                             const double v = (double)val[j];
-                            if (v == (double)(long long)v && v > -1e15 && v < 1e15) {
+                            // integer fast path only for finite values in range (the cast of Inf / NaN / 1e300 is undefined behaviour) and not for -0.0 (its sign would be lost)
+                            if (std::isfinite(v) && v > -1e15 && v < 1e15 && v == (double)(long long)v && !(v == 0.0 && std::signbit(v))) {
                                 long long iv = (long long)v;
                                 if (iv < 0) { *p++ = '-'; iv = -iv; }
                                 p = put_uint(p, (unsigned long long)iv);
