@@ -294,8 +294,9 @@ typedef struct {
     int nt_stream;      /* value / entry-record / dense-tile loads: 1 nontemporal, 0 default cache policy; unset: nontemporal where one SpMV moves more
                            than 400 MB (about 1.6 x the Infinity Cache)                                                             TILESPMV_NT_STREAM */
     int pace;           /* slab pacing of the workgroup entry mode (round 4): the workgroups one XCD holds at one time sweep x by a common timetable, so that
-                           their scattered gathers fall into the same few ~1-MB slabs, which stay in the XCD's L2; 1 on, 0 off, unset: tried on entry-heavy
-                           shards whose x does not fit an L2 (and kept only if the calibration finds it faster)                    TILESPMV_PACE */
+                           their scattered gathers fall into the same few ~1-MB slabs, which stay in the XCD's L2; 1 = on (kept only if the calibration at plan
+                           creation finds it at least 3 % faster than the unpaced launch), 0 / unset = off: it measured slower or equal on every matrix of the
+                           round-4 sweep and stays as the counter-backed answer to "synchronise the sweeps"       TILESPMV_PACE */
     int pace_slab_kb;   /* ... KB of x per slab (power of two; unset: 1024)                                   TILESPMV_PACE_SLAB_KB */
     int pace_window;    /* ... slabs a wavefront may be ahead of the timetable, plus one (unset: 2)           TILESPMV_PACE_WINDOW */
     int pace_team;      /* ... workgroups per team and XCD (unset: what the occupancy query says one XCD holds)  TILESPMV_PACE_TEAM */

@@ -385,6 +385,23 @@ __device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t
 #endif
 // NTL: the records are read with nontemporal loads (plans whose streams do not fit the Infinity Cache: the once-read stream
 // then does not displace x in the L2s; DevStream::nt_stream).
+// Diagnostic builds (scripts/r4_gather_policy.sh): cache policy of the scattered x gathers of the workgroup entry phase — 0 default, 1 nontemporal, 2 agent scope (sc1), 3 system scope (sc0 sc1)
+#ifndef TILESPMV_GATHER_POLICY
+#define TILESPMV_GATHER_POLICY 0
+#endif
+__device__ __forceinline__ val_t gather_x(const val_t *p)
+{
+#if TILESPMV_GATHER_POLICY == 1
+    return __builtin_nontemporal_load(p);
+#elif TILESPMV_GATHER_POLICY == 2
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif TILESPMV_GATHER_POLICY == 3
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    return *p;
+#endif
+}
+
 template <int CT, int NT, bool NTL>
 __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, const unsigned *__restrict__ base, int chunk0, int db, bool ordered,
                                                const val_t *__restrict__ x, lacc_t *sy, int tid, int gb, int ge)
@@ -418,7 +435,7 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
         val_t xx[CT];
         if (!WG_TRIP_PIPE && e0 > gb) load_trip(e0, rr, cb);
 #pragma unroll
-        for (int q = 0; q < CT; q++) xx[q] = x[(size_t)(cb[q] + (rr[q].w >> db))];
+        for (int q = 0; q < CT; q++) xx[q] = gather_x(&x[(size_t)(cb[q] + (rr[q].w >> db))]);
 #if defined(TILESPMV_ABL) && TILESPMV_ABL == 2
 #pragma unroll
         for (int q = 0; q < CT; q++) xx[q] = x[(e0 + NT * q + tid) & 0xFFFFF];

@@ -277,7 +277,11 @@ void StreamBuilder::choose()
     // an L2 — on shards that fill the chip (the teams are what one XCD holds at one time) with enough entries to pay for the bookkeeping
     {
         const long long x_bytes = (long long)colA * sv;
-        pace_on = entry_mode == 2 && wg_strips == 16 && !xwin && (K.pace > 0 || (K.pace < 0 && x_bytes >= (8ll << 20) && NC >= (4ll << 20) && est_wgs >= 1024));
+        (void)x_bytes;
+        // Opt-in only (pace = 1).  Measured in round 4 (profiles/r04_slab_pacing.txt): a team keeps to a timetable only at >= 3 us per slab — every slab
+        // opens with all the team's wavefronts missing on its lines at once — and the teams of one XCD run one after the other, so no timetable beat the unpaced launch
+        // on band + random fill (2 M rows), uniform random (8 M), R-MAT (scale 22) or the power-law case; the calibration dropped every one of them.
+        pace_on = entry_mode == 2 && wg_strips == 16 && !xwin && K.pace > 0;
         if (pace_on) {
             long long cols_per_slab = std::max<long long>(256, (long long)std::max(1, K.pace_slab_kb) * 1024 / sv);
             pace_shift = 0;
