@@ -346,6 +346,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:  # one process per GPU shares the host cores: this rank's share of what the job may really use (affinity mask and cgroup quota, not os.cpu_count())
         os.environ.setdefault("TILESPMV_NUM_THREADS", str(max(1, min(16, usable_cores() // world))))
+    host_threads = int(os.environ.get("TILESPMV_NUM_THREADS", "0")) or None
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -556,6 +557,13 @@ def main():
             try:
                 if mode == "halo":
                     halo = make_halo()
+                elif not args.no_check:
+                    # the first rows of every rank's block as that rank computed them, BEFORE any combine (its whole block was checked against the CSR golden above):
+                    # what the neighbours' rows of the combined y are compared with below — a rank-consistent misplacement in the combine cannot pass
+                    step("none"); torch.cuda.synchronize()
+                    mine_first = yd[sh.r0:min(sh.r0 + 2048, sh.r1)].cpu().numpy().copy()
+                    first_rows = [None] * world
+                    dist.all_gather_object(first_rows, mine_first)
                 w2, _ = timed(mode, ksteps, 3)
                 extra[mode] = {"ms_per_step": round(w2 * 1e3 / ksteps, 5), "gflops": round(flops / (w2 / ksteps) * 1e-9, 2)}
                 if mode == "halo":
@@ -573,10 +581,8 @@ def main():
                         nb = (rank + 1) % world
                         ra = np.arange(int(bounds[nb]), min(int(bounds[nb]) + 2048, int(bounds[nb + 1])))
                         mine_ok = check_rows(yd[sh.r0:sh.r1].cpu().numpy(), mode) == "pass"
-                        # rows of the next rank as that rank computed them before the combine: all-gathered reference values
-                        ref_rows = yd[torch.from_numpy(ra).cuda()].clone()
-                        sh.spmv(xd, yd, stream.cuda_stream); sh.combine(yd, mode); torch.cuda.synchronize()
-                        okv = 1.0 if (mine_ok and bool(torch.equal(ref_rows, yd[torch.from_numpy(ra).cuda()]))) else 0.0
+                        got_nb = yd[torch.from_numpy(ra).cuda()].cpu().numpy()       # the next rank's first rows as they arrived here through the combine
+                        okv = 1.0 if (mine_ok and np.array_equal(got_nb, first_rows[nb][:len(ra)])) else 0.0
                         key = "check_full_y_on_every_rank"
                     okc = torch.tensor([okv], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
                     dist.all_reduce(okc, op=dist.ReduceOp.MIN)
@@ -618,7 +624,7 @@ def main():
         "launched_by": "self (child torch.distributed.run)" if os.environ.get("TILESPMV_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "direct"),
         "reference_style_timing": {"ms_per_spmv": round(ref_style_ms, 5), "gflops": round(2.0 * sh.local_nnz / (ref_style_ms * 1e-3) * 1e-9, 2), "reps": nref,
                                    "protocol": "C loop: gettimeofday around one launch + stream synchronize (reference src/tilespmv_cuda.h:1112-1137), this rank's shard"},
-        "prep_seconds": prep_mine, "prep_seconds_per_rank": prep_all,
+        "prep_seconds": prep_mine, "prep_seconds_per_rank": prep_all, "host_threads_per_rank": host_threads, "usable_host_cores": usable_cores(),
     }
     if extra:
         out["with_y_combine"] = extra

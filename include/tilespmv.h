@@ -318,7 +318,10 @@ void tilespmv_plan_destroy(tilespmv_plan *plan);
 /* Values: x (and the matrix values) must be FINITE.  Zero-padded payload is multiplied by real x entries — the padding
  * slots of ELL / HYB tiles exactly as in the reference (src/tilespmv_cpu.h:173-192 walks all `width` slots), and in
  * this engine also CSR tiles re-expressed as units, dense tiles, and the clamped reads of a partial last column block —
- * so an Inf or NaN in x can reach rows that store no entry in that column (0 * Inf = NaN).
+ * so an Inf or NaN in x can reach rows that store no entry in that column (0 * Inf = NaN).  One more carrier, outside the tile: the merged entry
+ * lists (wavefront / workgroup entry modes, CSR fallback) pad a 64-record chunk that had to be closed early — its columns span 2^(32 - dest_bits)
+ * (2^20 ... 2^23) or more, or, in slab-paced plans, the local part of a list ends — with null records (value 0, destination = the group's first
+ * row, column = the chunk's first column): they add 0 * x[that column] to that row (tests/test_gpu_configs.py::test_non_finite_x_reaches_only_what_the_header_says).
  *
  * y[16*tilerow_begin .. 16*tilerow_end) = A_shard * x.  d_x has colA elements, d_y points at
  * element 0 of the FULL-length y (the shard writes only its own rows).  Asynchronous on

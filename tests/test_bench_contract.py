@@ -58,6 +58,15 @@ def test_single_gpu_line_real_valued_data(tmp_path):
     assert "U(-1,1)" in lines[0]["data"] and "<=" in lines[0]["check"] and lines[0]["check"].startswith("pass")
     assert lines[0]["prep_seconds"]["tile_cache"] == "miss" and lines[1]["prep_seconds"]["tile_cache"] == "hit"
     assert lines[1]["check"].startswith("pass")
+    # the cache is tied to its input: with another digest beside it (= same shape, other values / flags / generator) it is not used
+    keys = [f for f in os.listdir(tmp_path) if f.endswith(".key")]
+    assert len(keys) == 1
+    with open(os.path.join(tmp_path, keys[0]), "w") as f:
+        f.write("0" * 32 + "\n")
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    third = _last_json(r.stdout)
+    assert third["prep_seconds"]["tile_cache"] == "miss" and third["check"].startswith("pass")
 
 
 def test_two_rank_rehearsal_over_gloo():
@@ -84,3 +93,36 @@ def test_two_rank_halo_mode_over_gloo():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     assert d["config"]["y_combine"] == "halo" and d["halo_bytes_per_rank"] > 0 and d["check"].startswith("pass") and d["value"] > 0
+
+
+def test_one_rank_through_the_launcher_equals_the_bare_run():
+    """The SCALE N = 1 point (driver: `python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1`) must agree with BENCH (`python bench.py`):
+    same code path (no process group at world size 1), same line, same value within run-to-run noise."""
+    args = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--workload", "laplacian1024", "--no-cpu-baseline", "--no-extras"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bare = subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert bare.returncode == 0, bare.stderr[-2000:]
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29731",
+                               "bench.py"] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert launched.returncode == 0, launched.stderr[-2000:]
+    a, b = _last_json(bare.stdout), _last_json(launched.stdout)
+    assert a["n_gpus"] == b["n_gpus"] == 1 and a["ranks"] == b["ranks"] == 1 and a["config"] == b["config"]
+    assert a["launched_by"] == "direct" and b["launched_by"] == "direct" and b["backend"] is None      # world size 1: no process group either way
+    assert a["check"] == b["check"] and a["check"].startswith("pass")
+    assert abs(a["value"] - b["value"]) / a["value"] < 0.15, (a["value"], b["value"])
+    assert a["roofline"]["plan_fingerprint"] == b["roofline"]["plan_fingerprint"]
+
+
+def test_six_rank_rehearsal_over_gloo():
+    """As many ranks as the GPU box lets one job put on its card (process guard: 6) through the driver's command shape, all on device 0 over gloo: the plumbing of an
+    8-rank run — per-rank generation and preprocessing with a share of the host cores each, the three y combines, max-over-ranks timing — before there is an 8-GPU node."""
+    cmd = [sys.executable, "bench.py", "--gpus", "6", "--steps", "10", "--warmup", "3", "--backend", "gloo", "--workload", "laplacian1024"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 6 and d["ranks"] == 6 and d["devices"] == [0] * 6 and d["check"].startswith("pass")
+    assert len(d["prep_seconds_per_rank"]) == 6 and len(d["per_rank_ms_per_step"]["wall"]) == 6
+    assert all(v["check_full_y_on_every_rank"] == "pass" for k, v in d["with_y_combine"].items() if k != "halo"), d["with_y_combine"]
+    assert d["with_y_combine"]["halo"]["check_own_rows_on_every_rank"] == "pass"
+    assert 1 <= d["host_threads_per_rank"] <= 16

@@ -352,6 +352,11 @@ def test_cli_device_list(torch_cuda, tmp_path):
         r = subprocess.run([exe, "-d", "0,0", mtx] + extra, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert r.returncode == 0, (extra, r.stdout, r.stderr)
         assert "HIP SpMV on 2 device(s)" in r.stdout and "Check... PASS!" in r.stdout
+    # the shape of the first 8-GPU run, rehearsed on the one device there is: eight tile-row shards, eight streams, the y combine through RCCL's all-reduce
+    for extra in (["--combine=allreduce"], ["--combine=allgather"]):
+        r = subprocess.run([exe, "-d", "0,0,0,0,0,0,0,0", mtx] + extra, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, (extra, r.stdout, r.stderr)
+        assert "HIP SpMV on 8 device(s)" in r.stdout and "Check... PASS!" in r.stdout
     r = subprocess.run([exe, "-d", "0,7", mtx], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 3 and "no such HIP device" in r.stderr
     r = subprocess.run([exe, "-d", "0,0", mtx, "--combine=bogus"], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)

@@ -38,6 +38,20 @@ def shard_csr(rowptr, colidx, vals, r0, r1):
     return rp, colidx[lo:hi], vals[lo:hi]
 
 
+def _block_key(rp, ci, v, dtype, hyb):
+    """Digest of one rank's input block + the create flags (xxh3 where available: ~10 GB/s; blake2b otherwise)."""
+    try:
+        import xxhash
+        h = xxhash.xxh3_128()
+    except ImportError:   # pragma: no cover
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+    for a in (rp, ci, v):
+        h.update(memoryview(np.ascontiguousarray(a)).cast("B"))
+    h.update(("|%s|hyb=%d|v1" % (np.dtype(dtype).name, 1 if hyb else 0)).encode())
+    return h.hexdigest()
+
+
 class ShardedSpMV:
     """One rank's share of a row-partitioned SpMV.
 
@@ -72,10 +86,14 @@ class ShardedSpMV:
             import time
             t0 = time.perf_counter()
             self.tm, self.tile_cache = None, None
+            key = None
             if tile_cache is not None:
                 import os
+                # the cache belongs to THIS input: a digest of the block (row pointer, columns, values) and of the create flags sits beside it and must match —
+                # same shape with other values, another HYB setting or a changed generator is a miss, not a silent hit
+                key = _block_key(rp, ci, v, self.dtype, hyb)
                 self.tile_cache = "miss"
-                if os.path.exists(tile_cache):
+                if os.path.exists(tile_cache) and os.path.exists(tile_cache + ".key") and open(tile_cache + ".key").read().strip() == key:
                     try:
                         tm, r2, c2, z2 = api.matrix_load(tile_cache, self.dtype)
                         if (r2, c2, z2) == (self.local_rows, cols, self.local_nnz):
@@ -89,6 +107,8 @@ class ShardedSpMV:
                 if tile_cache is not None:
                     try:
                         api.matrix_save(self.tm, self.local_rows, cols, self.local_nnz, tile_cache)
+                        with open(tile_cache + ".key", "w") as f:
+                            f.write(key + "\n")
                     except OSError:
                         self.tile_cache = "miss, not writable"
             t1 = time.perf_counter()
