@@ -16,7 +16,7 @@ objs = []
 for f in ("host_tile_create.cpp", "host_tilespmv_cpu.cpp", "host_mmio.cpp", "host_matrix_io.cpp", "host_multi.cpp"):
     o = os.path.join(out, f + ".o"); objs.append(o)
     subprocess.check_call([hip] + common + ["-ffp-contract=off", "-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-c", os.path.join(src, f), "-o", o])
-for f in ("hip_plan.hip", "hip_kernels.hip"):
+for f in ("hip_plan.hip", "hip_plan_stream.hip", "hip_kernels.hip"):
     o = os.path.join(out, f + ".o"); objs.append(o)
     subprocess.check_call([hip] + common + ["--offload-arch=gfx950", "-munsafe-fp-atomics", "-c", os.path.join(src, f), "-o", o])
 subprocess.check_call([hip, "-shared", "-fPIC", "--offload-arch=gfx950", "-pthread"] + objs + ["-ldl", "-o", lib])
@@ -53,7 +53,7 @@ rt = (s[:, 7] - s[:, 7].min()) * 10e-3          # s_memrealtime: 100 MHz -> us
 d = np.diff(s[:, :7], axis=1).astype(np.float64)  # cycles per segment
 names = ["entry -> task arrived", "-> prologue + entry loads arrived", "-> entry phase done", "-> unit loop done", "-> stores issued", "-> stores acknowledged"]
 life = (s[:, 6] - s[:, 0]).astype(np.float64)
-print("%s: %.4f ms per SpMV in this (stamped) build, entry mode %d, %d wavefronts with work" % (wl, ms, info["entry_mode"], len(s)))
+print("%s: %.4f ms per SpMV in this (stamped) build, entry mode %d, %d x 256 entries per trip, %d tasks, %d wavefronts with work" % (wl, ms, info["entry_mode"], info["entry_trip"], info["num_tasks"], len(s)))
 print("wavefront start skew (s_memrealtime at entry): p50 %.2f us, p90 %.2f us, max %.2f us" % tuple(np.percentile(rt, [50, 90, 100])))
 print("wavefront lifetime: median %.0f cycles, p90 %.0f, max %.0f" % tuple(np.percentile(life, [50, 90, 100])))
 for i, nm in enumerate(names):
