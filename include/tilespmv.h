@@ -302,8 +302,6 @@ typedef struct {
     int pace_team;      /* ... workgroups per team and XCD (unset: what the occupancy query says one XCD holds)  TILESPMV_PACE_TEAM */
     int pace_period_us; /* ... microseconds one team's sweep over x is given (the timetable's length); unset: calibrated by timing at plan creation — and a
                            plan that does not get faster is launched unpaced; 0: nobody waits                        TILESPMV_PACE_PERIOD_US */
-    int entry_trip;     /* workgroup entry mode: 256-entry sub-chunks per trip, 6 or 16; unset: 16 when the whole grid is resident at 3 workgroups per CU
-                           (all of a workgroup's records in flight at once: two dependent hops instead of two per trip), 6 otherwise        TILESPMV_ENTRY_TRIP */
     int reserved[2];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
@@ -410,8 +408,7 @@ enum {
     TILESPMV_INFO_PACE_TEAM = 23,         /* ... workgroups per team and XCD */
     TILESPMV_INFO_PLACEMENT_TRIES = 24,   /* arena placements timed at plan creation (large plans; 0 / 1 = the first one was kept) */
     TILESPMV_INFO_PACE_PERIOD_US = 25,    /* ... microseconds of one team's timetable (0 = not paced) */
-    TILESPMV_INFO_ENTRY_TRIP = 26,        /* workgroup entry mode: sub-chunks of 256 entries per trip (6 or 16) */
-    TILESPMV_INFO_COUNT = 27
+    TILESPMV_INFO_COUNT = 26
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
 

@@ -53,7 +53,7 @@ rt = (s[:, 7] - s[:, 7].min()) * 10e-3          # s_memrealtime: 100 MHz -> us
 d = np.diff(s[:, :7], axis=1).astype(np.float64)  # cycles per segment
 names = ["entry -> task arrived", "-> prologue + entry loads arrived", "-> entry phase done", "-> unit loop done", "-> stores issued", "-> stores acknowledged"]
 life = (s[:, 6] - s[:, 0]).astype(np.float64)
-print("%s: %.4f ms per SpMV in this (stamped) build, entry mode %d, %d x 256 entries per trip, %d tasks, %d wavefronts with work" % (wl, ms, info["entry_mode"], info["entry_trip"], info["num_tasks"], len(s)))
+print("%s: %.4f ms per SpMV in this (stamped) build, entry mode %d, %d tasks, %d wavefronts with work" % (wl, ms, info["entry_mode"], info["num_tasks"], len(s)))
 print("wavefront start skew (s_memrealtime at entry): p50 %.2f us, p90 %.2f us, max %.2f us" % tuple(np.percentile(rt, [50, 90, 100])))
 print("wavefront lifetime: median %.0f cycles, p90 %.0f, max %.0f" % tuple(np.percentile(life, [50, 90, 100])))
 for i, nm in enumerate(names):

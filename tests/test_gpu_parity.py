@@ -352,8 +352,9 @@ def test_cli_device_list(torch_cuda, tmp_path):
         r = subprocess.run([exe, "-d", "0,0", mtx] + extra, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert r.returncode == 0, (extra, r.stdout, r.stderr)
         assert "HIP SpMV on 2 device(s)" in r.stdout and "Check... PASS!" in r.stdout
-    # the shape of the first 8-GPU run, rehearsed on the one device there is: eight tile-row shards, eight streams, the y combine through RCCL's all-reduce
-    for extra in (["--combine=allreduce"], ["--combine=allgather"]):
+    # the shape of the first 8-GPU run, rehearsed on the one device there is: eight tile-row shards, eight streams, the peer-copy all-gather of y
+    # (the RCCL all-reduce cannot be rehearsed this way: ncclCommInitAll refuses a device list with duplicates — it runs at world size 1 in test_rccl_collectives_on_the_real_y_world_size_one)
+    for extra in (["--combine=none"], ["--combine=allgather"]):
         r = subprocess.run([exe, "-d", "0,0,0,0,0,0,0,0", mtx] + extra, cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert r.returncode == 0, (extra, r.stdout, r.stderr)
         assert "HIP SpMV on 8 device(s)" in r.stdout and "Check... PASS!" in r.stdout
@@ -670,8 +671,7 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
                  dict(x_window=1, entry_mode=2, strip_cost=200), dict(x_window=1, x_stride1=3), dict(lds_pad=12288, xcd_remap=0),
                  dict(x_window=1, strip_cost=64, split_above=200), dict(x_window=2), dict(x_window=2, entry_mode=2, xcd_chunk=4), dict(x_window=0),
                  dict(desc_dict=0), dict(desc_dict=0, entry_mode=2), dict(desc_dict=0, entry_mode=1), dict(desc_dict=1, entry_mode=1, strip_cost=100),
-                 dict(nt_stream=1), dict(nt_stream=1, entry_mode=2, entry_ordered=1), dict(nt_stream=1, desc_dict=0, entry_mode=0), dict(nt_stream=0),
-                 dict(entry_mode=2, entry_trip=16, entry_ordered=1), dict(entry_mode=2, entry_trip=16, entry_ordered=0, desc_dict=0), dict(entry_mode=2, entry_trip=16, strip_cost=1600, xcd_remap=0)]
+                 dict(nt_stream=1), dict(nt_stream=1, entry_mode=2, entry_ordered=1), dict(nt_stream=1, desc_dict=0, entry_mode=0), dict(nt_stream=0)]
     windowed = bricks = 0
     desc = {4: 0, 12: 0}
     for name, gen in mats.items():
@@ -685,8 +685,6 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
             assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
             if "entry_mode" in kw and not kw.get("x_window"):
                 assert info["entry_mode"] == kw["entry_mode"]
-            if kw.get("entry_trip") == 16:      # the resident-grid form (all records of a workgroup in flight at once) really ran: these matrices are small
-                assert info["entry_trip"] == 16, (name, kw, info["entry_trip"])
             windowed += info["x_window_slots"] > 0
             bricks += info["brick_order"] == 1
             desc[info["desc_bytes"]] += 1

@@ -627,12 +627,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
 // gathered from the dictionary one chunk ahead (when its word has arrived), so neither hop is waited for in the unit loop.
 // NTS: value and entry-record loads are nontemporal (plans larger than the Infinity Cache, DevStream::nt_stream).
 // PACE: slab-paced workgroup entry phase (wg_entry_paced above; ECOO = 2, 256-thread workgroups, no x windows).
-// ECT: sub-chunks of 256 entries per trip of the workgroup entry phase.  6 = the form built for 6 waves per SIMD (grids that fill the chip several times over); 16 = the
-// resident-grid form (round 4): when the whole grid is on the chip at once (<= 3 workgroups per CU) occupancy buys nothing and the kernel is a chain of dependent round
-// trips — task -> list range -> per trip {records -> gathers} — so ALL of a workgroup's records (up to 4,096: 16 per lane) go in flight at once, then all gathers, then
-// the adds: two hops instead of two per trip (webbase-1M stand-in: 2.7 trips).  Built for 3 waves per SIMD (fp64: 16 records + 16 gathered values per lane do not fit 128 VGPRs).
-template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD, bool NTS, bool PACE = false, int ECT = WCOO_HEAVY_CT>
-__global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 : ECOO == 2 ? (ECT > 8 ? 3 : ECOO2_MIN_WAVES) : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD, bool NTS, bool PACE = false>
+__global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
@@ -641,7 +637,6 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     static_assert(!(XWIN && CD), "x-window plans keep 12-B descriptors (their low bits hold window slots)");
     static_assert(!(NTS && (XWIN || ECOO == 1)), "nontemporal streams: large plans only (entry mode 1 = small grids; x windows are an opt-in experiment)");
     static_assert(!PACE || (ECOO == 2 && GPB == 16 && !XWIN), "slab pacing: workgroup entry mode, 256-thread workgroups, no x windows");
-    static_assert(ECT == WCOO_HEAVY_CT || (ECOO == 2 && GPB == 16 && !XWIN && !NTS && !PACE), "long trips: resident grids of the workgroup entry mode (small plans: default cache policy, unpaced)");
     constexpr int GROUPS_PER_BLOCK = GPB;
     constexpr int SROWS = XWIN ? XWIN_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
     constexpr bool NT = NTS;  // nontemporal value loads
@@ -778,7 +773,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             wg_entry_paced<WCOO_HEAVY_CT, NTS>(S, S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y, wr.x + wr.w, team, team_wgs * 4u);
             if (wr.y > wr.x) __syncthreads();
         } else if (wr.y > wr.x) {
-            wg_entry_trips<ECT, 16 * GPB, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y);
+            wg_entry_trips<WCOO_HEAVY_CT, 16 * GPB, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y);
             __syncthreads();
         }
         TSPMV_STAMP_WAIT(3);   // entry phase done
@@ -1638,9 +1633,7 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
 {
     if (S.ntasks > 0) {
 #define TSPMV_L5(X, W, B, XW, CD, NTS, PC) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, B, XW, CD, NTS, PC>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
-#define TSPMV_L6(X, W, B, XW, CD, NTS) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, B, XW, CD, NTS, false, ((W) == 2 && (B) == 16 && !(XW) && !(NTS)) ? 16 : WCOO_HEAVY_CT>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
-#define TSPMV_L4(X, W, B, XW, CD, NTS) do { if ((W) == 2 && (B) == 16 && !(XW) && S.pace != nullptr) TSPMV_L5(X, W, B, XW, CD, NTS, ((W) == 2 && (B) == 16 && !(XW))); \
-        else if ((W) == 2 && (B) == 16 && !(XW) && !(NTS) && S.entry_ct == 16) TSPMV_L6(X, W, B, XW, CD, NTS); else TSPMV_L5(X, W, B, XW, CD, NTS, false); } while (0)
+#define TSPMV_L4(X, W, B, XW, CD, NTS) do { if ((W) == 2 && (B) == 16 && !(XW) && S.pace != nullptr) TSPMV_L5(X, W, B, XW, CD, NTS, ((W) == 2 && (B) == 16 && !(XW))); else TSPMV_L5(X, W, B, XW, CD, NTS, false); } while (0)
 #define TSPMV_L3(X, W, B, CD) do { if (S.nt_stream) TSPMV_L4(X, W, B, false, CD, true); else TSPMV_L4(X, W, B, false, CD, false); } while (0)
 #define TSPMV_L2(X, W, B) do { if (S.cb_bits > 0) TSPMV_L3(X, W, B, true); else TSPMV_L3(X, W, B, false); } while (0)
 #define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L4(X, 2, 16, true, false, false); else if (xwin_lds_bytes > 0) TSPMV_L4(X, 0, 16, true, false, false); \
@@ -1652,7 +1645,6 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
 #undef TSPMV_L3
 #undef TSPMV_L4
 #undef TSPMV_L5
-#undef TSPMV_L6
     }
     // whole-tile passes (y += ...): CSR tiles kept as tiles, dense tiles on the matrix cores; then the split-row fix-up
     hipError_t e = launch_tiles_direct(P, dense_mfma, /*accumulate=*/true, /*fixup=*/false, x, y, st);

@@ -122,7 +122,6 @@ struct DevStream {
     int ntasks;
     int coo_heavy_min;                    // entry mode 0: strips with more COO entries than this run their entry list before the unit pipeline
     int coo_ordered;                      // workgroup entry mode: wavefronts add in turn (bit-reproducible sums)
-    int entry_ct;                         // workgroup entry mode: sub-chunks of 256 entries per trip — 6, or 16 on grids that are resident as a whole (k_units<.., ECT = 16>)
     int y_streaming;                      // y stores carry the nontemporal hint (plans whose y is a real share of the traffic) or are plain
     // entry modes 1 / 2 (k_units<.., 1 | 2>): the entries of the 4 strips of one wavefront / the 16 or 32 strips of one
     // workgroup, merged and ordered by column, so that the lanes of one gather share x lines; packed records (ERec),

@@ -62,7 +62,6 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.pace_window = std::max(1, pick(o.pace_window, "TILESPMV_PACE_WINDOW", 2));
     k.pace_team = pick(o.pace_team, "TILESPMV_PACE_TEAM", 0);
     k.pace_period_us = pick(o.pace_period_us, "TILESPMV_PACE_PERIOD_US", -1);
-    k.entry_trip = pick(o.entry_trip, "TILESPMV_ENTRY_TRIP", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
     k.entry_from_caller = pinned(o.entry_mode, "TILESPMV_WAVE_COO");
     k.strip_from_caller = o.strip_cost > 0 || env_int("TILESPMV_STRIP_COST", 0) > 0;
@@ -129,7 +128,7 @@ const char *tilespmv_plan_options_layout(void)
         TSPMV_F(entry_mode) TSPMV_F(entry_ordered) TSPMV_F(strip_cost) TSPMV_F(split_above) TSPMV_F(split_cap) TSPMV_F(xcd_remap) TSPMV_F(xcd_chunk)
         TSPMV_F(csr_split) TSPMV_F(fix_inline) TSPMV_F(coo_cost) TSPMV_F(coo_heavy_min) TSPMV_F(coo_piece) TSPMV_F(strip_even) TSPMV_F(wg_strips)
         TSPMV_F(x_window) TSPMV_F(x_stride1) TSPMV_F(x_stride2) TSPMV_F(mv_native) TSPMV_F(mv_xcd_chunk) TSPMV_F(lds_pad) TSPMV_F(y_store)
-        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(entry_trip) TSPMV_F(reserved)
+        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(reserved)
 #undef TSPMV_F
         return o;
     }();

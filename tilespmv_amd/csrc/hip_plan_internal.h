@@ -58,7 +58,6 @@ struct Knobs {
     int mv_native;       // -1 = by nvec
     int mv_xcd_chunk;    // -1 = the plan's XCD chunk
     int nt_stream;       // -1 by size, 0 plain, 1 nontemporal loads of the value / entry-record streams
-    int entry_trip;      // workgroup entry mode: sub-chunks per trip (6 / 16); -1 by rule
     int pace;            // slab pacing of the workgroup entry mode: -1 by rule, 0 off, 1 on
     int pace_slab_kb, pace_window, pace_team, pace_period_us;   // pace_period_us < 0: calibrate at plan creation
     int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows

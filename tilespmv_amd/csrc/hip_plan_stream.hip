@@ -892,13 +892,6 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     // webbase stand-ins in round 1, best or within 1 %)
     S.coo_heavy_min = K.coo_heavy_min;
     S.coo_ordered = coo_ordered ? 1 : 0;
-    // resident grids of the workgroup entry mode: every record of a workgroup in flight at once (k_units<.., ECT = 16>, built for 3 workgroups per CU)
-    {
-        const long long nwg = ((long long)tasks.size() + 15) / 16;
-        const bool fits = entry_mode == 2 && wg_strips == 16 && !xwin && !pace_on && nwg <= 3 * 256;
-        S.entry_ct = (fits && (K.entry_trip == 16 || (K.entry_trip < 0 && n_rec <= nwg * 16 * 256 * 3 / 2))) ? 16 : 6;   // (lists of up to ~1.5 long trips on average)
-        plan->info[TILESPMV_INFO_ENTRY_TRIP] = entry_mode == 2 ? S.entry_ct : 0;
-    }
     // y stores: streaming (nontemporal) where y is a real share of what the launch moves — they keep y from displacing x in L2: config 4 0.1946 -> 0.1845 ms,
     // 7-pt 256^3 0.2533 -> 0.2432, power-law 8 M 0.1078 -> 0.1043 — plain where it is a few per cent: there the streaming form buys nothing and makes the time
     // depend on where the CALLER's y happens to sit (nlpkkt160 stand-in fp64: 0.413 or 0.459 ms by the copy of y; plain: 0.408-0.411 with every copy)
