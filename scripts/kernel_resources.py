@@ -5,7 +5,7 @@ dt = sys.argv[1] if len(sys.argv) > 1 else "f64"
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 defs = ["-DMAT_VAL_TYPE=double"] if dt == "f64" else ["-DMAT_VAL_TYPE=float", "-DTILESPMV_F32"]
 out = "/tmp/kres_%s.s" % dt
-subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-I" + os.path.join(root, "include"), "--offload-arch=gfx950", "-munsafe-fp-atomics", "-w"] + defs +
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-I" + os.path.join(root, "include"), "--offload-arch=gfx950", "-munsafe-fp-atomics", "-w"] + defs + os.environ.get("KRES_DEFS", "").split() +
                ["-S", "--cuda-device-only", os.path.join(root, "tilespmv_amd/csrc/hip_kernels.hip"), "-o", out], check=True)
 s = open(out).read()
 names = re.findall(r"\.amdhsa_kernel (\S+)", s)

@@ -671,7 +671,10 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
                  dict(x_window=1, entry_mode=2, strip_cost=200), dict(x_window=1, x_stride1=3), dict(lds_pad=12288, xcd_remap=0),
                  dict(x_window=1, strip_cost=64, split_above=200), dict(x_window=2), dict(x_window=2, entry_mode=2, xcd_chunk=4), dict(x_window=0),
                  dict(desc_dict=0), dict(desc_dict=0, entry_mode=2), dict(desc_dict=0, entry_mode=1), dict(desc_dict=1, entry_mode=1, strip_cost=100),
-                 dict(nt_stream=1), dict(nt_stream=1, entry_mode=2, entry_ordered=1), dict(nt_stream=1, desc_dict=0, entry_mode=0), dict(nt_stream=0)]
+                 dict(nt_stream=1), dict(nt_stream=1, entry_mode=2, entry_ordered=1), dict(nt_stream=1, desc_dict=0, entry_mode=0), dict(nt_stream=0),
+                 # placement retry (round 4): the plan is moved to freshly allocated blocks, every device pointer rebased, and the faster placement kept — same bits either way
+                 dict(placement_tries=3), dict(placement_tries=2, entry_mode=2, strip_cost=64, split_above=200), dict(placement_tries=3, coo_mode=2), dict(placement_tries=2, x_window=1),
+                 dict(placement_tries=3, dense_mode=1, csr_split=0)]
     windowed = bricks = 0
     desc = {4: 0, 12: 0}
     for name, gen in mats.items():
@@ -685,6 +688,8 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
             assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
             if "entry_mode" in kw and not kw.get("x_window"):
                 assert info["entry_mode"] == kw["entry_mode"]
+            if "placement_tries" in kw:
+                assert info["placement_tries"] == kw["placement_tries"], (name, kw, info["placement_tries"])
             windowed += info["x_window_slots"] > 0
             bricks += info["brick_order"] == 1
             desc[info["desc_bytes"]] += 1

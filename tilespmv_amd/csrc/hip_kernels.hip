@@ -1120,6 +1120,9 @@ struct alignas(NV * sizeof(val_t) >= 16 ? 16 : NV * sizeof(val_t)) MVec { val_t 
 // skip_entries: the plan's merged, column-ordered entry lists are multiplied by k_entries_mv afterwards (entry-dominated plans with the
 // workgroup entry mode); this kernel then handles units only and stores zeros for the rows without units.
 // CD: dictionary plans (4-B descriptors): the next chunk's words are prefetched (one register), its patterns gathered at the switch.
+#ifndef MV_DEFER_F32_NV8
+#define MV_DEFER_F32_NV8 1   // fp32 nvec 8: a retired Y row is stored behind the next batch's loads (0.494 -> 0.465 ms in round 2; costs 16-24 bytes of scratch at 80 VGPRs)
+#endif
 #ifndef MV_NT_Y
 #define MV_NT_Y 1   // streaming stores of Y (as y in k_units)
 #endif
@@ -1145,6 +1148,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     // (profiles/r03_spmm.txt)
     constexpr bool MV_PREFETCH_DESC = !(sizeof(val_t) == 8 && NVT >= 4);
     __shared__ lacc_t s_c[GROUPS_PER_BLOCK][16][NV];
+    __shared__ val_t s_p[GROUPS_PER_BLOCK][16][NV];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
     unsigned bid = blockIdx.x;
@@ -1183,11 +1187,10 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     const bool have_units = unit_begin < unit_end;
     const long long xlast = (long long)colA - 1;
 
-    // first 16 COO entries of the strip: loaded and multiplied up front, scattered when their tile-row retires
+    // first 16 COO entries of the strip: loaded and multiplied up front, scattered when their tile-row retires.  The products wait in LDS (s_p, this lane's own slot),
+    // not in registers: held across the whole unit loop they were what the allocator spilled at 80 VGPRs (12-36 bytes of scratch, one reload per strip; round 3's
+    // "0 B scratch" was true of the dictionary forms in fp64 only)
     unsigned rb0 = 0xFFFFFFFFu;
-    vec_t p0;
-#pragma unroll
-    for (int j = 0; j < NV; j++) p0.v[j] = 0;
     if (epre) {
         for (int k = 0; k < nrows; k++) {
 #pragma unroll
@@ -1218,7 +1221,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
         const val_t cv = S.cval[coo_begin + r];
         const vec_t xx = Xv[(long long)cc * Q];
 #pragma unroll
-        for (int j = 0; j < NV; j++) p0.v[j] = cv * xx.v[j];
+        for (int j = 0; j < NV; j++) s_p[g][r][j] = cv * xx.v[j];
     }
     uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
     const unsigned *__restrict__ udw = reinterpret_cast<const unsigned *>(S.udesc_cb);
@@ -1255,7 +1258,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
         }
         if ((rb0 >> 4) == (unsigned)kr) {
 #pragma unroll
-            for (int j = 0; j < NV; j++) atomicAdd(&s_c[g][rb0 & 15u][j], (lacc_t)p0.v[j]);
+            for (int j = 0; j < NV; j++) atomicAdd(&s_c[g][rb0 & 15u][j], (lacc_t)s_p[g][r][j]);
         }
         for (int e0 = in_order ? scan_from : coo_begin + 16; e0 < coo_end; e0 += 16) {
             unsigned rb = 0xFFFFFFFFu;
@@ -1275,15 +1278,22 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
             }
         }
         wave_lds_fence();
+        // (the zeros that reset the slab come from a move the optimiser cannot hoist: kept live across the unit loop as a 16-byte constant they were spilled and RELOADED FROM
+        //  SCRATCH here in the fp32 build — 20 bytes of scratch for four zeros)
+        unsigned zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
 #pragma unroll
-        for (int j = 0; j < NV; j++) { acc[j] = (val_t)((lacc_t)acc[j] + s_c[g][r][j]); s_c[g][r][j] = 0; }
+        for (int j = 0; j < NV; j++) {
+            acc[j] = (val_t)((lacc_t)acc[j] + s_c[g][r][j]);
+            *reinterpret_cast<uint2 *>(&s_c[g][r][j]) = make_uint2(zero, zero);
+        }
         wave_lds_fence();
     };
     // Stores count in the same in-order vmcnt queue as loads: a store issued at the end of a batch makes the next batch's wait
     // for its gathers also wait for the store's acknowledge.  Where registers allow (no spill at 6 waves/SIMD), a retired row
     // waits in registers and is stored right AFTER the next batch's loads have been issued: nvec 2 fp64 0.256 -> 0.249 ms, nvec 8
     // fp32 0.494 -> 0.465 ms; with the spills it brings elsewhere (fp64 nvec 4 / 8: 6 VGPRs) it loses 5-7 %, so it is per variant.
-    constexpr bool MV_DEFER_STORE = NVT == 2 || (sizeof(val_t) == 4 && NVT == 8);
+    constexpr bool MV_DEFER_STORE = NVT == 2 || (MV_DEFER_F32_NV8 && sizeof(val_t) == 4 && NVT == 8);
     vec_t pend; int pend_kr = -1;
     auto store_vec = [&](int kr, const vec_t &o) {
         const long long yi = ((long long)row0 + kr) * 16 + r;

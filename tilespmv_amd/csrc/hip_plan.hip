@@ -6,6 +6,8 @@
 // tile stream of generation 1) and uploaded; the chunk schedule that the reference derives inside
 // tilespmv_cpu (:68-118) and patches up with a one-off v5 launch (:1045-1056) is replaced by a
 // cost-balanced strip list built here.
+#include <type_traits>
+
 #include "hip_plan_internal.h"
 
 namespace tilespmv {
@@ -62,6 +64,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.pace_window = std::max(1, pick(o.pace_window, "TILESPMV_PACE_WINDOW", 2));
     k.pace_team = pick(o.pace_team, "TILESPMV_PACE_TEAM", 0);
     k.pace_period_us = pick(o.pace_period_us, "TILESPMV_PACE_PERIOD_US", -1);
+    k.placement_tries = pick(o.placement_tries, "TILESPMV_PLACEMENT_TRIES", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
     k.entry_from_caller = pinned(o.entry_mode, "TILESPMV_WAVE_COO");
     k.strip_from_caller = o.strip_cost > 0 || env_int("TILESPMV_STRIP_COST", 0) > 0;
@@ -72,6 +75,79 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
 }  // namespace tilespmv
 
 using namespace tilespmv;
+
+// Every device pointer of a plan that points into its arena blocks (or the partial-slot array)
+template <class F>
+static void for_each_plan_pointer(tilespmv_plan *plan, F f)
+{
+    DevPlan &D = plan->dev; DevStream &S = plan->st; DevDense &N = plan->dn;
+    auto v = [&](auto &p) {   // (pointer members of different types and constness: moved through a const void * of the same bits)
+        const void *q = (const void *)p;
+        f(q);
+        p = (std::remove_reference_t<decltype(p)>)const_cast<void *>(q);
+    };
+    v(D.desc); v(D.val); v(D.idx); v(D.task); v(D.partial); v(D.fix); v(D.fix_late); v(D.f_blk); v(D.f_rec); v(D.f_base);
+    v(S.udesc); v(S.uval); v(S.cval); v(S.ccol); v(S.crow); v(S.task); v(S.wg_coo); v(S.grec); v(S.gbase); v(S.wg_win); v(S.win_cb); v(S.udict); v(S.udesc_cb);
+    v(S.ifix); v(S.ifix_count); v(S.pace); v(S.pace_sched);
+    v(N.cb); v(N.val); v(N.rows);
+}
+
+// Placement retry: identical plans run in one of two states 13 % apart on the KKT matrices, decided by where their blocks
+// landed in the card's memory — not by the plan.  So a large plan is timed where it was built, then MOVED: new blocks are allocated while the old ones are still
+// held (they land elsewhere), the streams are copied device to device, every pointer is rebased, and the plan is timed again; the faster placement stays (a later one
+// must be >= 4 % faster than the best so far), up to `tries` placements.  Costs two copies of the plan for a moment and a few launches.
+static void retry_placement(tilespmv_plan *plan, int tries)
+{
+    const bool verbose = getenv("TILESPMV_PLAN_VERBOSE") != nullptr;
+    plan->info[TILESPMV_INFO_PLACEMENT_TRIES] = 1;
+    if (tries <= 1 || plan->arena_blocks.empty()) return;
+    val_t *dx = nullptr, *dy = nullptr;
+    const size_t nx = (size_t)plan->dev.colA + 16, ny = (size_t)plan->dev.rowA + 16;
+    if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) return;
+    if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); return; }
+    { std::vector<val_t> ones(nx, (val_t)1); (void)hipMemcpy(dx, ones.data(), nx * sizeof(val_t), hipMemcpyHostToDevice); }
+    double best = tilespmv_plan_time(plan, dx, dy, nullptr, 3, 5);
+    if (verbose) fprintf(stderr, "tilespmv: placement 1: %.4f ms\n", best);
+    for (int t = 2; t <= tries && best > 0; t++) {
+        std::vector<std::pair<void *, size_t>> fresh;
+        bool ok = true;
+        for (auto &b : plan->arena_blocks) {
+            void *nb = nullptr;
+            if (hipMalloc(&nb, b.second) != hipSuccess) { ok = false; break; }
+            fresh.push_back({nb, b.second});
+            if (hipMemcpy(nb, b.first, b.second, hipMemcpyDeviceToDevice) != hipSuccess) { ok = false; break; }
+        }
+        if (!ok) { for (auto &b : fresh) (void)hipFree(b.first); break; }
+        auto rebase = [&](const std::vector<std::pair<void *, size_t>> &from, const std::vector<std::pair<void *, size_t>> &to) {
+            for_each_plan_pointer(plan, [&](const void *&p) {
+                if (!p) return;
+                for (size_t i = 0; i < from.size(); i++) {
+                    const char *b0 = (const char *)from[i].first;
+                    if ((const char *)p >= b0 && (const char *)p < b0 + from[i].second) { p = (const char *)to[i].first + ((const char *)p - b0); return; }
+                }
+            });
+        };
+        const std::vector<std::pair<void *, size_t>> old = plan->arena_blocks;
+        rebase(old, fresh);
+        const double ms = tilespmv_plan_time(plan, dx, dy, nullptr, 3, 5);
+        if (verbose) fprintf(stderr, "tilespmv: placement %d: %.4f ms (best so far %.4f)\n", t, ms, best);
+        plan->info[TILESPMV_INFO_PLACEMENT_TRIES] = t;
+        const bool keep = ms > 0 && ms < 0.96 * best;
+        const auto &drop = keep ? old : fresh;
+        if (!keep) rebase(fresh, old);
+        for (auto &b : drop) {
+            (void)hipFree(b.first);
+            auto it = std::find(plan->allocs.begin(), plan->allocs.end(), b.first);
+            if (it != plan->allocs.end()) plan->allocs.erase(it);
+        }
+        if (keep) {
+            for (auto &b : fresh) plan->allocs.push_back(b.first);
+            plan->arena_blocks = fresh;
+            best = ms;
+        }
+    }
+    (void)hipFree(dx); (void)hipFree(dy);
+}
 
 extern "C" {
 
@@ -128,7 +204,7 @@ const char *tilespmv_plan_options_layout(void)
         TSPMV_F(entry_mode) TSPMV_F(entry_ordered) TSPMV_F(strip_cost) TSPMV_F(split_above) TSPMV_F(split_cap) TSPMV_F(xcd_remap) TSPMV_F(xcd_chunk)
         TSPMV_F(csr_split) TSPMV_F(fix_inline) TSPMV_F(coo_cost) TSPMV_F(coo_heavy_min) TSPMV_F(coo_piece) TSPMV_F(strip_even) TSPMV_F(wg_strips)
         TSPMV_F(x_window) TSPMV_F(x_stride1) TSPMV_F(x_stride2) TSPMV_F(mv_native) TSPMV_F(mv_xcd_chunk) TSPMV_F(lds_pad) TSPMV_F(y_store)
-        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(reserved)
+        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(placement_tries) TSPMV_F(reserved)
 #undef TSPMV_F
         return o;
     }();
@@ -574,7 +650,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         void *p = nullptr;
         if (K.dry) { }
         else if (hipMalloc(&p, (size_t)npartial * 16 * sizeof(val_t) * TILESPMV_MAX_NVEC) != hipSuccess) rc = -3;  // slots are nvec wide in tilespmv_plan_spmm
-        else { plan->allocs.push_back(p); D.partial = (val_t *)p; }
+        else { plan->allocs.push_back(p); plan->arena_blocks.push_back({p, (size_t)npartial * 16 * sizeof(val_t) * TILESPMV_MAX_NVEC}); D.partial = (val_t *)p; }
     }
     if (!f_blk.empty()) {
         rc |= plan->upload(f_rec.data(), f_rec.size(), &D.f_rec);
@@ -602,6 +678,12 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     // bytes one SpMV has to move at least: the three streams + tasks + x once + y once (+ fallback)
     I[TILESPMV_INFO_STREAM_BYTES] = model_bytes + (long long)colA * sv + (long long)rows * sv +
                                     (f_nnz ? (long long)f_rec.size() * (long long)sizeof(ERec) + (long long)f_base.size() * 4 + 2LL * sv * rows + (long long)f_blk.size() * 16 : 0);   // the fallback re-reads and re-writes its rows of y
+    if (!K.dry) {
+        const int tries = K.placement_tries >= 0 ? K.placement_tries : (I[TILESPMV_INFO_DEVICE_BYTES] >= (1ll << 30) ? 3 : 1);
+        const double t0p = now_us();
+        retry_placement(plan, tries);
+        I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0p);
+    }
     if (!K.dry && plan->pace_calibrate && plan->st.pace != nullptr) {
         const double t0c = now_us();
         calibrate_pace(plan);

@@ -60,6 +60,7 @@ struct Knobs {
     int nt_stream;       // -1 by size, 0 plain, 1 nontemporal loads of the value / entry-record streams
     int pace;            // slab pacing of the workgroup entry mode: -1 by rule, 0 off, 1 on
     int pace_slab_kb, pace_window, pace_team, pace_period_us;   // pace_period_us < 0: calibrate at plan creation
+    int placement_tries; // large plans: arena placements timed at plan creation (-1 by size, 0 / 1 off, n)
     int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
     bool dry;            // tilespmv_plan_layout_digest: build the layout on the host only, hash instead of upload
@@ -82,6 +83,7 @@ struct tilespmv_plan {
     int mv_slab_rows = 0;                    // > 0: the multi-vector kernel scatters a strip's entries up front into an LDS slab of this many tile-rows per lane group
     int entry_mode = 0;                 // COO entry lists walked per 16-lane strip (0), per wavefront (1) or per workgroup, column-ordered (2)
     std::vector<void *> allocs;
+    std::vector<std::pair<void *, size_t>> arena_blocks;   // the blocks the plan's streams were carved from (and the partial-slot array), with their sizes: what a re-placement moves
     long long info[TILESPMV_INFO_COUNT] = {0};
     int coo_mode = 0, dense_mode = 0, kernel = 0;
     int device = 0;
@@ -120,6 +122,7 @@ struct tilespmv_plan {
             if (arena_flags) HIP_TRY(hipExtMallocWithFlags(&b, blk, (unsigned)arena_flags));   // experiment knob TILESPMV_ARENA_FLAGS (4 = physically contiguous)
             else HIP_TRY(hipMalloc(&b, blk));
             allocs.push_back(b);
+            arena_blocks.push_back({b, blk});
             arena_at = (char *)b; arena_left = blk;
         }
         d = arena_at; arena_at += need; arena_left -= need;
