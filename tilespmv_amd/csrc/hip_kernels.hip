@@ -1121,7 +1121,7 @@ struct alignas(NV * sizeof(val_t) >= 16 ? 16 : NV * sizeof(val_t)) MVec { val_t 
 // workgroup entry mode); this kernel then handles units only and stores zeros for the rows without units.
 // CD: dictionary plans (4-B descriptors): the next chunk's words are prefetched (one register), its patterns gathered at the switch.
 #ifndef MV_DEFER_F32_NV8
-#define MV_DEFER_F32_NV8 1   // fp32 nvec 8: a retired Y row is stored behind the next batch's loads (0.494 -> 0.465 ms in round 2; costs 16-24 bytes of scratch at 80 VGPRs)
+#define MV_DEFER_F32_NV8 0   // fp32 nvec 8: a retired Y row stored behind the next batch's loads won in round 2 (0.494 -> 0.465 ms); with the round-4 kernel it costs 16-24 bytes of scratch and loses (config 4 0.528 vs 0.469 ms, KKT fp32 0.981 vs 0.968: profiles/r04_spmm.txt)
 #endif
 #ifndef MV_NT_Y
 #define MV_NT_Y 1   // streaming stores of Y (as y in k_units)

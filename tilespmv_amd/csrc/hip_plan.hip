@@ -101,51 +101,64 @@ static void retry_placement(tilespmv_plan *plan, int tries)
     const bool verbose = getenv("TILESPMV_PLAN_VERBOSE") != nullptr;
     plan->info[TILESPMV_INFO_PLACEMENT_TRIES] = 1;
     if (tries <= 1 || plan->arena_blocks.empty()) return;
+    typedef std::vector<std::pair<void *, size_t>> Blocks;
     val_t *dx = nullptr, *dy = nullptr;
     const size_t nx = (size_t)plan->dev.colA + 16, ny = (size_t)plan->dev.rowA + 16;
     if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) return;
     if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); return; }
     { std::vector<val_t> ones(nx, (val_t)1); (void)hipMemcpy(dx, ones.data(), nx * sizeof(val_t), hipMemcpyHostToDevice); }
-    double best = tilespmv_plan_time(plan, dx, dy, nullptr, 3, 5);
-    if (verbose) fprintf(stderr, "tilespmv: placement 1: %.4f ms\n", best);
-    for (int t = 2; t <= tries && best > 0; t++) {
-        std::vector<std::pair<void *, size_t>> fresh;
+    auto rebase = [&](const Blocks &from, const Blocks &to) {
+        for_each_plan_pointer(plan, [&](const void *&p) {
+            if (!p) return;
+            for (size_t i = 0; i < from.size(); i++) {
+                const char *b0 = (const char *)from[i].first;
+                if ((const char *)p >= b0 && (const char *)p < b0 + from[i].second) { p = (const char *)to[i].first + ((const char *)p - b0); return; }
+            }
+        });
+    };
+    auto show = [&](int t, double ms, const Blocks &bl) {
+        if (!verbose) return;
+        fprintf(stderr, "tilespmv: placement %d: %.4f ms  blocks at", t, ms);
+        for (auto &b : bl) fprintf(stderr, " %p(+%zu MB)", b.first, b.second >> 20);
+        fprintf(stderr, "\n");
+    };
+    // every candidate placement stays allocated until the choice is made: a freed block would simply be handed out again and the same placement timed twice
+    std::vector<Blocks> cand{plan->arena_blocks};
+    std::vector<double> ms{tilespmv_plan_time(plan, dx, dy, nullptr, 3, 5)};
+    show(1, ms[0], cand[0]);
+    size_t at = 0, best = 0;   // where the plan's pointers point now; the placement to keep
+    for (int t = 2; t <= tries && ms[0] > 0; t++) {
+        Blocks fresh;
         bool ok = true;
-        for (auto &b : plan->arena_blocks) {
+        for (auto &b : cand[0]) {
             void *nb = nullptr;
             if (hipMalloc(&nb, b.second) != hipSuccess) { ok = false; break; }
             fresh.push_back({nb, b.second});
-            if (hipMemcpy(nb, b.first, b.second, hipMemcpyDeviceToDevice) != hipSuccess) { ok = false; break; }
+            if (hipMemcpy(nb, cand[at][fresh.size() - 1].first, b.second, hipMemcpyDeviceToDevice) != hipSuccess) { ok = false; break; }
         }
         if (!ok) { for (auto &b : fresh) (void)hipFree(b.first); break; }
-        auto rebase = [&](const std::vector<std::pair<void *, size_t>> &from, const std::vector<std::pair<void *, size_t>> &to) {
-            for_each_plan_pointer(plan, [&](const void *&p) {
-                if (!p) return;
-                for (size_t i = 0; i < from.size(); i++) {
-                    const char *b0 = (const char *)from[i].first;
-                    if ((const char *)p >= b0 && (const char *)p < b0 + from[i].second) { p = (const char *)to[i].first + ((const char *)p - b0); return; }
-                }
-            });
-        };
-        const std::vector<std::pair<void *, size_t>> old = plan->arena_blocks;
-        rebase(old, fresh);
-        const double ms = tilespmv_plan_time(plan, dx, dy, nullptr, 3, 5);
-        if (verbose) fprintf(stderr, "tilespmv: placement %d: %.4f ms (best so far %.4f)\n", t, ms, best);
+        rebase(cand[at], fresh);
+        cand.push_back(fresh); at = cand.size() - 1;
+        ms.push_back(tilespmv_plan_time(plan, dx, dy, nullptr, 3, 5));
+        show(t, ms.back(), fresh);
         plan->info[TILESPMV_INFO_PLACEMENT_TRIES] = t;
-        const bool keep = ms > 0 && ms < 0.96 * best;
-        const auto &drop = keep ? old : fresh;
-        if (!keep) rebase(fresh, old);
-        for (auto &b : drop) {
+        if (ms.back() > 0 && ms.back() < 0.96 * ms[best]) best = at;   // a later placement must be clearly faster
+        if (ms[best] < 0.96 * ms[0] && best == at) break;             // found a faster state: the states are two, tight (S6.13) — stop looking
+    }
+    if (at != best) rebase(cand[at], cand[best]);
+    for (size_t i = 0; i < cand.size(); i++) {
+        if (i == best) continue;
+        for (auto &b : cand[i]) {
             (void)hipFree(b.first);
             auto it = std::find(plan->allocs.begin(), plan->allocs.end(), b.first);
             if (it != plan->allocs.end()) plan->allocs.erase(it);
         }
-        if (keep) {
-            for (auto &b : fresh) plan->allocs.push_back(b.first);
-            plan->arena_blocks = fresh;
-            best = ms;
-        }
     }
+    if (best != 0) {
+        for (auto &b : cand[best]) plan->allocs.push_back(b.first);
+        plan->arena_blocks = cand[best];
+    }
+    if (verbose) fprintf(stderr, "tilespmv: placement %zu of %zu kept (%.4f ms; first %.4f)\n", best + 1, cand.size(), ms[best], ms[0]);
     (void)hipFree(dx); (void)hipFree(dy);
 }
 
@@ -679,7 +692,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     I[TILESPMV_INFO_STREAM_BYTES] = model_bytes + (long long)colA * sv + (long long)rows * sv +
                                     (f_nnz ? (long long)f_rec.size() * (long long)sizeof(ERec) + (long long)f_base.size() * 4 + 2LL * sv * rows + (long long)f_blk.size() * 16 : 0);   // the fallback re-reads and re-writes its rows of y
     if (!K.dry) {
-        const int tries = K.placement_tries >= 0 ? K.placement_tries : (I[TILESPMV_INFO_DEVICE_BYTES] >= (1ll << 30) ? 3 : 1);
+        const int tries = K.placement_tries >= 0 ? K.placement_tries : (I[TILESPMV_INFO_DEVICE_BYTES] >= (1ll << 30) ? 5 : 1);
         const double t0p = now_us();
         retry_placement(plan, tries);
         I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0p);
