@@ -38,7 +38,11 @@ bench = None
 for line in open(os.path.join(d, "bench_under_trace.json")):
     if line.startswith("{"):
         bench = json.loads(line)
-out = {"workload": wl, "dtype": dt, "kernel": dom, "measured": time.strftime("round 3, %Y-%m-%d"),
+if bench is not None and isinstance(bench.get("roofline"), dict):
+    # the line printed under the trace looked at the PREVIOUS traffic file (this one did not exist yet): what it says about that file's freshness is not about this one
+    for k in ("traffic", "traffic_source", "actual_traffic_gbps", "actual_traffic_over_read_ceiling"):
+        bench["roofline"].pop(k, None)
+out = {"workload": wl, "dtype": dt, "kernel": dom, "measured": time.strftime(os.environ.get("TILESPMV_ROUND_TAG", "round 4") + ", %Y-%m-%d"),
        # the plan these passes measured: bench.py reports `traffic` only while its live plan has the same fingerprint
        "plan_fingerprint": None if bench is None else (bench.get("roofline") or {}).get("plan_fingerprint"),
        "FETCH_SIZE_kb": per.get(dom, {}).get("FETCH_SIZE_kb"), "WRITE_SIZE_kb": per.get(dom, {}).get("WRITE_SIZE_kb"),

@@ -688,8 +688,8 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
             assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
             if "entry_mode" in kw and not kw.get("x_window"):
                 assert info["entry_mode"] == kw["entry_mode"]
-            if "placement_tries" in kw:
-                assert info["placement_tries"] == kw["placement_tries"], (name, kw, info["placement_tries"])
+            if "placement_tries" in kw:      # (the retry stops at the first placement that is clearly faster than the first one)
+                assert 2 <= info["placement_tries"] <= kw["placement_tries"], (name, kw, info["placement_tries"])
             windowed += info["x_window_slots"] > 0
             bricks += info["brick_order"] == 1
             desc[info["desc_bytes"]] += 1
