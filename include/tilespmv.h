@@ -302,6 +302,10 @@ typedef struct {
     int pace_team;      /* ... workgroups per team and XCD (unset: what the occupancy query says one XCD holds)  TILESPMV_PACE_TEAM */
     int pace_period_us; /* ... microseconds one team's sweep over x is given (the timetable's length); unset: calibrated by timing at plan creation — and a
                            plan that does not get faster is launched unpaced; 0: nobody waits                        TILESPMV_PACE_PERIOD_US */
+    int x_panel_kb;     /* column panels (round 4): the merged entry lists of the workgroup entry mode are cut by column into panels of this many KB of x; the unit kernel
+                           takes panel 0 and one more launch per further panel adds its entries (y +=): the kernel boundary is the one cheap chip-wide synchronisation, so
+                           all gathers of a pass fall into one panel of x and far more of them hit the L2s (scattered matrices with a large x).  0 off; unset: by rule
+                                                                                                            TILESPMV_X_PANEL_KB */
     int placement_tries; /* where a large plan's blocks land in the card's memory decides between two states 13 % apart on the KKT matrices:
                            at plan creation the plan is timed (5 launches), moved to freshly allocated blocks (allocated BEFORE the old ones are freed) and timed
                            again, up to this many placements (all held until the choice is made); the first placement >= 4 % faster than the first one is kept.  unset: 5 for plans of >= 1 GB, else 1 (= off)
@@ -412,7 +416,8 @@ enum {
     TILESPMV_INFO_PACE_TEAM = 23,         /* ... workgroups per team and XCD */
     TILESPMV_INFO_PLACEMENT_TRIES = 24,   /* arena placements timed at plan creation (large plans; 0 / 1 = the first one was kept) */
     TILESPMV_INFO_PACE_PERIOD_US = 25,    /* ... microseconds of one team's timetable (0 = not paced) */
-    TILESPMV_INFO_COUNT = 26
+    TILESPMV_INFO_X_PANELS = 26,          /* column panels of the entry lists = launches of the entry part (1 = not panelled) */
+    TILESPMV_INFO_COUNT = 27
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
 

@@ -616,6 +616,49 @@ def test_inline_fixup_of_split_rows_is_stable_across_launches(torch_cuda, monkey
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_column_panels_bit_exact(torch_cuda, dtype):
+    """Round 4: the merged entry lists cut by column into panels — panel 0 with the unit kernel, one k_entries_acc launch (y +=) per further panel.  The oracle's y bit for bit
+    with 2 ... 64 panels, ordered and unordered adds, split tile-rows (their pieces add atomically), tiny strips, both descriptor forms; repeated launches on one plan; and the
+    multi-vector product on a panelled plan (which must not take the entry pass over panel 0 alone)."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    O = CpuImpl("oracle", dtype)
+    mats = {"powerlaw200k": MEDIUM["powerlaw200k"], "bandrand60k": lambda: G.band_plus_random(60000, 4, 3, 5), "uniform40k": lambda: G.uniform_per_row(40000, 70001, 8, 1),
+            "allfmt": SMALL["allfmt"], "one_long_row": SMALL["one_long_row"], "wide_row_tiles": SMALL["wide_row_tiles"], "circuit60k": MEDIUM["circuit60k"]}
+    knob_sets = [dict(x_panel_kb=64), dict(x_panel_kb=8, entry_ordered=0), dict(x_panel_kb=1, entry_ordered=1), dict(x_panel_kb=256, desc_dict=0, nt_stream=1),
+                 dict(x_panel_kb=16, strip_cost=64, split_above=200), dict(x_panel_kb=32, xcd_remap=0, strip_cost=100), dict(x_panel_kb=128, placement_tries=2)]
+    panelled = 0
+    for name, gen in mats.items():
+        m, n, rp, ci = gen()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, x = values_for(name, nnz, n, dtype)
+        want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, x)["y"]
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=True)
+        for kw in knob_sets:
+            y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, entry_mode=2, **kw)
+            assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
+            panelled += info["x_panels"] > 1
+            assert info["x_panels"] <= 64
+        plan = api.Plan(tp, rowA, n, nnz, entry_mode=2, x_panel_kb=16)
+        xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda(); yd = torch_cuda.zeros(rowA + 16, dtype=xd.dtype, device="cuda")
+        for it in range(5):
+            yd.fill_(3.0); plan.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()
+            assert np.array_equal(yd.cpu().numpy()[:rowA], want), (name, "launch", it)
+        X = (np.arange(n * 4, dtype=np.int64) % 5).astype(dtype).reshape(n, 4)
+        Xd = torch_cuda.from_numpy(X).cuda(); Yd = torch_cuda.zeros((rowA + 16, 4), dtype=Xd.dtype, device="cuda")
+        for nv in (2, 4):
+            plan.spmm(Xd[:, :nv].contiguous().data_ptr(), Yd[:, :nv].contiguous().data_ptr(), nv)    # (contiguous copies: checked through a second buffer below)
+        Xc = Xd[:, :2].contiguous(); Yc = torch_cuda.zeros((rowA + 16, 2), dtype=Xd.dtype, device="cuda")
+        plan.spmm(Xc.data_ptr(), Yc.data_ptr(), 2); torch_cuda.cuda.synchronize()
+        for j in range(2):
+            wj = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"]
+            assert np.array_equal(Yc.cpu().numpy()[:rowA, j], wj), (name, "spmm on a panelled plan", j)
+        plan.close()
+        api.Tile_destroy(tp)
+    assert panelled >= 25
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_slab_paced_entry_phase_bit_exact(torch_cuda, dtype):
     """Round 4: the workgroup entry mode with slab pacing (teams of co-resident workgroups gather from the same few slabs of x at one time; pacing is
     speed only).  The oracle's y bit for bit — with slabs so small that the test matrices have hundreds, teams of one

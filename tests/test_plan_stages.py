@@ -133,3 +133,14 @@ def test_slab_pacing_adds_a_sentinel_to_the_lists_and_counters_to_the_plan(mats)
         assert api.plan_layout_stages(tm, rows, n, nnz, pace=1, pace_slab_kb=1, **kw)[1]["pace_slabs"] == 0, kw
     tm, rows, n, nnz = mats["allfmt"]         # 192 columns: one slab, nothing to pace
     assert api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, pace=1, pace_slab_kb=1)[1]["pace_slabs"] == 0
+
+
+def test_column_panels_cut_the_lists_and_nothing_else(mats):
+    tm, rows, n, nnz = mats["bandrand"]
+    one, i1 = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2)
+    many, ik = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32)
+    assert (i1["x_panels"], ik["x_panels"]) == (1, -(-n // 4096))
+    assert _changed(one, many) == ["choose", "entries", "finish"]
+    assert ik["stream_bytes"] > i1["stream_bytes"]                      # the panel passes read and write their rows of y
+    for kw in (dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, wg_strips=32), dict(entry_mode=2, pace=1, pace_slab_kb=1)):
+        assert api.plan_layout_stages(tm, rows, n, nnz, x_panel_kb=32, **kw)[1]["x_panels"] == 1, kw

@@ -1013,6 +1013,64 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
 }
 
 // ------------------------------------------------------------------------------------------------
+// Column panels (round 4; DevStream::x_panels): y += A_p x for the entries of column panel p >= 1.  The merged, column-ordered lists of the workgroup entry mode are
+// cut by column into panels of a few MB of x at plan time; k_units walks panel 0 with the units, and every further panel is one launch of this kernel: the same groups
+// of 16 strips, the same records and trip routine, row sums in the same LDS slabs, then y += for the strips that have entries.  Why launches: on scattered matrices with
+// a large x every gather misses the XCD's L2 and pulls a 128-byte line across the fabric (profiles/r04_pmc_*_before.json); the workgroups would have to sweep x TOGETHER
+// for the lines to be shared, and a kernel boundary is the one chip-wide synchronisation that costs microseconds instead of the polls and timetables of S6.17 — inside one
+// launch every gather of the chip falls into one panel.  The price is the read-modify-write of y per pass.  Pieces of split tile-rows add atomically (their row was written
+// by the piece that finished last in k_units).
+// ------------------------------------------------------------------------------------------------
+template <int XCD_REMAP, bool NTS>
+__global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream S, int rowA, int xcd_chunk, int panel, const val_t *__restrict__ x, val_t *__restrict__ y)
+{
+    __shared__ lacc_t s_acc[GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16];
+    const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
+    unsigned bid = blockIdx.x;
+    if (XCD_REMAP == 2) {   // the same workgroup -> XCD windows as k_units: a group's rows of y and its x neighbourhood stay with the XCD that touched them
+        const unsigned C = (unsigned)xcd_chunk, W = 8u * C, win = bid / W, off = bid % W, k = off & 7u;
+        if ((win + 1) * W <= gridDim.x) bid = win * W + k * C + (off >> 3);
+    }
+    const int4 wr = S.wg_coo[(size_t)panel * (size_t)S.n_groups + bid];
+    if (wr.y <= wr.x) return;   // workgroup-uniform: nothing of this group in this panel
+    const long long task_id = (long long)bid * GROUPS_PER_BLOCK + g;
+    int4 t0 = make_int4(0, 0, 0, 0), t1 = make_int4(0, -1, 0, 0);
+    if (task_id < S.ntasks) {
+        t0 = reinterpret_cast<const int4 *>(S.task)[task_id * 2];
+        t1 = reinterpret_cast<const int4 *>(S.task)[task_id * 2 + 1];
+    }
+    const bool side = t0.w > t0.z;
+    const int row0 = t1.x, part = t1.y, nrows = t1.w;
+    for (int i = tid; i < GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16; i += 256) s_acc[i] = 0;
+    __syncthreads();
+    wg_entry_trips<WCOO_HEAVY_CT, 256, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, s_acc, tid, wr.x, wr.y);
+    __syncthreads();
+    if (!side) return;
+    const lacc_t *mine = s_acc + g * (STRIP_MAX_ROWS * 16);
+    if (part >= 0) {
+        const long long yi = (long long)row0 * 16 + r;
+        if (yi < rowA) atomicAdd(&y[yi], (val_t)mine[r]);
+    } else {
+        for (int k = 0; k < nrows; k++) {
+            const long long yi = ((long long)row0 + k) * 16 + r;
+            if (yi < rowA) y[yi] = (val_t)((lacc_t)y[yi] + mine[k * 16 + r]);
+        }
+    }
+}
+
+hipError_t launch_entry_panels(const DevStream &S, int rowA, int xcd_remap, int xcd_chunk, const val_t *x, val_t *y, hipStream_t st)
+{
+    for (int p = 1; p < S.x_panels; p++) {
+        const dim3 grid((unsigned)S.n_groups), blk(256);
+        if (xcd_remap == 2) { if (S.nt_stream) hipLaunchKernelGGL((k_entries_acc<2, true>), grid, blk, 0, st, S, rowA, xcd_chunk, p, x, y);
+                              else hipLaunchKernelGGL((k_entries_acc<2, false>), grid, blk, 0, st, S, rowA, xcd_chunk, p, x, y); }
+        else { if (S.nt_stream) hipLaunchKernelGGL((k_entries_acc<0, true>), grid, blk, 0, st, S, rowA, xcd_chunk, p, x, y);
+               else hipLaunchKernelGGL((k_entries_acc<0, false>), grid, blk, 0, st, S, rowA, xcd_chunk, p, x, y); }
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dense tiles on the matrix cores (reference dense kernel: src/tilespmv_cuda.h:664-710).
 // One wavefront per tile-row.  A dense tile is 256 contiguous values (stored in operand order, below); k-step s of
 // v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 with lane group q (= k index) covers tile column
@@ -1666,6 +1724,7 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
         Q.fix = P.fix_late; Q.nfix = P.nfix_late;
         hipLaunchKernelGGL(k_fixup_split, dim3((Q.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, Q, y);
     }
+    if (S.x_panels > 1 && S.ntasks > 0) return launch_entry_panels(S, P.rowA, xcd_remap, xcd_chunk, x, y, st);   // y += the entries of the other column panels, last: every row has been written
     return hipGetLastError();
 }
 

@@ -144,6 +144,9 @@ struct DevStream {
     // that its scattered gathers fall into the same few slabs — which stay in the XCD's L2 — instead of each pulling a 128-byte line across the fabric
     // (profiles/r04_gather_locality.txt).  Lists of paced plans: the workgroup's local entries first (wg_coo.w = their record count, a multiple of 64),
     // then the remote ones in column order, one more base word per list (its last column).  Speed only: no result depends on the clock.
+    // column panels (round 4): wg_coo holds x_panels x (groups) list ranges, panel-major; k_units walks panel 0, k_entries_acc adds panel p >= 1 (y +=) in a launch of its own
+    int x_panels;                         // 1: not panelled
+    int n_groups;                         // groups (workgroups of the entry phase) per panel
     unsigned *pace;                       // per team {start clock, wavefronts done}; nullptr: no pacing
     const unsigned *pace_sched;           // [pace_nslab + 1]: share of the shard's remote entries left of slab s, in 1 / 2^24
     unsigned pace_period;                 // 10-ns ticks one team's sweep is given (calibrated at plan creation; 0: nobody waits)

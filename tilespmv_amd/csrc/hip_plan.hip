@@ -65,6 +65,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.pace_team = pick(o.pace_team, "TILESPMV_PACE_TEAM", 0);
     k.pace_period_us = pick(o.pace_period_us, "TILESPMV_PACE_PERIOD_US", -1);
     k.placement_tries = pick(o.placement_tries, "TILESPMV_PLACEMENT_TRIES", -1);
+    k.x_panel_kb = pick(o.x_panel_kb, "TILESPMV_X_PANEL_KB", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
     k.entry_from_caller = pinned(o.entry_mode, "TILESPMV_WAVE_COO");
     k.strip_from_caller = o.strip_cost > 0 || env_int("TILESPMV_STRIP_COST", 0) > 0;
@@ -217,7 +218,7 @@ const char *tilespmv_plan_options_layout(void)
         TSPMV_F(entry_mode) TSPMV_F(entry_ordered) TSPMV_F(strip_cost) TSPMV_F(split_above) TSPMV_F(split_cap) TSPMV_F(xcd_remap) TSPMV_F(xcd_chunk)
         TSPMV_F(csr_split) TSPMV_F(fix_inline) TSPMV_F(coo_cost) TSPMV_F(coo_heavy_min) TSPMV_F(coo_piece) TSPMV_F(strip_even) TSPMV_F(wg_strips)
         TSPMV_F(x_window) TSPMV_F(x_stride1) TSPMV_F(x_stride2) TSPMV_F(mv_native) TSPMV_F(mv_xcd_chunk) TSPMV_F(lds_pad) TSPMV_F(y_store)
-        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(placement_tries) TSPMV_F(reserved)
+        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(x_panel_kb) TSPMV_F(placement_tries) TSPMV_F(reserved)
 #undef TSPMV_F
         return o;
     }();
@@ -772,7 +773,7 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
     // at a time at every nvec (webbase stand-in 37 / 58 / 93 us against 42 / 85 / 223) and beats the separate entry pass over the merged lists (k_entries_mv; workgroup entry mode,
     // 16 strips, no x windows) from nvec 4 on (power-law 8 M: 0.254 / 0.375 / 0.678 ms against 0.198 / 0.469 / 1.364 with the pass): the pass stays for nvec 2.
     // mv_native: -1 by rule, 0 one right-hand side at a time, 1 the multi-vector kernel alone, 2 the multi-vector kernel + entry pass
-    const bool can_pass = has_native && plan->entry_mode == 2 && plan->wg_strips == 16 && plan->xwin_lds_bytes == 0;
+    const bool can_pass = has_native && plan->entry_mode == 2 && plan->wg_strips == 16 && plan->xwin_lds_bytes == 0 && plan->st.x_panels <= 1;   // (a panelled plan's wg_coo[group] is panel 0 only)
     const bool entries_pass = can_pass && (mv_native == 2 || (mv_native < 0 && plan->mv_by_columns && nvec < 4));
     const bool one_at_a_time = !has_native || mv_native == 0 || (mv_native < 0 && plan->mv_by_columns && !entries_pass && plan->mv_slab_rows == 0 && nvec < 8);
     if (one_at_a_time) {

@@ -60,6 +60,7 @@ struct Knobs {
     int nt_stream;       // -1 by size, 0 plain, 1 nontemporal loads of the value / entry-record streams
     int pace;            // slab pacing of the workgroup entry mode: -1 by rule, 0 off, 1 on
     int pace_slab_kb, pace_window, pace_team, pace_period_us;   // pace_period_us < 0: calibrate at plan creation
+    int x_panel_kb;      // column panels of the entry lists: KB of x per panel; 0 off, -1 by rule
     int placement_tries; // large plans: arena placements timed at plan creation (-1 by size, 0 / 1 off, n)
     int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
