@@ -302,10 +302,14 @@ typedef struct {
     int pace_team;      /* ... workgroups per team and XCD (unset: what the occupancy query says one XCD holds)  TILESPMV_PACE_TEAM */
     int pace_period_us; /* ... microseconds one team's sweep over x is given (the timetable's length); unset: calibrated by timing at plan creation — and a
                            plan that does not get faster is launched unpaced; 0: nobody waits                        TILESPMV_PACE_PERIOD_US */
-    int x_panel_kb;     /* column panels (round 4): the merged entry lists of the workgroup entry mode are cut by column into panels of this many KB of x; the unit kernel
-                           takes panel 0 and one more launch per further panel adds its entries (y +=): the kernel boundary is the one cheap chip-wide synchronisation, so
-                           all gathers of a pass fall into one panel of x and far more of them hit the L2s (scattered matrices with a large x).  0 off; unset: by rule
-                                                                                                            TILESPMV_X_PANEL_KB */
+    int x_panel_kb;     /* column panels (round 4): the merged entry lists of the workgroup entry mode are in column order, so the entries of a column panel (this many
+                           KB of x; a power of two) are a run of a list; the plan records where the panels begin.  A panelled launch gives the unit kernel the first
+                           x_panel_merge panels and every further run of x_panel_merge panels one more launch that adds its entries (y +=): the kernel boundary is the
+                           one cheap chip-wide synchronisation, so all gathers of a pass fall into one slice of x and more of them hit the L2s (scattered matrices
+                           with a large x: uniform random 8 M rows 1.00 -> 0.80 ms).  0 = no panels; unset: 2048 on entry-dominated shards whose x is >= 12 MB
+                                                                                                                             TILESPMV_X_PANEL_KB */
+    int x_panel_merge;  /* ... panels per pass: 0 = whole lists in the unit kernel (unpanelled launch); unset: chosen by timing at plan creation among 0 and the merges
+                           that make passes of 4, 8 and 16 MB of x (kept when >= 3 % faster than the unpanelled launch)       TILESPMV_X_PANEL_MERGE */
     int placement_tries; /* where a large plan's blocks land in the card's memory decides between two states 13 % apart on the KKT matrices:
                            at plan creation the plan is timed (5 launches), moved to freshly allocated blocks (allocated BEFORE the old ones are freed) and timed
                            again, up to this many placements (all held until the choice is made); the first placement >= 4 % faster than the first one is kept.  unset: 5 for plans of >= 1 GB, else 1 (= off)

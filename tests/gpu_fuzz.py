@@ -107,7 +107,7 @@ def check(seed):
     if seed % 3 == 1: env["TILESPMV_DESC_DICT"] = "0"   # 12-B unit descriptors (the default takes the 4-B dictionary form wherever the patterns are few)
     # round 4: column panels of the entry lists (panel 0 in the unit kernel, one y += launch per further panel)
     if env.get("TILESPMV_WAVE_COO") == "2" and env.get("TILESPMV_WG_STRIPS") != "32" and seed % 3 == 2:
-        env["TILESPMV_X_PANEL_KB"] = str([1, 4, 2, 16][(seed // 3) % 4])
+        env.update({"TILESPMV_X_PANEL_KB": str([1, 4, 2, 16][(seed // 3) % 4]), "TILESPMV_X_PANEL_MERGE": str(1 + (seed // 7) % 3)})
     # round 4: slab-paced workgroup entry phase — tiny slabs (128 ... 2048 columns) so that the small fuzz matrices have many, teams of 1 ... 192 workgroups
     # (a team larger than the grid is clamped), leads of 0-2 slabs, timetables of 0 (nobody waits), 20 and 200 microseconds
     if env.get("TILESPMV_WAVE_COO") == "2" and env.get("TILESPMV_WG_STRIPS") != "32" and seed % 3 != 2:

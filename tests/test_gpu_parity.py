@@ -617,16 +617,18 @@ def test_inline_fixup_of_split_rows_is_stable_across_launches(torch_cuda, monkey
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_column_panels_bit_exact(torch_cuda, dtype):
-    """Round 4: the merged entry lists cut by column into panels — panel 0 with the unit kernel, one k_entries_acc launch (y +=) per further panel.  The oracle's y bit for bit
-    with 2 ... 64 panels, ordered and unordered adds, split tile-rows (their pieces add atomically), tiny strips, both descriptor forms; repeated launches on one plan; and the
+    """Round 4: column panels of the merged entry lists — the first run of panels with the unit kernel, one k_entries_acc launch (y +=) per further run.  The oracle's y bit for bit
+    with 2 ... 64 passes, ordered and unordered adds, split tile-rows (their pieces add atomically), tiny strips, both descriptor forms; repeated launches on one plan; and the
     multi-vector product on a panelled plan (which must not take the entry pass over panel 0 alone)."""
     from oracle.oracle import CpuImpl
     from tilespmv_amd import api, generators as G
     O = CpuImpl("oracle", dtype)
     mats = {"powerlaw200k": MEDIUM["powerlaw200k"], "bandrand60k": lambda: G.band_plus_random(60000, 4, 3, 5), "uniform40k": lambda: G.uniform_per_row(40000, 70001, 8, 1),
             "allfmt": SMALL["allfmt"], "one_long_row": SMALL["one_long_row"], "wide_row_tiles": SMALL["wide_row_tiles"], "circuit60k": MEDIUM["circuit60k"]}
-    knob_sets = [dict(x_panel_kb=64), dict(x_panel_kb=8, entry_ordered=0), dict(x_panel_kb=1, entry_ordered=1), dict(x_panel_kb=256, desc_dict=0, nt_stream=1),
-                 dict(x_panel_kb=16, strip_cost=64, split_above=200), dict(x_panel_kb=32, xcd_remap=0, strip_cost=100), dict(x_panel_kb=128, placement_tries=2)]
+    # x_panel_merge >= 1 forces the panelled launch (unset, the plan decides by timing and small matrices drop it: last set)
+    knob_sets = [dict(x_panel_kb=64, x_panel_merge=1), dict(x_panel_kb=8, x_panel_merge=1, entry_ordered=0), dict(x_panel_kb=8, x_panel_merge=3, entry_ordered=1), dict(x_panel_kb=256, x_panel_merge=1, desc_dict=0, nt_stream=1),
+                 dict(x_panel_kb=16, x_panel_merge=2, strip_cost=64, split_above=200), dict(x_panel_kb=32, x_panel_merge=1, xcd_remap=0, strip_cost=100), dict(x_panel_kb=128, x_panel_merge=1, placement_tries=2),
+                 dict(x_panel_kb=64)]
     panelled = 0
     for name, gen in mats.items():
         m, n, rp, ci = gen()
@@ -639,7 +641,7 @@ def test_column_panels_bit_exact(torch_cuda, dtype):
             assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
             panelled += info["x_panels"] > 1
             assert info["x_panels"] <= 64
-        plan = api.Plan(tp, rowA, n, nnz, entry_mode=2, x_panel_kb=16)
+        plan = api.Plan(tp, rowA, n, nnz, entry_mode=2, x_panel_kb=16, x_panel_merge=1)
         xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda(); yd = torch_cuda.zeros(rowA + 16, dtype=xd.dtype, device="cuda")
         for it in range(5):
             yd.fill_(3.0); plan.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()

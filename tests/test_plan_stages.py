@@ -135,12 +135,17 @@ def test_slab_pacing_adds_a_sentinel_to_the_lists_and_counters_to_the_plan(mats)
     assert api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, pace=1, pace_slab_kb=1)[1]["pace_slabs"] == 0
 
 
-def test_column_panels_cut_the_lists_and_nothing_else(mats):
+def test_column_panels_are_offsets_into_the_same_lists(mats):
+    """Panels are recorded as offsets into the one column-ordered list of a group: the records do not change, and how many panels a pass takes is a launch fact."""
     tm, rows, n, nnz = mats["bandrand"]
-    one, i1 = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2)
-    many, ik = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32)
+    one, i1 = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=0)
+    many, ik = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, x_panel_merge=1)
     assert (i1["x_panels"], ik["x_panels"]) == (1, -(-n // 4096))
-    assert _changed(one, many) == ["choose", "entries", "finish"]
-    assert ik["stream_bytes"] > i1["stream_bytes"]                      # the panel passes read and write their rows of y
+    assert _changed(one, many) == ["choose", "entries"]
+    m2, i2 = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, x_panel_merge=2)
+    assert _changed(many, m2) == [] and i2["x_panels"] == -(-ik["x_panels"] // 2)
+    assert ik["stream_bytes"] > i2["stream_bytes"] > i1["stream_bytes"]          # the passes beyond the first read and write their rows of y
+    off, io = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, x_panel_merge=0)
+    assert _changed(many, off) == [] and io["x_panels"] == 1 and io["stream_bytes"] == i1["stream_bytes"]
     for kw in (dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, wg_strips=32), dict(entry_mode=2, pace=1, pace_slab_kb=1)):
-        assert api.plan_layout_stages(tm, rows, n, nnz, x_panel_kb=32, **kw)[1]["x_panels"] == 1, kw
+        assert api.plan_layout_stages(tm, rows, n, nnz, x_panel_kb=32, x_panel_merge=1, **kw)[1]["x_panels"] == 1, kw

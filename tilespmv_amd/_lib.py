@@ -24,7 +24,7 @@ INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode"
 KNOB_DEFAULT = -1
 # tuning knobs of tilespmv_plan_options (include/tilespmv.h), in struct order after `autotune`
 KNOB_NAMES = ["entry_mode", "entry_ordered", "strip_cost", "split_above", "split_cap", "xcd_remap", "xcd_chunk", "csr_split", "fix_inline",
-              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "x_stride1", "x_stride2", "mv_native", "mv_xcd_chunk", "lds_pad", "y_store", "desc_dict", "nt_stream", "pace", "pace_slab_kb", "pace_window", "pace_team", "pace_period_us", "x_panel_kb", "placement_tries"]
+              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "x_stride1", "x_stride2", "mv_native", "mv_xcd_chunk", "lds_pad", "y_store", "desc_dict", "nt_stream", "pace", "pace_slab_kb", "pace_window", "pace_team", "pace_period_us", "x_panel_kb", "x_panel_merge", "placement_tries"]
 
 
 class PlanOptions(C.Structure):

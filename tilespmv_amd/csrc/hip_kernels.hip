@@ -404,8 +404,11 @@ __device__ __forceinline__ val_t gather_x(const val_t *p)
 
 template <int CT, int NT, bool NTL>
 __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, const unsigned *__restrict__ base, int chunk0, int db, bool ordered,
-                                               const val_t *__restrict__ x, lacc_t *sy, int tid, int gb, int ge)
+                                               const val_t *__restrict__ x, lacc_t *sy, int tid, int gb, int ge, int gs = -1)
 {
+    // [gs, ge) = the records to execute; gb = the list's begin, which chunk numbers count from (column panels execute a run that starts inside the list, even inside a chunk)
+    if (gs < 0) gs = gb;
+    const int e_first = gb + ((gs - gb) & ~63);
     const unsigned dmask = (1u << db) - 1u;
     const int wave = tid >> 6;
     const int clast = chunk0 + ((ge - 1 - gb) >> 6);
@@ -430,10 +433,10 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
 #endif
         }
     };
-    if (gb < ge) load_trip(gb, rr, cb);
-    for (int e0 = gb; e0 < ge; e0 += NT * CT) {
+    if (e_first < ge) load_trip(e_first, rr, cb);
+    for (int e0 = e_first; e0 < ge; e0 += NT * CT) {
         val_t xx[CT];
-        if (!WG_TRIP_PIPE && e0 > gb) load_trip(e0, rr, cb);
+        if (!WG_TRIP_PIPE && e0 > e_first) load_trip(e0, rr, cb);
 #pragma unroll
         for (int q = 0; q < CT; q++) xx[q] = gather_x(&x[(size_t)(cb[q] + (rr[q].w >> db))]);
 #if defined(TILESPMV_ABL) && TILESPMV_ABL == 2
@@ -457,14 +460,14 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
                 if (wave == w) {
 #pragma unroll
                     for (int q = 0; q < CT; q++)
-                        if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
+                        if (e0 + NT * q + tid < ge && e0 + NT * q + tid >= gs) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
                 }
                 __syncthreads();
             }
         } else {
 #pragma unroll
             for (int q = 0; q < CT; q++)
-                if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
+                if (e0 + NT * q + tid < ge && e0 + NT * q + tid >= gs) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
         }
 #endif
         if (WG_TRIP_PIPE) {
@@ -755,9 +758,14 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     if constexpr (ECOO == 2) {
         const int4 wr = S.wg_coo[bid];
         TSPMV_STAMP_WAIT(1);   // task and list range have arrived
+        // a strip with entries adds its slab at the end, so its slab is zeroed even when the workgroup's list is empty: in a column-panelled plan (x_panels > 1) all of a
+        // strip's entries may sit in the other panels' lists
         if (wr.y > wr.x) {  // workgroup-uniform
             if (side) for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
             __syncthreads();
+        } else if (S.panel_merge > 0 && side) {
+            for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
+            wave_lds_fence();
         }
         // (issuing the unit prologue after the entry phase instead frees 16 VGPRs — 8 waves per SIMD at 6 x 256 per trip, or 8 x 256 at
         // 6 waves — and changes nothing: power-law 8 M 0.1026-0.1034 ms either way, profiles/r03_entry_ablations.txt: bytes in flight are not the limit)
@@ -773,7 +781,9 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             wg_entry_paced<WCOO_HEAVY_CT, NTS>(S, S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y, wr.x + wr.w, team, team_wgs * 4u);
             if (wr.y > wr.x) __syncthreads();
         } else if (wr.y > wr.x) {
-            wg_entry_trips<WCOO_HEAVY_CT, 16 * GPB, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y);
+            int ge = wr.y;   // column-panelled launch: this kernel takes the first panel_merge panels of the list, k_entries_acc the rest
+            if (GPB == 16 && S.panel_merge > 0) ge = S.panel_off[(size_t)bid * (size_t)(S.x_panels + 1) + (size_t)min(S.x_panels, S.panel_merge)];
+            wg_entry_trips<WCOO_HEAVY_CT, 16 * GPB, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, ge);
             __syncthreads();
         }
         TSPMV_STAMP_WAIT(3);   // entry phase done
@@ -1013,8 +1023,8 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
 }
 
 // ------------------------------------------------------------------------------------------------
-// Column panels (round 4; DevStream::x_panels): y += A_p x for the entries of column panel p >= 1.  The merged, column-ordered lists of the workgroup entry mode are
-// cut by column into panels of a few MB of x at plan time; k_units walks panel 0 with the units, and every further panel is one launch of this kernel: the same groups
+// Column panels (round 4; DevStream::panel_off): y += A_p x for the entries of one run of column panels.  The merged lists of the workgroup entry mode are in column order,
+// so a panel of a few MB of x is a run of a list (offsets recorded at plan time); k_units walks the first run with the units, and every further run is one launch of this kernel: the same groups
 // of 16 strips, the same records and trip routine, row sums in the same LDS slabs, then y += for the strips that have entries.  Why launches: on scattered matrices with
 // a large x every gather misses the XCD's L2 and pulls a 128-byte line across the fabric (profiles/r04_pmc_*_before.json); the workgroups would have to sweep x TOGETHER
 // for the lines to be shared, and a kernel boundary is the one chip-wide synchronisation that costs microseconds instead of the polls and timetables of S6.17 — inside one
@@ -1031,8 +1041,10 @@ __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream 
         const unsigned C = (unsigned)xcd_chunk, W = 8u * C, win = bid / W, off = bid % W, k = off & 7u;
         if ((win + 1) * W <= gridDim.x) bid = win * W + k * C + (off >> 3);
     }
-    const int4 wr = S.wg_coo[(size_t)panel * (size_t)S.n_groups + bid];
-    if (wr.y <= wr.x) return;   // workgroup-uniform: nothing of this group in this panel
+    const int4 wr = S.wg_coo[bid];
+    const int *po = S.panel_off + (size_t)bid * (size_t)(S.x_panels + 1);
+    const int gs = po[min(S.x_panels, panel * S.panel_merge)], ge = po[min(S.x_panels, (panel + 1) * S.panel_merge)];   // this pass: panels [panel * merge, (panel + 1) * merge)
+    if (ge <= gs) return;   // workgroup-uniform: nothing of this group in this pass
     const long long task_id = (long long)bid * GROUPS_PER_BLOCK + g;
     int4 t0 = make_int4(0, 0, 0, 0), t1 = make_int4(0, -1, 0, 0);
     if (task_id < S.ntasks) {
@@ -1043,7 +1055,7 @@ __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream 
     const int row0 = t1.x, part = t1.y, nrows = t1.w;
     for (int i = tid; i < GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16; i += 256) s_acc[i] = 0;
     __syncthreads();
-    wg_entry_trips<WCOO_HEAVY_CT, 256, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, s_acc, tid, wr.x, wr.y);
+    wg_entry_trips<WCOO_HEAVY_CT, 256, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, s_acc, tid, wr.x, ge, gs);
     __syncthreads();
     if (!side) return;
     const lacc_t *mine = s_acc + g * (STRIP_MAX_ROWS * 16);
@@ -1060,7 +1072,8 @@ __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream 
 
 hipError_t launch_entry_panels(const DevStream &S, int rowA, int xcd_remap, int xcd_chunk, const val_t *x, val_t *y, hipStream_t st)
 {
-    for (int p = 1; p < S.x_panels; p++) {
+    const int passes = (S.x_panels + S.panel_merge - 1) / S.panel_merge;
+    for (int p = 1; p < passes; p++) {
         const dim3 grid((unsigned)S.n_groups), blk(256);
         if (xcd_remap == 2) { if (S.nt_stream) hipLaunchKernelGGL((k_entries_acc<2, true>), grid, blk, 0, st, S, rowA, xcd_chunk, p, x, y);
                               else hipLaunchKernelGGL((k_entries_acc<2, false>), grid, blk, 0, st, S, rowA, xcd_chunk, p, x, y); }
@@ -1724,7 +1737,7 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
         Q.fix = P.fix_late; Q.nfix = P.nfix_late;
         hipLaunchKernelGGL(k_fixup_split, dim3((Q.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, Q, y);
     }
-    if (S.x_panels > 1 && S.ntasks > 0) return launch_entry_panels(S, P.rowA, xcd_remap, xcd_chunk, x, y, st);   // y += the entries of the other column panels, last: every row has been written
+    if (S.panel_merge > 0 && S.x_panels > S.panel_merge && S.ntasks > 0) return launch_entry_panels(S, P.rowA, xcd_remap, xcd_chunk, x, y, st);   // y += the entries of the other column panels, last: every row has been written
     return hipGetLastError();
 }
 

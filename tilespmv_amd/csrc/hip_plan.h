@@ -144,9 +144,13 @@ struct DevStream {
     // that its scattered gathers fall into the same few slabs — which stay in the XCD's L2 — instead of each pulling a 128-byte line across the fabric
     // (profiles/r04_gather_locality.txt).  Lists of paced plans: the workgroup's local entries first (wg_coo.w = their record count, a multiple of 64),
     // then the remote ones in column order, one more base word per list (its last column).  Speed only: no result depends on the clock.
-    // column panels (round 4): wg_coo holds x_panels x (groups) list ranges, panel-major; k_units walks panel 0, k_entries_acc adds panel p >= 1 (y +=) in a launch of its own
-    int x_panels;                         // 1: not panelled
-    int n_groups;                         // groups (workgroups of the entry phase) per panel
+    // column panels (round 4): a group's merged list is in column order, so the entries of column panel p (2^k columns, a few MB of x) are the run
+    // [panel_off[group * (x_panels + 1) + p], panel_off[.. + p + 1]) of it.  A launch either walks whole lists in k_units (panel_merge = 0) or gives k_units the first
+    // panel_merge panels and each further run of panel_merge panels a launch of k_entries_acc (y +=): all gathers of one pass then fall into one slice of x.
+    const int *panel_off;                 // nullptr: no panels recorded
+    int x_panels;                         // finest panels recorded (1: none)
+    int panel_merge;                      // panels per pass of the panelled form; 0 = whole lists in k_units (chosen by timing at plan creation, hip_plan.hip)
+    int n_groups;                         // groups (workgroups of the entry phase)
     unsigned *pace;                       // per team {start clock, wavefronts done}; nullptr: no pacing
     const unsigned *pace_sched;           // [pace_nslab + 1]: share of the shard's remote entries left of slab s, in 1 / 2^24
     unsigned pace_period;                 // 10-ns ticks one team's sweep is given (calibrated at plan creation; 0: nobody waits)

@@ -66,6 +66,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.pace_period_us = pick(o.pace_period_us, "TILESPMV_PACE_PERIOD_US", -1);
     k.placement_tries = pick(o.placement_tries, "TILESPMV_PLACEMENT_TRIES", -1);
     k.x_panel_kb = pick(o.x_panel_kb, "TILESPMV_X_PANEL_KB", -1);
+    k.x_panel_merge = pick(o.x_panel_merge, "TILESPMV_X_PANEL_MERGE", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
     k.entry_from_caller = pinned(o.entry_mode, "TILESPMV_WAVE_COO");
     k.strip_from_caller = o.strip_cost > 0 || env_int("TILESPMV_STRIP_COST", 0) > 0;
@@ -218,7 +219,7 @@ const char *tilespmv_plan_options_layout(void)
         TSPMV_F(entry_mode) TSPMV_F(entry_ordered) TSPMV_F(strip_cost) TSPMV_F(split_above) TSPMV_F(split_cap) TSPMV_F(xcd_remap) TSPMV_F(xcd_chunk)
         TSPMV_F(csr_split) TSPMV_F(fix_inline) TSPMV_F(coo_cost) TSPMV_F(coo_heavy_min) TSPMV_F(coo_piece) TSPMV_F(strip_even) TSPMV_F(wg_strips)
         TSPMV_F(x_window) TSPMV_F(x_stride1) TSPMV_F(x_stride2) TSPMV_F(mv_native) TSPMV_F(mv_xcd_chunk) TSPMV_F(lds_pad) TSPMV_F(y_store)
-        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(x_panel_kb) TSPMV_F(placement_tries) TSPMV_F(reserved)
+        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(x_panel_kb) TSPMV_F(x_panel_merge) TSPMV_F(placement_tries) TSPMV_F(reserved)
 #undef TSPMV_F
         return o;
     }();
@@ -391,6 +392,36 @@ static void calibrate_pace(tilespmv_plan *plan)
         plan->info[TILESPMV_INFO_PACE_PERIOD_US] = (long long)(best_ticks / 100.0 + 0.5);
     } else give_up();
     if (verbose) fprintf(stderr, "tilespmv: pace calibration: %s (unpaced %.4f ms, best paced %.4f ms at %.1f us)\n", S.pace ? "kept" : "dropped", t_base, best, best_ticks / 100.0);
+}
+
+// Column panels (DevStream::panel_off): how many of the recorded panels one pass takes, found by timing — the unpanelled launch, then passes of about 4, 8 and 16 MB of x.
+// The panelled form stays only when it is at least 3 % faster.  Launch-time choice: every candidate runs on the same lists.
+static void calibrate_panels(tilespmv_plan *plan, int colA)
+{
+    DevStream &S = plan->st;
+    const bool verbose = getenv("TILESPMV_PLAN_VERBOSE") != nullptr;
+    val_t *dx = nullptr, *dy = nullptr;
+    const size_t nx = (size_t)plan->dev.colA + 16, ny = (size_t)plan->dev.rowA + 16;
+    S.panel_merge = 0;
+    if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) return;
+    if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); return; }
+    { std::vector<val_t> ones(nx, (val_t)1); (void)hipMemcpy(dx, ones.data(), nx * sizeof(val_t), hipMemcpyHostToDevice); }
+    const double t_base = tilespmv_plan_time(plan, dx, dy, nullptr, 3, 8);
+    double best = t_base; int best_m = 0;
+    const double panel_mb = (double)colA * sizeof(val_t) / S.x_panels / (1 << 20);   // MB of x per recorded panel
+    int last = 0;
+    for (double mb : {4.0, 8.0, 16.0}) {
+        const int m = std::max(1, (int)(mb / std::max(panel_mb, 1e-9) + 0.5));
+        if (m == last || m >= S.x_panels) continue;
+        last = m;
+        S.panel_merge = m;
+        const double t = tilespmv_plan_time(plan, dx, dy, nullptr, 2, 8);
+        if (verbose) fprintf(stderr, "tilespmv: column panels: %d passes of %.1f MB of x -> %.4f ms (unpanelled %.4f)\n", (S.x_panels + m - 1) / m, m * panel_mb, t, t_base);
+        if (t > 0 && t < best) { best = t; best_m = m; }
+    }
+    S.panel_merge = (best_m > 0 && best < 0.97 * t_base) ? best_m : 0;
+    if (verbose) fprintf(stderr, "tilespmv: column panels: %s\n", S.panel_merge ? "kept" : "dropped");
+    (void)hipFree(dx); (void)hipFree(dy);
 }
 
 static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const Knobs &K)
@@ -698,6 +729,16 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         retry_placement(plan, tries);
         I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0p);
     }
+    if (!K.dry && plan->panel_calibrate) {
+        const double t0c = now_us();
+        calibrate_panels(plan, colA);
+        I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0c);
+    }
+    if (plan->st.panel_merge > 0) {   // the panelled form: passes beyond the first read and write their rows of y and re-read the task records
+        const int m = plan->st.panel_merge, passes = (plan->st.x_panels + m - 1) / m;
+        I[TILESPMV_INFO_X_PANELS] = passes;
+        I[TILESPMV_INFO_STREAM_BYTES] += 2LL * sv * plan->panel_rmw_rows / m + (passes - 1LL) * (n_tasks * 32 + (long long)plan->st.n_groups * 16);
+    } else I[TILESPMV_INFO_X_PANELS] = 1;
     if (!K.dry && plan->pace_calibrate && plan->st.pace != nullptr) {
         const double t0c = now_us();
         calibrate_pace(plan);
@@ -773,7 +814,7 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
     // at a time at every nvec (webbase stand-in 37 / 58 / 93 us against 42 / 85 / 223) and beats the separate entry pass over the merged lists (k_entries_mv; workgroup entry mode,
     // 16 strips, no x windows) from nvec 4 on (power-law 8 M: 0.254 / 0.375 / 0.678 ms against 0.198 / 0.469 / 1.364 with the pass): the pass stays for nvec 2.
     // mv_native: -1 by rule, 0 one right-hand side at a time, 1 the multi-vector kernel alone, 2 the multi-vector kernel + entry pass
-    const bool can_pass = has_native && plan->entry_mode == 2 && plan->wg_strips == 16 && plan->xwin_lds_bytes == 0 && plan->st.x_panels <= 1;   // (a panelled plan's wg_coo[group] is panel 0 only)
+    const bool can_pass = has_native && plan->entry_mode == 2 && plan->wg_strips == 16 && plan->xwin_lds_bytes == 0;
     const bool entries_pass = can_pass && (mv_native == 2 || (mv_native < 0 && plan->mv_by_columns && nvec < 4));
     const bool one_at_a_time = !has_native || mv_native == 0 || (mv_native < 0 && plan->mv_by_columns && !entries_pass && plan->mv_slab_rows == 0 && nvec < 8);
     if (one_at_a_time) {

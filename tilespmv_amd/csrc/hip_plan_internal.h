@@ -61,6 +61,7 @@ struct Knobs {
     int pace;            // slab pacing of the workgroup entry mode: -1 by rule, 0 off, 1 on
     int pace_slab_kb, pace_window, pace_team, pace_period_us;   // pace_period_us < 0: calibrate at plan creation
     int x_panel_kb;      // column panels of the entry lists: KB of x per panel; 0 off, -1 by rule
+    int x_panel_merge;   // ... panels per pass; 0 unpanelled launch, -1 chosen by timing
     int placement_tries; // large plans: arena placements timed at plan creation (-1 by size, 0 / 1 off, n)
     int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
@@ -94,6 +95,8 @@ struct tilespmv_plan {
     int arena_flags = 0; size_t arena_skew = 0;
     char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20, arena_next = (size_t)1 << 20, size_hint = 0;   // bump allocator of upload(); size_hint = the builder's estimate of the plan's bytes
     bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
+    bool panel_calibrate = false;       // panels recorded, panels per pass still to be chosen by timing (plan_create_one)
+    long long panel_rmw_rows = 0;       // rows of y the passes beyond the first read and write, at the finest panels (byte model)
     bool pace_calibrate = false;        // slab-paced plan whose timetable length is still to be found by timing (plan_create_one)
     unsigned long long digest = 1469598103934665603ull;
     unsigned long long stage_digest[TILESPMV_STAGE_COUNT] = {0};   // layout-digest builds: one hash per stage of the unit-stream builder (hip_plan_stream.hip)

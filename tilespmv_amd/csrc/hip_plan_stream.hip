@@ -296,7 +296,9 @@ void StreamBuilder::choose()
     // ---- column panels of the entry lists (hip_plan.h DevStream::x_panels): scattered, entry-dominated shards whose x is several times an XCD's L2
     {
         const long long x_bytes = (long long)colA * sv;
-        const int kb = K.x_panel_kb >= 0 ? K.x_panel_kb : 0;   // (rule: see DESIGN.md S6.17 — set below once measured)
+        // rule: shards whose work is mostly scattered entries and whose x is several XCD L2s (>= 12 MB) record 2-MB panels; whether a panelled launch pays is then
+        // decided by timing (plan_create_one) — it does on uniform-random-like shards (8 M rows: 1.00 -> 0.80 ms) and does not where most entries sit near the diagonal
+        const int kb = K.x_panel_kb >= 0 ? K.x_panel_kb : ((entry_dominated && x_bytes >= (12ll << 20)) ? 2048 : 0);
         x_panels = 1; panel_shift = 0;
         if (kb > 0 && entry_mode == 2 && wg_strips == 16 && !xwin && !pace_on && x_bytes > 1024LL * kb) {
             long long cols = std::max<long long>(1024, 1024LL * kb / sv);
@@ -793,9 +795,10 @@ void StreamBuilder::entries()
         const int dest_bits = entry_mode == 2 ? (wg_strips == 32 ? 12 : 4 + slab_shift) : 9;   // strip-in-group | row-in-strip | row (4)
         S.dest_bits = dest_bits;
         const size_t nwg = (tasks.size() + GS - 1) / GS;
-        const size_t NP = (size_t)x_panels;          // lists are stored panel-major: list of (panel p, group w) at p * nwg + w
-        std::vector<std::vector<ERec>> grp_rec(nwg * NP);
-        std::vector<std::vector<unsigned>> grp_base(nwg * NP);
+        const size_t NP = (size_t)x_panels;          // column panels: a group's list stays ONE column-ordered list; panel p is the run [panel_off[p], panel_off[p + 1]) of it
+        std::vector<std::vector<ERec>> grp_rec(nwg);
+        std::vector<std::vector<unsigned>> grp_base(nwg);
+        std::vector<int> h_panel_off(NP > 1 ? nwg * (NP + 1) : 0, 0);   // (relative to the list's begin here; absolute record indices below)
         std::vector<int> wg_local(nwg, 0);      // paced lists: records of the local part (whole chunks)
         std::mutex hist_mutex;
         pace_hist.assign(pace_on ? (size_t)pace_nslab : 0, 0);
@@ -840,55 +843,74 @@ void StreamBuilder::entries()
                         wg_local[(size_t)w] = (int)grp_rec[(size_t)w].size();
                     }
                 }
-                if (NP > 1) {
-                    // column panels: the list is in column order, so a panel is a run of it; panel 0 stays with the unit kernel, every further panel gets a list of its own
-                    size_t i0 = 0;
-                    while (i0 < ents.size() && (ents[i0].col >> panel_shift) == 0u) i0++;
-                    for (size_t a = i0; a < ents.size();) {
-                        const unsigned pnl = ents[a].col >> panel_shift;
-                        size_t b2 = a;
-                        while (b2 < ents.size() && (ents[b2].col >> panel_shift) == pnl) b2++;
-                        local.assign(ents.begin() + (long)a, ents.begin() + (long)b2);
-                        if (!pack_list(local, dest_bits, grp_rec[(size_t)pnl * nwg + (size_t)w], grp_base[(size_t)pnl * nwg + (size_t)w], plan->dry)) bad++;
-                        a = b2;
-                    }
-                    ents.resize(i0);
-                }
                 if (!pack_list(ents, dest_bits, grp_rec[(size_t)w], grp_base[(size_t)w], plan->dry)) bad++;
                 if (pace_on) grp_base[(size_t)w].push_back(ents.empty() ? (local.empty() ? 0u : local.back().col) : ents.back().col);   // one more base word: the list's last column
+                if (NP > 1) {
+                    // where each panel begins in the PACKED list: records are in column order except that the null padding of a chunk closed early repeats the chunk's first
+                    // column — padding counts as part of the panel of the record before it (it adds 0 * x[.] to the group's first row whichever pass executes it)
+                    const std::vector<ERec> &R = grp_rec[(size_t)w];
+                    const std::vector<unsigned> &B = grp_base[(size_t)w];
+                    int *off = &h_panel_off[(size_t)w * (NP + 1)];
+                    unsigned cur = 0;   // panel of the previous record
+                    size_t nextp = 1;
+                    for (size_t i = 0; i < R.size(); i++) {
+                        const ERec &rr = R[i];
+#if defined(TILESPMV_F32)
+                        const bool null_like = rr.w == 0u && rr.v == 0u;
+#else
+                        const bool null_like = rr.w == 0u && rr.lo == 0u && rr.hi == 0u;
+#endif
+                        const unsigned pnl = null_like && i % ECHUNK != 0 ? cur : std::max(cur, (B[i / ECHUNK] + (rr.w >> dest_bits)) >> panel_shift);
+                        while (nextp <= (size_t)pnl) off[nextp++] = (int)i;
+                        cur = pnl;
+                    }
+                    while (nextp <= NP) off[nextp++] = (int)R.size();
+                }
             }
             if (pace_on) { std::lock_guard<std::mutex> lk(hist_mutex); for (size_t i2 = 0; i2 < hist.size(); i2++) pace_hist[i2] += hist[i2]; }
         });
         if (bad.load()) { fprintf(stderr, "tilespmv: internal error: %d packed entry lists do not decode to their entries\n", bad.load()); rc = -6; }
-        std::vector<int4> wg((size_t)(nwg * NP));
-        for (size_t w = 0; w < nwg * NP; w++) {
-            wg[w] = make_int4((int)n_rec, (int)(n_rec + (long long)grp_rec[w].size()), (int)n_chunk, w < nwg ? wg_local[w] : 0);
+        std::vector<int4> wg((size_t)nwg);
+        for (size_t w = 0; w < nwg; w++) {
+            wg[w] = make_int4((int)n_rec, (int)(n_rec + (long long)grp_rec[w].size()), (int)n_chunk, wg_local[w]);
+            if (NP > 1) for (size_t q = 0; q <= NP; q++) h_panel_off[w * (NP + 1) + q] += (int)n_rec;
             n_rec += (long long)grp_rec[w].size(); n_chunk += (long long)grp_base[w].size();
         }
         if (n_rec > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit entry ids\n"); rc = -2; n_rec = 0; }
         std::vector<ERec> g_rec((size_t)n_rec);
         std::vector<unsigned> g_base((size_t)n_chunk);
         if (rc == 0)
-            parallel_chunks((int64_t)(nwg * NP), 256, [&](int64_t b, int64_t e, int) {
+            parallel_chunks((int64_t)nwg, 256, [&](int64_t b, int64_t e, int) {
                 for (int64_t w = b; w < e; w++) {
                     if (!grp_rec[(size_t)w].empty()) memcpy(&g_rec[(size_t)wg[(size_t)w].x], grp_rec[(size_t)w].data(), grp_rec[(size_t)w].size() * sizeof(ERec));
                     if (!grp_base[(size_t)w].empty()) memcpy(&g_base[(size_t)wg[(size_t)w].z], grp_base[(size_t)w].data(), grp_base[(size_t)w].size() * sizeof(unsigned));
                 }
             });
         n_groups = (long long)nwg;
-        // rows whose sums a panel pass adds to y: the strips of the groups that have a list in that panel (16 bytes per row, read + written)
+        // rows whose sums ONE panel pass adds to y (16 bytes per row, read + written): the strips with entries of the groups that have any record in that panel; averaged over the panels
         panel_rmw_rows = 0;
-        for (size_t pnl = 1; pnl < NP; pnl++)
-            for (size_t w = 0; w < nwg; w++)
-                if (!grp_rec[pnl * nwg + w].empty())
-                    for (size_t t = GS * w; t < std::min(tasks.size(), GS * w + GS); t++)
-                        if (tasks[t].coo_end > tasks[t].coo_begin) panel_rmw_rows += 16LL * std::max(1, tasks[t].nrows);
+        if (NP > 1) {
+            long long acc_rows = 0;
+            for (size_t w = 0; w < nwg; w++) {
+                long long rows_w = 0;
+                for (size_t t = GS * w; t < std::min(tasks.size(), GS * w + GS); t++)
+                    if (tasks[t].coo_end > tasks[t].coo_begin) rows_w += 16LL * std::max(1, tasks[t].nrows);
+                for (size_t q = 1; q < NP; q++)
+                    if (h_panel_off[w * (NP + 1) + q + 1] > h_panel_off[w * (NP + 1) + q]) acc_rows += rows_w;
+            }
+            panel_rmw_rows = acc_rows;    // at the finest panels; a launch that merges m panels per pass touches about 1 / m of it (tilespmv_plan_info reports the model of the form chosen)
+        }
         rc |= plan->upload(wg.data(), wg.size(), &S.wg_coo);
         rc |= plan->upload(g_rec.data(), g_rec.size(), &S.grec);
         rc |= plan->upload(g_base.data(), g_base.size(), &S.gbase);
+        S.panel_off = nullptr;
+        if (NP > 1) rc |= plan->upload(h_panel_off.data(), h_panel_off.size(), &S.panel_off);
     }
     S.x_panels = x_panels; S.n_groups = (int)n_groups;
-    plan->info[TILESPMV_INFO_X_PANELS] = x_panels;
+    S.panel_merge = (x_panels > 1 && K.x_panel_merge > 0) ? std::min(K.x_panel_merge, x_panels) : 0;
+    plan->panel_calibrate = x_panels > 1 && K.x_panel_merge < 0;
+    plan->panel_rmw_rows = panel_rmw_rows;
+    plan->info[TILESPMV_INFO_X_PANELS] = S.panel_merge > 0 ? (x_panels + S.panel_merge - 1) / S.panel_merge : 1;   // launches of the entry part
     if (hashing()) { Hash h; h.num((long long)(plan->digest ^ d0)); h.num(n_rec); h.num(n_chunk); h.num(n_groups); h.num(S.dest_bits); h.num(x_panels); stage_done(TILESPMV_STAGE_ENTRIES, h); }
 }
 
@@ -951,7 +973,7 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     }
     plan->mv_by_columns = entry_dominated && target >= 800;   // (small strips hold few entries each: scircuit-like 18 / 22 / 32 us native against 22 / 41 / 78 us)
     n_tasks = (long long)tasks.size();
-    model_bytes = NUP * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16 * x_panels + 2LL * sv * panel_rmw_rows + (x_panels - 1LL) * n_tasks * (long long)sizeof(STask)) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
+    model_bytes = NUP * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
                   ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
     // The once-read streams (values, entry records) are loaded nontemporally when the launch moves clearly more than the Infinity Cache holds: they then do
