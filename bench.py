@@ -497,7 +497,7 @@ def main():
     if world == 1 and os.path.exists(tj):
         tjd = json.load(open(tj))
         fresh = tjd.get("plan_fingerprint") == fingerprint
-        traffic = tjd.get("hbm_bytes_per_launch") if fresh else None
+        traffic = (tjd.get("hbm_bytes_per_spmv") or tjd.get("hbm_bytes_per_launch")) if fresh else None   # (per SpMV: a plan with dense-tile or column-panel passes is several launches)
         traffic_source = {"file": os.path.relpath(tj, ROOT), "measured": tjd.get("measured"), "kernel": tjd.get("kernel"),
                           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this command; FETCH_SIZE x2 (gfx950 correction, calibrated)",
                           "live": False, "plan_fingerprint_matches": fresh}
@@ -612,7 +612,7 @@ def main():
                    "partition": "tile-row blocks, nnz-balanced, %d rank(s)" % world, "y_combine": args.combine, "backend": args.backend if world > 1 else None,
                    "tiles": getattr(sh, "tiles", None), "tasks": info["num_tasks"], "coo_mode": info["coo_mode"], "dense_mode": info["dense_mode"],
                    "entry_mode": info["entry_mode"], "sums_bit_reproducible": bool(info["entry_ordered"]), "strip_cost": info["strip_cost"],
-                   "x_window_slots": info["x_window_slots"], "x_panels": info["x_panels"], "placement_tries": info["placement_tries"]},
+                   "x_window_slots": info["x_window_slots"], "x_panels": info["x_panels"], "x_panel_merge": info["x_panel_merge"], "placement_tries": info["placement_tries"]},
         "hbm_gbps_algorithmic": round(b_alg_total / (wall / args.steps) * 1e-9, 1),
         "hbm_roofline_frac": round(b_alg_total / (wall / args.steps) * 1e-9 / (HBM_PEAK_GBPS * world), 4),
         "roofline": roofline,
@@ -710,7 +710,8 @@ def main():
                 if os.path.exists(tj2):   # HBM-side bytes per launch of the default plan, from the committed counter passes (not live)
                     t2 = json.load(open(tj2))
                     fresh2 = t2.get("plan_fingerprint") == fp2
-                    rec["traffic"] = {"hbm_bytes_per_launch": t2.get("hbm_bytes_per_launch") if fresh2 else None, "kernel": t2.get("kernel"), "measured": t2.get("measured"),
+                    rec["traffic"] = {"hbm_bytes_per_spmv": (t2.get("hbm_bytes_per_spmv") or t2.get("hbm_bytes_per_launch")) if fresh2 else None,
+                                      "hbm_bytes_per_launch_of_the_dominant_kernel": t2.get("hbm_bytes_per_launch") if fresh2 else None, "kernel": t2.get("kernel"), "measured": t2.get("measured"),
                                       "file": os.path.relpath(tj2, ROOT), "live": False, "plan_fingerprint_matches": fresh2}
                 else:
                     rec["traffic"] = None

@@ -421,7 +421,8 @@ enum {
     TILESPMV_INFO_PLACEMENT_TRIES = 24,   /* arena placements timed at plan creation (large plans; 0 / 1 = the first one was kept) */
     TILESPMV_INFO_PACE_PERIOD_US = 25,    /* ... microseconds of one team's timetable (0 = not paced) */
     TILESPMV_INFO_X_PANELS = 26,          /* column panels of the entry lists = launches of the entry part (1 = not panelled) */
-    TILESPMV_INFO_COUNT = 27
+    TILESPMV_INFO_X_PANEL_MERGE = 27,     /* recorded panels per pass of the panelled launch (0 = whole lists in the unit kernel) */
+    TILESPMV_INFO_COUNT = 28
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
 

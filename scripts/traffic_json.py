@@ -34,6 +34,15 @@ for (k, c), (v, n) in list(fetch.items()) + list(write.items()):
 total = 0
 for k, t in per.items():
     t["bytes_per_launch"] = int((t.get("FETCH_SIZE_kb", 0) * factor + t.get("WRITE_SIZE_kb", 0)) * 1024)
+# a SpMV of a panelled / dense-tile plan is several launches: bytes per SpMV = sum over the kernels of bytes per launch x launches per SpMV (k_units runs once per SpMV)
+calls = {k["name"]: k["calls"] for k in kern}
+unit_calls = max([c for n, c in calls.items() if "k_units<" in n or "k_tiles_direct" in n] or [0])
+per_spmv = None
+if unit_calls:
+    per_spmv = 0
+    for k, t in per.items():
+        c = calls.get(k) or calls.get("void " + k) or 0
+        per_spmv += int(t["bytes_per_launch"] * c / unit_calls)
 bench = None
 for line in open(os.path.join(d, "bench_under_trace.json")):
     if line.startswith("{"):
@@ -46,7 +55,8 @@ out = {"workload": wl, "dtype": dt, "kernel": dom, "measured": time.strftime(os.
        # the plan these passes measured: bench.py reports `traffic` only while its live plan has the same fingerprint
        "plan_fingerprint": None if bench is None else (bench.get("roofline") or {}).get("plan_fingerprint"),
        "FETCH_SIZE_kb": per.get(dom, {}).get("FETCH_SIZE_kb"), "WRITE_SIZE_kb": per.get(dom, {}).get("WRITE_SIZE_kb"),
-       "fetch_correction": factor, "hbm_bytes_per_launch": per.get(dom, {}).get("bytes_per_launch"),
+       "fetch_correction": factor, "hbm_bytes_per_launch": per.get(dom, {}).get("bytes_per_launch"), "hbm_bytes_per_spmv": per_spmv,
+       "launches_per_spmv": {k: round(c / unit_calls, 3) for k, c in calls.items()} if unit_calls else None,
        "all_kernels_bytes_per_launch": {k: t["bytes_per_launch"] for k, t in per.items()},
        "kernel_stats": kern,
        "bench_under_trace": None if bench is None else {k: bench.get(k) for k in ("value", "ms_per_step", "roofline")},

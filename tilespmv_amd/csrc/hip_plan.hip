@@ -739,6 +739,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         I[TILESPMV_INFO_X_PANELS] = passes;
         I[TILESPMV_INFO_STREAM_BYTES] += 2LL * sv * plan->panel_rmw_rows / m + (passes - 1LL) * (n_tasks * 32 + (long long)plan->st.n_groups * 16);
     } else I[TILESPMV_INFO_X_PANELS] = 1;
+    I[TILESPMV_INFO_X_PANEL_MERGE] = plan->st.panel_merge;
     if (!K.dry && plan->pace_calibrate && plan->st.pace != nullptr) {
         const double t0c = now_us();
         calibrate_pace(plan);
