@@ -1053,6 +1053,14 @@ __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream 
     }
     const bool side = t0.w > t0.z;
     const int row0 = t1.x, part = t1.y, nrows = t1.w;
+    // the strip's rows of y are requested now, ahead of the records and the gathers: the pass is a short chain of dependent hops (ranges -> records -> gathers -> y), and this
+    // takes the last one out of it
+    val_t yold[STRIP_MAX_ROWS];
+#pragma unroll
+    for (int k = 0; k < STRIP_MAX_ROWS; k++) {
+        const long long yi = ((long long)row0 + k) * 16 + r;
+        yold[k] = (side && part < 0 && k < nrows && yi < rowA) ? y[yi] : (val_t)0;
+    }
     for (int i = tid; i < GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16; i += 256) s_acc[i] = 0;
     __syncthreads();
     wg_entry_trips<WCOO_HEAVY_CT, 256, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, s_acc, tid, wr.x, ge, gs);
@@ -1063,9 +1071,10 @@ __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream 
         const long long yi = (long long)row0 * 16 + r;
         if (yi < rowA) atomicAdd(&y[yi], (val_t)mine[r]);
     } else {
-        for (int k = 0; k < nrows; k++) {
+#pragma unroll
+        for (int k = 0; k < STRIP_MAX_ROWS; k++) {
             const long long yi = ((long long)row0 + k) * 16 + r;
-            if (yi < rowA) y[yi] = (val_t)((lacc_t)y[yi] + mine[k * 16 + r]);
+            if (k < nrows && yi < rowA) y[yi] = (val_t)((lacc_t)yold[k] + mine[k * 16 + r]);
         }
     }
 }
