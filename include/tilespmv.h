@@ -312,7 +312,7 @@ typedef struct {
                            that make passes of 4, 8 and 16 MB of x (kept when >= 3 % faster than the unpanelled launch)       TILESPMV_X_PANEL_MERGE */
     int placement_tries; /* where a large plan's blocks land in the card's memory decides between two states 13 % apart on the KKT matrices:
                            at plan creation the plan is timed (5 launches), moved to freshly allocated blocks (allocated BEFORE the old ones are freed) and timed
-                           again, up to this many placements (all held until the choice is made); the first placement >= 4 % faster than the first one is kept.  unset: 5 for plans of >= 1 GB, else 1 (= off)
+                           again, up to this many placements (all held until the choice is made); the first placement >= 4 % faster than the first one is kept.  unset: 8 for plans of >= 1 GB, else 1 (= off)
                                                                                                                     TILESPMV_PLACEMENT_TRIES */
     int reserved[2];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;

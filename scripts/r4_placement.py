@@ -18,7 +18,7 @@ tm = api.Tile_create(rows, n, nnz, rp, ci, vals, dtype=dt)
 xd = torch.from_numpy(x).cuda(); yd = torch.zeros(rows + 16, dtype=xd.dtype, device="cuda")
 balg = api.algorithmic_bytes(nnz, rows, n, np.dtype(dt).itemsize)
 print("%s (%s) %s, %d rows, %d nnz" % (wl, src, np.dtype(dt).name, rows, nnz), flush=True)
-for label, kw in (("no retry (placement_tries=1)", dict(placement_tries=1)), ("default (up to 5 placements for plans >= 1 GB)", dict())):
+for label, kw in (("no retry (placement_tries=1)", dict(placement_tries=1)), ("default (up to 8 placements for plans >= 1 GB)", dict())):
     plans, out = [], []
     for i in range(N):
         p = api.Plan(tm, rows, n, nnz, **kw)

@@ -97,7 +97,7 @@ static void for_each_plan_pointer(tilespmv_plan *plan, F f)
 // Placement retry: identical plans run in one of two states 13 % apart on the KKT matrices, decided by where their blocks
 // landed in the card's memory — not by the plan.  So a large plan is timed where it was built, then MOVED: new blocks are allocated while the old ones are still
 // held (they land elsewhere), the streams are copied device to device, every pointer is rebased, and the plan is timed again; the faster placement stays (a later one
-// must be >= 4 % faster than the best so far), up to `tries` placements.  Costs two copies of the plan for a moment and a few launches.
+// must be >= 4 % faster than the best so far), up to `tries` placements.  Costs up to `tries` copies of the plan for a moment and a few launches each.
 static void retry_placement(tilespmv_plan *plan, int tries)
 {
     const bool verbose = getenv("TILESPMV_PLAN_VERBOSE") != nullptr;
@@ -443,6 +443,8 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     plan->dry = K.dry;
     if (const char *af = getenv("TILESPMV_ARENA_FLAGS")) plan->arena_flags = atoi(af);
     if (const char *as = getenv("TILESPMV_ARENA_SKEW")) plan->arena_skew = (size_t)std::max(0ll, atoll(as)) / 256 * 256;
+    if (const char *sp = getenv("TILESPMV_ARENA_SPACER_MB")) plan->arena_spacer = (size_t)std::max(0ll, atoll(sp)) << 20;
+    plan->arena_spacer_first_only = env_int("TILESPMV_ARENA_SPACER_FIRST", 0) != 0;
     if (const char *ab = getenv("TILESPMV_ARENA_MB")) plan->arena_block = (size_t)std::max(0, atoi(ab)) << 20;   // (experiment knob; 0 = one hipMalloc per stream)
     if (!K.dry && hipGetDevice(&plan->device) != hipSuccess) { fprintf(stderr, "tilespmv: hipGetDevice failed\n"); delete plan; return -1; }
 
@@ -724,7 +726,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     I[TILESPMV_INFO_STREAM_BYTES] = model_bytes + (long long)colA * sv + (long long)rows * sv +
                                     (f_nnz ? (long long)f_rec.size() * (long long)sizeof(ERec) + (long long)f_base.size() * 4 + 2LL * sv * rows + (long long)f_blk.size() * 16 : 0);   // the fallback re-reads and re-writes its rows of y
     if (!K.dry) {
-        const int tries = K.placement_tries >= 0 ? K.placement_tries : (I[TILESPMV_INFO_DEVICE_BYTES] >= (1ll << 30) ? 5 : 1);
+        const int tries = K.placement_tries >= 0 ? K.placement_tries : (I[TILESPMV_INFO_DEVICE_BYTES] >= (1ll << 30) ? 8 : 1);
         const double t0p = now_us();
         retry_placement(plan, tries);
         I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0p);

@@ -92,7 +92,7 @@ struct tilespmv_plan {
     int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
     int lds_pad_bytes = 0;              // extra (unused) dynamic LDS per workgroup of the unit kernel: caps the workgroups resident on a CU (knob lds_pad)
     int xwin_lds_bytes = 0;             // x-window plans: dynamic LDS of the unit kernel (largest window of the plan); 0 = no windows
-    int arena_flags = 0; size_t arena_skew = 0;
+    int arena_flags = 0; size_t arena_skew = 0, arena_spacer = 0; bool arena_spacer_first_only = false;
     char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20, arena_next = (size_t)1 << 20, size_hint = 0;   // bump allocator of upload(); size_hint = the builder's estimate of the plan's bytes
     bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
     bool panel_calibrate = false;       // panels recorded, panels per pass still to be chosen by timing (plan_create_one)
@@ -123,6 +123,10 @@ struct tilespmv_plan {
             const size_t blk = std::max<size_t>(need, std::min(want, arena_block));
             arena_next = std::min<size_t>(arena_next * 4, std::max<size_t>(arena_block, 1));
             void *b = nullptr;
+            if (arena_spacer && (!arena_spacer_first_only || arena_blocks.empty())) {   // experiment knob TILESPMV_ARENA_SPACER_MB: an unused allocation in front of every block (does where a block lands decide its state? DESIGN.md S6.19)
+                void *sp = nullptr;
+                if (hipMalloc(&sp, arena_spacer) == hipSuccess) allocs.push_back(sp);
+            }
             if (arena_flags) HIP_TRY(hipExtMallocWithFlags(&b, blk, (unsigned)arena_flags));   // experiment knob TILESPMV_ARENA_FLAGS (4 = physically contiguous)
             else HIP_TRY(hipMalloc(&b, blk));
             allocs.push_back(b);
