@@ -615,6 +615,40 @@ def test_inline_fixup_of_split_rows_is_stable_across_launches(torch_cuda, monkey
         p.close()
 
 
+def test_spmv_is_capturable_into_a_hip_graph(torch_cuda):
+    """include/tilespmv.h promises that tilespmv_plan_spmv neither allocates nor synchronises — safe to capture into a hipGraph.  Captured and replayed here (torch's graph API on a
+    side stream) for a single-launch plan, a column-panelled plan (several launches), a slab-paced plan (its teams' clocks reset themselves), split tile-rows summed in-kernel (counters
+    reset themselves) and the CSR fallback (second launch): every replay gives the oracle's y."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    O = CpuImpl("oracle", np.float64)
+    m, n, rp, ci = G.band_plus_random(40000, 4, 3, 5)
+    nnz, rowA = len(ci), truncated_rows(m)
+    vals, x = values_for("bandrand", nnz, n, np.float64)
+    want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals), rowA, n, nnz, rp, ci, vals, x)["y"]
+    tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
+    xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda()
+    for kw in (dict(), dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, pace=1, pace_slab_kb=1, pace_period_us=5), dict(entry_mode=2, strip_cost=64, split_above=200),
+               dict(coo_mode=api.COO_FALLBACK), dict(entry_mode=1)):
+        plan = api.Plan(tp, rowA, n, nnz, **kw)
+        yd = torch_cuda.zeros(rowA + 16, dtype=xd.dtype, device="cuda")
+        side = torch_cuda.cuda.Stream()
+        side.wait_stream(torch_cuda.cuda.current_stream())
+        graph = torch_cuda.cuda.CUDAGraph()
+        with torch_cuda.cuda.stream(side):
+            plan.spmv(xd.data_ptr(), yd.data_ptr(), side.cuda_stream)      # (warm-up outside the capture)
+            with torch_cuda.cuda.graph(graph, stream=side):
+                plan.spmv(xd.data_ptr(), yd.data_ptr(), side.cuda_stream)
+        torch_cuda.cuda.current_stream().wait_stream(side)
+        for it in range(3):
+            yd.fill_(-5.0)
+            graph.replay(); torch_cuda.cuda.synchronize()
+            assert np.array_equal(yd.cpu().numpy()[:rowA], want), (kw, "replay", it)
+        del graph
+        plan.close()
+    api.Tile_destroy(tp)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_column_panels_bit_exact(torch_cuda, dtype):
     """Round 4: column panels of the merged entry lists — the first run of panels with the unit kernel, one k_entries_acc launch (y +=) per further run.  The oracle's y bit for bit
