@@ -123,6 +123,39 @@ def test_config5_nlpkkt160_full_size_f32(torch_cuda):
     plan.close()
 
 
+@pytest.mark.parametrize("workload", ["bandrand4x3_2000000", "uniform8_2000000", "powerlaw8000000"])
+def test_irregular_class_default_plans_full_size(torch_cuda, workload):
+    """The north star's "synthetic banded / power-law" side and the scattered class VERDICT round 3 named, at the size the bench line quotes them (uniform random at half of it), DEFAULT plan:
+    the two scattered matrices record column panels by rule (x >= 12 MB, entry-dominated) and decide by timing whether a panelled launch is used; whatever is chosen, the whole y equals the
+    CSR golden bit for bit (integer data), twice in a row, and y = A (x1 + x2) = A x1 + A x2."""
+    import torch
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    m, n, rp, ci, _ = _bench().build_matrix(workload)
+    rowA = (m // 16) * 16; nnz = int(rp[rowA])
+    vals = G.compat_values(len(ci))
+    tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
+    plan = api.Plan(tp, rowA, n, nnz)
+    api.Tile_destroy(tp)
+    info = plan.info()
+    assert info["entry_mode"] == 2 and info["x_panels"] >= 1 and info["x_panels"] == (1 if info["x_panel_merge"] == 0 else info["x_panels"])
+    if workload.startswith("powerlaw"):
+        assert info["x_panels"] == 1          # most entries sit near the diagonal: every pass would re-read y for a handful of entries (the timing drops the panels)
+    rng = np.random.default_rng(4)
+    x1 = rng.integers(0, 4, n).astype(np.float64); x2 = rng.integers(0, 4, n).astype(np.float64)
+    O = CpuImpl("oracle")
+    ys = []
+    for x in (x1, x2, x1 + x2):
+        xd = torch.from_numpy(x).cuda(); yd = torch.full((rowA + 16,), -3.0, dtype=torch.float64, device="cuda")
+        plan.spmv(xd.data_ptr(), yd.data_ptr()); plan.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize()
+        y = yd.cpu().numpy()
+        assert (y[rowA:] == -3.0).all()
+        ys.append(y[:rowA])
+    assert np.array_equal(ys[0], O.csr_spmv(rowA, rp, ci, vals, x1)), workload
+    assert np.array_equal(ys[0] + ys[1], ys[2])
+    plan.close()
+
+
 def test_wide_band_dense_pieces_with_large_strip_cost(torch_cuda, monkeypatch):
     """A tile-row with more dense tiles than one matrix-core piece may hold (k_dense_mfma broadcasts the column blocks of
     a piece from one 64-lane load) must be cut into pieces whatever the cost knobs say: band with half-bandwidth 640
