@@ -615,6 +615,42 @@ def test_inline_fixup_of_split_rows_is_stable_across_launches(torch_cuda, monkey
         p.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_every_plan_kind_survives_being_moved(torch_cuda, monkeypatch, dtype):
+    """The placement retry moves a plan to freshly allocated blocks and rebases its device pointers; a pointer it misses dangles once the old blocks are freed (round 4: the
+    column-panel offsets did, and the GPU suite aborted in the one run in which the timing happened to keep a moved placement).  TILESPMV_PLACEMENT_FORCE=1 keeps the LAST
+    placement always: every plan kind — panels, pacing, x windows, dictionary / 12-B descriptors, CSR fallback, first-generation kernel, whole CSR tiles, dense tiles on the
+    matrix cores, split rows — is moved twice and must still give the oracle's y, SpMM included."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    monkeypatch.setenv("TILESPMV_PLACEMENT_FORCE", "1")
+    O = CpuImpl("oracle", dtype)
+    mats = {"allfmt": SMALL["allfmt"], "bandrand60k": lambda: G.band_plus_random(60000, 4, 3, 5), "kkt_like24": lambda: G.nlpkkt_like(24, target_nnz=None), "band4096_40": SMALL["band4096_40"],
+            "one_long_row": SMALL["one_long_row"]}
+    knob_sets = [dict(), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, pace=1, pace_slab_kb=1, pace_period_us=5),
+                 dict(x_window=1), dict(x_window=1, entry_mode=2), dict(desc_dict=0), dict(coo_mode=api.COO_FALLBACK), dict(kernel=api.KERNEL_DIRECT), dict(csr_split=0),
+                 dict(dense_mode=api.DENSE_MFMA), dict(dense_mode=api.DENSE_VALU), dict(strip_cost=64, split_above=200), dict(strip_cost=64, split_above=200, fix_inline=0)]
+    for name, gen in mats.items():
+        m, n, rp, ci = gen()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, x = values_for(name, nnz, n, dtype)
+        want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, x)["y"]
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=True)
+        for kw in knob_sets:
+            y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, placement_tries=3, **kw)
+            assert info["placement_tries"] == 3, (name, kw)
+            assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
+        plan = api.Plan(tp, rowA, n, nnz, placement_tries=2)
+        X = (np.arange(n * 4, dtype=np.int64) % 5).astype(dtype).reshape(n, 4)
+        Xd = torch_cuda.from_numpy(X).cuda(); Yd = torch_cuda.zeros((rowA + 16, 4), dtype=Xd.dtype, device="cuda")
+        plan.spmm(Xd.data_ptr(), Yd.data_ptr(), 4); torch_cuda.cuda.synchronize()
+        for j in range(4):
+            wj = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"]
+            assert np.array_equal(Yd.cpu().numpy()[:rowA, j], wj), (name, "spmm on a moved plan", j)
+        plan.close()
+        api.Tile_destroy(tp)
+
+
 def test_spmv_is_capturable_into_a_hip_graph(torch_cuda):
     """include/tilespmv.h promises that tilespmv_plan_spmv neither allocates nor synchronises — safe to capture into a hipGraph.  Captured and replayed here (torch's graph API on a
     side stream) for a single-launch plan, a column-panelled plan (several launches), a slab-paced plan (its teams' clocks reset themselves), split tile-rows summed in-kernel (counters

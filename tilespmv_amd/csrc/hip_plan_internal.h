@@ -100,9 +100,11 @@ struct tilespmv_plan {
     bool pace_calibrate = false;        // slab-paced plan whose timetable length is still to be found by timing (plan_create_one)
     unsigned long long digest = 1469598103934665603ull;
     unsigned long long stage_digest[TILESPMV_STAGE_COUNT] = {0};   // layout-digest builds: one hash per stage of the unit-stream builder (hip_plan_stream.hip)
+    std::vector<const void **> uploaded_slots;   // every device-pointer MEMBER of this plan that upload() filled: what a re-placement rebases (hip_plan.hip retry_placement)
     template <class T>
     int upload(const T *host, size_t n, const T **out)
     {
+        if ((const char *)out >= (const char *)this && (const char *)out < (const char *)this + sizeof(*this)) uploaded_slots.push_back((const void **)out);
         if (dry) {   // FNV-1a-64 over (element count, bytes) of every stream, in upload order
             auto mix = [&](const unsigned char *p, size_t len) { for (size_t i = 0; i < len; i++) { digest ^= p[i]; digest *= 1099511628211ull; } };
             const unsigned long long cnt = n;
