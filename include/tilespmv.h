@@ -322,7 +322,10 @@ void tilespmv_plan_options_init(tilespmv_plan_options *opts);
 const char *tilespmv_plan_options_layout(void);
 
 /* Returns 0 on success, non-zero (message on stderr) when no HIP device / extension is
- * usable — there is no CPU fallback behind this entry point. */
+ * usable — there is no CPU fallback behind this entry point.
+ * Plan creation allocates, copies and synchronises (it always did); since round 4 it may also TIME a few launches of the finished plan on the default stream with scratch
+ * x / y of its own: plans of >= 1 GB try up to `placement_tries` memory placements, shards with column panels recorded choose the panels per pass, opt-in paced plans
+ * calibrate their timetable.  Every such choice has a knob that fixes it (placement_tries = 1, x_panel_merge, pace_period_us) — a fixed choice times nothing. */
 int tilespmv_plan_create(tilespmv_plan **plan, const Tile_matrix *matrix, int rowA, int colA,
                          MAT_PTR_TYPE nnzA, const tilespmv_plan_options *opts);
 void tilespmv_plan_destroy(tilespmv_plan *plan);
