@@ -651,6 +651,34 @@ def test_every_plan_kind_survives_being_moved(torch_cuda, monkeypatch, dtype):
         api.Tile_destroy(tp)
 
 
+def test_tile_row_shards_with_panels_and_pacing(torch_cuda):
+    """Tile-row shards (what one rank of a multi-GPU run owns) of a panelled / paced plan write exactly their rows of the full-length y: three shards with uneven cuts, columns not a
+    multiple of 16, panelled launches and paced launches; the union is the oracle's y and nothing outside a shard's rows is touched."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    O = CpuImpl("oracle", np.float64)
+    m, n, rp, ci = G.uniform_per_row(30000, 50003, 8, 3)
+    nnz, rowA = len(ci), truncated_rows(m)
+    vals, x = values_for("uniform", nnz, n, np.float64)
+    want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals), rowA, n, nnz, rp, ci, vals, x)["y"]
+    tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
+    tilem = rowA // 16
+    cuts = [0, tilem // 5, tilem // 2 + 3, tilem]
+    xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda()
+    for kw in (dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, x_panel_kb=8, x_panel_merge=2, entry_ordered=0), dict(entry_mode=2, pace=1, pace_slab_kb=1, pace_period_us=5)):
+        yd = torch_cuda.full((rowA + 16,), -7.0, dtype=xd.dtype, device="cuda")
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            plan = api.Plan(tp, rowA, n, nnz, tilerow_begin=a, tilerow_end=b, **kw)
+            before = yd.clone()
+            plan.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()
+            got = yd.cpu().numpy(); old = before.cpu().numpy()
+            assert np.array_equal(got[16 * a:16 * b], want[16 * a:16 * b]), (kw, a, b)
+            assert np.array_equal(got[:16 * a], old[:16 * a]) and np.array_equal(got[16 * b:], old[16 * b:]), (kw, a, b, "wrote outside its rows")
+            plan.close()
+        assert np.array_equal(yd.cpu().numpy()[:rowA], want)
+    api.Tile_destroy(tp)
+
+
 def test_spmv_is_capturable_into_a_hip_graph(torch_cuda):
     """include/tilespmv.h promises that tilespmv_plan_spmv neither allocates nor synchronises — safe to capture into a hipGraph.  Captured and replayed here (torch's graph API on a
     side stream) for a single-launch plan, a column-panelled plan (several launches), a slab-paced plan (its teams' clocks reset themselves), split tile-rows summed in-kernel (counters
