@@ -102,7 +102,11 @@ def test_one_rank_through_the_launcher_equals_the_bare_run():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     bare = subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert bare.returncode == 0, bare.stderr[-2000:]
-    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29731",
+    import socket
+    with socket.socket() as so:      # a free port for the rendezvous (a fixed one may still be in TIME_WAIT from an earlier run)
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
                                "bench.py"] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert launched.returncode == 0, launched.stderr[-2000:]
     a, b = _last_json(bare.stdout), _last_json(launched.stdout)
