@@ -425,7 +425,9 @@ enum {
     TILESPMV_INFO_PACE_PERIOD_US = 25,    /* ... microseconds of one team's timetable (0 = not paced) */
     TILESPMV_INFO_X_PANELS = 26,          /* column panels of the entry lists = launches of the entry part (1 = not panelled) */
     TILESPMV_INFO_X_PANEL_MERGE = 27,     /* recorded panels per pass of the panelled launch (0 = whole lists in the unit kernel) */
-    TILESPMV_INFO_COUNT = 28
+    TILESPMV_INFO_SCATTERED_ENTRIES = 28, /* workgroup entry mode: list entries whose column lies more than 2,048 columns outside their group's own rows — the gathers that
+                                             no neighbour shares (the chip resolves about 59 G of those per second from a table that misses the L2s: profiles/r04_gather_granule.txt) */
+    TILESPMV_INFO_COUNT = 29
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
 

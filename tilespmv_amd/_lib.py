@@ -18,7 +18,7 @@ _CACHE = {}
 
 INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel",
               "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us", "entry_mode", "entry_ordered", "strip_cost",
-              "wg_strips", "x_window_slots", "x_window_segments", "brick_order", "desc_bytes", "nt_stream", "pace_slabs", "pace_team", "placement_tries", "pace_period_us", "x_panels", "x_panel_merge"]
+              "wg_strips", "x_window_slots", "x_window_segments", "brick_order", "desc_bytes", "nt_stream", "pace_slabs", "pace_team", "placement_tries", "pace_period_us", "x_panels", "x_panel_merge", "scattered_entries"]
 
 
 KNOB_DEFAULT = -1

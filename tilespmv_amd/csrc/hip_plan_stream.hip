@@ -803,6 +803,7 @@ void StreamBuilder::entries()
         std::mutex hist_mutex;
         pace_hist.assign(pace_on ? (size_t)pace_nslab : 0, 0);
         std::atomic<int> bad(0);
+        std::atomic<long long> scattered(0);
         parallel_chunks((int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
             std::vector<std::pair<unsigned long long, unsigned>> key;   // (column << 32 | position in strip / list order, destination)
             std::vector<int> src;
@@ -826,6 +827,11 @@ void StreamBuilder::entries()
                     ents[i] = PEnt{(unsigned)h_ccol[(size_t)q], key[i].second, h_cval[q]};
                 }
                 wg_local[(size_t)w] = 0;
+                if (entry_mode == 2) {   // plan fact: entries far from the group's own rows (scattered gathers)
+                    long long far = 0;
+                    for (const PEnt &en : ents) far += !((long long)en.col >= own_lo - 2048 && (long long)en.col < own_hi + 2048);
+                    scattered.fetch_add(far, std::memory_order_relaxed);
+                }
                 if (pace_on) {
                     // paced lists: the local entries first (columns around the group's own rows — the neighbouring workgroups want the same x lines anyway; never paced),
                     // padded to whole chunks, then the remote entries in column order = slab order (the part the team sweeps by its timetable)
@@ -887,6 +893,7 @@ void StreamBuilder::entries()
                 }
             });
         n_groups = (long long)nwg;
+        plan->info[TILESPMV_INFO_SCATTERED_ENTRIES] = scattered.load();
         // rows whose sums ONE panel pass adds to y (16 bytes per row, read + written): the strips with entries of the groups that have any record in that panel; averaged over the panels
         panel_rmw_rows = 0;
         if (NP > 1) {
