@@ -692,11 +692,11 @@ def main():
                                   "entry_mode": i2["entry_mode"], "sums_bit_reproducible": bool(i2["entry_ordered"]),
                                   "strip_cost": i2["strip_cost"], "tasks": i2["num_tasks"], "x_panels": i2["x_panels"], "nt_stream": i2["nt_stream"],
                                   "placement_tries": i2["placement_tries"]}
-                    if i2["scattered_entries"] * 5 >= nz2:   # a scattered matrix: the chip's ceiling for gathers that no neighbour shares (59 G/s, profiles/r04_gather_granule.txt) beside the byte roofline
+                    if i2["scattered_entries"] * 5 >= nz2 and n2 * np.dtype(dt2).itemsize > (8 << 20):   # a scattered matrix whose x is larger than two L2s (every XCD gathers from all of x): the chip's ceiling for gathers that no neighbour shares (59 G/s, profiles/r04_gather_granule.txt) beside the byte roofline
                         rec[label]["scattered_gathers"] = {"count": i2["scattered_entries"], "share_of_nnz": round(i2["scattered_entries"] / nz2, 3),
                                                            "gathers_per_second": round(i2["scattered_entries"] / ms2 * 1e3, 0), "chip_ceiling_unstructured": SCATTERED_GATHER_CEILING,
-                                                           "frac_of_gather_ceiling": round(i2["scattered_entries"] / ms2 * 1e3 / SCATTERED_GATHER_CEILING, 3),
-                                                           "note": "above 1 = the plan found locality the access pattern does not have by itself (column panels, popular columns)"}
+                                                           "rate_vs_unstructured_ceiling": round(i2["scattered_entries"] / ms2 * 1e3 / SCATTERED_GATHER_CEILING, 3),
+                                                           "note": "a ratio, not a roofline fraction: the ceiling is what the chip sustains when every gather misses its L2; above 1 = the matrix's popular columns or the plan's column panels make gathers hit"}
                     if also_real and label in ("coo_in_tile", "default_plan"):   # the same plan on real-valued data: the time does not depend on the values
                         vr, xr = G.real_values(len(ci2), dt2), G.real_x(n2, len(ci2), dt2)
                         tmr = api.Tile_create(r2, n2, nz2, rp2, ci2, vr, dtype=dt2, hyb=(wl == "scircuit"))
