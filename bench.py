@@ -492,7 +492,7 @@ def main():
     # for this workload/dtype — and only if that pass saw THIS plan: the summary carries a fingerprint of the plan it
     # measured (entry mode, strip cost, tasks, stream bytes); on a mismatch traffic is null and marked stale.
     traffic, traffic_source = None, None
-    FP_KEYS = ("entry_mode", "strip_cost", "num_tasks", "stream_bytes", "x_window_slots", "desc_bytes", "nt_stream", "x_panels")
+    FP_KEYS = ("entry_mode", "strip_cost", "num_tasks", "stream_bytes", "x_window_slots", "desc_bytes", "nt_stream", "x_panels", "x_slice_passes")
     fingerprint = {k: info[k] for k in FP_KEYS}
     tj = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, dname))
     if world == 1 and os.path.exists(tj):
@@ -613,7 +613,7 @@ def main():
                    "partition": "tile-row blocks, nnz-balanced, %d rank(s)" % world, "y_combine": args.combine, "backend": args.backend if world > 1 else None,
                    "tiles": getattr(sh, "tiles", None), "tasks": info["num_tasks"], "coo_mode": info["coo_mode"], "dense_mode": info["dense_mode"],
                    "entry_mode": info["entry_mode"], "sums_bit_reproducible": bool(info["entry_ordered"]), "strip_cost": info["strip_cost"],
-                   "x_window_slots": info["x_window_slots"], "x_panels": info["x_panels"], "x_panel_merge": info["x_panel_merge"], "placement_tries": info["placement_tries"]},
+                   "x_window_slots": info["x_window_slots"], "x_panels": info["x_panels"], "x_panel_merge": info["x_panel_merge"], "x_slice_passes": info["x_slice_passes"], "placement_tries": info["placement_tries"]},
         "hbm_gbps_algorithmic": round(b_alg_total / (wall / args.steps) * 1e-9, 1),
         "hbm_roofline_frac": round(b_alg_total / (wall / args.steps) * 1e-9 / (HBM_PEAK_GBPS * world), 4),
         "roofline": roofline,
@@ -690,7 +690,7 @@ def main():
                                   "frac_min_bytes": round(bmin2 / ms2 * 1e-6 / HBM_PEAK_GBPS, 4), "frac_by_plan_bytes": round(i2["stream_bytes"] / ms2 * 1e-6 / HBM_PEAK_GBPS, 4),
                                   "check": "pass" if ok2 else "FAIL", "fallback_nnz": i2["fallback_nnz"],
                                   "entry_mode": i2["entry_mode"], "sums_bit_reproducible": bool(i2["entry_ordered"]),
-                                  "strip_cost": i2["strip_cost"], "tasks": i2["num_tasks"], "x_panels": i2["x_panels"], "nt_stream": i2["nt_stream"],
+                                  "strip_cost": i2["strip_cost"], "tasks": i2["num_tasks"], "x_panels": i2["x_panels"], "x_slice_passes": i2["x_slice_passes"], "nt_stream": i2["nt_stream"],
                                   "placement_tries": i2["placement_tries"]}
                     if i2["scattered_entries"] * 5 >= nz2 and n2 * np.dtype(dt2).itemsize > (8 << 20):   # a scattered matrix whose x is larger than two L2s (every XCD gathers from all of x): the chip's ceiling for gathers that no neighbour shares (59 G/s, profiles/r04_gather_granule.txt) beside the byte roofline
                         rec[label]["scattered_gathers"] = {"count": i2["scattered_entries"], "share_of_nnz": round(i2["scattered_entries"] / nz2, 3),

@@ -314,7 +314,13 @@ typedef struct {
                            at plan creation the plan is timed (5 launches), moved to freshly allocated blocks (allocated BEFORE the old ones are freed) and timed
                            again, up to this many placements (all held until the choice is made); the first placement >= 4 % faster than the first one is kept.  unset: 8 for plans of >= 1 GB, else 1 (= off)
                                                                                                                     TILESPMV_PLACEMENT_TRIES */
-    int reserved[2];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
+    int x_slice_passes; /* column slices pinned to XCDs (round 4): the other use of the recorded panels.  The unit kernel leaves the entry lists alone; per pass one launch of
+                           8 x groups workgroups follows in which workgroup b (dispatched to XCD b & 7) takes its group's entries of column slice pass * 8 + (b & 7), so an XCD
+                           only ever gathers from its own slice of x, which stays in its L2, and adds the rows it touched to y atomically — the eight partial sums of a row
+                           meet in an order that is not fixed: never chosen when entry_ordered = 1.  N > 0 = N passes (8 N slices); 0 = off; unset (and x_panel_merge unset): timed at plan creation
+                           beside the panelled forms (1, 2, 4 passes where a slice would be about 1-8 MB), kept when fastest and >= 3 % faster than the plain launch
+                                                                                                                    TILESPMV_X_SLICE_PASSES */
+    int reserved[1];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
 /* "name:offset,..." of every field above as the library was built: lets a binding that mirrors the struct by hand verify
@@ -325,7 +331,7 @@ const char *tilespmv_plan_options_layout(void);
  * usable — there is no CPU fallback behind this entry point.
  * Plan creation allocates, copies and synchronises (it always did); since round 4 it may also TIME a few launches of the finished plan on the default stream with scratch
  * x / y of its own: plans of >= 1 GB try up to `placement_tries` memory placements, shards with column panels recorded choose the panels per pass, opt-in paced plans
- * calibrate their timetable.  Every such choice has a knob that fixes it (placement_tries = 1, x_panel_merge, pace_period_us) — a fixed choice times nothing. */
+ * calibrate their timetable.  Every such choice has a knob that fixes it (placement_tries = 1, x_panel_merge + x_slice_passes, pace_period_us) — a fixed choice times nothing. */
 int tilespmv_plan_create(tilespmv_plan **plan, const Tile_matrix *matrix, int rowA, int colA,
                          MAT_PTR_TYPE nnzA, const tilespmv_plan_options *opts);
 void tilespmv_plan_destroy(tilespmv_plan *plan);
@@ -427,7 +433,8 @@ enum {
     TILESPMV_INFO_X_PANEL_MERGE = 27,     /* recorded panels per pass of the panelled launch (0 = whole lists in the unit kernel) */
     TILESPMV_INFO_SCATTERED_ENTRIES = 28, /* workgroup entry mode: list entries whose column lies more than 2,048 columns outside their group's own rows — the gathers that
                                              no neighbour shares (the chip resolves about 59 G of those per second from a table that misses the L2s: profiles/r04_gather_granule.txt) */
-    TILESPMV_INFO_COUNT = 29
+    TILESPMV_INFO_X_SLICE_PASSES = 29,    /* column slices pinned to XCDs: launches of the sliced entry part (0 = not used); 8 x this many slices of x */
+    TILESPMV_INFO_COUNT = 30
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
 

@@ -12,10 +12,10 @@ mkdir -p $out; cd /tmp
 args="--workload $wl --dtype $dt --no-cpu-baseline --no-extras"
 # plans that choose something by timing at creation (column panels per pass) must be THE SAME plan in all three passes, and their calibration launches must not be in the
 # profiles: one untraced run decides, the profiled runs get the choice as a knob
-if [ -z "$TILESPMV_X_PANEL_MERGE" ]; then
-  m=$(python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-check $args 2>/dev/null | python -c "import sys,json; print(json.loads([l for l in sys.stdin if l.startswith('{')][-1])['config']['x_panel_merge'])" 2>/dev/null)
-  export TILESPMV_X_PANEL_MERGE=${m:-0}
-  echo "column panels per pass fixed for the profiled runs: $TILESPMV_X_PANEL_MERGE"
+if [ -z "$TILESPMV_X_PANEL_MERGE" ] && [ -z "$TILESPMV_X_SLICE_PASSES" ]; then
+  read m sp < <(python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-check $args 2>/dev/null | python -c "import sys,json; c=json.loads([l for l in sys.stdin if l.startswith('{')][-1])['config']; print(c['x_panel_merge'], c['x_slice_passes'])" 2>/dev/null)
+  export TILESPMV_X_PANEL_MERGE=${m:-0} TILESPMV_X_SLICE_PASSES=${sp:-0}
+  echo "entry-list form fixed for the profiled runs: panels per pass $TILESPMV_X_PANEL_MERGE, slice passes $TILESPMV_X_SLICE_PASSES"
 fi
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 20 $args > $out/bench_under_trace.json 2> $out/trace.err || echo "trace failed"
 cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv

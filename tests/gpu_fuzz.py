@@ -108,6 +108,9 @@ def check(seed):
     # round 4: column panels of the entry lists (panel 0 in the unit kernel, one y += launch per further panel)
     if env.get("TILESPMV_WAVE_COO") == "2" and env.get("TILESPMV_WG_STRIPS") != "32" and seed % 3 == 2:
         env.update({"TILESPMV_X_PANEL_KB": str([1, 4, 2, 16][(seed // 3) % 4]), "TILESPMV_X_PANEL_MERGE": str(1 + (seed // 7) % 3)})
+        # ... or, on every other such seed with unordered adds allowed, the same lists by column slices pinned to XCDs (1-4 passes; atomic adds of the touched rows)
+        if (seed // 3) % 2 == 1 and env.get("TILESPMV_COO_ORDERED") != "1":
+            del env["TILESPMV_X_PANEL_MERGE"]; env["TILESPMV_X_SLICE_PASSES"] = str(1 + (seed // 5) % 4)
     # round 4: slab-paced workgroup entry phase — tiny slabs (128 ... 2048 columns) so that the small fuzz matrices have many, teams of 1 ... 192 workgroups
     # (a team larger than the grid is clamped), leads of 0-2 slabs, timetables of 0 (nobody waits), 20 and 200 microseconds
     if env.get("TILESPMV_WAVE_COO") == "2" and env.get("TILESPMV_WG_STRIPS") != "32" and seed % 3 != 2:

@@ -759,6 +759,61 @@ def test_column_panels_bit_exact(torch_cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_column_slices_on_xcds_bit_exact(torch_cuda, dtype):
+    """Round 4: column slices pinned to XCDs — the unit kernel leaves the entry lists alone, k_entries_xcd launches of 8 x groups workgroups take them by slices of x and add the
+    rows they touched to y atomically.  On the reference driver's integer data every order of the adds gives the same bits: the oracle's y bit for bit with 1 ... 8 passes over
+    2 ... 64 recorded panels (more slices than panels included), split tile-rows, tiny strips, both descriptor forms, y pre-filled with rubbish, launch after launch on one plan,
+    the multi-vector product on a sliced plan; entry_ordered = 1 (reproducible sums asked) keeps the sliced form out, and the plan reports unordered sums when it is in."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    O = CpuImpl("oracle", dtype)
+    mats = {"powerlaw200k": MEDIUM["powerlaw200k"], "bandrand60k": lambda: G.band_plus_random(60000, 4, 3, 5), "uniform40k": lambda: G.uniform_per_row(40000, 70001, 8, 1),
+            "allfmt": SMALL["allfmt"], "one_long_row": SMALL["one_long_row"], "wide_row_tiles": SMALL["wide_row_tiles"], "empty_rows": SMALL["empty_rows"], "circuit60k": MEDIUM["circuit60k"]}
+    knob_sets = [dict(x_panel_kb=64, x_slice_passes=1), dict(x_panel_kb=8, x_slice_passes=2, entry_ordered=0), dict(x_panel_kb=8, x_slice_passes=8), dict(x_panel_kb=256, x_slice_passes=1, desc_dict=0, nt_stream=1),
+                 dict(x_panel_kb=16, x_slice_passes=4, strip_cost=64, split_above=200), dict(x_panel_kb=32, x_slice_passes=1, xcd_remap=0, strip_cost=100), dict(x_panel_kb=128, x_slice_passes=3, placement_tries=2),
+                 dict(x_panel_kb=64, x_slice_passes=1, x_panel_merge=2), dict(x_panel_kb=64)]
+    sliced = 0
+    for name, gen in mats.items():
+        m, n, rp, ci = gen()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, x = values_for(name, nnz, n, dtype)
+        want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, x)["y"]
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=True)
+        for kw in knob_sets:
+            y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, entry_mode=2, **kw)
+            assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
+            if info["x_slice_passes"] > 0:
+                sliced += 1
+                assert info["entry_ordered"] == 0 and info["x_panel_merge"] == 0 and info["x_panels"] == info["x_slice_passes"], (name, kw, info)
+        y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, entry_mode=2, x_panel_kb=16, x_slice_passes=2, entry_ordered=1)
+        assert np.array_equal(y, want) and info["x_slice_passes"] == 0 and info["entry_ordered"] == 1, (name, "ordered sums asked", info)
+        plan = api.Plan(tp, rowA, n, nnz, entry_mode=2, x_panel_kb=16, x_slice_passes=2)
+        xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda(); yd = torch_cuda.zeros(rowA + 16, dtype=xd.dtype, device="cuda")
+        for it in range(5):
+            yd.fill_(3.0); plan.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()
+            assert np.array_equal(yd.cpu().numpy()[:rowA], want), (name, "launch", it)
+            assert np.all(yd.cpu().numpy()[rowA:] == 3.0), (name, "wrote past the rows", it)
+        X = (np.arange(n * 2, dtype=np.int64) % 5).astype(dtype).reshape(n, 2)
+        Xc = torch_cuda.from_numpy(X).cuda(); Yc = torch_cuda.zeros((rowA + 16, 2), dtype=Xc.dtype, device="cuda")
+        plan.spmm(Xc.data_ptr(), Yc.data_ptr(), 2); torch_cuda.cuda.synchronize()
+        for j in range(2):
+            wj = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"]
+            assert np.array_equal(Yc.cpu().numpy()[:rowA, j], wj), (name, "spmm on a sliced plan", j)
+        plan.close()
+        api.Tile_destroy(tp)
+        # real values: the eight partial sums of a row meet in any order — within the tolerance of every other path
+        rvals, rx = values_for(name, nnz, n, dtype, real=True)
+        rwant = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, rvals, hyb=True), rowA, n, nnz, rp, ci, rvals, rx)["y"].astype(np.float64)
+        rtp = api.Tile_create(rowA, n, nnz, rp, ci, rvals, dtype=dtype, hyb=True)
+        bound = TOL[np.dtype(dtype)] * _abs_bound(rowA, rp, ci, rvals, rx) + 1e-300
+        for kw in (dict(x_panel_kb=16, x_slice_passes=1), dict(x_panel_kb=8, x_slice_passes=4)):
+            y, info = _gpu_y(torch_cuda, rtp, rowA, n, nnz, rx, entry_mode=2, **kw)
+            assert (np.abs(y.astype(np.float64) - rwant) <= bound).all(), (name, "real values", kw)
+        api.Tile_destroy(rtp)
+    assert sliced >= 30
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_slab_paced_entry_phase_bit_exact(torch_cuda, dtype):
     """Round 4: the workgroup entry mode with slab pacing (teams of co-resident workgroups gather from the same few slabs of x at one time; pacing is
     speed only).  The oracle's y bit for bit — with slabs so small that the test matrices have hundreds, teams of one

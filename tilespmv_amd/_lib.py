@@ -18,20 +18,20 @@ _CACHE = {}
 
 INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel",
               "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us", "entry_mode", "entry_ordered", "strip_cost",
-              "wg_strips", "x_window_slots", "x_window_segments", "brick_order", "desc_bytes", "nt_stream", "pace_slabs", "pace_team", "placement_tries", "pace_period_us", "x_panels", "x_panel_merge", "scattered_entries"]
+              "wg_strips", "x_window_slots", "x_window_segments", "brick_order", "desc_bytes", "nt_stream", "pace_slabs", "pace_team", "placement_tries", "pace_period_us", "x_panels", "x_panel_merge", "scattered_entries", "x_slice_passes"]
 
 
 KNOB_DEFAULT = -1
 # tuning knobs of tilespmv_plan_options (include/tilespmv.h), in struct order after `autotune`
 KNOB_NAMES = ["entry_mode", "entry_ordered", "strip_cost", "split_above", "split_cap", "xcd_remap", "xcd_chunk", "csr_split", "fix_inline",
-              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "x_stride1", "x_stride2", "mv_native", "mv_xcd_chunk", "lds_pad", "y_store", "desc_dict", "nt_stream", "pace", "pace_slab_kb", "pace_window", "pace_team", "pace_period_us", "x_panel_kb", "x_panel_merge", "placement_tries"]
+              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "x_stride1", "x_stride2", "mv_native", "mv_xcd_chunk", "lds_pad", "y_store", "desc_dict", "nt_stream", "pace", "pace_slab_kb", "pace_window", "pace_team", "pace_period_us", "x_panel_kb", "x_panel_merge", "placement_tries", "x_slice_passes"]
 
 
 class PlanOptions(C.Structure):
     """Mirror of the versioned tilespmv_plan_options: `size` first, unset knobs = KNOB_DEFAULT."""
     _fields_ = ([("size", C.c_uint), ("coo_mode", C.c_int), ("dense_mode", C.c_int), ("kernel", C.c_int),
                  ("tilerow_begin", C.c_int), ("tilerow_end", C.c_int), ("autotune", C.c_int)] +
-                [(k, C.c_int) for k in KNOB_NAMES] + [("reserved", C.c_int * 2)])
+                [(k, C.c_int) for k in KNOB_NAMES] + [("reserved", C.c_int * 1)])
 
     def __init__(self, coo_mode=0, dense_mode=0, kernel=0, tilerow_begin=0, tilerow_end=0, autotune=False, **knobs):
         super().__init__()
@@ -40,7 +40,7 @@ class PlanOptions(C.Structure):
         self.tilerow_begin, self.tilerow_end, self.autotune = tilerow_begin, tilerow_end, 1 if autotune else 0
         for k in KNOB_NAMES:
             setattr(self, k, KNOB_DEFAULT)
-        for i in range(2):
+        for i in range(len(self.reserved)):
             self.reserved[i] = KNOB_DEFAULT
         for k, v in knobs.items():
             if k not in KNOB_NAMES:

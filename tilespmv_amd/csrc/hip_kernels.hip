@@ -763,7 +763,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         if (wr.y > wr.x) {  // workgroup-uniform
             if (side) for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
             __syncthreads();
-        } else if (S.panel_merge > 0 && side) {
+        } else if ((S.panel_merge > 0 || S.slice_passes > 0) && side) {
             for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
             wave_lds_fence();
         }
@@ -783,6 +783,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         } else if (wr.y > wr.x) {
             int ge = wr.y;   // column-panelled launch: this kernel takes the first panel_merge panels of the list, k_entries_acc the rest
             if (GPB == 16 && S.panel_merge > 0) ge = S.panel_off[(size_t)bid * (size_t)(S.x_panels + 1) + (size_t)min(S.x_panels, S.panel_merge)];
+            if (GPB == 16 && S.slice_passes > 0) ge = wr.x;   // column slices pinned to XCDs: the whole list belongs to k_entries_xcd
             wg_entry_trips<WCOO_HEAVY_CT, 16 * GPB, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, ge);
             __syncthreads();
         }
@@ -1077,6 +1078,70 @@ __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream 
             if (k < nrows && yi < rowA) y[yi] = (val_t)((lacc_t)yold[k] + mine[k * 16 + r]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column slices pinned to XCDs (round 4; DevStream::slice_passes; scripts/micro/xcd_columns.hip is the model this was sized on).  A panel pass makes all eight XCDs sweep the
+// SAME slice of x, one kernel per slice, and pays a read-modify-write of y per pass.  The other way round: the dispatcher hands workgroup b to XCD b & 7, so workgroup b takes
+// group b >> 3's entries of column slice (pass * 8 + (b & 7)): an XCD only ever gathers from its own slice, which stays in its 4-MB L2 for the whole launch, and x crosses the
+// fabric once instead of once per XCD.  The eight partial sums of a row meet in y by atomic adds of the rows a workgroup touched (the unit kernel stored y before this launch);
+// the order of those adds is not fixed, so this form is only chosen when the caller has not asked for bit-reproducible sums.  (If a driver dispatched differently, only the
+// speed would change.)
+// ------------------------------------------------------------------------------------------------
+template <bool NTS, int CT>
+__global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_xcd(DevStream S, int rowA, int pass, const val_t *__restrict__ x, val_t *__restrict__ y)
+{
+    __shared__ lacc_t s_acc[GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16];
+    const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
+    const unsigned bid = blockIdx.x >> 3, slice = (unsigned)pass * 8u + (blockIdx.x & 7u), slices = 8u * (unsigned)S.slice_passes;
+    const int4 wr = S.wg_coo[bid];
+    const int *po = S.panel_off + (size_t)bid * (size_t)(S.x_panels + 1);
+    const unsigned P = (unsigned)S.x_panels;
+    const int gs = po[slice * P / slices], ge = po[(slice + 1u) * P / slices];   // slice s = panels [s P / slices, (s + 1) P / slices): together all of them, each once
+    if (ge <= gs) return;   // workgroup-uniform: nothing of this group in this slice
+    const long long task_id = (long long)bid * GROUPS_PER_BLOCK + g;
+    int4 t0 = make_int4(0, 0, 0, 0), t1 = make_int4(0, -1, 0, 0);
+    if (task_id < S.ntasks) {
+        t0 = reinterpret_cast<const int4 *>(S.task)[task_id * 2];
+        t1 = reinterpret_cast<const int4 *>(S.task)[task_id * 2 + 1];
+    }
+    const bool side = t0.w > t0.z;
+    const int row0 = t1.x, part = t1.y, nrows = t1.w;
+    for (int i = tid; i < GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16; i += 256) s_acc[i] = 0;
+    __syncthreads();
+    wg_entry_trips<CT, 256, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, false, x, s_acc, tid, wr.x, ge, gs);
+    __syncthreads();
+    if (!side) return;
+    const lacc_t *mine = s_acc + g * (STRIP_MAX_ROWS * 16);
+    if (part >= 0) {
+        const long long yi = (long long)row0 * 16 + r;
+        const val_t v = (val_t)mine[r];
+        if (yi < rowA && v != (val_t)0) atomicAdd(&y[yi], v);
+    } else {
+#pragma unroll
+        for (int k = 0; k < STRIP_MAX_ROWS; k++) {
+            const long long yi = ((long long)row0 + k) * 16 + r;
+            const val_t v = (val_t)mine[k * 16 + r];
+            if (k < nrows && yi < rowA && v != (val_t)0) atomicAdd(&y[yi], v);
+        }
+    }
+}
+
+hipError_t launch_entry_slices(const DevStream &S, int rowA, const val_t *x, val_t *y, hipStream_t st)
+{
+    const dim3 grid((unsigned)S.n_groups * 8u), blk(256);
+    // records per trip (256 x CT): the smallest trip that takes an average (group, slice) run whole — a second trip for a few stragglers costs a full round of latencies
+    // (uniform random 4 M rows, 1,536 records per run: CT 6 0.2815 ms, CT 8 0.2563; 8 M rows in two passes, 768 per run: CT 4 0.700, CT 6 0.706, CT 8 0.716)
+    const int ct = S.slice_ct;
+    for (int p = 0; p < S.slice_passes; p++) {
+        if (ct == 8) { if (S.nt_stream) hipLaunchKernelGGL((k_entries_xcd<true, 8>), grid, blk, 0, st, S, rowA, p, x, y);
+                       else hipLaunchKernelGGL((k_entries_xcd<false, 8>), grid, blk, 0, st, S, rowA, p, x, y); }
+        else if (ct == 4) { if (S.nt_stream) hipLaunchKernelGGL((k_entries_xcd<true, 4>), grid, blk, 0, st, S, rowA, p, x, y);
+                            else hipLaunchKernelGGL((k_entries_xcd<false, 4>), grid, blk, 0, st, S, rowA, p, x, y); }
+        else { if (S.nt_stream) hipLaunchKernelGGL((k_entries_xcd<true, 6>), grid, blk, 0, st, S, rowA, p, x, y);
+               else hipLaunchKernelGGL((k_entries_xcd<false, 6>), grid, blk, 0, st, S, rowA, p, x, y); }
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_entry_panels(const DevStream &S, int rowA, int xcd_remap, int xcd_chunk, const val_t *x, val_t *y, hipStream_t st)
@@ -1746,6 +1811,7 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
         Q.fix = P.fix_late; Q.nfix = P.nfix_late;
         hipLaunchKernelGGL(k_fixup_split, dim3((Q.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, Q, y);
     }
+    if (S.slice_passes > 0 && S.x_panels > 1 && S.ntasks > 0) return launch_entry_slices(S, P.rowA, x, y, st);   // the lists, by column slices pinned to XCDs
     if (S.panel_merge > 0 && S.x_panels > S.panel_merge && S.ntasks > 0) return launch_entry_panels(S, P.rowA, xcd_remap, xcd_chunk, x, y, st);   // y += the entries of the other column panels, last: every row has been written
     return hipGetLastError();
 }

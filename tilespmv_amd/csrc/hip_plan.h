@@ -151,6 +151,11 @@ struct DevStream {
     int x_panels;                         // finest panels recorded (1: none)
     int panel_merge;                      // panels per pass of the panelled form; 0 = whole lists in k_units (chosen by timing at plan creation, hip_plan.hip)
     int n_groups;                         // groups (workgroups of the entry phase)
+    // column slices pinned to XCDs (round 4, hip_kernels.hip k_entries_xcd): the other use of panel_off.  k_units leaves the lists alone; a launch of 8 x n_groups workgroups
+    // follows per pass, workgroup b (dispatched to XCD b & 7) takes group b >> 3's entries of column slice (pass * 8 + (b & 7)) of 8 * slice_passes slices, so one XCD only
+    // ever gathers from its own slice of x — which stays in its L2 — and adds the rows it touched to y atomically (sums not bit-reproducible).  0 = off
+    int slice_passes;
+    int slice_ct;                         // ... records per lane and trip of k_entries_xcd (4, 6 or 8: set with slice_passes from the average run length)
     unsigned *pace;                       // per team {start clock, wavefronts done}; nullptr: no pacing
     const unsigned *pace_sched;           // [pace_nslab + 1]: share of the shard's remote entries left of slab s, in 1 / 2^24
     unsigned pace_period;                 // 10-ns ticks one team's sweep is given (calibrated at plan creation; 0: nobody waits)

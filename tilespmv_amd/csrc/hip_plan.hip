@@ -67,6 +67,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.placement_tries = pick(o.placement_tries, "TILESPMV_PLACEMENT_TRIES", -1);
     k.x_panel_kb = pick(o.x_panel_kb, "TILESPMV_X_PANEL_KB", -1);
     k.x_panel_merge = pick(o.x_panel_merge, "TILESPMV_X_PANEL_MERGE", -1);
+    k.x_slice_passes = pick(o.x_slice_passes, "TILESPMV_X_SLICE_PASSES", -1);
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
     k.entry_from_caller = pinned(o.entry_mode, "TILESPMV_WAVE_COO");
     k.strip_from_caller = o.strip_cost > 0 || env_int("TILESPMV_STRIP_COST", 0) > 0;
@@ -233,7 +234,7 @@ const char *tilespmv_plan_options_layout(void)
         TSPMV_F(entry_mode) TSPMV_F(entry_ordered) TSPMV_F(strip_cost) TSPMV_F(split_above) TSPMV_F(split_cap) TSPMV_F(xcd_remap) TSPMV_F(xcd_chunk)
         TSPMV_F(csr_split) TSPMV_F(fix_inline) TSPMV_F(coo_cost) TSPMV_F(coo_heavy_min) TSPMV_F(coo_piece) TSPMV_F(strip_even) TSPMV_F(wg_strips)
         TSPMV_F(x_window) TSPMV_F(x_stride1) TSPMV_F(x_stride2) TSPMV_F(mv_native) TSPMV_F(mv_xcd_chunk) TSPMV_F(lds_pad) TSPMV_F(y_store)
-        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(x_panel_kb) TSPMV_F(x_panel_merge) TSPMV_F(placement_tries) TSPMV_F(reserved)
+        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(x_panel_kb) TSPMV_F(x_panel_merge) TSPMV_F(placement_tries) TSPMV_F(x_slice_passes) TSPMV_F(reserved)
 #undef TSPMV_F
         return o;
     }();
@@ -408,33 +409,56 @@ static void calibrate_pace(tilespmv_plan *plan)
     if (verbose) fprintf(stderr, "tilespmv: pace calibration: %s (unpaced %.4f ms, best paced %.4f ms at %.1f us)\n", S.pace ? "kept" : "dropped", t_base, best, best_ticks / 100.0);
 }
 
-// Column panels (DevStream::panel_off): how many of the recorded panels one pass takes, found by timing — the unpanelled launch, then passes of about 4, 8 and 16 MB of x.
-// The panelled form stays only when it is at least 3 % faster.  Launch-time choice: every candidate runs on the same lists.
+// Column panels (DevStream::panel_off): which launch form the entry lists get, found by timing — the plain launch (whole lists in the unit kernel), panelled launches with
+// passes of about 4, 8 and 16 MB of x, and column slices pinned to XCDs (k_entries_xcd) in 1, 2 or 4 passes where a slice is about 1-8 MB.  A form other than the plain launch
+// stays only when it is at least 3 % faster than it.  Launch-time choice: every candidate runs on the same lists.
 static void calibrate_panels(tilespmv_plan *plan, int colA)
 {
     DevStream &S = plan->st;
     const bool verbose = getenv("TILESPMV_PLAN_VERBOSE") != nullptr;
     val_t *dx = nullptr, *dy = nullptr;
     const size_t nx = (size_t)plan->dev.colA + 16, ny = (size_t)plan->dev.rowA + 16;
-    S.panel_merge = 0;
+    const int fixed_merge = S.panel_merge;   // > 0: the caller fixed the panelled form (only the slices are then timed against it)
+    if (plan->panel_calibrate) S.panel_merge = 0;
+    S.slice_passes = 0;
     if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) return;
     if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); return; }
     { std::vector<val_t> ones(nx, (val_t)1); (void)hipMemcpy(dx, ones.data(), nx * sizeof(val_t), hipMemcpyHostToDevice); }
     const double t_base = tilespmv_plan_time(plan, dx, dy, nullptr, 3, 8);
-    double best = t_base; int best_m = 0;
-    const double panel_mb = (double)colA * sizeof(val_t) / S.x_panels / (1 << 20);   // MB of x per recorded panel
-    int last = 0;
-    for (double mb : {4.0, 8.0, 16.0}) {
-        const int m = std::max(1, (int)(mb / std::max(panel_mb, 1e-9) + 0.5));
-        if (m == last || m >= S.x_panels) continue;
-        last = m;
-        S.panel_merge = m;
-        const double t = tilespmv_plan_time(plan, dx, dy, nullptr, 2, 8);
-        if (verbose) fprintf(stderr, "tilespmv: column panels: %d passes of %.1f MB of x -> %.4f ms (unpanelled %.4f)\n", (S.x_panels + m - 1) / m, m * panel_mb, t, t_base);
-        if (t > 0 && t < best) { best = t; best_m = m; }
+    double best = t_base; int best_m = fixed_merge, best_s = 0;
+    const double x_mb = (double)colA * sizeof(val_t) / (1 << 20), panel_mb = x_mb / S.x_panels;   // MB of x per recorded panel
+    if (plan->panel_calibrate) {
+        int last = 0;
+        for (double mb : {4.0, 8.0, 16.0}) {
+            const int m = std::max(1, (int)(mb / std::max(panel_mb, 1e-9) + 0.5));
+            if (m == last || m >= S.x_panels) continue;
+            last = m;
+            S.panel_merge = m;
+            const double t = tilespmv_plan_time(plan, dx, dy, nullptr, 2, 8);
+            if (verbose) fprintf(stderr, "tilespmv: column panels: %d passes of %.1f MB of x -> %.4f ms (plain %.4f)\n", (S.x_panels + m - 1) / m, m * panel_mb, t, t_base);
+            if (t > 0 && t < best) { best = t; best_m = m; best_s = 0; }
+        }
+        S.panel_merge = 0;
     }
-    S.panel_merge = (best_m > 0 && best < 0.97 * t_base) ? best_m : 0;
-    if (verbose) fprintf(stderr, "tilespmv: column panels: %s\n", S.panel_merge ? "kept" : "dropped");
+    if (plan->slice_calibrate) {
+        const int keep_merge = S.panel_merge;
+        S.panel_merge = 0;
+        for (int passes : {1, 2, 4}) {
+            const double slice_mb = x_mb / (8.0 * passes);
+            if (slice_mb > 8.5 || (passes > 1 && slice_mb < 0.9) || 8 * passes > 2 * S.x_panels) continue;
+            S.slice_passes = passes; S.slice_ct = slice_trip_records(plan->list_records, S.n_groups, passes);
+            const double t = tilespmv_plan_time(plan, dx, dy, nullptr, 2, 8);
+            if (verbose) fprintf(stderr, "tilespmv: column slices on XCDs: %d pass(es), %.1f MB of x per XCD -> %.4f ms (plain %.4f)\n", passes, slice_mb, t, t_base);
+            if (t > 0 && t < best) { best = t; best_m = 0; best_s = passes; }
+        }
+        S.slice_passes = 0;
+        S.panel_merge = keep_merge;
+    }
+    const bool keep = best < 0.97 * t_base;
+    S.slice_passes = keep ? best_s : 0;
+    S.slice_ct = slice_trip_records(plan->list_records, S.n_groups, std::max(1, S.slice_passes));
+    S.panel_merge = S.slice_passes > 0 ? 0 : (plan->panel_calibrate ? (keep ? best_m : 0) : fixed_merge);
+    if (verbose) fprintf(stderr, "tilespmv: entry lists: %s\n", S.slice_passes ? "column slices on XCDs" : S.panel_merge ? "column panels" : "plain launch");
     (void)hipFree(dx); (void)hipFree(dy);
 }
 
@@ -745,7 +769,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         retry_placement(plan, tries);
         I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0p);
     }
-    if (!K.dry && plan->panel_calibrate) {
+    if (!K.dry && (plan->panel_calibrate || plan->slice_calibrate)) {
         const double t0c = now_us();
         calibrate_panels(plan, colA);
         I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0c);
@@ -756,6 +780,12 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         I[TILESPMV_INFO_STREAM_BYTES] += 2LL * sv * plan->panel_rmw_rows / m + (passes - 1LL) * (n_tasks * 32 + (long long)plan->st.n_groups * 16);
     } else I[TILESPMV_INFO_X_PANELS] = 1;
     I[TILESPMV_INFO_X_PANEL_MERGE] = plan->st.panel_merge;
+    I[TILESPMV_INFO_X_SLICE_PASSES] = plan->st.slice_passes;
+    if (plan->st.slice_passes > 0) {   // every slice launch re-reads the task records and range words; a touched row costs one atomic (8 partial sums at most)
+        I[TILESPMV_INFO_X_PANELS] = plan->st.slice_passes;
+        I[TILESPMV_INFO_ENTRY_ORDERED] = 0;
+        I[TILESPMV_INFO_STREAM_BYTES] += plan->st.slice_passes * 8LL * (n_tasks * 32 + (long long)plan->st.n_groups * 16) + 2LL * sv * std::min<long long>(I[TILESPMV_INFO_SCATTERED_ENTRIES], 8LL * plan->st.slice_passes * plan->panel_rmw_rows / std::max(1, plan->st.x_panels));
+    }
     if (!K.dry && plan->pace_calibrate && plan->st.pace != nullptr) {
         const double t0c = now_us();
         calibrate_pace(plan);

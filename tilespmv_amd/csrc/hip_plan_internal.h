@@ -62,6 +62,7 @@ struct Knobs {
     int pace_slab_kb, pace_window, pace_team, pace_period_us;   // pace_period_us < 0: calibrate at plan creation
     int x_panel_kb;      // column panels of the entry lists: KB of x per panel; 0 off, -1 by rule
     int x_panel_merge;   // ... panels per pass; 0 unpanelled launch, -1 chosen by timing
+    int x_slice_passes;  // column slices pinned to XCDs: passes (8 slices each); 0 off, -1 chosen by timing beside the panelled forms
     int placement_tries; // large plans: arena placements timed at plan creation (-1 by size, 0 / 1 off, n)
     int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
@@ -72,6 +73,13 @@ struct Knobs {
 }  // namespace tilespmv
 
 using namespace tilespmv;
+
+// k_entries_xcd's trip size for `passes` slice passes: the smallest of 4 / 6 / 8 records per lane whose trip (x 256 lanes) holds an average run with 10 % to spare
+static inline int slice_trip_records(long long list_records, int groups, int passes)
+{
+    const double avg = (double)list_records / std::max(1.0, 8.0 * passes * (double)std::max(1, groups));
+    return avg * 1.1 <= 1024 ? 4 : avg * 1.1 <= 1536 ? 6 : 8;
+}
 
 struct tilespmv_plan {
     DevPlan dev{};
@@ -95,6 +103,8 @@ struct tilespmv_plan {
     int arena_flags = 0; size_t arena_skew = 0, arena_spacer = 0; bool arena_spacer_first_only = false;
     char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20, arena_next = (size_t)1 << 20, size_hint = 0;   // bump allocator of upload(); size_hint = the builder's estimate of the plan's bytes
     bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
+    long long list_records = 0;         // records of the merged entry lists (workgroup entry mode)
+    bool slice_calibrate = false;       // ... and whether column slices pinned to XCDs beat them (DevStream::slice_passes)
     bool panel_calibrate = false;       // panels recorded, panels per pass still to be chosen by timing (plan_create_one)
     long long panel_rmw_rows = 0;       // rows of y the passes beyond the first read and write, at the finest panels (byte model)
     bool pace_calibrate = false;        // slab-paced plan whose timetable length is still to be found by timing (plan_create_one)

@@ -915,7 +915,14 @@ void StreamBuilder::entries()
     }
     S.x_panels = x_panels; S.n_groups = (int)n_groups;
     S.panel_merge = (x_panels > 1 && K.x_panel_merge > 0) ? std::min(K.x_panel_merge, x_panels) : 0;
-    plan->panel_calibrate = x_panels > 1 && K.x_panel_merge < 0;
+    // column slices pinned to XCDs (DevStream::slice_passes): same lists and offsets, another launch form; never when the caller asked for reproducible sums
+    const bool slices_allowed = x_panels > 1 && K.entry_ordered != 1;
+    S.slice_passes = (slices_allowed && K.x_slice_passes > 0) ? std::min(K.x_slice_passes, 8) : 0;
+    plan->list_records = n_rec;
+    S.slice_ct = slice_trip_records(n_rec, (int)n_groups, std::max(1, S.slice_passes));
+    if (S.slice_passes > 0) S.panel_merge = 0;
+    plan->panel_calibrate = x_panels > 1 && K.x_panel_merge < 0 && S.slice_passes == 0;
+    plan->slice_calibrate = slices_allowed && K.x_slice_passes < 0 && K.x_panel_merge < 0;   // (a caller who fixes the panels per pass has chosen the form)
     plan->panel_rmw_rows = panel_rmw_rows;
     plan->info[TILESPMV_INFO_X_PANELS] = S.panel_merge > 0 ? (x_panels + S.panel_merge - 1) / S.panel_merge : 1;   // launches of the entry part
     if (hashing()) { Hash h; h.num((long long)(plan->digest ^ d0)); h.num(n_rec); h.num(n_chunk); h.num(n_groups); h.num(S.dest_bits); h.num(x_panels); stage_done(TILESPMV_STAGE_ENTRIES, h); }
