@@ -136,7 +136,8 @@ def test_slab_pacing_adds_a_sentinel_to_the_lists_and_counters_to_the_plan(mats)
 
 
 def test_column_panels_are_offsets_into_the_same_lists(mats):
-    """Panels are recorded as offsets into the one column-ordered list of a group: the records do not change, and how many panels a pass takes is a launch fact."""
+    """Panels are recorded as offsets into the one column-ordered list of a group: the records do not change, and how many panels a pass takes — or whether the XCDs take them as
+    column slices — is a launch fact.  (Putting a group's entries around its own rows first and letting the panels divide only the rest was tried: slower in all three forms.)"""
     tm, rows, n, nnz = mats["bandrand"]
     one, i1 = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=0)
     many, ik = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, x_panel_merge=1)
@@ -147,5 +148,9 @@ def test_column_panels_are_offsets_into_the_same_lists(mats):
     assert ik["stream_bytes"] > i2["stream_bytes"] > i1["stream_bytes"]          # the passes beyond the first read and write their rows of y
     off, io = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, x_panel_merge=0)
     assert _changed(many, off) == [] and io["x_panels"] == 1 and io["stream_bytes"] == i1["stream_bytes"]
+    sl, isl = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, x_slice_passes=2)
+    assert _changed(many, sl) == [] and isl["x_slice_passes"] == 2 and isl["x_panels"] == 2 and isl["x_panel_merge"] == 0 and isl["entry_ordered"] == 0
+    so, iso = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, x_slice_passes=2, entry_ordered=1)
+    assert iso["x_slice_passes"] == 0 and iso["entry_ordered"] == 1                # reproducible sums asked: the sliced form (atomic adds in any order) stays out
     for kw in (dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, wg_strips=32), dict(entry_mode=2, pace=1, pace_slab_kb=1)):
         assert api.plan_layout_stages(tm, rows, n, nnz, x_panel_kb=32, x_panel_merge=1, **kw)[1]["x_panels"] == 1, kw
