@@ -414,36 +414,32 @@ static void calibrate_pace(tilespmv_plan *plan)
 // stays only when it is at least 3 % faster than it.  Launch-time choice: every candidate runs on the same lists.
 static void calibrate_panels(tilespmv_plan *plan, int colA)
 {
+    // (runs only when the panels per pass are the plan's to choose — plan->panel_calibrate; the sliced candidates join when plan->slice_calibrate allows them)
     DevStream &S = plan->st;
     const bool verbose = getenv("TILESPMV_PLAN_VERBOSE") != nullptr;
     val_t *dx = nullptr, *dy = nullptr;
     const size_t nx = (size_t)plan->dev.colA + 16, ny = (size_t)plan->dev.rowA + 16;
-    const int fixed_merge = S.panel_merge;   // > 0: the caller fixed the panelled form (only the slices are then timed against it)
-    if (plan->panel_calibrate) S.panel_merge = 0;
-    S.slice_passes = 0;
+    S.panel_merge = 0; S.slice_passes = 0;
     if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) return;
     if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); return; }
     { std::vector<val_t> ones(nx, (val_t)1); (void)hipMemcpy(dx, ones.data(), nx * sizeof(val_t), hipMemcpyHostToDevice); }
     const double t_base = tilespmv_plan_time(plan, dx, dy, nullptr, 3, 8);
-    double best = t_base; int best_m = fixed_merge, best_s = 0;
+    double best = t_base; int best_m = 0, best_s = 0;
     const double x_mb = (double)colA * sizeof(val_t) / (1 << 20), panel_mb = x_mb / S.x_panels;   // MB of x per recorded panel
-    if (plan->panel_calibrate) {
-        int last = 0;
-        for (double mb : {4.0, 8.0, 16.0}) {
-            const int m = std::max(1, (int)(mb / std::max(panel_mb, 1e-9) + 0.5));
-            if (m == last || m >= S.x_panels) continue;
-            last = m;
-            S.panel_merge = m;
-            const double t = tilespmv_plan_time(plan, dx, dy, nullptr, 2, 8);
-            if (verbose) fprintf(stderr, "tilespmv: column panels: %d passes of %.1f MB of x -> %.4f ms (plain %.4f)\n", (S.x_panels + m - 1) / m, m * panel_mb, t, t_base);
-            if (t > 0 && t < best) { best = t; best_m = m; best_s = 0; }
-        }
-        S.panel_merge = 0;
+    int last = 0;
+    for (double mb : {4.0, 8.0, 16.0}) {
+        const int m = std::max(1, (int)(mb / std::max(panel_mb, 1e-9) + 0.5));
+        if (m == last || m >= S.x_panels) continue;
+        last = m;
+        S.panel_merge = m;
+        const double t = tilespmv_plan_time(plan, dx, dy, nullptr, 2, 8);
+        if (verbose) fprintf(stderr, "tilespmv: column panels: %d passes of %.1f MB of x -> %.4f ms (plain %.4f)\n", (S.x_panels + m - 1) / m, m * panel_mb, t, t_base);
+        if (t > 0 && t < best) { best = t; best_m = m; best_s = 0; }
     }
-    if (plan->slice_calibrate) {
-        const int keep_merge = S.panel_merge;
-        S.panel_merge = 0;
+    S.panel_merge = 0;
+    if (plan->slice_calibrate)
         for (int passes : {1, 2, 4}) {
+            // fewest slices that still mostly fit an L2: a (group, slice) run is one trip, and more, shorter runs cost more than the misses they avoid (profiles/r04_column_slices.txt)
             const double slice_mb = x_mb / (8.0 * passes);
             if (slice_mb > 8.5 || (passes > 1 && slice_mb < 0.9) || 8 * passes > 2 * S.x_panels) continue;
             S.slice_passes = passes; S.slice_ct = slice_trip_records(plan->list_records, S.n_groups, passes);
@@ -451,13 +447,10 @@ static void calibrate_panels(tilespmv_plan *plan, int colA)
             if (verbose) fprintf(stderr, "tilespmv: column slices on XCDs: %d pass(es), %.1f MB of x per XCD -> %.4f ms (plain %.4f)\n", passes, slice_mb, t, t_base);
             if (t > 0 && t < best) { best = t; best_m = 0; best_s = passes; }
         }
-        S.slice_passes = 0;
-        S.panel_merge = keep_merge;
-    }
     const bool keep = best < 0.97 * t_base;
     S.slice_passes = keep ? best_s : 0;
     S.slice_ct = slice_trip_records(plan->list_records, S.n_groups, std::max(1, S.slice_passes));
-    S.panel_merge = S.slice_passes > 0 ? 0 : (plan->panel_calibrate ? (keep ? best_m : 0) : fixed_merge);
+    S.panel_merge = keep ? best_m : 0;
     if (verbose) fprintf(stderr, "tilespmv: entry lists: %s\n", S.slice_passes ? "column slices on XCDs" : S.panel_merge ? "column panels" : "plain launch");
     (void)hipFree(dx); (void)hipFree(dy);
 }
@@ -769,7 +762,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         retry_placement(plan, tries);
         I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0p);
     }
-    if (!K.dry && (plan->panel_calibrate || plan->slice_calibrate)) {
+    if (!K.dry && plan->panel_calibrate) {
         const double t0c = now_us();
         calibrate_panels(plan, colA);
         I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0c);
