@@ -653,7 +653,7 @@ def test_every_plan_kind_survives_being_moved(torch_cuda, monkeypatch, dtype):
 
 def test_tile_row_shards_with_panels_and_pacing(torch_cuda):
     """Tile-row shards (what one rank of a multi-GPU run owns) of a panelled / paced plan write exactly their rows of the full-length y: three shards with uneven cuts, columns not a
-    multiple of 16, panelled launches and paced launches; the union is the oracle's y and nothing outside a shard's rows is touched."""
+    multiple of 16, panelled, paced and sliced (column slices on XCDs: atomic adds into the shard's rows only) launches; the union is the oracle's y and nothing outside a shard's rows is touched."""
     from oracle.oracle import CpuImpl
     from tilespmv_amd import api, generators as G
     O = CpuImpl("oracle", np.float64)
@@ -665,7 +665,8 @@ def test_tile_row_shards_with_panels_and_pacing(torch_cuda):
     tilem = rowA // 16
     cuts = [0, tilem // 5, tilem // 2 + 3, tilem]
     xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda()
-    for kw in (dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, x_panel_kb=8, x_panel_merge=2, entry_ordered=0), dict(entry_mode=2, pace=1, pace_slab_kb=1, pace_period_us=5)):
+    for kw in (dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, x_panel_kb=8, x_panel_merge=2, entry_ordered=0), dict(entry_mode=2, pace=1, pace_slab_kb=1, pace_period_us=5),
+               dict(entry_mode=2, x_panel_kb=16, x_slice_passes=1), dict(entry_mode=2, x_panel_kb=8, x_slice_passes=3)):
         yd = torch_cuda.full((rowA + 16,), -7.0, dtype=xd.dtype, device="cuda")
         for a, b in zip(cuts[:-1], cuts[1:]):
             plan = api.Plan(tp, rowA, n, nnz, tilerow_begin=a, tilerow_end=b, **kw)
@@ -681,7 +682,7 @@ def test_tile_row_shards_with_panels_and_pacing(torch_cuda):
 
 def test_spmv_is_capturable_into_a_hip_graph(torch_cuda):
     """include/tilespmv.h promises that tilespmv_plan_spmv neither allocates nor synchronises — safe to capture into a hipGraph.  Captured and replayed here (torch's graph API on a
-    side stream) for a single-launch plan, a column-panelled plan (several launches), a slab-paced plan (its teams' clocks reset themselves), split tile-rows summed in-kernel (counters
+    side stream) for a single-launch plan, a column-panelled plan (several launches), a plan with column slices on XCDs (unit kernel + two slice launches), a slab-paced plan (its teams' clocks reset themselves), split tile-rows summed in-kernel (counters
     reset themselves) and the CSR fallback (second launch): every replay gives the oracle's y."""
     from oracle.oracle import CpuImpl
     from tilespmv_amd import api, generators as G
@@ -693,7 +694,7 @@ def test_spmv_is_capturable_into_a_hip_graph(torch_cuda):
     tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
     xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda()
     for kw in (dict(), dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, pace=1, pace_slab_kb=1, pace_period_us=5), dict(entry_mode=2, strip_cost=64, split_above=200),
-               dict(coo_mode=api.COO_FALLBACK), dict(entry_mode=1)):
+               dict(coo_mode=api.COO_FALLBACK), dict(entry_mode=1), dict(entry_mode=2, x_panel_kb=16, x_slice_passes=2)):
         plan = api.Plan(tp, rowA, n, nnz, **kw)
         yd = torch_cuda.zeros(rowA + 16, dtype=xd.dtype, device="cuda")
         side = torch_cuda.cuda.Stream()
