@@ -312,7 +312,8 @@ typedef struct {
                            that make passes of 4, 8 and 16 MB of x (kept when >= 3 % faster than the unpanelled launch)       TILESPMV_X_PANEL_MERGE */
     int placement_tries; /* where a large plan's blocks land in the card's memory decides between two states 13 % apart on the KKT matrices:
                            at plan creation the plan is timed (5 launches), moved to freshly allocated blocks (allocated BEFORE the old ones are freed) and timed
-                           again, up to this many placements (all held until the choice is made); the first placement >= 4 % faster than the first one is kept.  unset: 8 for plans of >= 1 GB, else 1 (= off)
+                           again, up to this many placements (all held until the choice is made); the fastest one seen is kept, and the search ends early once a placement is >= 9 % faster
+                           than a slow time two placements agree on, or five placements agree within 1.5 %.  unset: 8 for plans of >= 1 GB, else 1 (= off)
                                                                                                                     TILESPMV_PLACEMENT_TRIES */
     int x_slice_passes; /* column slices pinned to XCDs (round 4): the other use of the recorded panels.  The unit kernel leaves the entry lists alone; per pass one launch of
                            8 x groups workgroups follows in which workgroup b (dispatched to XCD b & 7) takes its group's entries of column slice pass * 8 + (b & 7), so an XCD
