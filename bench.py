@@ -645,7 +645,7 @@ def main():
         specs = [("scircuit", "scircuit", dtype, "small", True), ("webbase", "webbase", dtype, "small", True), ("nlpkkt160", "nlpkkt160", f32_, "large", True),
                  ("nlpkkt160_f64", "nlpkkt160", f64_, "large", False), ("lap3d256", "lap3d256", f64_, "large", False), ("band40_2m", "band40_2000000", f64_, "large", False),
                  ("powerlaw8m", "powerlaw8000000", f64_, "large", False), ("bandrand4x3_2m", "bandrand4x3_2000000", f64_, "large", False),
-                 ("uniform8_4m", "uniform8_4000000", f64_, "large", False)]
+                 ("uniform8_4m", "uniform8_4000000", f64_, "large", False), ("uniform8_8m", "uniform8_8000000", f64_, "large", False)]
         if args.extras:
             keep = set(args.extras.split(","))
             specs = [sp_ for sp_ in specs if sp_[0] in keep]
