@@ -1107,10 +1107,18 @@ __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_xcd(DevStream 
     }
     const bool side = t0.w > t0.z;
     const int row0 = t1.x, part = t1.y, nrows = t1.w;
+#if !(defined(XCD_ABL) && XCD_ABL == 2)   // diagnostic builds (timing only, results wrong): 1 no adds to y, 2 no zeroing of the slab, 3 neither and no trip at all (the skeleton: ranges, tasks, barriers)
     for (int i = tid; i < GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16; i += 256) s_acc[i] = 0;
+#endif
     __syncthreads();
+#if !(defined(XCD_ABL) && XCD_ABL == 3)
     wg_entry_trips<CT, 256, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, false, x, s_acc, tid, wr.x, ge, gs);
+#endif
     __syncthreads();
+#if defined(XCD_ABL) && (XCD_ABL == 1 || XCD_ABL == 3)
+    if (s_acc[tid] == (lacc_t)1.2345e300) y[0] = 1;
+    return;
+#endif
     if (!side) return;
     const lacc_t *mine = s_acc + g * (STRIP_MAX_ROWS * 16);
     if (part >= 0) {
