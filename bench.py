@@ -52,6 +52,9 @@ def build_matrix(name, cache_dir=None):
         return G.laplacian7pt(int(name[5:])) + ("synthetic 7-pt Laplacian on a cube",)
     if name.startswith("powerlaw"):
         return G.powerlaw(int(name[8:]), seed=2) + ("synthetic power-law",)
+    if name.startswith("fem"):   # fem<dof>[s<window>]_<n>: 27-point hexahedral mesh on n^3 nodes, <dof> unknowns per node (natural order, or nodes shuffled inside windows)
+        dof, win, nn = parse_fem(name)
+        return G.fem_hex(nn, nn, nn, dof, shuffle=win) + ("synthetic FEM-like: 27-point hex mesh %d^3 nodes x %d dof%s" % (nn, dof, ", nodes shuffled in windows of %d" % win if win else ", natural order"),)
     if name.startswith("circuit") and name[7:].isdigit():
         return G.circuit_like(int(name[7:]), seed=1) + ("synthetic circuit-like",)
     if name.startswith("laplacian"):
@@ -82,6 +85,12 @@ def build_matrix(name, cache_dir=None):
     raise SystemExit("unknown workload " + name)
 
 
+def parse_fem(name):
+    a, nn = name[3:].split("_")
+    dof, _, win = a.partition("s")
+    return int(dof), int(win or 0), int(nn)
+
+
 def build_block(name, rank, world, cache_dir=None):
     """This rank's row block of the workload: (rows, cols, bounds, rowptr_block, colidx_block, first_nnz, nnz_total, source, how).
     Stencil workloads (incl. the headline) have row-block generators: the cheap row pointer is computed by everyone, the
@@ -94,6 +103,10 @@ def build_block(name, rank, world, cache_dir=None):
         n = int(name[len("laplacian"):]); gen = (G.laplacian5pt, G.laplacian5pt_rowptr, n, "synthetic 5-pt Laplacian %d^2" % n)
     elif name.startswith("lap3d"):
         n = int(name[5:]); gen = (G.laplacian7pt, G.laplacian7pt_rowptr, n, "synthetic 7-pt Laplacian on a cube")
+    elif name.startswith("fem"):
+        dof, win, nn = parse_fem(name)
+        gen = (lambda n_, rows=None: G.fem_hex(n_, n_, n_, dof, shuffle=win, rows=rows), lambda n_: G.fem_hex(n_, n_, n_, dof, shuffle=win, rowptr_only=True), nn,
+               "synthetic FEM-like: 27-point hex mesh %d^3 nodes x %d dof%s" % (nn, dof, ", nodes shuffled in windows of %d" % win if win else ", natural order"))
     if gen is not None:
         full_rp = gen[1](gen[2])
         m = len(full_rp) - 1
@@ -613,7 +626,8 @@ def main():
                    "partition": "tile-row blocks, nnz-balanced, %d rank(s)" % world, "y_combine": args.combine, "backend": args.backend if world > 1 else None,
                    "tiles": getattr(sh, "tiles", None), "tasks": info["num_tasks"], "coo_mode": info["coo_mode"], "dense_mode": info["dense_mode"],
                    "entry_mode": info["entry_mode"], "sums_bit_reproducible": bool(info["entry_ordered"]), "strip_cost": info["strip_cost"],
-                   "x_window_slots": info["x_window_slots"], "x_panels": info["x_panels"], "x_panel_merge": info["x_panel_merge"], "x_slice_passes": info["x_slice_passes"], "placement_tries": info["placement_tries"]},
+                   "x_window_slots": info["x_window_slots"], "x_panels": info["x_panels"], "x_panel_merge": info["x_panel_merge"], "x_slice_passes": info["x_slice_passes"], "placement_tries": info["placement_tries"],
+                   "csr_form": info["csr_form"], "timed_choices_ms": round(info["timed_choices_us"] * 1e-3, 1)},
         "hbm_gbps_algorithmic": round(b_alg_total / (wall / args.steps) * 1e-9, 1),
         "hbm_roofline_frac": round(b_alg_total / (wall / args.steps) * 1e-9 / (HBM_PEAK_GBPS * world), 4),
         "roofline": roofline,
@@ -645,7 +659,10 @@ def main():
         specs = [("scircuit", "scircuit", dtype, "small", True), ("webbase", "webbase", dtype, "small", True), ("nlpkkt160", "nlpkkt160", f32_, "large", True),
                  ("nlpkkt160_f64", "nlpkkt160", f64_, "large", False), ("lap3d256", "lap3d256", f64_, "large", False), ("band40_2m", "band40_2000000", f64_, "large", False),
                  ("powerlaw8m", "powerlaw8000000", f64_, "large", False), ("bandrand4x3_2m", "bandrand4x3_2000000", f64_, "large", False),
-                 ("uniform8_4m", "uniform8_4000000", f64_, "large", False), ("uniform8_8m", "uniform8_8000000", f64_, "large", False)]
+                 ("uniform8_4m", "uniform8_4000000", f64_, "large", False), ("uniform8_8m", "uniform8_8000000", f64_, "large", False),
+                 # round 5: the FEM / block-structured class (the largest group among the >= 10 M-nnz matrices of the reference's sweep list): 27-point hex meshes, 3 and 6 unknowns
+                 # per node, natural order and nodes shuffled inside windows of 64 — > 90 % of their nonzeros sit in CSR-format tiles, executed as pooled units
+                 ("fem3_68", "fem3_68", f64_, "large", False), ("fem6_46", "fem6_46", f64_, "large", False), ("fem3s64_68", "fem3s64_68", f64_, "large", False)]
         if args.extras:
             keep = set(args.extras.split(","))
             specs = [sp_ for sp_ in specs if sp_[0] in keep]
@@ -665,7 +682,9 @@ def main():
                 r2 = (m2 // 16) * 16; nz2 = int(rp2[r2])
                 v2, x2 = G.compat_values(len(ci2), dt2), G.compat_x(n2, dt2)
                 # config 2 must exercise all seven tile formats: HYB is only reachable with the opt-in rule
+                t_tc = time.time()
                 tm2 = api.Tile_create(r2, n2, nz2, rp2, ci2, v2, dtype=dt2, hyb=(wl == "scircuit"))
+                t_tc = time.time() - t_tc
                 hist = np.bincount(field_array(tm2, "Format", tm2.tilenum), minlength=7).tolist()
                 ref2 = sp.csr_matrix((v2[:nz2], ci2[:nz2], rp2[:r2 + 1]), shape=(r2, n2)).astype(np.float64) @ x2.astype(np.float64)
                 b2 = api.algorithmic_bytes(nz2, r2, n2, dt2.itemsize)
@@ -677,8 +696,11 @@ def main():
                                else "HBM-bound; integer-valued data, checked exactly against scipy CSR"}
                 xd2 = torch.from_numpy(x2).cuda()
                 modes = (("coo_in_tile", api.COO_IN_TILE), ("coo_csr_fallback", api.COO_FALLBACK)) if small else (("default_plan", api.COO_AUTO),)
+                rec["tile_create_seconds"] = round(t_tc, 3)
                 for label, coo in modes:
+                    t_pc = time.time()
                     p2 = api.Plan(tm2, r2, n2, nz2, coo_mode=coo)
+                    t_pc = time.time() - t_pc
                     yd2 = torch.zeros(r2 + 16, dtype=td2, device="cuda")
                     ms2 = p2.time(xd2.data_ptr(), yd2.data_ptr(), stream.cuda_stream, warmup=20, reps=200 if small else 50)
                     i2 = p2.info()
@@ -691,7 +713,20 @@ def main():
                                   "check": "pass" if ok2 else "FAIL", "fallback_nnz": i2["fallback_nnz"],
                                   "entry_mode": i2["entry_mode"], "sums_bit_reproducible": bool(i2["entry_ordered"]),
                                   "strip_cost": i2["strip_cost"], "tasks": i2["num_tasks"], "x_panels": i2["x_panels"], "x_slice_passes": i2["x_slice_passes"], "nt_stream": i2["nt_stream"],
-                                  "placement_tries": i2["placement_tries"]}
+                                  "placement_tries": i2["placement_tries"], "csr_form": i2["csr_form"],
+                                  # what creating this plan cost (host re-layout + upload + whatever was timed on the device), and how much of it went into choices made by a stopwatch
+                                  "plan_create_seconds": round(t_pc, 3), "timed_choices_ms": round(i2["timed_choices_us"] * 1e-3, 1)}
+                    if i2["timed_choices_us"] > 0 and label != "coo_csr_fallback":
+                        # the same matrix with the one documented switch: no timed choice, every sum in a plan-fixed order (tilespmv_plan_options.deterministic) — what reproducibility costs here
+                        t_pd = time.time()
+                        pd_ = api.Plan(tm2, r2, n2, nz2, coo_mode=coo, deterministic=1)
+                        t_pd = time.time() - t_pd
+                        msd = pd_.time(xd2.data_ptr(), yd2.data_ptr(), stream.cuda_stream, warmup=20, reps=200 if small else 50)
+                        okd = bool(np.array_equal(yd2.cpu().numpy()[:r2].astype(np.float64), ref2))
+                        idt = pd_.info()
+                        rec[label]["deterministic"] = {"ms_per_spmv": round(msd, 5), "slowdown": round(msd / ms2, 3), "plan_create_seconds": round(t_pd, 3), "check": "pass" if okd else "FAIL",
+                                                       "sums_bit_reproducible": bool(idt["entry_ordered"]), "timed_choices_ms": round(idt["timed_choices_us"] * 1e-3, 1)}
+                        pd_.close()
                     if i2["scattered_entries"] * 5 >= nz2 and n2 * np.dtype(dt2).itemsize > (8 << 20):   # a scattered matrix whose x is larger than two L2s (every XCD gathers from all of x): the chip's ceiling for gathers that no neighbour shares (59 G/s, profiles/r04_gather_granule.txt) beside the byte roofline
                         rec[label]["scattered_gathers"] = {"count": i2["scattered_entries"], "share_of_nnz": round(i2["scattered_entries"] / nz2, 3),
                                                            "gathers_per_second": round(i2["scattered_entries"] / ms2 * 1e3, 0), "chip_ceiling_unstructured": SCATTERED_GATHER_CEILING,

@@ -272,7 +272,12 @@ typedef struct {
     int split_cap;      /* ... and the cap of that threshold in the wavefront / workgroup entry modes        TILESPMV_SPLIT_CAP */
     int xcd_remap;      /* workgroup -> XCD map: 0 round-robin, 2 windows of 8 x xcd_chunk workgroups         TILESPMV_XCD_REMAP */
     int xcd_chunk;      /*                                                                                   TILESPMV_XCD_CHUNK */
-    int csr_split;      /* CSR tiles as units + entries (1) or whole tiles in their own pass (0)             TILESPMV_CSR_SPLIT */
+    int csr_split;      /* what the device executes for CSR-format tiles: 0 whole tiles in their own pass (first-generation routine, y +=); 1 ELL-style split — the first w
+                           entries of every row as w zero-padded 16-value units, the rest as list entries; 2 POOLED units (round 5) — the nonzeros of a tile-row's CSR tiles, COO
+                           tiles and HYB remainders pooled in column-major order and cut into units of up to 16 nonzeros inside a 16-column window of x (value + column-offset nibble +
+                           row nibble per slot, products scattered into the strip's LDS rows): no padding beyond the last unit of a run of columns, about s_v + 1.3 bytes per nonzero
+                           on block-structured / FEM-like matrices; unset: 1 or 2, whichever puts at least 5 % fewer bytes into the streams (2 on shards whose nonzeros sit
+                           mostly in ragged CSR tiles, 1 on stencil-like shards whose units share a handful of column patterns)             TILESPMV_CSR_SPLIT */
     int fix_inline;     /* split tile-rows summed inside the unit kernel (1) or by k_fixup_split (0)         TILESPMV_FIX_INLINE */
     int coo_cost;       /* cost units per COO entry in the strip cutter                                      TILESPMV_COO_COST */
     int coo_heavy_min;  /* entry mode 0: strips with more entries run their list before the unit pipeline    TILESPMV_COO_HEAVY_MIN */
@@ -321,6 +326,10 @@ typedef struct {
                            meet in an order that is not fixed: never chosen when entry_ordered = 1.  N > 0 = N passes (8 N slices); 0 = off; unset (and x_panel_merge unset): timed at plan creation
                            beside the panelled forms (1, 2, 4 passes where a slice would be about 1-8 MB), kept when fastest and >= 3 % faster than the plain launch
                                                                                                                     TILESPMV_X_SLICE_PASSES */
+    int deterministic;  /* 1: no decision of this plan is taken by a stopwatch and every sum has a plan-fixed order — placement_tries, x_panel_merge, x_slice_passes, pace and autotune
+                           that the caller left unset are switched off (as if 1 / 0 / 0 / 0 / 0) and entry_ordered is 1: two plans of the same matrix then have the same layout,
+                           the same launch form and give bit-identical y on any data, run after run and rank after rank (the reference's own timing loop never changes the
+                           result either, src/tilespmv_cuda.h:1112-1137).  0 / unset: the defaults described above                       TILESPMV_DETERMINISTIC */
     int reserved[1];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
@@ -435,7 +444,9 @@ enum {
     TILESPMV_INFO_SCATTERED_ENTRIES = 28, /* workgroup entry mode: list entries whose column lies more than 2,048 columns outside their group's own rows — the gathers that
                                              no neighbour shares (the chip resolves about 59 G of those per second from a table that misses the L2s: profiles/r04_gather_granule.txt) */
     TILESPMV_INFO_X_SLICE_PASSES = 29,    /* column slices pinned to XCDs: launches of the sliced entry part (0 = not used); 8 x this many slices of x */
-    TILESPMV_INFO_COUNT = 30
+    TILESPMV_INFO_CSR_FORM = 30,          /* what CSR-format tiles became: 0 whole tiles (own pass), 1 ELL-style split (units + list entries), 2 pooled units */
+    TILESPMV_INFO_TIMED_CHOICES_US = 31,  /* microseconds of plan creation spent TIMING candidates (placement retry, column panels / slices, pacing); part of build_us; 0 = nothing was timed */
+    TILESPMV_INFO_COUNT = 32
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
 

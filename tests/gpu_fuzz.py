@@ -105,6 +105,10 @@ def check(seed):
     if seed % 9 == 5: env["TILESPMV_LDS_PAD"] = "8192"
     if seed % 4 == 2: env["TILESPMV_NT_STREAM"] = "1"   # nontemporal value / entry-record loads (by rule only on launches above 400 MB)
     if seed % 3 == 1: env["TILESPMV_DESC_DICT"] = "0"   # 12-B unit descriptors (the default takes the 4-B dictionary form wherever the patterns are few)
+    # round 5: what CSR-format tiles become — pooled units on three seeds of ten (with the COO tiles and HYB remainders of their tile-rows; every unit of the plan then has the
+    # pooled form), the ELL-style split on another two, the byte model's choice otherwise
+    if seed % 10 in (2, 5, 8): env["TILESPMV_CSR_SPLIT"] = "2"
+    elif seed % 10 in (3, 7): env["TILESPMV_CSR_SPLIT"] = "1"
     # round 4: column panels of the entry lists (panel 0 in the unit kernel, one y += launch per further panel)
     if env.get("TILESPMV_WAVE_COO") == "2" and env.get("TILESPMV_WG_STRIPS") != "32" and seed % 3 == 2:
         env.update({"TILESPMV_X_PANEL_KB": str([1, 4, 2, 16][(seed // 3) % 4]), "TILESPMV_X_PANEL_MERGE": str(1 + (seed // 7) % 3)})

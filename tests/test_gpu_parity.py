@@ -621,7 +621,7 @@ def test_every_plan_kind_survives_being_moved(torch_cuda, monkeypatch, dtype):
     column-panel offsets did, and the GPU suite aborted in the one run in which the timing happened to keep a moved placement).  TILESPMV_PLACEMENT_FORCE=1 keeps the LAST
     placement always: every plan kind — panels, pacing, x windows, dictionary / 12-B descriptors, CSR fallback, first-generation kernel, whole CSR tiles, dense tiles on the
     matrix cores, split rows — is moved twice and must still give the oracle's y, SpMM included; half of them with their blocks as virtual ranges over
-    separately created physical chunks (hipMemCreate / hipMemMap: what plans with blocks above 64 MB get by default)."""
+    separately created physical chunks (hipMemCreate / hipMemMap: opt-in, TILESPMV_ARENA_VMM_MB — off by default)."""
     from oracle.oracle import CpuImpl
     from tilespmv_amd import api, generators as G
     monkeypatch.setenv("TILESPMV_PLACEMENT_FORCE", "1")
@@ -630,7 +630,8 @@ def test_every_plan_kind_survives_being_moved(torch_cuda, monkeypatch, dtype):
             "one_long_row": SMALL["one_long_row"]}
     knob_sets = [dict(), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, pace=1, pace_slab_kb=1, pace_period_us=5),
                  dict(x_window=1), dict(x_window=1, entry_mode=2), dict(desc_dict=0), dict(coo_mode=api.COO_FALLBACK), dict(kernel=api.KERNEL_DIRECT), dict(csr_split=0),
-                 dict(dense_mode=api.DENSE_MFMA), dict(dense_mode=api.DENSE_VALU), dict(strip_cost=64, split_above=200), dict(strip_cost=64, split_above=200, fix_inline=0)]
+                 dict(dense_mode=api.DENSE_MFMA), dict(dense_mode=api.DENSE_VALU), dict(strip_cost=64, split_above=200), dict(strip_cost=64, split_above=200, fix_inline=0),
+                 dict(csr_split=2), dict(csr_split=2, entry_mode=2), dict(csr_split=2, strip_cost=64, split_above=200)]
     for name, gen in mats.items():
         m, n, rp, ci = gen()
         nnz, rowA = len(ci), truncated_rows(m)
@@ -1089,3 +1090,90 @@ def test_spmm_entry_pass_on_entry_dominated_plans(torch_cuda, dtype):
                 assert (Y[rowA:] == -7.0).all()
             plan.close()
         api.Tile_destroy(tp)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pooled_units_bit_exact(torch_cuda, dtype):
+    """Round 5: CSR-format tiles (with the COO tiles and HYB remainders of their tile-rows) as POOLED units — up to 16 nonzeros inside a 16-column window of x, value + column-offset
+    nibble + row nibble per slot, products scattered into the strip's LDS rows (k_units<.., POOL>; replaces reference src/csr2tile.h:429-451 + src/tilespmv_cuda.h:531-561 on the device).
+    Every unit of such a plan has that form (ELL slots, dense / dense-col columns, dense-row units too), so every tile format goes through it here: FEM-like meshes (natural and
+    shuffled order, 2 / 3 / 6 dof), the all-format matrices (HYB rule on, partial last tile column), KKT, band with dense tiles, a power-law matrix, one very long row — in every
+    entry mode, ordered and unordered, with split rows, tiny strips, the late fix-up, both dense modes, the CSR fallback, tile-row shards; whole y against the oracle bit for bit,
+    twice in a row; SpMM (one right-hand side at a time on these plans) and real-valued data inside the tolerance."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    O = CpuImpl("oracle", dtype)
+    mats = {"fem3_12": lambda: G.fem_hex(12, 12, 12, 3), "fem3s_14": lambda: G.fem_hex(14, 11, 9, 3, shuffle=16), "fem6_9": lambda: G.fem_hex(9, 9, 9, 6), "fem2_odd": lambda: G.fem_hex(13, 7, 5, 2),
+            "allfmt": SMALL["allfmt"], "allfmt_pad5": SMALL["allfmt_pad5"], "kkt12": MEDIUM["kkt12"], "band4096_40": SMALL["band4096_40"], "powerlaw20k": SMALL["powerlaw20k"],
+            "one_long_row": SMALL["one_long_row"], "empty_rows": SMALL["empty_rows"], "rand500x700": SMALL["rand500x700"]}
+    knob_sets = [dict(), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, entry_ordered=1), dict(entry_mode=2, entry_ordered=0), dict(strip_cost=64, split_above=200),
+                 dict(entry_mode=2, strip_cost=100, split_above=300, split_cap=300), dict(entry_mode=0, fix_inline=0, split_above=150, strip_cost=50), dict(dense_mode=api.DENSE_MFMA),
+                 dict(dense_mode=api.DENSE_VALU), dict(coo_mode=api.COO_FALLBACK), dict(xcd_remap=0, nt_stream=1), dict(entry_mode=2, nt_stream=1), dict(x_window=2), dict(lds_pad=8192)]
+    for name, gen in mats.items():
+        m, n, rp, ci = gen()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, x = values_for(name, nnz, n, dtype)
+        hyb = name.startswith("allfmt")
+        want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=hyb), rowA, n, nnz, rp, ci, vals, x)["y"]
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=hyb)
+        for kw in knob_sets:
+            y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, csr_split=2, **kw)
+            assert info["csr_form"] == 2 and info["desc_bytes"] == 20, (name, kw)
+            assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
+        # tile-row shards of a pooled plan write their own rows only
+        tilem = rowA // 16
+        if tilem >= 4:
+            xd = torch_cuda.from_numpy(x).cuda(); yd = torch_cuda.full((rowA + 16,), -7.0, dtype=xd.dtype, device="cuda")
+            cuts = [0, tilem // 3, tilem // 3 + 1, tilem]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                p = api.Plan(tp, rowA, n, nnz, csr_split=2, tilerow_begin=a, tilerow_end=b)
+                p.spmv(xd.data_ptr(), yd.data_ptr()); p.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()
+                p.close()
+            got = yd.cpu().numpy()
+            assert np.array_equal(got[:rowA], want) and (got[rowA:] == -7.0).all(), (name, "shards")
+        # SpMM: pooled plans have no native multi-vector kernel, every right-hand side goes through the plan's own SpMV
+        plan = api.Plan(tp, rowA, n, nnz, csr_split=2)
+        X = (np.arange(n * 4, dtype=np.int64) % 5).astype(dtype).reshape(n, 4)
+        Xd = torch_cuda.from_numpy(X).cuda(); Yd = torch_cuda.zeros((rowA + 16, 4), dtype=Xd.dtype, device="cuda")
+        plan.spmm(Xd.data_ptr(), Yd.data_ptr(), 4); torch_cuda.cuda.synchronize()
+        for j in range(4):
+            wj = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=hyb), rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"]
+            assert np.array_equal(Yd.cpu().numpy()[:rowA, j], wj), (name, "spmm", j)
+        plan.close()
+        api.Tile_destroy(tp)
+        # real-valued data: the pooled form adds a row's products in another order than the reference — inside the stated tolerance, and the same bits twice
+        vr, xr = values_for(name, nnz, n, dtype, real=True)
+        tr = api.Tile_create(rowA, n, nnz, rp, ci, vr, dtype=dtype, hyb=hyb)
+        wr = O.csr_spmv(rowA, rp, ci, vr, xr).astype(np.float64)
+        bound = TOL[np.dtype(dtype)] * _abs_bound(rowA, rp, ci, vr, xr) + 1e-300
+        for kw in (dict(), dict(entry_mode=2, entry_ordered=1)):
+            y1, _ = _gpu_y(torch_cuda, tr, rowA, n, nnz, xr, csr_split=2, **kw)
+            y2, _ = _gpu_y(torch_cuda, tr, rowA, n, nnz, xr, csr_split=2, **kw)
+            assert np.all(np.abs(y1.astype(np.float64) - wr) <= bound), (name, kw)
+            assert np.array_equal(y1, y2), (name, kw, "two plans, two launches: different bits")
+        api.Tile_destroy(tr)
+
+
+def test_deterministic_plans_give_the_same_bits_on_real_valued_data(torch_cuda):
+    """tilespmv_plan_options.deterministic = 1: no decision by a stopwatch (placement retry, column panels / slices, pacing) and ordered sums, so that two
+    plan creations of the same matrix give bit-identical y on REAL-valued data, launch after launch — also on the scattered matrices whose default plan is chosen by timing and may
+    add partial sums atomically.  (The reference's own timing loop never alters the result: src/tilespmv_cuda.h:1112-1137.)"""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    O = CpuImpl("oracle", np.float64)
+    for name, gen in (("uniform8_400k", lambda: G.uniform_per_row(400000, 2000000, 8, 1)), ("bandrand", lambda: G.band_plus_random(300000, 4, 3, 5)), ("powerlaw200k", MEDIUM["powerlaw200k"]),
+                      ("fem3_16", lambda: G.fem_hex(16, 16, 16, 3))):
+        m, n, rp, ci = gen()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vr, xr = values_for(name, nnz, n, np.float64, real=True)
+        tr = api.Tile_create(rowA, n, nnz, rp, ci, vr)
+        wr = O.csr_spmv(rowA, rp, ci, vr, xr)
+        bound = 1e-12 * _abs_bound(rowA, rp, ci, vr, xr) + 1e-300
+        ys = []
+        for _ in range(3):
+            y, info = _gpu_y(torch_cuda, tr, rowA, n, nnz, xr, deterministic=1)
+            assert info["entry_ordered"] == 1 and info["x_slice_passes"] == 0 and info["placement_tries"] <= 1 and info["timed_choices_us"] == 0, (name, info)
+            assert np.all(np.abs(y - wr) <= bound), name
+            ys.append(y)
+        assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2]), name
+        api.Tile_destroy(tr)

@@ -154,3 +154,54 @@ def test_column_panels_are_offsets_into_the_same_lists(mats):
     assert iso["x_slice_passes"] == 0 and iso["entry_ordered"] == 1                # reproducible sums asked: the sliced form (atomic adds in any order) stays out
     for kw in (dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, wg_strips=32), dict(entry_mode=2, pace=1, pace_slab_kb=1)):
         assert api.plan_layout_stages(tm, rows, n, nnz, x_panel_kb=32, x_panel_merge=1, **kw)[1]["x_panels"] == 1, kw
+
+
+def test_pooled_units_are_chosen_by_the_byte_model_and_are_a_layout_of_their_own():
+    """Round 5: CSR-format tiles as pooled units (csr_split = 2).  Unset, the form is the one that puts fewer bytes into the streams: pooled on a block-structured (FEM-like) shard whose
+    nonzeros sit in ragged CSR tiles, the ELL-style split on stencil-like shards whose units share a few column patterns (4-byte dictionary descriptors).  The form is decided in the
+    count stage, so every later stage follows; pooled plans have 20-byte descriptors, 4-row strips, no column panels and no dictionary."""
+    tm, rows, n, nnz = _tm(G.fem_hex(12, 12, 12, 3))
+    auto, ia = api.plan_layout_stages(tm, rows, n, nnz)
+    split, is_ = api.plan_layout_stages(tm, rows, n, nnz, csr_split=1)
+    pooled, ip = api.plan_layout_stages(tm, rows, n, nnz, csr_split=2)
+    whole, iw = api.plan_layout_stages(tm, rows, n, nnz, csr_split=0)
+    assert (ia["csr_form"], is_["csr_form"], ip["csr_form"], iw["csr_form"]) == (2, 1, 2, 0)
+    assert auto == pooled and {k: v for k, v in ia.items() if not k.endswith("_us")} == {k: v for k, v in ip.items() if not k.endswith("_us")}
+    assert ip["stream_bytes"] < 0.93 * is_["stream_bytes"] and ip["desc_bytes"] == 20
+    assert _changed(split, pooled) == ALL
+    b_alg = api.algorithmic_bytes(nnz, rows, n, 8)
+    assert ip["stream_bytes"] < 0.85 * b_alg            # values + 1.25 bytes per slot, fill > 0.9 even on this small mesh (boundary rows are a third of it)
+    for kw in (dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2), dict(entry_mode=2, x_panel_kb=4, x_panel_merge=1), dict(desc_dict=1), dict(x_window=1), dict(entry_mode=2, wg_strips=32), dict(entry_mode=2, pace=1, pace_slab_kb=1)):
+        _, i = api.plan_layout_stages(tm, rows, n, nnz, csr_split=2, **kw)
+        assert i["csr_form"] == 2 and i["desc_bytes"] == 20 and i["x_panels"] == 1 and i["x_window_slots"] == 0 and i["wg_strips"] == 16 and i["pace_slabs"] == 0, kw
+    api.Tile_destroy(tm)
+    for gen, want in ((G.laplacian7pt(48), 1), (G.laplacian5pt(200), 1), (G.fem_hex(9, 9, 9, 6), 2), (G.fem_hex(14, 11, 9, 3, shuffle=16), 2)):
+        tm, rows, n, nnz = _tm(gen)
+        assert api.plan_layout_stages(tm, rows, n, nnz)[1]["csr_form"] == want
+        api.Tile_destroy(tm)
+    for dtype in (np.float32,):
+        tm, rows, n, nnz = _tm(G.fem_hex(12, 12, 12, 3), dtype)
+        _, i = api.plan_layout_stages(tm, rows, n, nnz)
+        assert i["csr_form"] == 2 and i["stream_bytes"] < 0.80 * api.algorithmic_bytes(nnz, rows, n, 4)
+        api.Tile_destroy(tm)
+
+
+def test_pooled_plans_keep_every_nonzero_once(mats):
+    """The pooled form re-distributes nonzeros between units and list entries; whatever the knobs, units x 16 + list entries must cover the stored nonzeros (the GPU suite checks the values)."""
+    tm, rows, n, nnz = mats["allfmt"]
+    for kw in (dict(), dict(coo_mode=api.COO_FALLBACK), dict(dense_mode=api.DENSE_MFMA), dict(entry_mode=0, strip_cost=64, split_above=200)):
+        a, ia = api.plan_layout_stages(tm, rows, n, nnz, csr_split=2, **kw)
+        b, ib = api.plan_layout_stages(tm, rows, n, nnz, csr_split=2, **kw)
+        assert a == b and ia["csr_form"] == 2
+
+
+def test_deterministic_switch_turns_every_timed_choice_off(mats):
+    """tilespmv_plan_options.deterministic: no stopwatch (placement retry, column panels / slices, pacing calibration) and ordered sums; a layout fact, visible without a GPU."""
+    tm, rows, n, nnz = mats["bandrand"]
+    base, ib = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32)
+    det, idt = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, deterministic=1)
+    assert idt["entry_ordered"] == 1 and idt["x_panel_merge"] == 0 and idt["x_slice_passes"] == 0
+    sl, isl = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, x_slice_passes=2, entry_ordered=0, deterministic=1)
+    assert isl["x_slice_passes"] == 0 and isl["entry_ordered"] == 1      # the switch wins over knobs that would make the sums meet in any order
+    pm, ipm = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, x_panel_merge=2, deterministic=1)
+    assert ipm["x_panel_merge"] == 2                                      # a FIXED panelled form times nothing and adds in a fixed order: allowed

@@ -295,6 +295,16 @@ __device__ __forceinline__ uint4 load_udesc(const UDesc *__restrict__ d, int i)
     return make_uint4(u.w0, u.n0, u.w0, u.n1);
 }
 
+// ... and the same descriptor as it is held in registers while it waits for its turn (k_units): the three loaded words as they arrive, (w0, n0, n1, -).  Building the LDS form
+// right behind the load needs a register move of w0, and the move needs the load's data: the wavefront then waits a full memory round trip for a prefetch it
+// will not use for four batches (that is what the 12-byte-descriptor kernels did until round 5).  The LDS form is built when the chunk is parked.
+__device__ __forceinline__ uint4 load_udesc_raw(const UDesc *__restrict__ d, int i)
+{
+    const UDesc u = d[i];
+    return make_uint4(u.w0, u.n0, u.n1, 0u);
+}
+__device__ __forceinline__ uint4 udesc_park_form(const uint4 raw) { return make_uint4(raw.x, raw.y, raw.x, raw.z); }
+
 // Dictionary plans (DevStream::cb_bits > 0; hip_plan.hip): 4 B per unit in HBM — column block | pattern id << cb_bits |
 // flags << 27 — and the unit's column pattern (the two nibble words) in a small dictionary that stays in the vector L1.
 // A lane expands its unit's descriptor to the 16-B LDS form when the chunk is parked.
@@ -335,6 +345,12 @@ typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 #endif
 #ifndef UNITS_MIN_WAVES
 #define UNITS_MIN_WAVES 8  // waves per SIMD asked of the register allocator (64 VGPRs)
+#endif
+#ifndef POOL_ECOO2_MIN_WAVES
+#define POOL_ECOO2_MIN_WAVES 5   // pooled plans, workgroup entry mode: 96 VGPRs (at 6 waves = 80 VGPRs the kernel spills 12 bytes)
+#endif
+#ifndef POOL_MIN_WAVES
+#define POOL_MIN_WAVES 7   // pooled plans, per-strip entries: 14.5 KB of LDS per workgroup; 72 VGPRs (at 8 waves = 64 VGPRs the kernel spills 20 bytes and runs slower)
 #endif
 
 // ---- packed entry records (hip_plan.h ERec): value + (column - chunk base) << dest_bits | destination
@@ -630,8 +646,12 @@ extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
 // gathered from the dictionary one chunk ahead (when its word has arrived), so neither hop is waited for in the unit loop.
 // NTS: value and entry-record loads are nontemporal (plans larger than the Infinity Cache, DevStream::nt_stream).
 // PACE: slab-paced workgroup entry phase (wg_entry_paced above; ECOO = 2, 256-thread workgroups, no x windows).
-template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD, bool NTS, bool PACE = false>
-__global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 : ECOO == 2 ? ECOO2_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+// POOL: pooled plans (hip_plan.h "pooled units", round 5): a unit is up to 16 nonzeros of a tile-row inside one 16-column window of x — slot s = value, column-offset nibble, row nibble —
+// so a lane no longer owns a row: it gathers x[base + its column nibble] and adds its product to the strip's slab of s_y with ds_add (destination = tile-row in strip, its row
+// nibble); there is no register accumulator, no end-of-row handling and no "rows without units": the slab is zeroed up front, entries and units add into it, y is stored from it.
+// The row nibbles travel like the descriptors (8 bytes per unit, one coalesced lane load per chunk of 16 units, parked in LDS: + 2 KB per workgroup -> 7 workgroups per CU).
+template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD, bool NTS, bool PACE = false, bool POOL = false>
+__global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_ECOO2_MIN_WAVES : ECOO2_MIN_WAVES) : POOL ? POOL_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
@@ -640,8 +660,9 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     static_assert(!(XWIN && CD), "x-window plans keep 12-B descriptors (their low bits hold window slots)");
     static_assert(!(NTS && (XWIN || ECOO == 1)), "nontemporal streams: large plans only (entry mode 1 = small grids; x windows are an opt-in experiment)");
     static_assert(!PACE || (ECOO == 2 && GPB == 16 && !XWIN), "slab pacing: workgroup entry mode, 256-thread workgroups, no x windows");
+    static_assert(!POOL || (GPB == 16 && !XWIN && !CD && !PACE), "pooled plans: 256-thread workgroups, 12-B descriptors + row nibbles, no x windows, no pacing");
     constexpr int GROUPS_PER_BLOCK = GPB;
-    constexpr int SROWS = XWIN ? XWIN_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
+    constexpr int SROWS = XWIN ? XWIN_STRIP_ROWS : POOL ? POOL_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
     constexpr bool NT = NTS;  // nontemporal value loads
 #ifndef TILESPMV_NT_DESC
 #define TILESPMV_NT_DESC 0
@@ -652,6 +673,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     constexpr bool NT_DESC = NTS && TILESPMV_NT_DESC, NT_COO0 = NTS && TILESPMV_NT_COO0;
     __shared__ lacc_t s_y[GROUPS_PER_BLOCK][SROWS][16];   // (lacc_t: fp64 in both builds, see its typedef)
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
+    __shared__ uint2 s_r[POOL ? GROUPS_PER_BLOCK : 1][POOL ? DCHUNK : 1];   // pooled plans: row nibbles of the parked descriptor chunk
     val_t *s_xw = reinterpret_cast<val_t *>(s_dyn);   // [window slot][16]
 #ifdef TILESPMV_ABL_LDS_PAD   // diagnostic builds only: extra LDS per workgroup, to measure what fewer resident workgroups cost
     __shared__ unsigned s_pad[TILESPMV_ABL_LDS_PAD / 4];
@@ -684,7 +706,11 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     const int unit_begin = t0.x, unit_end = t0.y, coo_begin = t0.z, coo_end = t0.w;
     const int row0 = t1.x, part = t1.y, nrows = t1.w;
     const unsigned nounit = (unsigned)t1.z;
-    const bool side = coo_end > coo_begin;
+    const bool side = POOL || coo_end > coo_begin;   // the strip's slab of s_y holds sums (entries; in pooled plans everything)
+    if constexpr (POOL) {   // the slab is zeroed before anything adds into it (the entry phases below sit behind a fence / barrier of their own)
+        for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
+        wave_lds_fence();
+    }
     // values are stored in groups of G = UNIT_GROUP units of one task (hip_plan.hip): row r of the group that starts at
     // task-relative unit j (a multiple of G) sits at uval[(unit_begin + j) * 16 + G r .. + G - 1]; a batch of UB units
     // is UB / G sixteen-byte loads per lane
@@ -707,6 +733,8 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         }
     }
     uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
+    uint2 rcur = make_uint2(0u, 0u), rnext = rcur;   // POOL: row nibbles of the chunks in dcur / dnext
+    const uint2 *__restrict__ urw = reinterpret_cast<const uint2 *>(S.urow);
     unsigned wnn = 0;   // CD: descriptor word of the chunk after `dnext`
     const unsigned *__restrict__ udw = reinterpret_cast<const unsigned *>(S.udesc);
     val_t v[UB];
@@ -716,8 +744,9 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
                 dcur.x = stream_load<NT_DESC>(udw + min(unit_begin + r, last));
                 dnext.x = stream_load<NT_DESC>(udw + min(unit_begin + DCHUNK + r, last));
             } else {
-                dcur = load_udesc(S.udesc, min(unit_begin + r, last));
-                dnext = load_udesc(S.udesc, min(unit_begin + DCHUNK + r, last));
+                dcur = load_udesc_raw(S.udesc, min(unit_begin + r, last));
+                dnext = load_udesc_raw(S.udesc, min(unit_begin + DCHUNK + r, last));
+                if constexpr (POOL) { rcur = urw[min(unit_begin + r, last)]; rnext = urw[min(unit_begin + DCHUNK + r, last)]; }
             }
 #pragma unroll
             for (int k = 0; k < UB; k += G) {
@@ -731,18 +760,28 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     // descriptors (from the chunk parked in LDS) and x gathers of one unit batch; j0 = position of the batch in the chunk
     const uint2 *sd = reinterpret_cast<const uint2 *>(&s_d[g][0]) + (r >> 3);  // this lane's 8-B half of a descriptor
     uint2 d[UB];
+    unsigned rw[UB];   // POOL: this lane's half of the unit's row nibbles
     val_t xv[UB];
+    const unsigned *sr = reinterpret_cast<const unsigned *>(&s_r[POOL ? g : 0][0]) + (r >> 3);
     auto park_first = [&]() {   // chunk 0 into LDS (CD: the patterns of chunks 0 and 1 are gathered here, the word of chunk 2 loaded)
         if constexpr (CD) {
             const uint2 p0 = udict_of(S, dcur.x), p1 = udict_of(S, dnext.x);
             wnn = stream_load<NT_DESC>(udw + min(unit_begin + 2 * DCHUNK + r, last));
             dnext.y = p1.x; dnext.w = p1.y;
             s_d[g][r] = udesc_expand(S, dcur.x, p0);
-        } else s_d[g][r] = dcur;
+        } else s_d[g][r] = udesc_park_form(dcur);
+        if constexpr (POOL) s_r[g][r] = rcur;
     };
     auto fetch_batch = [&](int j0) {
 #pragma unroll
         for (int k = 0; k < UB; k++) d[k] = sd[2 * (j0 + k)];
+        if constexpr (POOL) {
+#pragma unroll
+            for (int k = 0; k < UB; k++) rw[k] = sr[2 * (j0 + k)];
+#pragma unroll
+            for (int k = 0; k < UB; k++) xv[k] = x[min((long long)(d[k].x & POOL_BASE_MASK) + (long long)((d[k].y >> (28 - 4 * (r & 7))) & 15u), xlast)];
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < UB; k++) {
             const unsigned fl = d[k].x >> 24;
@@ -883,6 +922,23 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     // lane stores.  (Stores share the in-order vmcnt queue with the loads on CDNA4: a store in the middle
     // of the unit loop makes every later counted wait also wait for its write acknowledge.)
     auto retire = [&](val_t prod, unsigned flags, unsigned word1) {
+        if constexpr (POOL) {   // flags = word 0 >> 24 (tile-row in strip in its top nibble), word1 = this lane's half of the row nibbles
+            unsigned dest = ((flags >> (POOL_KR_SHIFT - 24)) & 7u) * 16u + ((word1 >> (28 - 4 * (r & 7))) & 15u);
+#if defined(TILESPMV_POOL_ABL)   // diagnostic builds only (timing; results wrong by construction): 1 plain LDS store instead of the atomic add, 2 atomic add to a lane-private address (no two lanes of a unit share one), 3 no LDS operation at all
+#if TILESPMV_POOL_ABL == 2
+            dest = (dest & ~15u) | (unsigned)r;
+#endif
+#if TILESPMV_POOL_ABL == 1
+            (&s_y[g][0][0])[dest] = (lacc_t)prod;
+            return;
+#elif TILESPMV_POOL_ABL == 3
+            acc += prod;
+            return;
+#endif
+#endif
+            atomicAdd(&s_y[g][0][0] + dest, (lacc_t)prod);
+            return;
+        }
         if (flags & UNIT_ROWUNIT) {  // dense-row unit: lanes hold one row's products
             prod = strip_allreduce(prod);
             if (r != (int)(word1 & 15u)) prod = 0;
@@ -916,14 +972,15 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             if (u == chunk_end) {  // next descriptor chunk: already in registers, fetch the one after it
                 wave_lds_fence();
                 if constexpr (CD) s_d[g][r] = udesc_expand(S, dnext.x, make_uint2(dnext.y, dnext.w));
-                else s_d[g][r] = dnext;
+                else s_d[g][r] = udesc_park_form(dnext);
+                if constexpr (POOL) { s_r[g][r] = rnext; rnext = urw[min(chunk_end + DCHUNK + r, last)]; }
                 wave_lds_fence();
                 chunk_end += DCHUNK;
                 if constexpr (CD) {
                     const uint2 p = udict_of(S, wnn);   // (its word was loaded a chunk ago)
                     dnext = make_uint4(wnn, p.x, 0u, p.y);
                     wnn = stream_load<NT_DESC>(udw + min(chunk_end + DCHUNK + r, last));
-                } else dnext = load_udesc(S.udesc, min(chunk_end + r, last));
+                } else dnext = load_udesc_raw(S.udesc, min(chunk_end + r, last));
             }
             if (!(ECOO == 1 && u == unit_begin)) fetch_batch(u - (chunk_end - DCHUNK));
             val_t vn[UB];
@@ -935,12 +992,19 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             }
 #pragma unroll
             for (int k = 0; k < UB; k++)
-                if (u + k < unit_end) retire(v[k] * xv[k], d[k].x >> 24, d[k].y);
+            {
+                if constexpr (POOL) {
+                    // unconditional adds (a unit past the task's end adds 0 to a row of this strip's slab: its descriptor is the clamped load of the task's last unit): with the add
+                    // under a branch the compiler sinks the unit's gather into the branch and waits for it with vmcnt(0) — every unit then pays a full memory round trip
+                    retire((u + k < unit_end) ? v[k] * xv[k] : (val_t)0, d[k].x >> 24, rw[k]);
+                } else if (u + k < unit_end) retire(v[k] * xv[k], d[k].x >> 24, d[k].y);
+            }
 #pragma unroll
             for (int k = 0; k < UB; k++) v[k] = vn[k];
         }
     }
     TSPMV_STAMP_WAIT(4);       // unit loop done
+    if constexpr (POOL) wave_lds_fence();   // every add of this wavefront into the slab is behind us
     if (part >= 0) {
         val_t out = acc;
         if (side) out = (val_t)((lacc_t)acc + s_y[g][0][r]);
@@ -975,7 +1039,14 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             }
         }
     } else {
-        if constexpr (sizeof(val_t) == sizeof(lacc_t)) {
+        if constexpr (POOL) {
+            if constexpr (sizeof(val_t) != sizeof(lacc_t)) {   // fp32 build: the fp64 sums go back as floats into the head of each row's 128 bytes (the form the store below reads; lane r's 4 bytes
+                for (int k = 0; k < nrows; k++) {              // overlap the doubles of lanes r / 2, which every lane of the strip has read one instruction earlier)
+                    const val_t o = (val_t)s_y[g][k][r];
+                    reinterpret_cast<val_t *>(&s_y[g][k][0])[r] = o;
+                }
+            }
+        } else if constexpr (sizeof(val_t) == sizeof(lacc_t)) {
             if (!side) {  // rows without any unit and no COO contribution are zero
                 unsigned m = nounit;
                 while (m) { const int kr = __ffs((int)m) - 1; m &= m - 1; s_y[g][kr][r] = 0; }
@@ -1802,7 +1873,13 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
 #define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L4(X, 2, 16, true, false, false); else if (xwin_lds_bytes > 0) TSPMV_L4(X, 0, 16, true, false, false); \
         else if (entry_mode == 2 && wg_strips == 32) TSPMV_L2(X, 2, 32); else if (entry_mode == 2) TSPMV_L2(X, 2, 16); \
         else if (entry_mode == 1) { if (S.cb_bits > 0) TSPMV_L4(X, 1, 16, false, true, false); else TSPMV_L4(X, 1, 16, false, false, false); } else TSPMV_L2(X, 0, 16); } while (0)
-        if (xcd_remap == 2) TSPMV_L1(2); else TSPMV_L1(0);
+#define TSPMV_LP(X, W, NTS) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, 16, false, false, NTS, false, true>), dim3((unsigned)((S.ntasks + 15) / 16)), dim3(256), (size_t)lds_pad_bytes, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_LP1(X) do { if (entry_mode == 1) TSPMV_LP(X, 1, false); else if (entry_mode == 2) { if (S.nt_stream) TSPMV_LP(X, 2, true); else TSPMV_LP(X, 2, false); } \
+        else { if (S.nt_stream) TSPMV_LP(X, 0, true); else TSPMV_LP(X, 0, false); } } while (0)
+        if (S.pooled) { if (xcd_remap == 2) TSPMV_LP1(2); else TSPMV_LP1(0); }
+        else if (xcd_remap == 2) TSPMV_L1(2); else TSPMV_L1(0);
+#undef TSPMV_LP1
+#undef TSPMV_LP
 #undef TSPMV_L1
 #undef TSPMV_L2
 #undef TSPMV_L3

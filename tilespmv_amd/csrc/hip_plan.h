@@ -102,6 +102,22 @@ constexpr int UNIT_FLAG_SHIFT = 24;       // flags live above the 24-bit column 
 
 struct UDesc { unsigned w0, n0, n1; };    // 12 bytes in HBM; lanes expand it to (w0, n0, w0, n1) in LDS so that a lane reads one 8-B half
 
+// ---- pooled units (round 5; the execution form of CSR-format tiles on block-structured / FEM-like shards, where > 90 % of the nonzeros sit in ragged CSR tiles:
+// reference pack src/csr2tile.h:429-451, GPU routine src/tilespmv_cuda.h:531-561).  The nonzeros of a tile-row's CSR tiles, COO tiles and HYB remainders are POOLED in
+// column-major order (column, then row) and cut into units of up to 16 of them whose columns fall into one window [base, base + 16) of x: slot s of a unit = value,
+// column offset nibble, row nibble.  A unit costs 12 (UDesc: w0 = base | tile-row-in-strip << 28, the 16 column nibbles) + 8 (URow: the 16 row nibbles) + 16 values;
+// only the last unit of a run of adjacent columns is partly empty (fill 0.99 on a 27-point hex mesh with 3 dof per node), so the streams come to about s_v + 1.3 bytes
+// per nonzero — against the s_v + 1 per STORED slot + 12 per unit of the ELL-style split (w padded units per tile, the rest as 13-byte list entries), which on ragged
+// tiles stores 1.3-1.6 slots per nonzero.  Lanes no longer own rows: every product goes to the strip's slab of s_y with ds_add_f64 (destination = tile-row-in-strip,
+// row nibble) and y is stored from the slab.  In a pooled plan EVERY unit has this form (ELL slots, dense and dense-col columns: base = 16 x column block, identity row
+// nibbles; dense-row units: identity column nibbles, one row nibble), so the kernel has one code path.  Windows that hold fewer nonzeros than a unit is worth
+// (POOL_MIN_FILL) stay on the strip's entry list.
+constexpr int POOL_KR_SHIFT = 28;         // w0 of a pooled unit: first column of the window (28 bits: the unit path already limits shards to 2^24 column blocks) | tile-row in strip << 28
+constexpr unsigned POOL_BASE_MASK = (1u << POOL_KR_SHIFT) - 1u;
+constexpr int POOL_MIN_FILL = sizeof(val_t) == 8 ? 12 : 10;   // 16 s_v + 20 bytes per unit against s_v + 5 (4 in the packed lists) per list entry
+constexpr int POOL_STRIP_ROWS = 4;        // tile-rows per strip of a pooled plan (their tile-rows are heavy; the slab of s_y is half the size: 14.5 KB of LDS per workgroup)
+struct URow { unsigned r0, r1; };         // row nibbles of slots 0-7 / 8-15 (slot 0 in the top nibble)
+
 struct STask {                            // 32 bytes
     int unit_begin, unit_end;
     int coo_begin, coo_end;
@@ -114,6 +130,8 @@ struct STask {                            // 32 bytes
 
 struct DevStream {
     const UDesc *udesc;                   // per unit, 12 B: column block | flags << 24, column nibbles of rows 0-7, of rows 8-15 (dictionary plans: 4-B words, see cb_bits)
+    const URow *urow;                     // pooled plans: the row nibbles of every unit (nullptr otherwise)
+    int pooled;                           // 1: every unit is a pooled unit (above)
     const val_t *uval;                    // 16 values per unit, stored in groups of UNIT_GROUP units of one task, interleaved per row
     const val_t *cval;                    // COO entry list: value, global column, (row-in-strip << 4) | row
     const int *ccol;

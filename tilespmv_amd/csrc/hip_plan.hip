@@ -42,7 +42,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.split_cap = pick(o.split_cap, "TILESPMV_SPLIT_CAP", 4800);
     k.xcd_remap = pick(o.xcd_remap, "TILESPMV_XCD_REMAP", 2) ? 2 : 0;
     k.xcd_chunk = std::max(1, pick(o.xcd_chunk, "TILESPMV_XCD_CHUNK", 32));
-    k.csr_split = pick(o.csr_split, "TILESPMV_CSR_SPLIT", 1);
+    k.csr_split = pick(o.csr_split, "TILESPMV_CSR_SPLIT", -1);
     k.fix_inline = pick(o.fix_inline, "TILESPMV_FIX_INLINE", 1);
     k.coo_cost = pick(o.coo_cost, "TILESPMV_COO_COST", 4);
     k.coo_heavy_min = std::max(0, pick(o.coo_heavy_min, "TILESPMV_COO_HEAVY_MIN", 32));
@@ -68,6 +68,16 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.x_panel_kb = pick(o.x_panel_kb, "TILESPMV_X_PANEL_KB", -1);
     k.x_panel_merge = pick(o.x_panel_merge, "TILESPMV_X_PANEL_MERGE", -1);
     k.x_slice_passes = pick(o.x_slice_passes, "TILESPMV_X_SLICE_PASSES", -1);
+    k.deterministic = pick(o.deterministic, "TILESPMV_DETERMINISTIC", 0) > 0 ? 1 : 0;
+    if (k.deterministic) {   // no stopwatch, no unordered sum: whatever the caller left unset among the timed choices is switched off
+        if (k.placement_tries < 0) k.placement_tries = 1;
+        if (k.x_panel_merge < 0) k.x_panel_merge = 0;
+        if (k.x_slice_passes < 0) k.x_slice_passes = 0;
+        if (k.pace < 0) k.pace = 0;
+        if (k.pace > 0 && k.pace_period_us < 0) k.pace = 0;   // (a paced plan calibrates its timetable by timing)
+        k.autotune = 0;
+        k.entry_ordered = 1; k.x_slice_passes = 0;            // (column slices add rows in an order that is not fixed)
+    }
     k.xcd_from_caller = pinned(o.xcd_remap, "TILESPMV_XCD_REMAP") || pinned(o.xcd_chunk, "TILESPMV_XCD_CHUNK");
     k.entry_from_caller = pinned(o.entry_mode, "TILESPMV_WAVE_COO");
     k.strip_from_caller = o.strip_cost > 0 || env_int("TILESPMV_STRIP_COST", 0) > 0;
@@ -110,8 +120,8 @@ static void retry_placement(tilespmv_plan *plan, int tries)
     typedef std::vector<std::pair<void *, size_t>> Blocks;
     val_t *dx = nullptr, *dy = nullptr;
     const size_t nx = (size_t)plan->dev.colA + 16, ny = (size_t)plan->dev.rowA + 16;
-    if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) return;
-    if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); return; }
+    if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dx); return; }
     { std::vector<val_t> ones(nx, (val_t)1); (void)hipMemcpy(dx, ones.data(), nx * sizeof(val_t), hipMemcpyHostToDevice); }
     auto rebase = [&](const Blocks &from, const Blocks &to) {
         for_each_plan_pointer(plan, [&](const void *&p) {
@@ -146,9 +156,14 @@ static void retry_placement(tilespmv_plan *plan, int tries)
                 if (hipMalloc(&sp, sz) == hipSuccess) spacers.push_back(sp); else (void)hipGetLastError();
             }
             void *nb = nullptr;
-            if (plan->block_alloc(&nb, b.second) != 0) { ok = false; break; }
+            {   // a candidate needs room for itself with some to spare: ask first instead of probing by failure (all earlier candidates are still held)
+                size_t mem_free = 0, mem_total = 0;
+                if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+                if (mem_free < b.second + ((size_t)512 << 20)) { ok = false; break; }
+            }
+            if (plan->block_alloc(&nb, b.second, /*quiet=*/true) != 0) { ok = false; break; }
             fresh.push_back({nb, b.second});
-            if (hipMemcpy(nb, cand[at][fresh.size() - 1].first, b.second, hipMemcpyDeviceToDevice) != hipSuccess) { ok = false; break; }
+            if (hipMemcpy(nb, cand[at][fresh.size() - 1].first, b.second, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
         }
         if (!ok) { for (auto &b : fresh) plan->block_free(b.first); break; }
         rebase(cand[at], fresh);
@@ -185,6 +200,7 @@ static void retry_placement(tilespmv_plan *plan, int tries)
         for (auto &b : cand[i]) plan->block_free(b.first);   // (block_alloc registered every candidate with the plan; block_free takes it off again)
     }
     if (best != 0) plan->arena_blocks = cand[best];
+    plan->arena_at = nullptr; plan->arena_left = 0;   // the bump allocator pointed into the first placement's last block, which may be gone: placement is final, a later upload starts a fresh block
     for (void *sp : spacers) (void)hipFree(sp);
     if (verbose) fprintf(stderr, "tilespmv: placement %zu of %zu kept (%.4f ms; first %.4f)\n", best + 1, cand.size(), ms[best], ms[0]);
     (void)hipFree(dx); (void)hipFree(dy);
@@ -246,7 +262,7 @@ const char *tilespmv_plan_options_layout(void)
         TSPMV_F(entry_mode) TSPMV_F(entry_ordered) TSPMV_F(strip_cost) TSPMV_F(split_above) TSPMV_F(split_cap) TSPMV_F(xcd_remap) TSPMV_F(xcd_chunk)
         TSPMV_F(csr_split) TSPMV_F(fix_inline) TSPMV_F(coo_cost) TSPMV_F(coo_heavy_min) TSPMV_F(coo_piece) TSPMV_F(strip_even) TSPMV_F(wg_strips)
         TSPMV_F(x_window) TSPMV_F(x_stride1) TSPMV_F(x_stride2) TSPMV_F(mv_native) TSPMV_F(mv_xcd_chunk) TSPMV_F(lds_pad) TSPMV_F(y_store)
-        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(x_panel_kb) TSPMV_F(x_panel_merge) TSPMV_F(placement_tries) TSPMV_F(x_slice_passes) TSPMV_F(reserved)
+        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(x_panel_kb) TSPMV_F(x_panel_merge) TSPMV_F(placement_tries) TSPMV_F(x_slice_passes) TSPMV_F(deterministic) TSPMV_F(reserved)
 #undef TSPMV_F
         return o;
     }();
@@ -260,8 +276,11 @@ const char *tilespmv_plan_options_layout(void)
 int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA,
                          const tilespmv_plan_options *opts)
 {
-    const Knobs K0 = resolve_knobs(opts);
-    if (!K0.autotune) return plan_create_one(out, T, rowA, colA, nnzA, K0);
+    const Knobs Kc = resolve_knobs(opts);
+    if (!Kc.autotune) return plan_create_one(out, T, rowA, colA, nnzA, Kc);
+    // candidates are timed where they land: the placement search (up to 8 held copies of a >= 1 GB plan, each timed) runs ONCE, on the winner
+    Knobs K0 = Kc;
+    if (Kc.placement_tries < 0) K0.placement_tries = 1;
     *out = nullptr;
     const int tilem = T->tilem;
     const int tr0 = std::max(0, K0.tilerow_begin), tr1 = (K0.tilerow_end <= 0 || K0.tilerow_end > tilem) ? tilem : K0.tilerow_end;
@@ -375,6 +394,12 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     }
     (void)hipFree(dx); (void)hipFree(dy);
     if (!best) return -4;
+    if (Kc.placement_tries < 0 && best->info[TILESPMV_INFO_DEVICE_BYTES] >= (1ll << 30)) {
+        const double t0p = now_us();
+        retry_placement(best, 8);
+        best->info[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0p);
+        best->info[TILESPMV_INFO_TIMED_CHOICES_US] += (long long)(now_us() - t0p);
+    }
     *out = best;
     return 0;
 }
@@ -390,8 +415,8 @@ static void calibrate_pace(tilespmv_plan *plan)
     const size_t nx = (size_t)plan->dev.colA + 16, ny = (size_t)plan->dev.rowA + 16;
     unsigned *const pace = S.pace;
     auto give_up = [&]() { S.pace = nullptr; S.pace_period = 0; plan->info[TILESPMV_INFO_PACE_SLABS] = 0; plan->info[TILESPMV_INFO_PACE_PERIOD_US] = 0; };
-    if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) { give_up(); return; }
-    if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); give_up(); return; }
+    if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) { (void)hipGetLastError(); give_up(); return; }
+    if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dx); give_up(); return; }
     {
         std::vector<val_t> ones(nx, (val_t)1);
         (void)hipMemcpy(dx, ones.data(), nx * sizeof(val_t), hipMemcpyHostToDevice);
@@ -432,8 +457,8 @@ static void calibrate_panels(tilespmv_plan *plan, int colA)
     val_t *dx = nullptr, *dy = nullptr;
     const size_t nx = (size_t)plan->dev.colA + 16, ny = (size_t)plan->dev.rowA + 16;
     S.panel_merge = 0; S.slice_passes = 0;
-    if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) return;
-    if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); return; }
+    if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dx); return; }
     { std::vector<val_t> ones(nx, (val_t)1); (void)hipMemcpy(dx, ones.data(), nx * sizeof(val_t), hipMemcpyHostToDevice); }
     const double t_base = tilespmv_plan_time(plan, dx, dy, nullptr, 3, 8);
     double best = t_base; int best_m = 0, best_s = 0;
@@ -774,11 +799,13 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         const double t0p = now_us();
         retry_placement(plan, tries);
         I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0p);
+        if (tries > 1 && !plan->arena_blocks.empty()) I[TILESPMV_INFO_TIMED_CHOICES_US] += (long long)(now_us() - t0p);
     }
     if (!K.dry && plan->panel_calibrate) {
         const double t0c = now_us();
         calibrate_panels(plan, colA);
         I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0c);
+        I[TILESPMV_INFO_TIMED_CHOICES_US] += (long long)(now_us() - t0c);
     }
     if (plan->st.panel_merge > 0) {   // the panelled form: passes beyond the first read and write their rows of y and re-read the task records
         const int m = plan->st.panel_merge, passes = (plan->st.x_panels + m - 1) / m;
@@ -796,6 +823,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         const double t0c = now_us();
         calibrate_pace(plan);
         I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0c);
+        I[TILESPMV_INFO_TIMED_CHOICES_US] += (long long)(now_us() - t0c);
     }
     *out = plan;
     return 0;
@@ -862,7 +890,7 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
     // native multi-vector kernels: unit-stream plans whose COO entries run in-tile and whose CSR tiles were split into units
     // (the defaults).  Generation-1 plans, whole-tile passes and the CSR fallback go one right-hand side at a time.
     const int mv_native = plan->mv_native;   // 1 / 0: force the multi-vector kernel / the one-at-a-time path on entry-dominated plans
-    const bool has_native = plan->kernel == TILESPMV_KERNEL_STREAM && plan->dev.ntasks == 0 && plan->dev.f_nblk == 0;
+    const bool has_native = plan->kernel == TILESPMV_KERNEL_STREAM && plan->dev.ntasks == 0 && plan->dev.f_nblk == 0 && !plan->pooled;
     // entry-dominated plans (round 3, final): the multi-vector kernel scatters a strip's entries up front (entry slab, mv_slab_rows), which beats going one right-hand side
     // at a time at every nvec (webbase stand-in 37 / 58 / 93 us against 42 / 85 / 223) and beats the separate entry pass over the merged lists (k_entries_mv; workgroup entry mode,
     // 16 strips, no x windows) from nvec 4 on (power-law 8 M: 0.254 / 0.375 / 0.678 ms against 0.198 / 0.469 / 1.364 with the pass): the pass stays for nvec 2.

@@ -64,6 +64,7 @@ struct Knobs {
     int x_panel_merge;   // ... panels per pass; 0 unpanelled launch, -1 chosen by timing
     int x_slice_passes;  // column slices pinned to XCDs: passes (8 slices each); 0 off, -1 chosen by timing beside the panelled forms
     int placement_tries; // large plans: arena placements timed at plan creation (-1 by size, 0 / 1 off, n)
+    int deterministic;   // 1: nothing is chosen by timing, every sum in a plan-fixed order (tilespmv_plan_options.deterministic)
     int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
     bool dry;            // tilespmv_plan_layout_digest: build the layout on the host only, hash instead of upload
@@ -91,6 +92,7 @@ struct tilespmv_plan {
     bool mv_by_columns = false;              // ... and plans whose work is mostly COO entries (the multi-vector kernel walks them per 16-lane strip)
     int mv_native = -1, mv_xcd_chunk = -1;   // knobs of tilespmv_plan_spmm (Knobs)
     int mv_slab_rows = 0;                    // > 0: the multi-vector kernel scatters a strip's entries up front into an LDS slab of this many tile-rows per lane group
+    bool pooled = false;                // every unit is a pooled unit (hip_plan.h): k_units<.., POOL>; no native multi-vector kernel yet
     int entry_mode = 0;                 // COO entry lists walked per 16-lane strip (0), per wavefront (1) or per workgroup, column-ordered (2)
     std::vector<void *> allocs;
     std::vector<std::pair<void *, size_t>> arena_blocks;   // the blocks the plan's streams were carved from (and the partial-slot array), with their sizes: what a re-placement moves
@@ -152,7 +154,7 @@ struct tilespmv_plan {
         return 0;
     }
     // a block of the arena (or a candidate placement of one): chunked physical backing when large, hipMalloc otherwise; the plan owns it until block_free / destroy
-    int block_alloc(void **out, size_t bytes)
+    int block_alloc(void **out, size_t bytes, bool quiet = false)
     {
         // A block starts out as zeros, explicitly: the kernels read a little past the end of some streams (a strip's last descriptor chunk, masked tail lanes — the 256 bytes of
         // slack behind every stream are there for that) and what they find must decode to "nothing" (unit 0, offset 0).  hipMalloc happens to hand out zeroed memory;
@@ -164,7 +166,15 @@ struct tilespmv_plan {
         }
         hipError_t e = arena_flags ? hipExtMallocWithFlags(out, bytes, (unsigned)arena_flags) : hipMalloc(out, bytes);   // experiment knob TILESPMV_ARENA_FLAGS (4 = physically contiguous)
         if (e == hipSuccess) e = hipMemset(*out, 0, bytes);
-        if (e != hipSuccess) { fprintf(stderr, "tilespmv: device allocation of %zu MB failed: %s\n", bytes >> 20, hipGetErrorString(e)); if (*out) (void)hipFree(*out); *out = nullptr; return -1; }
+        if (e != hipSuccess) {
+            // a tolerated failure (a candidate placement that does not fit) must not leave HIP's sticky last error behind: the next launch_* returns hipGetLastError() and
+            // would report this out-of-memory for a healthy launch
+            (void)hipGetLastError();
+            if (!quiet) fprintf(stderr, "tilespmv: device allocation of %zu MB failed: %s\n", bytes >> 20, hipGetErrorString(e));
+            if (*out) (void)hipFree(*out);
+            *out = nullptr;
+            return -1;
+        }
         allocs.push_back(*out);
         return 0;
     }
@@ -217,7 +227,7 @@ struct tilespmv_plan {
             void *b = nullptr;
             if (arena_spacer && (!arena_spacer_first_only || arena_blocks.empty())) {   // experiment knob TILESPMV_ARENA_SPACER_MB: an unused allocation in front of every block (does where a block lands decide its state? DESIGN.md S6.19)
                 void *sp = nullptr;
-                if (hipMalloc(&sp, arena_spacer) == hipSuccess) allocs.push_back(sp);
+                if (hipMalloc(&sp, arena_spacer) == hipSuccess) allocs.push_back(sp); else (void)hipGetLastError();
             }
             if (block_alloc(&b, blk) != 0) return -1;
             arena_blocks.push_back({b, blk});

@@ -29,26 +29,88 @@ inline int csr_split_width(const unsigned char *ptr, int rowlen, int nnz, int *r
     return best_w;
 }
 
-inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, bool csr_split, int coo_cost)
+// ---- pooled units (hip_plan.h): the nonzeros of a tile-row's CSR tiles, COO tiles and HYB remainders, in column-major order (column, then row; tiles are in
+// ascending column-block order and a tile's own nonzeros are bucketed by column nibble, so no comparison sort is needed)
+struct PoolEnt { unsigned col; unsigned row; val_t val; };   // global column, row inside the tile-row
+
+// Cuts a column-major run of pooled nonzeros into windows: a window starts at the first nonzero not yet taken and holds the (up to 16) following ones whose column is
+// less than 16 above its first column.  `col(i)` = column of nonzero i; `emit(begin, end)` is called once per window.
+template <class ColOf, class Emit>
+inline void pool_windows(long long n, ColOf col, Emit emit)
 {
+    long long i = 0;
+    while (i < n) {
+        const unsigned long long lim = (unsigned long long)col(i) + 16ull;
+        long long j = i + 1;
+        while (j < n && j - i < 16 && (unsigned long long)col(j) < lim) j++;
+        emit(i, j);
+        i = j;
+    }
+}
+
+// The pooled nonzeros of one tile: appended to `out` in column-major order (a stable bucket pass over the tile's row-major entries).  src(k) -> (row, column nibble, value)
+template <class Src>
+inline void pool_tile(int cb, int count, Src src, std::vector<PoolEnt> &out)
+{
+    int start[17] = {0};
+    for (int k = 0; k < count; k++) { unsigned r, c; val_t v; src(k, r, c, v); start[c + 1]++; }
+    for (int c = 0; c < 16; c++) start[c + 1] += start[c];
+    const size_t base = out.size();
+    out.resize(base + (size_t)count);
+    for (int k = 0; k < count; k++) { unsigned r, c; val_t v; src(k, r, c, v); out[base + (size_t)start[c]++] = PoolEnt{(unsigned)cb * 16u + c, r, v}; }
+}
+
+// Everything tile-row bi pools (hip_plan.h "pooled units"), column-major.  CSR tiles always; COO tiles and HYB remainders when they run in-tile.
+inline void pool_row(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, const std::vector<long long> &hyb_off, std::vector<PoolEnt> &out)
+{
+    out.clear();
+    for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], cb = T->tile_columnidx[t];
+        if (fmt == TILESPMV_FMT_CSR) {
+            const int off = T->csr_offset[t];
+            const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
+            unsigned char rowof[256];
+            for (int r = 0; r < rowlen; r++) { const int k0 = ptr[r], k1 = (r == rowlen - 1) ? stored : ptr[r + 1]; for (int k = k0; k < k1; k++) rowof[k] = (unsigned char)r; }
+            pool_tile(cb, stored, [&](int k, unsigned &r, unsigned &c, val_t &v) { r = rowof[k]; c = (unsigned)nib(T->csr_compressedIdx, (long long)off + k); v = T->Blockcsr_Val[off + k]; }, out);
+        } else if (fmt == TILESPMV_FMT_COO && coo_in_tile) {
+            const int off = T->coo_offset[t];
+            pool_tile(cb, stored, [&](int k, unsigned &r, unsigned &c, val_t &v) { const unsigned b = T->coo_compressed_Idx[off + k]; r = b >> 4; c = b & 15u; v = T->Blockcoo_Val[off + k]; }, out);
+        } else if (fmt == TILESPMV_FMT_HYB && coo_in_tile) {
+            const int off = T->hyb_offset[t], nell = T->tilewidth[t] * rowlen;
+            const unsigned char *src = T->hybIdx + hyb_off[t];
+            pool_tile(cb, stored - nell, [&](int k, unsigned &r, unsigned &c, val_t &v) { const unsigned b = src[(nell + 1) / 2 + k]; r = b >> 4; c = b & 15u; v = T->Blockhyb_Val[off + nell + k]; }, out);
+        }
+    }
+}
+
+inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, int coo_cost, const std::vector<long long> &hyb_off, std::vector<PoolEnt> &scratch)
+{
+    // csr_form: 0 CSR tiles stay whole tiles (their own pass), 1 ELL-style split (w units + list entries), 2 pooled units
     RowCount c{0, 0, 0, 0, 0, 0, 0};
+    const bool pooled = csr_form == 2;
     for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
         const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
         switch (fmt) {
         case TILESPMV_FMT_ELL: c.nunits += w; break;
-        case TILESPMV_FMT_HYB: c.nunits += w; if (coo_in_tile) c.ncoo += stored - w * rowlen; break;
+        case TILESPMV_FMT_HYB: c.nunits += w; if (coo_in_tile && !pooled) c.ncoo += stored - w * rowlen; break;
         case TILESPMV_FMT_DNSCOL: c.nunits += T->dnscolptr[t + 1] - T->dnscolptr[t]; break;
         case TILESPMV_FMT_DNS:
             if (dense_mfma) c.ndense++;
             else c.nunits += tile_collen(T->tile_columnidx[t], tilen, colA);
             break;
-        case TILESPMV_FMT_COO: if (coo_in_tile) c.ncoo += stored; break;
+        case TILESPMV_FMT_COO: if (coo_in_tile && !pooled) c.ncoo += stored; break;
         case TILESPMV_FMT_CSR:
-            if (csr_split) { int rem; c.nunits += csr_split_width(T->Blockcsr_Ptr + T->csrptr_offset[t], rowlen, stored, &rem); c.ncoo += rem; }
+            if (pooled) break;
+            if (csr_form == 1) { int rem; c.nunits += csr_split_width(T->Blockcsr_Ptr + T->csrptr_offset[t], rowlen, stored, &rem); c.ncoo += rem; }
             else { c.nheavy++; c.hval += stored; c.hidx += 16 + (stored + 1) / 2; }
             break;
         case TILESPMV_FMT_DNSROW: c.nunits += T->dnsrowptr[t + 1] - T->dnsrowptr[t]; break;  // one row unit per dense row
         }
+    }
+    if (pooled) {
+        pool_row(T, bi, rowlen, coo_in_tile, hyb_off, scratch);
+        pool_windows((long long)scratch.size(), [&](long long i) { return scratch[(size_t)i].col; },
+                     [&](long long b, long long e) { if (e - b >= POOL_MIN_FILL) c.nunits++; else c.ncoo += (int)(e - b); });
     }
     // heavy tiles are latency-bound (one tile at a time): weigh them so that long lists get split
     c.cost = 16LL * c.nunits + (long long)coo_cost * c.ncoo + c.hval + 256LL * c.nheavy + 64LL * c.ndense + 8;
@@ -115,7 +177,7 @@ struct StreamBuilder {
     DevStream &S;
     int rc = 0;
     // COUNT
-    bool csr_split = true; int target_in = 0, split_above_in = 0, tilem = 0, tilen = 0, ntr = 0, sv = 0;
+    bool csr_split = true, pooled = false; int csr_form = 1, target_in = 0, split_above_in = 0, tilem = 0, tilen = 0, ntr = 0, sv = 0;
     std::vector<RowCount> rc_;
     std::vector<long long> pu, pc, ph, phv, phi, pd;
     long long NU = 0, NC = 0, NH = 0, NHV = 0, NHI = 0, ND = 0;
@@ -135,6 +197,7 @@ struct StreamBuilder {
     int npartial0 = 0;
     // EMIT
     std::vector<uint4> h_udesc;
+    std::vector<uint2> h_urow;            // pooled plans: row nibbles of every unit
     val_t *h_uval = nullptr, *h_cval = nullptr, *h_hval = nullptr, *h_dval = nullptr;
     unsigned char *h_hidx = nullptr;
     std::vector<int> h_ccol, h_dcb;
@@ -179,13 +242,35 @@ struct StreamBuilder {
 
 void StreamBuilder::count()
 {
-    csr_split = K.csr_split != 0;
     target_in = K.strip_cost; split_above_in = K.split_above;
     tilem = T->tilem; tilen = T->tilen; ntr = std::max(0, tr1 - tr0); sv = (int)sizeof(val_t);
-    rc_.assign((size_t)ntr, RowCount{0, 0, 0, 0, 0, 0, 0});
-    parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
-        for (int64_t i = b; i < e; i++) rc_[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, csr_split, K.coo_cost);
-    });
+    // ---- what CSR tiles become: 0 whole tiles in their own pass, 1 ELL-style split (w padded units + list entries), 2 pooled units (hip_plan.h), unset: 1 or 2 by the bytes
+    // the two forms put into the streams.  Both are counted (a shard without CSR tiles is not: nothing to choose); the pooled form is taken when its streams are at least
+    // 5 % smaller than the split form's WITH 4-byte dictionary descriptors (whether the dictionary applies is only known once the units exist: the split form gets the benefit
+    // of the doubt, so stencil-like shards with a few CSR tiles — KKT, unaligned grids — keep their 4-byte descriptors).
+    csr_form = K.csr_split < 0 ? 1 : std::min(K.csr_split, 2);
+    const int t_begin = T->tile_ptr[tr0], t_end = T->tile_ptr[tr1];
+    auto count_all = [&](int form, std::vector<RowCount> &out) {
+        out.assign((size_t)ntr, RowCount{0, 0, 0, 0, 0, 0, 0});
+        parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
+            std::vector<PoolEnt> scratch;
+            for (int64_t i = b; i < e; i++) out[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, form, K.coo_cost, hyb_off, scratch);
+        });
+    };
+    count_all(csr_form, rc_);
+    if (K.csr_split < 0 && (long long)T->csr_offset[t_end] - T->csr_offset[t_begin] > 0) {
+        std::vector<RowCount> alt;
+        count_all(2, alt);
+        long long u1 = 0, e1 = 0, u2 = 0, e2 = 0;
+        for (int i = 0; i < ntr; i++) { u1 += rc_[i].nunits; e1 += rc_[i].ncoo; u2 += alt[i].nunits; e2 += alt[i].ncoo; }
+        const long long split_b = u1 * (4 + 16LL * sv) + e1 * (sv + 5LL), pooled_b = u2 * (20 + 16LL * sv) + e2 * (sv + 5LL);
+        // ... and only where units carry the shard: an entry-dominated shard (power-law, scattered) lives in its entry lists, whose launch forms (512-thread workgroups,
+        // column panels / slices, pacing) exist for the classic kernel only
+        if (pooled_b * 100 <= split_b * 95 && 16 * u2 >= e2) { rc_.swap(alt); csr_form = 2; }
+        if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: CSR tiles: split form %lld units + %lld entries = %.1f MB, pooled form %lld units + %lld entries = %.1f MB -> %s\n",
+                                                     u1, e1, split_b / 1e6, u2, e2, pooled_b / 1e6, csr_form == 2 ? "pooled" : "split");
+    }
+    csr_split = csr_form != 0; pooled = csr_form == 2;
     for (std::vector<long long> *p : {&pu, &pc, &ph, &phv, &phi, &pd}) p->assign((size_t)ntr + 1, 0);
     for (int i = 0; i < ntr; i++) pd[i + 1] = pd[i] + rc_[i].ndense;
     ND = pd[ntr];
@@ -196,7 +281,7 @@ void StreamBuilder::count()
     NU = pu[ntr]; NC = pc[ntr]; NH = ph[ntr]; NHV = phv[ntr]; NHI = phi[ntr];
     if (tilen > (1 << UNIT_FLAG_SHIFT)) { fprintf(stderr, "tilespmv: more than 2^24 column blocks: use TILESPMV_KERNEL=1\n"); rc = -2; return; }
     if (NU > INT32_MAX || NC > INT32_MAX || NH > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit unit ids\n"); rc = -2; return; }
-    if (hashing()) { Hash h; h.vec(rc_); for (long long v : {NU, NC, NH, NHV, NHI, ND}) h.num(v); stage_done(TILESPMV_STAGE_COUNT_ROWS, h); }
+    if (hashing()) { Hash h; h.vec(rc_); for (long long v : {NU, NC, NH, NHV, NHI, ND, (long long)csr_form}) h.num(v); stage_done(TILESPMV_STAGE_COUNT_ROWS, h); }
 }
 
 void StreamBuilder::choose()
@@ -249,7 +334,7 @@ void StreamBuilder::choose()
     // strips per workgroup: 32 (512 threads) only on request and only with the workgroup entry mode — twice as many tile-rows share
     // one column-ordered list (power-law 8 M rows: 0.204 -> 0.152 distinct 128-B x lines per entry) at the same 6 waves per SIMD, but
     // it measures slower everywhere (power-law 8 M 0.1038 -> 0.1072 ms, webbase-like 13.1 -> 13.9 us, KKT fp64 equal): default 16
-    wg_strips = (entry_mode == 2 && K.wg_strips == 32) ? 32 : 16;
+    wg_strips = (entry_mode == 2 && K.wg_strips == 32 && !pooled) ? 32 : 16;   // (pooled plans: 256-thread workgroups only)
     plan->wg_strips = wg_strips;
     // Workgroup mode: the four wavefronts add into shared slabs.  Taking turns (4 barriers per trip) fixes the order of the
     // additions -> bit-reproducible sums; free or a gain on large grids (fewer LDS conflicts: power-law 8 M rows 0.122 ->
@@ -270,9 +355,9 @@ void StreamBuilder::choose()
     brick = K.x_window != 0 && wg_strips == 16 && (K.x_window > 0 || est_wgs >= 2048);
     if (brick && xs1 == 0) detect_strides(T, tr0, tr1, csr_split, dense_mfma, &xs1, &xs2);
     if (xs1 < 2 || (K.x_window < 0 && xs2 == 0)) brick = false;   // (2-D grids: measured neutral on the 5-point 4096^2 case)
-    xwin = brick && K.x_window == 1 && entry_mode != 1;   // (the windowed kernel exists for entry modes 0 and 2)
+    xwin = brick && K.x_window == 1 && entry_mode != 1 && !pooled;   // (the windowed kernel exists for entry modes 0 and 2, and for classic units)
     // (strips of at most 4 tile-rows in brick plans: nlpkkt160 stand-in fp64 0.418 -> 0.414 ms, fp32 0.252 -> 0.250 in one process; 2 rows: KKT 0.408 but 7-pt 256^3 +5 %)
-    max_strip_rows = xwin ? XWIN_STRIP_ROWS : brick ? (K.brick_rows > 0 ? std::min(K.brick_rows, STRIP_MAX_ROWS) : 4) : STRIP_MAX_ROWS;
+    max_strip_rows = xwin ? XWIN_STRIP_ROWS : pooled ? POOL_STRIP_ROWS : brick ? (K.brick_rows > 0 ? std::min(K.brick_rows, STRIP_MAX_ROWS) : 4) : STRIP_MAX_ROWS;
     if (brick && !K.xcd_from_caller) plan->xcd_chunk = 8;   // bricks are compact: smaller XCD windows keep an XCD's resident set together
     // ---- slab pacing of the workgroup entry mode (hip_plan.h DevStream::pace): worth it where scattered gathers miss the XCD's L2 — x clearly larger than
     // an L2 — on shards that fill the chip (the teams are what one XCD holds at one time) with enough entries to pay for the bookkeeping
@@ -282,7 +367,7 @@ void StreamBuilder::choose()
         // Opt-in only (pace = 1).  Measured in round 4 (profiles/r04_slab_pacing.txt): a team keeps to a timetable only at >= 3 us per slab — every slab
         // opens with all the team's wavefronts missing on its lines at once — and the teams of one XCD run one after the other, so no timetable beat the unpaced launch
         // on band + random fill (2 M rows), uniform random (8 M), R-MAT (scale 22) or the power-law case; the calibration dropped every one of them.
-        pace_on = entry_mode == 2 && wg_strips == 16 && !xwin && K.pace > 0;
+        pace_on = entry_mode == 2 && wg_strips == 16 && !xwin && !pooled && K.pace > 0;
         if (pace_on) {
             long long cols_per_slab = std::max<long long>(256, (long long)std::max(1, K.pace_slab_kb) * 1024 / sv);
             pace_shift = 0;
@@ -300,7 +385,7 @@ void StreamBuilder::choose()
         // decided by timing (plan_create_one) — it does on uniform-random-like shards (8 M rows: 1.00 -> 0.80 ms) and does not where most entries sit near the diagonal
         const int kb = K.x_panel_kb >= 0 ? K.x_panel_kb : ((entry_dominated && x_bytes >= (12ll << 20)) ? 2048 : 0);
         x_panels = 1; panel_shift = 0;
-        if (kb > 0 && entry_mode == 2 && wg_strips == 16 && !xwin && !pace_on && x_bytes > 1024LL * kb) {
+        if (kb > 0 && entry_mode == 2 && wg_strips == 16 && !xwin && !pooled && !pace_on && x_bytes > 1024LL * kb) {   // (the panel / slice kernels add into 8-row slabs: classic plans)
             long long cols = std::max<long long>(1024, 1024LL * kb / sv);
             while ((2ll << panel_shift) <= cols) panel_shift++;
             while ((((long long)colA - 1) >> panel_shift) + 1 > 64) panel_shift++;     // at most 64 passes
@@ -434,6 +519,7 @@ void StreamBuilder::emit()
 {
     // ---- fill
     h_udesc.assign((size_t)NU, make_uint4(0u, 0u, 0u, 0u));
+    h_urow.assign(pooled ? (size_t)NU : 0, make_uint2(0x01234567u, 0x89ABCDEFu));   // (units that keep one row per lane: identity)
     h_uval = zalloc<val_t>((size_t)NU * 16);
     h_cval = zalloc<val_t>((size_t)NC);
     h_ccol.assign((size_t)NC, 0);
@@ -444,14 +530,17 @@ void StreamBuilder::emit()
     h_dcb.assign((size_t)ND, 0);
     h_dval = zalloc<val_t>((size_t)ND * 256);
     parallel_chunks(ntr, 256, [&](int64_t b, int64_t e, int) {
+        std::vector<PoolEnt> pool;
         for (int64_t i = b; i < e; i++) {
             const int bi = tr0 + (int)i, rowlen = tile_rowlen(bi, tilem, rowA);
             const unsigned kr = row_k[i];
             long long u = pu[i], c = pc[i], h = ph[i], hv = phv[i], hi = phi[i], dq = pd[i];
+            // word 0 of a unit of column block cb: classic = column block | flags << 24; pooled = first column of the window | tile-row in strip << 28
+            auto unit_w0 = [&](int cb, unsigned flags) { return pooled ? (((unsigned)cb * 16u) | (kr << POOL_KR_SHIFT)) : ((unsigned)cb | (((kr << UNIT_ROW_SHIFT) | flags) << UNIT_FLAG_SHIFT)); };
             auto put_unit = [&](int cb, const val_t *src, int stride_ok_rows, unsigned long long nibs) {
                 // src: rowlen consecutive values of this column; nibs: 16 nibbles, row 0 in the top nibble
                 for (int r = 0; r < stride_ok_rows; r++) h_uval[u * 16 + r] = src[r];
-                const unsigned w0 = (unsigned)cb | ((kr << UNIT_ROW_SHIFT) << UNIT_FLAG_SHIFT);
+                const unsigned w0 = unit_w0(cb, 0u);
                 h_udesc[(size_t)u] = make_uint4(w0, (unsigned)(nibs >> 32), w0, (unsigned)(nibs & 0xffffffffull));
                 u++;
             };
@@ -476,7 +565,7 @@ void StreamBuilder::emit()
                         for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib(src, s * rowlen + r) << (60 - 4 * r);
                         put_unit(cb, T->Blockhyb_Val + off + s * rowlen, rowlen, nibs);
                     }
-                    if (coo_in_tile)
+                    if (coo_in_tile && !pooled)
                         for (int q = 0; q < stored - nell; q++) {
                             const unsigned char rcb = src[(nell + 1) / 2 + q];
                             h_cval[c] = T->Blockhyb_Val[off + nell + q]; h_ccol[(size_t)c] = cb * 16 + (rcb & 15);
@@ -490,7 +579,7 @@ void StreamBuilder::emit()
                     break;
                 }
                 case TILESPMV_FMT_COO:
-                    if (coo_in_tile) {
+                    if (coo_in_tile && !pooled) {
                         const int off = T->coo_offset[t];
                         for (int q = 0; q < stored; q++) {
                             const unsigned char rcb = T->coo_compressed_Idx[off + q];
@@ -518,14 +607,18 @@ void StreamBuilder::emit()
                     const int off = T->dnsrow_offset[t], ro = T->dnsrowptr[t], k = T->dnsrowptr[t + 1] - ro;
                     for (int q = 0; q < k; q++) {
                         for (int cc = 0; cc < collen; cc++) h_uval[u * 16 + cc] = T->Blockdenserow_Val[off + q * collen + cc];
-                        const unsigned w0 = (unsigned)cb | (((kr << UNIT_ROW_SHIFT) | UNIT_ROWUNIT) << UNIT_FLAG_SHIFT);
+                        const unsigned w0 = unit_w0(cb, UNIT_ROWUNIT);
                         const unsigned rid = (unsigned)(T->denserowid[ro + q] & 15);
-                        h_udesc[(size_t)u] = make_uint4(w0, rid, w0, rid);
+                        if (pooled) {   // slot s = column s of the dense row: identity column nibbles, one row nibble
+                            h_udesc[(size_t)u] = make_uint4(w0, 0x01234567u, w0, 0x89ABCDEFu);
+                            h_urow[(size_t)u] = make_uint2(0x11111111u * rid, 0x11111111u * rid);
+                        } else h_udesc[(size_t)u] = make_uint4(w0, rid, w0, rid);
                         u++;
                     }
                     break;
                 }
                 case TILESPMV_FMT_CSR:
+                    if (pooled) break;   // (with the tile-row's other pooled nonzeros, below)
                     if (csr_split) {
                         const int off = T->csr_offset[t];
                         const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
@@ -563,13 +656,42 @@ void StreamBuilder::emit()
                 }
                 }
             }
-            if (!row_split[i] && u > pu[i]) { h_udesc[(size_t)u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; h_udesc[(size_t)u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
+            if (pooled) {   // the pooled nonzeros of the tile-row: windows of 16 columns -> units (slot s = s-th nonzero of the window), sparse windows -> list entries
+                pool_row(T, bi, rowlen, coo_in_tile, hyb_off, pool);
+                pool_windows((long long)pool.size(), [&](long long q) { return pool[(size_t)q].col; }, [&](long long wb, long long we) {
+                    if (we - wb >= POOL_MIN_FILL) {
+                        const unsigned base = pool[(size_t)wb].col;
+                        unsigned cn[2] = {0u, 0u}, rn[2] = {0u, 0u};
+                        // slots in ROW order (stable: columns ascending inside a row): the nonzeros of one row sit in neighbouring lanes, which is what the kernel's
+                        // two interleaved copies of the slab rely on — neighbouring lanes add into different copies, so two nonzeros of a row never meet in one LDS atomic
+                        int order[16], cnt[17] = {0};
+                        for (long long q = wb; q < we; q++) cnt[pool[(size_t)q].row + 1]++;
+                        for (int rr = 0; rr < 16; rr++) cnt[rr + 1] += cnt[rr];
+                        for (long long q = wb; q < we; q++) order[cnt[pool[(size_t)q].row]++] = (int)(q - wb);
+                        for (int sl = 0; sl < (int)(we - wb); sl++) {
+                            const PoolEnt &pe = pool[(size_t)(wb + order[sl])];
+                            h_uval[u * 16 + sl] = pe.val;
+                            cn[sl >> 3] |= (pe.col - base) << (28 - 4 * (sl & 7));
+                            rn[sl >> 3] |= pe.row << (28 - 4 * (sl & 7));
+                        }
+                        const unsigned w0 = base | (kr << POOL_KR_SHIFT);
+                        h_udesc[(size_t)u] = make_uint4(w0, cn[0], w0, cn[1]);
+                        h_urow[(size_t)u] = make_uint2(rn[0], rn[1]);   // (empty slots: value 0, column offset 0, row 0 — they add 0 * x[base] to row 0 of the tile-row)
+                        u++;
+                    } else
+                        for (long long q = wb; q < we; q++) {
+                            h_cval[c] = pool[(size_t)q].val; h_ccol[(size_t)c] = (int)pool[(size_t)q].col;
+                            h_crow[(size_t)c] = (unsigned char)((kr << 4) | pool[(size_t)q].row); c++;
+                        }
+                });
+            }
+            if (!pooled && !row_split[i] && u > pu[i]) { h_udesc[(size_t)u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; h_udesc[(size_t)u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
             if (h > ph[i]) h_hdesc[(size_t)h - 1].y |= DESC_EOR;
         }
     });
     if (hashing()) {
         Hash h;
-        h.vec(h_udesc); h.arr(h_uval, (size_t)NU * 16); h.arr(h_cval, (size_t)NC); h.vec(h_ccol); h.vec(h_crow); h.vec(h_hdesc); h.arr(h_hval, (size_t)NHV); h.arr(h_hidx, (size_t)NHI);
+        h.vec(h_udesc); h.vec(h_urow); h.arr(h_uval, (size_t)NU * 16); h.arr(h_cval, (size_t)NC); h.vec(h_ccol); h.vec(h_crow); h.vec(h_hdesc); h.arr(h_hval, (size_t)NHV); h.arr(h_hidx, (size_t)NHI);
         h.vec(h_dcb); h.arr(h_dval, (size_t)ND * 256);
         stage_done(TILESPMV_STAGE_EMIT, h);
     }
@@ -597,7 +719,7 @@ void StreamBuilder::order()
             }
         }
         auto blocks_of = [&](const STask &k, std::vector<int> &out) {
-            for (int u = k.unit_begin; u < k.unit_end; u++) out.push_back((int)(h_udesc[(size_t)u].x & 0xFFFFFFu));
+            for (int u = k.unit_begin; u < k.unit_end; u++) out.push_back(pooled ? (int)((h_udesc[(size_t)u].x & POOL_BASE_MASK) >> 4) : (int)(h_udesc[(size_t)u].x & 0xFFFFFFu));
         };
         struct Shape { int px, py, pz; };
         const Shape shapes3[] = {{1, 4, 4}, {2, 2, 4}, {2, 4, 2}, {4, 2, 2}, {1, 2, 8}, {1, 8, 2}, {4, 4, 1}, {2, 8, 1}, {1, 16, 1}, {16, 1, 1}};
@@ -667,7 +789,7 @@ void StreamBuilder::order()
     } else { xwin = false; brick = false; }
     plan->info[TILESPMV_INFO_BRICK_ORDER] = brick ? 1 : 0;
     plan->xwin_lds_bytes = xwin ? xwin_slots_max * 16 * (int)sizeof(val_t) : 0;
-    plan->size_hint = (size_t)(NU * (12 + 16LL * sv) + NC * (2LL * sv + 13) + NHV * sv + NHI + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);   // estimate of the plan's bytes: picks the block size of upload()
+    plan->size_hint = (size_t)(NU * (12 + (pooled ? 8 : 0) + 16LL * sv) + NC * (2LL * sv + 13) + NHV * sv + NHI + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);   // estimate of the plan's bytes: picks the block size of upload()
     if (hashing()) { Hash h; h.vec(tasks); h.vec(h_wg_win); h.vec(h_win_cb); h.num(brick); h.num(xwin); stage_done(TILESPMV_STAGE_ORDER, h); }
 }
 
@@ -690,6 +812,7 @@ void StreamBuilder::encode()
     }
     {
         std::vector<UDesc> packed((size_t)NUP, UDesc{0u, 0u, 0u});
+        std::vector<URow> packed_row(pooled ? (size_t)NUP : 0, URow{0u, 0u});
         val_t *paired = zalloc<val_t>((size_t)NUP * 16);
         std::vector<long long> new_begin(tasks.size());
         old_begin.assign(tasks.size(), 0);
@@ -703,6 +826,7 @@ void StreamBuilder::encode()
                 for (long long j = 0; j < n; j++) {
                     const uint4 d = h_udesc[(size_t)(ub + j)];
                     packed[(size_t)(nb + j)] = UDesc{d.x, d.y, d.w};
+                    if (pooled) packed_row[(size_t)(nb + j)] = URow{h_urow[(size_t)(ub + j)].x, h_urow[(size_t)(ub + j)].y};
                     const val_t *src = h_uval + (ub + j) * 16;
                     val_t *dst = paired + (nb + j / G * G) * 16 + (j % G);
                     for (int r = 0; r < 16; r++) dst[G * r] = src[r];
@@ -719,7 +843,7 @@ void StreamBuilder::encode()
         // ... and only where it pays: 8 bytes per unit must be at least 2 % of the streams (an entry-dominated plan with a handful of units would only buy the dictionary
         // hop at the start of every strip: webbase-1M stand-in 13.2 -> 13.6 us); desc_dict = 1 asks for it wherever it is possible
         const bool dict_pays = K.desc_dict > 0 ? true : 8LL * NUP * 50 >= NUP * (12 + 16LL * sv) + NC * (sv + 4LL);
-        if (K.desc_dict != 0 && dict_pays && !xwin && NUP > 0) {
+        if (K.desc_dict != 0 && dict_pays && !xwin && !pooled && NUP > 0) {
             const int cb_bits = std::max(1, 32 - __builtin_clz((unsigned)std::max(1, T->tilen - 1)));
             const int pid_bits = std::min(DICT_MAX_BITS, 27 - cb_bits);
             if (pid_bits >= 1) {
@@ -761,7 +885,9 @@ void StreamBuilder::encode()
             rc |= plan->upload(compact.data(), compact.size(), reinterpret_cast<const unsigned **>(&S.udesc));
             rc |= plan->upload(dict.data(), dict.size(), &S.udict);
         } else rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc);
-        plan->info[TILESPMV_INFO_DESC_BYTES] = S.cb_bits > 0 ? 4 : 12;
+        plan->info[TILESPMV_INFO_DESC_BYTES] = S.cb_bits > 0 ? 4 : pooled ? 20 : 12;
+        S.urow = nullptr; S.pooled = pooled ? 1 : 0;
+        if (pooled) rc |= plan->upload(packed_row.data(), (size_t)NUP, &S.urow);
         rc |= plan->upload(paired, (size_t)NUP * 16, &S.uval);
         free(paired);
         S.udesc_cb = S.udesc;
@@ -781,7 +907,7 @@ void StreamBuilder::encode()
             rc |= plan->upload(h_win_cb.data(), h_win_cb.size(), &S.win_cb);
         } else { S.wg_win = nullptr; S.win_cb = nullptr; }
     }
-    if (hashing()) { Hash h; h.num((long long)(plan->digest ^ d0)); h.num(NUP); h.num(S.cb_bits); stage_done(TILESPMV_STAGE_ENCODE, h); }   // (everything this stage produces is uploaded: the running upload digest covers it)
+    if (hashing()) { Hash h; h.num((long long)(plan->digest ^ d0)); h.num(NUP); h.num(S.cb_bits); h.num(S.pooled); stage_done(TILESPMV_STAGE_ENCODE, h); }   // (everything this stage produces is uploaded: the running upload digest covers it)
 }
 
 void StreamBuilder::entries()
@@ -791,7 +917,7 @@ void StreamBuilder::entries()
     n_rec = 0; n_chunk = 0; n_groups = 0;
     if (entry_mode != 0) {
         const size_t GS = entry_mode == 2 ? (size_t)wg_strips : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
-        const int slab_shift = xwin ? 6 : 7;   // a strip's slab of s_y: XWIN_STRIP_ROWS x 16 values in x-window plans, STRIP_MAX_ROWS x 16 otherwise
+        const int slab_shift = (xwin || pooled) ? 6 : 7;   // a strip's slab of s_y: XWIN_STRIP_ROWS / POOL_STRIP_ROWS x 16 values in x-window and pooled plans, STRIP_MAX_ROWS x 16 otherwise
         const int dest_bits = entry_mode == 2 ? (wg_strips == 32 ? 12 : 4 + slab_shift) : 9;   // strip-in-group | row-in-strip | row (4)
         S.dest_bits = dest_bits;
         const size_t nwg = (tasks.size() + GS - 1) / GS;
@@ -970,13 +1096,15 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     // 7-pt 256^3 0.2533 -> 0.2432, power-law 8 M 0.1078 -> 0.1043 — plain where it is a few per cent: there the streaming form buys nothing and makes the time
     // depend on where the CALLER's y happens to sit (nlpkkt160 stand-in fp64: 0.413 or 0.459 ms by the copy of y; plain: 0.408-0.411 with every copy)
     {
-        const long long stream_b = NU * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + NC * (sv + 4LL), y_b = 16LL * ntr * sv;
+        const long long stream_b = NU * ((S.cb_bits > 0 ? 4 : pooled ? 20 : 12) + 16LL * sv) + NC * (sv + 4LL), y_b = 16LL * ntr * sv;
         S.y_streaming = K.y_store >= 0 ? (K.y_store != 0) : (y_b * 20 >= stream_b);   // >= 5 %
     }
     plan->info[TILESPMV_INFO_ENTRY_MODE] = entry_mode;
     plan->info[TILESPMV_INFO_ENTRY_ORDERED] = (entry_mode != 2 || coo_ordered) ? 1 : 0;
     plan->info[TILESPMV_INFO_STRIP_COST] = target;
     plan->info[TILESPMV_INFO_WG_STRIPS] = wg_strips;
+    plan->info[TILESPMV_INFO_CSR_FORM] = csr_form;
+    plan->pooled = pooled;
     plan->info[TILESPMV_INFO_X_WINDOW_SLOTS] = xwin ? xwin_slots_max : 0;
     plan->info[TILESPMV_INFO_X_WINDOW_SEGMENTS] = xwin ? xwin_segments : 0;
     {   // entry slab of the multi-vector kernel: shards with >= 3 entries per tile-row (strips then regularly hold more than the 16 entries that travel with the prologue)
@@ -987,7 +1115,7 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     }
     plan->mv_by_columns = entry_dominated && target >= 800;   // (small strips hold few entries each: scircuit-like 18 / 22 / 32 us native against 22 / 41 / 78 us)
     n_tasks = (long long)tasks.size();
-    model_bytes = NUP * ((S.cb_bits > 0 ? 4 : 12) + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
+    model_bytes = NUP * ((S.cb_bits > 0 ? 4 : pooled ? 20 : 12) + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
                   ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
     // The once-read streams (values, entry records) are loaded nontemporally when the launch moves clearly more than the Infinity Cache holds: they then do

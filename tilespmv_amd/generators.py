@@ -310,6 +310,90 @@ def kkt_like(g, seed=5):
     return 2 * n, 2 * n, rowptr.astype(np.int32), Cc.astype(np.int32)
 
 
+def _fem_node_order(nn, shuffle, seed):
+    """new index of every node: identity, or a random permutation inside consecutive windows of ``shuffle`` nodes."""
+    if not shuffle or shuffle <= 1:
+        return None
+    rng = np.random.default_rng(seed)
+    win = np.arange(nn, dtype=np.int64) // shuffle
+    order = np.lexsort((rng.random(nn), win))      # inside a window: by random key
+    new_of_old = np.empty(nn, dtype=np.int64)
+    new_of_old[order] = np.arange(nn, dtype=np.int64)   # (windows are contiguous ranges, so positions stay inside the window)
+    return new_of_old
+
+
+def fem_hex(nx, ny, nz, dof, shuffle=0, seed=11, rows=None, rowptr_only=False):
+    """Structural-FEM-like matrix (the largest class among the >= 10 M-nnz matrices of the reference's sweep list,
+    src/external/CSR5_cuda/2757-matrix.csv: audikw_1 :1252, ldoor :1268, bone010 :1453, Flan_1565 :2544 ...): trilinear hexahedra
+    on an nx x ny x nz grid of nodes, ``dof`` unknowns per node, every node coupled to its 27-point neighbourhood with a
+    full dof x dof block — 81 (dof 3) / 162 (dof 6) nonzeros in an interior row, columns ascending.  Natural (x fastest)
+    node order, or, with ``shuffle`` = w, nodes renumbered at random inside windows of w consecutive nodes (a mediocre
+    ordering: locality kept at the scale of the window, none inside it).  ``rows=(r0, r1)``: only that row block (global
+    columns, row pointer rebased); ``rowptr_only``: the int64 row pointer alone."""
+    nn = nx * ny * nz
+    N = nn * dof
+    new_of_old = _fem_node_order(nn, shuffle, seed)
+    if new_of_old is None:
+        old_of_new = None
+    else:
+        old_of_new = np.empty(nn, dtype=np.int64)
+        old_of_new[new_of_old] = np.arange(nn, dtype=np.int64)
+    offs = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+
+    def node_nb(nodes_new):
+        """(len, 27) neighbour nodes (new numbering, ascending, invalid = nn at the end) of the given nodes (new numbering)."""
+        old = nodes_new if old_of_new is None else old_of_new[nodes_new]
+        z, y, x = old // (nx * ny), (old // nx) % ny, old % nx
+        nb = np.empty((len(old), 27), dtype=np.int64)
+        for k, (dz, dy, dx) in enumerate(offs):
+            ok = (z + dz >= 0) & (z + dz < nz) & (y + dy >= 0) & (y + dy < ny) & (x + dx >= 0) & (x + dx < nx)
+            q = old + (dz * ny + dy) * nx + dx
+            if new_of_old is not None:
+                q = new_of_old[np.where(ok, q, 0)]
+            nb[:, k] = np.where(ok, q, nn)
+        if new_of_old is not None:
+            nb.sort(axis=1)
+        return nb
+
+    if rowptr_only:
+        idx = np.arange(nn, dtype=np.int64)
+        old = idx if old_of_new is None else old_of_new
+        z, y, x = old // (nx * ny), (old // nx) % ny, old % nx
+        cnt = (3 - (x == 0) - (x == nx - 1)) * (3 - (y == 0) - (y == ny - 1)) * (3 - (z == 0) - (z == nz - 1))
+        rp = np.zeros(N + 1, dtype=np.int64)
+        np.cumsum(np.repeat(cnt * dof, dof), out=rp[1:])
+        return rp
+    r0, r1 = (0, N) if rows is None else (int(rows[0]), int(rows[1]))
+    n0, n1 = r0 // dof, (r1 + dof - 1) // dof
+    nb = node_nb(np.arange(n0, n1, dtype=np.int64))
+    valid = nb < nn
+    cols_node = (nb[:, :, None] * dof + np.arange(dof, dtype=np.int64)[None, None, :]).reshape(len(nb), 27 * dof)
+    mask_node = np.repeat(valid, dof, axis=1)
+    del nb, valid
+    # the dof rows of a node share its column list
+    rsel = np.arange(r0, r1, dtype=np.int64) // dof - n0
+    counts = mask_node.sum(axis=1, dtype=np.int64)[rsel]
+    rowptr = np.zeros(r1 - r0 + 1, dtype=np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    assert rowptr[-1] < 2**31
+    if r0 % dof == 0 and r1 % dof == 0:
+        # whole nodes: repeat every node's compacted column list dof times without materialising the (rows, 27 dof) candidate array
+        flat = cols_node[mask_node].astype(np.int32)
+        per_node = mask_node.sum(axis=1, dtype=np.int64)
+        starts = np.zeros(len(per_node) + 1, dtype=np.int64)
+        np.cumsum(per_node, out=starts[1:])
+        del cols_node, mask_node
+        colidx = np.empty(int(rowptr[-1]), dtype=np.int32)
+        # rows d, d + dof, ... of the block take the node lists in order: row-major positions rowptr[d::dof]
+        for d in range(dof):
+            dst = rowptr[d:-1:dof]
+            idx = np.repeat(dst - starts[:-1], per_node) + np.arange(len(flat), dtype=np.int64)
+            colidx[idx] = flat
+        return N, N, rowptr.astype(np.int32), colidx
+    colidx = cols_node[rsel][mask_node[rsel]].astype(np.int32)
+    return N, N, rowptr.astype(np.int32), colidx
+
+
 NLPKKT160_ROWS, NLPKKT160_NNZ = 8345600, 229518112   # reference src/external/CSR5_cuda/2757-matrix.csv:1903
 
 
