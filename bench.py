@@ -52,6 +52,9 @@ def build_matrix(name, cache_dir=None):
         return G.laplacian7pt(int(name[5:])) + ("synthetic 7-pt Laplacian on a cube",)
     if name.startswith("powerlaw"):
         return G.powerlaw(int(name[8:]), seed=2) + ("synthetic power-law",)
+    if name.startswith("shell"):   # shell<dof>[s<window>]_<n>: 9-point quadrilateral mesh on n^2 nodes (a shell model: af_shell-like)
+        dof, win, nn = parse_fem("fem" + name[5:])
+        return G.fem_hex(nn, nn, 1, dof, shuffle=win) + ("synthetic shell-like: 9-point quad mesh %d^2 nodes x %d dof%s" % (nn, dof, ", nodes shuffled in windows of %d" % win if win else ", natural order"),)
     if name.startswith("fem"):   # fem<dof>[s<window>]_<n>: 27-point hexahedral mesh on n^3 nodes, <dof> unknowns per node (natural order, or nodes shuffled inside windows)
         dof, win, nn = parse_fem(name)
         return G.fem_hex(nn, nn, nn, dof, shuffle=win) + ("synthetic FEM-like: 27-point hex mesh %d^3 nodes x %d dof%s" % (nn, dof, ", nodes shuffled in windows of %d" % win if win else ", natural order"),)
@@ -59,6 +62,16 @@ def build_matrix(name, cache_dir=None):
         return G.circuit_like(int(name[7:]), seed=1) + ("synthetic circuit-like",)
     if name.startswith("laplacian"):
         return G.laplacian5pt(int(name[len("laplacian"):])) + ("synthetic 5-pt Laplacian",)
+    # meshes of the population sweep (round 5): tri<n>[s<w>] 2-D triangulation on n^2 nodes, tet<n>[s<w>] 3-D tetrahedral mesh on n^3 nodes, road<n>[s<w>] road-network-like
+    # grid graph on n^2 junctions — natural order, or nodes shuffled inside windows of w; plaw<alpha x 10>_<rows>: power-law with another exponent
+    for pre, gen, what in (("tri", lambda k, w: G.tri_mesh(k, k, shuffle=w), "2-D triangulation %d^2 nodes"), ("tet", lambda k, w: G.tet_mesh(k, shuffle=w), "3-D tetrahedral mesh %d^3 nodes"),
+                           ("road", lambda k, w: G.road_like(k, k, shuffle=w), "road-network-like grid graph %d^2 junctions")):
+        if name.startswith(pre) and name[len(pre):len(pre) + 1].isdigit():
+            k, _, w = name[len(pre):].partition("s")
+            return gen(int(k), int(w or 0)) + ("synthetic " + what % int(k) + (", nodes shuffled in windows of %s" % w if w else ", natural order"),)
+    if name.startswith("plaw"):
+        a, nn = name[4:].split("_")
+        return G.powerlaw(int(nn), seed=2, alpha=int(a) / 10.0) + ("synthetic power-law, exponent %.1f" % (int(a) / 10.0),)
     # the HBM-resident irregular / mixed class: bandrand<hbw>x<extra>_<rows>, uniform<per_row>_<rows>[x<cols>], rmat<scale>x<edge factor>
     if name.startswith("bandrand"):
         a, nn = name[8:].split("_"); hbw, extra = a.split("x")
@@ -764,6 +777,38 @@ def main():
                 out["other_workloads"][key] = {"error": repr(e)}
         built.clear()
         out["other_workloads_seconds"] = round(time.time() - t_extras, 1)
+        # ---- the population (round 5): the committed sweep of 26 generated structures >= 10 M nnz in the class mix of the reference's >= 10 M-nnz matrices
+        # (scripts/population_sweep.py -> profiles/r05_population.json: its summary is quoted here), and six of them measured LIVE in this run with the same routine
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import population_sweep as PS
+            pop = {"what": "default plans over a population of generated structures (reference's method is a sweep: src/external/CSR5_cuda/bench0.sh:1-14); frac = B_alg / t / 8 TB/s"}
+            pj = os.path.join(ROOT, "profiles", "r05_population.json")
+            if os.path.exists(pj):
+                pjd = json.load(open(pj))
+                pop["committed_sweep"] = dict(pjd["summary"], file=os.path.relpath(pj, ROOT), measured=pjd.get("measured"), live=False)
+            t_pop = time.time()
+            live = {}
+            for key, wl, klass in PS.POPULATION:
+                if key in PS.LIVE_SUBSET:
+                    try:
+                        r = PS.measure(key, wl, klass, f64_, torch, api, G, build_matrix, reps=30)
+                        live[key] = {k: r[k] for k in ("class", "rows", "nnz", "ms_per_spmv", "frac", "frac_min_bytes", "plan_over_irreducible_bytes", "check_whole_y_exact", "plan_create_seconds", "timed_choices_ms",
+                                                     "tile_create_seconds", "tile_format_histogram[csr,coo,ell,hyb,dns,dnsrow,dnscol]")}
+                        live[key]["csr_form"] = r["plan"]["csr_form"]; live[key]["entry_mode"] = r["plan"]["entry_mode"]
+                    except Exception as e:
+                        live[key] = {"error": repr(e)}
+                    torch.cuda.empty_cache()
+            pop["live_subset"] = dict(live, seconds=round(time.time() - t_pop, 1))
+            # this run's own view of the whole line: the live subset + the large other_workloads + the headline
+            fr = [v["frac"] for v in live.values() if "frac" in v] + [v["default_plan"]["frac_of_8TBps"] for v in out["other_workloads"].values() if "default_plan" in v] + [round(achieved / HBM_PEAK_GBPS, 4)]
+            fm = [v["frac_min_bytes"] for v in live.values() if "frac_min_bytes" in v] + [v["default_plan"]["frac_min_bytes"] for v in out["other_workloads"].values() if "default_plan" in v] + [roofline["frac_min_bytes"]]
+            pop["this_run"] = {"count": len(fr), "frac_median": round(float(np.median(fr)), 4), "frac_min": min(fr), "share_frac_ge_0.70": round(sum(f >= 0.70 for f in fr) / len(fr), 3),
+                               "share_frac_min_bytes_ge_0.60": round(sum(f >= 0.60 for f in fm) / len(fm), 3),
+                               "note": "HBM-bound workloads measured live in this run: headline + large other_workloads + the live subset of the population"}
+            out["population"] = pop
+        except Exception as e:
+            out["population"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rows, n, rowptr, colidx, vals, x, dtype)
     elif rank == 0:

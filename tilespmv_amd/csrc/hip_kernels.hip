@@ -27,6 +27,33 @@
 
 #include "hip_plan.h"
 
+// Timing-only diagnostics (ablations whose results are wrong by construction, clock stamps, cache-policy probes) live in hip_kernels_diag.h, which only a diagnostic build
+// includes: `make VARIANT=_name EXTRA_DEFS=-D...` adds -DTILESPMV_DIAG and writes lib*_name.so; the Makefile refuses EXTRA_DEFS without VARIANT, so no stray define can
+// turn the product libraries into something that returns wrong rows.  In a product build every hook below expands to nothing.
+#if !defined(TILESPMV_DIAG) && (defined(TILESPMV_ABL) || defined(XCD_ABL) || defined(TILESPMV_STAMPS) || defined(TILESPMV_POOL_ABL) || defined(TILESPMV_ABL_LDS_PAD) || defined(TILESPMV_GATHER_POLICY))
+#error "diagnostic defines (TILESPMV_ABL, XCD_ABL, TILESPMV_STAMPS, TILESPMV_POOL_ABL, TILESPMV_ABL_LDS_PAD, TILESPMV_GATHER_POLICY) need -DTILESPMV_DIAG: build with make VARIANT=_name EXTRA_DEFS=..."
+#endif
+#ifdef TILESPMV_DIAG
+#include "hip_kernels_diag.h"
+#else
+#define TSPMV_DIAG_GATHER_X(p) (*(p))
+#define TSPMV_DIAG_TRIP_DECL
+#define TSPMV_DIAG_TRIP_RECORD(r, q, e0)
+#define TSPMV_DIAG_TRIP_GATHERS
+#define TSPMV_DIAG_TRIP_ADDS_REPLACED 0
+#define TSPMV_DIAG_TRIP_ADDS
+#define TSPMV_DIAG_UNITS_LDS_PAD
+#define TSPMV_DIAG_UNIT_GATHER_SKIP(k) false
+#define TSPMV_DIAG_POOL_ADD(dest, prod) false
+#define TSPMV_DIAG_XCD_ZERO 1
+#define TSPMV_DIAG_XCD_TRIP 1
+#define TSPMV_DIAG_XCD_SKIP_ADDS
+#define TSPMV_STAMP_DECL
+#define TSPMV_STAMP(i) do { } while (0)
+#define TSPMV_STAMP_WAIT(i) do { } while (0)
+#define TSPMV_STAMP_STORE
+#endif
+
 namespace tilespmv {
 
 // LDS scatter accumulators are fp64 in BOTH builds: on gfx950 a wavefront's ds_add_f32 takes about 170 cycles whatever the address
@@ -401,22 +428,7 @@ __device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t
 #endif
 // NTL: the records are read with nontemporal loads (plans whose streams do not fit the Infinity Cache: the once-read stream
 // then does not displace x in the L2s; DevStream::nt_stream).
-// Diagnostic builds (scripts/r4_gather_policy.sh): cache policy of the scattered x gathers of the workgroup entry phase — 0 default, 1 nontemporal, 2 agent scope (sc1), 3 system scope (sc0 sc1)
-#ifndef TILESPMV_GATHER_POLICY
-#define TILESPMV_GATHER_POLICY 0
-#endif
-__device__ __forceinline__ val_t gather_x(const val_t *p)
-{
-#if TILESPMV_GATHER_POLICY == 1
-    return __builtin_nontemporal_load(p);
-#elif TILESPMV_GATHER_POLICY == 2
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif TILESPMV_GATHER_POLICY == 3
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#else
-    return *p;
-#endif
-}
+__device__ __forceinline__ val_t gather_x(const val_t *p) { return TSPMV_DIAG_GATHER_X(p); }   // (diagnostic builds probe other cache policies here: hip_kernels_diag.h)
 
 template <int CT, int NT, bool NTL>
 __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, const unsigned *__restrict__ base, int chunk0, int db, bool ordered,
@@ -428,11 +440,7 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
     const unsigned dmask = (1u << db) - 1u;
     const int wave = tid >> 6;
     const int clast = chunk0 + ((ge - 1 - gb) >> 6);
-#ifdef TILESPMV_ABL
-    // Diagnostic builds only (scripts/ablate_entries.sh; results are wrong by construction, timing only):
-    //   1 no LDS adds   2 contiguous instead of gathered x   5 one extra 2-byte stream load per entry
-    val_t abl_acc = 0;
-#endif
+    TSPMV_DIAG_TRIP_DECL
     ERec rr[CT]; unsigned cb[CT];
     auto load_trip = [&](int e0, ERec (&r)[CT], unsigned (&c)[CT]) {   // unconditional, clamped: exact vmcnt
 #pragma unroll
@@ -444,9 +452,7 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
                 for (int z = 0; z < (int)(sizeof(ERec) / 4); z++) rw[z] = __builtin_nontemporal_load(pw + z);
             } else r[q] = rec[min(e0 + NT * q + tid, ge - 1)];
             c[q] = base[__builtin_amdgcn_readfirstlane(min(chunk0 + ((e0 - gb) >> 6) + (NT / 64) * q + wave, clast))];   // a wavefront's 64 records are one chunk
-#if defined(TILESPMV_ABL) && TILESPMV_ABL == 5
-            r[q].w += reinterpret_cast<const unsigned short *>(base)[min(e0 + NT * q + tid, ge - 1)] & 1u;
-#endif
+            TSPMV_DIAG_TRIP_RECORD(r, q, e0)
         }
     };
     if (e_first < ge) load_trip(e_first, rr, cb);
@@ -455,20 +461,13 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
         if (!WG_TRIP_PIPE && e0 > e_first) load_trip(e0, rr, cb);
 #pragma unroll
         for (int q = 0; q < CT; q++) xx[q] = gather_x(&x[(size_t)(cb[q] + (rr[q].w >> db))]);
-#if defined(TILESPMV_ABL) && TILESPMV_ABL == 2
-#pragma unroll
-        for (int q = 0; q < CT; q++) xx[q] = x[(e0 + NT * q + tid) & 0xFFFFF];
-#endif
+        TSPMV_DIAG_TRIP_GATHERS
         // the next trip's records go in flight behind this trip's gathers (loads return in issue order: the gathers are waited
         // for with the prefetch still outstanding); the last trip re-requests its own (clamped) records, which costs nothing
         ERec rn[CT]; unsigned cn[CT];
         if (WG_TRIP_PIPE) load_trip(min(e0 + NT * CT, gb + (ge - 1 - gb) / (NT * CT) * (NT * CT)), rn, cn);
-#if defined(TILESPMV_ABL) && TILESPMV_ABL == 1
-#pragma unroll
-        for (int q = 0; q < CT; q++) abl_acc += erec_val(rr[q]) * xx[q] + (val_t)(rr[q].w & dmask);
-        if (e0 + NT * CT >= ge) atomicAdd(&sy[tid], (lacc_t)abl_acc);
-#else
-        if (ordered) {
+        if constexpr (TSPMV_DIAG_TRIP_ADDS_REPLACED) { TSPMV_DIAG_TRIP_ADDS }
+        else if (ordered) {
             // the wavefronts add in turn: the order of the additions into one y element is then fixed by the plan (entry
             // order inside a wavefront instruction, instruction order inside a wavefront, wavefront 0..NT/64-1 inside a trip), not
             // by timing, and two launches give the same bits (the reference's atomicAdd, src/tilespmv_cuda.h:784-790, does not)
@@ -485,7 +484,6 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
             for (int q = 0; q < CT; q++)
                 if (e0 + NT * q + tid < ge && e0 + NT * q + tid >= gs) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
         }
-#endif
         if (WG_TRIP_PIPE) {
 #pragma unroll
             for (int q = 0; q < CT; q++) { rr[q] = rn[q]; cb[q] = cn[q]; }
@@ -621,18 +619,6 @@ hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream
     return hipGetLastError();
 }
 
-#ifdef TILESPMV_STAMPS
-// Diagnostic build (never the product): lane 0 of every wavefront records the shader clock at a few points of k_units; the
-// stamps go to a buffer of their own and no output depends on them.  Read the SHARES, not the length (the waits the stamps
-// force are not in the real kernel).
-#define TSPMV_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-        __builtin_amdgcn_sched_barrier(0); stamp_[i] = t_; } while (0)
-#define TSPMV_STAMP_WAIT(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TSPMV_STAMP(i); } while (0)
-#else
-#define TSPMV_STAMP(i) do { } while (0)
-#define TSPMV_STAMP_WAIT(i) do { } while (0)
-#endif
-
 // ECOO: how the COO entry lists are executed — 0 per 16-lane strip (regular matrices: a handful of entries per strip),
 // 1 per wavefront (the four strips' lists concatenated), 2 per workgroup (merged + column-ordered list, see above).
 // GPB: strips (16-lane groups) per workgroup — 16 (256 threads) or, for the workgroup entry mode on large entry-heavy shards, 32
@@ -675,10 +661,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     __shared__ uint2 s_r[POOL ? GROUPS_PER_BLOCK : 1][POOL ? DCHUNK : 1];   // pooled plans: row nibbles of the parked descriptor chunk
     val_t *s_xw = reinterpret_cast<val_t *>(s_dyn);   // [window slot][16]
-#ifdef TILESPMV_ABL_LDS_PAD   // diagnostic builds only: extra LDS per workgroup, to measure what fewer resident workgroups cost
-    __shared__ unsigned s_pad[TILESPMV_ABL_LDS_PAD / 4];
-    if (rowA < 0) s_pad[threadIdx.x] = 1u, y[0] = (val_t)s_pad[(threadIdx.x * 7) % (TILESPMV_ABL_LDS_PAD / 4)];
-#endif
+    TSPMV_DIAG_UNITS_LDS_PAD
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), each
     // with a private L2; XCD_REMAP = 2 gives every XCD runs of xcd_chunk consecutive workgroups inside
@@ -688,10 +671,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         const unsigned C = (unsigned)xcd_chunk, W = 8u * C, win = bid / W, off = bid % W, k = off & 7u;
         if ((win + 1) * W <= gridDim.x) bid = win * W + k * C + (off >> 3);
     }
-#ifdef TILESPMV_STAMPS
-    unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); stamp_[7] = rt_; }
-#endif
+    TSPMV_STAMP_DECL
     TSPMV_STAMP(0);
     const long long task_id = (long long)bid * GROUPS_PER_BLOCK + g;
     const bool have = task_id < S.ntasks;
@@ -787,9 +767,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             const unsigned fl = d[k].x >> 24;
             const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
             if (XWIN && wcount > 0) xv[k] = s_xw[(d[k].x & 0xFFFFFFu) * 16 + nib];   // workgroup-uniform: a windowed workgroup's descriptors hold slots
-#if defined(TILESPMV_ABL) && TILESPMV_ABL == 7   // timing only: a unit whose column block equals the previous unit's skips its gather (what sharing the x segment would save)
-            else if (k > 0 && ((d[k].x ^ d[k - 1].x) & 0xFFFFFFu) == 0) xv[k] = xv[k - 1];
-#endif
+            else if (TSPMV_DIAG_UNIT_GATHER_SKIP(k)) xv[k] = xv[k - 1];
             else xv[k] = x[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast)];
         }
     };
@@ -923,19 +901,8 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     // of the unit loop makes every later counted wait also wait for its write acknowledge.)
     auto retire = [&](val_t prod, unsigned flags, unsigned word1) {
         if constexpr (POOL) {   // flags = word 0 >> 24 (tile-row in strip in its top nibble), word1 = this lane's half of the row nibbles
-            unsigned dest = ((flags >> (POOL_KR_SHIFT - 24)) & 7u) * 16u + ((word1 >> (28 - 4 * (r & 7))) & 15u);
-#if defined(TILESPMV_POOL_ABL)   // diagnostic builds only (timing; results wrong by construction): 1 plain LDS store instead of the atomic add, 2 atomic add to a lane-private address (no two lanes of a unit share one), 3 no LDS operation at all
-#if TILESPMV_POOL_ABL == 2
-            dest = (dest & ~15u) | (unsigned)r;
-#endif
-#if TILESPMV_POOL_ABL == 1
-            (&s_y[g][0][0])[dest] = (lacc_t)prod;
-            return;
-#elif TILESPMV_POOL_ABL == 3
-            acc += prod;
-            return;
-#endif
-#endif
+            const unsigned dest = ((flags >> (POOL_KR_SHIFT - 24)) & 7u) * 16u + ((word1 >> (28 - 4 * (r & 7))) & 15u);
+            if (TSPMV_DIAG_POOL_ADD(dest, prod)) return;
             atomicAdd(&s_y[g][0][0] + dest, (lacc_t)prod);
             return;
         }
@@ -1084,14 +1051,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             }
         }
     }
-#ifdef TILESPMV_STAMPS
-    TSPMV_STAMP(5);            // stores issued
-    TSPMV_STAMP_WAIT(6);       // stores acknowledged
-    if (S.stamps && (tid & 63) == 0) {
-        unsigned long long *o = S.stamps + ((long long)blockIdx.x * 4 + (tid >> 6)) * 8;
-        for (int i = 0; i < 8; i++) o[i] = stamp_[i];
-    }
-#endif
+    TSPMV_STAMP_STORE
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1178,18 +1138,11 @@ __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_xcd(DevStream 
     }
     const bool side = t0.w > t0.z;
     const int row0 = t1.x, part = t1.y, nrows = t1.w;
-#if !(defined(XCD_ABL) && XCD_ABL == 2)   // diagnostic builds (timing only, results wrong): 1 no adds to y, 2 no zeroing of the slab, 3 neither and no trip at all (the skeleton: ranges, tasks, barriers)
-    for (int i = tid; i < GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16; i += 256) s_acc[i] = 0;
-#endif
+    if (TSPMV_DIAG_XCD_ZERO) for (int i = tid; i < GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16; i += 256) s_acc[i] = 0;
     __syncthreads();
-#if !(defined(XCD_ABL) && XCD_ABL == 3)
-    wg_entry_trips<CT, 256, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, false, x, s_acc, tid, wr.x, ge, gs);
-#endif
+    if (TSPMV_DIAG_XCD_TRIP) wg_entry_trips<CT, 256, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, false, x, s_acc, tid, wr.x, ge, gs);
     __syncthreads();
-#if defined(XCD_ABL) && (XCD_ABL == 1 || XCD_ABL == 3)
-    if (s_acc[tid] == (lacc_t)1.2345e300) y[0] = 1;
-    return;
-#endif
+    TSPMV_DIAG_XCD_SKIP_ADDS
     if (!side) return;
     const lacc_t *mine = s_acc + g * (STRIP_MAX_ROWS * 16);
     if (part >= 0) {

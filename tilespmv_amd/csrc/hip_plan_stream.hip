@@ -263,12 +263,34 @@ void StreamBuilder::count()
         count_all(2, alt);
         long long u1 = 0, e1 = 0, u2 = 0, e2 = 0;
         for (int i = 0; i < ntr; i++) { u1 += rc_[i].nunits; e1 += rc_[i].ncoo; u2 += alt[i].nunits; e2 += alt[i].ncoo; }
-        const long long split_b = u1 * (4 + 16LL * sv) + e1 * (sv + 5LL), pooled_b = u2 * (20 + 16LL * sv) + e2 * (sv + 5LL);
+        // would the split form get 4-byte dictionary descriptors?  Its units' column patterns on a sample of tiles (ELL slots exactly; of a CSR tile the pattern of its first
+        // unit: the first column nibble of every row): more than the dictionary holds on the sample -> 12-byte descriptors for certain
+        int desc_split = 4;
+        if (K.desc_dict == 0) desc_split = 12;
+        else {
+            std::unordered_set<unsigned long long> pats;
+            const int nt = t_end - t_begin, step = std::max(1, nt / 16384);
+            for (int t = t_begin; t < t_end && pats.size() <= ((size_t)1 << DICT_MAX_BITS); t += step) {
+                const int fmt = T->Format[t];
+                if (fmt == TILESPMV_FMT_ELL) {
+                    const int off = T->ell_offset[t], w = T->tilewidth[t];
+                    for (int sl = 0; sl < w; sl++) { unsigned long long nibs = 0; for (int r = 0; r < 16; r++) nibs |= (unsigned long long)nib(T->ell_compressedIdx, (long long)off + sl * 16 + r) << (60 - 4 * r); pats.insert(nibs); }
+                } else if (fmt == TILESPMV_FMT_CSR) {
+                    const int off = T->csr_offset[t], stored = T->blknnz[t + 1] - T->blknnz[t];
+                    const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
+                    unsigned long long nibs = 0;
+                    for (int r = 0; r < 16; r++) { const int k0 = ptr[r], k1 = r == 15 ? stored : ptr[r + 1]; if (k1 > k0) nibs |= (unsigned long long)nib(T->csr_compressedIdx, (long long)off + k0) << (60 - 4 * r); }
+                    pats.insert(nibs);
+                }
+            }
+            if (pats.size() > ((size_t)1 << DICT_MAX_BITS)) desc_split = 12;
+        }
+        const long long split_b = u1 * (desc_split + 16LL * sv) + e1 * (sv + 5LL), pooled_b = u2 * (20 + 16LL * sv) + e2 * (sv + 5LL);
         // ... and only where units carry the shard: an entry-dominated shard (power-law, scattered) lives in its entry lists, whose launch forms (512-thread workgroups,
         // column panels / slices, pacing) exist for the classic kernel only
         if (pooled_b * 100 <= split_b * 95 && 16 * u2 >= e2) { rc_.swap(alt); csr_form = 2; }
-        if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: CSR tiles: split form %lld units + %lld entries = %.1f MB, pooled form %lld units + %lld entries = %.1f MB -> %s\n",
-                                                     u1, e1, split_b / 1e6, u2, e2, pooled_b / 1e6, csr_form == 2 ? "pooled" : "split");
+        if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: CSR tiles: split form (%d-byte descriptors) %lld units + %lld entries = %.1f MB, pooled form %lld units + %lld entries = %.1f MB -> %s\n",
+                                                     desc_split, u1, e1, split_b / 1e6, u2, e2, pooled_b / 1e6, csr_form == 2 ? "pooled" : "split");
     }
     csr_split = csr_form != 0; pooled = csr_form == 2;
     for (std::vector<long long> *p : {&pu, &pc, &ph, &phv, &phi, &pd}) p->assign((size_t)ntr + 1, 0);

@@ -322,14 +322,11 @@ def _fem_node_order(nn, shuffle, seed):
     return new_of_old
 
 
-def fem_hex(nx, ny, nz, dof, shuffle=0, seed=11, rows=None, rowptr_only=False):
-    """Structural-FEM-like matrix (the largest class among the >= 10 M-nnz matrices of the reference's sweep list,
-    src/external/CSR5_cuda/2757-matrix.csv: audikw_1 :1252, ldoor :1268, bone010 :1453, Flan_1565 :2544 ...): trilinear hexahedra
-    on an nx x ny x nz grid of nodes, ``dof`` unknowns per node, every node coupled to its 27-point neighbourhood with a
-    full dof x dof block — 81 (dof 3) / 162 (dof 6) nonzeros in an interior row, columns ascending.  Natural (x fastest)
-    node order, or, with ``shuffle`` = w, nodes renumbered at random inside windows of w consecutive nodes (a mediocre
-    ordering: locality kept at the scale of the window, none inside it).  ``rows=(r0, r1)``: only that row block (global
-    columns, row pointer rebased); ``rowptr_only``: the int64 row pointer alone."""
+def mesh_matrix(nx, ny, nz, dof, offs, shuffle=0, seed=11, rows=None, rowptr_only=False):
+    """Sparsity of a mesh discretisation: nodes on an nx x ny x nz grid, ``dof`` unknowns per node, every node coupled to the nodes at the offsets ``offs`` (dz, dy, dx; the
+    node itself included if (0, 0, 0) is listed) with a full dof x dof block, columns ascending.  Natural (x fastest) node order, or, with ``shuffle`` = w, nodes renumbered
+    at random inside windows of w consecutive nodes (a mediocre ordering: locality kept at the scale of the window, none inside it).  ``rows=(r0, r1)``: only that row
+    block (global columns, row pointer rebased); ``rowptr_only``: the int64 row pointer alone."""
     nn = nx * ny * nz
     N = nn * dof
     new_of_old = _fem_node_order(nn, shuffle, seed)
@@ -338,13 +335,14 @@ def fem_hex(nx, ny, nz, dof, shuffle=0, seed=11, rows=None, rowptr_only=False):
     else:
         old_of_new = np.empty(nn, dtype=np.int64)
         old_of_new[new_of_old] = np.arange(nn, dtype=np.int64)
-    offs = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    offs = sorted(offs)
+    K = len(offs)
 
     def node_nb(nodes_new):
-        """(len, 27) neighbour nodes (new numbering, ascending, invalid = nn at the end) of the given nodes (new numbering)."""
+        """(len, K) neighbour nodes (new numbering, ascending, invalid = nn at the end) of the given nodes (new numbering)."""
         old = nodes_new if old_of_new is None else old_of_new[nodes_new]
         z, y, x = old // (nx * ny), (old // nx) % ny, old % nx
-        nb = np.empty((len(old), 27), dtype=np.int64)
+        nb = np.empty((len(old), K), dtype=np.int64)
         for k, (dz, dy, dx) in enumerate(offs):
             ok = (z + dz >= 0) & (z + dz < nz) & (y + dy >= 0) & (y + dy < ny) & (x + dx >= 0) & (x + dx < nx)
             q = old + (dz * ny + dy) * nx + dx
@@ -359,7 +357,9 @@ def fem_hex(nx, ny, nz, dof, shuffle=0, seed=11, rows=None, rowptr_only=False):
         idx = np.arange(nn, dtype=np.int64)
         old = idx if old_of_new is None else old_of_new
         z, y, x = old // (nx * ny), (old // nx) % ny, old % nx
-        cnt = (3 - (x == 0) - (x == nx - 1)) * (3 - (y == 0) - (y == ny - 1)) * (3 - (z == 0) - (z == nz - 1))
+        cnt = np.zeros(nn, dtype=np.int64)
+        for dz, dy, dx in offs:
+            cnt += (z + dz >= 0) & (z + dz < nz) & (y + dy >= 0) & (y + dy < ny) & (x + dx >= 0) & (x + dx < nx)
         rp = np.zeros(N + 1, dtype=np.int64)
         np.cumsum(np.repeat(cnt * dof, dof), out=rp[1:])
         return rp
@@ -367,7 +367,7 @@ def fem_hex(nx, ny, nz, dof, shuffle=0, seed=11, rows=None, rowptr_only=False):
     n0, n1 = r0 // dof, (r1 + dof - 1) // dof
     nb = node_nb(np.arange(n0, n1, dtype=np.int64))
     valid = nb < nn
-    cols_node = (nb[:, :, None] * dof + np.arange(dof, dtype=np.int64)[None, None, :]).reshape(len(nb), 27 * dof)
+    cols_node = (nb[:, :, None] * dof + np.arange(dof, dtype=np.int64)[None, None, :]).reshape(len(nb), K * dof)
     mask_node = np.repeat(valid, dof, axis=1)
     del nb, valid
     # the dof rows of a node share its column list
@@ -377,7 +377,7 @@ def fem_hex(nx, ny, nz, dof, shuffle=0, seed=11, rows=None, rowptr_only=False):
     np.cumsum(counts, out=rowptr[1:])
     assert rowptr[-1] < 2**31
     if r0 % dof == 0 and r1 % dof == 0:
-        # whole nodes: repeat every node's compacted column list dof times without materialising the (rows, 27 dof) candidate array
+        # whole nodes: repeat every node's compacted column list dof times without materialising the (rows, K dof) candidate array
         flat = cols_node[mask_node].astype(np.int32)
         per_node = mask_node.sum(axis=1, dtype=np.int64)
         starts = np.zeros(len(per_node) + 1, dtype=np.int64)
@@ -392,6 +392,45 @@ def fem_hex(nx, ny, nz, dof, shuffle=0, seed=11, rows=None, rowptr_only=False):
         return N, N, rowptr.astype(np.int32), colidx
     colidx = cols_node[rsel][mask_node[rsel]].astype(np.int32)
     return N, N, rowptr.astype(np.int32), colidx
+
+OFFS_27 = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+OFFS_9 = [(0, dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+OFFS_TRI7 = [(0, 0, 0), (0, 0, 1), (0, 0, -1), (0, 1, 0), (0, -1, 0), (0, 1, 1), (0, -1, -1)]                      # structured triangulation of the plane: 6 neighbours + the node
+OFFS_TET15 = sorted(set([(0, 0, 0)] + [s for a in ((0, 0, 1), (0, 1, 0), (1, 0, 0), (0, 1, 1), (1, 1, 0), (1, 0, 1), (1, 1, 1)) for s in (a, (-a[0], -a[1], -a[2]))]))   # Kuhn subdivision of the cubes: 14 neighbours + the node
+
+
+def fem_hex(nx, ny, nz, dof, shuffle=0, seed=11, rows=None, rowptr_only=False):
+    """Structural-FEM-like matrix (the largest class among the >= 10 M-nnz matrices of the reference's sweep list,
+    src/external/CSR5_cuda/2757-matrix.csv: audikw_1 :1252, ldoor :1268, bone010 :1453, Flan_1565 :2544 ...): trilinear hexahedra
+    on an nx x ny x nz grid of nodes, ``dof`` unknowns per node, every node coupled to its 27-point neighbourhood with a
+    full dof x dof block — 81 (dof 3) / 162 (dof 6) nonzeros in an interior row.  nz = 1 gives the 9-point quadrilateral
+    mesh of a shell model (af_shell10 :1586: 34.9 nonzeros per row = 9 neighbours x 4 unknowns).  See ``mesh_matrix``."""
+    return mesh_matrix(nx, ny, nz, dof, OFFS_27 if nz > 1 else OFFS_9, shuffle, seed, rows, rowptr_only)
+
+
+def tri_mesh(nx, ny, shuffle=0, seed=12, rows=None, rowptr_only=False):
+    """2-D triangulation (delaunay_n2x-like, :2476-2479: 6.0 nonzeros per row): every node of an nx x ny grid coupled to its six neighbours in a structured triangulation, plus itself."""
+    return mesh_matrix(nx, ny, 1, 1, OFFS_TRI7, shuffle, seed, rows, rowptr_only)
+
+
+def tet_mesh(n, dof=1, shuffle=0, seed=13, rows=None, rowptr_only=False):
+    """3-D tetrahedral mesh (CFD / electromagnetics class, 12-20 nonzeros per row): Kuhn subdivision of an n^3 grid of cubes, every node coupled to its 14 neighbours and itself."""
+    return mesh_matrix(n, n, n, dof, OFFS_TET15, shuffle, seed, rows, rowptr_only)
+
+
+def road_like(nx, ny, keep=0.62, shuffle=0, seed=14):
+    """Road-network-like graph (*_osm, road_usa :2509-2514: 2.1-2.4 nonzeros per row, no diagonal): the 4-neighbour grid graph of nx x ny junctions with each (undirected) edge kept
+    with probability ``keep``; natural order or window-shuffled like the meshes."""
+    rng = np.random.default_rng(seed)
+    nn = nx * ny
+    idx = np.arange(nn, dtype=np.int64)
+    y, x = idx // nx, idx % nx
+    right = (x < nx - 1) & (rng.random(nn) < keep); down = (y < ny - 1) & (rng.random(nn) < keep)
+    a = np.concatenate([idx[right], idx[down]]); b = np.concatenate([idx[right] + 1, idx[down] + nx])
+    new_of_old = _fem_node_order(nn, shuffle, seed)
+    if new_of_old is not None:
+        a, b = new_of_old[a], new_of_old[b]
+    return from_coo(nn, nn, np.concatenate([a, b]), np.concatenate([b, a]))
 
 
 NLPKKT160_ROWS, NLPKKT160_NNZ = 8345600, 229518112   # reference src/external/CSR5_cuda/2757-matrix.csv:1903
