@@ -386,7 +386,7 @@ def test_cli_same_stdout_lines_and_pass(torch_cuda, tmp_path):
 
 def test_full_size_properties_laplacian4096(torch_cuda):
     """BASELINE config 4 at full size (16.7 M rows, 83.9 M nnz): properties that do not need the oracle
-    to finish — exact CSR golden on sampled rows, linearity, all-ones row sums, idempotent relaunch."""
+    to finish — exact CSR golden on every row, linearity, all-ones row sums, idempotent relaunch."""
     import torch
     from tilespmv_amd import api, generators as G
     m, n, rp, ci = G.laplacian5pt(4096)
@@ -402,9 +402,8 @@ def test_full_size_properties_laplacian4096(torch_cuda):
         plan.spmv(xd.data_ptr(), yd.data_ptr()); plan.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize()
         ys.append(yd.cpu().numpy()[:m])
     assert np.array_equal(ys[0] + ys[1], ys[2])                     # linearity (exact: integer data)
-    rows = np.unique(np.concatenate([rng.integers(0, m, 200000), np.arange(70000), np.arange(m - 70000, m)]))
-    seg = np.add.reduceat(vals * x1[ci], rp[:-1])                    # CSR golden, vectorised
-    assert np.array_equal(ys[0][rows], seg[rows])
+    seg = np.add.reduceat(vals * x1[ci], rp[:-1])                    # CSR golden, vectorised (every row has entries)
+    assert np.array_equal(ys[0], seg)                                # the WHOLE y (rounds 1-4 compared 340 k sampled rows although the golden was in hand)
     assert np.array_equal(ys[3], np.add.reduceat(vals, rp[:-1]))     # A * 1 = row sums
     plan.close()
 

@@ -657,7 +657,15 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
 #define TILESPMV_NT_COO0 0
 #endif
     constexpr bool NT_DESC = NTS && TILESPMV_NT_DESC, NT_COO0 = NTS && TILESPMV_NT_COO0;
-    __shared__ lacc_t s_y[GROUPS_PER_BLOCK][SROWS][16];   // (lacc_t: fp64 in both builds, see its typedef)
+    // Pooled plans of the fp32 build keep a SECOND copy of the slabs (PCOPY): the slots of a unit are in row order, so the nonzeros of one row sit in neighbouring lanes, and lanes of
+    // odd / even slot add into different copies — two lanes of one LDS atomic then (almost) never hit one address.  A same-address pair costs the fp32 build a quarter of its time
+    // (fem3_68: 0.119 ms, 0.088 with lane-private addresses: profiles/r05_pool_ablations.txt; the fp64 build is bound by its bytes and gains nothing).  The copy sits 16 doubles
+    // off a multiple of the bank count, so that the two halves of a pair also fall into different banks; the copies are summed when the strip is done.
+    constexpr bool PCOPY = POOL && sizeof(val_t) == 4;
+    constexpr int SLAB = GROUPS_PER_BLOCK * SROWS * 16;
+    __shared__ lacc_t s_yall[SLAB + (PCOPY ? SLAB + 16 : 0)];   // (lacc_t: fp64 in both builds, see its typedef)
+    lacc_t (*s_y)[SROWS][16] = reinterpret_cast<lacc_t (*)[SROWS][16]>(&s_yall[0]);
+    lacc_t *s_y1 = &s_yall[PCOPY ? SLAB + 16 : 0];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     __shared__ uint2 s_r[POOL ? GROUPS_PER_BLOCK : 1][POOL ? DCHUNK : 1];   // pooled plans: row nibbles of the parked descriptor chunk
     val_t *s_xw = reinterpret_cast<val_t *>(s_dyn);   // [window slot][16]
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     const unsigned nounit = (unsigned)t1.z;
     const bool side = POOL || coo_end > coo_begin;   // the strip's slab of s_y holds sums (entries; in pooled plans everything)
     if constexpr (POOL) {   // the slab is zeroed before anything adds into it (the entry phases below sit behind a fence / barrier of their own)
-        for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
+        for (int k = 0; k < nrows; k++) { s_y[g][k][r] = 0; if constexpr (PCOPY) s_y1[(g * SROWS + k) * 16 + r] = 0; }
         wave_lds_fence();
     }
     // values are stored in groups of G = UNIT_GROUP units of one task (hip_plan.hip): row r of the group that starts at
@@ -903,7 +911,8 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         if constexpr (POOL) {   // flags = word 0 >> 24 (tile-row in strip in its top nibble), word1 = this lane's half of the row nibbles
             const unsigned dest = ((flags >> (POOL_KR_SHIFT - 24)) & 7u) * 16u + ((word1 >> (28 - 4 * (r & 7))) & 15u);
             if (TSPMV_DIAG_POOL_ADD(dest, prod)) return;
-            atomicAdd(&s_y[g][0][0] + dest, (lacc_t)prod);
+            if constexpr (PCOPY) atomicAdd(((r & 1) ? s_y1 : &s_y[0][0][0]) + g * (SROWS * 16) + dest, (lacc_t)prod);
+            else atomicAdd(&s_y[g][0][0] + dest, (lacc_t)prod);
             return;
         }
         if (flags & UNIT_ROWUNIT) {  // dense-row unit: lanes hold one row's products
@@ -971,7 +980,13 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         }
     }
     TSPMV_STAMP_WAIT(4);       // unit loop done
-    if constexpr (POOL) wave_lds_fence();   // every add of this wavefront into the slab is behind us
+    if constexpr (POOL) {   // every add of this wavefront into the slab is behind us
+        wave_lds_fence();
+        if constexpr (PCOPY) {
+            for (int k = 0; k < nrows; k++) s_y[g][k][r] += s_y1[(g * SROWS + k) * 16 + r];
+            wave_lds_fence();
+        }
+    }
     if (part >= 0) {
         val_t out = acc;
         if (side) out = (val_t)((lacc_t)acc + s_y[g][0][r]);
@@ -1191,23 +1206,33 @@ hipError_t launch_entry_panels(const DevStream &S, int rowA, int xcd_remap, int 
 
 // ------------------------------------------------------------------------------------------------
 // Dense tiles on the matrix cores (reference dense kernel: src/tilespmv_cuda.h:664-710).
-// One wavefront per tile-row.  A dense tile is 256 contiguous values (stored in operand order, below); k-step s of
+// A dense tile is 256 contiguous values (stored in operand order, below); k-step s of
 // v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 with lane group q (= k index) covers tile column
 // 4q + s: A[row][k=q] = tile[row][4q+s] (four 128-B runs per load), B[k=q][*] = x[16cb + 4q + s].
-// The accumulator D is carried ACROSS the tiles of the tile-row (C-in = previous D), so a row with
-// n dense tiles costs 4n MFMAs and one 16-value update of y at the end; summation order is fixed.
-// Loads of the next tile are issued before the MFMAs of the current one (unconditionally, clamped).
+// The accumulator D is carried ACROSS the tiles of a tile-row (C-in = previous D), so a row with
+// n dense tiles costs 4n MFMAs and one 16-value update of y at its end; summation order is fixed.
+// Round 5: one wavefront walks DENSE_ROWS_PER_WAVE consecutive row records as ONE flat run of tiles (the records' tile
+// ranges are contiguous by construction: hip_plan_stream.hip checks it) — the next tile's loads are always in flight,
+// across row boundaries too, and the row's 16 values of y are requested when the row STARTS, so that the read-modify-write
+// at its end waits for nothing.  With one row per wavefront (rounds 1-4) a wavefront of the band matrix lived for five
+// tiles: three dependent round trips (record, column blocks, first tile) before it streamed 10 KB, and the y update
+// behind the last tile — 5.7 TB/s where the unit kernel reaches 6.9.
 // ------------------------------------------------------------------------------------------------
+#ifndef DENSE_MIN_WAVES
+#define DENSE_MIN_WAVES 7   // waves per SIMD asked of the register allocator for k_dense_mfma (72 VGPRs; at 8 waves = 64 VGPRs it spills 20 bytes)
+#endif
+constexpr int DENSE_ROWS_PER_WAVE = 8;   // at most; fewer where that would leave the chip short of wavefronts (launch_dense_mfma)
 template <bool NTS>   // NTS: the tile values (read once) are loaded nontemporally — plans above 400 MB per launch, as in k_units
-__global__ __launch_bounds__(256) void k_dense_mfma(DevDense D, int rowA, int colA, val_t *__restrict__ partial,
+__global__ __launch_bounds__(256, DENSE_MIN_WAVES) void k_dense_mfma(DevDense D, int R, int rowA, int colA, val_t *__restrict__ partial,
                                                     const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= D.nrows) return;  // whole wavefronts only
-    const int4 dr = reinterpret_cast<const int4 *>(D.rows)[w];
-    const int row = dr.x, t0 = dr.y, t1 = dr.z, part = dr.w;
-    const int last = t1 - 1, kq = lane >> 4, rr0 = lane & 15;
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (r0 >= D.nrows) return;  // whole wavefronts only
+    const int nr = min(R, D.nrows - r0);
+    const int4 dr = reinterpret_cast<const int4 *>(D.rows)[r0 + min(lane, nr - 1)];   // lane l < nr holds record l: {tile-row, tile_begin, tile_end, partial slot or -1}
+    const int tb = __builtin_amdgcn_readlane(dr.y, 0), te = __builtin_amdgcn_readlane(dr.z, nr - 1), last = te - 1;
+    const int kq = lane >> 4, rr0 = lane & 15;
     const long long xlast = (long long)colA - 1;
 #if defined(TILESPMV_F32)
     v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -1217,13 +1242,15 @@ __global__ __launch_bounds__(256) void k_dense_mfma(DevDense D, int rowA, int co
     // k-step s of lane group q covers tile column c = 4q + s (any bijection of the 16 columns onto
     // (s, q) works as long as A and B agree): the four B values of a lane are then x[16cb + 4q .. +3],
     // 32 contiguous bytes, and its four A values are val[(4q + s) * 16 + row].
-    // column blocks of the whole row piece in one load (<= 64 tiles per piece by construction), then
-    // broadcast per tile with v_readlane: the per-tile loads depend on nothing but the loop counter
-    const int cbv = D.cb[min(t0 + lane, last)];
+    // column blocks: 64 tiles per lane load, broadcast per tile with v_readlane; a run longer than that reloads (wave-uniform, rare)
+    int cbase = tb;
+    int cbv = D.cb[min(tb + lane, last)];
     auto load_tile = [&](int t, val_t (&a)[4], val_t (&b)[4]) {
-        const int cb = __builtin_amdgcn_readlane(cbv, __builtin_amdgcn_readfirstlane(min(t, last) - t0));
+        const int tc = min(t, last);
+        if (tc - cbase >= 64) { cbase = tc; cbv = D.cb[min(tc + lane, last)]; }
+        const int cb = __builtin_amdgcn_readlane(cbv, __builtin_amdgcn_readfirstlane(tc - cbase));
         const long long xb = (long long)cb * 16 + 4 * kq;
-        const val_t *tv = D.val + (long long)min(t, last) * 256;   // operand order (dense_slot): fp32 one 16-byte load per lane, fp64 two, each covering whole lines
+        const val_t *tv = D.val + (long long)tc * 256;   // operand order (dense_slot): fp32 one 16-byte load per lane, fp64 two, each covering whole lines
 #pragma unroll
         for (int s = 0; s < 4; s++) a[s] = stream_load<NTS>(tv + dense_slot(rr0, 4 * kq + s));
         if (xb + 3 <= xlast) {
@@ -1244,38 +1271,64 @@ __global__ __launch_bounds__(256) void k_dense_mfma(DevDense D, int rowA, int co
 #endif
         }
     };
+    // the rows of D a lane writes: column 0 of D (lanes 0, 16, 32, 48), rows rr(i)
+    auto out_row = [&](int i) {
+#if defined(TILESPMV_F32)
+        return 4 * kq + i;   // f32 C/D map
+#else
+        return kq + 4 * i;   // f64 C/D map
+#endif
+    };
+    int cur = 0;
+    int row = __builtin_amdgcn_readlane(dr.x, 0), row_end = __builtin_amdgcn_readlane(dr.z, 0), part = __builtin_amdgcn_readlane(dr.w, 0);
+    val_t yold[4] = {0, 0, 0, 0};
+    auto fetch_y = [&]() {   // the row's values of y, requested when the row starts
+        if ((lane & 15) == 0 && part < 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const long long yi = (long long)row * 16 + out_row(i); yold[i] = yi < rowA ? y[yi] : (val_t)0; }
+        }
+    };
     val_t a0[4], b0[4];
-    load_tile(t0, a0, b0);
-    for (int t = t0; t < last; t++) {  // next tile's loads in flight ahead of this tile's MFMAs (unconditional: exact wait counts)
+    load_tile(tb, a0, b0);
+    fetch_y();
+    for (int t = tb; t < te; t++) {  // next tile's loads in flight ahead of this tile's MFMAs (unconditional, clamped: exact wait counts)
         val_t a1[4], b1[4];
         load_tile(t + 1, a1, b1);
         mfma4(a0, b0);
+        if (t + 1 == row_end) {   // wave-uniform: the row is complete
+            if ((lane & 15) == 0) {  // every column of D holds the same 16 results; column 0 writes them
 #pragma unroll
-        for (int s = 0; s < 4; s++) { a0[s] = a1[s]; b0[s] = b1[s]; }
-    }
-    mfma4(a0, b0);  // last tile: nothing left to prefetch
-    if ((lane & 15) == 0) {  // every column of D holds the same 16 results; column 0 writes them
+                for (int i = 0; i < 4; i++) {
+                    const int rr = out_row(i);
+                    if (part >= 0) partial[(long long)part * 16 + rr] = acc[i];
+                    else {
+                        const long long yi = (long long)row * 16 + rr;
+                        if (yi < rowA) y[yi] = yold[i] + acc[i];
+                    }
+                }
+            }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-#if defined(TILESPMV_F32)
-            const int rr = 4 * kq + i;   // f32 C/D map
-#else
-            const int rr = kq + 4 * i;   // f64 C/D map
-#endif
-            if (part >= 0) partial[(long long)part * 16 + rr] = acc[i];
-            else {
-                const long long yi = (long long)row * 16 + rr;
-                if (yi < rowA) y[yi] += acc[i];
+            for (int i = 0; i < 4; i++) acc[i] = 0;
+            cur++;
+            if (cur < nr) {
+                row = __builtin_amdgcn_readlane(dr.x, cur); row_end = __builtin_amdgcn_readlane(dr.z, cur); part = __builtin_amdgcn_readlane(dr.w, cur);
+                fetch_y();
             }
         }
+#pragma unroll
+        for (int s = 0; s < 4; s++) { a0[s] = a1[s]; b0[s] = b1[s]; }
     }
 }
 
 hipError_t launch_dense_mfma(const DevDense &D, bool nt_stream, int rowA, int colA, val_t *partial, const val_t *x, val_t *y, hipStream_t st)
 {
     if (D.nrows > 0) {
-        if (nt_stream) hipLaunchKernelGGL(k_dense_mfma<true>, dim3((D.nrows + 3) / 4), dim3(256), 0, st, D, rowA, colA, partial, x, y);
-        else hipLaunchKernelGGL(k_dense_mfma<false>, dim3((D.nrows + 3) / 4), dim3(256), 0, st, D, rowA, colA, partial, x, y);
+        // row records per wavefront: up to 8, but never so many that the grid falls below ~16 wavefronts per SIMD of the chip (fem6_46: 36 k records — 8 per wavefront left
+        // 4.5 wavefronts per SIMD, one round at low occupancy: 4.6 TB/s)
+        const int R = std::max(1, std::min(DENSE_ROWS_PER_WAVE, D.nrows / 16384));
+        const dim3 grid((unsigned)((D.nrows + 4 * R - 1) / (4 * R)));
+        if (nt_stream) hipLaunchKernelGGL(k_dense_mfma<true>, grid, dim3(256), 0, st, D, R, rowA, colA, partial, x, y);
+        else hipLaunchKernelGGL(k_dense_mfma<false>, grid, dim3(256), 0, st, D, R, rowA, colA, partial, x, y);
     }
     return hipGetLastError();
 }

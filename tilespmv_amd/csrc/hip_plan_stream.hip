@@ -258,7 +258,10 @@ void StreamBuilder::count()
         });
     };
     count_all(csr_form, rc_);
-    if (K.csr_split < 0 && (long long)T->csr_offset[t_end] - T->csr_offset[t_begin] > 0) {
+    // (a caller who asks for a launch form that exists for the classic units only — column panels / slices, pacing, 512-thread workgroups, LDS x windows, a forced dictionary —
+    //  gets the classic units)
+    const bool classic_asked = K.x_panel_kb > 0 || K.x_slice_passes > 0 || K.pace > 0 || K.wg_strips == 32 || K.x_window == 1 || K.desc_dict == 1;
+    if (K.csr_split < 0 && !classic_asked && (long long)T->csr_offset[t_end] - T->csr_offset[t_begin] > 0) {
         std::vector<RowCount> alt;
         count_all(2, alt);
         long long u1 = 0, e1 = 0, u2 = 0, e2 = 0;
@@ -285,10 +288,14 @@ void StreamBuilder::count()
             }
             if (pats.size() > ((size_t)1 << DICT_MAX_BITS)) desc_split = 12;
         }
-        const long long split_b = u1 * (desc_split + 16LL * sv) + e1 * (sv + 5LL), pooled_b = u2 * (20 + 16LL * sv) + e2 * (sv + 5LL);
-        // ... and only where units carry the shard: an entry-dominated shard (power-law, scattered) lives in its entry lists, whose launch forms (512-thread workgroups,
-        // column panels / slices, pacing) exist for the classic kernel only
-        if (pooled_b * 100 <= split_b * 95 && 16 * u2 >= e2) { rc_.swap(alt); csr_form = 2; }
+        const long long xy_b = ((long long)colA + 16LL * ntr) * sv;   // x once, y once: part of what either form moves
+        const long long split_b = u1 * (desc_split + 16LL * sv) + e1 * (sv + 5LL) + xy_b, pooled_b = u2 * (20 + 16LL * sv) + e2 * (sv + 5LL) + xy_b;
+        // Calibrated on the population (scripts/r5_form_study.py, profiles/r05_form_study.txt): the pooled kernel's time follows its bytes with about 8 % on top of the
+        // classic kernel's at equal bytes, so it is taken where one SpMV moves at least 5 % fewer bytes — and only where units carry the shard (an entry-dominated shard
+        // lives in its entry lists) and the shard would not get column panels (scattered entries over an x of >= 12 MB: the panel / slice launches exist for the
+        // classic kernel; band + random fill loses 23 % without them)
+        const bool would_panel = (long long)K.coo_cost * e2 * 2 > 16LL * u2 + (long long)K.coo_cost * e2 && (long long)colA * sv >= (12ll << 20);
+        if (pooled_b * 100 <= split_b * 95 && 16 * u2 >= e2 && !would_panel) { rc_.swap(alt); csr_form = 2; }
         if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: CSR tiles: split form (%d-byte descriptors) %lld units + %lld entries = %.1f MB, pooled form %lld units + %lld entries = %.1f MB -> %s\n",
                                                      desc_split, u1, e1, split_b / 1e6, u2, e2, pooled_b / 1e6, csr_form == 2 ? "pooled" : "split");
     }
@@ -1092,8 +1099,10 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     rc |= plan->upload(h_dval, (size_t)ND * 256, &plan->dn.val);
     rc |= plan->upload(drows.data(), drows.size(), &plan->dn.rows);
     plan->dn.nrows = (int)drows.size();
-    for (const DenseRow &dr : drows)
-        if (dr.tile_end - dr.tile_begin > 64) { fprintf(stderr, "tilespmv: internal error: dense piece of %d tiles\n", dr.tile_end - dr.tile_begin); rc = -6; }
+    for (size_t i = 0; i < drows.size(); i++) {   // k_dense_mfma walks consecutive records as one flat run of tiles: their ranges must be non-empty and follow each other
+        const DenseRow &dr = drows[i];
+        if (dr.tile_end <= dr.tile_begin || (i > 0 && dr.tile_begin != drows[i - 1].tile_end)) { fprintf(stderr, "tilespmv: internal error: dense row records are not one contiguous run of tiles\n"); rc = -6; break; }
+    }
     release();
     S.ntasks = (int)tasks.size();
 #ifdef TILESPMV_STAMPS
@@ -1190,15 +1199,26 @@ int tilespmv::build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matri
                            std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes)
 {
     StreamBuilder B(plan, K, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mfma, hyb_off, fix, npartial);
-    B.count();
+    const bool verbose = getenv("TILESPMV_PLAN_VERBOSE") != nullptr;
+    double t_prev = now_us(), up_prev = (double)plan->info[TILESPMV_INFO_UPLOAD_US];
+    std::string times;
+    auto lap = [&](const char *name) {   // host milliseconds of the stage (its uploads counted apart)
+        if (!verbose) return;
+        const double t = now_us(), up = (double)plan->info[TILESPMV_INFO_UPLOAD_US];
+        char buf[96];
+        snprintf(buf, sizeof(buf), " %s %.1f (+%.1f upload)", name, (t - t_prev - (up - up_prev)) * 1e-3, (up - up_prev) * 1e-3);
+        times += buf; t_prev = t; up_prev = up;
+    };
+    B.count(); lap("count");
     if (B.rc) return B.rc;
-    B.choose();
-    B.cut();
-    B.emit();
-    B.order();
-    B.encode();
+    B.choose(); lap("choose");
+    B.cut(); lap("cut");
+    B.emit(); lap("emit");
+    B.order(); lap("order");
+    B.encode(); lap("encode");
     if (B.rc == -2) return B.rc;   // (shard too large for 32-bit unit ids)
-    B.entries();
-    B.finish(n_tasks, model_bytes);
+    B.entries(); lap("entries");
+    B.finish(n_tasks, model_bytes); lap("finish");
+    if (verbose) fprintf(stderr, "tilespmv: unit-stream layout, ms per stage:%s\n", times.c_str());
     return B.rc;
 }
