@@ -12,4 +12,5 @@ hipError_t launch_tiles_stream_mv(const DevPlan &, const DevStream &, const DevD
 hipError_t launch_rows_to_columns(const val_t *, int, long long, long long, val_t *, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_columns_to_rows(const val_t *, int, long long, long long, long long, val_t *, hipStream_t) { return hipErrorNotSupported; }
 int paced_team_workgroups(bool, bool, int, int) { return 192; }
+hipError_t launch_pair_values(const val_t *, val_t *, const int4 *, int) { return hipErrorNotSupported; }
 }

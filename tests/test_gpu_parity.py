@@ -1176,3 +1176,36 @@ def test_deterministic_plans_give_the_same_bits_on_real_valued_data(torch_cuda):
             ys.append(y)
         assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2]), name
         api.Tile_destroy(tr)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_value_pass_on_the_device_equals_the_host_pass(torch_cuda, monkeypatch, dtype):
+    """Round 5 (device-side plan build — first piece): the ENCODE stage's value pass (the plan's largest array, permuted into per-task groups) runs on the device
+    (k_pair_values); the host pass stays as the checker.  TILESPMV_ENCODE_CHECK=1 runs both and fails plan creation (-6) unless the device's stream equals the host's byte for byte;
+    TILESPMV_ENCODE_ON_HOST=1 is the host-only path.  Every plan kind with units: classic (dictionary / 12-B descriptors), pooled, split rows, brick order, x windows, shards."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api, generators as G
+    O = CpuImpl("oracle", dtype)
+    mats = {"allfmt": SMALL["allfmt"], "fem3_12": lambda: G.fem_hex(12, 12, 12, 3), "kkt12": MEDIUM["kkt12"], "lap3d48": lambda: G.laplacian7pt(48), "band4096_40": SMALL["band4096_40"],
+            "one_long_row": SMALL["one_long_row"], "powerlaw20k": SMALL["powerlaw20k"]}
+    knob_sets = [dict(), dict(csr_split=1), dict(csr_split=2), dict(desc_dict=0), dict(strip_cost=64, split_above=200), dict(x_window=2), dict(x_window=1, entry_mode=0), dict(strip_even=0),
+                 dict(dense_mode=api.DENSE_VALU), dict(tilerow_begin=2, tilerow_end=5)]
+    for name, gen in mats.items():
+        m, n, rp, ci = gen()
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, x = values_for(name, nnz, n, dtype)
+        want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, x)["y"]
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=True)
+        for kw in knob_sets:
+            for env in ({"TILESPMV_ENCODE_CHECK": "1"}, {"TILESPMV_ENCODE_ON_HOST": "1"}, {}):
+                for k in ("TILESPMV_ENCODE_CHECK", "TILESPMV_ENCODE_ON_HOST"):
+                    monkeypatch.delenv(k, raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                plan = api.Plan(tp, rowA, n, nnz, **kw)      # raises if the check inside plan creation fails
+                xd = torch_cuda.from_numpy(x).cuda(); yd = torch_cuda.full((rowA + 16,), 5.0, dtype=xd.dtype, device="cuda")
+                plan.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()
+                r0, r1 = 16 * kw.get("tilerow_begin", 0), (16 * kw["tilerow_end"] if "tilerow_end" in kw else rowA)
+                assert np.array_equal(yd.cpu().numpy()[r0:r1], want[r0:r1]), (name, kw, env)
+                plan.close()
+        api.Tile_destroy(tp)

@@ -1854,6 +1854,31 @@ hipError_t launch_columns_to_rows(const val_t *YT, int nvec, long long row0, lon
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Plan creation on the device, first piece (round 5; SURVEY S8 f1 "device-side ..."): the ENCODE stage's value pass.  The builder emits the 16 values of every unit in tile order
+// (src); what the unit kernel reads is, per task, groups of UNIT_GROUP units interleaved per row (hip_plan.h "unit stream").  On the host that permutation is a second full pass
+// over the plan's largest array (0.67 GB for config 4) into a staging copy; here the emitted values are uploaded as they are and one workgroup per task writes them to their final
+// place.  map[i] = {first unit of task i in src, first unit in dst, units, -}.  Padding slots of a task's last group are never written: the arena block they lie in was zeroed.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pair_values(const val_t *__restrict__ src, val_t *__restrict__ dst, const int4 *__restrict__ map, int ntasks)
+{
+    constexpr int G = UNIT_GROUP;
+    for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {
+        const int4 m = map[t];
+        const long long so = (long long)m.x * 16, dofs = (long long)m.y * 16;
+        for (int i = threadIdx.x; i < m.z * 16; i += 256) {
+            const int j = i >> 4, r = i & 15;
+            dst[dofs + (long long)(j / G * G) * 16 + G * r + (j % G)] = src[so + i];
+        }
+    }
+}
+
+hipError_t launch_pair_values(const val_t *src, val_t *dst, const int4 *map, int ntasks)
+{
+    if (ntasks > 0) hipLaunchKernelGGL(k_pair_values, dim3((unsigned)std::min(ntasks, 1 << 20)), dim3(256), 0, nullptr, src, dst, map, ntasks);
+    return hipGetLastError();
+}
+
 int paced_team_workgroups(bool dict_desc, bool nt_stream, int xcd_remap, int lds_pad_bytes)
 {
     int per_cu = 0, dev = 0;

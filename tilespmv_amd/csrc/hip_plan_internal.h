@@ -201,6 +201,9 @@ struct tilespmv_plan {
     unsigned long long digest = 1469598103934665603ull;
     unsigned long long stage_digest[TILESPMV_STAGE_COUNT] = {0};   // layout-digest builds: one hash per stage of the unit-stream builder (hip_plan_stream.hip)
     std::vector<const void **> uploaded_slots;   // every device-pointer MEMBER of this plan that upload() filled: what a re-placement rebases (hip_plan.hip retry_placement)
+    // arena space for n elements that a device kernel will fill (zeroed like every block); same bookkeeping as upload()
+    template <class T>
+    int reserve(size_t n, const T **out) { return upload<T>(nullptr, n, out); }
     template <class T>
     int upload(const T *host, size_t n, const T **out)
     {
@@ -234,7 +237,7 @@ struct tilespmv_plan {
             arena_at = (char *)b; arena_left = blk;
         }
         d = arena_at; arena_at += need; arena_left -= need;
-        if (n) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+        if (n && host) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
         info[TILESPMV_INFO_DEVICE_BYTES] += (long long)(n * sizeof(T));
         info[TILESPMV_INFO_UPLOAD_US] += (long long)(now_us() - t0);
         *out = (const T *)d;
@@ -389,6 +392,9 @@ inline bool pack_list(const std::vector<PEnt> &ents, int dest_bits, std::vector<
     }
     return j == ents.size() && base.size() - base0 == (rec.size() - rec0 + ECHUNK - 1) / ECHUNK;
 }
+
+// the value pass of the ENCODE stage on the device (hip_kernels.hip k_pair_values)
+hipError_t launch_pair_values(const val_t *src, val_t *dst, const int4 *map, int ntasks);
 
 // Workgroups of the slab-paced unit kernel one XCD holds at one time (occupancy query on the current device; hip_kernels.hip)
 int paced_team_workgroups(bool dict_desc, bool nt_stream, int xcd_remap, int lds_pad_bytes);

@@ -217,7 +217,20 @@ struct StreamBuilder {
                   const std::vector<long long> &hyb_off_, std::vector<FixRow> &fix_, int &npartial_)
         : plan(plan_), K(K_), T(T_), rowA(rowA_), colA(colA_), tr0(tr0_), tr1(tr1_), coo_in_tile(coo_in_tile_), dense_mfma(dense_mfma_), hyb_off(hyb_off_), fix(fix_), npartial(npartial_), S(plan_->st) {}
     ~StreamBuilder() { release(); }
-    void release() { free(h_uval); free(h_cval); free(h_hval); free(h_hidx); free(h_dval); h_uval = h_cval = h_hval = h_dval = nullptr; h_hidx = nullptr; }
+    // The staging arrays of a GB-sized plan take tens of milliseconds to give back (munmap of 0.7 GB each: 70-80 ms of the 320 ms config 4's plan build took): a detached
+    // thread does it while the builder goes on.  Small arrays are freed in place.
+    static void free_later(std::vector<void *> ptrs, size_t bytes_hint)
+    {
+        ptrs.erase(std::remove(ptrs.begin(), ptrs.end(), (void *)nullptr), ptrs.end());
+        if (ptrs.empty()) return;
+        if (bytes_hint < ((size_t)64 << 20)) { for (void *q : ptrs) free(q); return; }
+        std::thread([ptrs]() { for (void *q : ptrs) free(q); }).detach();
+    }
+    void release()
+    {
+        free_later({h_uval, h_cval, h_hval, h_hidx, h_dval}, (size_t)(NU * 16 + NC + NHV + ND * 256) * sizeof(val_t));
+        h_uval = h_cval = h_hval = h_dval = nullptr; h_hidx = nullptr;
+    }
 
     // ---- stage digests (layout-digest builds only): FNV-1a-64 over (element count, bytes) of what the stage produced
     struct Hash {
@@ -842,7 +855,12 @@ void StreamBuilder::encode()
     {
         std::vector<UDesc> packed((size_t)NUP, UDesc{0u, 0u, 0u});
         std::vector<URow> packed_row(pooled ? (size_t)NUP : 0, URow{0u, 0u});
-        val_t *paired = zalloc<val_t>((size_t)NUP * 16);
+        // The value pass (the plan's largest array, permuted into groups per task) runs on the DEVICE unless this is a layout-digest build or TILESPMV_ENCODE_ON_HOST=1 asks for
+        // the host pass — which stays as the checker: TILESPMV_ENCODE_CHECK=1 runs both and compares the device's stream with the host's, byte for byte (tests/test_gpu_parity.py)
+        const bool encode_check = !plan->dry && env_int("TILESPMV_ENCODE_CHECK", 0) != 0;
+        const bool on_device = !plan->dry && NUP > 0 && env_int("TILESPMV_ENCODE_ON_HOST", 0) == 0;
+        val_t *paired = (on_device && !encode_check) ? nullptr : zalloc<val_t>((size_t)NUP * 16);
+        std::vector<int4> pair_map(on_device ? tasks.size() : 0);
         std::vector<long long> new_begin(tasks.size());
         old_begin.assign(tasks.size(), 0);
         for (size_t i = 0; i < tasks.size(); i++) old_begin[i] = tasks[i].unit_begin;
@@ -856,10 +874,13 @@ void StreamBuilder::encode()
                     const uint4 d = h_udesc[(size_t)(ub + j)];
                     packed[(size_t)(nb + j)] = UDesc{d.x, d.y, d.w};
                     if (pooled) packed_row[(size_t)(nb + j)] = URow{h_urow[(size_t)(ub + j)].x, h_urow[(size_t)(ub + j)].y};
-                    const val_t *src = h_uval + (ub + j) * 16;
-                    val_t *dst = paired + (nb + j / G * G) * 16 + (j % G);
-                    for (int r = 0; r < 16; r++) dst[G * r] = src[r];
+                    if (paired) {
+                        const val_t *src = h_uval + (ub + j) * 16;
+                        val_t *dst = paired + (nb + j / G * G) * 16 + (j % G);
+                        for (int r = 0; r < 16; r++) dst[G * r] = src[r];
+                    }
                 }
+                if (on_device) pair_map[(size_t)i] = make_int4((int)ub, (int)nb, (int)n, 0);
                 if (n > 0) { k.unit_begin = (int)nb; k.unit_end = (int)(nb + n); }
             }
         });
@@ -917,8 +938,31 @@ void StreamBuilder::encode()
         plan->info[TILESPMV_INFO_DESC_BYTES] = S.cb_bits > 0 ? 4 : pooled ? 20 : 12;
         S.urow = nullptr; S.pooled = pooled ? 1 : 0;
         if (pooled) rc |= plan->upload(packed_row.data(), (size_t)NUP, &S.urow);
-        rc |= plan->upload(paired, (size_t)NUP * 16, &S.uval);
-        free(paired);
+        if (on_device) {
+            // emitted values as they are -> a scratch buffer on the device; one workgroup per task writes them to their final place in the plan's arena
+            const double t0 = now_us();
+            void *d_src = nullptr, *d_map = nullptr;
+            const size_t src_b = (size_t)NU * 16 * sizeof(val_t), map_b = pair_map.size() * sizeof(int4);
+            rc |= plan->reserve((size_t)NUP * 16, &S.uval);
+            hipError_t e = hipMalloc(&d_src, std::max<size_t>(src_b, 16));
+            if (e == hipSuccess) e = hipMalloc(&d_map, std::max<size_t>(map_b, 16));
+            if (e == hipSuccess) e = hipMemcpy(d_src, h_uval, src_b, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_map, pair_map.data(), map_b, hipMemcpyHostToDevice);
+            if (e == hipSuccess && rc == 0) e = launch_pair_values((const val_t *)d_src, const_cast<val_t *>(S.uval), (const int4 *)d_map, (int)pair_map.size());
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e == hipSuccess && encode_check) {
+                std::vector<val_t> back((size_t)NUP * 16);
+                e = hipMemcpy(back.data(), S.uval, back.size() * sizeof(val_t), hipMemcpyDeviceToHost);
+                if (e == hipSuccess && memcmp(back.data(), paired, back.size() * sizeof(val_t)) != 0) { fprintf(stderr, "tilespmv: internal error: the device's value stream differs from the host's\n"); rc = -6; }
+                else if (e == hipSuccess && getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: encode check: %lld units, device value stream == host value stream\n", NUP);
+            }
+            if (d_src) (void)hipFree(d_src);
+            if (d_map) (void)hipFree(d_map);
+            if (e != hipSuccess) { fprintf(stderr, "tilespmv: value pass on the device failed: %s\n", hipGetErrorString(e)); (void)hipGetLastError(); rc = -3; }
+            plan->info[TILESPMV_INFO_UPLOAD_US] += (long long)(now_us() - t0);
+        } else rc |= plan->upload(paired, (size_t)NUP * 16, &S.uval);
+        free_later({paired, h_uval}, (size_t)NUP * 16 * sizeof(val_t));   // (h_uval was read for the last time above)
+        h_uval = nullptr;
         S.udesc_cb = S.udesc;
         if (xwin) {   // the multi-vector kernel keeps reading x from global memory: its descriptors carry column blocks
             std::fill(packed.begin(), packed.end(), UDesc{0u, 0u, 0u});
