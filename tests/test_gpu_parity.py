@@ -881,7 +881,7 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
                  dict(placement_tries=3), dict(placement_tries=2, entry_mode=2, strip_cost=64, split_above=200), dict(placement_tries=3, coo_mode=2), dict(placement_tries=2, x_window=1),
                  dict(placement_tries=3, dense_mode=1, csr_split=0)]
     windowed = bricks = 0
-    desc = {4: 0, 12: 0}
+    desc = {4: 0, 12: 0, 20: 0}   # (20: pooled plans, where the byte model chooses them)
     for name, gen in mats.items():
         m, n, rp, ci = gen()
         nnz, rowA = len(ci), truncated_rows(m)
@@ -899,7 +899,7 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
             bricks += info["brick_order"] == 1
             desc[info["desc_bytes"]] += 1
             assert info["nt_stream"] == (1 if kw.get("nt_stream") == 1 and info["entry_mode"] != 1 and not info["x_window_slots"] else 0)   # (small test matrices: off by rule)
-            assert info["desc_bytes"] == 12 or (kw.get("desc_dict") != 0 and info["x_window_slots"] == 0)
+            assert info["desc_bytes"] == 12 or (info["desc_bytes"] == 20 and info["csr_form"] == 2) or (kw.get("desc_dict") != 0 and info["x_window_slots"] == 0)   # (20: a pooled plan, chosen by the byte model)
             assert not (kw.get("x_window") == 0 and info["brick_order"])
         # multi-vector product on an x-window plan: its kernel reads the column-block descriptors kept beside the slotted ones
         plan = api.Plan(tp, rowA, n, nnz, x_window=1, entry_mode=0)
@@ -1205,7 +1205,7 @@ def test_value_pass_on_the_device_equals_the_host_pass(torch_cuda, monkeypatch, 
                 plan = api.Plan(tp, rowA, n, nnz, **kw)      # raises if the check inside plan creation fails
                 xd = torch_cuda.from_numpy(x).cuda(); yd = torch_cuda.full((rowA + 16,), 5.0, dtype=xd.dtype, device="cuda")
                 plan.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()
-                r0, r1 = 16 * kw.get("tilerow_begin", 0), (16 * kw["tilerow_end"] if "tilerow_end" in kw else rowA)
+                r0, r1 = min(rowA, 16 * kw.get("tilerow_begin", 0)), min(rowA, 16 * kw["tilerow_end"] if "tilerow_end" in kw else rowA)
                 assert np.array_equal(yd.cpu().numpy()[r0:r1], want[r0:r1]), (name, kw, env)
                 plan.close()
         api.Tile_destroy(tp)
