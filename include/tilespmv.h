@@ -324,7 +324,10 @@ typedef struct {
                            8 x groups workgroups follows in which workgroup b (dispatched to XCD b & 7) takes its group's entries of column slice pass * 8 + (b & 7), so an XCD
                            only ever gathers from its own slice of x, which stays in its L2, and adds the rows it touched to y atomically — the eight partial sums of a row
                            meet in an order that is not fixed: never chosen when entry_ordered = 1.  N > 0 = N passes (8 N slices); 0 = off; unset (and x_panel_merge unset): timed at plan creation
-                           beside the panelled forms (1, 2, 4 passes where a slice would be about 1-8 MB), kept when fastest and >= 3 % faster than the plain launch
+                           beside the panelled forms (1, 2, 4 passes where a slice would be about 1-8 MB), kept when fastest and >= 3 % faster than the plain launch.
+                           NOTE: that timed choice can pick this form on large grids where the rule alone would have added in a fixed order — the default plan of a large scattered shard
+                           is then NOT bit-reproducible on real-valued data (its facts say so: TILESPMV_INFO_ENTRY_ORDERED = 0, TILESPMV_INFO_X_SLICE_PASSES > 0) and which form it has can differ
+                           from run to run and rank to rank; entry_ordered = 1 or deterministic = 1 pins reproducible sums (bench.py reports what that costs per workload)
                                                                                                                     TILESPMV_X_SLICE_PASSES */
     int deterministic;  /* 1: no decision of this plan is taken by a stopwatch and every sum has a plan-fixed order — placement_tries, x_panel_merge, x_slice_passes, pace and autotune
                            that the caller left unset are switched off (as if 1 / 0 / 0 / 0 / 0) and entry_ordered is 1: two plans of the same matrix then have the same layout,

@@ -1,7 +1,7 @@
 """Which placements of the KKT plan are fast?  One plan, placement_tries = 14, TILESPMV_PLAN_VERBOSE prints every placement's block addresses and time."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["TILESPMV_PLAN_VERBOSE"] = "1"
 import torch
 from tilespmv_amd import api, generators as G

@@ -1,8 +1,8 @@
 """Does WHERE a plan's blocks land decide its state?  One Tile_matrix, plans built one after the other (each destroyed before the next), with an unused allocation of S MB in front of
-every arena block (TILESPMV_ARENA_SPACER_MB) and with different block sizes (TILESPMV_ARENA_MB): python scripts/r4_placement_spacer.py [workload] [f32]"""
+every arena block (TILESPMV_ARENA_SPACER_MB) and with different block sizes (TILESPMV_ARENA_MB): python scripts/rounds/r4_placement_spacer.py [workload] [f32]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tilespmv_amd import api, generators as G
 wl = sys.argv[1] if len(sys.argv) > 1 else "nlpkkt160"

@@ -1,8 +1,8 @@
 """Round 5: split (csr_split = 1) against pooled (csr_split = 2) units over the population — times and stream bytes side by side, to calibrate the byte-model rule that chooses between them."""
 import os, sys, time
 import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench, population_sweep as PS
 from tilespmv_amd import api, generators as G
 st = torch.cuda.current_stream().cuda_stream

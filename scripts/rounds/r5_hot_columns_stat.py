@@ -5,7 +5,7 @@ records, for all entries and for the entries that are NOT among the top-H column
 Groups are approximated as consecutive row blocks holding about the entries one workgroup's list has (5.7 k on the power-law matrix, 4.1 k on the webbase stand-in)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 
 def stat(wl, per_group, H=4096):

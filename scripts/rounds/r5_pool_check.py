@@ -1,8 +1,8 @@
 """Round 5: pooled units (csr_split = 2) — whole-y exact check against scipy on small matrices in every entry mode, then timing of the FEM class split vs pooled.
-python scripts/r5_pool_check.py [check|time|all]"""
+python scripts/rounds/r5_pool_check.py [check|time|all]"""
 import os, sys, time
 import numpy as np, scipy.sparse as sp, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tilespmv_amd import api, generators as G
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"

@@ -1,7 +1,7 @@
 """Round 5: knob sweep of the pooled plans on the FEM class (granularity of the strips: a 27-point x 3 dof tile-row is 81 units = one strip of 1,300 cost units; 59 k strips = 3,685 workgroups = two rounds on 256 CUs)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tilespmv_amd import api, generators as G
 st = torch.cuda.current_stream().cuda_stream
 wls = {"fem3_68": lambda: G.fem_hex(68, 68, 68, 3), "fem6_46": lambda: G.fem_hex(46, 46, 46, 6), "fem3s64_68": lambda: G.fem_hex(68, 68, 68, 3, shuffle=64)}

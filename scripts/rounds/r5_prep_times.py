@@ -2,7 +2,7 @@
 import os, sys, time
 os.environ["TILESPMV_PLAN_VERBOSE"] = "1"
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from tilespmv_amd import api, generators as G
 for wl in sys.argv[1].split(","):

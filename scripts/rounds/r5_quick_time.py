@@ -1,7 +1,7 @@
-"""Round 5: default-plan times of a few workloads, fp64 and fp32 (python scripts/r5_quick_time.py wl,wl [f64|f32|both])."""
+"""Round 5: default-plan times of a few workloads, fp64 and fp32 (python scripts/rounds/r5_quick_time.py wl,wl [f64|f32|both])."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from tilespmv_amd import api, generators as G
 st = torch.cuda.current_stream().cuda_stream
