@@ -1098,7 +1098,7 @@ def test_pooled_units_bit_exact(torch_cuda, dtype):
     Every unit of such a plan has that form (ELL slots, dense / dense-col columns, dense-row units too), so every tile format goes through it here: FEM-like meshes (natural and
     shuffled order, 2 / 3 / 6 dof), the all-format matrices (HYB rule on, partial last tile column), KKT, band with dense tiles, a power-law matrix, one very long row — in every
     entry mode, ordered and unordered, with split rows, tiny strips, the late fix-up, both dense modes, the CSR fallback, tile-row shards; whole y against the oracle bit for bit,
-    twice in a row; SpMM (one right-hand side at a time on these plans) and real-valued data inside the tolerance."""
+    twice in a row; SpMM (the pooled plans' own multi-vector kernel, nvec 2 / 4 / 8) and real-valued data inside the tolerance."""
     from oracle.oracle import CpuImpl
     from tilespmv_amd import api, generators as G
     O = CpuImpl("oracle", dtype)
@@ -1130,15 +1130,20 @@ def test_pooled_units_bit_exact(torch_cuda, dtype):
                 p.close()
             got = yd.cpu().numpy()
             assert np.array_equal(got[:rowA], want) and (got[rowA:] == -7.0).all(), (name, "shards")
-        # SpMM: pooled plans have no native multi-vector kernel, every right-hand side goes through the plan's own SpMV
-        plan = api.Plan(tp, rowA, n, nnz, csr_split=2)
-        X = (np.arange(n * 4, dtype=np.int64) % 5).astype(dtype).reshape(n, 4)
-        Xd = torch_cuda.from_numpy(X).cuda(); Yd = torch_cuda.zeros((rowA + 16, 4), dtype=Xd.dtype, device="cuda")
-        plan.spmm(Xd.data_ptr(), Yd.data_ptr(), 4); torch_cuda.cuda.synchronize()
-        for j in range(4):
-            wj = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=hyb), rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"]
-            assert np.array_equal(Yd.cpu().numpy()[:rowA, j], wj), (name, "spmm", j)
-        plan.close()
+        # SpMM: pooled plans have a multi-vector kernel of their own (k_pool_mv: the slab holds [tile-row][vector][row] sums); every nvec, with split rows and tiny strips, with the
+        # dense tiles on the matrix cores (k_dense_mfma_mv adds into Y afterwards), and one right-hand side at a time (mv_native = 0) as the cross-check
+        X = (np.arange(n * 8, dtype=np.int64) % 5).astype(dtype).reshape(n, 8)
+        wcols = [O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=hyb), rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"] for j in range(8)]
+        for kw in (dict(), dict(strip_cost=64, split_above=200), dict(dense_mode=api.DENSE_MFMA, entry_mode=2), dict(mv_native=0)):
+            plan = api.Plan(tp, rowA, n, nnz, csr_split=2, **kw)
+            for nv in (2, 4, 8):
+                Xd = torch_cuda.from_numpy(np.ascontiguousarray(X[:, :nv])).cuda(); Yd = torch_cuda.full((rowA + 16, nv), -4.0, dtype=Xd.dtype, device="cuda")
+                plan.spmm(Xd.data_ptr(), Yd.data_ptr(), nv); torch_cuda.cuda.synchronize()
+                Yh = Yd.cpu().numpy()
+                assert (Yh[rowA:] == -4.0).all(), (name, kw, nv)
+                for j in range(nv):
+                    assert np.array_equal(Yh[:rowA, j], wcols[j]), (name, "spmm", kw, nv, j)
+            plan.close()
         api.Tile_destroy(tp)
         # real-valued data: the pooled form adds a row's products in another order than the reference — inside the stated tolerance, and the same bits twice
         vr, xr = values_for(name, nnz, n, dtype, real=True)

@@ -1639,6 +1639,146 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// Multi-vector product on POOLED plans (round 5; hip_plan.h "pooled units"): Y[rows][NVT] = A X[cols][NVT].  Same division of labour as k_units_mv — a lane carries NV = min(NVT, 2)
+// right-hand sides, Q = NVT / NV lane groups of a wavefront work on the SAME strip with different slices of the vectors — and the pooled kernel's data flow: the strip's slab
+// [tile-row in strip][row][NVT] (fp64 sums, 16 KB per workgroup whatever NVT) is zeroed, the strip's list entries are scattered into it up front, every unit adds its 16 products per
+// right-hand side with ds_add (unconditionally: a unit past the task's end adds 0), and the rows of Y are stored from the slab.  The matrix streams are read once for all NVT vectors;
+// before this kernel a pooled plan ran SpMM one right-hand side at a time.
+// ------------------------------------------------------------------------------------------------
+template <int NVT, bool NTS>
+__global__ __launch_bounds__(256, MV_MIN_WAVES) void k_pool_mv(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial, const val_t *__restrict__ X, val_t *__restrict__ Y)
+{
+    constexpr int NV = NVT < 2 ? NVT : 2;   // vectors per lane
+    constexpr int Q = NVT / NV;             // lane groups per strip
+    constexpr int STRIPS = GROUPS_PER_BLOCK / Q;
+    constexpr int SR = POOL_STRIP_ROWS;
+    typedef MVec<NV> vec_t;
+    constexpr int UB = UNIT_GROUP;
+    // slab: [tile-row in strip][vector][row], the 16 rows of one vector contiguous (the lanes of a strip hit neighbouring banks) and the vectors 20 doubles apart, so that the lane
+    // groups of a wavefront — same rows, different vectors — do not all fall into the same banks (16 apart = 128 bytes = all of them into one half of the banks)
+    constexpr int VS = 20;
+    __shared__ lacc_t s_acc[STRIPS][SR][NVT][VS];
+    __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
+    __shared__ uint2 s_r[GROUPS_PER_BLOCK][DCHUNK];
+    const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned C = (unsigned)xcd_chunk, W = 8u * C, win = bid / W, off = bid % W, k = off & 7u;
+        if (C > 0 && (win + 1) * W <= gridDim.x) bid = win * W + k * C + (off >> 3);
+    }
+    const int q = g % Q, sg = g / Q;        // this lane group's slice of the vectors, its strip inside the workgroup
+    const long long task_id = (long long)bid * STRIPS + sg;
+    if (task_id >= S.ntasks) return;        // (no workgroup barrier below: lane groups leave on their own)
+    const int4 t0 = reinterpret_cast<const int4 *>(S.task)[task_id * 2];
+    const int4 t1 = reinterpret_cast<const int4 *>(S.task)[task_id * 2 + 1];
+    const int unit_begin = t0.x, unit_end = t0.y, coo_begin = t0.z, coo_end = t0.w;
+    const int row0 = t1.x, part = t1.y, nrows = t1.w;
+    typedef val_t grp_t __attribute__((ext_vector_type(UNIT_GROUP)));
+    const grp_t *__restrict__ ugrp = reinterpret_cast<const grp_t *>(S.uval) + r;
+    const uint2 *__restrict__ urw = reinterpret_cast<const uint2 *>(S.urow);
+    const vec_t *__restrict__ Xv = reinterpret_cast<const vec_t *>(X) + q;   // row i, slice q: Xv[i * Q]
+    vec_t *__restrict__ Yv = reinterpret_cast<vec_t *>(Y) + q;
+    const int last = unit_end - 1;
+    const int last_grp = unit_begin + (unit_end - 1 - unit_begin) / UNIT_GROUP * UNIT_GROUP;
+    const bool have_units = unit_begin < unit_end;
+    const long long xlast = (long long)colA - 1;
+    lacc_t (*slab)[NVT][VS] = s_acc[sg];
+    // the Q lane groups of a strip zero their own slices of the slab: [k][r][q NV .. q NV + NV)
+    for (int k = 0; k < nrows; k++) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) slab[k][q * NV + j][r] = 0;
+    }
+    uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
+    uint2 rcur = make_uint2(0u, 0u), rnext = rcur;
+    val_t v[UB];
+    auto load_grp = [&](int u, val_t (&out)[UB]) {
+        const grp_t pv = stream_load<NTS>(ugrp + (long long)min(u, last_grp) * (16 / UNIT_GROUP));
+#pragma unroll
+        for (int k = 0; k < UNIT_GROUP; k++) out[k] = pv[k];
+    };
+    if (have_units) {   // descriptor chunks 0 and 1, first value group: in flight across the entry phase
+        dcur = load_udesc_raw(S.udesc, min(unit_begin + r, last)); dnext = load_udesc_raw(S.udesc, min(unit_begin + DCHUNK + r, last));
+        rcur = urw[min(unit_begin + r, last)]; rnext = urw[min(unit_begin + DCHUNK + r, last)];
+        load_grp(unit_begin, v);
+    }
+    wave_lds_fence();
+    // ---- the strip's list entries: every load of a trip in flight, then the gathers, then the adds (each lane group for its own slice of the vectors)
+    {
+        constexpr int ECT = 4;
+        for (int e0 = coo_begin; e0 < coo_end; e0 += 16 * ECT) {
+            unsigned rb[ECT]; int cc[ECT]; val_t cv[ECT]; vec_t xx[ECT];
+#pragma unroll
+            for (int k = 0; k < ECT; k++) {
+                const int e = min(e0 + 16 * k + r, coo_end - 1);
+                rb[k] = S.crow[e]; cc[k] = S.ccol[e]; cv[k] = S.cval[e];
+            }
+#pragma unroll
+            for (int k = 0; k < ECT; k++) xx[k] = Xv[(long long)cc[k] * Q];
+#pragma unroll
+            for (int k = 0; k < ECT; k++)
+                if (e0 + 16 * k + r < coo_end) {
+#pragma unroll
+                    for (int j = 0; j < NV; j++) atomicAdd(&slab[rb[k] >> 4][q * NV + j][rb[k] & 15u], (lacc_t)(cv[k] * xx[k].v[j]));
+                }
+        }
+    }
+    // ---- units
+    if (have_units) {
+        const uint2 *sd = reinterpret_cast<const uint2 *>(&s_d[g][0]) + (r >> 3);
+        const unsigned *sr = reinterpret_cast<const unsigned *>(&s_r[g][0]) + (r >> 3);
+        s_d[g][r] = udesc_park_form(dcur); s_r[g][r] = rcur;
+        wave_lds_fence();
+        int chunk_end = unit_begin + DCHUNK;
+        for (int u = unit_begin; u < unit_end; u += UB) {
+            if (u == chunk_end) {
+                wave_lds_fence();
+                s_d[g][r] = udesc_park_form(dnext); s_r[g][r] = rnext;
+                wave_lds_fence();
+                chunk_end += DCHUNK;
+                dnext = load_udesc_raw(S.udesc, min(chunk_end + r, last)); rnext = urw[min(chunk_end + r, last)];
+            }
+            const int j0 = u - (chunk_end - DCHUNK);
+            uint2 d[UB]; unsigned rw[UB]; vec_t xv[UB];
+#pragma unroll
+            for (int k = 0; k < UB; k++) { d[k] = sd[2 * (j0 + k)]; rw[k] = sr[2 * (j0 + k)]; }
+#pragma unroll
+            for (int k = 0; k < UB; k++) xv[k] = Xv[min((long long)(d[k].x & POOL_BASE_MASK) + (long long)((d[k].y >> (28 - 4 * (r & 7))) & 15u), xlast) * Q];
+            val_t vn[UB];
+            load_grp(u + UB, vn);
+#pragma unroll
+            for (int k = 0; k < UB; k++) {
+                const val_t vk = (u + k < unit_end) ? v[k] : (val_t)0;
+                const unsigned kr = (d[k].x >> POOL_KR_SHIFT) & 7u, rn = (rw[k] >> (28 - 4 * (r & 7))) & 15u;
+#pragma unroll
+                for (int j = 0; j < NV; j++) atomicAdd(&slab[kr][q * NV + j][rn], (lacc_t)(vk * xv[k].v[j]));
+            }
+#pragma unroll
+            for (int k = 0; k < UB; k++) v[k] = vn[k];
+        }
+    }
+    wave_lds_fence();
+    // ---- results: this lane group's slice of the strip's rows
+    if (part >= 0) {
+        vec_t o;
+#pragma unroll
+        for (int j = 0; j < NV; j++) o.v[j] = (val_t)slab[0][q * NV + j][r];
+        reinterpret_cast<vec_t *>(partial)[((long long)part * 16 + r) * Q + q] = o;
+    } else {
+        for (int k = 0; k < nrows; k++) {
+            const long long yi = ((long long)row0 + k) * 16 + r;
+            if (yi < rowA) {
+                vec_t o;
+#pragma unroll
+                for (int j = 0; j < NV; j++) o.v[j] = (val_t)slab[k][q * NV + j][r];
+                if constexpr (sizeof(vec_t) == 16) { v4u_t w; __builtin_memcpy(&w, &o, 16); MV_STORE16(w, reinterpret_cast<v4u_t *>(&Yv[yi * Q])); }
+                else if constexpr (sizeof(vec_t) == 8) { v2u_t w; __builtin_memcpy(&w, &o, 8); __builtin_nontemporal_store(w, reinterpret_cast<v2u_t *>(&Yv[yi * Q])); }
+                else Yv[yi * Q] = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Multi-vector entry pass (round 3): Y[rows][NVT] += A_entries * X for plans whose COO entries run per workgroup (entry mode 2, 16 strips):
 // the same merged, column-ordered, packed lists k_units<.., 2> walks, two right-hand sides per pass (one 16-byte gather per entry and lane
 // in fp64), NVT / 2 passes over the workgroup's list (the list of a workgroup is ~80 KB: the later passes find it in L2).  Row sums of
@@ -1801,7 +1941,11 @@ static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense
         const size_t slab_bytes = (size_t)GROUPS_PER_BLOCK * slab * 16 * (NV < 2 ? NV : 2) * sizeof(lacc_t);
 #define TSPMV_MV(CD, NTS) hipLaunchKernelGGL((k_units_mv<NV, CD, NTS>), dim3((unsigned)((S.ntasks + strips - 1) / strips)), dim3(256), slab_bytes, st, \
                                              S, P.rowA, P.colA, xcd_chunk, entries_pass ? 1 : 0, slab, P.partial, X, Y)
-        if (S.cb_bits > 0) { if (S.nt_stream) TSPMV_MV(true, true); else TSPMV_MV(true, false); }
+        if (S.pooled) {   // pooled plans: their own multi-vector kernel (entries in-kernel: no entry pass, no dynamic slab)
+            const dim3 grid((unsigned)((S.ntasks + strips - 1) / strips));
+            if (S.nt_stream) hipLaunchKernelGGL((k_pool_mv<NV, true>), grid, dim3(256), 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, X, Y);
+            else hipLaunchKernelGGL((k_pool_mv<NV, false>), grid, dim3(256), 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, X, Y);
+        } else if (S.cb_bits > 0) { if (S.nt_stream) TSPMV_MV(true, true); else TSPMV_MV(true, false); }
         else { if (S.nt_stream) TSPMV_MV(false, true); else TSPMV_MV(false, false); }
 #undef TSPMV_MV
     }
@@ -1809,7 +1953,7 @@ static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense
         hipLaunchKernelGGL((k_dense_mfma_mv<NV>), dim3((DN.nrows + 3) / 4), dim3(256), 0, st, DN, P.rowA, P.colA, P.partial, X, Y);
     if (P.nfix > 0)
         hipLaunchKernelGGL((k_fixup_split_mv<NV>), dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, Y);
-    if (entries_pass && S.ntasks > 0)   // Y += entries (after the units, the dense pass and the split-row sums have written Y)
+    if (entries_pass && !S.pooled && S.ntasks > 0)   // Y += entries (after the units, the dense pass and the split-row sums have written Y)
         hipLaunchKernelGGL((k_entries_mv<NV>), dim3((unsigned)((S.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), dim3(256), 0, st, S, P.rowA, X, Y);
     return hipGetLastError();
 }

@@ -890,14 +890,14 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
     // native multi-vector kernels: unit-stream plans whose COO entries run in-tile and whose CSR tiles were split into units
     // (the defaults).  Generation-1 plans, whole-tile passes and the CSR fallback go one right-hand side at a time.
     const int mv_native = plan->mv_native;   // 1 / 0: force the multi-vector kernel / the one-at-a-time path on entry-dominated plans
-    const bool has_native = plan->kernel == TILESPMV_KERNEL_STREAM && plan->dev.ntasks == 0 && plan->dev.f_nblk == 0 && !plan->pooled;
+    const bool has_native = plan->kernel == TILESPMV_KERNEL_STREAM && plan->dev.ntasks == 0 && plan->dev.f_nblk == 0;   // (pooled plans have k_pool_mv since round 5)
     // entry-dominated plans (round 3, final): the multi-vector kernel scatters a strip's entries up front (entry slab, mv_slab_rows), which beats going one right-hand side
     // at a time at every nvec (webbase stand-in 37 / 58 / 93 us against 42 / 85 / 223) and beats the separate entry pass over the merged lists (k_entries_mv; workgroup entry mode,
     // 16 strips, no x windows) from nvec 4 on (power-law 8 M: 0.254 / 0.375 / 0.678 ms against 0.198 / 0.469 / 1.364 with the pass): the pass stays for nvec 2.
     // mv_native: -1 by rule, 0 one right-hand side at a time, 1 the multi-vector kernel alone, 2 the multi-vector kernel + entry pass
-    const bool can_pass = has_native && plan->entry_mode == 2 && plan->wg_strips == 16 && plan->xwin_lds_bytes == 0;
+    const bool can_pass = has_native && plan->entry_mode == 2 && plan->wg_strips == 16 && plan->xwin_lds_bytes == 0 && !plan->pooled;
     const bool entries_pass = can_pass && (mv_native == 2 || (mv_native < 0 && plan->mv_by_columns && nvec < 4));
-    const bool one_at_a_time = !has_native || mv_native == 0 || (mv_native < 0 && plan->mv_by_columns && !entries_pass && plan->mv_slab_rows == 0 && nvec < 8);
+    const bool one_at_a_time = !has_native || mv_native == 0 || (mv_native < 0 && !plan->pooled && plan->mv_by_columns && !entries_pass && plan->mv_slab_rows == 0 && nvec < 8);
     if (one_at_a_time) {
         hipStream_t st = (hipStream_t)stream;
         // leading dimensions of the column copies: multiples of 16 elements, so that every column of X / Y starts 64- / 128-byte

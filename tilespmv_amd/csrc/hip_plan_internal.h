@@ -92,7 +92,7 @@ struct tilespmv_plan {
     bool mv_by_columns = false;              // ... and plans whose work is mostly COO entries (the multi-vector kernel walks them per 16-lane strip)
     int mv_native = -1, mv_xcd_chunk = -1;   // knobs of tilespmv_plan_spmm (Knobs)
     int mv_slab_rows = 0;                    // > 0: the multi-vector kernel scatters a strip's entries up front into an LDS slab of this many tile-rows per lane group
-    bool pooled = false;                // every unit is a pooled unit (hip_plan.h): k_units<.., POOL>; no native multi-vector kernel yet
+    bool pooled = false;                // every unit is a pooled unit (hip_plan.h): k_units<.., POOL>, k_pool_mv
     int entry_mode = 0;                 // COO entry lists walked per 16-lane strip (0), per wavefront (1) or per workgroup, column-ordered (2)
     std::vector<void *> allocs;
     std::vector<std::pair<void *, size_t>> arena_blocks;   // the blocks the plan's streams were carved from (and the partial-slot array), with their sizes: what a re-placement moves
@@ -191,6 +191,7 @@ struct tilespmv_plan {
         for (VmmRange &R : vmm) vmm_release(R);
         vmm.clear();
     }
+    size_t arena_used = 0;              // bytes handed out by upload() so far
     char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20, arena_next = (size_t)1 << 20, size_hint = 0;   // bump allocator of upload(); size_hint = the builder's estimate of the plan's bytes
     bool dry = false;                   // layout-digest build: no HIP call, streams are hashed instead of uploaded
     long long list_records = 0;         // records of the merged entry lists (workgroup entry mode)
@@ -224,7 +225,11 @@ struct tilespmv_plan {
         // page-table fragments whatever state the allocator is in (fewer hipMalloc calls, too).
         const size_t need = (std::max<size_t>(n, 1) * sizeof(T) + 256 + 255) / 256 * 256 + arena_skew;   // (arena_skew: experiment knob, bytes left unused behind every stream)
         if (need > arena_left) {   // blocks of arena_block bytes (256 MB) for plans of that size and more; a smaller plan gets one block of about its own size (size_hint)
-            const size_t want = size_hint >= arena_block ? arena_block : std::max<size_t>(arena_next, size_hint + size_hint / 4 + ((size_t)1 << 20));
+            // ... and the LAST blocks of a large plan are sized by what the builder still expects to upload (round 5: config 4's plan is 689 MB — its third 256-MB block was
+            // followed by a fourth for the last few MB of task records, and allocating + zeroing that block was 90 ms of a 260-ms plan creation)
+            const size_t left_hint = size_hint > arena_used ? size_hint - arena_used : 0;
+            const size_t tail = std::max<size_t>((size_t)32 << 20, left_hint + left_hint / 8 + ((size_t)4 << 20));
+            const size_t want = size_hint >= arena_block ? std::min(arena_block, tail) : std::max<size_t>(arena_next, size_hint + size_hint / 4 + ((size_t)1 << 20));
             const size_t blk = std::max<size_t>(need, std::min(want, arena_block));
             arena_next = std::min<size_t>(arena_next * 4, std::max<size_t>(arena_block, 1));
             void *b = nullptr;
@@ -236,7 +241,7 @@ struct tilespmv_plan {
             arena_blocks.push_back({b, blk});
             arena_at = (char *)b; arena_left = blk;
         }
-        d = arena_at; arena_at += need; arena_left -= need;
+        d = arena_at; arena_at += need; arena_left -= need; arena_used += need;
         if (n && host) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
         info[TILESPMV_INFO_DEVICE_BYTES] += (long long)(n * sizeof(T));
         info[TILESPMV_INFO_UPLOAD_US] += (long long)(now_us() - t0);

@@ -9,6 +9,7 @@
 //     Tile_matrix API exposes (the reference overflows silently, e.g. :912);
 //   * threads come from std::thread (no OpenMP runtime dependency).
 // What each output field means: SURVEY.md Appendix A.  Selection rules: src/csr2tile.h:143-325.
+#include <sys/time.h>
 #include <cmath>
 
 #include "host_util.h"
@@ -139,6 +140,10 @@ void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *ro
                       const val_t *vals, unsigned flags)
 {
     memset(T, 0, sizeof(*T));
+    const bool tverbose = getenv("TILESPMV_CREATE_VERBOSE") != nullptr;   // per-phase milliseconds on stderr
+    auto now_ms = [] { timeval t; gettimeofday(&t, NULL); return t.tv_sec * 1e3 + t.tv_usec * 1e-3; };
+    double tprev = now_ms();
+    auto lap = [&](const char *what) { if (!tverbose) return; const double now = now_ms(); fprintf(stderr, "tilespmv: Tile_create %s %.1f ms\n", what, now - tprev); tprev = now; };
     const bool allow_hyb = flags & TILESPMV_CREATE_HYB, cdna4 = flags & TILESPMV_CREATE_CDNA4;
     const int tilem = (rowA + BS - 1) / BS, tilen = (colA + BS - 1) / BS;
     T->tilem = tilem; T->tilen = tilen;
@@ -173,6 +178,7 @@ void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *ro
     int *ent = zalloc<int>((size_t)nnz_used);        // CSR position of each entry, tile order
     uint8_t *lrc = zalloc<uint8_t>((size_t)nnz_used);  // (local row << 4) | local col, tile order
 
+    lap("pass 1 (tiles per tile-row)");
     // ---- pass 2: tile list (ascending column block), per-row counts and the tile-ordered gather.
     // Because tiles are numbered tile-row-major, the nonzeros of tile-row bi occupy the same
     // index range [rowptr[16bi], rowptr[16bi+16)) before and after the gather.
@@ -210,6 +216,7 @@ void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *ro
     T->tile_nnz[tilenum] = (int)nnz_used;
     for (auto *s : scratch) delete s;
 
+    lap("pass 2 (tile columns, tile-ordered gather)");
     // ---- per-tile metadata + format selection
     T->Format = zalloc<char>(tilenum);
     T->blknnz = zalloc<int>(np1);
@@ -248,11 +255,20 @@ void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *ro
             }
         }
     });
+    lap("format selection");
     int64_t hybell = 0;
-    for (int bi = 0; bi < tilem; bi++) {
-        const int rowlen = tile_rowlen(bi, tilem, rowA);
-        for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++)
-            if (T->Format[t] == TILESPMV_FMT_HYB) hybell += (int64_t)T->tilewidth[t] * rowlen;
+    {
+        std::vector<int64_t> part((size_t)host_threads(), 0);
+        parallel_chunks(tilem, 4096, [&](int64_t b, int64_t e, int tid) {
+            int64_t acc = 0;
+            for (int bi = (int)b; bi < (int)e; bi++) {
+                const int rowlen = tile_rowlen(bi, tilem, rowA);
+                for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++)
+                    if (T->Format[t] == TILESPMV_FMT_HYB) acc += (int64_t)T->tilewidth[t] * rowlen;
+            }
+            part[(size_t)tid] += acc;
+        });
+        for (int64_t v : part) hybell += v;
     }
     int *scans[] = { T->csr_offset, T->csrptr_offset, T->coo_offset, T->ell_offset, T->hyb_offset, T->dns_offset,
                      T->dnsrow_offset, T->dnscol_offset, T->dnsrowptr, T->dnscolptr, T->hyb_coocount,
@@ -260,18 +276,14 @@ void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *ro
     static const char *names[] = { "csr_offset", "csrptr_offset", "coo_offset", "ell_offset", "hyb_offset", "dns_offset",
                                    "dnsrow_offset", "dnscol_offset", "dnsrowptr", "dnscolptr", "hyb_coocount",
                                    "new_coocount", "blknnz" };
-    {
-        std::vector<std::thread> th;
-        for (size_t k = 0; k < sizeof(scans) / sizeof(*scans); k++)
-            th.emplace_back([&, k] { exclusive_scan_checked(scans[k], (int64_t)np1, names[k]); });
-        for (auto &t : th) t.join();
-    }
+    exclusive_scan_checked_multi(scans, names, (int)(sizeof(scans) / sizeof(*scans)), (int64_t)np1);
     T->csrsize = T->csr_offset[tilenum]; T->csrptrlen = T->csrptr_offset[tilenum];
     T->coosize = T->coo_offset[tilenum]; T->ellsize = T->ell_offset[tilenum];
     T->hybsize = T->hyb_offset[tilenum]; T->hybellsize = (int)hybell; T->hybcoosize = T->hyb_coocount[tilenum];
     T->dnssize = T->dns_offset[tilenum]; T->dnsrowsize = T->dnsrow_offset[tilenum];
     T->dnscolsize = T->dnscol_offset[tilenum]; T->coototal = T->new_coocount[tilenum];
 
+    lap("scans");
     // ---- payload arrays
     T->Blockcsr_Val = zalloc<val_t>(T->csrsize);
     T->Blockcsr_Ptr = zalloc<unsigned char>(T->csrptrlen);
@@ -297,6 +309,7 @@ void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *ro
     int *x_col = zalloc<int>(T->coototal);
     val_t *x_val = zalloc<val_t>(T->coototal);
 
+    lap("payload allocation");
     // ---- pass 3: pack every tile into its format's arrays (src/csr2tile.h:420-622) and, per
     // tile-row, turn its slice of the extracted list into CSR rows (src/csr2tile.h:899-960).
     parallel_chunks(tilem, 128, [&](int64_t b, int64_t e, int) {
@@ -375,7 +388,7 @@ void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *ro
             for (int i = x0; i < x1; i++) T->deferredcoo_ptr[bi * BS + x_row[i]]++;
         }
     });
-    exclusive_scan_checked(T->deferredcoo_ptr, (int64_t)rowA + 1, "deferredcoo_ptr");
+    { int *one[] = {T->deferredcoo_ptr}; static const char *nm[] = {"deferredcoo_ptr"}; exclusive_scan_checked_multi(one, nm, 1, (int64_t)rowA + 1); }
     parallel_chunks(tilem, 256, [&](int64_t b, int64_t e, int) {
         for (int bi = (int)b; bi < (int)e; bi++) {
             const int rowlen = tile_rowlen(bi, tilem, rowA);
@@ -414,9 +427,9 @@ void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *ro
             }
         }
     }
-    free(csr_col); free(ell_col); free(hyb_col); free(hyb_row);
-    free(x_row); free(x_col); free(x_val);
-    free(cnt_row); free(ent); free(lrc);
+    lap("pass 3 (packing, extraction, nibble streams)");
+    free_later({csr_col, ell_col, hyb_col, hyb_row, x_row, x_col, x_val, cnt_row, ent, lrc});   // (0.5 GB for config 4: given back on a detached thread)
+    lap("frees");
 }
 
 }  // namespace tilespmv

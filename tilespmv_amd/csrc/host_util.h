@@ -10,6 +10,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
+
 #include "../../include/tilespmv.h"
 
 namespace tilespmv {
@@ -56,6 +58,17 @@ inline T *zalloc(size_t n)
 {
     T *p = (T *)calloc(n ? n : 1, sizeof(T));
     if (!p) { fprintf(stderr, "tilespmv: out of host memory (%zu x %zu bytes)\n", n, sizeof(T)); exit(2); }
+    // Large arrays: ask for transparent huge pages (round 5; what numpy does for its own large arrays).  A calloc of this size is a fresh anonymous mapping that is zeroed page
+    // by page at first touch: the per-tile arrays of config 4's Tile_matrix (1.5 GB) and the plan builder's staging arrays cost 4-KB page faults by the hundred thousand — on the
+    // GPU box's host 2/3 of Tile_create's time and 1/3 of plan creation's (config 4: 0.26 -> 0.08-0.14 s and 0.31 -> 0.19 s, scripts/rounds/r5_hugepages.sh); with THP in
+    // "madvise" mode (this image) the advice turns them into 2-MB faults.  Still plain malloc memory: the caller frees it with free() as the reference's API requires.
+    // TILESPMV_HUGEPAGES=0 switches the advice off (a host whose memory is too fragmented to have huge pages at hand compacts synchronously inside such a fault).
+    static const bool thp = [] { const char *e = getenv("TILESPMV_HUGEPAGES"); return !(e && *e && atoi(e) == 0); }();
+    const size_t bytes = n * sizeof(T);
+    if (thp && bytes >= ((size_t)8 << 20)) {
+        const uintptr_t lo = ((uintptr_t)p + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1), hi = ((uintptr_t)p + bytes) & ~(((uintptr_t)2 << 20) - 1);
+        if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+    }
     return p;
 }
 
@@ -70,6 +83,52 @@ inline void exclusive_scan_checked(int *a, int64_t n, const char *what)
         a[i] = (int)run;
         run += v;
     }
+}
+
+// The same scan for K arrays of n ints at once, in parallel (round 5: Tile_create ran its 13 per-tile scans as 13 serial loops on 13 threads — 140 ms of config 4's 570 ms on
+// 8 cores — and the scan of deferredcoo_ptr as one serial loop): pass A sums every array over chunks, a serial prefix over the chunk sums, pass B scans every chunk in place from
+// its offset.  Same result, same abort on a prefix that leaves the int range.
+inline void exclusive_scan_checked_multi(int *const *arrays, const char *const *names, int K, int64_t n)
+{
+    const int64_t chunk = std::max<int64_t>(1 << 14, (n + 4LL * host_threads() - 1) / (4LL * host_threads()));
+    const int64_t nch = (n + chunk - 1) / chunk;
+    std::vector<int64_t> sums((size_t)(nch * K), 0);
+    parallel_chunks(nch, 1, [&](int64_t b, int64_t e, int) {
+        for (int64_t c = b; c < e; c++)
+            for (int k = 0; k < K; k++) {
+                const int *a = arrays[k];
+                int64_t run = 0;
+                for (int64_t i = c * chunk; i < std::min(n, (c + 1) * chunk); i++) run += a[i];
+                sums[(size_t)(c * K + k)] = run;
+            }
+    });
+    for (int k = 0; k < K; k++) {
+        int64_t run = 0;
+        for (int64_t c = 0; c < nch; c++) { const int64_t v = sums[(size_t)(c * K + k)]; sums[(size_t)(c * K + k)] = run; run += v; }
+    }
+    std::atomic<int> overflow(-1);
+    parallel_chunks(nch, 1, [&](int64_t b, int64_t e, int) {
+        for (int64_t c = b; c < e; c++)
+            for (int k = 0; k < K; k++) {
+                int *a = arrays[k];
+                int64_t run = sums[(size_t)(c * K + k)];
+                for (int64_t i = c * chunk; i < std::min(n, (c + 1) * chunk); i++) {
+                    const int v = a[i];
+                    if (run > INT32_MAX) overflow.store(k);
+                    a[i] = (int)run;
+                    run += v;
+                }
+            }
+    });
+    if (overflow.load() >= 0) { fprintf(stderr, "tilespmv: %s exceeds the int32 offsets of Tile_matrix\n", names[overflow.load()]); exit(2); }
+}
+
+// free() of large temporaries on a detached thread (munmap of hundreds of MB takes tens of milliseconds)
+inline void free_later(std::vector<void *> ptrs)
+{
+    ptrs.erase(std::remove(ptrs.begin(), ptrs.end(), (void *)nullptr), ptrs.end());
+    if (ptrs.empty()) return;
+    std::thread([ptrs]() { for (void *q : ptrs) free(q); }).detach();
 }
 
 inline int tile_rowlen(int bi, int tilem, int rowA) { return bi == tilem - 1 ? rowA - (tilem - 1) * BS : BS; }
