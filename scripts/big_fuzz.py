@@ -19,7 +19,14 @@ def make(rng, kind):
     if kind == 4: n = int(rng.integers(200_000, 1_000_000)); return "circuit%d" % n, G.circuit_like(n, seed=int(rng.integers(1 << 30)))
     if kind == 5: nb = int(rng.integers(2_000, 20_000)); return "blockdiag%d" % nb, G.block_diag_plus_sparse(nb, int(rng.integers(20, 70)), int(rng.integers(1, 5)), int(rng.integers(1 << 30)))
     if kind == 6: n = int(rng.integers(400, 1400)); return "lap5_%d" % n, G.laplacian5pt(n)
-    n = int(rng.integers(200_000, 1_500_000)); return "band%d" % n, G.band(n, int(rng.integers(2, 48)))
+    if kind == 7: n = int(rng.integers(200_000, 1_500_000)); return "band%d" % n, G.band(n, int(rng.integers(2, 48)))
+    # round 5: the mesh classes (FEM with 1-6 unknowns per node, shells, triangulations, tetrahedral meshes, road-like graphs), natural order or shuffled inside windows
+    sh = int(rng.choice([0, 0, 16, 64, 512, 4096])); sd = int(rng.integers(1 << 30))
+    if kind == 8: k = int(rng.integers(14, 40)); d = int(rng.integers(1, 7)); return "fem%d_%d s%d" % (d, k, sh), G.fem_hex(k, k + int(rng.integers(0, 5)), k, d, shuffle=sh, seed=sd)
+    if kind == 9: k = int(rng.integers(150, 500)); d = int(rng.integers(1, 7)); return "shell%d_%d s%d" % (d, k, sh), G.fem_hex(k, k, 1, d, shuffle=sh, seed=sd)
+    if kind == 10: k = int(rng.integers(400, 1500)); return "tri%d s%d" % (k, sh), G.tri_mesh(k, k + 3, shuffle=sh, seed=sd)
+    if kind == 11: k = int(rng.integers(40, 110)); return "tet%d s%d" % (k, sh), G.tet_mesh(k, dof=int(rng.integers(1, 3)), shuffle=sh, seed=sd)
+    k = int(rng.integers(600, 2000)); return "road%d s%d" % (k, sh), G.road_like(k, k, shuffle=sh, seed=sd)
 
 
 def knobs(rng):
@@ -40,6 +47,10 @@ def knobs(rng):
     if rng.random() < 0.3: kw.update(xcd_remap=int(rng.choice([0, 2])), xcd_chunk=int(rng.choice([8, 32, 64])))
     if rng.random() < 0.2: kw["placement_tries"] = 2
     if rng.random() < 0.2: kw["dense_mode"] = int(rng.choice([api.DENSE_MFMA, api.DENSE_VALU]))
+    r = rng.random()      # round 5: what CSR-format tiles become — forced pooled / forced split on a third of the plans each way, the byte model's choice otherwise
+    if r < 0.3: kw["csr_split"] = 2
+    elif r < 0.45: kw["csr_split"] = 1
+    if rng.random() < 0.15: kw["deterministic"] = 1
     return kw
 
 
@@ -50,7 +61,7 @@ def main():
     t0 = time.time()
     for i in range(nmat):
         rng = np.random.default_rng(seed0 + i)
-        name, (m, n, rp, ci) = make(rng, (seed0 + i) % 8)
+        name, (m, n, rp, ci) = make(rng, (seed0 + i) % 13)
         rows = (m // 16) * 16; nnz = int(rp[rows])
         for dt in (np.float64, np.float32):
             vals = rng.integers(1, 4, len(ci)).astype(dt); x = rng.integers(0, 4, n).astype(dt)
@@ -72,8 +83,8 @@ def main():
                 y = yd.cpu().numpy()
                 ok = bool(np.array_equal(y[:rows].astype(np.float64), want)) and bool((y[rows:] == -9.0).all())
                 bad += not ok
-                print("%-22s %s rows %8d nnz %9d  %s  shards %d  panels %s slices %s merge %s  %s" % (name, np.dtype(dt).name, rows, nnz, "ok  " if ok else "MISMATCH", len(cuts) - 1,
-                      [q["x_panels"] for q in infos], [q["x_slice_passes"] for q in infos], [q["x_panel_merge"] for q in infos], kw), flush=True)
+                print("%-22s %s rows %8d nnz %9d  %s  shards %d  form %s panels %s slices %s merge %s  %s" % (name, np.dtype(dt).name, rows, nnz, "ok  " if ok else "MISMATCH", len(cuts) - 1,
+                      [q["csr_form"] for q in infos], [q["x_panels"] for q in infos], [q["x_slice_passes"] for q in infos], [q["x_panel_merge"] for q in infos], kw), flush=True)
             api.Tile_destroy(tm)
     print("BIG FUZZ: %d matrices, %d plans, %d mismatches, %.0f s" % (nmat, plans, bad, time.time() - t0))
     sys.exit(1 if bad else 0)

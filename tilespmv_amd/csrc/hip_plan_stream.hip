@@ -274,7 +274,10 @@ void StreamBuilder::count()
     // (a caller who asks for a launch form that exists for the classic units only — column panels / slices, pacing, 512-thread workgroups, LDS x windows, a forced dictionary —
     //  gets the classic units)
     const bool classic_asked = K.x_panel_kb > 0 || K.x_slice_passes > 0 || K.pace > 0 || K.wg_strips == 32 || K.x_window == 1 || K.desc_dict == 1;
-    if (K.csr_split < 0 && !classic_asked && (long long)T->csr_offset[t_end] - T->csr_offset[t_begin] > 0) {
+    // (nor is the second count worth its time where CSR tiles hold less than 3 % of the shard's stored values — the KKT stand-in: under 1 %; the band matrix's 5 % is worth it —: the pooled form pays 8-16 bytes more per
+    //  unit on everything else and cannot come out 5 % ahead)
+    const long long csr_vals = (long long)T->csr_offset[t_end] - T->csr_offset[t_begin], all_vals = (long long)T->blknnz[t_end] - T->blknnz[t_begin];
+    if (K.csr_split < 0 && !classic_asked && csr_vals > 0 && csr_vals * 33 >= all_vals) {
         std::vector<RowCount> alt;
         count_all(2, alt);
         long long u1 = 0, e1 = 0, u2 = 0, e2 = 0;
