@@ -45,6 +45,7 @@
 #define TSPMV_DIAG_UNITS_LDS_PAD
 #define TSPMV_DIAG_UNIT_GATHER_SKIP(k) false
 #define TSPMV_DIAG_POOL_ADD(dest, prod) false
+#define TSPMV_DIAG_POOL_X(load, d) (load)
 #define TSPMV_DIAG_XCD_ZERO 1
 #define TSPMV_DIAG_XCD_TRIP 1
 #define TSPMV_DIAG_XCD_SKIP_ADDS
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
 #pragma unroll
             for (int k = 0; k < UB; k++) rw[k] = sr[2 * (j0 + k)];
 #pragma unroll
-            for (int k = 0; k < UB; k++) xv[k] = x[min((long long)(d[k].x & POOL_BASE_MASK) + (long long)((d[k].y >> (28 - 4 * (r & 7))) & 15u), xlast)];
+            for (int k = 0; k < UB; k++) xv[k] = TSPMV_DIAG_POOL_X(x[min((long long)(d[k].x & POOL_BASE_MASK) + (long long)((d[k].y >> (28 - 4 * (r & 7))) & 15u), xlast)], d[k]);
             return;
         }
 #pragma unroll

@@ -63,6 +63,15 @@
 #define TSPMV_DIAG_POOL_ADD(dest, prod) false
 #endif
 
+// TILESPMV_POOL_ABL 4: no x gather (the value is made from the descriptor word: the loads of values, descriptors and row nibbles stay), 6: the gather reads x at the window's first column only (one line per strip)
+#if defined(TILESPMV_POOL_ABL) && TILESPMV_POOL_ABL == 4
+#define TSPMV_DIAG_POOL_X(load, d) ((val_t)((d).x & 3u))
+#elif defined(TILESPMV_POOL_ABL) && TILESPMV_POOL_ABL == 6
+#define TSPMV_DIAG_POOL_X(load, d) (x[min((long long)((d).x & POOL_BASE_MASK), xlast)])
+#else
+#define TSPMV_DIAG_POOL_X(load, d) (load)
+#endif
+
 // ---- k_entries_xcd: XCD_ABL 1 no adds to y, 2 no zeroing of the slab, 3 neither and no trip at all (the skeleton: ranges, tasks, barriers)
 #if defined(XCD_ABL) && XCD_ABL == 2
 #define TSPMV_DIAG_XCD_ZERO 0
