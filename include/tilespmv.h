@@ -344,7 +344,9 @@ const char *tilespmv_plan_options_layout(void);
  * usable — there is no CPU fallback behind this entry point.
  * Plan creation allocates, copies and synchronises (it always did); since round 4 it may also TIME a few launches of the finished plan on the default stream with scratch
  * x / y of its own: plans of >= 1 GB try up to `placement_tries` memory placements, shards with column panels recorded choose the panels per pass, opt-in paced plans
- * calibrate their timetable.  Every such choice has a knob that fixes it (placement_tries = 1, x_panel_merge + x_slice_passes, pace_period_us) — a fixed choice times nothing. */
+ * calibrate their timetable.  Every such choice has a knob that fixes it (placement_tries = 1, x_panel_merge + x_slice_passes, pace_period_us) — a fixed choice times nothing;
+ * `deterministic = 1` fixes them all.  Since round 5 the value stream's final layout is written by a kernel (the emitted values are uploaded to a scratch buffer first): peak device
+ * memory during creation = the plan + one more copy of its unit values (freed before the call returns); TILESPMV_ENCODE_ON_HOST=1 keeps that pass on the host. */
 int tilespmv_plan_create(tilespmv_plan **plan, const Tile_matrix *matrix, int rowA, int colA,
                          MAT_PTR_TYPE nnzA, const tilespmv_plan_options *opts);
 void tilespmv_plan_destroy(tilespmv_plan *plan);
