@@ -82,6 +82,8 @@ def load(dtype=np.float64):
     lib.Tile_create.restype = None
     lib.Tile_create_ex.argtypes = [TP, C.c_int, C.c_int, C.c_int, _I, _I, VP, C.c_uint]
     lib.Tile_create_ex.restype = None
+    lib.Tile_create_device.argtypes = [TP, C.c_int, C.c_int, C.c_int, _I, _I, VP, C.c_uint]
+    lib.Tile_create_device.restype = C.c_int
     lib.Tile_destroy.argtypes = [TP]
     lib.Tile_destroy.restype = None
     lib.tilespmv_cpu.argtypes = [TP, _I, _I, _I, C.POINTER(_U), C.POINTER(_I), C.POINTER(_I), C.c_int, C.c_int, C.c_int,
@@ -154,4 +156,5 @@ DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_c
                     "tilespmv_device_count", "tilespmv_matrix_save", "tilespmv_matrix_load", "tilespmv_plan_spmv_n",
                     "call_tilespmv_hip_multi", "tilespmv_plan_spmm", "tilespmv_plan_time_spmm", "tilespmv_plan_options_init", "tilespmv_plan_layout_digest",
                     "tilespmv_csr_save", "tilespmv_csr_load", "mmio_allinone_cached", "tilespmv_mtx_write",
-                    "tilespmv_plan_time_reference_style", "tilespmv_plan_reserve_spmm", "tilespmv_plan_options_layout", "tilespmv_plan_layout_stages"]
+                    "tilespmv_plan_time_reference_style", "tilespmv_plan_reserve_spmm", "tilespmv_plan_options_layout", "tilespmv_plan_layout_stages",
+                    "Tile_create_device"]

@@ -51,6 +51,22 @@ def Tile_create(rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, h
     return tm
 
 
+def Tile_create_device(rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, quiet=True, cdna4=False):
+    """``Tile_create`` computed on the GPU (hip_tile_create.hip): the CSR arrays go up, the tiled matrix comes back, byte for byte what ``Tile_create`` builds.
+    No CPU fallback: raises when no device is visible (rc -1); HYB tiles are a host-only option."""
+    dtype = np.dtype(dtype or np.asarray(csrValA).dtype)
+    lib = _lib.load(dtype)
+    rp, ci, v = _csr(lib, csrRowPtrA, csrColIdxA, csrValA)
+    tm = lib._TM()
+    flags = (CREATE_QUIET if quiet else 0) | (CREATE_CDNA4 if cdna4 else 0)
+    rc = lib.Tile_create_device(C.byref(tm), rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int), _p(v, lib._vt), flags)
+    if rc != 0:
+        raise RuntimeError("Tile_create_device failed (%d): no usable HIP device / extension, or offsets beyond int32" % rc)
+    tm._keep = (rp, ci, v)
+    tm._lib = lib
+    return tm
+
+
 def Tile_destroy(tm):
     tm._lib.Tile_destroy(C.byref(tm))
 

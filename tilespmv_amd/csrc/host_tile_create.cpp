@@ -13,111 +13,10 @@
 #include <cmath>
 
 #include "host_util.h"
+#include "tile_select.h"
 
 namespace tilespmv {
 namespace {
-
-struct Choice { int fmt = 0, stored = 0, width = 0, ndr = 0, ndc = 0, hybcoo = 0, extracted = 0, csrptr = 0; };
-
-// One tile.  cnt_row[r]: entries in local row r.  lrc: (row<<4|col) byte of each entry.
-Choice select_format(int nnz, int rowlen, int collen, const uint8_t *cnt_row, const uint8_t *lrc, bool allow_hyb, bool cdna4)
-{
-    Choice c;
-    if (cdna4) {
-        // TILESPMV_CREATE_CDNA4 (opt-in; SURVEY S8 f3, selection side): the reference's thresholds (dense at 75 % fill, COO up to
-        // COO_NNZ_TH entries, ELL at a row-length variation of 0.2: src/csr2tile.h:150,159,267-270) were tuned for the byte costs of
-        // its 32-lane kernels.  Here every format runs as 16-value units (12-byte descriptor + 16 values) plus 13- / 9-byte entries,
-        // so the choice is made by those bytes: w = the unit width that minimises units + remainder entries; w = 0 -> COO (while it
-        // fits the reference's COO tile), w = widest row -> ELL, in between CSR (which the plan splits at that very w); dense when
-        // 16 whole columns are cheaper than that.  Whole-row / whole-column tiles keep the reference rule (exact patterns only).
-        const int sv = (int)sizeof(val_t);
-        const long long unit_b = 12 + 16LL * sv, entry_b = sv + 5;
-        int widest = 0;
-        for (int r = 0; r < rowlen; r++) widest = std::max<int>(widest, cnt_row[r]);
-        int best_w = 0; long long best = entry_b * nnz;
-        for (int w = 1; w <= widest; w++) {
-            int rem = 0;
-            for (int r = 0; r < rowlen; r++) rem += std::max(0, (int)cnt_row[r] - w);
-            const long long b = unit_b * w + entry_b * rem;
-            if (b < best) { best = b; best_w = w; }
-        }
-        if ((long long)collen * unit_b <= best) { c.fmt = TILESPMV_FMT_DNS; c.stored = rowlen * collen; return c; }
-        if (nnz % collen == 0 || nnz % rowlen == 0) {
-            Choice r = select_format(nnz, rowlen, collen, cnt_row, lrc, false, false);
-            if (r.fmt == TILESPMV_FMT_DNSROW || r.fmt == TILESPMV_FMT_DNSCOL) return r;
-        }
-        if (best_w == 0 && nnz <= TILESPMV_COO_NNZ_TH) { c.fmt = TILESPMV_FMT_COO; c.stored = nnz; c.extracted = nnz; return c; }
-        if (best_w == widest && widest > 0) { c.fmt = TILESPMV_FMT_ELL; c.width = widest; c.stored = widest * rowlen; return c; }
-        c.fmt = TILESPMV_FMT_CSR; c.stored = nnz; c.csrptr = rowlen;
-        return c;
-    }
-    if (nnz >= (int)(rowlen * collen * 0.75)) {  // near-dense tile stored dense (src/csr2tile.h:150-158)
-        c.fmt = TILESPMV_FMT_DNS; c.stored = rowlen * collen; return c;
-    }
-    if (nnz <= TILESPMV_COO_NNZ_TH) {  // very sparse tile: COO + copy into the extracted matrix (:159-168)
-        c.fmt = TILESPMV_FMT_COO; c.stored = nnz; c.extracted = nnz; return c;
-    }
-    if (nnz % collen == 0 || nnz % rowlen == 0) {  // candidates for whole-row / whole-column storage (:169-242)
-        bool usable = false; int full = 0;
-        for (int r = 0; r < rowlen; r++) {
-            if (cnt_row[r] % collen) { usable = false; break; }
-            if (cnt_row[r] == collen) { usable = true; full++; }
-        }
-        if (usable) { c.fmt = TILESPMV_FMT_DNSROW; c.ndr = full; c.stored = full * collen; return c; }
-        uint8_t cnt_col[BS] = {0};
-        for (int k = 0; k < nnz; k++) cnt_col[lrc[k] & 15]++;
-        usable = false; full = 0;
-        for (int j = 0; j < collen; j++) {
-            if (cnt_col[j] % rowlen) { usable = false; break; }
-            if (cnt_col[j] == rowlen) { usable = true; full++; }
-        }
-        if (usable) { c.fmt = TILESPMV_FMT_DNSCOL; c.ndc = full; c.stored = full * rowlen; return c; }
-    }
-    int widest = 0;
-    for (int r = 0; r < rowlen; r++) widest = std::max<int>(widest, cnt_row[r]);
-    const double mean = ((double)nnz) / rowlen;
-    double var = 0.0;
-    for (int r = 0; r < rowlen; r++) { double d = (double)(cnt_row[r] - mean); var += d * d; }
-    var /= rowlen;
-    const double variation = std::sqrt(var) / mean;  // (:251-265)
-    if (variation <= 0.2) {  // regular rows: ELL padded to the widest row (:270-276)
-        c.fmt = TILESPMV_FMT_ELL; c.width = widest; c.stored = widest * rowlen; return c;
-    }
-    if (allow_hyb && variation >= 1.0) {  // dormant in the shipped reference (:279-316)
-        const int sv = (int)sizeof(val_t);
-        auto bytes = [&](int w, int spill) { return w * rowlen * sv + (w * rowlen + 1) / 2 + spill * (sv + 1); };
-        int hw = widest, best = bytes(widest, 0), best_spill = 0;
-        for (int w = widest - 1; w > 0; w--) {
-            int spill = 0;
-            for (int r = 0; r < rowlen; r++) spill += std::max(0, (int)cnt_row[r] - w);
-            int b = bytes(w, spill);
-            if (best <= b) { hw = w + 1; break; }
-            hw = w; best = b; best_spill = spill;
-        }
-        if (best_spill <= 4) {
-            c.fmt = TILESPMV_FMT_HYB; c.width = hw; c.hybcoo = best_spill;
-            c.stored = best_spill + hw * rowlen; c.extracted = best_spill; return c;
-        }
-    }
-    c.fmt = TILESPMV_FMT_CSR; c.stored = nnz; c.csrptr = rowlen;  // (:318-323)
-    return c;
-}
-
-// First-element-pivot partition sort of the reference (src/utils.h:103-137), restated so that
-// rows holding duplicate column ids come out in the same (unstable) order.
-void pivot_sort(int *key, val_t *val, int n)
-{
-    while (n > 1) {
-        const int pivot = key[0];
-        std::swap(key[0], key[n - 1]); std::swap(val[0], val[n - 1]);
-        int lo = 0;
-        for (int i = 0; i < n; i++)
-            if (key[i] < pivot) { std::swap(key[i], key[lo]); std::swap(val[i], val[lo]); lo++; }
-        std::swap(key[n - 1], key[lo]); std::swap(val[n - 1], val[lo]);
-        pivot_sort(key, val, lo);
-        key += lo + 1; val += lo + 1; n -= lo + 1;
-    }
-}
 
 struct RowScratch {
     std::vector<int> stamp, local, touched, cursor;
@@ -135,6 +34,22 @@ void pack_nibble_stream(const uint8_t *src, uint8_t *dst, int64_t n)
 }
 
 }  // namespace
+
+// First-element-pivot partition sort of the reference (src/utils.h:103-137), restated so that
+// rows holding duplicate column ids come out in the same (unstable) order.
+void pivot_sort(int *key, val_t *val, int n)
+{
+    while (n > 1) {
+        const int pivot = key[0];
+        std::swap(key[0], key[n - 1]); std::swap(val[0], val[n - 1]);
+        int lo = 0;
+        for (int i = 0; i < n; i++)
+            if (key[i] < pivot) { std::swap(key[i], key[lo]); std::swap(val[i], val[lo]); lo++; }
+        std::swap(key[n - 1], key[lo]); std::swap(val[n - 1], val[lo]);
+        pivot_sort(key, val, lo);
+        key += lo + 1; val += lo + 1; n -= lo + 1;
+    }
+}
 
 void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *rowptr, const int *colidx,
                       const val_t *vals, unsigned flags)
@@ -241,7 +156,8 @@ void tile_create_impl(Tile_matrix *T, int rowA, int colA, const MAT_PTR_TYPE *ro
             for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
                 const int collen = tile_collen(T->tile_columnidx[t], tilen, colA);
                 const int n = T->tile_nnz[t + 1] - T->tile_nnz[t];
-                Choice c = select_format(n, rowlen, collen, cnt_row + (size_t)t * BS, lrc + T->tile_nnz[t], allow_hyb, cdna4);
+                const uint8_t *cr = cnt_row + (size_t)t * BS, *lr = lrc + T->tile_nnz[t];
+                const Choice c = select_format(n, rowlen, collen, [cr](int r) { return (int)cr[r]; }, [lr](int k) { return (int)lr[k]; }, allow_hyb, cdna4);   // (tile_select.h: shared with the device builder)
                 T->Format[t] = (char)c.fmt;
                 T->blknnz[t] = c.stored;
                 T->blknnznnz[t] = (unsigned char)c.stored;

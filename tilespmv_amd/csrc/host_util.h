@@ -14,6 +14,13 @@
 
 #include "../../include/tilespmv.h"
 
+// functions shared by host code and device kernels (the .cpp sources are compiled as plain C++: there the qualifiers vanish)
+#if defined(__HIP__)
+#define TILESPMV_HD __host__ __device__
+#else
+#define TILESPMV_HD
+#endif
+
 namespace tilespmv {
 
 typedef MAT_VAL_TYPE val_t;
@@ -131,8 +138,11 @@ inline void free_later(std::vector<void *> ptrs)
     std::thread([ptrs]() { for (void *q : ptrs) free(q); }).detach();
 }
 
-inline int tile_rowlen(int bi, int tilem, int rowA) { return bi == tilem - 1 ? rowA - (tilem - 1) * BS : BS; }
-inline int tile_collen(int cb, int tilen, int colA) { return cb == tilen - 1 ? colA - (tilen - 1) * BS : BS; }
+TILESPMV_HD inline int tile_rowlen(int bi, int tilem, int rowA) { return bi == tilem - 1 ? rowA - (tilem - 1) * BS : BS; }
+TILESPMV_HD inline int tile_collen(int cb, int tilen, int colA) { return cb == tilen - 1 ? colA - (tilen - 1) * BS : BS; }
+
+// First-element-pivot partition sort of the reference (host_tile_create.cpp; also used by the device builder's download for rows of the extracted matrix that arrive unsorted)
+void pivot_sort(int *key, val_t *val, int n);
 
 // Row-block schedule of the reference (src/tilespmv_cpu.h:68-118); arrays are malloc'd.
 int build_rowblock_schedule(const Tile_matrix *T, unsigned int **rowidx, int **colstart, int **colstop);
