@@ -2,6 +2,7 @@
 #include <mutex>
 
 #include "hip_plan_internal.h"
+#include "plan_tile_ops.h"
 
 // ------------------------------------------------------------------------------------------------
 // Second-generation layout builder (hip_plan.h "unit stream").
@@ -10,107 +11,19 @@ namespace {
 
 struct RowCount { int nunits, ncoo, nheavy, ndense; long long hval, hidx; long long cost; };
 
-// A CSR tile is executed as w ELL-style units (the first w entries of every row) plus the rest of
-// its entries on the strip's COO list; w minimises the bytes moved (HYB's idea, src/csr2tile.h:279-306,
-// with this kernel's byte costs).  Returns w and the number of remainder entries.
-inline int csr_split_width(const unsigned char *ptr, int rowlen, int nnz, int *remainder)
+// One tile-row's counts: the sum of its tiles' (plan_tile_ops.h tile_count) plus, in pooled plans, its pool's windows.  `scratch`: room for the tile-row's stored nonzeros (pooled plans)
+inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, int coo_cost, const long long *hyb_off, std::vector<PoolEnt> &scratch)
 {
-    const long long unit_b = 16 + 16 * (long long)sizeof(val_t), entry_b = (long long)sizeof(val_t) + 5;
-    int len[16], wmax = 0;
-    for (int r = 0; r < 16; r++) { len[r] = r < rowlen ? ((r == rowlen - 1 ? nnz : ptr[r + 1]) - ptr[r]) : 0; wmax = std::max(wmax, len[r]); }
-    int best_w = 0, best_rem = nnz; long long best = entry_b * nnz;
-    for (int w = 1; w <= wmax; w++) {
-        int rem = 0;
-        for (int r = 0; r < 16; r++) rem += std::max(0, len[r] - w);
-        const long long b = unit_b * w + entry_b * rem;
-        if (b < best) { best = b; best_w = w; best_rem = rem; }
-    }
-    *remainder = best_rem;
-    return best_w;
-}
-
-// ---- pooled units (hip_plan.h): the nonzeros of a tile-row's CSR tiles, COO tiles and HYB remainders, in column-major order (column, then row; tiles are in
-// ascending column-block order and a tile's own nonzeros are bucketed by column nibble, so no comparison sort is needed)
-struct PoolEnt { unsigned col; unsigned row; val_t val; };   // global column, row inside the tile-row
-
-// Cuts a column-major run of pooled nonzeros into windows: a window starts at the first nonzero not yet taken and holds the (up to 16) following ones whose column is
-// less than 16 above its first column.  `col(i)` = column of nonzero i; `emit(begin, end)` is called once per window.
-template <class ColOf, class Emit>
-inline void pool_windows(long long n, ColOf col, Emit emit)
-{
-    long long i = 0;
-    while (i < n) {
-        const unsigned long long lim = (unsigned long long)col(i) + 16ull;
-        long long j = i + 1;
-        while (j < n && j - i < 16 && (unsigned long long)col(j) < lim) j++;
-        emit(i, j);
-        i = j;
-    }
-}
-
-// The pooled nonzeros of one tile: appended to `out` in column-major order (a stable bucket pass over the tile's row-major entries).  src(k) -> (row, column nibble, value)
-template <class Src>
-inline void pool_tile(int cb, int count, Src src, std::vector<PoolEnt> &out)
-{
-    int start[17] = {0};
-    for (int k = 0; k < count; k++) { unsigned r, c; val_t v; src(k, r, c, v); start[c + 1]++; }
-    for (int c = 0; c < 16; c++) start[c + 1] += start[c];
-    const size_t base = out.size();
-    out.resize(base + (size_t)count);
-    for (int k = 0; k < count; k++) { unsigned r, c; val_t v; src(k, r, c, v); out[base + (size_t)start[c]++] = PoolEnt{(unsigned)cb * 16u + c, r, v}; }
-}
-
-// Everything tile-row bi pools (hip_plan.h "pooled units"), column-major.  CSR tiles always; COO tiles and HYB remainders when they run in-tile.
-inline void pool_row(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, const std::vector<long long> &hyb_off, std::vector<PoolEnt> &out)
-{
-    out.clear();
-    for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
-        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], cb = T->tile_columnidx[t];
-        if (fmt == TILESPMV_FMT_CSR) {
-            const int off = T->csr_offset[t];
-            const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
-            unsigned char rowof[256];
-            for (int r = 0; r < rowlen; r++) { const int k0 = ptr[r], k1 = (r == rowlen - 1) ? stored : ptr[r + 1]; for (int k = k0; k < k1; k++) rowof[k] = (unsigned char)r; }
-            pool_tile(cb, stored, [&](int k, unsigned &r, unsigned &c, val_t &v) { r = rowof[k]; c = (unsigned)nib(T->csr_compressedIdx, (long long)off + k); v = T->Blockcsr_Val[off + k]; }, out);
-        } else if (fmt == TILESPMV_FMT_COO && coo_in_tile) {
-            const int off = T->coo_offset[t];
-            pool_tile(cb, stored, [&](int k, unsigned &r, unsigned &c, val_t &v) { const unsigned b = T->coo_compressed_Idx[off + k]; r = b >> 4; c = b & 15u; v = T->Blockcoo_Val[off + k]; }, out);
-        } else if (fmt == TILESPMV_FMT_HYB && coo_in_tile) {
-            const int off = T->hyb_offset[t], nell = T->tilewidth[t] * rowlen;
-            const unsigned char *src = T->hybIdx + hyb_off[t];
-            pool_tile(cb, stored - nell, [&](int k, unsigned &r, unsigned &c, val_t &v) { const unsigned b = src[(nell + 1) / 2 + k]; r = b >> 4; c = b & 15u; v = T->Blockhyb_Val[off + nell + k]; }, out);
-        }
-    }
-}
-
-inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, int coo_cost, const std::vector<long long> &hyb_off, std::vector<PoolEnt> &scratch)
-{
-    // csr_form: 0 CSR tiles stay whole tiles (their own pass), 1 ELL-style split (w units + list entries), 2 pooled units
     RowCount c{0, 0, 0, 0, 0, 0, 0};
-    const bool pooled = csr_form == 2;
     for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
-        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
-        switch (fmt) {
-        case TILESPMV_FMT_ELL: c.nunits += w; break;
-        case TILESPMV_FMT_HYB: c.nunits += w; if (coo_in_tile && !pooled) c.ncoo += stored - w * rowlen; break;
-        case TILESPMV_FMT_DNSCOL: c.nunits += T->dnscolptr[t + 1] - T->dnscolptr[t]; break;
-        case TILESPMV_FMT_DNS:
-            if (dense_mfma) c.ndense++;
-            else c.nunits += tile_collen(T->tile_columnidx[t], tilen, colA);
-            break;
-        case TILESPMV_FMT_COO: if (coo_in_tile && !pooled) c.ncoo += stored; break;
-        case TILESPMV_FMT_CSR:
-            if (pooled) break;
-            if (csr_form == 1) { int rem; c.nunits += csr_split_width(T->Blockcsr_Ptr + T->csrptr_offset[t], rowlen, stored, &rem); c.ncoo += rem; }
-            else { c.nheavy++; c.hval += stored; c.hidx += 16 + (stored + 1) / 2; }
-            break;
-        case TILESPMV_FMT_DNSROW: c.nunits += T->dnsrowptr[t + 1] - T->dnsrowptr[t]; break;  // one row unit per dense row
-        }
+        const TileCount k = tile_count(T, t, rowlen, tilen, colA, coo_in_tile, dense_mfma, csr_form);
+        c.nunits += k.nunits; c.ncoo += k.ncoo; c.nheavy += k.nheavy; c.ndense += k.ndense; c.hval += k.hval; c.hidx += k.hidx;
     }
-    if (pooled) {
-        pool_row(T, bi, rowlen, coo_in_tile, hyb_off, scratch);
-        pool_windows((long long)scratch.size(), [&](long long i) { return scratch[(size_t)i].col; },
-                     [&](long long b, long long e) { if (e - b >= POOL_MIN_FILL) c.nunits++; else c.ncoo += (int)(e - b); });
+    if (csr_form == 2) {
+        scratch.resize((size_t)std::max<long long>(1, pool_row_capacity(T, bi)));
+        int nu, nc;
+        pool_row_count(T, bi, rowlen, coo_in_tile, hyb_off, scratch.data(), &nu, &nc);
+        c.nunits += nu; c.ncoo += nc;
     }
     // heavy tiles are latency-bound (one tile at a time): weigh them so that long lists get split
     c.cost = 16LL * c.nunits + (long long)coo_cost * c.ncoo + c.hval + 256LL * c.nheavy + 64LL * c.ndense + 8;
@@ -173,6 +86,7 @@ inline void detect_strides(const Tile_matrix *T, int tr0, int tr1, bool csr_spli
 struct StreamBuilder {
     tilespmv_plan *plan; const Knobs &K; const Tile_matrix *T; const int rowA, colA, tr0, tr1; const bool coo_in_tile, dense_mfma;
     const std::vector<long long> &hyb_off;
+    const long long *hyb_ptr() const { return hyb_off.empty() ? nullptr : hyb_off.data(); }
     std::vector<FixRow> &fix; int &npartial;
     DevStream &S;
     int rc = 0;
@@ -267,7 +181,7 @@ void StreamBuilder::count()
         out.assign((size_t)ntr, RowCount{0, 0, 0, 0, 0, 0, 0});
         parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
             std::vector<PoolEnt> scratch;
-            for (int64_t i = b; i < e; i++) out[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, form, K.coo_cost, hyb_off, scratch);
+            for (int64_t i = b; i < e; i++) out[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, form, K.coo_cost, hyb_ptr(), scratch);
         });
     };
     count_all(csr_form, rc_);
@@ -574,163 +488,28 @@ void StreamBuilder::emit()
     h_hidx = zalloc<unsigned char>((size_t)NHI + 16);
     h_dcb.assign((size_t)ND, 0);
     h_dval = zalloc<val_t>((size_t)ND * 256);
+    const EmitOut O{h_udesc.data(), h_urow.data(), h_uval, h_cval, h_ccol.data(), h_crow.data(), h_dcb.data(), h_dval};
     parallel_chunks(ntr, 256, [&](int64_t b, int64_t e, int) {
         std::vector<PoolEnt> pool;
         for (int64_t i = b; i < e; i++) {
             const int bi = tr0 + (int)i, rowlen = tile_rowlen(bi, tilem, rowA);
             const unsigned kr = row_k[i];
-            long long u = pu[i], c = pc[i], h = ph[i], hv = phv[i], hi = phi[i], dq = pd[i];
-            // word 0 of a unit of column block cb: classic = column block | flags << 24; pooled = first column of the window | tile-row in strip << 28
-            auto unit_w0 = [&](int cb, unsigned flags) { return pooled ? (((unsigned)cb * 16u) | (kr << POOL_KR_SHIFT)) : ((unsigned)cb | (((kr << UNIT_ROW_SHIFT) | flags) << UNIT_FLAG_SHIFT)); };
-            auto put_unit = [&](int cb, const val_t *src, int stride_ok_rows, unsigned long long nibs) {
-                // src: rowlen consecutive values of this column; nibs: 16 nibbles, row 0 in the top nibble
-                for (int r = 0; r < stride_ok_rows; r++) h_uval[u * 16 + r] = src[r];
-                const unsigned w0 = unit_w0(cb, 0u);
-                h_udesc[(size_t)u] = make_uint4(w0, (unsigned)(nibs >> 32), w0, (unsigned)(nibs & 0xffffffffull));
-                u++;
-            };
+            EmitPos pos{pu[i], pc[i], pd[i]};
+            long long h = ph[i], hv = phv[i], hi = phi[i];
             for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
-                const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
-                const int cb = T->tile_columnidx[t], collen = tile_collen(cb, tilen, colA);
-                switch (fmt) {
-                case TILESPMV_FMT_ELL: {
-                    const int off = T->ell_offset[t];
-                    for (int s = 0; s < w; s++) {
-                        unsigned long long nibs = 0;
-                        for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib(T->ell_compressedIdx, (long long)off + s * rowlen + r) << (60 - 4 * r);
-                        put_unit(cb, T->Blockell_Val + off + s * rowlen, rowlen, nibs);
-                    }
-                    break;
-                }
-                case TILESPMV_FMT_HYB: {
-                    const int off = T->hyb_offset[t], nell = w * rowlen;
-                    const unsigned char *src = T->hybIdx + hyb_off[t];
-                    for (int s = 0; s < w; s++) {
-                        unsigned long long nibs = 0;
-                        for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib(src, s * rowlen + r) << (60 - 4 * r);
-                        put_unit(cb, T->Blockhyb_Val + off + s * rowlen, rowlen, nibs);
-                    }
-                    if (coo_in_tile && !pooled)
-                        for (int q = 0; q < stored - nell; q++) {
-                            const unsigned char rcb = src[(nell + 1) / 2 + q];
-                            h_cval[c] = T->Blockhyb_Val[off + nell + q]; h_ccol[(size_t)c] = cb * 16 + (rcb & 15);
-                            h_crow[(size_t)c] = (unsigned char)((kr << 4) | (rcb >> 4)); c++;
-                        }
-                    break;
-                }
-                case TILESPMV_FMT_DNSCOL: {
-                    const int off = T->dnscol_offset[t], co = T->dnscolptr[t], k = T->dnscolptr[t + 1] - co;
-                    for (int q = 0; q < k; q++) put_unit(cb, T->Blockdensecol_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)(T->densecolid[co + q] & 15));
-                    break;
-                }
-                case TILESPMV_FMT_COO:
-                    if (coo_in_tile && !pooled) {
-                        const int off = T->coo_offset[t];
-                        for (int q = 0; q < stored; q++) {
-                            const unsigned char rcb = T->coo_compressed_Idx[off + q];
-                            h_cval[c] = T->Blockcoo_Val[off + q]; h_ccol[(size_t)c] = cb * 16 + (rcb & 15);
-                            h_crow[(size_t)c] = (unsigned char)((kr << 4) | (rcb >> 4)); c++;
-                        }
-                    }
-                    break;
-                case TILESPMV_FMT_DNS:
-                    if (!dense_mfma) {
-                        const int off = T->dns_offset[t];
-                        for (int q = 0; q < collen; q++) put_unit(cb, T->Blockdense_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)q);
-                        break;
-                    }
-                    {   // dense tile for the matrix cores: 256 values, zero padded, in MFMA operand order (dense_slot, hip_plan.h)
-                        const int off = T->dns_offset[t];
-                        val_t *dst = h_dval + dq * 256;
-                        for (int cc = 0; cc < collen; cc++)
-                            for (int r = 0; r < rowlen; r++) dst[dense_slot(r, cc)] = T->Blockdense_Val[off + cc * rowlen + r];
-                        h_dcb[(size_t)dq] = cb;
-                        dq++;
-                    }
-                    break;
-                case TILESPMV_FMT_DNSROW: {
-                    const int off = T->dnsrow_offset[t], ro = T->dnsrowptr[t], k = T->dnsrowptr[t + 1] - ro;
-                    for (int q = 0; q < k; q++) {
-                        for (int cc = 0; cc < collen; cc++) h_uval[u * 16 + cc] = T->Blockdenserow_Val[off + q * collen + cc];
-                        const unsigned w0 = unit_w0(cb, UNIT_ROWUNIT);
-                        const unsigned rid = (unsigned)(T->denserowid[ro + q] & 15);
-                        if (pooled) {   // slot s = column s of the dense row: identity column nibbles, one row nibble
-                            h_udesc[(size_t)u] = make_uint4(w0, 0x01234567u, w0, 0x89ABCDEFu);
-                            h_urow[(size_t)u] = make_uint2(0x11111111u * rid, 0x11111111u * rid);
-                        } else h_udesc[(size_t)u] = make_uint4(w0, rid, w0, rid);
-                        u++;
-                    }
-                    break;
-                }
-                case TILESPMV_FMT_CSR:
-                    if (pooled) break;   // (with the tile-row's other pooled nonzeros, below)
-                    if (csr_split) {
-                        const int off = T->csr_offset[t];
-                        const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
-                        int rem;
-                        const int w = csr_split_width(ptr, rowlen, stored, &rem);
-                        const long long u0 = u;
-                        for (int sidx = 0; sidx < w; sidx++) {  // descriptors first (zero nibbles), payload below
-                            const unsigned w0 = (unsigned)cb | ((kr << UNIT_ROW_SHIFT) << UNIT_FLAG_SHIFT);
-                            h_udesc[(size_t)u] = make_uint4(w0, 0u, w0, 0u);
-                            u++;
-                        }
-                        for (int r = 0; r < rowlen; r++) {
-                            const int k0 = ptr[r], k1 = (r == rowlen - 1) ? stored : ptr[r + 1];
-                            for (int kk = k0; kk < k1; kk++) {
-                                const int lc = nib(T->csr_compressedIdx, (long long)off + kk), sidx = kk - k0;
-                                if (sidx < w) {
-                                    h_uval[(u0 + sidx) * 16 + r] = T->Blockcsr_Val[off + kk];
-                                    if (r < 8) h_udesc[(size_t)(u0 + sidx)].y |= (unsigned)lc << (28 - 4 * r);
-                                    else h_udesc[(size_t)(u0 + sidx)].w |= (unsigned)lc << (28 - 4 * (r - 8));
-                                } else {
-                                    h_cval[c] = T->Blockcsr_Val[off + kk]; h_ccol[(size_t)c] = cb * 16 + lc;
-                                    h_crow[(size_t)c] = (unsigned char)((kr << 4) | r); c++;
-                                }
-                            }
-                        }
-                        break;
-                    }
-                    // fallthrough: CSR tile as a heavy (whole) tile
-                {
+                if (T->Format[t] == TILESPMV_FMT_CSR && csr_form == 0) {   // CSR tile as a heavy (whole) tile: the first-generation layout and routine
+                    const int cb = T->tile_columnidx[t];
                     Emit em = emit_of(T, t, rowlen, true);
-                    repack_tile(T, t, em, rowlen, collen, 0, h_hval + hv, h_hidx + hi);
+                    repack_tile(T, t, em, rowlen, tile_collen(cb, tilen, colA), 0, h_hval + hv, h_hidx + hi);
                     h_hdesc[(size_t)h] = make_uint2((unsigned)cb, (unsigned)em.fmt | ((unsigned)em.p1 << DESC_P1_SHIFT));
                     h++; hv += em.nv; hi += em.ni;
-                    break;
-                }
-                }
+                } else tile_emit(T, t, rowlen, tilen, colA, coo_in_tile, dense_mfma, csr_form, kr, hyb_ptr(), O, pos);   // (plan_tile_ops.h: shared with the device builder)
             }
-            if (pooled) {   // the pooled nonzeros of the tile-row: windows of 16 columns -> units (slot s = s-th nonzero of the window), sparse windows -> list entries
-                pool_row(T, bi, rowlen, coo_in_tile, hyb_off, pool);
-                pool_windows((long long)pool.size(), [&](long long q) { return pool[(size_t)q].col; }, [&](long long wb, long long we) {
-                    if (we - wb >= POOL_MIN_FILL) {
-                        const unsigned base = pool[(size_t)wb].col;
-                        unsigned cn[2] = {0u, 0u}, rn[2] = {0u, 0u};
-                        // slots in ROW order (stable: columns ascending inside a row): the nonzeros of one row sit in neighbouring lanes, which is what the kernel's
-                        // two interleaved copies of the slab rely on — neighbouring lanes add into different copies, so two nonzeros of a row never meet in one LDS atomic
-                        int order[16], cnt[17] = {0};
-                        for (long long q = wb; q < we; q++) cnt[pool[(size_t)q].row + 1]++;
-                        for (int rr = 0; rr < 16; rr++) cnt[rr + 1] += cnt[rr];
-                        for (long long q = wb; q < we; q++) order[cnt[pool[(size_t)q].row]++] = (int)(q - wb);
-                        for (int sl = 0; sl < (int)(we - wb); sl++) {
-                            const PoolEnt &pe = pool[(size_t)(wb + order[sl])];
-                            h_uval[u * 16 + sl] = pe.val;
-                            cn[sl >> 3] |= (pe.col - base) << (28 - 4 * (sl & 7));
-                            rn[sl >> 3] |= pe.row << (28 - 4 * (sl & 7));
-                        }
-                        const unsigned w0 = base | (kr << POOL_KR_SHIFT);
-                        h_udesc[(size_t)u] = make_uint4(w0, cn[0], w0, cn[1]);
-                        h_urow[(size_t)u] = make_uint2(rn[0], rn[1]);   // (empty slots: value 0, column offset 0, row 0 — they add 0 * x[base] to row 0 of the tile-row)
-                        u++;
-                    } else
-                        for (long long q = wb; q < we; q++) {
-                            h_cval[c] = pool[(size_t)q].val; h_ccol[(size_t)c] = (int)pool[(size_t)q].col;
-                            h_crow[(size_t)c] = (unsigned char)((kr << 4) | pool[(size_t)q].row); c++;
-                        }
-                });
+            if (pooled) {   // the pooled nonzeros of the tile-row: windows of 16 columns -> units, sparse windows -> list entries
+                pool.resize((size_t)std::max<long long>(1, pool_row_capacity(T, bi)));
+                pool_row_emit(T, bi, rowlen, coo_in_tile, kr, hyb_ptr(), pool.data(), O, pos);
             }
-            if (!pooled && !row_split[i] && u > pu[i]) { h_udesc[(size_t)u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; h_udesc[(size_t)u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
+            if (!pooled && !row_split[i] && pos.u > pu[i]) { h_udesc[(size_t)pos.u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; h_udesc[(size_t)pos.u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
             if (h > ph[i]) h_hdesc[(size_t)h - 1].y |= DESC_EOR;
         }
     });

@@ -1,0 +1,295 @@
+// plan_tile_ops.h — what ONE source tile (and, for pooled plans, one tile-row's pool) becomes in the unit stream: counts and emitted records.
+// Written once for the host builder (hip_plan_stream.hip, loops over tile-rows on host threads) and the device builder (hip_plan_device.hip, one thread per tile /
+// per tile-row): both call THESE functions, so the streams come out byte for byte the same.  No allocation, no std:: containers; scratch comes from the caller.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hip_plan.h"
+
+namespace tilespmv {
+
+TILESPMV_HD inline int nib_at(const unsigned char *s, long long p) { return (p & 1) ? (s[p >> 1] & 15) : (s[p >> 1] >> 4); }
+
+// A CSR tile is executed as w ELL-style units (the first w entries of every row) plus the rest of its entries on the strip's COO list; w minimises the bytes moved
+// (HYB's idea, src/csr2tile.h:279-306, with this kernel's byte costs).  Returns w and the number of remainder entries.
+TILESPMV_HD inline int csr_split_width(const unsigned char *ptr, int rowlen, int nnz, int *remainder)
+{
+    const long long unit_b = 16 + 16 * (long long)sizeof(val_t), entry_b = (long long)sizeof(val_t) + 5;
+    int len[16], wmax = 0;
+    for (int r = 0; r < 16; r++) { len[r] = r < rowlen ? ((r == rowlen - 1 ? nnz : ptr[r + 1]) - ptr[r]) : 0; wmax = wmax > len[r] ? wmax : len[r]; }
+    int best_w = 0, best_rem = nnz; long long best = entry_b * nnz;
+    for (int w = 1; w <= wmax; w++) {
+        int rem = 0;
+        for (int r = 0; r < 16; r++) rem += len[r] - w > 0 ? len[r] - w : 0;
+        const long long b = unit_b * w + entry_b * rem;
+        if (b < best) { best = b; best_w = w; best_rem = rem; }
+    }
+    *remainder = best_rem;
+    return best_w;
+}
+
+// What one tile adds to its tile-row's counts.  csr_form: 0 CSR tiles stay whole tiles (their own pass), 1 ELL-style split (w units + list entries), 2 pooled units
+// (the pooled nonzeros — CSR tiles, in-tile COO tiles, HYB remainders — are counted per tile-row by pool_row_count, not here).
+struct TileCount { int nunits, ncoo, nheavy, ndense, hval, hidx; };
+TILESPMV_HD inline TileCount tile_count(const Tile_matrix *T, int t, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form)
+{
+    TileCount c{0, 0, 0, 0, 0, 0};
+    const bool pooled = csr_form == 2;
+    const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
+    switch (fmt) {
+    case TILESPMV_FMT_ELL: c.nunits = w; break;
+    case TILESPMV_FMT_HYB: c.nunits = w; if (coo_in_tile && !pooled) c.ncoo = stored - w * rowlen; break;
+    case TILESPMV_FMT_DNSCOL: c.nunits = T->dnscolptr[t + 1] - T->dnscolptr[t]; break;
+    case TILESPMV_FMT_DNS:
+        if (dense_mfma) c.ndense = 1;
+        else c.nunits = tile_collen(T->tile_columnidx[t], tilen, colA);
+        break;
+    case TILESPMV_FMT_COO: if (coo_in_tile && !pooled) c.ncoo = stored; break;
+    case TILESPMV_FMT_CSR:
+        if (pooled) break;
+        if (csr_form == 1) { int rem; c.nunits = csr_split_width(T->Blockcsr_Ptr + T->csrptr_offset[t], rowlen, stored, &rem); c.ncoo = rem; }
+        else { c.nheavy = 1; c.hval = stored; c.hidx = 16 + (stored + 1) / 2; }
+        break;
+    case TILESPMV_FMT_DNSROW: c.nunits = T->dnsrowptr[t + 1] - T->dnsrowptr[t]; break;  // one row unit per dense row
+    }
+    return c;
+}
+
+// ---- pooled units (hip_plan.h): the nonzeros of a tile-row's CSR tiles, COO tiles and HYB remainders, in column-major order (column, then row; tiles are in
+// ascending column-block order and a tile's own nonzeros are bucketed by column nibble, so no comparison sort is needed)
+struct PoolEnt { unsigned col; unsigned row; val_t val; };   // global column, row inside the tile-row
+
+// Cuts a column-major run of pooled nonzeros into windows: a window starts at the first nonzero not yet taken and holds the (up to 16) following ones whose column is
+// less than 16 above its first column.  `col(i)` = column of nonzero i; `emit(begin, end)` is called once per window.
+template <class ColOf, class Emit>
+TILESPMV_HD inline void pool_windows(long long n, ColOf col, Emit emit)
+{
+    long long i = 0;
+    while (i < n) {
+        const unsigned long long lim = (unsigned long long)col(i) + 16ull;
+        long long j = i + 1;
+        while (j < n && j - i < 16 && (unsigned long long)col(j) < lim) j++;
+        emit(i, j);
+        i = j;
+    }
+}
+
+// The pooled nonzeros of one tile: written to out[0 .. count) in column-major order (a stable bucket pass over the tile's row-major entries).  src(k, r, c, v) -> row, column nibble, value
+template <class Src>
+TILESPMV_HD inline void pool_tile(int cb, int count, Src src, PoolEnt *out)
+{
+    int start[17];
+    for (int c = 0; c < 17; c++) start[c] = 0;
+    for (int k = 0; k < count; k++) { unsigned r, c; val_t v; src(k, r, c, v); start[c + 1]++; }
+    for (int c = 0; c < 16; c++) start[c + 1] += start[c];
+    for (int k = 0; k < count; k++) { unsigned r, c; val_t v; src(k, r, c, v); out[start[c]++] = PoolEnt{(unsigned)cb * 16u + c, r, v}; }
+}
+
+// Everything tile-row bi pools (hip_plan.h "pooled units"), column-major, into out (room for the tile-row's stored nonzeros); returns how many.  CSR tiles always; COO
+// tiles and HYB remainders when they run in-tile.  hyb_off: byte offset of every HYB tile in hybIdx (nullptr: the matrix has none)
+TILESPMV_HD inline long long pool_row(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, const long long *hyb_off, PoolEnt *out)
+{
+    long long n = 0;
+    for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
+        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], cb = T->tile_columnidx[t];
+        if (fmt == TILESPMV_FMT_CSR) {
+            const int off = T->csr_offset[t];
+            const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
+            const unsigned char *idx = T->csr_compressedIdx; const val_t *val = T->Blockcsr_Val;
+            unsigned char rowof[256];   // row of entry k (a CSR tile holds fewer than 192 entries)
+            for (int r = 0; r < rowlen; r++) { const int k0 = ptr[r], k1 = (r == rowlen - 1) ? stored : ptr[r + 1]; for (int k = k0; k < k1; k++) rowof[k] = (unsigned char)r; }
+            const unsigned char *ro = rowof;
+            pool_tile(cb, stored, [=](int k, unsigned &r, unsigned &c, val_t &v) { r = ro[k]; c = (unsigned)nib_at(idx, (long long)off + k); v = val[off + k];
+            }, out + n);
+            n += stored;
+        } else if (fmt == TILESPMV_FMT_COO && coo_in_tile) {
+            const int off = T->coo_offset[t];
+            const unsigned char *idx = T->coo_compressed_Idx; const val_t *val = T->Blockcoo_Val;
+            pool_tile(cb, stored, [=](int k, unsigned &r, unsigned &c, val_t &v) { const unsigned b = idx[off + k]; r = b >> 4; c = b & 15u; v = val[off + k]; }, out + n);
+            n += stored;
+        } else if (fmt == TILESPMV_FMT_HYB && coo_in_tile && hyb_off) {
+            const int off = T->hyb_offset[t], nell = T->tilewidth[t] * rowlen;
+            const unsigned char *src = T->hybIdx + hyb_off[t]; const val_t *val = T->Blockhyb_Val;
+            pool_tile(cb, stored - nell, [=](int k, unsigned &r, unsigned &c, val_t &v) { const unsigned b = src[(nell + 1) / 2 + k]; r = b >> 4; c = b & 15u; v = val[off + nell + k]; }, out + n);
+            n += stored - nell;
+        }
+    }
+    return n;
+}
+
+// upper bound of what pool_row writes for tile-row bi (its stored nonzeros)
+TILESPMV_HD inline long long pool_row_capacity(const Tile_matrix *T, int bi) { return (long long)T->blknnz[T->tile_ptr[bi + 1]] - T->blknnz[T->tile_ptr[bi]]; }
+
+// pooled part of a tile-row's counts: windows that are worth a unit, and the nonzeros of the others (list entries)
+TILESPMV_HD inline void pool_row_count(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, const long long *hyb_off, PoolEnt *scratch, int *nunits, int *ncoo)
+{
+    const long long n = pool_row(T, bi, rowlen, coo_in_tile, hyb_off, scratch);
+    int nu = 0, nc = 0;
+    pool_windows(n, [=](long long i) { return scratch[i].col; }, [&](long long b, long long e) { if (e - b >= POOL_MIN_FILL) nu++; else nc += (int)(e - b); });
+    *nunits = nu; *ncoo = nc;
+}
+
+// ---- emission
+struct EmitOut {   // where the records go (host staging arrays or device memory); entries of arrays a plan does not have are never written
+    uint4 *udesc; uint2 *urow; val_t *uval;              // units: descriptor (w0, nibbles 0-7, w0, nibbles 8-15), pooled plans: row nibbles, 16 values
+    val_t *cval; int *ccol; unsigned char *crow;         // list entries: value, global column, tile-row-in-strip << 4 | row
+    int *dcb; val_t *dval;                               // dense tiles for the matrix cores: column block, 256 values in operand order
+};
+struct EmitPos { long long u, c, dq; };   // next unit, list entry, dense tile
+
+TILESPMV_HD inline unsigned unit_word0(bool pooled, unsigned kr, int cb, unsigned flags)
+{
+    return pooled ? (((unsigned)cb * 16u) | (kr << POOL_KR_SHIFT)) : ((unsigned)cb | (((kr << UNIT_ROW_SHIFT) | flags) << UNIT_FLAG_SHIFT));
+}
+// one unit of column block cb: src = rowlen consecutive values of this column; nibs: 16 column nibbles, row 0 in the top nibble
+TILESPMV_HD inline void put_unit(const EmitOut &O, EmitPos &p, bool pooled, unsigned kr, int cb, const val_t *src, int rows, unsigned long long nibs)
+{
+    for (int r = 0; r < rows; r++) O.uval[p.u * 16 + r] = src[r];
+    const unsigned w0 = unit_word0(pooled, kr, cb, 0u);
+    O.udesc[p.u] = make_uint4(w0, (unsigned)(nibs >> 32), w0, (unsigned)(nibs & 0xffffffffull));
+    p.u++;
+}
+
+// Everything one tile emits EXCEPT whole ("heavy") CSR tiles (csr_form 0: host only, hip_plan_stream.hip) and the pooled nonzeros (pool_row_emit).
+// kr = the tile-row's place in its strip; the caller sets the end-of-row flag on the row's last unit afterwards (classic plans).
+TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, unsigned kr, const long long *hyb_off,
+                                  const EmitOut &O, EmitPos &p)
+{
+    const bool pooled = csr_form == 2;
+    const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
+    const int cb = T->tile_columnidx[t], collen = tile_collen(cb, tilen, colA);
+    switch (fmt) {
+    case TILESPMV_FMT_ELL: {
+        const int off = T->ell_offset[t];
+        for (int s = 0; s < w; s++) {
+            unsigned long long nibs = 0;
+            for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib_at(T->ell_compressedIdx, (long long)off + s * rowlen + r) << (60 - 4 * r);
+            put_unit(O, p, pooled, kr, cb, T->Blockell_Val + off + s * rowlen, rowlen, nibs);
+        }
+        break;
+    }
+    case TILESPMV_FMT_HYB: {
+        if (!hyb_off) break;
+        const int off = T->hyb_offset[t], nell = w * rowlen;
+        const unsigned char *src = T->hybIdx + hyb_off[t];
+        for (int s = 0; s < w; s++) {
+            unsigned long long nibs = 0;
+            for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib_at(src, s * rowlen + r) << (60 - 4 * r);
+            put_unit(O, p, pooled, kr, cb, T->Blockhyb_Val + off + s * rowlen, rowlen, nibs);
+        }
+        if (coo_in_tile && !pooled)
+            for (int q = 0; q < stored - nell; q++) {
+                const unsigned char rcb = src[(nell + 1) / 2 + q];
+                O.cval[p.c] = T->Blockhyb_Val[off + nell + q]; O.ccol[p.c] = cb * 16 + (rcb & 15);
+                O.crow[p.c] = (unsigned char)((kr << 4) | (rcb >> 4)); p.c++;
+            }
+        break;
+    }
+    case TILESPMV_FMT_DNSCOL: {
+        const int off = T->dnscol_offset[t], co = T->dnscolptr[t], k = T->dnscolptr[t + 1] - co;
+        for (int q = 0; q < k; q++) put_unit(O, p, pooled, kr, cb, T->Blockdensecol_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)(T->densecolid[co + q] & 15));
+        break;
+    }
+    case TILESPMV_FMT_COO:
+        if (coo_in_tile && !pooled) {
+            const int off = T->coo_offset[t];
+            for (int q = 0; q < stored; q++) {
+                const unsigned char rcb = T->coo_compressed_Idx[off + q];
+                O.cval[p.c] = T->Blockcoo_Val[off + q]; O.ccol[p.c] = cb * 16 + (rcb & 15);
+                O.crow[p.c] = (unsigned char)((kr << 4) | (rcb >> 4)); p.c++;
+            }
+        }
+        break;
+    case TILESPMV_FMT_DNS: {
+        const int off = T->dns_offset[t];
+        if (!dense_mfma) {
+            for (int q = 0; q < collen; q++) put_unit(O, p, pooled, kr, cb, T->Blockdense_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)q);
+            break;
+        }
+        // dense tile for the matrix cores: 256 values, zero padded, in MFMA operand order (dense_slot, hip_plan.h)
+        val_t *dst = O.dval + p.dq * 256;
+        for (int cc = 0; cc < collen; cc++)
+            for (int r = 0; r < rowlen; r++) dst[dense_slot(r, cc)] = T->Blockdense_Val[off + cc * rowlen + r];
+        O.dcb[p.dq] = cb;
+        p.dq++;
+        break;
+    }
+    case TILESPMV_FMT_DNSROW: {
+        const int off = T->dnsrow_offset[t], ro = T->dnsrowptr[t], k = T->dnsrowptr[t + 1] - ro;
+        for (int q = 0; q < k; q++) {
+            for (int cc = 0; cc < collen; cc++) O.uval[p.u * 16 + cc] = T->Blockdenserow_Val[off + q * collen + cc];
+            const unsigned w0 = unit_word0(pooled, kr, cb, UNIT_ROWUNIT);
+            const unsigned rid = (unsigned)(T->denserowid[ro + q] & 15);
+            if (pooled) {   // slot s = column s of the dense row: identity column nibbles, one row nibble
+                O.udesc[p.u] = make_uint4(w0, 0x01234567u, w0, 0x89ABCDEFu);
+                O.urow[p.u] = make_uint2(0x11111111u * rid, 0x11111111u * rid);
+            } else O.udesc[p.u] = make_uint4(w0, rid, w0, rid);
+            p.u++;
+        }
+        break;
+    }
+    case TILESPMV_FMT_CSR:
+        if (csr_form == 1) {
+            const int off = T->csr_offset[t];
+            const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
+            int rem;
+            const int ws = csr_split_width(ptr, rowlen, stored, &rem);
+            const long long u0 = p.u;
+            for (int sidx = 0; sidx < ws; sidx++) {  // descriptors first (zero nibbles), payload below
+                const unsigned w0 = (unsigned)cb | ((kr << UNIT_ROW_SHIFT) << UNIT_FLAG_SHIFT);
+                O.udesc[p.u] = make_uint4(w0, 0u, w0, 0u);
+                p.u++;
+            }
+            for (int r = 0; r < rowlen; r++) {
+                const int k0 = ptr[r], k1 = (r == rowlen - 1) ? stored : ptr[r + 1];
+                for (int kk = k0; kk < k1; kk++) {
+                    const int lc = nib_at(T->csr_compressedIdx, (long long)off + kk), sidx = kk - k0;
+                    if (sidx < ws) {
+                        O.uval[(u0 + sidx) * 16 + r] = T->Blockcsr_Val[off + kk];
+                        if (r < 8) O.udesc[u0 + sidx].y |= (unsigned)lc << (28 - 4 * r);
+                        else O.udesc[u0 + sidx].w |= (unsigned)lc << (28 - 4 * (r - 8));
+                    } else {
+                        O.cval[p.c] = T->Blockcsr_Val[off + kk]; O.ccol[p.c] = cb * 16 + lc;
+                        O.crow[p.c] = (unsigned char)((kr << 4) | r); p.c++;
+                    }
+                }
+            }
+        }
+        break;
+    }
+}
+
+// the pooled nonzeros of tile-row bi: windows of 16 columns -> units (slot s = s-th nonzero of the window, in row order), sparse windows -> list entries
+TILESPMV_HD inline void pool_row_emit(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, unsigned kr, const long long *hyb_off, PoolEnt *pool, const EmitOut &O, EmitPos &p)
+{
+    const long long n = pool_row(T, bi, rowlen, coo_in_tile, hyb_off, pool);
+    pool_windows(n, [=](long long q) { return pool[q].col; }, [&](long long wb, long long we) {
+        if (we - wb >= POOL_MIN_FILL) {
+            const unsigned base = pool[wb].col;
+            unsigned cn[2] = {0u, 0u}, rn[2] = {0u, 0u};
+            // slots in ROW order (stable: columns ascending inside a row): the nonzeros of one row sit in neighbouring lanes, which is what the kernel's
+            // two interleaved copies of the slab rely on — neighbouring lanes add into different copies, so two nonzeros of a row never meet in one LDS atomic
+            int order[16], cnt[17];
+            for (int rr = 0; rr < 17; rr++) cnt[rr] = 0;
+            for (long long q = wb; q < we; q++) cnt[pool[q].row + 1]++;
+            for (int rr = 0; rr < 16; rr++) cnt[rr + 1] += cnt[rr];
+            for (long long q = wb; q < we; q++) order[cnt[pool[q].row]++] = (int)(q - wb);
+            for (int sl = 0; sl < (int)(we - wb); sl++) {
+                const PoolEnt &pe = pool[wb + order[sl]];
+                O.uval[p.u * 16 + sl] = pe.val;
+                cn[sl >> 3] |= (pe.col - base) << (28 - 4 * (sl & 7));
+                rn[sl >> 3] |= pe.row << (28 - 4 * (sl & 7));
+            }
+            const unsigned w0 = base | (kr << POOL_KR_SHIFT);
+            O.udesc[p.u] = make_uint4(w0, cn[0], w0, cn[1]);
+            O.urow[p.u] = make_uint2(rn[0], rn[1]);   // (empty slots: value 0, column offset 0, row 0 — they add 0 * x[base] to row 0 of the tile-row)
+            p.u++;
+        } else
+            for (long long q = wb; q < we; q++) {
+                O.cval[p.c] = pool[q].val; O.ccol[p.c] = (int)pool[q].col;
+                O.crow[p.c] = (unsigned char)((kr << 4) | pool[q].row); p.c++;
+            }
+    });
+}
+
+}  // namespace tilespmv
