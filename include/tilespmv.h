@@ -351,6 +351,23 @@ int tilespmv_plan_create(tilespmv_plan **plan, const Tile_matrix *matrix, int ro
                          MAT_PTR_TYPE nnzA, const tilespmv_plan_options *opts);
 void tilespmv_plan_destroy(tilespmv_plan *plan);
 
+/* Preprocessing on the device (new; SURVEY.md S8 f1 "device-side"; replaces the reference's Tile_create + upload, src/csr2tile.h:629-1020 + src/tilespmv_cuda.h:828-1057, end to end).
+ *
+ * Tile_create_device: the host Tile_create computed by kernels — the CSR arrays go up, every member array of the Tile_matrix comes back, byte for byte what Tile_create /
+ * Tile_create_ex builds (flags: TILESPMV_CREATE_QUIET, TILESPMV_CREATE_CDNA4; TILESPMV_CREATE_HYB is a host-only option).  Returns 0, -1 no HIP device (there is no CPU
+ * fallback behind this entry point: call Tile_create), -2 an offset leaves the int32 range of Tile_matrix, -3 HIP error / out of device memory, -4 unsupported flag.
+ *
+ * tilespmv_plan_create_from_csr: CSR in, resident plan out, nothing but the CSR arrays crossing the bus — the tiled matrix is built on the device and stays there, the stages of the
+ * plan builder that touch every nonzero run as kernels calling the same per-tile functions as the host builder, so the plan is the one tilespmv_plan_create makes from
+ * Tile_create's output (same streams, same y).  Not every option has a device path: returns -4 (and builds nothing) for autotune, the first-generation kernel, the CSR fallback
+ * mode, whole CSR tiles (csr_split = 0), LDS x windows (x_window = 1) and HYB tiles — use Tile_create + tilespmv_plan_create for those.  Other return codes as above.
+ * Peak device memory during the call: the CSR arrays + the tiled matrix + the sort's key buffers (about 40 bytes per nonzero in fp64) beside the plan. */
+int Tile_create_device(Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *csrRowPtrA,
+                       const int *csrColIdxA, const MAT_VAL_TYPE *csrValA, unsigned flags);
+int tilespmv_plan_create_from_csr(tilespmv_plan **plan, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *csrRowPtrA,
+                                  const int *csrColIdxA, const MAT_VAL_TYPE *csrValA, unsigned create_flags,
+                                  const tilespmv_plan_options *opts);
+
 /* Values: x (and the matrix values) must be FINITE.  Zero-padded payload is multiplied by real x entries — the padding
  * slots of ELL / HYB tiles exactly as in the reference (src/tilespmv_cpu.h:173-192 walks all `width` slots), and in
  * this engine also CSR tiles re-expressed as units, dense tiles, and the clamped reads of a partial last column block —
@@ -451,9 +468,15 @@ enum {
     TILESPMV_INFO_X_SLICE_PASSES = 29,    /* column slices pinned to XCDs: launches of the sliced entry part (0 = not used); 8 x this many slices of x */
     TILESPMV_INFO_CSR_FORM = 30,          /* what CSR-format tiles became: 0 whole tiles (own pass), 1 ELL-style split (units + list entries), 2 pooled units */
     TILESPMV_INFO_TIMED_CHOICES_US = 31,  /* microseconds of plan creation spent TIMING candidates (placement retry, column panels / slices, pacing); part of build_us; 0 = nothing was timed */
-    TILESPMV_INFO_COUNT = 32
+    TILESPMV_INFO_DEVICE_BUILD = 32,      /* 1: built by tilespmv_plan_create_from_csr (Tile_create, COUNT / EMIT / ENCODE on the device) */
+    TILESPMV_INFO_TILE_CREATE_US = 33,    /* ... microseconds of its device Tile_create, the upload of the CSR arrays included (0 otherwise) */
+    TILESPMV_INFO_COUNT = 34
 };
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out /* [TILESPMV_INFO_COUNT] */);
+/* Test / audit aid: one (member offset in the plan object, bytes, FNV-1a-64 of the bytes read back from the device) triple per stream of the plan, at most max_streams of them
+ * written; returns the number of streams (or -3 on a HIP error).  Two plans of one matrix and one option set — one built from a host Tile_matrix, one by
+ * tilespmv_plan_create_from_csr — must agree triple for triple (tests/test_gpu_device_build.py). */
+long long tilespmv_plan_stream_digests(const tilespmv_plan *plan, unsigned long long *out /* [3 * max_streams] */, long long max_streams);
 
 /* Times `reps` back-to-back SpMVs on `stream` with hipEvents recorded on that stream (after
  * `warmup` untimed ones) and returns the mean milliseconds per SpMV, or a negative value on

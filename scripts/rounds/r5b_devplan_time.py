@@ -1,0 +1,25 @@
+"""Round 5 (second session): preparation end to end — host Tile_create + tilespmv_plan_create against tilespmv_plan_create_from_csr (everything on the device) — per workload,
+with the stream digests and the first SpMV compared.  TILESPMV_PLAN_VERBOSE / TILESPMV_CREATE_VERBOSE print the stages."""
+import os, sys, time
+os.environ["TILESPMV_PLAN_VERBOSE"] = "1"; os.environ["TILESPMV_CREATE_VERBOSE"] = "1"
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench
+from tilespmv_amd import api, generators as G
+for wl in sys.argv[1].split(","):
+    m, n, rp, ci, _ = bench.build_matrix(wl); rows = (m // 16) * 16; nnz = int(rp[rows])
+    dt = np.float32 if wl == "nlpkkt160" else np.float64
+    v = G.real_values(len(ci), dt); x = G.real_x(n, nnz, dt)
+    xd = torch.from_numpy(x).cuda(); yh = torch.zeros(rows + 16, dtype=xd.dtype, device="cuda"); yd = torch.zeros_like(yh)
+    for rep in range(2):
+        t0 = time.time(); tm = api.Tile_create(rows, n, nnz, rp, ci, v, dtype=dt); t_tc = time.time() - t0
+        t0 = time.time(); ph = api.Plan(tm, rows, n, nnz, placement_tries=1); t_pc = time.time() - t0
+        t0 = time.time(); pd = api.Plan.from_csr(rows, n, nnz, rp, ci, v, dtype=dt, placement_tries=1); t_dev = time.time() - t0
+        ph.spmv(xd.data_ptr(), yh.data_ptr()); pd.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize()
+        hs, ds = ph.stream_digests(), pd.stream_digests()
+        same = sorted(hs) == sorted(ds) and all(hs[k] == ds[k] for k in hs)
+        ms_h = ph.time(xd.data_ptr(), yh.data_ptr(), 0, 5, 20); ms_d = pd.time(xd.data_ptr(), yd.data_ptr(), 0, 5, 20)
+        i = pd.info()
+        print("%s rep %d: host Tile_create %.3f s + plan create %.3f s = %.3f s | from_csr %.3f s (device Tile_create %.3f s incl. CSR upload) | streams identical: %s, y identical: %s | SpMV %.4f / %.4f ms"
+              % (wl, rep, t_tc, t_pc, t_tc + t_pc, t_dev, i["tile_create_us"] * 1e-6, same, bool(torch.equal(yh, yd)), ms_h, ms_d), flush=True)
+        ph.close(); pd.close(); api.Tile_destroy(tm)

@@ -72,3 +72,113 @@ def test_device_tile_create_large_classes():
     """One matrix of each large class at a size where tile-rows, sorts and scans run many workgroups: stencil, FEM (CSR tiles), power-law (hub rows), KKT."""
     for rows, cols, rp, ci in [G.laplacian5pt(700), G.fem_hex(24, 24, 24, 3), G.powerlaw(400000), G.kkt_like(40), G.rmat(17, 8, 3)]:
         assert same_tile_matrix(rows, cols, rp, ci, np.float64) == []
+
+
+# ---- the plan built on the device (tilespmv_plan_create_from_csr) against the plan built from the host Tile_matrix
+
+KNOB_SETS = [dict(), dict(deterministic=1), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2), dict(csr_split=1), dict(csr_split=2), dict(csr_split=2, entry_mode=2),
+             dict(dense_mode=1), dict(dense_mode=2), dict(strip_cost=64, split_above=200), dict(csr_split=2, strip_cost=64, split_above=128, dense_mode=1), dict(x_window=2), dict(desc_dict=0),
+             dict(desc_dict=1), dict(x_panel_kb=1, x_panel_merge=1, entry_mode=2), dict(wg_strips=32, entry_mode=2)]
+FACTS = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel", "num_tasks", "num_split_rows", "entry_mode", "entry_ordered", "strip_cost", "wg_strips", "brick_order",
+         "desc_bytes", "nt_stream", "x_panels", "scattered_entries", "csr_form"]
+
+
+def _spmv(torch, plan, rows, x):
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    yd = torch.full((rows + 16,), 12345.0, dtype=xd.dtype, device="cuda")
+    plan.spmv(xd.data_ptr(), yd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    assert (y[rows:] == 12345.0).all()
+    return y[:rows]
+
+
+def same_plan(torch, rows, cols, rp, ci, dtype, knobs, cdna4=False, shard=None):
+    """Host-built and device-built plan of one matrix and one option set: the same streams (per-stream digests read back from the device), the same facts, the same bits of y."""
+    nnz = int(rp[rows])
+    v, x = G.real_values(nnz, dtype), G.real_x(cols, nnz, dtype)
+    kw = dict(knobs)
+    kw.setdefault("placement_tries", 1)
+    if shard:
+        kw["tilerow_begin"], kw["tilerow_end"] = shard
+    tm = api.Tile_create(rows, cols, nnz, rp, ci, v, dtype=dtype, cdna4=cdna4)
+    host = api.Plan(tm, rows, cols, nnz, **kw)
+    dev = api.Plan.from_csr(rows, cols, nnz, rp, ci, v, dtype=dtype, cdna4=cdna4, **kw)
+    try:
+        hi, di = host.info(), dev.info()
+        assert di["device_build"] == 1 and hi["device_build"] == 0
+        bad = [(k, hi[k], di[k]) for k in FACTS if hi[k] != di[k]]
+        assert bad == [], bad
+        hs, ds = host.stream_digests(), dev.stream_digests()
+        assert sorted(hs) == sorted(ds), (sorted(hs), sorted(ds))
+        assert [k for k in hs if hs[k] != ds[k]] == [], {k: (hs[k], ds[k]) for k in hs if hs[k] != ds[k]}
+        r0, r1 = (shard[0] * 16, min(rows, shard[1] * 16)) if shard else (0, rows)
+        yh, yd = _spmv(torch, host, rows, x), _spmv(torch, dev, rows, x)
+        if hi["entry_ordered"]:
+            assert np.array_equal(yh[r0:r1], yd[r0:r1])
+        else:
+            assert np.allclose(yh[r0:r1], yd[r0:r1], rtol=1e-4 if dtype == np.float32 else 1e-11, atol=1e-4 if dtype == np.float32 else 1e-11)
+    finally:
+        host.close(); dev.close(); api.Tile_destroy(tm)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.mark.parametrize("name", sorted(cases.SMALL) + sorted(cases.MEDIUM))
+def test_device_built_plan_equals_host_built_plan(torch_cuda, name):
+    rows, cols, rp, ci = (cases.SMALL.get(name) or cases.MEDIUM[name])()
+    rows = cases.truncated_rows(rows)
+    for i, knobs in enumerate(KNOB_SETS):
+        same_plan(torch_cuda, rows, cols, rp, ci, np.float64 if i % 2 == 0 else np.float32, knobs)
+
+
+def test_device_built_plan_classes_and_shards(torch_cuda):
+    """FEM (pooled units), 3-D stencil and KKT (brick order, dictionary), power-law (workgroup entry lists, split rows), band (dense tiles on the matrix cores), R-MAT;
+    whole matrix and a shard of tile-rows, fp64 and fp32."""
+    mats = {"fem3": G.fem_hex(14, 14, 14, 3), "fem6s": G.fem_hex(10, 10, 10, 6, shuffle=16), "lap3d": G.laplacian7pt(48), "kkt24": G.kkt_like(24), "powerlaw": G.powerlaw(300000),
+            "band40": G.band(60000, 40), "rmat16": G.rmat(16, 8, 3), "lap2d": G.laplacian5pt(500)}
+    for name, (rows, cols, rp, ci) in mats.items():
+        rows = cases.truncated_rows(rows)
+        tilem = rows // 16
+        for dtype in (np.float64, np.float32):
+            same_plan(torch_cuda, rows, cols, rp, ci, dtype, dict())
+            same_plan(torch_cuda, rows, cols, rp, ci, dtype, dict(deterministic=1), shard=(tilem // 3, 2 * tilem // 3))
+
+
+def test_device_built_plan_random_ingredients(torch_cuda):
+    for seed in range(40):
+        rows, cols, rp, ci = random_matrix(2000 + seed)
+        knobs = KNOB_SETS[seed % len(KNOB_SETS)]
+        same_plan(torch_cuda, rows, cols, rp, ci, np.float64 if seed % 2 else np.float32, knobs, cdna4=seed % 7 == 0)
+
+
+def test_device_built_plan_matches_the_oracle(torch_cuda):
+    """y of device-built plans against the oracle's CSR golden, bit-exact on the reference's small-integer data (the same bar as every other plan)."""
+    from oracle.oracle import CpuImpl
+    for name in ["allfmt", "allfmt_pad5", "circuit8k", "powerlaw20k", "one_long_row", "kkt12"]:
+        rows, cols, rp, ci = (cases.SMALL.get(name) or cases.MEDIUM[name])()
+        rows = cases.truncated_rows(rows)
+        nnz = int(rp[rows])
+        for dtype in (np.float64, np.float32):
+            v, x = cases.values_for(name, nnz, cols, dtype)
+            O = CpuImpl("oracle", dtype)
+            to = O.tile_create(rows, cols, nnz, rp, ci, v)
+            want = O.spmv(to, rows, cols, nnz, rp, ci, v, x)["y"]
+            for knobs in (dict(), dict(csr_split=2), dict(entry_mode=2, dense_mode=1)):
+                plan = api.Plan.from_csr(rows, cols, nnz, rp, ci, v, dtype=dtype, **knobs)
+                y = _spmv(torch_cuda, plan, rows, x)
+                plan.close()
+                assert np.array_equal(y, want), (name, dtype, knobs, int(np.count_nonzero(y != want)))
+
+
+def test_options_without_a_device_path_are_refused(torch_cuda):
+    rows, cols, rp, ci = cases.SMALL["lap64"]()
+    v = G.compat_values(len(ci), np.float64)
+    for knobs in (dict(csr_split=0), dict(kernel=api.KERNEL_DIRECT), dict(coo_mode=api.COO_FALLBACK), dict(x_window=1)):
+        with pytest.raises(NotImplementedError):
+            api.Plan.from_csr(rows, cols, len(ci), rp, ci, v, **knobs)

@@ -18,7 +18,7 @@ _CACHE = {}
 
 INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel",
               "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us", "entry_mode", "entry_ordered", "strip_cost",
-              "wg_strips", "x_window_slots", "x_window_segments", "brick_order", "desc_bytes", "nt_stream", "pace_slabs", "pace_team", "placement_tries", "pace_period_us", "x_panels", "x_panel_merge", "scattered_entries", "x_slice_passes", "csr_form", "timed_choices_us"]
+              "wg_strips", "x_window_slots", "x_window_segments", "brick_order", "desc_bytes", "nt_stream", "pace_slabs", "pace_team", "placement_tries", "pace_period_us", "x_panels", "x_panel_merge", "scattered_entries", "x_slice_passes", "csr_form", "timed_choices_us", "device_build", "tile_create_us"]
 
 
 KNOB_DEFAULT = -1
@@ -84,6 +84,10 @@ def load(dtype=np.float64):
     lib.Tile_create_ex.restype = None
     lib.Tile_create_device.argtypes = [TP, C.c_int, C.c_int, C.c_int, _I, _I, VP, C.c_uint]
     lib.Tile_create_device.restype = C.c_int
+    lib.tilespmv_plan_create_from_csr.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, _I, _I, VP, C.c_uint, C.POINTER(PlanOptions)]
+    lib.tilespmv_plan_create_from_csr.restype = C.c_int
+    lib.tilespmv_plan_stream_digests.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_longlong]
+    lib.tilespmv_plan_stream_digests.restype = C.c_longlong
     lib.Tile_destroy.argtypes = [TP]
     lib.Tile_destroy.restype = None
     lib.tilespmv_cpu.argtypes = [TP, _I, _I, _I, C.POINTER(_U), C.POINTER(_I), C.POINTER(_I), C.c_int, C.c_int, C.c_int,
@@ -157,4 +161,4 @@ DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_c
                     "call_tilespmv_hip_multi", "tilespmv_plan_spmm", "tilespmv_plan_time_spmm", "tilespmv_plan_options_init", "tilespmv_plan_layout_digest",
                     "tilespmv_csr_save", "tilespmv_csr_load", "mmio_allinone_cached", "tilespmv_mtx_write",
                     "tilespmv_plan_time_reference_style", "tilespmv_plan_reserve_spmm", "tilespmv_plan_options_layout", "tilespmv_plan_layout_stages",
-                    "Tile_create_device"]
+                    "Tile_create_device", "tilespmv_plan_create_from_csr", "tilespmv_plan_stream_digests"]

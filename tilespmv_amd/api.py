@@ -217,6 +217,26 @@ class Plan:
             raise RuntimeError("tilespmv_plan_create failed (%d): no usable HIP device / extension" % rc)
         self.h = h
 
+    @classmethod
+    def from_csr(cls, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, cdna4=False, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, **knobs):
+        """``tilespmv_plan_create_from_csr``: the tiled matrix and the plan's streams are built on the device; only the CSR arrays cross the bus.
+        Raises ``NotImplementedError`` for the options that have no device path (rc -4: autotune, first-generation kernel, CSR fallback, csr_split=0, x_window=1)."""
+        dtype = np.dtype(dtype or np.asarray(csrValA).dtype)
+        lib = _lib.load(dtype)
+        rp, ci, v = _csr(lib, csrRowPtrA, csrColIdxA, csrValA)
+        self = cls.__new__(cls)
+        self.lib = lib
+        self.rowA, self.colA, self.nnzA = rowA, colA, nnzA
+        opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, False, **knobs)
+        h = C.c_void_p()
+        rc = lib.tilespmv_plan_create_from_csr(C.byref(h), rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int), _p(v, lib._vt), CREATE_QUIET | (CREATE_CDNA4 if cdna4 else 0), C.byref(opts))
+        if rc == -4:
+            raise NotImplementedError("tilespmv_plan_create_from_csr: these options have no device path")
+        if rc != 0 or not h:
+            raise RuntimeError("tilespmv_plan_create_from_csr failed (%d)" % rc)
+        self.h = h
+        return self
+
     def spmv(self, d_x, d_y, stream=0):
         rc = self.lib.tilespmv_plan_spmv(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream))
         if rc != 0:
@@ -263,6 +283,14 @@ class Plan:
         out = (C.c_longlong * len(_lib.INFO_NAMES))()
         self.lib.tilespmv_plan_info(self.h, out)
         return {k: int(out[i]) for i, k in enumerate(_lib.INFO_NAMES)}
+
+    def stream_digests(self):
+        """{member offset: (bytes, FNV-1a-64)} of every stream of the plan, read back from the device (test / audit aid)."""
+        out = (C.c_ulonglong * (3 * 64))()
+        n = self.lib.tilespmv_plan_stream_digests(self.h, out, 64)
+        if n < 0 or n > 64:
+            raise RuntimeError("tilespmv_plan_stream_digests failed (%d)" % n)
+        return {int(out[3 * i]): (int(out[3 * i + 1]), int(out[3 * i + 2])) for i in range(n)}
 
     def close(self):
         if getattr(self, "h", None):

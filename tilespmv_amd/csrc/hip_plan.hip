@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "hip_plan_internal.h"
+#include "hip_plan_device.h"
 
 namespace tilespmv {
 
@@ -240,7 +241,7 @@ void tilespmv_plan_destroy(tilespmv_plan *plan)
     delete plan;
 }
 
-static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const Knobs &K);
+static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const Knobs &K, const DevTile *DT = nullptr);
 
 void tilespmv_plan_options_init(tilespmv_plan_options *o)
 {
@@ -492,7 +493,9 @@ static void calibrate_panels(tilespmv_plan *plan, int colA)
     (void)hipFree(dx); (void)hipFree(dy);
 }
 
-static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const Knobs &K)
+// DT != nullptr: device mode (tilespmv_plan_create_from_csr).  T is then a host copy of the tile LIST only (tile_ptr, tile_columnidx, Format + the counts); the other member
+// arrays are read from DT->T (device memory) where a number is needed here, and by kernels in the builder (hip_plan_device.h).
+static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const Knobs &K, const DevTile *DT)
 {
     (void)nnzA;
     *out = nullptr;
@@ -521,9 +524,17 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     const int t_begin = T->tile_ptr[tr0], t_end = T->tile_ptr[tr1];
     const long long shard_rows = std::min<long long>((long long)tr1 * 16, rowA) - (long long)tr0 * 16;
     long long ncoo_tiles = 0, ncoo_vals = 0;
-    for (int t = t_begin; t < t_end; t++)
-        if (T->Format[t] == TILESPMV_FMT_COO) { ncoo_tiles++; ncoo_vals += T->blknnz[t + 1] - T->blknnz[t]; }
-    const long long extracted = T->new_coocount[t_end] - T->new_coocount[t_begin];
+    if (!DT)   // (read by the first-generation layout's choice only)
+        for (int t = t_begin; t < t_end; t++)
+            if (T->Format[t] == TILESPMV_FMT_COO) { ncoo_tiles++; ncoo_vals += T->blknnz[t + 1] - T->blknnz[t]; }
+    // a difference of two elements of a per-tile prefix array, wherever the array lives
+    auto span = [&](const int *host_array, const int *dev_array, int a, int b) -> long long {
+        if (!DT) return (long long)host_array[b] - host_array[a];
+        const long long idx[2] = {a, b}; int v[2] = {0, 0};
+        if (dev_fetch_ints(dev_array, idx, 2, v) != 0) return 0;
+        return (long long)v[1] - v[0];
+    };
+    const long long extracted = DT ? 0 : (long long)T->new_coocount[t_end] - T->new_coocount[t_begin];   // (device mode runs COO tiles in-tile: the extracted matrix is not built)
     int coo_mode = o.coo_mode, dense_mode = o.dense_mode, kernel = o.kernel;
     if (kernel == TILESPMV_KERNEL_AUTO)  // the unit descriptor keeps the column block in 24 bits
         kernel = tilen <= (1 << UNIT_FLAG_SHIFT) ? TILESPMV_KERNEL_STREAM : TILESPMV_KERNEL_DIRECT;
@@ -557,7 +568,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
                 for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) if (T->Format[t] == TILESPMV_FMT_DNS) nd++;
                 dense_vals += 256 * nd; dense_rows += nd > 0;
             }
-            const long long all_vals = (long long)T->blknnz[t_end] - T->blknnz[t_begin];
+            const long long all_vals = span(T->blknnz, DT ? DT->T.blknnz : nullptr, t_begin, t_end);
             dense_mode = (dense_vals * 10 >= all_vals && dense_vals >= 256 * 1024 && dense_vals >= 256 * 5 * dense_rows / 2) ? TILESPMV_DENSE_MFMA : TILESPMV_DENSE_VALU;
         }
     }
@@ -597,7 +608,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     int rc = 0;
     DevPlan &D = plan->dev;
     if (kernel == TILESPMV_KERNEL_STREAM) {
-        rc = build_stream(plan, K, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mode == TILESPMV_DENSE_MFMA, hyb_off, fix, npartial, n_tasks, model_bytes);
+        rc = build_stream(plan, K, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mode == TILESPMV_DENSE_MFMA, hyb_off, fix, npartial, n_tasks, model_bytes, DT);
     } else {
     // ---- pass 1: stream sizes per tile-row
     std::vector<long long> row_tile((size_t)ntr + 1, 0), row_val((size_t)ntr + 1, 0), row_idx((size_t)ntr + 1, 0);
@@ -783,7 +794,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     D.f_row0 = row0; D.f_rows = rows;
 
     long long *I = plan->info;
-    I[TILESPMV_INFO_NNZ] = T->tile_nnz[t_end] - T->tile_nnz[t_begin];
+    I[TILESPMV_INFO_NNZ] = span(T->tile_nnz, DT ? DT->T.tile_nnz : nullptr, t_begin, t_end);
     I[TILESPMV_INFO_ROWS] = rows;
     I[TILESPMV_INFO_TILES] = t_end - t_begin;
     I[TILESPMV_INFO_COO_MODE] = coo_mode; I[TILESPMV_INFO_DENSE_MODE] = dense_mode; I[TILESPMV_INFO_KERNEL] = plan->kernel;
@@ -827,6 +838,48 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     }
     *out = plan;
     return 0;
+}
+
+int tilespmv_plan_create_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *rowptr, const int *colidx, const MAT_VAL_TYPE *val, unsigned create_flags,
+                                  const tilespmv_plan_options *opts)
+{
+    *out = nullptr;
+    const Knobs K = resolve_knobs(opts);
+    const int tilen = (colA + BS - 1) / BS;
+    // what has no device path (include/tilespmv.h): the caller builds those plans from a host Tile_matrix
+    if (K.autotune || K.dry || (create_flags & TILESPMV_CREATE_HYB) || K.kernel == TILESPMV_KERNEL_DIRECT || tilen > (1 << UNIT_FLAG_SHIFT) || K.coo_mode == TILESPMV_COO_FALLBACK || K.csr_split == 0 ||
+        K.x_window == 1)
+        return -4;
+    const double t0 = now_us();
+    DevTile *D = nullptr;
+    int rc = devtile_create(&D, rowA, colA, rowptr, colidx, val, create_flags, false);
+    if (rc != 0) return rc;
+    const double t1 = now_us();
+    // the tile LIST on the host (what CHOOSE / CUT / the stride detection read); everything else of the tiled matrix stays where it is
+    Tile_matrix H = D->T;
+    {
+        Tile_matrix Z;   // counts stay, every pointer member is cleared (three are replaced below) memset(&Z, 0, sizeof(Z));
+        Z.tilem = H.tilem; Z.tilen = H.tilen; Z.tilenum = H.tilenum;
+        Z.csrsize = H.csrsize; Z.csrptrlen = H.csrptrlen; Z.coosize = H.coosize; Z.ellsize = H.ellsize; Z.dnssize = H.dnssize; Z.dnsrowsize = H.dnsrowsize; Z.dnscolsize = H.dnscolsize; Z.coototal = H.coototal;
+        H = Z;
+    }
+    std::vector<int> h_tile_ptr((size_t)H.tilem + 1, 0), h_tile_col((size_t)std::max(1, H.tilenum), 0);
+    std::vector<char> h_fmt((size_t)std::max(1, H.tilenum), 0);
+    hipError_t e = hipMemcpy(h_tile_ptr.data(), D->T.tile_ptr, h_tile_ptr.size() * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && H.tilenum > 0) e = hipMemcpy(h_tile_col.data(), D->T.tile_columnidx, (size_t)H.tilenum * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && H.tilenum > 0) e = hipMemcpy(h_fmt.data(), D->T.Format, (size_t)H.tilenum, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { fprintf(stderr, "tilespmv: tile list to the host: %s\n", hipGetErrorString(e)); (void)hipGetLastError(); devtile_destroy(D); return -3; }
+    H.tile_ptr = h_tile_ptr.data(); H.tile_columnidx = h_tile_col.data(); H.Format = h_fmt.data();
+    Knobs Kd = K;
+    if (Kd.kernel == TILESPMV_KERNEL_AUTO) Kd.kernel = TILESPMV_KERNEL_STREAM;
+    if (Kd.coo_mode == TILESPMV_COO_AUTO) Kd.coo_mode = TILESPMV_COO_IN_TILE;
+    rc = plan_create_one(out, &H, rowA, colA, nnzA, Kd, D);
+    devtile_destroy(D);
+    if (rc == 0 && *out) {
+        (*out)->info[TILESPMV_INFO_DEVICE_BUILD] = 1;
+        (*out)->info[TILESPMV_INFO_TILE_CREATE_US] = (long long)(t1 - t0);
+    }
+    return rc;
 }
 
 int tilespmv_plan_layout_digest(const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const tilespmv_plan_options *opts,
@@ -957,6 +1010,26 @@ long long tilespmv_plan_stamps(const tilespmv_plan *plan, unsigned long long *ou
     return n;
 }
 #endif
+
+long long tilespmv_plan_stream_digests(const tilespmv_plan *plan, unsigned long long *out, long long max_streams)
+{
+    // every stream the builder placed in the plan's arena (upload() / reserve() record the member they filled and its size): the member's offset in the plan object names it
+    long long n = 0;
+    std::vector<unsigned char> buf;
+    for (size_t i = 0; i < plan->uploaded_slots.size(); i++) {
+        const void *dev = *plan->uploaded_slots[i];
+        const size_t bytes = plan->uploaded_bytes[i];
+        unsigned long long h = 1469598103934665603ull;
+        if (bytes && dev) {
+            buf.resize(bytes);
+            if (hipMemcpy(buf.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -3; }
+            for (size_t q = 0; q < bytes; q++) { h ^= buf[q]; h *= 1099511628211ull; }
+        }
+        if (n < max_streams) { out[3 * n] = (unsigned long long)((const char *)plan->uploaded_slots[i] - (const char *)plan); out[3 * n + 1] = bytes; out[3 * n + 2] = h; }
+        n++;
+    }
+    return n;
+}
 
 void tilespmv_plan_info(const tilespmv_plan *plan, long long *out)
 {

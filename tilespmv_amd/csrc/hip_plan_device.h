@@ -1,0 +1,41 @@
+// hip_plan_device.h — the stages of the unit-stream builder (hip_plan_stream.hip) that touch every nonzero, as kernels over a device-resident Tile_matrix
+// (hip_tile_create.h DevTile): COUNT and EMIT call the same per-tile functions as the host builder (plan_tile_ops.h), ENCODE's descriptor pass and pattern dictionary
+// are a sort + run-length encoding.  The decisions in between (CHOOSE, CUT, ORDER: functions of per-tile-row counts) stay on the host.  SURVEY S8 f1; reference
+// src/csr2tile.h:629-1020 is the preprocessing this replaces end to end: with tilespmv_plan_create_from_csr only the CSR arrays cross the bus.
+#pragma once
+#include <vector>
+
+#include "hip_tile_create.h"
+#include "plan_tile_ops.h"
+
+namespace tilespmv {
+
+// per-tile exclusive prefixes of one counting pass over the shard's tiles [t_begin, t_end] (device arrays of t_end - t_begin + 1 ints), + the pooled part per tile-row
+struct DevCounts {
+    int csr_form = -1;
+    int *tu = nullptr, *tc = nullptr, *td = nullptr;   // units / list entries / dense tiles emitted by the tiles before tile t (pool excluded)
+    int *pool_u = nullptr, *pool_c = nullptr;          // pooled plans: units / list entries of every tile-row's pool
+    PoolEnt *pool = nullptr;                           // pooled plans: scratch, the shard's stored nonzeros
+    void release();
+};
+
+struct DevShard { const DevTile *D; int tr0, tr1, t_begin, t_end; bool coo_in_tile, dense_mfma; long long stored0, stored; };   // stored: blknnz[t_end] - blknnz[t_begin]
+
+// rc 0 or -3 (HIP error, reported on stderr)
+int dev_fetch_ints(const int *d_array, const long long *idx, int n, int *out);   // out[k] = d_array[idx[k]]
+int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &nunits, std::vector<int> &ncoo, std::vector<int> &ndense);
+// column patterns of the first units on a sample of tiles (what the split form's dictionary would have to hold): ELL slots exactly, of a CSR tile its first unit
+int dev_pattern_sample(const DevShard &S, int step, std::vector<unsigned long long> &patterns);
+// EMIT: pu / pc / pd = first unit / list entry / dense tile of every tile-row (ntr + 1), row_k / row_split as in the host builder.  O: device destinations (zeroed by the caller;
+// urow is filled with the identity here)
+int dev_emit(const DevShard &S, const DevCounts &C, const std::vector<long long> &pu, const std::vector<long long> &pc, const std::vector<long long> &pd, const std::vector<unsigned char> &row_k,
+             const std::vector<unsigned char> &row_split, long long NU, const EmitOut &O);
+// word 0 of every emitted unit descriptor -> host (brick order scores the column blocks of the strips)
+int dev_fetch_word0(const uint4 *d_udesc, long long NU, std::vector<unsigned> &w0);
+// ENCODE: units of task i move from [map.x, map.x + map.z) to [map.y, ..) of the packed numbering (padding units in between stay zero)
+int dev_pack_desc(const uint4 *d_udesc, const uint2 *d_urow, const int4 *d_map, int ntasks, UDesc *d_packed, URow *d_packed_row);   // d_map: device copy of the (old begin, new begin, count) triples
+// the distinct (n0, n1) patterns of NUP packed descriptors, ascending, if there are at most `cap` of them (else `over` = true); then the 4-byte form
+int dev_dict_patterns(const UDesc *d_packed, long long NUP, size_t cap, std::vector<unsigned long long> &sorted_patterns, bool *over);
+int dev_compact_desc(const UDesc *d_packed, long long NUP, const uint2 *d_dict, int ndict, int cb_bits, unsigned *d_compact);
+
+}  // namespace tilespmv

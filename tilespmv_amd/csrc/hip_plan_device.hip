@@ -1,0 +1,333 @@
+// hip_plan_device.hip — COUNT / EMIT / ENCODE of the unit-stream builder as kernels over a device-resident Tile_matrix (hip_plan_device.h).
+// One thread per tile (one per tile-row for the pooled windows, which run across a tile-row's tiles) calling the functions of plan_tile_ops.h that the host builder
+// calls from its loops: the same records at the same offsets.  The host keeps the decisions (hip_plan_stream.hip CHOOSE / CUT / ORDER) and sends back prefix arrays.
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "hip_plan_device.h"
+
+namespace tilespmv {
+namespace {
+
+#define PD_TRY(expr)                                                                                                \
+    do {                                                                                                            \
+        hipError_t e_ = (expr);                                                                                     \
+        if (e_ != hipSuccess) {                                                                                     \
+            fprintf(stderr, "tilespmv: device plan build: HIP error %d (%s) at %s:%d\n", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (void)hipGetLastError();                                                                                \
+            return -3;                                                                                              \
+        }                                                                                                           \
+    } while (0)
+
+typedef unsigned long long u64;
+inline unsigned nblk(long long n, int per) { return (unsigned)std::max<long long>(1, (n + per - 1) / per); }
+
+// a temporary device array that frees itself
+template <class V>
+struct Tmp {
+    V *p = nullptr;
+    ~Tmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n, bool zero)
+    {
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(V) + 16);
+        if (e == hipSuccess && zero) e = hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(V) + 16, 0);
+        return e;
+    }
+    hipError_t from(const std::vector<V> &h) { hipError_t e = alloc(h.size(), false); if (e == hipSuccess && !h.empty()) e = hipMemcpy(p, h.data(), h.size() * sizeof(V), hipMemcpyHostToDevice); return e; }
+};
+
+hipError_t scan_in_place(int *a, size_t n)
+{
+    size_t tmp_b = 0; void *tmp = nullptr;
+    hipError_t e = rocprim::exclusive_scan(nullptr, tmp_b, a, a, 0, n, rocprim::plus<int>(), (hipStream_t)0);
+    if (e != hipSuccess) return e;
+    e = hipMalloc(&tmp, std::max<size_t>(tmp_b, 16));
+    if (e != hipSuccess) return e;
+    e = rocprim::exclusive_scan(tmp, tmp_b, a, a, 0, n, rocprim::plus<int>(), (hipStream_t)0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(tmp);
+    return e;
+}
+
+__global__ __launch_bounds__(256) void k_pd_gather_ints(const int *__restrict__ a, const long long *__restrict__ idx, int n, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[idx[i]];
+}
+
+// ---- COUNT
+__global__ __launch_bounds__(256) void k_pd_count_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, int t_begin, int nt, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form,
+                                                          int *__restrict__ tu, int *__restrict__ tc, int *__restrict__ td)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nt) return;
+    const int t = t_begin + (int)gid;
+    const TileCount k = tile_count(&T, t, tile_rowlen(tile_bi[t], T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form);
+    tu[gid] = k.nunits; tc[gid] = k.ncoo; td[gid] = k.ndense;
+}
+__global__ __launch_bounds__(64) void k_pd_count_pool(const Tile_matrix T, int tr0, int ntr, int rowA, bool coo_in_tile, long long stored0, PoolEnt *__restrict__ pool, int *__restrict__ pool_u, int *__restrict__ pool_c)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntr) return;
+    const int bi = tr0 + (int)i;
+    int nu, nc;
+    pool_row_count(&T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, nullptr, pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0), &nu, &nc);
+    pool_u[i] = nu; pool_c[i] = nc;
+}
+__global__ __launch_bounds__(256) void k_pd_row_counts(const int *__restrict__ tile_ptr, int tr0, int ntr, int t_begin, const int *__restrict__ tu, const int *__restrict__ tc, const int *__restrict__ td,
+                                                         const int *__restrict__ pool_u, const int *__restrict__ pool_c, int *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntr) return;
+    const int a = tile_ptr[tr0 + i] - t_begin, b = tile_ptr[tr0 + i + 1] - t_begin;
+    out[3 * i] = tu[b] - tu[a] + (pool_u ? pool_u[i] : 0);
+    out[3 * i + 1] = tc[b] - tc[a] + (pool_c ? pool_c[i] : 0);
+    out[3 * i + 2] = td[b] - td[a];
+}
+
+// the sample of hip_plan_stream.hip StreamBuilder::count(), literally (it reads 16 rows of every sampled tile: a sample, not a count)
+__global__ __launch_bounds__(256) void k_pd_pattern_sample(const Tile_matrix T, int t_begin, int t_end, int step, int nsample, u64 *__restrict__ pats, int *__restrict__ npat)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsample) return;
+    const int t = t_begin + s * step;
+    int n = 0;
+    if (t < t_end) {
+        const int fmt = T.Format[t];
+        if (fmt == TILESPMV_FMT_ELL) {
+            const int off = T.ell_offset[t], w = T.tilewidth[t];
+            for (int sl = 0; sl < w; sl++) { u64 nibs = 0; for (int r = 0; r < 16; r++) nibs |= (u64)nib_at(T.ell_compressedIdx, (long long)off + sl * 16 + r) << (60 - 4 * r); pats[(size_t)s * 16 + n++] = nibs; }
+        } else if (fmt == TILESPMV_FMT_CSR) {
+            const int off = T.csr_offset[t], stored = T.blknnz[t + 1] - T.blknnz[t];
+            const unsigned char *ptr = T.Blockcsr_Ptr + T.csrptr_offset[t];
+            u64 nibs = 0;
+            for (int r = 0; r < 16; r++) { const int k0 = ptr[r], k1 = r == 15 ? stored : ptr[r + 1]; if (k1 > k0) nibs |= (u64)nib_at(T.csr_compressedIdx, (long long)off + k0) << (60 - 4 * r); }
+            pats[(size_t)s * 16 + n++] = nibs;
+        }
+    }
+    npat[s] = n;
+}
+
+// ---- EMIT
+__global__ __launch_bounds__(256) void k_pd_fill_urow(uint2 *__restrict__ urow, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) urow[i] = make_uint2(0x01234567u, 0x89ABCDEFu);   // (units that keep one row per lane: identity)
+}
+__global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, int t_begin, int nt, int tr0, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form,
+                                                         const int *__restrict__ tu, const int *__restrict__ tc, const int *__restrict__ td, const int *__restrict__ pu, const int *__restrict__ pc,
+                                                         const int *__restrict__ pd, const unsigned char *__restrict__ row_k, const unsigned char *__restrict__ row_split, const EmitOut O)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nt) return;
+    const int t = t_begin + (int)gid, bi = tile_bi[t], i = bi - tr0, a = T.tile_ptr[bi] - t_begin;
+    EmitPos p{(long long)pu[i] + tu[gid] - tu[a], (long long)pc[i] + tc[gid] - tc[a], (long long)pd[i] + td[gid] - td[a]};
+    const long long u0 = p.u;
+    tile_emit(&T, t, tile_rowlen(bi, T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form, (unsigned)row_k[i], nullptr, O, p);
+    // the tile that emits the last unit of an unsplit tile-row of a classic plan marks it (the kernel writes y there)
+    if (csr_form != 2 && !row_split[i] && p.u > u0 && p.u == pu[i + 1]) { O.udesc[p.u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; O.udesc[p.u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
+}
+__global__ __launch_bounds__(64) void k_pd_emit_pool(const Tile_matrix T, int tr0, int ntr, int t_begin, int rowA, bool coo_in_tile, long long stored0, PoolEnt *__restrict__ pool, const int *__restrict__ tu,
+                                                       const int *__restrict__ tc, const int *__restrict__ pu, const int *__restrict__ pc, const unsigned char *__restrict__ row_k, const EmitOut O)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntr) return;
+    const int bi = tr0 + (int)i, a = T.tile_ptr[bi] - t_begin, b = T.tile_ptr[bi + 1] - t_begin;
+    EmitPos p{(long long)pu[i] + tu[b] - tu[a], (long long)pc[i] + tc[b] - tc[a], 0};   // behind what the tile-row's tiles emitted themselves
+    pool_row_emit(&T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, (unsigned)row_k[i], nullptr, pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0), O, p);
+}
+__global__ __launch_bounds__(256) void k_pd_word0(const uint4 *__restrict__ udesc, long long n, unsigned *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = udesc[i].x;
+}
+
+// ---- ENCODE
+__global__ __launch_bounds__(256) void k_pd_pack_desc(const uint4 *__restrict__ udesc, const uint2 *__restrict__ urow, const int4 *__restrict__ map, int ntasks, UDesc *__restrict__ packed, URow *__restrict__ packed_row)
+{
+    for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {
+        const int4 m = map[t];
+        for (int j = threadIdx.x; j < m.z; j += 256) {
+            const uint4 d = udesc[(long long)m.x + j];
+            packed[(long long)m.y + j] = UDesc{d.x, d.y, d.w};
+            if (urow) { const uint2 r = urow[(long long)m.x + j]; packed_row[(long long)m.y + j] = URow{r.x, r.y}; }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_pd_patterns(const UDesc *__restrict__ packed, long long n, u64 *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ((u64)packed[i].n0 << 32) | packed[i].n1;
+}
+__global__ __launch_bounds__(256) void k_pd_compact(const UDesc *__restrict__ packed, long long n, const uint2 *__restrict__ dict, int ndict, int cb_bits, unsigned *__restrict__ compact)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const UDesc d = packed[i];
+    const u64 key = ((u64)d.n0 << 32) | d.n1;
+    int lo = 0, hi = ndict;   // lower bound in the ascending dictionary
+    while (lo < hi) { const int mid = (lo + hi) >> 1; const uint2 q = dict[mid]; if ((((u64)q.x << 32) | q.y) < key) lo = mid + 1; else hi = mid; }
+    compact[i] = (d.w0 & ((1u << cb_bits) - 1u)) | ((unsigned)lo << cb_bits) | ((d.w0 >> UNIT_FLAG_SHIFT) << 27);
+}
+
+}  // namespace
+
+void DevCounts::release()
+{
+    for (void *q : {(void *)tu, (void *)tc, (void *)td, (void *)pool_u, (void *)pool_c, (void *)pool}) if (q) (void)hipFree(q);
+    tu = tc = td = pool_u = pool_c = nullptr; pool = nullptr; csr_form = -1;
+}
+
+int dev_fetch_ints(const int *d_array, const long long *idx, int n, int *out)
+{
+    if (n <= 0) return 0;
+    Tmp<long long> d_idx; Tmp<int> d_out;
+    PD_TRY(d_idx.alloc((size_t)n, false)); PD_TRY(d_out.alloc((size_t)n, false));
+    PD_TRY(hipMemcpy(d_idx.p, idx, (size_t)n * sizeof(long long), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pd_gather_ints, dim3(nblk(n, 256)), dim3(256), 0, 0, d_array, (const long long *)d_idx.p, n, d_out.p);
+    PD_TRY(hipGetLastError());
+    PD_TRY(hipMemcpy(out, d_out.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &nunits, std::vector<int> &ncoo, std::vector<int> &ndense)
+{
+    const DevTile *D = S.D;
+    const int nt = S.t_end - S.t_begin, ntr = S.tr1 - S.tr0;
+    C->release();
+    C->csr_form = csr_form;
+    nunits.assign((size_t)ntr, 0); ncoo.assign((size_t)ntr, 0); ndense.assign((size_t)ntr, 0);
+    auto alloc_ints = [&](int **p, size_t n) { hipError_t e = hipMalloc((void **)p, (n + 4) * sizeof(int)); if (e == hipSuccess) e = hipMemsetAsync(*p, 0, (n + 4) * sizeof(int), 0); return e; };
+    PD_TRY(alloc_ints(&C->tu, (size_t)nt + 1)); PD_TRY(alloc_ints(&C->tc, (size_t)nt + 1)); PD_TRY(alloc_ints(&C->td, (size_t)nt + 1));
+    if (nt > 0) {
+        hipLaunchKernelGGL(k_pd_count_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, S.t_begin, nt, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, csr_form, C->tu, C->tc, C->td);
+        PD_TRY(hipGetLastError());
+        PD_TRY(scan_in_place(C->tu, (size_t)nt + 1)); PD_TRY(scan_in_place(C->tc, (size_t)nt + 1)); PD_TRY(scan_in_place(C->td, (size_t)nt + 1));
+    }
+    if (csr_form == 2 && ntr > 0) {
+        PD_TRY(alloc_ints(&C->pool_u, (size_t)ntr)); PD_TRY(alloc_ints(&C->pool_c, (size_t)ntr));
+        PD_TRY(hipMalloc((void **)&C->pool, (size_t)std::max<long long>(1, S.stored) * sizeof(PoolEnt) + 16));
+        hipLaunchKernelGGL(k_pd_count_pool, dim3(nblk(ntr, 64)), dim3(64), 0, 0, D->T, S.tr0, ntr, D->rowA, S.coo_in_tile, S.stored0, C->pool, C->pool_u, C->pool_c);
+        PD_TRY(hipGetLastError());
+    }
+    if (ntr > 0) {
+        Tmp<int> d_out;
+        PD_TRY(d_out.alloc((size_t)ntr * 3, false));
+        hipLaunchKernelGGL(k_pd_row_counts, dim3(nblk(ntr, 256)), dim3(256), 0, 0, (const int *)D->T.tile_ptr, S.tr0, ntr, S.t_begin, (const int *)C->tu, (const int *)C->tc, (const int *)C->td,
+                           (const int *)C->pool_u, (const int *)C->pool_c, d_out.p);
+        PD_TRY(hipGetLastError());
+        std::vector<int> h((size_t)ntr * 3);
+        PD_TRY(hipMemcpy(h.data(), d_out.p, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < ntr; i++) { nunits[(size_t)i] = h[3 * (size_t)i]; ncoo[(size_t)i] = h[3 * (size_t)i + 1]; ndense[(size_t)i] = h[3 * (size_t)i + 2]; }
+    }
+    return 0;
+}
+
+int dev_pattern_sample(const DevShard &S, int step, std::vector<unsigned long long> &patterns)
+{
+    patterns.clear();
+    const int nt = S.t_end - S.t_begin;
+    if (nt <= 0) return 0;
+    const int nsample = (nt + step - 1) / step;
+    Tmp<u64> d_p; Tmp<int> d_n;
+    PD_TRY(d_p.alloc((size_t)nsample * 16, false)); PD_TRY(d_n.alloc((size_t)nsample, true));
+    hipLaunchKernelGGL(k_pd_pattern_sample, dim3(nblk(nsample, 256)), dim3(256), 0, 0, S.D->T, S.t_begin, S.t_end, step, nsample, d_p.p, d_n.p);
+    PD_TRY(hipGetLastError());
+    std::vector<u64> hp((size_t)nsample * 16); std::vector<int> hn((size_t)nsample);
+    PD_TRY(hipMemcpy(hp.data(), d_p.p, hp.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    PD_TRY(hipMemcpy(hn.data(), d_n.p, hn.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int s = 0; s < nsample; s++) for (int q = 0; q < hn[(size_t)s]; q++) patterns.push_back(hp[(size_t)s * 16 + q]);
+    return 0;
+}
+
+int dev_emit(const DevShard &S, const DevCounts &C, const std::vector<long long> &pu, const std::vector<long long> &pc, const std::vector<long long> &pd, const std::vector<unsigned char> &row_k,
+             const std::vector<unsigned char> &row_split, long long NU, const EmitOut &O)
+{
+    const DevTile *D = S.D;
+    const int nt = S.t_end - S.t_begin, ntr = S.tr1 - S.tr0;
+    if (ntr <= 0) return 0;
+    auto narrow = [](const std::vector<long long> &v) { std::vector<int> o(v.size()); for (size_t i = 0; i < v.size(); i++) o[i] = (int)v[i]; return o; };   // (the builder refuses shards beyond 2^31 units / entries)
+    Tmp<int> d_pu, d_pc, d_pd; Tmp<unsigned char> d_rk, d_rs;
+    PD_TRY(d_pu.from(narrow(pu))); PD_TRY(d_pc.from(narrow(pc))); PD_TRY(d_pd.from(narrow(pd)));
+    PD_TRY(d_rk.from(row_k)); PD_TRY(d_rs.from(row_split));
+    if (O.urow && NU > 0) { hipLaunchKernelGGL(k_pd_fill_urow, dim3(nblk(NU, 256)), dim3(256), 0, 0, O.urow, NU); PD_TRY(hipGetLastError()); }
+    if (nt > 0) {
+        hipLaunchKernelGGL(k_pd_emit_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, S.t_begin, nt, S.tr0, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, C.csr_form, (const int *)C.tu,
+                           (const int *)C.tc, (const int *)C.td, (const int *)d_pu.p, (const int *)d_pc.p, (const int *)d_pd.p, (const unsigned char *)d_rk.p, (const unsigned char *)d_rs.p, O);
+        PD_TRY(hipGetLastError());
+    }
+    if (C.csr_form == 2) {
+        hipLaunchKernelGGL(k_pd_emit_pool, dim3(nblk(ntr, 64)), dim3(64), 0, 0, D->T, S.tr0, ntr, S.t_begin, D->rowA, S.coo_in_tile, S.stored0, C.pool, (const int *)C.tu, (const int *)C.tc, (const int *)d_pu.p,
+                           (const int *)d_pc.p, (const unsigned char *)d_rk.p, O);
+        PD_TRY(hipGetLastError());
+    }
+    PD_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+int dev_fetch_word0(const uint4 *d_udesc, long long NU, std::vector<unsigned> &w0)
+{
+    w0.assign((size_t)NU, 0u);
+    if (NU <= 0) return 0;
+    Tmp<unsigned> d;
+    PD_TRY(d.alloc((size_t)NU, false));
+    hipLaunchKernelGGL(k_pd_word0, dim3(nblk(NU, 256)), dim3(256), 0, 0, d_udesc, NU, d.p);
+    PD_TRY(hipGetLastError());
+    PD_TRY(hipMemcpy(w0.data(), d.p, (size_t)NU * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dev_pack_desc(const uint4 *d_udesc, const uint2 *d_urow, const int4 *d_map, int ntasks, UDesc *d_packed, URow *d_packed_row)
+{
+    if (ntasks <= 0) return 0;
+    hipLaunchKernelGGL(k_pd_pack_desc, dim3((unsigned)std::min(ntasks, 1 << 20)), dim3(256), 0, 0, d_udesc, d_urow, d_map, ntasks, d_packed, d_packed_row);
+    PD_TRY(hipGetLastError());
+    PD_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+int dev_dict_patterns(const UDesc *d_packed, long long NUP, size_t cap, std::vector<unsigned long long> &sorted_patterns, bool *over)
+{
+    sorted_patterns.clear(); *over = false;
+    if (NUP <= 0) return 0;
+    Tmp<u64> a, b, uniq; Tmp<int> counts, nruns;
+    PD_TRY(a.alloc((size_t)NUP, false)); PD_TRY(b.alloc((size_t)NUP, false));
+    hipLaunchKernelGGL(k_pd_patterns, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, NUP, a.p);
+    PD_TRY(hipGetLastError());
+    rocprim::double_buffer<u64> kb(a.p, b.p);
+    size_t tmp_b = 0; void *tmp = nullptr;
+    PD_TRY(rocprim::radix_sort_keys(nullptr, tmp_b, kb, (size_t)NUP, 0u, 64u, (hipStream_t)0));
+    PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
+    hipError_t e = rocprim::radix_sort_keys(tmp, tmp_b, kb, (size_t)NUP, 0u, 64u, (hipStream_t)0);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(tmp);
+    PD_TRY(e);
+    PD_TRY(uniq.alloc((size_t)NUP, false)); PD_TRY(counts.alloc((size_t)NUP, false)); PD_TRY(nruns.alloc(1, true));
+    tmp_b = 0; tmp = nullptr;
+    PD_TRY(rocprim::run_length_encode(nullptr, tmp_b, kb.current(), (unsigned)NUP, uniq.p, counts.p, nruns.p, (hipStream_t)0));
+    PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
+    e = rocprim::run_length_encode(tmp, tmp_b, kb.current(), (unsigned)NUP, uniq.p, counts.p, nruns.p, (hipStream_t)0);
+    int n = 0;
+    if (e == hipSuccess) e = hipMemcpy(&n, nruns.p, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    PD_TRY(e);
+    if ((size_t)n > cap) { *over = true; return 0; }
+    sorted_patterns.resize((size_t)n);
+    PD_TRY(hipMemcpy(sorted_patterns.data(), uniq.p, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dev_compact_desc(const UDesc *d_packed, long long NUP, const uint2 *d_dict, int ndict, int cb_bits, unsigned *d_compact)
+{
+    if (NUP <= 0) return 0;
+    hipLaunchKernelGGL(k_pd_compact, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, NUP, d_dict, ndict, cb_bits, d_compact);
+    PD_TRY(hipGetLastError());
+    PD_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+}  // namespace tilespmv

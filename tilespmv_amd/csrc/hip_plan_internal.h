@@ -201,6 +201,7 @@ struct tilespmv_plan {
     bool pace_calibrate = false;        // slab-paced plan whose timetable length is still to be found by timing (plan_create_one)
     unsigned long long digest = 1469598103934665603ull;
     unsigned long long stage_digest[TILESPMV_STAGE_COUNT] = {0};   // layout-digest builds: one hash per stage of the unit-stream builder (hip_plan_stream.hip)
+    std::vector<size_t> uploaded_bytes;          // ... and the bytes of each (tilespmv_plan_stream_digests)
     std::vector<const void **> uploaded_slots;   // every device-pointer MEMBER of this plan that upload() filled: what a re-placement rebases (hip_plan.hip retry_placement)
     // arena space for n elements that a device kernel will fill (zeroed like every block); same bookkeeping as upload()
     template <class T>
@@ -208,7 +209,7 @@ struct tilespmv_plan {
     template <class T>
     int upload(const T *host, size_t n, const T **out)
     {
-        if ((const char *)out >= (const char *)this && (const char *)out < (const char *)this + sizeof(*this)) uploaded_slots.push_back((const void **)out);
+        if ((const char *)out >= (const char *)this && (const char *)out < (const char *)this + sizeof(*this)) { uploaded_slots.push_back((const void **)out); uploaded_bytes.push_back(n * sizeof(T)); }
         if (dry) {   // FNV-1a-64 over (element count, bytes) of every stream, in upload order
             auto mix = [&](const unsigned char *p, size_t len) { for (size_t i = 0; i < len; i++) { digest ^= p[i]; digest *= 1099511628211ull; } };
             const unsigned long long cnt = n;
@@ -407,6 +408,6 @@ int paced_team_workgroups(bool dict_desc, bool nt_stream, int xcd_remap, int lds
 // Second-generation layout (hip_plan_stream.hip): fills plan->st / plan->dn / the whole-tile pass of plan->dev for tile-rows [tr0, tr1).
 int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,
                  bool dense_mfma, const std::vector<long long> &hyb_off,
-                 std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes);
+                 std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes, const struct DevTile *DT = nullptr);   // DT: device mode (hip_plan_device.h)
 
 }  // namespace tilespmv

@@ -3,6 +3,7 @@
 
 #include "hip_plan_internal.h"
 #include "plan_tile_ops.h"
+#include "hip_plan_device.h"
 
 // ------------------------------------------------------------------------------------------------
 // Second-generation layout builder (hip_plan.h "unit stream").
@@ -87,8 +88,15 @@ struct StreamBuilder {
     tilespmv_plan *plan; const Knobs &K; const Tile_matrix *T; const int rowA, colA, tr0, tr1; const bool coo_in_tile, dense_mfma;
     const std::vector<long long> &hyb_off;
     const long long *hyb_ptr() const { return hyb_off.empty() ? nullptr : hyb_off.data(); }
+    DevShard DS{};
+    DevCounts dcnt, dcnt_alt;
+    uint4 *d_udesc = nullptr; uint2 *d_urow = nullptr; val_t *d_uval = nullptr;   // EMIT's unit records (scratch: ENCODE writes their final form into the plan's arena)
+    std::vector<unsigned> h_uw0;   // word 0 of every emitted unit (brick order only)
     std::vector<FixRow> &fix; int &npartial;
     DevStream &S;
+    // device mode (hip_plan_device.h; tilespmv_plan_create_from_csr): T is then a host copy of the tile LIST only (tile_ptr, tile_columnidx, Format); everything else of the
+    // tiled matrix stays on the device, and the stages that touch every nonzero run there
+    const DevTile *DT = nullptr;
     int rc = 0;
     // COUNT
     bool csr_split = true, pooled = false; int csr_form = 1, target_in = 0, split_above_in = 0, tilem = 0, tilen = 0, ntr = 0, sv = 0;
@@ -128,9 +136,9 @@ struct StreamBuilder {
     std::vector<long long> old_begin;
 
     StreamBuilder(tilespmv_plan *plan_, const Knobs &K_, const Tile_matrix *T_, int rowA_, int colA_, int tr0_, int tr1_, bool coo_in_tile_, bool dense_mfma_,
-                  const std::vector<long long> &hyb_off_, std::vector<FixRow> &fix_, int &npartial_)
-        : plan(plan_), K(K_), T(T_), rowA(rowA_), colA(colA_), tr0(tr0_), tr1(tr1_), coo_in_tile(coo_in_tile_), dense_mfma(dense_mfma_), hyb_off(hyb_off_), fix(fix_), npartial(npartial_), S(plan_->st) {}
-    ~StreamBuilder() { release(); }
+                  const std::vector<long long> &hyb_off_, std::vector<FixRow> &fix_, int &npartial_, const DevTile *DT_)
+        : plan(plan_), K(K_), T(T_), rowA(rowA_), colA(colA_), tr0(tr0_), tr1(tr1_), coo_in_tile(coo_in_tile_), dense_mfma(dense_mfma_), hyb_off(hyb_off_), fix(fix_), npartial(npartial_), S(plan_->st), DT(DT_) {}
+    ~StreamBuilder() { release(); dcnt.release(); dcnt_alt.release(); for (void *q : {(void *)d_udesc, (void *)d_urow, (void *)d_uval}) if (q) (void)hipFree(q); }
     // The staging arrays of a GB-sized plan take tens of milliseconds to give back (munmap of 0.7 GB each: 70-80 ms of the 320 ms config 4's plan build took): a detached
     // thread does it while the builder goes on.  Small arrays are freed in place.
     static void free_later(std::vector<void *> ptrs, size_t bytes_hint)
@@ -163,6 +171,7 @@ struct StreamBuilder {
     void emit();
     void order();
     void encode();
+    void encode_device();
     void entries();
     void finish(long long &n_tasks, long long &model_bytes);
 };
@@ -177,23 +186,47 @@ void StreamBuilder::count()
     // of the doubt, so stencil-like shards with a few CSR tiles — KKT, unaligned grids — keep their 4-byte descriptors).
     csr_form = K.csr_split < 0 ? 1 : std::min(K.csr_split, 2);
     const int t_begin = T->tile_ptr[tr0], t_end = T->tile_ptr[tr1];
+    if (DT) {
+        DS = DevShard{DT, tr0, tr1, t_begin, t_end, coo_in_tile, dense_mfma, 0, 0};
+        const long long idx[2] = {t_begin, t_end}; int v[2] = {0, 0};
+        if (dev_fetch_ints(DT->T.blknnz, idx, 2, v) != 0) { rc = -3; return; }
+        DS.stored0 = v[0]; DS.stored = (long long)v[1] - v[0];
+    }
     auto count_all = [&](int form, std::vector<RowCount> &out) {
         out.assign((size_t)ntr, RowCount{0, 0, 0, 0, 0, 0, 0});
+        if (DT) {   // one thread per tile (per tile-row for the pooled windows) on the device: the same per-tile functions (plan_tile_ops.h)
+            std::vector<int> nu, nc, nd;
+            DevCounts &C = form == csr_form ? dcnt : dcnt_alt;
+            if (dev_count(DS, form, &C, nu, nc, nd) != 0) { rc = -3; return; }
+            for (int i = 0; i < ntr; i++) {
+                RowCount c{nu[(size_t)i], nc[(size_t)i], 0, nd[(size_t)i], 0, 0, 0};
+                c.cost = 16LL * c.nunits + (long long)K.coo_cost * c.ncoo + 64LL * c.ndense + 8;
+                out[(size_t)i] = c;
+            }
+            return;
+        }
         parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
             std::vector<PoolEnt> scratch;
             for (int64_t i = b; i < e; i++) out[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, form, K.coo_cost, hyb_ptr(), scratch);
         });
     };
     count_all(csr_form, rc_);
+    if (rc) return;
     // (a caller who asks for a launch form that exists for the classic units only — column panels / slices, pacing, 512-thread workgroups, LDS x windows, a forced dictionary —
     //  gets the classic units)
     const bool classic_asked = K.x_panel_kb > 0 || K.x_slice_passes > 0 || K.pace > 0 || K.wg_strips == 32 || K.x_window == 1 || K.desc_dict == 1;
     // (nor is the second count worth its time where CSR tiles hold less than 3 % of the shard's stored values — the KKT stand-in: under 1 %; the band matrix's 5 % is worth it —: the pooled form pays 8-16 bytes more per
     //  unit on everything else and cannot come out 5 % ahead)
-    const long long csr_vals = (long long)T->csr_offset[t_end] - T->csr_offset[t_begin], all_vals = (long long)T->blknnz[t_end] - T->blknnz[t_begin];
+    long long csr_vals, all_vals;
+    if (DT) {
+        const long long idx[2] = {t_begin, t_end}; int v[2] = {0, 0};
+        if (dev_fetch_ints(DT->T.csr_offset, idx, 2, v) != 0) { rc = -3; return; }
+        csr_vals = (long long)v[1] - v[0]; all_vals = DS.stored;
+    } else { csr_vals = (long long)T->csr_offset[t_end] - T->csr_offset[t_begin]; all_vals = (long long)T->blknnz[t_end] - T->blknnz[t_begin]; }
     if (K.csr_split < 0 && !classic_asked && csr_vals > 0 && csr_vals * 33 >= all_vals) {
         std::vector<RowCount> alt;
         count_all(2, alt);
+        if (rc) return;
         long long u1 = 0, e1 = 0, u2 = 0, e2 = 0;
         for (int i = 0; i < ntr; i++) { u1 += rc_[i].nunits; e1 += rc_[i].ncoo; u2 += alt[i].nunits; e2 += alt[i].ncoo; }
         // would the split form get 4-byte dictionary descriptors?  Its units' column patterns on a sample of tiles (ELL slots exactly; of a CSR tile the pattern of its first
@@ -203,6 +236,11 @@ void StreamBuilder::count()
         else {
             std::unordered_set<unsigned long long> pats;
             const int nt = t_end - t_begin, step = std::max(1, nt / 16384);
+            if (DT) {   // the same sample, taken by a kernel
+                std::vector<unsigned long long> got;
+                if (dev_pattern_sample(DS, step, got) != 0) { rc = -3; return; }
+                pats.insert(got.begin(), got.end());
+            } else
             for (int t = t_begin; t < t_end && pats.size() <= ((size_t)1 << DICT_MAX_BITS); t += step) {
                 const int fmt = T->Format[t];
                 if (fmt == TILESPMV_FMT_ELL) {
@@ -225,7 +263,8 @@ void StreamBuilder::count()
         // lives in its entry lists) and the shard would not get column panels (scattered entries over an x of >= 12 MB: the panel / slice launches exist for the
         // classic kernel; band + random fill loses 23 % without them)
         const bool would_panel = (long long)K.coo_cost * e2 * 2 > 16LL * u2 + (long long)K.coo_cost * e2 && (long long)colA * sv >= (12ll << 20);
-        if (pooled_b * 100 <= split_b * 95 && 16 * u2 >= e2 && !would_panel) { rc_.swap(alt); csr_form = 2; }
+        if (pooled_b * 100 <= split_b * 95 && 16 * u2 >= e2 && !would_panel) { rc_.swap(alt); csr_form = 2; std::swap(dcnt, dcnt_alt); dcnt.csr_form = 2; }
+        dcnt_alt.release();
         if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: CSR tiles: split form (%d-byte descriptors) %lld units + %lld entries = %.1f MB, pooled form %lld units + %lld entries = %.1f MB -> %s\n",
                                                      desc_split, u1, e1, split_b / 1e6, u2, e2, pooled_b / 1e6, csr_form == 2 ? "pooled" : "split");
     }
@@ -476,6 +515,25 @@ void StreamBuilder::cut()
 
 void StreamBuilder::emit()
 {
+    if (DT) {
+        // device mode: the unit records go to scratch arrays on the device (ENCODE gives them their final form), list entries and dense tiles straight into the plan's arena
+        plan->size_hint = (size_t)(NU * (12 + (pooled ? 8 : 0) + 16LL * sv) + NC * (2LL * sv + 13) + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);
+        rc |= plan->reserve((size_t)NC, &S.cval); rc |= plan->reserve((size_t)NC, &S.ccol); rc |= plan->reserve((size_t)NC, &S.crow);
+        rc |= plan->reserve((size_t)ND, &plan->dn.cb); rc |= plan->reserve((size_t)ND * 256, &plan->dn.val);
+        auto scratch = [&](auto **q, size_t n) {
+            const size_t bytes = std::max<size_t>(n, 1) * sizeof(**q) + 256;
+            hipError_t e = hipMalloc((void **)q, bytes);
+            if (e == hipSuccess) e = hipMemsetAsync(*q, 0, bytes, 0);
+            if (e != hipSuccess) { fprintf(stderr, "tilespmv: device plan build: %zu MB of scratch: %s\n", bytes >> 20, hipGetErrorString(e)); (void)hipGetLastError(); rc = -3; }
+        };
+        scratch(&d_udesc, (size_t)NU); scratch(&d_uval, (size_t)NU * 16);
+        if (pooled) scratch(&d_urow, (size_t)NU);
+        if (rc) return;
+        const EmitOut O{d_udesc, d_urow, d_uval, const_cast<val_t *>(S.cval), const_cast<int *>(S.ccol), const_cast<unsigned char *>(S.crow), const_cast<int *>(plan->dn.cb), const_cast<val_t *>(plan->dn.val)};
+        if (dev_emit(DS, dcnt, pu, pc, pd, row_k, row_split, NU, O) != 0) rc = -3;
+        dcnt.release();
+        return;
+    }
     // ---- fill
     h_udesc.assign((size_t)NU, make_uint4(0u, 0u, 0u, 0u));
     h_urow.assign(pooled ? (size_t)NU : 0, make_uint2(0x01234567u, 0x89ABCDEFu));   // (units that keep one row per lane: identity)
@@ -527,6 +585,7 @@ void StreamBuilder::order()
     h_udesc_cb.clear();   // the descriptors with column blocks (multi-vector kernel), when windows put slots into h_udesc
     xwin_slots_max = 0;
     xwin_segments = 0; xwin_wgs = 0;
+    if (brick && !tasks.empty() && DT && dev_fetch_word0(d_udesc, NU, h_uw0) != 0) { rc = -3; return; }
     if (brick && !tasks.empty()) {
         const size_t nt = tasks.size();
         // grid coordinates of every strip: position in its line (ordinal of the strip), line in its plane, plane
@@ -543,7 +602,7 @@ void StreamBuilder::order()
             }
         }
         auto blocks_of = [&](const STask &k, std::vector<int> &out) {
-            for (int u = k.unit_begin; u < k.unit_end; u++) out.push_back(pooled ? (int)((h_udesc[(size_t)u].x & POOL_BASE_MASK) >> 4) : (int)(h_udesc[(size_t)u].x & 0xFFFFFFu));
+            for (int u = k.unit_begin; u < k.unit_end; u++) { const unsigned w0 = DT ? h_uw0[(size_t)u] : h_udesc[(size_t)u].x; out.push_back(pooled ? (int)((w0 & POOL_BASE_MASK) >> 4) : (int)(w0 & 0xFFFFFFu)); }
         };
         struct Shape { int px, py, pz; };
         const Shape shapes3[] = {{1, 4, 4}, {2, 2, 4}, {2, 4, 2}, {4, 2, 2}, {1, 2, 8}, {1, 8, 2}, {4, 4, 1}, {2, 8, 1}, {1, 16, 1}, {16, 1, 1}};
@@ -639,6 +698,70 @@ void StreamBuilder::order()
     if (hashing()) { Hash h; h.vec(tasks); h.vec(h_wg_win); h.vec(h_win_cb); h.num(brick); h.num(xwin); stage_done(TILESPMV_STAGE_ORDER, h); }
 }
 
+// ENCODE in device mode: the same final forms, produced from EMIT's device scratch (hip_plan_device.h)
+void StreamBuilder::encode_device()
+{
+    constexpr long long G = UNIT_GROUP;
+    auto padded = [&](long long n) { return (n + G - 1) / G * G; };
+    std::vector<int4> pair_map(tasks.size());
+    old_begin.assign(tasks.size(), 0);
+    long long at = 0;
+    for (size_t i = 0; i < tasks.size(); i++) {
+        STask &k = tasks[i];
+        const long long ub = k.unit_begin, n = k.unit_end - ub, nb = at;
+        old_begin[i] = ub;
+        at += padded(n);
+        pair_map[i] = make_int4((int)ub, (int)nb, (int)n, 0);
+        if (n > 0) { k.unit_begin = (int)nb; k.unit_end = (int)(nb + n); }
+    }
+    const double t0 = now_us();
+    S.udict = nullptr; S.cb_bits = 0; S.urow = nullptr; S.pooled = pooled ? 1 : 0;
+    void *d_map = nullptr; UDesc *d_packed = nullptr;
+    auto fail = [&](const char *what, hipError_t e) { fprintf(stderr, "tilespmv: device plan build: %s: %s\n", what, hipGetErrorString(e)); (void)hipGetLastError(); rc = -3; };
+    hipError_t e = hipMalloc(&d_map, std::max<size_t>(pair_map.size(), 1) * sizeof(int4));
+    if (e == hipSuccess && !pair_map.empty()) e = hipMemcpy(d_map, pair_map.data(), pair_map.size() * sizeof(int4), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_packed, std::max<long long>(NUP, 1) * sizeof(UDesc) + 256);
+    if (e == hipSuccess) e = hipMemsetAsync(d_packed, 0, std::max<long long>(NUP, 1) * sizeof(UDesc) + 256, 0);
+    if (e != hipSuccess) fail("scratch for the packed descriptors", e);
+    if (pooled) rc |= plan->reserve((size_t)NUP, &S.urow);
+    if (rc == 0 && dev_pack_desc(d_udesc, d_urow, (const int4 *)d_map, (int)pair_map.size(), d_packed, const_cast<URow *>(S.urow)) != 0) rc = -3;
+    // 4-B descriptors + pattern dictionary under the host builder's conditions (below); the distinct patterns come from a sort + run-length encoding of the packed descriptors
+    const bool dict_pays = K.desc_dict > 0 ? true : 8LL * NUP * 50 >= NUP * (12 + 16LL * sv) + NC * (sv + 4LL);
+    if (rc == 0 && K.desc_dict != 0 && dict_pays && !xwin && !pooled && NUP > 0) {
+        const int cb_bits = std::max(1, 32 - __builtin_clz((unsigned)std::max(1, T->tilen - 1)));
+        const int pid_bits = std::min(DICT_MAX_BITS, 27 - cb_bits);
+        if (pid_bits >= 1) {
+            std::vector<unsigned long long> all;
+            bool over = false;
+            if (dev_dict_patterns(d_packed, NUP, (size_t)1 << pid_bits, all, &over) != 0) rc = -3;
+            else if (!over) {
+                std::vector<uint2> dict(all.size());
+                for (size_t i = 0; i < all.size(); i++) dict[i] = make_uint2((unsigned)(all[i] >> 32), (unsigned)(all[i] & 0xffffffffull));
+                rc |= plan->upload(dict.data(), dict.size(), &S.udict);
+                rc |= plan->reserve((size_t)NUP, reinterpret_cast<const unsigned **>(&S.udesc));
+                if (rc == 0 && dev_compact_desc(d_packed, NUP, S.udict, (int)dict.size(), cb_bits, reinterpret_cast<unsigned *>(const_cast<UDesc *>(S.udesc))) != 0) rc = -3;
+                S.cb_bits = cb_bits;
+            }
+        }
+    }
+    if (rc == 0 && S.cb_bits == 0) {
+        rc |= plan->reserve((size_t)NUP, &S.udesc);
+        if (rc == 0 && NUP > 0 && (e = hipMemcpy(const_cast<UDesc *>(S.udesc), d_packed, (size_t)NUP * sizeof(UDesc), hipMemcpyDeviceToDevice)) != hipSuccess) fail("descriptor copy", e);
+    }
+    plan->info[TILESPMV_INFO_DESC_BYTES] = S.cb_bits > 0 ? 4 : pooled ? 20 : 12;
+    // the value pass (as in host mode: k_pair_values), its source already on the device
+    rc |= plan->reserve((size_t)NUP * 16, &S.uval);
+    if (rc == 0) {
+        e = launch_pair_values(d_uval, const_cast<val_t *>(S.uval), (const int4 *)d_map, (int)pair_map.size());
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) fail("value pass", e);
+    }
+    for (void *q : {(void *)d_map, (void *)d_packed, (void *)d_udesc, (void *)d_urow, (void *)d_uval}) if (q) (void)hipFree(q);
+    d_udesc = nullptr; d_urow = nullptr; d_uval = nullptr;
+    S.udesc_cb = S.udesc; S.wg_win = nullptr; S.win_cb = nullptr;
+    plan->info[TILESPMV_INFO_UPLOAD_US] += (long long)(now_us() - t0);
+}
+
 void StreamBuilder::encode()
 {
     const unsigned long long d0 = plan->digest;
@@ -656,6 +779,7 @@ void StreamBuilder::encode()
         rc = -2;
         return;
     }
+    if (DT) { encode_device(); return; }
     {
         std::vector<UDesc> packed((size_t)NUP, UDesc{0u, 0u, 0u});
         std::vector<URow> packed_row(pooled ? (size_t)NUP : 0, URow{0u, 0u});
@@ -792,6 +916,13 @@ void StreamBuilder::entries()
     const unsigned long long d0 = plan->digest;
     S.wg_coo = nullptr; S.grec = nullptr; S.gbase = nullptr; S.dest_bits = 11;
     n_rec = 0; n_chunk = 0; n_groups = 0;
+    if (entry_mode != 0 && DT && NC > 0) {   // device mode: the merged lists are still built on the host, from a copy of the emitted entries
+        h_cval = zalloc<val_t>((size_t)NC); h_ccol.assign((size_t)NC, 0); h_crow.assign((size_t)NC, 0);
+        hipError_t e = hipMemcpy(h_cval, S.cval, (size_t)NC * sizeof(val_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(h_ccol.data(), S.ccol, (size_t)NC * sizeof(int), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(h_crow.data(), S.crow, (size_t)NC, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { fprintf(stderr, "tilespmv: device plan build: list entries to the host: %s\n", hipGetErrorString(e)); (void)hipGetLastError(); rc = -3; return; }
+    }
     if (entry_mode != 0) {
         const size_t GS = entry_mode == 2 ? (size_t)wg_strips : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
         const int slab_shift = (xwin || pooled) ? 6 : 7;   // a strip's slab of s_y: XWIN_STRIP_ROWS / POOL_STRIP_ROWS x 16 values in x-window and pooled plans, STRIP_MAX_ROWS x 16 otherwise
@@ -933,9 +1064,11 @@ void StreamBuilder::entries()
 
 void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
 {
-    rc |= plan->upload(h_cval, (size_t)NC, &S.cval);
-    rc |= plan->upload(h_ccol.data(), (size_t)NC, &S.ccol);
-    rc |= plan->upload(h_crow.data(), (size_t)NC, &S.crow);
+    if (!DT) {   // (device mode: EMIT wrote them into the arena)
+        rc |= plan->upload(h_cval, (size_t)NC, &S.cval);
+        rc |= plan->upload(h_ccol.data(), (size_t)NC, &S.ccol);
+        rc |= plan->upload(h_crow.data(), (size_t)NC, &S.crow);
+    }
     DevPlan &D = plan->dev;  // heavy tiles reuse the first-generation streams + kernel (accumulate mode)
     rc |= plan->upload(h_hdesc.data(), (size_t)NH, &D.desc);
     rc |= plan->upload(h_hval, (size_t)NHV, &D.val);
@@ -943,8 +1076,10 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     rc |= plan->upload(htasks.data(), htasks.size(), &D.task);
     D.ntasks = (int)htasks.size();
     rc |= plan->upload(tasks.data(), tasks.size(), &S.task);
-    rc |= plan->upload(h_dcb.data(), (size_t)ND, &plan->dn.cb);
-    rc |= plan->upload(h_dval, (size_t)ND * 256, &plan->dn.val);
+    if (!DT) {
+        rc |= plan->upload(h_dcb.data(), (size_t)ND, &plan->dn.cb);
+        rc |= plan->upload(h_dval, (size_t)ND * 256, &plan->dn.val);
+    }
     rc |= plan->upload(drows.data(), drows.size(), &plan->dn.rows);
     plan->dn.nrows = (int)drows.size();
     for (size_t i = 0; i < drows.size(); i++) {   // k_dense_mfma walks consecutive records as one flat run of tiles: their ranges must be non-empty and follow each other
@@ -1044,9 +1179,9 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
 
 int tilespmv::build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,
                            bool dense_mfma, const std::vector<long long> &hyb_off,
-                           std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes)
+                           std::vector<FixRow> &fix, int &npartial, long long &n_tasks, long long &model_bytes, const DevTile *DT)
 {
-    StreamBuilder B(plan, K, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mfma, hyb_off, fix, npartial);
+    StreamBuilder B(plan, K, T, rowA, colA, tr0, tr1, coo_in_tile, dense_mfma, hyb_off, fix, npartial, DT);
     const bool verbose = getenv("TILESPMV_PLAN_VERBOSE") != nullptr;
     double t_prev = now_us(), up_prev = (double)plan->info[TILESPMV_INFO_UPLOAD_US];
     std::string times;
@@ -1062,9 +1197,10 @@ int tilespmv::build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matri
     B.choose(); lap("choose");
     B.cut(); lap("cut");
     B.emit(); lap("emit");
+    if (B.rc == -3) return B.rc;   // (device mode: a HIP error is final)
     B.order(); lap("order");
     B.encode(); lap("encode");
-    if (B.rc == -2) return B.rc;   // (shard too large for 32-bit unit ids)
+    if (B.rc == -2 || B.rc == -3) return B.rc;   // (shard too large for 32-bit unit ids)
     B.entries(); lap("entries");
     B.finish(n_tasks, model_bytes); lap("finish");
     if (verbose) fprintf(stderr, "tilespmv: unit-stream layout, ms per stage:%s\n", times.c_str());
