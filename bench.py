@@ -351,6 +351,9 @@ def main():
     ap.add_argument("--data", default="compat", choices=["compat", "real"],
                     help="compat: the reference driver's val[i] = i %% 10, x[i] = i %% 10 (exact check); real: U(-1, 1), seed 12345 (tolerance check)")
     ap.add_argument("--cache", default=None, metavar="DIR", help="parse / tile once: CSR cache of .mtx inputs and Tile_matrix cache of this rank's block live here")
+    ap.add_argument("--prep", default="host", choices=["host", "device"],
+                    help="how the measured plan is prepared: Tile_create on the host + tilespmv_plan_create (the reference's flow), or tilespmv_plan_create_from_csr (tiled matrix and plan built on the device); "
+                         "either way `prep_seconds` reports both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -403,7 +406,8 @@ def main():
     t0 = time.time()
     tile_cache = os.path.join(args.cache, "%s_%s_%s_rank%dof%d.tile_%s" % (args.workload, args.data, dname, rank, world, dname)) if args.cache else None
     # config 2 must exercise all seven tile formats: HYB is only reachable with the opt-in rule, here as in `other_workloads`
-    sh = ShardedSpMV(rank, world, rows, n, rp_b, ci_b, vals_b, dtype, bounds=bounds, tile_cache=tile_cache, hyb=(args.workload == "scircuit"))
+    prep_on_device = args.prep == "device" and args.workload != "scircuit"   # (config 2 needs HYB tiles: a host-only option)
+    sh = ShardedSpMV(rank, world, rows, n, rp_b, ci_b, vals_b, dtype, bounds=bounds, tile_cache=None if prep_on_device else tile_cache, hyb=(args.workload == "scircuit"), device_build=prep_on_device)
     t_prep = time.time() - t0
     info = sh.local.info()
     stream = torch.cuda.current_stream()
@@ -618,7 +622,30 @@ def main():
                 extra[mode] = {"error": repr(e)}
 
     # per-rank preprocessing seconds (every rank prepares only its own block)
-    prep_mine = dict({"generate": round(t_gen, 3), "total_tile_create_plus_plan": round(t_prep, 3)}, **{k: round(v, 3) for k, v in sh.seconds.items()})
+    prep_mine = dict({"generate": round(t_gen, 3), "total_tile_create_plus_plan": round(t_prep, 3)}, **{k: (round(v, 3) if isinstance(v, float) else v) for k, v in sh.seconds.items()})
+    # the other way of preparing the same plan, timed beside it: its streams must be the measured plan's, byte for byte (per-stream digests read back from the device)
+    if args.workload != "scircuit" and not args.no_extras:
+        try:
+            t0 = time.time()
+            if prep_on_device:
+                tm_o = api.Tile_create(len(rp_b) - 1, n, int(rp_b[-1]), rp_b, ci_b, vals_b, dtype=dtype)
+                t_tc_o = time.time() - t0
+                other = api.Plan(tm_o, len(rp_b) - 1, n, int(rp_b[-1]))
+                api.Tile_destroy(tm_o)
+            else:
+                other = api.Plan.from_csr(len(rp_b) - 1, n, int(rp_b[-1]), rp_b, ci_b, vals_b, dtype=dtype)
+                t_tc_o = other.info()["tile_create_us"] * 1e-6
+            t_o = time.time() - t0
+            a, b = sh.local.stream_digests(), other.stream_digests()
+            same = sorted(a) == sorted(b) and all(a[k] == b[k] for k in a)
+            oi = other.info()
+            prep_mine["other_path"] = {"built_on": "host" if prep_on_device else "device", "total_tile_create_plus_plan": round(t_o, 3), "tile_create": round(t_tc_o, 3),
+                                       "timed_choices_ms": round(oi["timed_choices_us"] * 1e-3, 1),
+                                       "streams_identical_to_measured_plan": bool(same) if oi["timed_choices_us"] == 0 and info["timed_choices_us"] == 0 else ("n/a: a timed choice was made" if not same else True)}
+            other.close()
+        except NotImplementedError:
+            prep_mine["other_path"] = "no device path for this option set"
+
     if getattr(sh, "tile_cache", None):
         prep_mine["tile_cache"] = sh.tile_cache
     prep_all = [prep_mine]
@@ -710,6 +737,17 @@ def main():
                 xd2 = torch.from_numpy(x2).cuda()
                 modes = (("coo_in_tile", api.COO_IN_TILE), ("coo_csr_fallback", api.COO_FALLBACK)) if small else (("default_plan", api.COO_AUTO),)
                 rec["tile_create_seconds"] = round(t_tc, 3)
+                if wl != "scircuit":   # (its HYB tiles are a host-only option)
+                    # the same default plan prepared on the device (tilespmv_plan_create_from_csr: only the CSR arrays cross the bus), whole y checked like the host-built plan's
+                    t_dv = time.time()
+                    pdv = api.Plan.from_csr(r2, n2, nz2, rp2, ci2, v2, dtype=dt2)
+                    t_dv = time.time() - t_dv
+                    ydv = torch.zeros(r2 + 16, dtype=td2, device="cuda")
+                    pdv.spmv(xd2.data_ptr(), ydv.data_ptr(), stream.cuda_stream); torch.cuda.synchronize()
+                    idv = pdv.info()
+                    rec["prepared_on_device"] = {"csr_to_plan_seconds": round(t_dv, 3), "tile_create_incl_csr_upload_seconds": round(idv["tile_create_us"] * 1e-6, 3),
+                                                 "timed_choices_ms": round(idv["timed_choices_us"] * 1e-3, 1), "check": "pass" if bool(np.array_equal(ydv.cpu().numpy()[:r2].astype(np.float64), ref2)) else "FAIL"}
+                    pdv.close(); del ydv
                 for label, coo in modes:
                     t_pc = time.time()
                     p2 = api.Plan(tm2, r2, n2, nz2, coo_mode=coo)

@@ -848,7 +848,7 @@ int tilespmv_plan_create_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_P
     const int tilen = (colA + BS - 1) / BS;
     // what has no device path (include/tilespmv.h): the caller builds those plans from a host Tile_matrix
     if (K.autotune || K.dry || (create_flags & TILESPMV_CREATE_HYB) || K.kernel == TILESPMV_KERNEL_DIRECT || tilen > (1 << UNIT_FLAG_SHIFT) || K.coo_mode == TILESPMV_COO_FALLBACK || K.csr_split == 0 ||
-        K.x_window == 1)
+        K.x_window == 1 || K.pace > 0)
         return -4;
     const double t0 = now_us();
     DevTile *D = nullptr;

@@ -38,4 +38,19 @@ int dev_pack_desc(const uint4 *d_udesc, const uint2 *d_urow, const int4 *d_map, 
 int dev_dict_patterns(const UDesc *d_packed, long long NUP, size_t cap, std::vector<unsigned long long> &sorted_patterns, bool *over);
 int dev_compact_desc(const UDesc *d_packed, long long NUP, const uint2 *d_dict, int ndict, int cb_bits, unsigned *d_compact);
 
+// ENTRIES (entry modes 1 / 2): the lists of every group of GS consecutive tasks merged, ordered by column (ties keep task / list order: ONE stable radix sort by
+// (group, column) of the entries laid out group by group) and packed (plan_tile_ops.h pack_chunks, the host builder's function) — two passes of one thread per group:
+// sizes, then records.  d_cval / d_ccol / d_crow: EMIT's list entries (device); tasks: host copy, coo ranges in EMIT's numbering.
+struct DevLists {
+    std::vector<int4> wg;           // per group: [record begin, end), first chunk, 0 (host copy: the caller uploads it)
+    long long n_rec = 0, n_chunk = 0, scattered = 0;
+    ERec *d_rec = nullptr; unsigned *d_base = nullptr;   // scratch until place() has copied them into the plan
+    int *d_panel_off = nullptr;      // x_panels > 1: (x_panels + 1) absolute record offsets per group
+    std::vector<int> panel_off;      // ... host copy
+    void release();
+    ~DevLists() { release(); }
+};
+int dev_entry_lists(const val_t *d_cval, const int *d_ccol, const unsigned char *d_crow, long long NC, const std::vector<STask> &tasks, int GS, int slab_shift, int dest_bits, bool count_scattered,
+                    int x_panels, int panel_shift, DevLists *L);
+
 }  // namespace tilespmv

@@ -174,6 +174,133 @@ __global__ __launch_bounds__(256) void k_pd_compact(const UDesc *__restrict__ pa
     compact[i] = (d.w0 & ((1u << cb_bits) - 1u)) | ((unsigned)lo << cb_bits) | ((d.w0 >> UNIT_FLAG_SHIFT) << 27);
 }
 
+
+// ---- ENTRIES
+__global__ __launch_bounds__(256) void k_pe_keys(const STask *__restrict__ tasks, int ntasks, const int *__restrict__ ofs, int GS, int slab_shift, const int *__restrict__ ccol, const unsigned char *__restrict__ crow,
+                                                  u64 *__restrict__ key, int *__restrict__ src, unsigned short *__restrict__ dest_q)
+{
+    for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {
+        const int b = tasks[t].coo_begin, e = tasks[t].coo_end, o = ofs[t];
+        const u64 grp = (u64)(t / GS) << 32;
+        const unsigned strip = (unsigned)(t & (GS - 1)) << slab_shift;
+        for (int q = b + threadIdx.x; q < e; q += 256) {
+            key[o + (q - b)] = grp | (unsigned)ccol[q];
+            src[o + (q - b)] = q;
+            dest_q[q] = (unsigned short)(strip | crow[q]);
+        }
+    }
+}
+// one thread per group: sizes of its packed list (+ the plan fact "entries far from the group's own rows")
+__global__ __launch_bounds__(64) void k_pe_sizes(const STask *__restrict__ tasks, int ntasks, const int *__restrict__ ofs, int nwg, int GS, int dest_bits, bool count_far, const u64 *__restrict__ key,
+                                                  int *__restrict__ nrec, int *__restrict__ nchunk, unsigned long long *__restrict__ far_total)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwg) return;
+    const int t0 = w * GS, t1 = min(ntasks, t0 + GS);
+    const u64 *K = key + ofs[t0];
+    const long long n = ofs[t1] - ofs[t0];
+    int nr = 0, nc = 0;
+    pack_chunks(n, dest_bits, [=](long long i) { return (unsigned)K[i]; }, [&](long long, unsigned) { nr++; }, [&]() { nr++; }, [&](unsigned) { nc++; });
+    nrec[w] = nr; nchunk[w] = nc;
+    if (count_far) {
+        long long own_lo = LLONG_MAX, own_hi = LLONG_MIN, far = 0;
+        for (int t = t0; t < t1; t++) { own_lo = min(own_lo, 16LL * tasks[t].row); own_hi = max(own_hi, 16LL * (tasks[t].row + max(1, tasks[t].nrows))); }
+        for (long long i = 0; i < n; i++) { const long long c = (unsigned)K[i]; far += !(c >= own_lo - 2048 && c < own_hi + 2048); }
+        if (far) atomicAdd(far_total, (unsigned long long)far);
+    }
+}
+// one thread per group: its records, chunk bases and (panelled plans) panel offsets
+__global__ __launch_bounds__(64) void k_pe_write(int ntasks, const int *__restrict__ ofs, int nwg, int GS, int dest_bits, const u64 *__restrict__ key, const int *__restrict__ src, const unsigned short *__restrict__ dest_q,
+                                                  const val_t *__restrict__ cval, const int4 *__restrict__ wg, ERec *__restrict__ rec, unsigned *__restrict__ base, int NP, int panel_shift, int *__restrict__ panel_off)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwg) return;
+    const int t0 = w * GS, t1 = min(ntasks, t0 + GS);
+    const u64 *K = key + ofs[t0]; const int *Q = src + ofs[t0];
+    const long long n = ofs[t1] - ofs[t0];
+    const int4 g = wg[w];
+    ERec *R = rec + g.x; unsigned *B = base + g.z;
+    long long r = 0, c = 0;
+    pack_chunks(n, dest_bits, [=](long long i) { return (unsigned)K[i]; },
+                [&](long long i, unsigned b) { const int q = Q[i]; R[r++] = make_erec(cval[q], (((unsigned)K[i] - b) << dest_bits) | dest_q[q]); },
+                [&]() { R[r++] = make_erec((val_t)0, 0u); }, [&](unsigned b) { B[c++] = b; });
+    if (NP > 1) {
+        int *off = panel_off + (size_t)w * (size_t)(NP + 1);
+        off[0] = 0;
+        panel_offsets(R, (long long)(g.y - g.x), B, dest_bits, panel_shift, NP, off);
+        for (int q = 0; q <= NP; q++) off[q] += g.x;   // absolute record indices
+    }
+}
+
+}  // namespace
+
+void DevLists::release()
+{
+    for (void *q : {(void *)d_rec, (void *)d_base, (void *)d_panel_off}) if (q) (void)hipFree(q);
+    d_rec = nullptr; d_base = nullptr; d_panel_off = nullptr;
+}
+
+int dev_entry_lists(const val_t *d_cval, const int *d_ccol, const unsigned char *d_crow, long long NC, const std::vector<STask> &tasks, int GS, int slab_shift, int dest_bits, bool count_scattered,
+                    int x_panels, int panel_shift, DevLists *L)
+{
+    const int ntasks = (int)tasks.size(), nwg = (ntasks + GS - 1) / GS;
+    L->release(); L->wg.assign((size_t)nwg, make_int4(0, 0, 0, 0)); L->n_rec = L->n_chunk = L->scattered = 0; L->panel_off.clear();
+    if (nwg == 0) return 0;
+    std::vector<int> ofs((size_t)ntasks + 1, 0);   // entries in front of task t, tasks in their final order
+    { long long run = 0; for (int t = 0; t < ntasks; t++) { ofs[(size_t)t] = (int)run; run += tasks[(size_t)t].coo_end - tasks[(size_t)t].coo_begin; } ofs[(size_t)ntasks] = (int)run; if (run > NC) return -3; }
+    const long long NE = ofs[(size_t)ntasks];
+    Tmp<STask> d_tasks; Tmp<int> d_ofs, src_a, src_b, d_nrec, d_nchunk; Tmp<u64> key_a, key_b; Tmp<unsigned short> d_dest; Tmp<unsigned long long> d_far; Tmp<int4> d_wg;
+    PD_TRY(d_tasks.from(tasks)); PD_TRY(d_ofs.from(ofs));
+    PD_TRY(key_a.alloc((size_t)NE, false)); PD_TRY(key_b.alloc((size_t)NE, false)); PD_TRY(src_a.alloc((size_t)NE, false)); PD_TRY(src_b.alloc((size_t)NE, false));
+    PD_TRY(d_dest.alloc((size_t)NC, true)); PD_TRY(d_nrec.alloc((size_t)nwg, true)); PD_TRY(d_nchunk.alloc((size_t)nwg, true)); PD_TRY(d_far.alloc(1, true));
+    hipLaunchKernelGGL(k_pe_keys, dim3((unsigned)std::min(ntasks, 1 << 20)), dim3(256), 0, 0, (const STask *)d_tasks.p, ntasks, (const int *)d_ofs.p, GS, slab_shift, d_ccol, d_crow, key_a.p, src_a.p, d_dest.p);
+    PD_TRY(hipGetLastError());
+    const u64 *K = key_a.p; const int *Q = src_a.p;
+    if (NE > 0) {
+        rocprim::double_buffer<u64> kb(key_a.p, key_b.p);
+        rocprim::double_buffer<int> vb(src_a.p, src_b.p);
+        int gbits = 1; while ((1ll << gbits) < nwg) gbits++;
+        size_t tmp_b = 0; void *tmp = nullptr;
+        PD_TRY(rocprim::radix_sort_pairs(nullptr, tmp_b, kb, vb, (size_t)NE, 0u, (unsigned)(32 + gbits), (hipStream_t)0));
+        PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
+        hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_b, kb, vb, (size_t)NE, 0u, (unsigned)(32 + gbits), (hipStream_t)0);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(tmp);
+        PD_TRY(e);
+        K = kb.current(); Q = vb.current();
+    }
+    hipLaunchKernelGGL(k_pe_sizes, dim3(nblk(nwg, 64)), dim3(64), 0, 0, (const STask *)d_tasks.p, ntasks, (const int *)d_ofs.p, nwg, GS, dest_bits, count_scattered, K, d_nrec.p, d_nchunk.p, d_far.p);
+    PD_TRY(hipGetLastError());
+    std::vector<int> nrec((size_t)nwg), nchunk((size_t)nwg);
+    unsigned long long far = 0;
+    PD_TRY(hipMemcpy(nrec.data(), d_nrec.p, (size_t)nwg * sizeof(int), hipMemcpyDeviceToHost));
+    PD_TRY(hipMemcpy(nchunk.data(), d_nchunk.p, (size_t)nwg * sizeof(int), hipMemcpyDeviceToHost));
+    PD_TRY(hipMemcpy(&far, d_far.p, sizeof(far), hipMemcpyDeviceToHost));
+    L->scattered = (long long)far;
+    long long n_rec = 0, n_chunk = 0;
+    for (int w = 0; w < nwg; w++) {
+        L->wg[(size_t)w] = make_int4((int)n_rec, (int)(n_rec + nrec[(size_t)w]), (int)n_chunk, 0);
+        n_rec += nrec[(size_t)w]; n_chunk += nchunk[(size_t)w];
+    }
+    L->n_rec = n_rec; L->n_chunk = n_chunk;
+    if (n_rec > INT32_MAX) return 0;   // (the caller reports it, like the host builder)
+    PD_TRY(d_wg.from(L->wg));
+    PD_TRY(hipMalloc((void **)&L->d_rec, std::max<long long>(n_rec, 1) * sizeof(ERec) + 256));
+    PD_TRY(hipMalloc((void **)&L->d_base, std::max<long long>(n_chunk, 1) * sizeof(unsigned) + 256));
+    const int NP = x_panels;
+    if (NP > 1) PD_TRY(hipMalloc((void **)&L->d_panel_off, (size_t)nwg * (size_t)(NP + 1) * sizeof(int) + 256));
+    hipLaunchKernelGGL(k_pe_write, dim3(nblk(nwg, 64)), dim3(64), 0, 0, ntasks, (const int *)d_ofs.p, nwg, GS, dest_bits, K, Q, (const unsigned short *)d_dest.p, d_cval, (const int4 *)d_wg.p, L->d_rec, L->d_base, NP,
+                       panel_shift, L->d_panel_off);
+    PD_TRY(hipGetLastError());
+    PD_TRY(hipDeviceSynchronize());
+    if (NP > 1) {
+        L->panel_off.resize((size_t)nwg * (size_t)(NP + 1));
+        PD_TRY(hipMemcpy(L->panel_off.data(), L->d_panel_off, L->panel_off.size() * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+namespace {
 }  // namespace
 
 void DevCounts::release()

@@ -12,6 +12,7 @@
 #include <unordered_set>
 
 #include "hip_plan.h"
+#include "plan_tile_ops.h"
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -347,18 +348,6 @@ inline void repack_tile(const Tile_matrix *T, int t, const Emit &e, int rowlen, 
 // One entry of a merged list before packing.
 struct PEnt { unsigned col, dest; val_t val; };
 
-inline ERec make_erec(val_t v, unsigned w)
-{
-    ERec r;
-#if defined(TILESPMV_F32)
-    memcpy(&r.v, &v, 4);
-#else
-    unsigned b[2]; memcpy(b, &v, 8); r.lo = b[0]; r.hi = b[1];
-#endif
-    r.w = w;
-    return r;
-}
-
 // Packs one list (entries already in their final order: by column, ties in list order) into records and per-chunk column
 // bases (hip_plan.h ERec).  Chunk k of the list = its records [64k, 64k + 64); base = column of the chunk's first entry;
 // an entry whose column is 2^(32 - dest_bits) or more above the base closes the chunk, which is filled up with null
@@ -366,19 +355,10 @@ inline ERec make_erec(val_t v, unsigned w)
 // does not decode back to the input (checked in layout-digest builds).
 inline bool pack_list(const std::vector<PEnt> &ents, int dest_bits, std::vector<ERec> &rec, std::vector<unsigned> &base, bool verify)
 {
-    const unsigned long long span = 1ull << (32 - dest_bits);
     const size_t rec0 = rec.size(), base0 = base.size();
-    size_t i = 0;
-    while (i < ents.size()) {
-        const unsigned b = ents[i].col;
-        base.push_back(b);
-        int n = 0;
-        while (i < ents.size() && n < ECHUNK && (unsigned long long)ents[i].col - b < span) {
-            rec.push_back(make_erec(ents[i].val, ((ents[i].col - b) << dest_bits) | ents[i].dest));
-            i++; n++;
-        }
-        if (i < ents.size()) for (; n < ECHUNK; n++) rec.push_back(make_erec((val_t)0, 0u));   // interior chunks are always full
-    }
+    pack_chunks((long long)ents.size(), dest_bits, [&](long long i) { return ents[(size_t)i].col; },
+                [&](long long i, unsigned b) { rec.push_back(make_erec(ents[(size_t)i].val, ((ents[(size_t)i].col - b) << dest_bits) | ents[(size_t)i].dest)); },
+                [&]() { rec.push_back(make_erec((val_t)0, 0u)); }, [&](unsigned b) { base.push_back(b); });   // (plan_tile_ops.h: shared with the device builder)
     if (!verify) return true;
     size_t j = 0;
     for (size_t q = rec0; q < rec.size(); q++) {

@@ -916,13 +916,6 @@ void StreamBuilder::entries()
     const unsigned long long d0 = plan->digest;
     S.wg_coo = nullptr; S.grec = nullptr; S.gbase = nullptr; S.dest_bits = 11;
     n_rec = 0; n_chunk = 0; n_groups = 0;
-    if (entry_mode != 0 && DT && NC > 0) {   // device mode: the merged lists are still built on the host, from a copy of the emitted entries
-        h_cval = zalloc<val_t>((size_t)NC); h_ccol.assign((size_t)NC, 0); h_crow.assign((size_t)NC, 0);
-        hipError_t e = hipMemcpy(h_cval, S.cval, (size_t)NC * sizeof(val_t), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(h_ccol.data(), S.ccol, (size_t)NC * sizeof(int), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(h_crow.data(), S.crow, (size_t)NC, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { fprintf(stderr, "tilespmv: device plan build: list entries to the host: %s\n", hipGetErrorString(e)); (void)hipGetLastError(); rc = -3; return; }
-    }
     if (entry_mode != 0) {
         const size_t GS = entry_mode == 2 ? (size_t)wg_strips : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
         const int slab_shift = (xwin || pooled) ? 6 : 7;   // a strip's slab of s_y: XWIN_STRIP_ROWS / POOL_STRIP_ROWS x 16 values in x-window and pooled plans, STRIP_MAX_ROWS x 16 otherwise
@@ -938,7 +931,13 @@ void StreamBuilder::entries()
         pace_hist.assign(pace_on ? (size_t)pace_nslab : 0, 0);
         std::atomic<int> bad(0);
         std::atomic<long long> scattered(0);
-        parallel_chunks((int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
+        DevLists dlists;   // device mode: the lists are merged, ordered and packed on the device (hip_plan_device.h: one stable sort by (group, column), then the same packing function)
+        if (DT) {
+            if (dev_entry_lists(S.cval, S.ccol, S.crow, NC, tasks, (int)GS, slab_shift, dest_bits, entry_mode == 2, x_panels, panel_shift, &dlists) != 0) { rc = -3; return; }
+            scattered.store(dlists.scattered);
+            if (NP > 1) h_panel_off = dlists.panel_off;
+        }
+        parallel_chunks(DT ? 0 : (int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
             std::vector<std::pair<unsigned long long, unsigned>> key;   // (column << 32 | position in strip / list order, destination)
             std::vector<int> src;
             std::vector<PEnt> ents, local;
@@ -988,38 +987,24 @@ void StreamBuilder::entries()
                 if (NP > 1) {
                     // where each panel begins in the PACKED list: records are in column order except that the null padding of a chunk closed early repeats the chunk's first
                     // column — padding counts as part of the panel of the record before it (it adds 0 * x[.] to the group's first row whichever pass executes it)
-                    const std::vector<ERec> &R = grp_rec[(size_t)w];
-                    const std::vector<unsigned> &B = grp_base[(size_t)w];
-                    int *off = &h_panel_off[(size_t)w * (NP + 1)];
-                    unsigned cur = 0;   // panel of the previous record
-                    size_t nextp = 1;
-                    for (size_t i = 0; i < R.size(); i++) {
-                        const ERec &rr = R[i];
-#if defined(TILESPMV_F32)
-                        const bool null_like = rr.w == 0u && rr.v == 0u;
-#else
-                        const bool null_like = rr.w == 0u && rr.lo == 0u && rr.hi == 0u;
-#endif
-                        const unsigned pnl = null_like && i % ECHUNK != 0 ? cur : std::max(cur, (B[i / ECHUNK] + (rr.w >> dest_bits)) >> panel_shift);
-                        while (nextp <= (size_t)pnl) off[nextp++] = (int)i;
-                        cur = pnl;
-                    }
-                    while (nextp <= NP) off[nextp++] = (int)R.size();
+                    panel_offsets(grp_rec[(size_t)w].data(), (long long)grp_rec[(size_t)w].size(), grp_base[(size_t)w].data(), dest_bits, panel_shift, (int)NP, &h_panel_off[(size_t)w * (NP + 1)]);
                 }
             }
             if (pace_on) { std::lock_guard<std::mutex> lk(hist_mutex); for (size_t i2 = 0; i2 < hist.size(); i2++) pace_hist[i2] += hist[i2]; }
         });
         if (bad.load()) { fprintf(stderr, "tilespmv: internal error: %d packed entry lists do not decode to their entries\n", bad.load()); rc = -6; }
         std::vector<int4> wg((size_t)nwg);
+        if (DT) { wg = dlists.wg; n_rec = dlists.n_rec; n_chunk = dlists.n_chunk; }
+        else
         for (size_t w = 0; w < nwg; w++) {
             wg[w] = make_int4((int)n_rec, (int)(n_rec + (long long)grp_rec[w].size()), (int)n_chunk, wg_local[w]);
             if (NP > 1) for (size_t q = 0; q <= NP; q++) h_panel_off[w * (NP + 1) + q] += (int)n_rec;
             n_rec += (long long)grp_rec[w].size(); n_chunk += (long long)grp_base[w].size();
         }
         if (n_rec > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit entry ids\n"); rc = -2; n_rec = 0; }
-        std::vector<ERec> g_rec((size_t)n_rec);
-        std::vector<unsigned> g_base((size_t)n_chunk);
-        if (rc == 0)
+        std::vector<ERec> g_rec(DT ? 0 : (size_t)n_rec);
+        std::vector<unsigned> g_base(DT ? 0 : (size_t)n_chunk);
+        if (rc == 0 && !DT)
             parallel_chunks((int64_t)nwg, 256, [&](int64_t b, int64_t e, int) {
                 for (int64_t w = b; w < e; w++) {
                     if (!grp_rec[(size_t)w].empty()) memcpy(&g_rec[(size_t)wg[(size_t)w].x], grp_rec[(size_t)w].data(), grp_rec[(size_t)w].size() * sizeof(ERec));
@@ -1042,8 +1027,18 @@ void StreamBuilder::entries()
             panel_rmw_rows = acc_rows;    // at the finest panels; a launch that merges m panels per pass touches about 1 / m of it (tilespmv_plan_info reports the model of the form chosen)
         }
         rc |= plan->upload(wg.data(), wg.size(), &S.wg_coo);
-        rc |= plan->upload(g_rec.data(), g_rec.size(), &S.grec);
-        rc |= plan->upload(g_base.data(), g_base.size(), &S.gbase);
+        if (DT) {   // records and bases are on the device already: into the plan's arena
+            rc |= plan->reserve((size_t)n_rec, &S.grec);
+            rc |= plan->reserve((size_t)n_chunk, &S.gbase);
+            hipError_t e = hipSuccess;
+            if (rc == 0 && n_rec > 0) e = hipMemcpy(const_cast<ERec *>(S.grec), dlists.d_rec, (size_t)n_rec * sizeof(ERec), hipMemcpyDeviceToDevice);
+            if (rc == 0 && e == hipSuccess && n_chunk > 0) e = hipMemcpy(const_cast<unsigned *>(S.gbase), dlists.d_base, (size_t)n_chunk * sizeof(unsigned), hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) { fprintf(stderr, "tilespmv: device plan build: entry lists into the plan: %s\n", hipGetErrorString(e)); (void)hipGetLastError(); rc = -3; }
+            dlists.release();
+        } else {
+            rc |= plan->upload(g_rec.data(), g_rec.size(), &S.grec);
+            rc |= plan->upload(g_base.data(), g_base.size(), &S.gbase);
+        }
         S.panel_off = nullptr;
         if (NP > 1) rc |= plan->upload(h_panel_off.data(), h_panel_off.size(), &S.panel_off);
     }

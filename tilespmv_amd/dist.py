@@ -60,11 +60,12 @@ class ShardedSpMV:
     exercised without a GPU.
     """
 
-    def __init__(self, rank, world, rows, cols, rowptr, colidx, vals, dtype=np.float64, make_local=None, bounds=None, tile_cache=None, hyb=False, **plan_kw):
+    def __init__(self, rank, world, rows, cols, rowptr, colidx, vals, dtype=np.float64, make_local=None, bounds=None, tile_cache=None, hyb=False, device_build=False, **plan_kw):
         """``bounds`` given: ``rowptr / colidx / vals`` are THIS RANK'S row block only (row pointer rebased to 0, global
         column ids) and ``bounds`` the row partition everybody agreed on — a rank then never holds the whole matrix.
         ``tile_cache``: path of a Tile_matrix cache for this rank's block (read when present and of the right shape, written
-        otherwise: api.matrix_load / matrix_save)."""
+        otherwise: api.matrix_load / matrix_save).  ``device_build``: the tiled matrix and the plan are built on the device from the CSR block
+        (``Plan.from_csr``: nothing but the CSR arrays crosses the bus; no host Tile_matrix, no tile cache, no HYB tiles)."""
         from . import api
         self.rank, self.world, self.rows, self.cols = rank, world, rows, cols
         self.dtype = np.dtype(dtype)
@@ -82,6 +83,16 @@ class ShardedSpMV:
         if make_local is not None:
             self.local = make_local(self.local_rows, cols, rp, ci, v)
             self.tm = None
+        elif device_build:
+            import time
+            t0 = time.perf_counter()
+            self.tm, self.tile_cache = None, None
+            self.local = api.Plan.from_csr(self.local_rows, cols, self.local_nnz, rp, ci, v, dtype=self.dtype, **plan_kw)
+            t1 = time.perf_counter()
+            info = self.local.info()
+            self.tiles = int(info["tiles"])
+            self.seconds = {"tile_create": info["tile_create_us"] * 1e-6, "plan_build": info["build_us"] * 1e-6, "plan_upload": info["upload_us"] * 1e-6,
+                            "plan_create_total": t1 - t0 - info["tile_create_us"] * 1e-6, "built_on": "device"}
         else:
             import time
             t0 = time.perf_counter()
