@@ -870,6 +870,7 @@ int tilespmv_plan_create_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_P
     if (e == hipSuccess && H.tilenum > 0) e = hipMemcpy(h_fmt.data(), D->T.Format, (size_t)H.tilenum, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { fprintf(stderr, "tilespmv: tile list to the host: %s\n", hipGetErrorString(e)); (void)hipGetLastError(); devtile_destroy(D); return -3; }
     H.tile_ptr = h_tile_ptr.data(); H.tile_columnidx = h_tile_col.data(); H.Format = h_fmt.data();
+    if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: plan from CSR: device Tile_create %.1f ms (CSR upload included), tile list to the host %.1f ms\n", (t1 - t0) * 1e-3, (now_us() - t1) * 1e-3);
     Knobs Kd = K;
     if (Kd.kernel == TILESPMV_KERNEL_AUTO) Kd.kernel = TILESPMV_KERNEL_STREAM;
     if (Kd.coo_mode == TILESPMV_COO_AUTO) Kd.coo_mode = TILESPMV_COO_IN_TILE;

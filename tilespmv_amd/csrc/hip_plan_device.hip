@@ -3,6 +3,8 @@
 // calls from its loops: the same records at the same offsets.  The host keeps the decisions (hip_plan_stream.hip CHOOSE / CUT / ORDER) and sends back prefix arrays.
 #include <cstring>
 
+#include <sys/time.h>
+
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
@@ -305,7 +307,7 @@ namespace {
 
 void DevCounts::release()
 {
-    for (void *q : {(void *)tu, (void *)tc, (void *)td, (void *)pool_u, (void *)pool_c, (void *)pool}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)tu, (void *)pool}) if (q) (void)hipFree(q);   // (tu heads the one block that holds tc, td, pool_u, pool_c too)
     tu = tc = td = pool_u = pool_c = nullptr; pool = nullptr; csr_form = -1;
 }
 
@@ -325,18 +327,34 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &n
 {
     const DevTile *D = S.D;
     const int nt = S.t_end - S.t_begin, ntr = S.tr1 - S.tr0;
+    const bool verbose = getenv("TILESPMV_PLAN_VERBOSE") != nullptr;
+    timeval tv0; gettimeofday(&tv0, NULL);
+    auto lap_ms = [&]() { timeval t; gettimeofday(&t, NULL); const double ms = (t.tv_sec - tv0.tv_sec) * 1e3 + (t.tv_usec - tv0.tv_usec) * 1e-3; tv0 = t; return ms; };
     C->release();
     C->csr_form = csr_form;
     nunits.assign((size_t)ntr, 0); ncoo.assign((size_t)ntr, 0); ndense.assign((size_t)ntr, 0);
-    auto alloc_ints = [&](int **p, size_t n) { hipError_t e = hipMalloc((void **)p, (n + 4) * sizeof(int)); if (e == hipSuccess) e = hipMemsetAsync(*p, 0, (n + 4) * sizeof(int), 0); return e; };
-    PD_TRY(alloc_ints(&C->tu, (size_t)nt + 1)); PD_TRY(alloc_ints(&C->tc, (size_t)nt + 1)); PD_TRY(alloc_ints(&C->td, (size_t)nt + 1));
+    // one allocation for the three per-tile prefix arrays (and the pooled counts): tu | tc | td | pool_u | pool_c
+    const size_t per = ((size_t)nt + 1 + 63) / 64 * 64, perr = ((size_t)std::max(ntr, 1) + 63) / 64 * 64;
+    int *blockp = nullptr;
+    const size_t ints = 3 * per + (csr_form == 2 ? 2 * perr : 0) + 16;
+    PD_TRY(hipMalloc((void **)&blockp, ints * sizeof(int)));
+    C->tu = blockp; C->tc = blockp + per; C->td = blockp + 2 * per;
+    PD_TRY(hipMemsetAsync(blockp, 0, ints * sizeof(int), 0));
     if (nt > 0) {
         hipLaunchKernelGGL(k_pd_count_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, S.t_begin, nt, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, csr_form, C->tu, C->tc, C->td);
         PD_TRY(hipGetLastError());
-        PD_TRY(scan_in_place(C->tu, (size_t)nt + 1)); PD_TRY(scan_in_place(C->tc, (size_t)nt + 1)); PD_TRY(scan_in_place(C->td, (size_t)nt + 1));
+        size_t tmp_b = 0; void *tmp = nullptr;
+        PD_TRY(rocprim::exclusive_scan(nullptr, tmp_b, C->tu, C->tu, 0, (size_t)nt + 1, rocprim::plus<int>(), (hipStream_t)0));
+        PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
+        hipError_t e = hipSuccess;
+        for (int *a : {C->tu, C->tc, C->td}) if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, tmp_b, a, a, 0, (size_t)nt + 1, rocprim::plus<int>(), (hipStream_t)0);   // (same stream: the scans run one after the other)
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        (void)hipFree(tmp);
+        PD_TRY(e);
     }
+    const double ms_tiles = lap_ms();
     if (csr_form == 2 && ntr > 0) {
-        PD_TRY(alloc_ints(&C->pool_u, (size_t)ntr)); PD_TRY(alloc_ints(&C->pool_c, (size_t)ntr));
+        C->pool_u = blockp + 3 * per; C->pool_c = blockp + 3 * per + perr;
         PD_TRY(hipMalloc((void **)&C->pool, (size_t)std::max<long long>(1, S.stored) * sizeof(PoolEnt) + 16));
         hipLaunchKernelGGL(k_pd_count_pool, dim3(nblk(ntr, 64)), dim3(64), 0, 0, D->T, S.tr0, ntr, D->rowA, S.coo_in_tile, S.stored0, C->pool, C->pool_u, C->pool_c);
         PD_TRY(hipGetLastError());
@@ -351,6 +369,7 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &n
         PD_TRY(hipMemcpy(h.data(), d_out.p, h.size() * sizeof(int), hipMemcpyDeviceToHost));
         for (int i = 0; i < ntr; i++) { nunits[(size_t)i] = h[3 * (size_t)i]; ncoo[(size_t)i] = h[3 * (size_t)i + 1]; ndense[(size_t)i] = h[3 * (size_t)i + 2]; }
     }
+    if (verbose) fprintf(stderr, "tilespmv: device count (form %d): per-tile counts + scans %.1f ms, pooled windows + per-row counts to the host %.1f ms\n", csr_form, ms_tiles, lap_ms());
     return 0;
 }
 
