@@ -182,3 +182,46 @@ def test_options_without_a_device_path_are_refused(torch_cuda):
     for knobs in (dict(csr_split=0), dict(kernel=api.KERNEL_DIRECT), dict(coo_mode=api.COO_FALLBACK), dict(x_window=1)):
         with pytest.raises(NotImplementedError):
             api.Plan.from_csr(rows, cols, len(ci), rp, ci, v, **knobs)
+
+
+def test_cli_with_the_plan_built_on_the_device(torch_cuda, tmp_path):
+    """`TILESPMV_DEVICE_BUILD=1 ./test -d 0 test.mtx`: call_tilespmv_hip builds its plan from the CSR arguments on the device; same lines, Check... PASS."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for exe in ("test_f64", "test_f32"):
+        env = dict(os.environ, TILESPMV_WARMUP="2", TILESPMV_BENCH_REPEAT="5", TILESPMV_DEVICE_BUILD="1", TILESPMV_PLAN_VERBOSE="1")
+        r = subprocess.run([os.path.join(root, "tilespmv_amd", "bin", exe), "-d", "0", os.path.join(root, "tests", "golden", "test.mtx")], cwd=tmp_path, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Run CPU TileSpMV, errcount = 0" in r.stdout and "Check... PASS!" in r.stdout
+        assert "plan from CSR: device Tile_create" in r.stderr   # the device path really ran
+    # the multi-device driver: every shard tiles ITS row block of the CSR arguments on its device (eight shards on the one device there is)
+    for extra in (["--combine=none"], ["--combine=allgather"]):
+        r = subprocess.run([os.path.join(root, "tilespmv_amd", "bin", "test_f64"), "-d", "0,0,0,0,0,0,0,0", os.path.join(root, "tests", "golden", "test.mtx")] + extra, cwd=tmp_path, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, (extra, r.stdout, r.stderr)
+        assert "HIP SpMV on 8 device(s)" in r.stdout and "Check... PASS!" in r.stdout
+        assert r.stderr.count("plan from CSR: device Tile_create") == 8
+
+
+def test_row_block_of_a_larger_csr(torch_cuda):
+    """tilespmv_plan_create_from_csr on a slice of a matrix's row pointer (pointers not rebased, as the multi-device driver passes them): the plan of that row block."""
+    import ctypes as C
+    from tilespmv_amd import _lib
+    rows, cols, rp, ci = G.fem_hex(12, 12, 12, 3)
+    lib = _lib.load(np.float64)
+    v = G.real_values(len(ci), np.float64); x = G.real_x(cols, len(ci), np.float64)
+    rp32, ci32 = np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32)
+    r0, r1 = 16 * 40, 16 * 200
+    h = C.c_void_p()
+    opts = _lib.PlanOptions(deterministic=1)
+    rc = lib.tilespmv_plan_create_from_csr(C.byref(h), r1 - r0, cols, int(rp32[r1] - rp32[r0]), rp32[r0:].ctypes.data_as(_lib._I), ci32.ctypes.data_as(_lib._I), v.ctypes.data_as(C.POINTER(C.c_double)),
+                                           api.CREATE_QUIET, C.byref(opts))
+    assert rc == 0
+    xd = torch_cuda.from_numpy(x).cuda(); yd = torch_cuda.zeros(r1 - r0 + 16, dtype=xd.dtype, device="cuda")
+    assert lib.tilespmv_plan_spmv(h, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None) == 0
+    torch_cuda.cuda.synchronize()
+    lib.tilespmv_plan_destroy(h)
+    import scipy.sparse as sp
+    want = sp.csr_matrix((v, ci, rp), shape=(rows, cols))[r0:r1] @ x
+    assert np.allclose(yd.cpu().numpy()[:r1 - r0], want, rtol=1e-11, atol=1e-11)

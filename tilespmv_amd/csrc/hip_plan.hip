@@ -1080,10 +1080,20 @@ void call_tilespmv_hip(char *filename, Tile_matrix *matrix, int *ptroffset1, int
     // The reference's schedule arrays are pure functions of the Tile_matrix (SURVEY.md Appendix A
     // invariants); the plan derives its own strip schedule, so they are accepted and not used.
     (void)ptroffset1; (void)ptroffset2; (void)rowblkblock; (void)blkcoostylerowidx; (void)blkcoostylerowidx_colstart;
-    (void)blkcoostylerowidx_colstop; (void)csrRowPtrA; (void)csrColIdxA; (void)csrValA; (void)alpha; (void)y_golden;
+    (void)blkcoostylerowidx_colstop; (void)alpha; (void)y_golden;
     auto die = [](const char *what, int code) { fprintf(stderr, "call_tilespmv_hip: %s failed (%d)\n", what, code); exit(3); };
     tilespmv_plan *plan = nullptr;
-    int rc = tilespmv_plan_create(&plan, matrix, rowA, colA, nnzA, nullptr);
+    int rc = -4;
+    // TILESPMV_DEVICE_BUILD=1 (opt-in): the plan is built on the device from the CSR arguments the reference's signature carries anyway (tilespmv_plan_create_from_csr: tiled matrix,
+    // counts, streams all made by kernels; only the CSR arrays cross the bus) instead of re-laying-out and uploading the host Tile_matrix.  For a matrix made by plain Tile_create the
+    // plan is the same, stream for stream; a matrix made with other Tile_create_ex flags (HYB, CDNA4 selection) keeps the host path.
+    if (env_int("TILESPMV_DEVICE_BUILD", 0) != 0 && matrix->hybsize == 0 && csrRowPtrA && csrColIdxA && csrValA) {
+        rc = tilespmv_plan_create_from_csr(&plan, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, TILESPMV_CREATE_QUIET, nullptr);
+        if (rc == -4) fprintf(stderr, "call_tilespmv_hip: this option set has no device build path: the plan is built from the host Tile_matrix\n");
+        else if (rc) die("tilespmv_plan_create_from_csr", rc);
+        else if (plan->info[TILESPMV_INFO_TILES] != matrix->tilenum) die("tilespmv_plan_create_from_csr (the CSR arguments do not tile into the matrix argument)", -6);
+    }
+    if (rc == -4) rc = tilespmv_plan_create(&plan, matrix, rowA, colA, nnzA, nullptr);
     if (rc) die("tilespmv_plan_create", rc);
     val_t *d_x = nullptr, *d_y = nullptr;
     if ((rc = hipMalloc((void **)&d_x, ((size_t)colA + 16) * sizeof(val_t)))) die("hipMalloc x", rc);

@@ -263,7 +263,14 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     const bool verbose = getenv("TILESPMV_CREATE_VERBOSE") != nullptr, cdna4 = flags & TILESPMV_CREATE_CDNA4;
     Tile_matrix &T = D->T;
     const int tilem = (rowA + BS - 1) / BS, tilen = (colA + BS - 1) / BS;
-    const long long nnz = h_rowptr[rowA];
+    // the row pointer may be a slice of a larger matrix's (a row block: pointers not rebased): the block's nonzeros are [base, base + nnz) of the column / value arrays
+    const long long base = h_rowptr[0], nnz = (long long)h_rowptr[rowA] - base;
+    std::vector<int> rebased;
+    if (base != 0) {
+        rebased.resize((size_t)rowA + 1);
+        for (int r = 0; r <= rowA; r++) rebased[(size_t)r] = (int)(h_rowptr[r] - base);
+        h_rowptr = rebased.data(); h_colidx += base; h_val += base;
+    }
     D->rowA = rowA; D->colA = colA; D->nnz = nnz;
     T.tilem = tilem; T.tilen = tilen;
     const int cb_bits = bits_for(tilen), bi_bits = bits_for(tilem);

@@ -63,12 +63,13 @@ struct Shard {
     hipStream_t stream = nullptr;
     tilespmv_plan *plan = nullptr;
     val_t *d_x = nullptr, *d_y = nullptr;
+    bool y_local = false;   // the plan numbers its rows from the shard's first row (built from the row block's CSR): launches get d_y + row0
 };
 
 }  // namespace
 
 static void run_multi(std::vector<Shard> &S, Rccl &rccl, std::vector<void *> &comms, char *filename, Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA,
-                      MAT_VAL_TYPE *x, MAT_VAL_TYPE *y, int ngpus, const int *device_ids, int y_combine_mode);
+                      const MAT_PTR_TYPE *csrRowPtrA, const int *csrColIdxA, const MAT_VAL_TYPE *csrValA, MAT_VAL_TYPE *x, MAT_VAL_TYPE *y, int ngpus, const int *device_ids, int y_combine_mode);
 
 extern "C" int call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int *ptroffset1, int *ptroffset2, int rowblkblock,
                                         unsigned int *blkcoostylerowidx, int *blkcoostylerowidx_colstart,
@@ -78,7 +79,7 @@ extern "C" int call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int 
                                         const int *device_ids, int y_combine_mode)
 {
     (void)ptroffset1; (void)ptroffset2; (void)rowblkblock; (void)blkcoostylerowidx; (void)blkcoostylerowidx_colstart;
-    (void)blkcoostylerowidx_colstop; (void)csrRowPtrA; (void)csrColIdxA; (void)csrValA; (void)alpha; (void)y_golden;
+    (void)blkcoostylerowidx_colstop; (void)alpha; (void)y_golden;
     int prev_device = 0;
     (void)hipGetDevice(&prev_device);
     std::vector<Shard> S;
@@ -86,7 +87,7 @@ extern "C" int call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int 
     std::vector<void *> comms;
     int status = 0;
     try {
-        run_multi(S, rccl, comms, filename, matrix, rowA, colA, nnzA, x, y, ngpus, device_ids, y_combine_mode);
+        run_multi(S, rccl, comms, filename, matrix, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, x, y, ngpus, device_ids, y_combine_mode);
     } catch (const Fail &f) {
         fprintf(stderr, "call_tilespmv_hip_multi: %s failed (%d)\n", f.what, f.code);
         status = 3;
@@ -104,7 +105,7 @@ extern "C" int call_tilespmv_hip_multi(char *filename, Tile_matrix *matrix, int 
 }
 
 static void run_multi(std::vector<Shard> &S, Rccl &rccl, std::vector<void *> &comms, char *filename, Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA,
-                      MAT_VAL_TYPE *x, MAT_VAL_TYPE *y, int ngpus, const int *device_ids, int y_combine_mode)
+                      const MAT_PTR_TYPE *csrRowPtrA, const int *csrColIdxA, const MAT_VAL_TYPE *csrValA, MAT_VAL_TYPE *x, MAT_VAL_TYPE *y, int ngpus, const int *device_ids, int y_combine_mode)
 {
     if (ngpus < 1 || !device_ids) die("argument check (ngpus >= 1, device_ids != NULL)", ngpus);
     if (y_combine_mode < TILESPMV_Y_SHARDED || y_combine_mode > TILESPMV_Y_ALLREDUCE) die("argument check (y_combine_mode)", y_combine_mode);
@@ -137,7 +138,15 @@ static void run_multi(std::vector<Shard> &S, Rccl &rccl, std::vector<void *> &co
         tilespmv_plan_options o;
         tilespmv_plan_options_init(&o);
         o.tilerow_begin = s.tr0; o.tilerow_end = s.tr1;
-        if (s.tr1 > s.tr0) CKT(tilespmv_plan_create(&s.plan, matrix, rowA, colA, nnzA, &o));
+        // TILESPMV_DEVICE_BUILD=1 (opt-in, as in call_tilespmv_hip): every device tiles ITS row block of the CSR arguments and builds its plan from it by kernels
+        // (tilespmv_plan_create_from_csr on the block: local row 0 = the shard's first row, so its SpMV writes at d_y + row0); only that block's CSR arrays cross its bus
+        int rc_dev = -4;
+        if (s.tr1 > s.tr0 && env_int("TILESPMV_DEVICE_BUILD", 0) != 0 && matrix->hybsize == 0 && csrRowPtrA && csrColIdxA && csrValA) {
+            rc_dev = tilespmv_plan_create_from_csr(&s.plan, (int)s.rows, colA, csrRowPtrA[s.row0 + s.rows] - csrRowPtrA[s.row0], csrRowPtrA + s.row0, csrColIdxA, csrValA, TILESPMV_CREATE_QUIET, nullptr);
+            if (rc_dev == 0) s.y_local = true;
+            else if (rc_dev != -4) { e.what = "tilespmv_plan_create_from_csr"; e.code = rc_dev; return; }
+        }
+        if (s.tr1 > s.tr0 && rc_dev == -4) CKT(tilespmv_plan_create(&s.plan, matrix, rowA, colA, nnzA, &o));
         CKT(hipMalloc((void **)&s.d_x, ((size_t)colA + 16) * sizeof(val_t)));
         CKT(hipMalloc((void **)&s.d_y, ybytes));
         CKT(hipMemcpy(s.d_x, x, (size_t)colA * sizeof(val_t), hipMemcpyHostToDevice));
@@ -175,7 +184,7 @@ static void run_multi(std::vector<Shard> &S, Rccl &rccl, std::vector<void *> &co
         for (Shard &s : S) {
             if (!s.plan) continue;
             CK(hipSetDevice(s.device));
-            CK(tilespmv_plan_spmv(s.plan, s.d_x, s.d_y, s.stream));
+            CK(tilespmv_plan_spmv(s.plan, s.d_x, s.y_local ? s.d_y + s.row0 : s.d_y, s.stream));
         }
     };
     auto combine = [&]() {
