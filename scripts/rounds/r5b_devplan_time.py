@@ -1,7 +1,7 @@
 """Round 5 (second session): preparation end to end — host Tile_create + tilespmv_plan_create against tilespmv_plan_create_from_csr (everything on the device) — per workload,
 with the stream digests and the first SpMV compared.  TILESPMV_PLAN_VERBOSE / TILESPMV_CREATE_VERBOSE print the stages."""
 import os, sys, time
-os.environ["TILESPMV_PLAN_VERBOSE"] = "1"; os.environ["TILESPMV_CREATE_VERBOSE"] = "1"
+if os.environ.get("R5B_VERBOSE"): os.environ["TILESPMV_PLAN_VERBOSE"] = "1"; os.environ["TILESPMV_CREATE_VERBOSE"] = "1"
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
@@ -20,6 +20,7 @@ for wl in sys.argv[1].split(","):
         same = sorted(hs) == sorted(ds) and all(hs[k] == ds[k] for k in hs)
         ms_h = ph.time(xd.data_ptr(), yh.data_ptr(), 0, 5, 20); ms_d = pd.time(xd.data_ptr(), yd.data_ptr(), 0, 5, 20)
         i = pd.info()
-        print("%s rep %d: host Tile_create %.3f s + plan create %.3f s = %.3f s | from_csr %.3f s (device Tile_create %.3f s incl. CSR upload) | streams identical: %s, y identical: %s | SpMV %.4f / %.4f ms"
-              % (wl, rep, t_tc, t_pc, t_tc + t_pc, t_dev, i["tile_create_us"] * 1e-6, same, bool(torch.equal(yh, yd)), ms_h, ms_d), flush=True)
+        hi = ph.info()
+        print("%s rep %d: host Tile_create %.3f s + plan create %.3f s = %.3f s (timed choices %.0f ms) | from_csr %.3f s (device Tile_create %.3f s incl. CSR upload; timed choices %.0f ms) | streams identical: %s, y identical: %s (plan-fixed summation order: %s) | SpMV %.4f / %.4f ms"
+              % (wl, rep, t_tc, t_pc, t_tc + t_pc, hi["timed_choices_us"] * 1e-3, t_dev, i["tile_create_us"] * 1e-6, i["timed_choices_us"] * 1e-3, same, bool(torch.equal(yh, yd)), bool(hi["entry_ordered"] and i["entry_ordered"]), ms_h, ms_d), flush=True)
         ph.close(); pd.close(); api.Tile_destroy(tm)

@@ -198,11 +198,13 @@ void StreamBuilder::count()
             std::vector<int> nu, nc, nd;
             DevCounts &C = form == csr_form ? dcnt : dcnt_alt;
             if (dev_count(DS, form, &C, nu, nc, nd) != 0) { rc = -3; return; }
-            for (int i = 0; i < ntr; i++) {
-                RowCount c{nu[(size_t)i], nc[(size_t)i], 0, nd[(size_t)i], 0, 0, 0};
-                c.cost = 16LL * c.nunits + (long long)K.coo_cost * c.ncoo + 64LL * c.ndense + 8;
-                out[(size_t)i] = c;
-            }
+            parallel_chunks(ntr, 1 << 16, [&](int64_t b, int64_t e, int) {
+                for (int64_t i = b; i < e; i++) {
+                    RowCount c{nu[(size_t)i], nc[(size_t)i], 0, nd[(size_t)i], 0, 0, 0};
+                    c.cost = 16LL * c.nunits + (long long)K.coo_cost * c.ncoo + 64LL * c.ndense + 8;
+                    out[(size_t)i] = c;
+                }
+            });
             return;
         }
         parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
@@ -269,7 +271,10 @@ void StreamBuilder::count()
                                                      desc_split, u1, e1, split_b / 1e6, u2, e2, pooled_b / 1e6, csr_form == 2 ? "pooled" : "split");
     }
     csr_split = csr_form != 0; pooled = csr_form == 2;
-    for (std::vector<long long> *p : {&pu, &pc, &ph, &phv, &phi, &pd}) p->assign((size_t)ntr + 1, 0);
+    {   // (six arrays of ntr + 1 prefixes: first touched side by side — a million tile-rows are 50 MB of fresh pages)
+        std::vector<long long> *six[6] = {&pu, &pc, &ph, &phv, &phi, &pd};
+        parallel_chunks(6, 1, [&](int64_t b, int64_t e, int) { for (int64_t q = b; q < e; q++) six[q]->assign((size_t)ntr + 1, 0); });
+    }
     for (int i = 0; i < ntr; i++) pd[i + 1] = pd[i] + rc_[i].ndense;
     ND = pd[ntr];
     for (int i = 0; i < ntr; i++) {
