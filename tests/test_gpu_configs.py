@@ -179,7 +179,7 @@ def test_fem_class_default_plans_full_size(torch_cuda, workload, dtype):
     for kw in (dict(), dict(entry_mode=2, entry_ordered=1)):
         plan = api.Plan(tp, rowA, n, nnz, **kw)
         info = plan.info()
-        assert info["csr_form"] == 2 and info["desc_bytes"] == 20, (workload, info)
+        assert info["csr_form"] == 2 and info["desc_bytes"] == (20 if workload == "fem3s64_68" else 8), (workload, info)   # (natural-order meshes: a few dozen patterns -> 8-byte descriptors + dictionary; the shuffled one keeps 20)
         if dtype == np.float64 and workload != "fem3s64_68":
             assert info["stream_bytes"] <= 0.82 * api.algorithmic_bytes(nnz, rowA, n, 8), (workload, info["stream_bytes"])
         ys = []

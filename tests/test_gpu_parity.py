@@ -881,7 +881,7 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
                  dict(placement_tries=3), dict(placement_tries=2, entry_mode=2, strip_cost=64, split_above=200), dict(placement_tries=3, coo_mode=2), dict(placement_tries=2, x_window=1),
                  dict(placement_tries=3, dense_mode=1, csr_split=0)]
     windowed = bricks = 0
-    desc = {4: 0, 12: 0, 20: 0}   # (20: pooled plans, where the byte model chooses them)
+    desc = {4: 0, 8: 0, 12: 0, 20: 0}   # (20 / 8: pooled plans, where the byte model chooses them — 8 with their pattern dictionary)
     for name, gen in mats.items():
         m, n, rp, ci = gen()
         nnz, rowA = len(ci), truncated_rows(m)
@@ -899,7 +899,8 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
             bricks += info["brick_order"] == 1
             desc[info["desc_bytes"]] += 1
             assert info["nt_stream"] == (1 if kw.get("nt_stream") == 1 and info["entry_mode"] != 1 and not info["x_window_slots"] else 0)   # (small test matrices: off by rule)
-            assert info["desc_bytes"] == 12 or (info["desc_bytes"] == 20 and info["csr_form"] == 2) or (kw.get("desc_dict") != 0 and info["x_window_slots"] == 0)   # (20: a pooled plan, chosen by the byte model)
+            assert info["desc_bytes"] == 12 or (info["desc_bytes"] == 20 and info["csr_form"] == 2) or (kw.get("desc_dict") != 0 and info["x_window_slots"] == 0)   # (20: a pooled plan, chosen by the byte model; 8: with its pattern dictionary)
+            assert info["desc_bytes"] != 8 or (info["csr_form"] == 2 and kw.get("desc_dict") != 0)
             assert not (kw.get("x_window") == 0 and info["brick_order"])
         # multi-vector product on an x-window plan: its kernel reads the column-block descriptors kept beside the slotted ones
         plan = api.Plan(tp, rowA, n, nnz, x_window=1, entry_mode=0)
@@ -1105,7 +1106,7 @@ def test_pooled_units_bit_exact(torch_cuda, dtype):
     mats = {"fem3_12": lambda: G.fem_hex(12, 12, 12, 3), "fem3s_14": lambda: G.fem_hex(14, 11, 9, 3, shuffle=16), "fem6_9": lambda: G.fem_hex(9, 9, 9, 6), "fem2_odd": lambda: G.fem_hex(13, 7, 5, 2),
             "allfmt": SMALL["allfmt"], "allfmt_pad5": SMALL["allfmt_pad5"], "kkt12": MEDIUM["kkt12"], "band4096_40": SMALL["band4096_40"], "powerlaw20k": SMALL["powerlaw20k"],
             "one_long_row": SMALL["one_long_row"], "empty_rows": SMALL["empty_rows"], "rand500x700": SMALL["rand500x700"]}
-    knob_sets = [dict(), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, entry_ordered=1), dict(entry_mode=2, entry_ordered=0), dict(strip_cost=64, split_above=200),
+    knob_sets = [dict(), dict(desc_dict=0), dict(desc_dict=0, entry_mode=2), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, entry_ordered=1), dict(entry_mode=2, entry_ordered=0), dict(strip_cost=64, split_above=200),
                  dict(entry_mode=2, strip_cost=100, split_above=300, split_cap=300), dict(entry_mode=0, fix_inline=0, split_above=150, strip_cost=50), dict(dense_mode=api.DENSE_MFMA),
                  dict(dense_mode=api.DENSE_VALU), dict(coo_mode=api.COO_FALLBACK), dict(xcd_remap=0, nt_stream=1), dict(entry_mode=2, nt_stream=1), dict(x_window=2), dict(lds_pad=8192)]
     for name, gen in mats.items():
@@ -1117,7 +1118,7 @@ def test_pooled_units_bit_exact(torch_cuda, dtype):
         tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=hyb)
         for kw in knob_sets:
             y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, csr_split=2, **kw)
-            assert info["csr_form"] == 2 and info["desc_bytes"] == 20, (name, kw)
+            assert info["csr_form"] == 2 and info["desc_bytes"] in ((20,) if kw.get("desc_dict") == 0 else (8, 20)), (name, kw)   # (8: the shard's units use few enough patterns for the dictionary)
             assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
         # tile-row shards of a pooled plan write their own rows only
         tilem = rowA // 16

@@ -647,7 +647,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     static_assert(!(XWIN && CD), "x-window plans keep 12-B descriptors (their low bits hold window slots)");
     static_assert(!(NTS && (XWIN || ECOO == 1)), "nontemporal streams: large plans only (entry mode 1 = small grids; x windows are an opt-in experiment)");
     static_assert(!PACE || (ECOO == 2 && GPB == 16 && !XWIN), "slab pacing: workgroup entry mode, 256-thread workgroups, no x windows");
-    static_assert(!POOL || (GPB == 16 && !XWIN && !CD && !PACE), "pooled plans: 256-thread workgroups, 12-B descriptors + row nibbles, no x windows, no pacing");
+    static_assert(!POOL || (GPB == 16 && !XWIN && !PACE), "pooled plans: 256-thread workgroups, no x windows, no pacing");
     constexpr int GROUPS_PER_BLOCK = GPB;
     constexpr int SROWS = XWIN ? XWIN_STRIP_ROWS : POOL ? POOL_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
     constexpr bool NT = NTS;  // nontemporal value loads
@@ -726,16 +726,24 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     const uint2 *__restrict__ urw = reinterpret_cast<const uint2 *>(S.urow);
     unsigned wnn = 0;   // CD: descriptor word of the chunk after `dnext`
     const unsigned *__restrict__ udw = reinterpret_cast<const unsigned *>(S.udesc);
+    // POOL + CD (pooled dictionary plans, round 5): a unit's descriptor in HBM is 8 bytes — word 0 (window base | tile-row in strip) and the id of its 16-byte pattern (the 16 column
+    // nibbles and the 16 row nibbles) in S.pdict, which stays in the vector L1 / L2: natural-order meshes use a few dozen patterns (fem3_68: 54).  Same staging as the classic
+    // dictionary: words two chunks ahead, the pattern gathered one chunk ahead, so neither hop is waited for in the unit loop.
+    uint2 wnn2 = make_uint2(0u, 0u);
+    const uint2 *__restrict__ udw2 = reinterpret_cast<const uint2 *>(S.udesc);
     val_t v[UB];
     auto unit_prologue = [&]() {  // descriptor chunks 0 and 1, first value batch: in flight across the entry phase
         if (have_units) {
-            if constexpr (CD) {
+            if constexpr (CD && POOL) {   // pooled dictionary plans: 8-byte descriptors (word 0, pattern id)
+                const uint2 a = udw2[min(unit_begin + r, last)], b = udw2[min(unit_begin + DCHUNK + r, last)];
+                dcur.x = a.x; dcur.y = a.y; dnext.x = b.x; dnext.y = b.y;
+            } else if constexpr (CD) {
                 dcur.x = stream_load<NT_DESC>(udw + min(unit_begin + r, last));
                 dnext.x = stream_load<NT_DESC>(udw + min(unit_begin + DCHUNK + r, last));
             } else {
                 dcur = load_udesc_raw(S.udesc, min(unit_begin + r, last));
                 dnext = load_udesc_raw(S.udesc, min(unit_begin + DCHUNK + r, last));
-                if constexpr (POOL) { rcur = urw[min(unit_begin + r, last)]; rnext = urw[min(unit_begin + DCHUNK + r, last)]; }
+                if constexpr (POOL) { rcur = urw[min(unit_begin + r, last)]; rnext = urw[min(unit_begin + DCHUNK + r, last)]; }   // (12-byte descriptors + 8 bytes of row nibbles)
             }
 #pragma unroll
             for (int k = 0; k < UB; k += G) {
@@ -753,13 +761,18 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     val_t xv[UB];
     const unsigned *sr = reinterpret_cast<const unsigned *>(&s_r[POOL ? g : 0][0]) + (r >> 3);
     auto park_first = [&]() {   // chunk 0 into LDS (CD: the patterns of chunks 0 and 1 are gathered here, the word of chunk 2 loaded)
-        if constexpr (CD) {
+        if constexpr (CD && POOL) {
+            const uint4 p0 = S.pdict[dcur.y], p1 = S.pdict[dnext.y];
+            wnn2 = udw2[min(unit_begin + 2 * DCHUNK + r, last)];
+            s_d[g][r] = make_uint4(dcur.x, p0.x, dcur.x, p0.y); s_r[g][r] = make_uint2(p0.z, p0.w);
+            dnext = make_uint4(dnext.x, p1.x, 0u, p1.y); rnext = make_uint2(p1.z, p1.w);
+        } else if constexpr (CD) {
             const uint2 p0 = udict_of(S, dcur.x), p1 = udict_of(S, dnext.x);
             wnn = stream_load<NT_DESC>(udw + min(unit_begin + 2 * DCHUNK + r, last));
             dnext.y = p1.x; dnext.w = p1.y;
             s_d[g][r] = udesc_expand(S, dcur.x, p0);
         } else s_d[g][r] = udesc_park_form(dcur);
-        if constexpr (POOL) s_r[g][r] = rcur;
+        if constexpr (POOL && !CD) s_r[g][r] = rcur;
     };
     auto fetch_batch = [&](int j0) {
 #pragma unroll
@@ -948,12 +961,17 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         for (int u = unit_begin; u < unit_end; u += UB) {
             if (u == chunk_end) {  // next descriptor chunk: already in registers, fetch the one after it
                 wave_lds_fence();
-                if constexpr (CD) s_d[g][r] = udesc_expand(S, dnext.x, make_uint2(dnext.y, dnext.w));
+                if constexpr (CD && POOL) { s_d[g][r] = make_uint4(dnext.x, dnext.y, dnext.x, dnext.w); s_r[g][r] = rnext; }
+                else if constexpr (CD) s_d[g][r] = udesc_expand(S, dnext.x, make_uint2(dnext.y, dnext.w));
                 else s_d[g][r] = udesc_park_form(dnext);
-                if constexpr (POOL) { s_r[g][r] = rnext; rnext = urw[min(chunk_end + DCHUNK + r, last)]; }
+                if constexpr (POOL && !CD) { s_r[g][r] = rnext; rnext = urw[min(chunk_end + DCHUNK + r, last)]; }
                 wave_lds_fence();
                 chunk_end += DCHUNK;
-                if constexpr (CD) {
+                if constexpr (CD && POOL) {
+                    const uint4 p = S.pdict[wnn2.y];   // (its words were loaded a chunk ago)
+                    dnext = make_uint4(wnn2.x, p.x, 0u, p.y); rnext = make_uint2(p.z, p.w);
+                    wnn2 = udw2[min(chunk_end + DCHUNK + r, last)];
+                } else if constexpr (CD) {
                     const uint2 p = udict_of(S, wnn);   // (its word was loaded a chunk ago)
                     dnext = make_uint4(wnn, p.x, 0u, p.y);
                     wnn = stream_load<NT_DESC>(udw + min(chunk_end + DCHUNK + r, last));
@@ -1697,9 +1715,18 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_pool_mv(DevStream S, int 
 #pragma unroll
         for (int k = 0; k < UNIT_GROUP; k++) out[k] = pv[k];
     };
+    // pooled dictionary plans (S.pdict): 8-byte descriptors (word 0, pattern id); the pattern — column and row nibbles — is gathered one chunk after its id was loaded
+    const uint2 *__restrict__ udw2 = reinterpret_cast<const uint2 *>(S.udesc);
+    const bool pd = S.pdict != nullptr;
+    uint2 wnn2 = make_uint2(0u, 0u);
     if (have_units) {   // descriptor chunks 0 and 1, first value group: in flight across the entry phase
-        dcur = load_udesc_raw(S.udesc, min(unit_begin + r, last)); dnext = load_udesc_raw(S.udesc, min(unit_begin + DCHUNK + r, last));
-        rcur = urw[min(unit_begin + r, last)]; rnext = urw[min(unit_begin + DCHUNK + r, last)];
+        if (pd) {
+            const uint2 a = udw2[min(unit_begin + r, last)], b = udw2[min(unit_begin + DCHUNK + r, last)];
+            dcur.x = a.x; dcur.y = a.y; dnext.x = b.x; dnext.y = b.y;
+        } else {
+            dcur = load_udesc_raw(S.udesc, min(unit_begin + r, last)); dnext = load_udesc_raw(S.udesc, min(unit_begin + DCHUNK + r, last));
+            rcur = urw[min(unit_begin + r, last)]; rnext = urw[min(unit_begin + DCHUNK + r, last)];
+        }
         load_grp(unit_begin, v);
     }
     wave_lds_fence();
@@ -1727,6 +1754,12 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_pool_mv(DevStream S, int 
     if (have_units) {
         const uint2 *sd = reinterpret_cast<const uint2 *>(&s_d[g][0]) + (r >> 3);
         const unsigned *sr = reinterpret_cast<const unsigned *>(&s_r[g][0]) + (r >> 3);
+        if (pd) {
+            const uint4 p0 = S.pdict[dcur.y], p1 = S.pdict[dnext.y];
+            wnn2 = udw2[min(unit_begin + 2 * DCHUNK + r, last)];
+            dcur = make_uint4(dcur.x, p0.x, p0.y, 0u); rcur = make_uint2(p0.z, p0.w);
+            dnext = make_uint4(dnext.x, p1.x, p1.y, 0u); rnext = make_uint2(p1.z, p1.w);
+        }
         s_d[g][r] = udesc_park_form(dcur); s_r[g][r] = rcur;
         wave_lds_fence();
         int chunk_end = unit_begin + DCHUNK;
@@ -1736,7 +1769,11 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_pool_mv(DevStream S, int 
                 s_d[g][r] = udesc_park_form(dnext); s_r[g][r] = rnext;
                 wave_lds_fence();
                 chunk_end += DCHUNK;
-                dnext = load_udesc_raw(S.udesc, min(chunk_end + r, last)); rnext = urw[min(chunk_end + r, last)];
+                if (pd) {
+                    const uint4 p = S.pdict[wnn2.y];
+                    dnext = make_uint4(wnn2.x, p.x, p.y, 0u); rnext = make_uint2(p.z, p.w);
+                    wnn2 = udw2[min(chunk_end + DCHUNK + r, last)];
+                } else { dnext = load_udesc_raw(S.udesc, min(chunk_end + r, last)); rnext = urw[min(chunk_end + r, last)]; }
             }
             const int j0 = u - (chunk_end - DCHUNK);
             uint2 d[UB]; unsigned rw[UB]; vec_t xv[UB];
@@ -2049,13 +2086,15 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
 #define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L4(X, 2, 16, true, false, false); else if (xwin_lds_bytes > 0) TSPMV_L4(X, 0, 16, true, false, false); \
         else if (entry_mode == 2 && wg_strips == 32) TSPMV_L2(X, 2, 32); else if (entry_mode == 2) TSPMV_L2(X, 2, 16); \
         else if (entry_mode == 1) { if (S.cb_bits > 0) TSPMV_L4(X, 1, 16, false, true, false); else TSPMV_L4(X, 1, 16, false, false, false); } else TSPMV_L2(X, 0, 16); } while (0)
-#define TSPMV_LP(X, W, NTS) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, 16, false, false, NTS, false, true>), dim3((unsigned)((S.ntasks + 15) / 16)), dim3(256), (size_t)lds_pad_bytes, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_LPD(X, W, NTS, PD) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, 16, false, PD, NTS, false, true>), dim3((unsigned)((S.ntasks + 15) / 16)), dim3(256), (size_t)lds_pad_bytes, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_LP(X, W, NTS) do { if (S.pdict) TSPMV_LPD(X, W, NTS, true); else TSPMV_LPD(X, W, NTS, false); } while (0)
 #define TSPMV_LP1(X) do { if (entry_mode == 1) TSPMV_LP(X, 1, false); else if (entry_mode == 2) { if (S.nt_stream) TSPMV_LP(X, 2, true); else TSPMV_LP(X, 2, false); } \
         else { if (S.nt_stream) TSPMV_LP(X, 0, true); else TSPMV_LP(X, 0, false); } } while (0)
         if (S.pooled) { if (xcd_remap == 2) TSPMV_LP1(2); else TSPMV_LP1(0); }
         else if (xcd_remap == 2) TSPMV_L1(2); else TSPMV_L1(0);
 #undef TSPMV_LP1
 #undef TSPMV_LP
+#undef TSPMV_LPD
 #undef TSPMV_L1
 #undef TSPMV_L2
 #undef TSPMV_L3

@@ -112,6 +112,10 @@ struct UDesc { unsigned w0, n0, n1; };    // 12 bytes in HBM; lanes expand it to
 // row nibble) and y is stored from the slab.  In a pooled plan EVERY unit has this form (ELL slots, dense and dense-col columns: base = 16 x column block, identity row
 // nibbles; dense-row units: identity column nibbles, one row nibble), so the kernel has one code path.  Windows that hold fewer nonzeros than a unit is worth
 // (POOL_MIN_FILL) stay on the strip's entry list.
+// Pooled DICTIONARY plans (round 5, second half): where the units of a shard use at most 2^DICT_MAX_BITS distinct 16-byte patterns (16 column nibbles + 16 row nibbles) — natural-order
+// meshes use a few dozen: 54 on the 27-point hex mesh x 3 unknowns, 31 on the tetrahedral mesh — a unit's descriptor in HBM is 8 bytes (w0, pattern id) and the patterns sit in
+// DevStream::pdict, which stays in the vector L1 / L2: 136 instead of 148 bytes per unit (streams -8 %, time -2 ... -5 %: profiles/r05_pool_dictionary_ab.txt).  desc_dict = 0 keeps the
+// 20-byte form; window-shuffled meshes (10^5 patterns) keep it by themselves.
 constexpr int POOL_KR_SHIFT = 28;         // w0 of a pooled unit: first column of the window (28 bits: the unit path already limits shards to 2^24 column blocks) | tile-row in strip << 28
 constexpr unsigned POOL_BASE_MASK = (1u << POOL_KR_SHIFT) - 1u;
 constexpr int POOL_MIN_FILL = sizeof(val_t) == 8 ? 12 : 10;   // 16 s_v + 20 bytes per unit against s_v + 5 (4 in the packed lists) per list entry
@@ -130,7 +134,8 @@ struct STask {                            // 32 bytes
 
 struct DevStream {
     const UDesc *udesc;                   // per unit, 12 B: column block | flags << 24, column nibbles of rows 0-7, of rows 8-15 (dictionary plans: 4-B words, see cb_bits)
-    const URow *urow;                     // pooled plans: the row nibbles of every unit (nullptr otherwise)
+    const URow *urow;                     // pooled plans: the row nibbles of every unit (nullptr otherwise, and in pooled dictionary plans)
+    const uint4 *pdict;                   // pooled dictionary plans: udesc holds 8-byte (word 0, pattern id) pairs, pdict[id] = column nibbles 0-7, 8-15, row nibbles 0-7, 8-15 (nullptr: none)
     int pooled;                           // 1: every unit is a pooled unit (above)
     const val_t *uval;                    // 16 values per unit, stored in groups of UNIT_GROUP units of one task, interleaved per row
     const val_t *cval;                    // COO entry list: value, global column, (row-in-strip << 4) | row

@@ -234,6 +234,68 @@ __global__ __launch_bounds__(64) void k_pe_write(int ntasks, const int *__restri
     }
 }
 
+
+// ---- pooled dictionary plans: the distinct 16-byte patterns (column nibbles, row nibbles) of the packed units, by an open-addressing table in global memory (a shard that qualifies has
+// at most 2^DICT_MAX_BITS of them; the table is eight times that).  Nobody ever waits for anybody: a slot is claimed by a 64-bit tag (a hash of the pattern, never 0) with one
+// compare-and-swap, the claimant writes the pattern behind it, a unit that meets its own tag takes the slot for its pattern.  That two different patterns share a tag (2^-64 per pair)
+// is not assumed away: after the insert kernel has finished, k_pd_pool_verify compares every unit's pattern with the one stored under its tag — a mismatch gives the dictionary up.
+constexpr int PTABLE = 8 << DICT_MAX_BITS;
+__device__ __forceinline__ u64 pattern_tag(const uint4 q)
+{
+    u64 h = 1469598103934665603ull;
+    for (unsigned w : {q.x, q.y, q.z, q.w}) { h ^= w; h *= 1099511628211ull; h ^= h >> 29; }
+    return h ? h : 1ull;
+}
+__global__ __launch_bounds__(256) void k_pd_pool_patterns(const UDesc *__restrict__ packed, const URow *__restrict__ prow, long long n, int cap, uint4 *__restrict__ table, u64 *__restrict__ tags,
+                                                            int *__restrict__ count_over /* [0] distinct so far, [1] over */)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 q = make_uint4(packed[i].n0, packed[i].n1, prow[i].r0, prow[i].r1);
+    if (i > 0 && packed[i - 1].n0 == q.x && packed[i - 1].n1 == q.y && prow[i - 1].r0 == q.z && prow[i - 1].r1 == q.w) return;   // (the unit before inserts it)
+    const u64 tag = pattern_tag(q);
+    unsigned h = (unsigned)(tag >> 20) & (unsigned)(PTABLE - 1);
+    for (int probe = 0; probe < PTABLE; probe++, h = (h + 1) & (unsigned)(PTABLE - 1)) {   // (bounded: every pass either ends the walk or moves to the next slot)
+        const u64 seen = atomicCAS(&tags[h], 0ull, tag);
+        if (seen == 0ull) {   // claimed: this thread alone writes the pattern
+            table[h] = q;
+            if (atomicAdd(&count_over[0], 1) + 1 > cap) count_over[1] = 1;
+            return;
+        }
+        if (seen == tag) return;
+    }
+    count_over[1] = 1;   // table full: far more patterns than a dictionary holds
+}
+__global__ __launch_bounds__(256) void k_pd_pool_verify(const UDesc *__restrict__ packed, const URow *__restrict__ prow, long long n, const uint4 *__restrict__ table, const u64 *__restrict__ tags, int *__restrict__ count_over)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 q = make_uint4(packed[i].n0, packed[i].n1, prow[i].r0, prow[i].r1);
+    const u64 tag = pattern_tag(q);
+    unsigned h = (unsigned)(tag >> 20) & (unsigned)(PTABLE - 1);
+    for (int probe = 0; probe < PTABLE; probe++, h = (h + 1) & (unsigned)(PTABLE - 1)) {
+        const u64 seen = tags[h];
+        if (seen == tag) { const uint4 t = table[h]; if (t.x != q.x || t.y != q.y || t.z != q.z || t.w != q.w) count_over[1] = 1; return; }
+        if (seen == 0ull) break;
+    }
+    count_over[1] = 1;   // (not found: cannot happen after a complete insert pass; treated like a mismatch)
+}
+__global__ __launch_bounds__(256) void k_pd_pool_compact(const UDesc *__restrict__ packed, const URow *__restrict__ prow, long long n, const uint4 *__restrict__ dict, int ndict, uint2 *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned q[4] = {packed[i].n0, packed[i].n1, prow[i].r0, prow[i].r1};
+    int lo = 0, hi = ndict;   // lower bound in the ascending (n0, n1, r0, r1) dictionary
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint4 d = dict[mid];
+        const unsigned e[4] = {d.x, d.y, d.z, d.w};
+        bool less = false;
+        for (int k = 0; k < 4; k++) { if (e[k] != q[k]) { less = e[k] < q[k]; break; } }
+        if (less) lo = mid + 1; else hi = mid;
+    }
+    out[i] = make_uint2(packed[i].w0, (unsigned)lo);
+}
 }  // namespace
 
 void DevLists::release()
@@ -464,6 +526,43 @@ int dev_dict_patterns(const UDesc *d_packed, long long NUP, size_t cap, std::vec
     if ((size_t)n > cap) { *over = true; return 0; }
     sorted_patterns.resize((size_t)n);
     PD_TRY(hipMemcpy(sorted_patterns.data(), uniq.p, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dev_pool_dict(const UDesc *d_packed, const URow *d_packed_row, long long NUP, size_t cap, std::vector<uint4> &sorted_patterns, bool *over)
+{
+    sorted_patterns.clear(); *over = false;
+    if (NUP <= 0) return 0;
+    Tmp<uint4> table; Tmp<u64> tags; Tmp<int> cnt;
+    PD_TRY(table.alloc((size_t)PTABLE, true)); PD_TRY(tags.alloc((size_t)PTABLE, true)); PD_TRY(cnt.alloc(2, true));
+    hipLaunchKernelGGL(k_pd_pool_patterns, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, d_packed_row, NUP, (int)cap, table.p, tags.p, cnt.p);
+    PD_TRY(hipGetLastError());
+    int h_cnt[2] = {0, 0};
+    PD_TRY(hipMemcpy(h_cnt, cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost));
+    if (h_cnt[1] || (size_t)h_cnt[0] > cap) { *over = true; return 0; }
+    hipLaunchKernelGGL(k_pd_pool_verify, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, d_packed_row, NUP, (const uint4 *)table.p, (const u64 *)tags.p, cnt.p);
+    PD_TRY(hipGetLastError());
+    PD_TRY(hipMemcpy(h_cnt, cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost));
+    if (h_cnt[1]) { *over = true; return 0; }   // (two patterns under one tag: the 20-byte form stays)
+    std::vector<uint4> ht((size_t)PTABLE); std::vector<u64> hs((size_t)PTABLE);
+    PD_TRY(hipMemcpy(ht.data(), table.p, ht.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    PD_TRY(hipMemcpy(hs.data(), tags.p, hs.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ht.size(); i++) if (hs[i] != 0ull) sorted_patterns.push_back(ht[i]);
+    std::sort(sorted_patterns.begin(), sorted_patterns.end(), [](const uint4 &a, const uint4 &b) {
+        if (a.x != b.x) return a.x < b.x;
+        if (a.y != b.y) return a.y < b.y;
+        if (a.z != b.z) return a.z < b.z;
+        return a.w < b.w;
+    });
+    return 0;
+}
+
+int dev_pool_compact(const UDesc *d_packed, const URow *d_packed_row, long long NUP, const uint4 *d_dict, int ndict, uint2 *d_out)
+{
+    if (NUP <= 0) return 0;
+    hipLaunchKernelGGL(k_pd_pool_compact, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, d_packed_row, NUP, d_dict, ndict, d_out);
+    PD_TRY(hipGetLastError());
+    PD_TRY(hipDeviceSynchronize());
     return 0;
 }
 

@@ -1,5 +1,7 @@
 // hip_plan_stream.hip — second-generation ("unit stream") layout builder of the plan (hip_plan.h), in stages.
+#include <array>
 #include <mutex>
+#include <set>
 
 #include "hip_plan_internal.h"
 #include "plan_tile_ops.h"
@@ -133,6 +135,8 @@ struct StreamBuilder {
     long long xwin_segments = 0, xwin_wgs = 0;
     // ENCODE / ENTRIES
     long long NUP = 0, n_rec = 0, n_chunk = 0, n_groups = 0, panel_rmw_rows = 0;
+    bool pool_dict = false;   // pooled plan with 8-B descriptors + pattern dictionary
+    long long desc_bytes() const { return S.cb_bits > 0 ? 4 : pooled ? (pool_dict ? 8 : 20) : 12; }
     std::vector<long long> old_begin;
 
     StreamBuilder(tilespmv_plan *plan_, const Knobs &K_, const Tile_matrix *T_, int rowA_, int colA_, int tr0_, int tr1_, bool coo_in_tile_, bool dense_mfma_,
@@ -720,16 +724,35 @@ void StreamBuilder::encode_device()
         if (n > 0) { k.unit_begin = (int)nb; k.unit_end = (int)(nb + n); }
     }
     const double t0 = now_us();
-    S.udict = nullptr; S.cb_bits = 0; S.urow = nullptr; S.pooled = pooled ? 1 : 0;
-    void *d_map = nullptr; UDesc *d_packed = nullptr;
+    S.udict = nullptr; S.cb_bits = 0; S.urow = nullptr; S.pooled = pooled ? 1 : 0; S.pdict = nullptr; pool_dict = false;
+    void *d_map = nullptr; UDesc *d_packed = nullptr; URow *d_prow = nullptr;
     auto fail = [&](const char *what, hipError_t e) { fprintf(stderr, "tilespmv: device plan build: %s: %s\n", what, hipGetErrorString(e)); (void)hipGetLastError(); rc = -3; };
     hipError_t e = hipMalloc(&d_map, std::max<size_t>(pair_map.size(), 1) * sizeof(int4));
     if (e == hipSuccess && !pair_map.empty()) e = hipMemcpy(d_map, pair_map.data(), pair_map.size() * sizeof(int4), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&d_packed, std::max<long long>(NUP, 1) * sizeof(UDesc) + 256);
     if (e == hipSuccess) e = hipMemsetAsync(d_packed, 0, std::max<long long>(NUP, 1) * sizeof(UDesc) + 256, 0);
     if (e != hipSuccess) fail("scratch for the packed descriptors", e);
-    if (pooled) rc |= plan->reserve((size_t)NUP, &S.urow);
-    if (rc == 0 && dev_pack_desc(d_udesc, d_urow, (const int4 *)d_map, (int)pair_map.size(), d_packed, const_cast<URow *>(S.urow)) != 0) rc = -3;
+    if (pooled && e == hipSuccess) {   // packed row nibbles: scratch (they end up in the plan's arena, or — pooled dictionary plans — in the dictionary)
+        e = hipMalloc((void **)&d_prow, std::max<long long>(NUP, 1) * sizeof(URow) + 256);
+        if (e == hipSuccess) e = hipMemsetAsync(d_prow, 0, std::max<long long>(NUP, 1) * sizeof(URow) + 256, 0);
+        if (e != hipSuccess) fail("scratch for the packed row nibbles", e);
+    }
+    if (rc == 0 && dev_pack_desc(d_udesc, d_urow, (const int4 *)d_map, (int)pair_map.size(), d_packed, d_prow) != 0) rc = -3;
+    if (rc == 0 && pooled && K.desc_dict != 0 && NUP > 0) {   // 8-B descriptors + pattern dictionary (the host builder's rule)
+        std::vector<uint4> pats;
+        bool over = false;
+        if (dev_pool_dict(d_packed, d_prow, NUP, (size_t)1 << DICT_MAX_BITS, pats, &over) != 0) rc = -3;
+        else if (!over) {
+            rc |= plan->upload(pats.data(), pats.size(), &S.pdict);
+            rc |= plan->reserve((size_t)NUP, reinterpret_cast<const uint2 **>(&S.udesc));
+            if (rc == 0 && dev_pool_compact(d_packed, d_prow, NUP, S.pdict, (int)pats.size(), reinterpret_cast<uint2 *>(const_cast<UDesc *>(S.udesc))) != 0) rc = -3;
+            pool_dict = true;
+        }
+    }
+    if (rc == 0 && pooled && !pool_dict) {
+        rc |= plan->reserve((size_t)NUP, &S.urow);
+        if (rc == 0 && NUP > 0 && (e = hipMemcpy(const_cast<URow *>(S.urow), d_prow, (size_t)NUP * sizeof(URow), hipMemcpyDeviceToDevice)) != hipSuccess) fail("row nibble copy", e);
+    }
     // 4-B descriptors + pattern dictionary under the host builder's conditions (below); the distinct patterns come from a sort + run-length encoding of the packed descriptors
     const bool dict_pays = K.desc_dict > 0 ? true : 8LL * NUP * 50 >= NUP * (12 + 16LL * sv) + NC * (sv + 4LL);
     if (rc == 0 && K.desc_dict != 0 && dict_pays && !xwin && !pooled && NUP > 0) {
@@ -749,11 +772,11 @@ void StreamBuilder::encode_device()
             }
         }
     }
-    if (rc == 0 && S.cb_bits == 0) {
+    if (rc == 0 && S.cb_bits == 0 && !pool_dict) {
         rc |= plan->reserve((size_t)NUP, &S.udesc);
         if (rc == 0 && NUP > 0 && (e = hipMemcpy(const_cast<UDesc *>(S.udesc), d_packed, (size_t)NUP * sizeof(UDesc), hipMemcpyDeviceToDevice)) != hipSuccess) fail("descriptor copy", e);
     }
-    plan->info[TILESPMV_INFO_DESC_BYTES] = S.cb_bits > 0 ? 4 : pooled ? 20 : 12;
+    plan->info[TILESPMV_INFO_DESC_BYTES] = desc_bytes();
     // the value pass (as in host mode: k_pair_values), its source already on the device
     rc |= plan->reserve((size_t)NUP * 16, &S.uval);
     if (rc == 0) {
@@ -761,7 +784,7 @@ void StreamBuilder::encode_device()
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) fail("value pass", e);
     }
-    for (void *q : {(void *)d_map, (void *)d_packed, (void *)d_udesc, (void *)d_urow, (void *)d_uval}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)d_map, (void *)d_packed, (void *)d_prow, (void *)d_udesc, (void *)d_urow, (void *)d_uval}) if (q) (void)hipFree(q);
     d_udesc = nullptr; d_urow = nullptr; d_uval = nullptr;
     S.udesc_cb = S.udesc; S.wg_win = nullptr; S.win_cb = nullptr;
     plan->info[TILESPMV_INFO_UPLOAD_US] += (long long)(now_us() - t0);
@@ -817,6 +840,14 @@ void StreamBuilder::encode()
                 if (n > 0) { k.unit_begin = (int)nb; k.unit_end = (int)(nb + n); }
             }
         });
+        if (pooled && getenv("TILESPMV_POOL_PATTERN_STAT")) {   // (study: how many distinct (column nibbles, row nibbles) patterns do the pooled units of this shard use?)
+            std::unordered_map<std::string, long long> cnt;
+            for (long long u = 0; u < NUP; u++) { unsigned w[4] = {packed[(size_t)u].n0, packed[(size_t)u].n1, packed_row[(size_t)u].r0, packed_row[(size_t)u].r1}; cnt[std::string((const char *)w, 16)]++; }
+            std::vector<long long> c; for (auto &kv : cnt) c.push_back(kv.second);
+            std::sort(c.begin(), c.end(), std::greater<long long>());
+            long long top1k = 0, top4k = 0, top64k = 0; for (size_t i = 0; i < c.size(); i++) { if (i < 1024) top1k += c[i]; if (i < 4096) top4k += c[i]; if (i < 65536) top64k += c[i]; }
+            fprintf(stderr, "tilespmv: pooled units: %lld units, %zu distinct 16-byte patterns; the 1,024 / 4,096 / 65,536 most frequent cover %.1f / %.1f / %.1f %% of the units\n", NUP, c.size(), 100.0 * top1k / std::max(1LL, NUP), 100.0 * top4k / std::max(1LL, NUP), 100.0 * top64k / std::max(1LL, NUP));
+        }
         // ---- 4-B descriptors where the units of the shard use few distinct column patterns (stencil-like shards: 4 patterns in the
         // 5- and 7-point grids, 36 in the KKT stand-in): column block | pattern id << cb_bits | flags << 27, the patterns (the
         // two nibble words) in a dictionary the kernels gather from.  Not for x-window plans (their descriptors hold slots).
@@ -864,13 +895,58 @@ void StreamBuilder::encode()
                 }
             }
         }
-        if (S.cb_bits > 0) {
+        // ---- pooled plans: 8-B descriptors (word 0, pattern id) + a dictionary of 16-byte patterns (the unit's 16 column nibbles and 16 row nibbles) where the shard's units use at most
+        // 2^DICT_MAX_BITS distinct ones — natural-order meshes use a few dozen (27-point hex mesh x 3 unknowns: 54; tetrahedral: 31), window-shuffled ones a hundred thousand and keep
+        // the 20-byte form.  12 of 148 bytes per unit: always worth it where it applies (desc_dict = 0 switches it off).  Patterns in ascending (n0, n1, r0, r1) order.
+        S.pdict = nullptr; pool_dict = false;
+        std::vector<uint4> pdict;
+        std::vector<uint2> compact2;
+        if (pooled && K.desc_dict != 0 && NUP > 0) {
+            typedef std::array<unsigned, 4> Pat;
+            const size_t cap = (size_t)1 << DICT_MAX_BITS;
+            std::vector<std::set<Pat>> local((size_t)host_threads());
+            std::atomic<int> over(0);
+            parallel_chunks((int64_t)NUP, 1 << 16, [&](int64_t b, int64_t e, int th) {
+                if (over.load(std::memory_order_relaxed)) return;
+                std::set<Pat> &L = local[(size_t)th];
+                Pat last{{~0u, ~0u, ~0u, ~0u}};
+                for (int64_t u = b; u < e; u++) {
+                    const Pat q{{packed[(size_t)u].n0, packed[(size_t)u].n1, packed_row[(size_t)u].r0, packed_row[(size_t)u].r1}};
+                    if (q == last) continue;
+                    last = q;
+                    L.insert(q);
+                    if (L.size() > cap) { over.store(1); return; }
+                }
+            });
+            std::vector<Pat> all;
+            if (!over.load()) {
+                for (auto &L : local) all.insert(all.end(), L.begin(), L.end());
+                std::sort(all.begin(), all.end());
+                all.erase(std::unique(all.begin(), all.end()), all.end());
+            }
+            if (!over.load() && all.size() <= cap) {
+                pdict.resize(all.size());
+                for (size_t i = 0; i < all.size(); i++) pdict[i] = make_uint4(all[i][0], all[i][1], all[i][2], all[i][3]);
+                compact2.resize((size_t)NUP);
+                parallel_chunks((int64_t)NUP, 1 << 16, [&](int64_t b, int64_t e, int) {
+                    for (int64_t u = b; u < e; u++) {
+                        const Pat q{{packed[(size_t)u].n0, packed[(size_t)u].n1, packed_row[(size_t)u].r0, packed_row[(size_t)u].r1}};
+                        compact2[(size_t)u] = make_uint2(packed[(size_t)u].w0, (unsigned)(std::lower_bound(all.begin(), all.end(), q) - all.begin()));
+                    }
+                });
+                pool_dict = true;
+            }
+        }
+        S.urow = nullptr; S.pooled = pooled ? 1 : 0;
+        if (pool_dict) {
+            rc |= plan->upload(compact2.data(), compact2.size(), reinterpret_cast<const uint2 **>(&S.udesc));
+            rc |= plan->upload(pdict.data(), pdict.size(), &S.pdict);
+        } else if (S.cb_bits > 0) {
             rc |= plan->upload(compact.data(), compact.size(), reinterpret_cast<const unsigned **>(&S.udesc));
             rc |= plan->upload(dict.data(), dict.size(), &S.udict);
         } else rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc);
-        plan->info[TILESPMV_INFO_DESC_BYTES] = S.cb_bits > 0 ? 4 : pooled ? 20 : 12;
-        S.urow = nullptr; S.pooled = pooled ? 1 : 0;
-        if (pooled) rc |= plan->upload(packed_row.data(), (size_t)NUP, &S.urow);
+        plan->info[TILESPMV_INFO_DESC_BYTES] = desc_bytes();
+        if (pooled && !pool_dict) rc |= plan->upload(packed_row.data(), (size_t)NUP, &S.urow);
         if (on_device) {
             // emitted values as they are -> a scratch buffer on the device; one workgroup per task writes them to their final place in the plan's arena
             const double t0 = now_us();
@@ -913,7 +989,7 @@ void StreamBuilder::encode()
             rc |= plan->upload(h_win_cb.data(), h_win_cb.size(), &S.win_cb);
         } else { S.wg_win = nullptr; S.win_cb = nullptr; }
     }
-    if (hashing()) { Hash h; h.num((long long)(plan->digest ^ d0)); h.num(NUP); h.num(S.cb_bits); h.num(S.pooled); stage_done(TILESPMV_STAGE_ENCODE, h); }   // (everything this stage produces is uploaded: the running upload digest covers it)
+    if (hashing()) { Hash h; h.num((long long)(plan->digest ^ d0)); h.num(NUP); h.num(S.cb_bits); h.num(S.pooled); if (pool_dict) h.num(8); stage_done(TILESPMV_STAGE_ENCODE, h); }   // (everything this stage produces is uploaded: the running upload digest covers it)
 }
 
 void StreamBuilder::entries()
@@ -1110,7 +1186,7 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     // 7-pt 256^3 0.2533 -> 0.2432, power-law 8 M 0.1078 -> 0.1043 — plain where it is a few per cent: there the streaming form buys nothing and makes the time
     // depend on where the CALLER's y happens to sit (nlpkkt160 stand-in fp64: 0.413 or 0.459 ms by the copy of y; plain: 0.408-0.411 with every copy)
     {
-        const long long stream_b = NU * ((S.cb_bits > 0 ? 4 : pooled ? 20 : 12) + 16LL * sv) + NC * (sv + 4LL), y_b = 16LL * ntr * sv;
+        const long long stream_b = NU * (desc_bytes() + 16LL * sv) + NC * (sv + 4LL), y_b = 16LL * ntr * sv;
         S.y_streaming = K.y_store >= 0 ? (K.y_store != 0) : (y_b * 20 >= stream_b);   // >= 5 %
     }
     plan->info[TILESPMV_INFO_ENTRY_MODE] = entry_mode;
@@ -1129,7 +1205,7 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     }
     plan->mv_by_columns = entry_dominated && target >= 800;   // (small strips hold few entries each: scircuit-like 18 / 22 / 32 us native against 22 / 41 / 78 us)
     n_tasks = (long long)tasks.size();
-    model_bytes = NUP * ((S.cb_bits > 0 ? 4 : pooled ? 20 : 12) + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
+    model_bytes = NUP * (desc_bytes() + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
                   ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
     // The once-read streams (values, entry records) are loaded nontemporally when the launch moves clearly more than the Infinity Cache holds: they then do
