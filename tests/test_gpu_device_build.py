@@ -78,7 +78,8 @@ def test_device_tile_create_large_classes():
 
 KNOB_SETS = [dict(), dict(deterministic=1), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2), dict(csr_split=1), dict(csr_split=2), dict(csr_split=2, entry_mode=2),
              dict(dense_mode=1), dict(dense_mode=2), dict(strip_cost=64, split_above=200), dict(csr_split=2, strip_cost=64, split_above=128, dense_mode=1), dict(x_window=2), dict(desc_dict=0),
-             dict(desc_dict=1), dict(x_panel_kb=1, x_panel_merge=1, entry_mode=2), dict(wg_strips=32, entry_mode=2)]
+             dict(desc_dict=1), dict(x_panel_kb=1, x_panel_merge=1, entry_mode=2), dict(wg_strips=32, entry_mode=2), dict(csr_split=3), dict(csr_split=3, entry_mode=2),
+             dict(csr_split=3, strip_cost=64, split_above=128, dense_mode=1), dict(csr_split=2, desc_dict=0)]
 FACTS = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel", "num_tasks", "num_split_rows", "entry_mode", "entry_ordered", "strip_cost", "wg_strips", "brick_order",
          "desc_bytes", "nt_stream", "x_panels", "scattered_entries", "csr_form"]
 
@@ -140,7 +141,7 @@ def test_device_built_plan_equals_host_built_plan(torch_cuda, name):
 def test_device_built_plan_classes_and_shards(torch_cuda):
     """FEM (pooled units), 3-D stencil and KKT (brick order, dictionary), power-law (workgroup entry lists, split rows), band (dense tiles on the matrix cores), R-MAT;
     whole matrix and a shard of tile-rows, fp64 and fp32."""
-    mats = {"fem3": G.fem_hex(14, 14, 14, 3), "fem6s": G.fem_hex(10, 10, 10, 6, shuffle=16), "lap3d": G.laplacian7pt(48), "kkt24": G.kkt_like(24), "powerlaw": G.powerlaw(300000),
+    mats = {"fem3": G.fem_hex(14, 14, 14, 3), "fem6s": G.fem_hex(10, 10, 10, 6, shuffle=16), "fem3s64": G.fem_hex(16, 16, 16, 3, shuffle=64), "circuit": G.circuit_like(120000), "lap3d": G.laplacian7pt(48), "kkt24": G.kkt_like(24), "powerlaw": G.powerlaw(300000),
             "band40": G.band(60000, 40), "rmat16": G.rmat(16, 8, 3), "lap2d": G.laplacian5pt(500)}
     for name, (rows, cols, rp, ci) in mats.items():
         rows = cases.truncated_rows(rows)

@@ -1120,6 +1120,10 @@ def test_pooled_units_bit_exact(torch_cuda, dtype):
             y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, csr_split=2, **kw)
             assert info["csr_form"] == 2 and info["desc_bytes"] in ((20,) if kw.get("desc_dict") == 0 else (8, 20)), (name, kw)   # (8: the shard's units use few enough patterns for the dictionary)
             assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
+            # wide pooled units (windows of 256 columns, one byte of column offset per slot): the same bar
+            y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, csr_split=3, **kw)
+            assert info["csr_form"] == 3 and info["desc_bytes"] == 28, (name, kw)
+            assert np.array_equal(y, want), (name, "wide", kw, int(np.count_nonzero(y != want)))
         # tile-row shards of a pooled plan write their own rows only
         tilem = rowA // 16
         if tilem >= 4:
@@ -1131,12 +1135,19 @@ def test_pooled_units_bit_exact(torch_cuda, dtype):
                 p.close()
             got = yd.cpu().numpy()
             assert np.array_equal(got[:rowA], want) and (got[rowA:] == -7.0).all(), (name, "shards")
+            yd.fill_(-7.0)
+            for a, b in zip(cuts[:-1], cuts[1:]):   # ... and of a wide pooled plan
+                p = api.Plan(tp, rowA, n, nnz, csr_split=3, tilerow_begin=a, tilerow_end=b)
+                p.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()
+                p.close()
+            got = yd.cpu().numpy()
+            assert np.array_equal(got[:rowA], want) and (got[rowA:] == -7.0).all(), (name, "wide shards")
         # SpMM: pooled plans have a multi-vector kernel of their own (k_pool_mv: the slab holds [tile-row][vector][row] sums); every nvec, with split rows and tiny strips, with the
         # dense tiles on the matrix cores (k_dense_mfma_mv adds into Y afterwards), and one right-hand side at a time (mv_native = 0) as the cross-check
         X = (np.arange(n * 8, dtype=np.int64) % 5).astype(dtype).reshape(n, 8)
         wcols = [O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=hyb), rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"] for j in range(8)]
-        for kw in (dict(), dict(strip_cost=64, split_above=200), dict(dense_mode=api.DENSE_MFMA, entry_mode=2), dict(mv_native=0)):
-            plan = api.Plan(tp, rowA, n, nnz, csr_split=2, **kw)
+        for kw in (dict(), dict(strip_cost=64, split_above=200), dict(dense_mode=api.DENSE_MFMA, entry_mode=2), dict(mv_native=0), dict(csr_split=3), dict(csr_split=3, strip_cost=64, split_above=200)):   # (wide pooled plans: one right-hand side at a time)
+            plan = api.Plan(tp, rowA, n, nnz, **dict(dict(csr_split=2), **kw))
             for nv in (2, 4, 8):
                 Xd = torch_cuda.from_numpy(np.ascontiguousarray(X[:, :nv])).cuda(); Yd = torch_cuda.full((rowA + 16, nv), -4.0, dtype=Xd.dtype, device="cuda")
                 plan.spmm(Xd.data_ptr(), Yd.data_ptr(), nv); torch_cuda.cuda.synchronize()
@@ -1151,9 +1162,9 @@ def test_pooled_units_bit_exact(torch_cuda, dtype):
         tr = api.Tile_create(rowA, n, nnz, rp, ci, vr, dtype=dtype, hyb=hyb)
         wr = O.csr_spmv(rowA, rp, ci, vr, xr).astype(np.float64)
         bound = TOL[np.dtype(dtype)] * _abs_bound(rowA, rp, ci, vr, xr) + 1e-300
-        for kw in (dict(), dict(entry_mode=2, entry_ordered=1)):
-            y1, _ = _gpu_y(torch_cuda, tr, rowA, n, nnz, xr, csr_split=2, **kw)
-            y2, _ = _gpu_y(torch_cuda, tr, rowA, n, nnz, xr, csr_split=2, **kw)
+        for kw in (dict(), dict(entry_mode=2, entry_ordered=1), dict(csr_split=3), dict(csr_split=3, entry_mode=2, entry_ordered=1)):
+            y1, _ = _gpu_y(torch_cuda, tr, rowA, n, nnz, xr, **dict(dict(csr_split=2), **kw))
+            y2, _ = _gpu_y(torch_cuda, tr, rowA, n, nnz, xr, **dict(dict(csr_split=2), **kw))
             assert np.all(np.abs(y1.astype(np.float64) - wr) <= bound), (name, kw)
             assert np.array_equal(y1, y2), (name, kw, "two plans, two launches: different bits")
         api.Tile_destroy(tr)

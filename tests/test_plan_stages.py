@@ -189,6 +189,23 @@ def test_pooled_units_are_chosen_by_the_byte_model_and_are_a_layout_of_their_own
         api.Tile_destroy(tm)
 
 
+def test_wide_windows_are_taken_where_their_gathers_stay_on_few_lines():
+    """Round 5 (second half): wide pooled units (csr_form 3: windows of 256 columns, a byte of column offset per slot).  Counted beside the 16-column form and taken where they move at
+    least 4 % of the nonzeros off the entry lists while a unit's gathers touch at most POOL_WIDE_MAX_LINES lines of x on average: window-shuffled FEM meshes yes, natural-order meshes no
+    (their 16-column windows are full and have the pattern dictionary), a mesh shuffled over thousands of nodes no (every slot on a line of its own)."""
+    for gen, want in ((G.fem_hex(16, 16, 16, 3, shuffle=64), 3), (G.fem_hex(12, 12, 12, 6, shuffle=64), 3), (G.fem_hex(12, 12, 12, 3), 2), (G.tet_mesh(30, shuffle=512), 1), (G.laplacian7pt(40), 1)):
+        tm, rows, n, nnz = _tm(gen)
+        st, i = api.plan_layout_stages(tm, rows, n, nnz)
+        assert i["csr_form"] == want, (rows, nnz, i["csr_form"], want)
+        if want == 3:
+            assert i["desc_bytes"] == 28
+            forced, i2 = api.plan_layout_stages(tm, rows, n, nnz, csr_split=3)
+            assert forced == st
+            p16, i16 = api.plan_layout_stages(tm, rows, n, nnz, csr_split=2)
+            assert i["stream_bytes"] <= 1.03 * i16["stream_bytes"]
+        api.Tile_destroy(tm)
+
+
 def test_pooled_plans_keep_every_nonzero_once(mats):
     """The pooled form re-distributes nonzeros between units and list entries; whatever the knobs, units x 16 + list entries must cover the stored nonzeros (the GPU suite checks the values)."""
     tm, rows, n, nnz = mats["allfmt"]

@@ -637,8 +637,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
 // so a lane no longer owns a row: it gathers x[base + its column nibble] and adds its product to the strip's slab of s_y with ds_add (destination = tile-row in strip, its row
 // nibble); there is no register accumulator, no end-of-row handling and no "rows without units": the slab is zeroed up front, entries and units add into it, y is stored from it.
 // The row nibbles travel like the descriptors (8 bytes per unit, one coalesced lane load per chunk of 16 units, parked in LDS: + 2 KB per workgroup -> 7 workgroups per CU).
-template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD, bool NTS, bool PACE = false, bool POOL = false>
-__global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_ECOO2_MIN_WAVES : ECOO2_MIN_WAVES) : POOL ? POOL_MIN_WAVES : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+// WIDE (with POOL; hip_plan.h "wide pooled units", csr_form 3): windows of 256 columns — a slot's column offset is a byte (16 bytes per unit in S.ucol, parked in s_c), the descriptor's nibble words hold the ROW nibbles.
+template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD, bool NTS, bool PACE = false, bool POOL = false, bool WIDE = false>
+__global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_ECOO2_MIN_WAVES : ECOO2_MIN_WAVES) : POOL ? (WIDE ? 6 : POOL_MIN_WAVES) : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
@@ -648,6 +649,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     static_assert(!(NTS && (XWIN || ECOO == 1)), "nontemporal streams: large plans only (entry mode 1 = small grids; x windows are an opt-in experiment)");
     static_assert(!PACE || (ECOO == 2 && GPB == 16 && !XWIN), "slab pacing: workgroup entry mode, 256-thread workgroups, no x windows");
     static_assert(!POOL || (GPB == 16 && !XWIN && !PACE), "pooled plans: 256-thread workgroups, no x windows, no pacing");
+    static_assert(!WIDE || (POOL && !CD), "wide windows: pooled plans, 12-B descriptors + 16 B of column offsets");
     constexpr int GROUPS_PER_BLOCK = GPB;
     constexpr int SROWS = XWIN ? XWIN_STRIP_ROWS : POOL ? POOL_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
     constexpr bool NT = NTS;  // nontemporal value loads
@@ -668,7 +670,8 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     lacc_t (*s_y)[SROWS][16] = reinterpret_cast<lacc_t (*)[SROWS][16]>(&s_yall[0]);
     lacc_t *s_y1 = &s_yall[PCOPY ? SLAB + 16 : 0];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
-    __shared__ uint2 s_r[POOL ? GROUPS_PER_BLOCK : 1][POOL ? DCHUNK : 1];   // pooled plans: row nibbles of the parked descriptor chunk
+    __shared__ uint2 s_r[POOL && !WIDE ? GROUPS_PER_BLOCK : 1][POOL && !WIDE ? DCHUNK : 1];   // pooled plans: row nibbles of the parked descriptor chunk
+    __shared__ uint4 s_c[WIDE ? GROUPS_PER_BLOCK : 1][WIDE ? DCHUNK : 1];                   // wide pooled plans: column-offset bytes of the parked chunk
     val_t *s_xw = reinterpret_cast<val_t *>(s_dyn);   // [window slot][16]
     TSPMV_DIAG_UNITS_LDS_PAD
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
@@ -724,6 +727,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
     uint2 rcur = make_uint2(0u, 0u), rnext = rcur;   // POOL: row nibbles of the chunks in dcur / dnext
     const uint2 *__restrict__ urw = reinterpret_cast<const uint2 *>(S.urow);
+    uint4 ccur = make_uint4(0u, 0u, 0u, 0u), cnext = ccur;   // WIDE: column-offset bytes of the chunks in dcur / dnext
     unsigned wnn = 0;   // CD: descriptor word of the chunk after `dnext`
     const unsigned *__restrict__ udw = reinterpret_cast<const unsigned *>(S.udesc);
     // POOL + CD (pooled dictionary plans, round 5): a unit's descriptor in HBM is 8 bytes — word 0 (window base | tile-row in strip) and the id of its 16-byte pattern (the 16 column
@@ -743,7 +747,8 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             } else {
                 dcur = load_udesc_raw(S.udesc, min(unit_begin + r, last));
                 dnext = load_udesc_raw(S.udesc, min(unit_begin + DCHUNK + r, last));
-                if constexpr (POOL) { rcur = urw[min(unit_begin + r, last)]; rnext = urw[min(unit_begin + DCHUNK + r, last)]; }   // (12-byte descriptors + 8 bytes of row nibbles)
+                if constexpr (WIDE) { ccur = S.ucol[min(unit_begin + r, last)]; cnext = S.ucol[min(unit_begin + DCHUNK + r, last)]; }
+                else if constexpr (POOL) { rcur = urw[min(unit_begin + r, last)]; rnext = urw[min(unit_begin + DCHUNK + r, last)]; }   // (12-byte descriptors + 8 bytes of row nibbles)
             }
 #pragma unroll
             for (int k = 0; k < UB; k += G) {
@@ -759,7 +764,8 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     uint2 d[UB];
     unsigned rw[UB];   // POOL: this lane's half of the unit's row nibbles
     val_t xv[UB];
-    const unsigned *sr = reinterpret_cast<const unsigned *>(&s_r[POOL ? g : 0][0]) + (r >> 3);
+    const unsigned *sr = reinterpret_cast<const unsigned *>(&s_r[POOL && !WIDE ? g : 0][0]) + (r >> 3);
+    const unsigned char *sc = reinterpret_cast<const unsigned char *>(&s_c[WIDE ? g : 0][0]) + r;   // this lane's byte of a unit's 16 column offsets
     auto park_first = [&]() {   // chunk 0 into LDS (CD: the patterns of chunks 0 and 1 are gathered here, the word of chunk 2 loaded)
         if constexpr (CD && POOL) {
             const uint4 p0 = S.pdict[dcur.y], p1 = S.pdict[dnext.y];
@@ -772,11 +778,19 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             dnext.y = p1.x; dnext.w = p1.y;
             s_d[g][r] = udesc_expand(S, dcur.x, p0);
         } else s_d[g][r] = udesc_park_form(dcur);
-        if constexpr (POOL && !CD) s_r[g][r] = rcur;
+        if constexpr (WIDE) s_c[g][r] = ccur;
+        else if constexpr (POOL && !CD) s_r[g][r] = rcur;
     };
     auto fetch_batch = [&](int j0) {
 #pragma unroll
         for (int k = 0; k < UB; k++) d[k] = sd[2 * (j0 + k)];
+        if constexpr (WIDE) {   // the descriptor's nibble half = this lane's row nibbles; the column offset is its byte of the unit's 16
+#pragma unroll
+            for (int k = 0; k < UB; k++) rw[k] = d[k].y;
+#pragma unroll
+            for (int k = 0; k < UB; k++) xv[k] = x[min((long long)(d[k].x & POOL_BASE_MASK) + (long long)sc[16 * (j0 + k)], xlast)];
+            return;
+        }
         if constexpr (POOL) {
 #pragma unroll
             for (int k = 0; k < UB; k++) rw[k] = sr[2 * (j0 + k)];
@@ -964,7 +978,8 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
                 if constexpr (CD && POOL) { s_d[g][r] = make_uint4(dnext.x, dnext.y, dnext.x, dnext.w); s_r[g][r] = rnext; }
                 else if constexpr (CD) s_d[g][r] = udesc_expand(S, dnext.x, make_uint2(dnext.y, dnext.w));
                 else s_d[g][r] = udesc_park_form(dnext);
-                if constexpr (POOL && !CD) { s_r[g][r] = rnext; rnext = urw[min(chunk_end + DCHUNK + r, last)]; }
+                if constexpr (WIDE) { s_c[g][r] = cnext; cnext = S.ucol[min(chunk_end + DCHUNK + r, last)]; }
+                else if constexpr (POOL && !CD) { s_r[g][r] = rnext; rnext = urw[min(chunk_end + DCHUNK + r, last)]; }
                 wave_lds_fence();
                 chunk_end += DCHUNK;
                 if constexpr (CD && POOL) {
@@ -2086,8 +2101,8 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
 #define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L4(X, 2, 16, true, false, false); else if (xwin_lds_bytes > 0) TSPMV_L4(X, 0, 16, true, false, false); \
         else if (entry_mode == 2 && wg_strips == 32) TSPMV_L2(X, 2, 32); else if (entry_mode == 2) TSPMV_L2(X, 2, 16); \
         else if (entry_mode == 1) { if (S.cb_bits > 0) TSPMV_L4(X, 1, 16, false, true, false); else TSPMV_L4(X, 1, 16, false, false, false); } else TSPMV_L2(X, 0, 16); } while (0)
-#define TSPMV_LPD(X, W, NTS, PD) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, 16, false, PD, NTS, false, true>), dim3((unsigned)((S.ntasks + 15) / 16)), dim3(256), (size_t)lds_pad_bytes, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
-#define TSPMV_LP(X, W, NTS) do { if (S.pdict) TSPMV_LPD(X, W, NTS, true); else TSPMV_LPD(X, W, NTS, false); } while (0)
+#define TSPMV_LPD(X, W, NTS, PD, WD) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, 16, false, PD, NTS, false, true, WD>), dim3((unsigned)((S.ntasks + 15) / 16)), dim3(256), (size_t)lds_pad_bytes, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_LP(X, W, NTS) do { if (S.ucol) TSPMV_LPD(X, W, NTS, false, true); else if (S.pdict) TSPMV_LPD(X, W, NTS, true, false); else TSPMV_LPD(X, W, NTS, false, false); } while (0)
 #define TSPMV_LP1(X) do { if (entry_mode == 1) TSPMV_LP(X, 1, false); else if (entry_mode == 2) { if (S.nt_stream) TSPMV_LP(X, 2, true); else TSPMV_LP(X, 2, false); } \
         else { if (S.nt_stream) TSPMV_LP(X, 0, true); else TSPMV_LP(X, 0, false); } } while (0)
         if (S.pooled) { if (xcd_remap == 2) TSPMV_LP1(2); else TSPMV_LP1(0); }

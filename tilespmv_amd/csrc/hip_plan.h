@@ -121,6 +121,12 @@ constexpr unsigned POOL_BASE_MASK = (1u << POOL_KR_SHIFT) - 1u;
 constexpr int POOL_MIN_FILL = sizeof(val_t) == 8 ? 12 : 10;   // 16 s_v + 20 bytes per unit against s_v + 5 (4 in the packed lists) per list entry
 constexpr int POOL_STRIP_ROWS = 4;        // tile-rows per strip of a pooled plan (their tile-rows are heavy; the slab of s_y is half the size: 14.5 KB of LDS per workgroup)
 struct URow { unsigned r0, r1; };         // row nibbles of slots 0-7 / 8-15 (slot 0 in the top nibble)
+// Wide pooled units (round 5, second half; csr_form 3): the same pooling with windows of POOL_WIDE_WINDOW columns — a slot's column offset is a byte instead of a nibble (16 bytes per unit in
+// DevStream::ucol, slot s in byte s; the descriptor's two nibble words then hold the ROW nibbles and there is no urow stream): 28 + 16 s_v bytes per unit.  For shards whose nonzeros are
+// spread inside a few hundred columns around their neighbours — window-shuffled meshes, circuit-like and web-graph-like local parts —, where 16-column windows leave 20-90 % of the nonzeros
+// on the 12-13-byte entry lists and 256-column windows take most of them at 9.75 bytes each.
+constexpr unsigned POOL_WIDE_WINDOW = 256;
+constexpr double POOL_WIDE_MAX_LINES = 3.5;   // wide windows are taken only where a unit's 16 gathers touch at most this many 128-byte lines of x on average (hip_plan_stream.hip count())
 
 struct STask {                            // 32 bytes
     int unit_begin, unit_end;
@@ -135,6 +141,7 @@ struct STask {                            // 32 bytes
 struct DevStream {
     const UDesc *udesc;                   // per unit, 12 B: column block | flags << 24, column nibbles of rows 0-7, of rows 8-15 (dictionary plans: 4-B words, see cb_bits)
     const URow *urow;                     // pooled plans: the row nibbles of every unit (nullptr otherwise, and in pooled dictionary plans)
+    const uint4 *ucol;                    // wide pooled plans (csr_form 3): the column-offset bytes of every unit (nullptr otherwise)
     const uint4 *pdict;                   // pooled dictionary plans: udesc holds 8-byte (word 0, pattern id) pairs, pdict[id] = column nibbles 0-7, 8-15, row nibbles 0-7, 8-15 (nullptr: none)
     int pooled;                           // 1: every unit is a pooled unit (above)
     const val_t *uval;                    // 16 values per unit, stored in groups of UNIT_GROUP units of one task, interleaved per row

@@ -71,14 +71,15 @@ __global__ __launch_bounds__(256) void k_pd_count_tiles(const Tile_matrix T, con
     const TileCount k = tile_count(&T, t, tile_rowlen(tile_bi[t], T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form);
     tu[gid] = k.nunits; tc[gid] = k.ncoo; td[gid] = k.ndense;
 }
-__global__ __launch_bounds__(64) void k_pd_count_pool(const Tile_matrix T, int tr0, int ntr, int rowA, bool coo_in_tile, long long stored0, PoolEnt *__restrict__ pool, int *__restrict__ pool_u, int *__restrict__ pool_c)
+__global__ __launch_bounds__(64) void k_pd_count_pool(const Tile_matrix T, int tr0, int ntr, int rowA, bool coo_in_tile, unsigned width, long long stored0, PoolEnt *__restrict__ pool, int *__restrict__ pool_u, int *__restrict__ pool_c, unsigned long long *__restrict__ stat /* [0] units, [1] lines */)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ntr) return;
     const int bi = tr0 + (int)i;
-    int nu, nc;
-    pool_row_count(&T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, nullptr, pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0), &nu, &nc);
+    int nu, nc, nl;
+    pool_row_count(&T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, nullptr, width, pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0), &nu, &nc, &nl);
     pool_u[i] = nu; pool_c[i] = nc;
+    if (nu) { atomicAdd(&stat[0], (unsigned long long)nu); atomicAdd(&stat[1], (unsigned long long)nl); }
 }
 __global__ __launch_bounds__(256) void k_pd_row_counts(const int *__restrict__ tile_ptr, int tr0, int ntr, int t_begin, const int *__restrict__ tu, const int *__restrict__ tc, const int *__restrict__ td,
                                                          const int *__restrict__ pool_u, const int *__restrict__ pool_c, int *__restrict__ out)
@@ -131,16 +132,16 @@ __global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, cons
     const long long u0 = p.u;
     tile_emit(&T, t, tile_rowlen(bi, T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form, (unsigned)row_k[i], nullptr, O, p);
     // the tile that emits the last unit of an unsplit tile-row of a classic plan marks it (the kernel writes y there)
-    if (csr_form != 2 && !row_split[i] && p.u > u0 && p.u == pu[i + 1]) { O.udesc[p.u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; O.udesc[p.u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
+    if (csr_form < 2 && !row_split[i] && p.u > u0 && p.u == pu[i + 1]) { O.udesc[p.u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; O.udesc[p.u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
 }
-__global__ __launch_bounds__(64) void k_pd_emit_pool(const Tile_matrix T, int tr0, int ntr, int t_begin, int rowA, bool coo_in_tile, long long stored0, PoolEnt *__restrict__ pool, const int *__restrict__ tu,
+__global__ __launch_bounds__(64) void k_pd_emit_pool(const Tile_matrix T, int tr0, int ntr, int t_begin, int rowA, bool coo_in_tile, unsigned width, long long stored0, PoolEnt *__restrict__ pool, const int *__restrict__ tu,
                                                        const int *__restrict__ tc, const int *__restrict__ pu, const int *__restrict__ pc, const unsigned char *__restrict__ row_k, const EmitOut O)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ntr) return;
     const int bi = tr0 + (int)i, a = T.tile_ptr[bi] - t_begin, b = T.tile_ptr[bi + 1] - t_begin;
     EmitPos p{(long long)pu[i] + tu[b] - tu[a], (long long)pc[i] + tc[b] - tc[a], 0};   // behind what the tile-row's tiles emitted themselves
-    pool_row_emit(&T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, (unsigned)row_k[i], nullptr, pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0), O, p);
+    pool_row_emit(&T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, (unsigned)row_k[i], nullptr, width, pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0), O, p);
 }
 __global__ __launch_bounds__(256) void k_pd_word0(const uint4 *__restrict__ udesc, long long n, unsigned *__restrict__ out)
 {
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(256) void k_pd_word0(const uint4 *__restrict__ udes
 }
 
 // ---- ENCODE
-__global__ __launch_bounds__(256) void k_pd_pack_desc(const uint4 *__restrict__ udesc, const uint2 *__restrict__ urow, const int4 *__restrict__ map, int ntasks, UDesc *__restrict__ packed, URow *__restrict__ packed_row)
+__global__ __launch_bounds__(256) void k_pd_pack_desc(const uint4 *__restrict__ udesc, const uint2 *__restrict__ urow, const uint4 *__restrict__ ucol, const int4 *__restrict__ map, int ntasks, UDesc *__restrict__ packed,
+                                                        URow *__restrict__ packed_row, uint4 *__restrict__ packed_col)
 {
     for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {
         const int4 m = map[t];
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(256) void k_pd_pack_desc(const uint4 *__restrict__ 
             const uint4 d = udesc[(long long)m.x + j];
             packed[(long long)m.y + j] = UDesc{d.x, d.y, d.w};
             if (urow) { const uint2 r = urow[(long long)m.x + j]; packed_row[(long long)m.y + j] = URow{r.x, r.y}; }
+            if (ucol) packed_col[(long long)m.y + j] = ucol[(long long)m.x + j];
         }
     }
 }
@@ -385,7 +388,7 @@ int dev_fetch_ints(const int *d_array, const long long *idx, int n, int *out)
     return 0;
 }
 
-int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &nunits, std::vector<int> &ncoo, std::vector<int> &ndense)
+int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &nunits, std::vector<int> &ncoo, std::vector<int> &ndense, long long *pool_units, long long *pool_lines)
 {
     const DevTile *D = S.D;
     const int nt = S.t_end - S.t_begin, ntr = S.tr1 - S.tr0;
@@ -398,7 +401,7 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &n
     // one allocation for the three per-tile prefix arrays (and the pooled counts): tu | tc | td | pool_u | pool_c
     const size_t per = ((size_t)nt + 1 + 63) / 64 * 64, perr = ((size_t)std::max(ntr, 1) + 63) / 64 * 64;
     int *blockp = nullptr;
-    const size_t ints = 3 * per + (csr_form == 2 ? 2 * perr : 0) + 16;
+    const size_t ints = 3 * per + (csr_form >= 2 ? 2 * perr : 0) + 16;
     PD_TRY(hipMalloc((void **)&blockp, ints * sizeof(int)));
     C->tu = blockp; C->tc = blockp + per; C->td = blockp + 2 * per;
     PD_TRY(hipMemsetAsync(blockp, 0, ints * sizeof(int), 0));
@@ -415,11 +418,17 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &n
         PD_TRY(e);
     }
     const double ms_tiles = lap_ms();
-    if (csr_form == 2 && ntr > 0) {
+    if (csr_form >= 2 && ntr > 0) {
         C->pool_u = blockp + 3 * per; C->pool_c = blockp + 3 * per + perr;
         PD_TRY(hipMalloc((void **)&C->pool, (size_t)std::max<long long>(1, S.stored) * sizeof(PoolEnt) + 16));
-        hipLaunchKernelGGL(k_pd_count_pool, dim3(nblk(ntr, 64)), dim3(64), 0, 0, D->T, S.tr0, ntr, D->rowA, S.coo_in_tile, S.stored0, C->pool, C->pool_u, C->pool_c);
+        Tmp<unsigned long long> d_stat;
+        PD_TRY(d_stat.alloc(2, true));
+        hipLaunchKernelGGL(k_pd_count_pool, dim3(nblk(ntr, 64)), dim3(64), 0, 0, D->T, S.tr0, ntr, D->rowA, S.coo_in_tile, csr_form == 3 ? POOL_WIDE_WINDOW : 16u, S.stored0, C->pool, C->pool_u, C->pool_c, d_stat.p);
         PD_TRY(hipGetLastError());
+        unsigned long long h_stat[2] = {0, 0};
+        PD_TRY(hipMemcpy(h_stat, d_stat.p, sizeof(h_stat), hipMemcpyDeviceToHost));
+        if (pool_units) *pool_units += (long long)h_stat[0];
+        if (pool_lines) *pool_lines += (long long)h_stat[1];
     }
     if (ntr > 0) {
         Tmp<int> d_out;
@@ -468,8 +477,8 @@ int dev_emit(const DevShard &S, const DevCounts &C, const std::vector<long long>
                            (const int *)C.tc, (const int *)C.td, (const int *)d_pu.p, (const int *)d_pc.p, (const int *)d_pd.p, (const unsigned char *)d_rk.p, (const unsigned char *)d_rs.p, O);
         PD_TRY(hipGetLastError());
     }
-    if (C.csr_form == 2) {
-        hipLaunchKernelGGL(k_pd_emit_pool, dim3(nblk(ntr, 64)), dim3(64), 0, 0, D->T, S.tr0, ntr, S.t_begin, D->rowA, S.coo_in_tile, S.stored0, C.pool, (const int *)C.tu, (const int *)C.tc, (const int *)d_pu.p,
+    if (C.csr_form >= 2) {
+        hipLaunchKernelGGL(k_pd_emit_pool, dim3(nblk(ntr, 64)), dim3(64), 0, 0, D->T, S.tr0, ntr, S.t_begin, D->rowA, S.coo_in_tile, C.csr_form == 3 ? POOL_WIDE_WINDOW : 16u, S.stored0, C.pool, (const int *)C.tu, (const int *)C.tc, (const int *)d_pu.p,
                            (const int *)d_pc.p, (const unsigned char *)d_rk.p, O);
         PD_TRY(hipGetLastError());
     }
@@ -489,10 +498,10 @@ int dev_fetch_word0(const uint4 *d_udesc, long long NU, std::vector<unsigned> &w
     return 0;
 }
 
-int dev_pack_desc(const uint4 *d_udesc, const uint2 *d_urow, const int4 *d_map, int ntasks, UDesc *d_packed, URow *d_packed_row)
+int dev_pack_desc(const uint4 *d_udesc, const uint2 *d_urow, const uint4 *d_ucol, const int4 *d_map, int ntasks, UDesc *d_packed, URow *d_packed_row, uint4 *d_packed_col)
 {
     if (ntasks <= 0) return 0;
-    hipLaunchKernelGGL(k_pd_pack_desc, dim3((unsigned)std::min(ntasks, 1 << 20)), dim3(256), 0, 0, d_udesc, d_urow, d_map, ntasks, d_packed, d_packed_row);
+    hipLaunchKernelGGL(k_pd_pack_desc, dim3((unsigned)std::min(ntasks, 1 << 20)), dim3(256), 0, 0, d_udesc, d_urow, d_ucol, d_map, ntasks, d_packed, d_packed_row, d_packed_col);
     PD_TRY(hipGetLastError());
     PD_TRY(hipDeviceSynchronize());
     return 0;

@@ -15,18 +15,19 @@ namespace {
 struct RowCount { int nunits, ncoo, nheavy, ndense; long long hval, hidx; long long cost; };
 
 // One tile-row's counts: the sum of its tiles' (plan_tile_ops.h tile_count) plus, in pooled plans, its pool's windows.  `scratch`: room for the tile-row's stored nonzeros (pooled plans)
-inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, int coo_cost, const long long *hyb_off, std::vector<PoolEnt> &scratch)
+inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, int coo_cost, const long long *hyb_off, std::vector<PoolEnt> &scratch, long long *pool_stat = nullptr)
 {
     RowCount c{0, 0, 0, 0, 0, 0, 0};
     for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
         const TileCount k = tile_count(T, t, rowlen, tilen, colA, coo_in_tile, dense_mfma, csr_form);
         c.nunits += k.nunits; c.ncoo += k.ncoo; c.nheavy += k.nheavy; c.ndense += k.ndense; c.hval += k.hval; c.hidx += k.hidx;
     }
-    if (csr_form == 2) {
+    if (csr_form >= 2) {
         scratch.resize((size_t)std::max<long long>(1, pool_row_capacity(T, bi)));
-        int nu, nc;
-        pool_row_count(T, bi, rowlen, coo_in_tile, hyb_off, scratch.data(), &nu, &nc);
+        int nu, nc, nl;
+        pool_row_count(T, bi, rowlen, coo_in_tile, hyb_off, csr_form == 3 ? POOL_WIDE_WINDOW : 16u, scratch.data(), &nu, &nc, &nl);
         c.nunits += nu; c.ncoo += nc;
+        if (pool_stat) { pool_stat[0] += nu; pool_stat[1] += nl; }
     }
     // heavy tiles are latency-bound (one tile at a time): weigh them so that long lists get split
     c.cost = 16LL * c.nunits + (long long)coo_cost * c.ncoo + c.hval + 256LL * c.nheavy + 64LL * c.ndense + 8;
@@ -92,7 +93,7 @@ struct StreamBuilder {
     const long long *hyb_ptr() const { return hyb_off.empty() ? nullptr : hyb_off.data(); }
     DevShard DS{};
     DevCounts dcnt, dcnt_alt;
-    uint4 *d_udesc = nullptr; uint2 *d_urow = nullptr; val_t *d_uval = nullptr;   // EMIT's unit records (scratch: ENCODE writes their final form into the plan's arena)
+    uint4 *d_udesc = nullptr, *d_ucol = nullptr; uint2 *d_urow = nullptr; val_t *d_uval = nullptr;   // EMIT's unit records (scratch: ENCODE writes their final form into the plan's arena)
     std::vector<unsigned> h_uw0;   // word 0 of every emitted unit (brick order only)
     std::vector<FixRow> &fix; int &npartial;
     DevStream &S;
@@ -101,7 +102,7 @@ struct StreamBuilder {
     const DevTile *DT = nullptr;
     int rc = 0;
     // COUNT
-    bool csr_split = true, pooled = false; int csr_form = 1, target_in = 0, split_above_in = 0, tilem = 0, tilen = 0, ntr = 0, sv = 0;
+    bool csr_split = true, pooled = false, wide = false; int csr_form = 1, target_in = 0, split_above_in = 0, tilem = 0, tilen = 0, ntr = 0, sv = 0;
     std::vector<RowCount> rc_;
     std::vector<long long> pu, pc, ph, phv, phi, pd;
     long long NU = 0, NC = 0, NH = 0, NHV = 0, NHI = 0, ND = 0;
@@ -122,6 +123,7 @@ struct StreamBuilder {
     // EMIT
     std::vector<uint4> h_udesc;
     std::vector<uint2> h_urow;            // pooled plans: row nibbles of every unit
+    std::vector<uint4> h_ucol;            // wide pooled plans: column-offset bytes of every unit
     val_t *h_uval = nullptr, *h_cval = nullptr, *h_hval = nullptr, *h_dval = nullptr;
     unsigned char *h_hidx = nullptr;
     std::vector<int> h_ccol, h_dcb;
@@ -136,13 +138,13 @@ struct StreamBuilder {
     // ENCODE / ENTRIES
     long long NUP = 0, n_rec = 0, n_chunk = 0, n_groups = 0, panel_rmw_rows = 0;
     bool pool_dict = false;   // pooled plan with 8-B descriptors + pattern dictionary
-    long long desc_bytes() const { return S.cb_bits > 0 ? 4 : pooled ? (pool_dict ? 8 : 20) : 12; }
+    long long desc_bytes() const { return S.cb_bits > 0 ? 4 : wide ? 28 : pooled ? (pool_dict ? 8 : 20) : 12; }
     std::vector<long long> old_begin;
 
     StreamBuilder(tilespmv_plan *plan_, const Knobs &K_, const Tile_matrix *T_, int rowA_, int colA_, int tr0_, int tr1_, bool coo_in_tile_, bool dense_mfma_,
                   const std::vector<long long> &hyb_off_, std::vector<FixRow> &fix_, int &npartial_, const DevTile *DT_)
         : plan(plan_), K(K_), T(T_), rowA(rowA_), colA(colA_), tr0(tr0_), tr1(tr1_), coo_in_tile(coo_in_tile_), dense_mfma(dense_mfma_), hyb_off(hyb_off_), fix(fix_), npartial(npartial_), S(plan_->st), DT(DT_) {}
-    ~StreamBuilder() { release(); dcnt.release(); dcnt_alt.release(); for (void *q : {(void *)d_udesc, (void *)d_urow, (void *)d_uval}) if (q) (void)hipFree(q); }
+    ~StreamBuilder() { release(); dcnt.release(); dcnt_alt.release(); for (void *q : {(void *)d_udesc, (void *)d_urow, (void *)d_uval, (void *)d_ucol}) if (q) (void)hipFree(q); }
     // The staging arrays of a GB-sized plan take tens of milliseconds to give back (munmap of 0.7 GB each: 70-80 ms of the 320 ms config 4's plan build took): a detached
     // thread does it while the builder goes on.  Small arrays are freed in place.
     static void free_later(std::vector<void *> ptrs, size_t bytes_hint)
@@ -188,7 +190,7 @@ void StreamBuilder::count()
     // the two forms put into the streams.  Both are counted (a shard without CSR tiles is not: nothing to choose); the pooled form is taken when its streams are at least
     // 5 % smaller than the split form's WITH 4-byte dictionary descriptors (whether the dictionary applies is only known once the units exist: the split form gets the benefit
     // of the doubt, so stencil-like shards with a few CSR tiles — KKT, unaligned grids — keep their 4-byte descriptors).
-    csr_form = K.csr_split < 0 ? 1 : std::min(K.csr_split, 2);
+    csr_form = K.csr_split < 0 ? 1 : std::min(K.csr_split, 3);
     const int t_begin = T->tile_ptr[tr0], t_end = T->tile_ptr[tr1];
     if (DT) {
         DS = DevShard{DT, tr0, tr1, t_begin, t_end, coo_in_tile, dense_mfma, 0, 0};
@@ -196,12 +198,13 @@ void StreamBuilder::count()
         if (dev_fetch_ints(DT->T.blknnz, idx, 2, v) != 0) { rc = -3; return; }
         DS.stored0 = v[0]; DS.stored = (long long)v[1] - v[0];
     }
+    long long pool_units_of[4] = {0, 0, 0, 0}, pool_lines_of[4] = {0, 0, 0, 0};   // per form: units made of pooled windows, 128-byte lines of x their gathers touch
     auto count_all = [&](int form, std::vector<RowCount> &out) {
         out.assign((size_t)ntr, RowCount{0, 0, 0, 0, 0, 0, 0});
         if (DT) {   // one thread per tile (per tile-row for the pooled windows) on the device: the same per-tile functions (plan_tile_ops.h)
             std::vector<int> nu, nc, nd;
             DevCounts &C = form == csr_form ? dcnt : dcnt_alt;
-            if (dev_count(DS, form, &C, nu, nc, nd) != 0) { rc = -3; return; }
+            if (dev_count(DS, form, &C, nu, nc, nd, &pool_units_of[form], &pool_lines_of[form]) != 0) { rc = -3; return; }
             parallel_chunks(ntr, 1 << 16, [&](int64_t b, int64_t e, int) {
                 for (int64_t i = b; i < e; i++) {
                     RowCount c{nu[(size_t)i], nc[(size_t)i], 0, nd[(size_t)i], 0, 0, 0};
@@ -211,9 +214,13 @@ void StreamBuilder::count()
             });
             return;
         }
+        std::mutex stat_mutex;
         parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
             std::vector<PoolEnt> scratch;
-            for (int64_t i = b; i < e; i++) out[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, form, K.coo_cost, hyb_ptr(), scratch);
+            long long st[2] = {0, 0};
+            for (int64_t i = b; i < e; i++) out[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, form, K.coo_cost, hyb_ptr(), scratch, st);
+            std::lock_guard<std::mutex> lk(stat_mutex);
+            pool_units_of[form & 3] += st[0]; pool_lines_of[form & 3] += st[1];
         });
     };
     count_all(csr_form, rc_);
@@ -224,6 +231,7 @@ void StreamBuilder::count()
     // (nor is the second count worth its time where CSR tiles hold less than 3 % of the shard's stored values — the KKT stand-in: under 1 %; the band matrix's 5 % is worth it —: the pooled form pays 8-16 bytes more per
     //  unit on everything else and cannot come out 5 % ahead)
     long long csr_vals, all_vals;
+    long long e16 = -1;   // list entries the 16-column pooled form would leave (-1: not counted)
     if (DT) {
         const long long idx[2] = {t_begin, t_end}; int v[2] = {0, 0};
         if (dev_fetch_ints(DT->T.csr_offset, idx, 2, v) != 0) { rc = -3; return; }
@@ -235,6 +243,7 @@ void StreamBuilder::count()
         if (rc) return;
         long long u1 = 0, e1 = 0, u2 = 0, e2 = 0;
         for (int i = 0; i < ntr; i++) { u1 += rc_[i].nunits; e1 += rc_[i].ncoo; u2 += alt[i].nunits; e2 += alt[i].ncoo; }
+        e16 = e2;
         // would the split form get 4-byte dictionary descriptors?  Its units' column patterns on a sample of tiles (ELL slots exactly; of a CSR tile the pattern of its first
         // unit: the first column nibble of every row): more than the dictionary holds on the sample -> 12-byte descriptors for certain
         int desc_split = 4;
@@ -274,7 +283,31 @@ void StreamBuilder::count()
         if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: CSR tiles: split form (%d-byte descriptors) %lld units + %lld entries = %.1f MB, pooled form %lld units + %lld entries = %.1f MB -> %s\n",
                                                      desc_split, u1, e1, split_b / 1e6, u2, e2, pooled_b / 1e6, csr_form == 2 ? "pooled" : "split");
     }
-    csr_split = csr_form != 0; pooled = csr_form == 2;
+    // ---- wide pooled units (hip_plan.h; csr_form 3): windows of 256 columns take what 16-column windows leave on the entry lists — where the nonzeros are dense enough inside those
+    // windows that a unit's 16 gathers still touch few lines of x (window-shuffled FEM / shell meshes: 1.5-3 lines per unit) it wins 5-20 %; where every slot sits on a line of its own
+    // (tetrahedral / 2-D meshes shuffled over thousands of nodes, web graphs) the column-ordered entry lists of a whole workgroup share lines better and the wide form loses up to 30 %
+    // (profiles/r05_wide_windows.txt).  Counted whenever the 16-column pooled form was, taken by the rule below.
+    if (K.csr_split < 0 && !classic_asked && csr_vals > 0 && csr_vals * 33 >= all_vals) {
+        long long ub = 0, eb = 0;
+        for (int i = 0; i < ntr; i++) { ub += rc_[i].nunits; eb += rc_[i].ncoo; }
+        std::vector<RowCount> alt;
+        count_all(3, alt);
+        if (rc) return;
+        long long u3 = 0, e3 = 0;
+        for (int i = 0; i < ntr; i++) { u3 += alt[i].nunits; e3 += alt[i].ncoo; }
+        const double lines3 = (double)pool_lines_of[3] / (double)std::max(1LL, pool_units_of[3]);
+        const long long xy_b = ((long long)colA + 16LL * ntr) * sv;
+        const long long best_b = ub * ((csr_form == 2 ? 20 : 12) + 16LL * sv) + eb * (sv + 5LL) + xy_b, wide_b = u3 * (28 + 16LL * sv) + e3 * (sv + 5LL) + xy_b;
+        const long long moved = (e16 >= 0 ? std::min(eb, e16) : eb) - e3;   // nonzeros that leave the entry lists — measured against the 16-column windows too, chosen or not (a natural-order mesh whose
+                                                                             // 16-column form narrowly missed its own bar must not get 256-column windows it has no use for)
+        const bool would_panel = (long long)K.coo_cost * e3 * 2 > 16LL * u3 + (long long)K.coo_cost * e3 && (long long)colA * sv >= (12ll << 20);
+        const bool take = lines3 <= POOL_WIDE_MAX_LINES && moved * 25 >= (16 * u3 + e3) && wide_b * 100 <= best_b * 103 && 16 * u3 >= e3 && !would_panel;
+        if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: wide windows: %lld units + %lld entries = %.1f MB (chosen so far: %lld + %lld = %.1f MB), %.2f lines of x per pooled unit, %.1f %% of the nonzeros leave the lists -> %s\n",
+                                                     u3, e3, wide_b / 1e6, ub, eb, best_b / 1e6, lines3, 100.0 * moved / std::max(1LL, 16 * u3 + e3), take ? "wide" : "kept");
+        if (take) { rc_.swap(alt); csr_form = 3; std::swap(dcnt, dcnt_alt); dcnt.csr_form = 3; }
+        dcnt_alt.release();
+    }
+    csr_split = csr_form != 0; pooled = csr_form >= 2; wide = csr_form == 3;
     {   // (six arrays of ntr + 1 prefixes: first touched side by side — a million tile-rows are 50 MB of fresh pages)
         std::vector<long long> *six[6] = {&pu, &pc, &ph, &phv, &phi, &pd};
         parallel_chunks(6, 1, [&](int64_t b, int64_t e, int) { for (int64_t q = b; q < e; q++) six[q]->assign((size_t)ntr + 1, 0); });
@@ -526,7 +559,7 @@ void StreamBuilder::emit()
 {
     if (DT) {
         // device mode: the unit records go to scratch arrays on the device (ENCODE gives them their final form), list entries and dense tiles straight into the plan's arena
-        plan->size_hint = (size_t)(NU * (12 + (pooled ? 8 : 0) + 16LL * sv) + NC * (2LL * sv + 13) + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);
+        plan->size_hint = (size_t)(NU * (12 + (wide ? 16 : pooled ? 8 : 0) + 16LL * sv) + NC * (2LL * sv + 13) + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);
         rc |= plan->reserve((size_t)NC, &S.cval); rc |= plan->reserve((size_t)NC, &S.ccol); rc |= plan->reserve((size_t)NC, &S.crow);
         rc |= plan->reserve((size_t)ND, &plan->dn.cb); rc |= plan->reserve((size_t)ND * 256, &plan->dn.val);
         auto scratch = [&](auto **q, size_t n) {
@@ -536,16 +569,18 @@ void StreamBuilder::emit()
             if (e != hipSuccess) { fprintf(stderr, "tilespmv: device plan build: %zu MB of scratch: %s\n", bytes >> 20, hipGetErrorString(e)); (void)hipGetLastError(); rc = -3; }
         };
         scratch(&d_udesc, (size_t)NU); scratch(&d_uval, (size_t)NU * 16);
-        if (pooled) scratch(&d_urow, (size_t)NU);
+        if (pooled && !wide) scratch(&d_urow, (size_t)NU);
+        if (wide) scratch(&d_ucol, (size_t)NU);
         if (rc) return;
-        const EmitOut O{d_udesc, d_urow, d_uval, const_cast<val_t *>(S.cval), const_cast<int *>(S.ccol), const_cast<unsigned char *>(S.crow), const_cast<int *>(plan->dn.cb), const_cast<val_t *>(plan->dn.val)};
+        const EmitOut O{d_udesc, d_urow, d_uval, d_ucol, const_cast<val_t *>(S.cval), const_cast<int *>(S.ccol), const_cast<unsigned char *>(S.crow), const_cast<int *>(plan->dn.cb), const_cast<val_t *>(plan->dn.val)};
         if (dev_emit(DS, dcnt, pu, pc, pd, row_k, row_split, NU, O) != 0) rc = -3;
         dcnt.release();
         return;
     }
     // ---- fill
     h_udesc.assign((size_t)NU, make_uint4(0u, 0u, 0u, 0u));
-    h_urow.assign(pooled ? (size_t)NU : 0, make_uint2(0x01234567u, 0x89ABCDEFu));   // (units that keep one row per lane: identity)
+    h_urow.assign(pooled && !wide ? (size_t)NU : 0, make_uint2(0x01234567u, 0x89ABCDEFu));   // (units that keep one row per lane: identity)
+    h_ucol.assign(wide ? (size_t)NU : 0, make_uint4(0u, 0u, 0u, 0u));                       // wide pooled plans: column-offset bytes
     h_uval = zalloc<val_t>((size_t)NU * 16);
     h_cval = zalloc<val_t>((size_t)NC);
     h_ccol.assign((size_t)NC, 0);
@@ -555,7 +590,7 @@ void StreamBuilder::emit()
     h_hidx = zalloc<unsigned char>((size_t)NHI + 16);
     h_dcb.assign((size_t)ND, 0);
     h_dval = zalloc<val_t>((size_t)ND * 256);
-    const EmitOut O{h_udesc.data(), h_urow.data(), h_uval, h_cval, h_ccol.data(), h_crow.data(), h_dcb.data(), h_dval};
+    const EmitOut O{h_udesc.data(), h_urow.data(), h_uval, h_ucol.data(), h_cval, h_ccol.data(), h_crow.data(), h_dcb.data(), h_dval};
     parallel_chunks(ntr, 256, [&](int64_t b, int64_t e, int) {
         std::vector<PoolEnt> pool;
         for (int64_t i = b; i < e; i++) {
@@ -574,7 +609,7 @@ void StreamBuilder::emit()
             }
             if (pooled) {   // the pooled nonzeros of the tile-row: windows of 16 columns -> units, sparse windows -> list entries
                 pool.resize((size_t)std::max<long long>(1, pool_row_capacity(T, bi)));
-                pool_row_emit(T, bi, rowlen, coo_in_tile, kr, hyb_ptr(), pool.data(), O, pos);
+                pool_row_emit(T, bi, rowlen, coo_in_tile, kr, hyb_ptr(), wide ? POOL_WIDE_WINDOW : 16u, pool.data(), O, pos);
             }
             if (!pooled && !row_split[i] && pos.u > pu[i]) { h_udesc[(size_t)pos.u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; h_udesc[(size_t)pos.u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
             if (h > ph[i]) h_hdesc[(size_t)h - 1].y |= DESC_EOR;
@@ -582,7 +617,7 @@ void StreamBuilder::emit()
     });
     if (hashing()) {
         Hash h;
-        h.vec(h_udesc); h.vec(h_urow); h.arr(h_uval, (size_t)NU * 16); h.arr(h_cval, (size_t)NC); h.vec(h_ccol); h.vec(h_crow); h.vec(h_hdesc); h.arr(h_hval, (size_t)NHV); h.arr(h_hidx, (size_t)NHI);
+        h.vec(h_udesc); h.vec(h_urow); if (wide) h.vec(h_ucol); h.arr(h_uval, (size_t)NU * 16); h.arr(h_cval, (size_t)NC); h.vec(h_ccol); h.vec(h_crow); h.vec(h_hdesc); h.arr(h_hval, (size_t)NHV); h.arr(h_hidx, (size_t)NHI);
         h.vec(h_dcb); h.arr(h_dval, (size_t)ND * 256);
         stage_done(TILESPMV_STAGE_EMIT, h);
     }
@@ -703,7 +738,7 @@ void StreamBuilder::order()
     } else { xwin = false; brick = false; }
     plan->info[TILESPMV_INFO_BRICK_ORDER] = brick ? 1 : 0;
     plan->xwin_lds_bytes = xwin ? xwin_slots_max * 16 * (int)sizeof(val_t) : 0;
-    plan->size_hint = (size_t)(NU * (12 + (pooled ? 8 : 0) + 16LL * sv) + NC * (2LL * sv + 13) + NHV * sv + NHI + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);   // estimate of the plan's bytes: picks the block size of upload()
+    plan->size_hint = (size_t)(NU * (12 + (wide ? 16 : pooled ? 8 : 0) + 16LL * sv) + NC * (2LL * sv + 13) + NHV * sv + NHI + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);   // estimate of the plan's bytes: picks the block size of upload()
     if (hashing()) { Hash h; h.vec(tasks); h.vec(h_wg_win); h.vec(h_win_cb); h.num(brick); h.num(xwin); stage_done(TILESPMV_STAGE_ORDER, h); }
 }
 
@@ -724,7 +759,7 @@ void StreamBuilder::encode_device()
         if (n > 0) { k.unit_begin = (int)nb; k.unit_end = (int)(nb + n); }
     }
     const double t0 = now_us();
-    S.udict = nullptr; S.cb_bits = 0; S.urow = nullptr; S.pooled = pooled ? 1 : 0; S.pdict = nullptr; pool_dict = false;
+    S.udict = nullptr; S.cb_bits = 0; S.urow = nullptr; S.ucol = nullptr; S.pooled = pooled ? 1 : 0; S.pdict = nullptr; pool_dict = false;
     void *d_map = nullptr; UDesc *d_packed = nullptr; URow *d_prow = nullptr;
     auto fail = [&](const char *what, hipError_t e) { fprintf(stderr, "tilespmv: device plan build: %s: %s\n", what, hipGetErrorString(e)); (void)hipGetLastError(); rc = -3; };
     hipError_t e = hipMalloc(&d_map, std::max<size_t>(pair_map.size(), 1) * sizeof(int4));
@@ -732,13 +767,14 @@ void StreamBuilder::encode_device()
     if (e == hipSuccess) e = hipMalloc((void **)&d_packed, std::max<long long>(NUP, 1) * sizeof(UDesc) + 256);
     if (e == hipSuccess) e = hipMemsetAsync(d_packed, 0, std::max<long long>(NUP, 1) * sizeof(UDesc) + 256, 0);
     if (e != hipSuccess) fail("scratch for the packed descriptors", e);
-    if (pooled && e == hipSuccess) {   // packed row nibbles: scratch (they end up in the plan's arena, or — pooled dictionary plans — in the dictionary)
+    if (wide) rc |= plan->reserve((size_t)NUP, &S.ucol);   // (wide pooled plans: the column-offset bytes are packed straight into the plan's arena)
+    if (pooled && !wide && e == hipSuccess) {   // packed row nibbles: scratch (they end up in the plan's arena, or — pooled dictionary plans — in the dictionary)
         e = hipMalloc((void **)&d_prow, std::max<long long>(NUP, 1) * sizeof(URow) + 256);
         if (e == hipSuccess) e = hipMemsetAsync(d_prow, 0, std::max<long long>(NUP, 1) * sizeof(URow) + 256, 0);
         if (e != hipSuccess) fail("scratch for the packed row nibbles", e);
     }
-    if (rc == 0 && dev_pack_desc(d_udesc, d_urow, (const int4 *)d_map, (int)pair_map.size(), d_packed, d_prow) != 0) rc = -3;
-    if (rc == 0 && pooled && K.desc_dict != 0 && NUP > 0) {   // 8-B descriptors + pattern dictionary (the host builder's rule)
+    if (rc == 0 && dev_pack_desc(d_udesc, d_urow, d_ucol, (const int4 *)d_map, (int)pair_map.size(), d_packed, d_prow, const_cast<uint4 *>(S.ucol)) != 0) rc = -3;
+    if (rc == 0 && pooled && !wide && K.desc_dict != 0 && NUP > 0) {   // 8-B descriptors + pattern dictionary (the host builder's rule)
         std::vector<uint4> pats;
         bool over = false;
         if (dev_pool_dict(d_packed, d_prow, NUP, (size_t)1 << DICT_MAX_BITS, pats, &over) != 0) rc = -3;
@@ -749,7 +785,7 @@ void StreamBuilder::encode_device()
             pool_dict = true;
         }
     }
-    if (rc == 0 && pooled && !pool_dict) {
+    if (rc == 0 && pooled && !wide && !pool_dict) {
         rc |= plan->reserve((size_t)NUP, &S.urow);
         if (rc == 0 && NUP > 0 && (e = hipMemcpy(const_cast<URow *>(S.urow), d_prow, (size_t)NUP * sizeof(URow), hipMemcpyDeviceToDevice)) != hipSuccess) fail("row nibble copy", e);
     }
@@ -784,8 +820,8 @@ void StreamBuilder::encode_device()
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) fail("value pass", e);
     }
-    for (void *q : {(void *)d_map, (void *)d_packed, (void *)d_prow, (void *)d_udesc, (void *)d_urow, (void *)d_uval}) if (q) (void)hipFree(q);
-    d_udesc = nullptr; d_urow = nullptr; d_uval = nullptr;
+    for (void *q : {(void *)d_map, (void *)d_packed, (void *)d_prow, (void *)d_udesc, (void *)d_urow, (void *)d_uval, (void *)d_ucol}) if (q) (void)hipFree(q);
+    d_udesc = nullptr; d_urow = nullptr; d_uval = nullptr; d_ucol = nullptr;
     S.udesc_cb = S.udesc; S.wg_win = nullptr; S.win_cb = nullptr;
     plan->info[TILESPMV_INFO_UPLOAD_US] += (long long)(now_us() - t0);
 }
@@ -810,7 +846,8 @@ void StreamBuilder::encode()
     if (DT) { encode_device(); return; }
     {
         std::vector<UDesc> packed((size_t)NUP, UDesc{0u, 0u, 0u});
-        std::vector<URow> packed_row(pooled ? (size_t)NUP : 0, URow{0u, 0u});
+        std::vector<URow> packed_row(pooled && !wide ? (size_t)NUP : 0, URow{0u, 0u});
+        std::vector<uint4> packed_col(wide ? (size_t)NUP : 0, make_uint4(0u, 0u, 0u, 0u));
         // The value pass (the plan's largest array, permuted into groups per task) runs on the DEVICE unless this is a layout-digest build or TILESPMV_ENCODE_ON_HOST=1 asks for
         // the host pass — which stays as the checker: TILESPMV_ENCODE_CHECK=1 runs both and compares the device's stream with the host's, byte for byte (tests/test_gpu_parity.py)
         const bool encode_check = !plan->dry && env_int("TILESPMV_ENCODE_CHECK", 0) != 0;
@@ -829,7 +866,8 @@ void StreamBuilder::encode()
                 for (long long j = 0; j < n; j++) {
                     const uint4 d = h_udesc[(size_t)(ub + j)];
                     packed[(size_t)(nb + j)] = UDesc{d.x, d.y, d.w};
-                    if (pooled) packed_row[(size_t)(nb + j)] = URow{h_urow[(size_t)(ub + j)].x, h_urow[(size_t)(ub + j)].y};
+                    if (pooled && !wide) packed_row[(size_t)(nb + j)] = URow{h_urow[(size_t)(ub + j)].x, h_urow[(size_t)(ub + j)].y};
+                    if (wide) packed_col[(size_t)(nb + j)] = h_ucol[(size_t)(ub + j)];
                     if (paired) {
                         const val_t *src = h_uval + (ub + j) * 16;
                         val_t *dst = paired + (nb + j / G * G) * 16 + (j % G);
@@ -840,7 +878,7 @@ void StreamBuilder::encode()
                 if (n > 0) { k.unit_begin = (int)nb; k.unit_end = (int)(nb + n); }
             }
         });
-        if (pooled && getenv("TILESPMV_POOL_PATTERN_STAT")) {   // (study: how many distinct (column nibbles, row nibbles) patterns do the pooled units of this shard use?)
+        if (pooled && !wide && getenv("TILESPMV_POOL_PATTERN_STAT")) {   // (study: how many distinct (column nibbles, row nibbles) patterns do the pooled units of this shard use?)
             std::unordered_map<std::string, long long> cnt;
             for (long long u = 0; u < NUP; u++) { unsigned w[4] = {packed[(size_t)u].n0, packed[(size_t)u].n1, packed_row[(size_t)u].r0, packed_row[(size_t)u].r1}; cnt[std::string((const char *)w, 16)]++; }
             std::vector<long long> c; for (auto &kv : cnt) c.push_back(kv.second);
@@ -901,7 +939,7 @@ void StreamBuilder::encode()
         S.pdict = nullptr; pool_dict = false;
         std::vector<uint4> pdict;
         std::vector<uint2> compact2;
-        if (pooled && K.desc_dict != 0 && NUP > 0) {
+        if (pooled && !wide && K.desc_dict != 0 && NUP > 0) {
             typedef std::array<unsigned, 4> Pat;
             const size_t cap = (size_t)1 << DICT_MAX_BITS;
             std::vector<std::set<Pat>> local((size_t)host_threads());
@@ -937,7 +975,7 @@ void StreamBuilder::encode()
                 pool_dict = true;
             }
         }
-        S.urow = nullptr; S.pooled = pooled ? 1 : 0;
+        S.urow = nullptr; S.ucol = nullptr; S.pooled = pooled ? 1 : 0;
         if (pool_dict) {
             rc |= plan->upload(compact2.data(), compact2.size(), reinterpret_cast<const uint2 **>(&S.udesc));
             rc |= plan->upload(pdict.data(), pdict.size(), &S.pdict);
@@ -946,7 +984,8 @@ void StreamBuilder::encode()
             rc |= plan->upload(dict.data(), dict.size(), &S.udict);
         } else rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc);
         plan->info[TILESPMV_INFO_DESC_BYTES] = desc_bytes();
-        if (pooled && !pool_dict) rc |= plan->upload(packed_row.data(), (size_t)NUP, &S.urow);
+        if (pooled && !wide && !pool_dict) rc |= plan->upload(packed_row.data(), (size_t)NUP, &S.urow);
+        if (wide) rc |= plan->upload(packed_col.data(), (size_t)NUP, &S.ucol);
         if (on_device) {
             // emitted values as they are -> a scratch buffer on the device; one workgroup per task writes them to their final place in the plan's arena
             const double t0 = now_us();

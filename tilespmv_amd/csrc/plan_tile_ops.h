@@ -28,13 +28,14 @@ TILESPMV_HD inline int csr_split_width(const unsigned char *ptr, int rowlen, int
     return best_w;
 }
 
-// What one tile adds to its tile-row's counts.  csr_form: 0 CSR tiles stay whole tiles (their own pass), 1 ELL-style split (w units + list entries), 2 pooled units
+// What one tile adds to its tile-row's counts.  csr_form: 0 CSR tiles stay whole tiles (their own pass), 1 ELL-style split (w units + list entries), 2 pooled units, 3 wide pooled units
+// (windows of POOL_WIDE_WINDOW columns, one byte of column offset per slot: hip_plan.h)
 // (the pooled nonzeros — CSR tiles, in-tile COO tiles, HYB remainders — are counted per tile-row by pool_row_count, not here).
 struct TileCount { int nunits, ncoo, nheavy, ndense, hval, hidx; };
 TILESPMV_HD inline TileCount tile_count(const Tile_matrix *T, int t, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form)
 {
     TileCount c{0, 0, 0, 0, 0, 0};
-    const bool pooled = csr_form == 2;
+    const bool pooled = csr_form >= 2;
     const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
     switch (fmt) {
     case TILESPMV_FMT_ELL: c.nunits = w; break;
@@ -60,13 +61,13 @@ TILESPMV_HD inline TileCount tile_count(const Tile_matrix *T, int t, int rowlen,
 struct PoolEnt { unsigned col; unsigned row; val_t val; };   // global column, row inside the tile-row
 
 // Cuts a column-major run of pooled nonzeros into windows: a window starts at the first nonzero not yet taken and holds the (up to 16) following ones whose column is
-// less than 16 above its first column.  `col(i)` = column of nonzero i; `emit(begin, end)` is called once per window.
+// less than `width` (16, or POOL_WIDE_WINDOW in wide plans) above its first column.  `col(i)` = column of nonzero i; `emit(begin, end)` is called once per window.
 template <class ColOf, class Emit>
-TILESPMV_HD inline void pool_windows(long long n, ColOf col, Emit emit)
+TILESPMV_HD inline void pool_windows(long long n, unsigned width, ColOf col, Emit emit)
 {
     long long i = 0;
     while (i < n) {
-        const unsigned long long lim = (unsigned long long)col(i) + 16ull;
+        const unsigned long long lim = (unsigned long long)col(i) + width;
         long long j = i + 1;
         while (j < n && j - i < 16 && (unsigned long long)col(j) < lim) j++;
         emit(i, j);
@@ -121,17 +122,27 @@ TILESPMV_HD inline long long pool_row(const Tile_matrix *T, int bi, int rowlen, 
 TILESPMV_HD inline long long pool_row_capacity(const Tile_matrix *T, int bi) { return (long long)T->blknnz[T->tile_ptr[bi + 1]] - T->blknnz[T->tile_ptr[bi]]; }
 
 // pooled part of a tile-row's counts: windows that are worth a unit, and the nonzeros of the others (list entries)
-TILESPMV_HD inline void pool_row_count(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, const long long *hyb_off, PoolEnt *scratch, int *nunits, int *ncoo)
+// (nlines, optional: 16-column segments of x — 128-byte lines in fp64 — the units' gathers touch, summed over the units: what a wide window costs the texture path)
+TILESPMV_HD inline void pool_row_count(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, const long long *hyb_off, unsigned width, PoolEnt *scratch, int *nunits, int *ncoo, int *nlines = nullptr)
 {
     const long long n = pool_row(T, bi, rowlen, coo_in_tile, hyb_off, scratch);
-    int nu = 0, nc = 0;
-    pool_windows(n, [=](long long i) { return scratch[i].col; }, [&](long long b, long long e) { if (e - b >= POOL_MIN_FILL) nu++; else nc += (int)(e - b); });
+    int nu = 0, nc = 0, nl = 0;
+    constexpr unsigned LSH = 4;   // 16-column segments of x (a 128-byte line in fp64; the rule calibrated on them is kept for fp32, where wide windows lose on the same structures)
+    pool_windows(n, width, [=](long long i) { return scratch[i].col; }, [&](long long b, long long e) {
+        if (e - b >= POOL_MIN_FILL) {
+            nu++;
+            unsigned last = ~0u;
+            for (long long q = b; q < e; q++) { const unsigned l = scratch[q].col >> LSH; if (l != last) { nl++; last = l; } }   // (columns ascend inside a window)
+        } else nc += (int)(e - b);
+    });
     *nunits = nu; *ncoo = nc;
+    if (nlines) *nlines = nl;
 }
 
 // ---- emission
 struct EmitOut {   // where the records go (host staging arrays or device memory); entries of arrays a plan does not have are never written
     uint4 *udesc; uint2 *urow; val_t *uval;              // units: descriptor (w0, nibbles 0-7, w0, nibbles 8-15), pooled plans: row nibbles, 16 values
+    uint4 *ucol;                                         // wide pooled plans: 16 column-offset bytes per unit (slot s in byte s); their descriptor's nibbles are the ROW nibbles, urow is unused
     val_t *cval; int *ccol; unsigned char *crow;         // list entries: value, global column, tile-row-in-strip << 4 | row
     int *dcb; val_t *dval;                               // dense tiles for the matrix cores: column block, 256 values in operand order
 };
@@ -142,11 +153,20 @@ TILESPMV_HD inline unsigned unit_word0(bool pooled, unsigned kr, int cb, unsigne
     return pooled ? (((unsigned)cb * 16u) | (kr << POOL_KR_SHIFT)) : ((unsigned)cb | (((kr << UNIT_ROW_SHIFT) | flags) << UNIT_FLAG_SHIFT));
 }
 // one unit of column block cb: src = rowlen consecutive values of this column; nibs: 16 column nibbles, row 0 in the top nibble
-TILESPMV_HD inline void put_unit(const EmitOut &O, EmitPos &p, bool pooled, unsigned kr, int cb, const val_t *src, int rows, unsigned long long nibs)
+TILESPMV_HD inline uint4 nibbles_to_bytes(unsigned long long nibs)   // 16 nibbles (slot 0 in the top nibble) -> 16 bytes (slot s in byte s)
+{
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    for (int sl = 0; sl < 16; sl++) w[sl >> 2] |= (unsigned)((nibs >> (60 - 4 * sl)) & 15ull) << (8 * (sl & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+TILESPMV_HD inline void put_unit(const EmitOut &O, EmitPos &p, int csr_form, unsigned kr, int cb, const val_t *src, int rows, unsigned long long nibs)
 {
     for (int r = 0; r < rows; r++) O.uval[p.u * 16 + r] = src[r];
-    const unsigned w0 = unit_word0(pooled, kr, cb, 0u);
-    O.udesc[p.u] = make_uint4(w0, (unsigned)(nibs >> 32), w0, (unsigned)(nibs & 0xffffffffull));
+    const unsigned w0 = unit_word0(csr_form >= 2, kr, cb, 0u);
+    if (csr_form == 3) {   // one row per lane: identity row nibbles; the column nibbles become offset bytes
+        O.udesc[p.u] = make_uint4(w0, 0x01234567u, w0, 0x89ABCDEFu);
+        O.ucol[p.u] = nibbles_to_bytes(nibs);
+    } else O.udesc[p.u] = make_uint4(w0, (unsigned)(nibs >> 32), w0, (unsigned)(nibs & 0xffffffffull));
     p.u++;
 }
 
@@ -155,7 +175,7 @@ TILESPMV_HD inline void put_unit(const EmitOut &O, EmitPos &p, bool pooled, unsi
 TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, unsigned kr, const long long *hyb_off,
                                   const EmitOut &O, EmitPos &p)
 {
-    const bool pooled = csr_form == 2;
+    const bool pooled = csr_form >= 2;
     const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
     const int cb = T->tile_columnidx[t], collen = tile_collen(cb, tilen, colA);
     switch (fmt) {
@@ -164,7 +184,7 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
         for (int s = 0; s < w; s++) {
             unsigned long long nibs = 0;
             for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib_at(T->ell_compressedIdx, (long long)off + s * rowlen + r) << (60 - 4 * r);
-            put_unit(O, p, pooled, kr, cb, T->Blockell_Val + off + s * rowlen, rowlen, nibs);
+            put_unit(O, p, csr_form, kr, cb, T->Blockell_Val + off + s * rowlen, rowlen, nibs);
         }
         break;
     }
@@ -175,7 +195,7 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
         for (int s = 0; s < w; s++) {
             unsigned long long nibs = 0;
             for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib_at(src, s * rowlen + r) << (60 - 4 * r);
-            put_unit(O, p, pooled, kr, cb, T->Blockhyb_Val + off + s * rowlen, rowlen, nibs);
+            put_unit(O, p, csr_form, kr, cb, T->Blockhyb_Val + off + s * rowlen, rowlen, nibs);
         }
         if (coo_in_tile && !pooled)
             for (int q = 0; q < stored - nell; q++) {
@@ -187,7 +207,7 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
     }
     case TILESPMV_FMT_DNSCOL: {
         const int off = T->dnscol_offset[t], co = T->dnscolptr[t], k = T->dnscolptr[t + 1] - co;
-        for (int q = 0; q < k; q++) put_unit(O, p, pooled, kr, cb, T->Blockdensecol_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)(T->densecolid[co + q] & 15));
+        for (int q = 0; q < k; q++) put_unit(O, p, csr_form, kr, cb, T->Blockdensecol_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)(T->densecolid[co + q] & 15));
         break;
     }
     case TILESPMV_FMT_COO:
@@ -203,7 +223,7 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
     case TILESPMV_FMT_DNS: {
         const int off = T->dns_offset[t];
         if (!dense_mfma) {
-            for (int q = 0; q < collen; q++) put_unit(O, p, pooled, kr, cb, T->Blockdense_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)q);
+            for (int q = 0; q < collen; q++) put_unit(O, p, csr_form, kr, cb, T->Blockdense_Val + off + q * rowlen, rowlen, 0x1111111111111111ull * (unsigned)q);
             break;
         }
         // dense tile for the matrix cores: 256 values, zero padded, in MFMA operand order (dense_slot, hip_plan.h)
@@ -220,7 +240,10 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
             for (int cc = 0; cc < collen; cc++) O.uval[p.u * 16 + cc] = T->Blockdenserow_Val[off + q * collen + cc];
             const unsigned w0 = unit_word0(pooled, kr, cb, UNIT_ROWUNIT);
             const unsigned rid = (unsigned)(T->denserowid[ro + q] & 15);
-            if (pooled) {   // slot s = column s of the dense row: identity column nibbles, one row nibble
+            if (csr_form == 3) {   // slot s = column s of the dense row: offsets 0 .. 15, one row nibble
+                O.udesc[p.u] = make_uint4(w0, 0x11111111u * rid, w0, 0x11111111u * rid);
+                O.ucol[p.u] = make_uint4(0x03020100u, 0x07060504u, 0x0B0A0908u, 0x0F0E0D0Cu);
+            } else if (pooled) {   // slot s = column s of the dense row: identity column nibbles, one row nibble
                 O.udesc[p.u] = make_uint4(w0, 0x01234567u, w0, 0x89ABCDEFu);
                 O.urow[p.u] = make_uint2(0x11111111u * rid, 0x11111111u * rid);
             } else O.udesc[p.u] = make_uint4(w0, rid, w0, rid);
@@ -260,13 +283,14 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
 }
 
 // the pooled nonzeros of tile-row bi: windows of 16 columns -> units (slot s = s-th nonzero of the window, in row order), sparse windows -> list entries
-TILESPMV_HD inline void pool_row_emit(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, unsigned kr, const long long *hyb_off, PoolEnt *pool, const EmitOut &O, EmitPos &p)
+TILESPMV_HD inline void pool_row_emit(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, unsigned kr, const long long *hyb_off, unsigned width, PoolEnt *pool, const EmitOut &O, EmitPos &p)
 {
+    const bool wide = width > 16u;
     const long long n = pool_row(T, bi, rowlen, coo_in_tile, hyb_off, pool);
-    pool_windows(n, [=](long long q) { return pool[q].col; }, [&](long long wb, long long we) {
+    pool_windows(n, width, [=](long long q) { return pool[q].col; }, [&](long long wb, long long we) {
         if (we - wb >= POOL_MIN_FILL) {
             const unsigned base = pool[wb].col;
-            unsigned cn[2] = {0u, 0u}, rn[2] = {0u, 0u};
+            unsigned cn[2] = {0u, 0u}, rn[2] = {0u, 0u}, cbytes[4] = {0u, 0u, 0u, 0u};
             // slots in ROW order (stable: columns ascending inside a row): the nonzeros of one row sit in neighbouring lanes, which is what the kernel's
             // two interleaved copies of the slab rely on — neighbouring lanes add into different copies, so two nonzeros of a row never meet in one LDS atomic
             int order[16], cnt[17];
@@ -277,12 +301,18 @@ TILESPMV_HD inline void pool_row_emit(const Tile_matrix *T, int bi, int rowlen, 
             for (int sl = 0; sl < (int)(we - wb); sl++) {
                 const PoolEnt &pe = pool[wb + order[sl]];
                 O.uval[p.u * 16 + sl] = pe.val;
-                cn[sl >> 3] |= (pe.col - base) << (28 - 4 * (sl & 7));
+                if (wide) cbytes[sl >> 2] |= (pe.col - base) << (8 * (sl & 3));
+                else cn[sl >> 3] |= (pe.col - base) << (28 - 4 * (sl & 7));
                 rn[sl >> 3] |= pe.row << (28 - 4 * (sl & 7));
             }
             const unsigned w0 = base | (kr << POOL_KR_SHIFT);
-            O.udesc[p.u] = make_uint4(w0, cn[0], w0, cn[1]);
-            O.urow[p.u] = make_uint2(rn[0], rn[1]);   // (empty slots: value 0, column offset 0, row 0 — they add 0 * x[base] to row 0 of the tile-row)
+            if (wide) {   // (descriptor nibbles = row nibbles, column offsets as bytes beside it)
+                O.udesc[p.u] = make_uint4(w0, rn[0], w0, rn[1]);
+                O.ucol[p.u] = make_uint4(cbytes[0], cbytes[1], cbytes[2], cbytes[3]);
+            } else {
+                O.udesc[p.u] = make_uint4(w0, cn[0], w0, cn[1]);
+                O.urow[p.u] = make_uint2(rn[0], rn[1]);   // (empty slots: value 0, column offset 0, row 0 — they add 0 * x[base] to row 0 of the tile-row)
+            }
             p.u++;
         } else
             for (long long q = wb; q < we; q++) {
