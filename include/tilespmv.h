@@ -277,7 +277,9 @@ typedef struct {
                            tiles and HYB remainders pooled in column-major order and cut into units of up to 16 nonzeros inside a 16-column window of x (value + column-offset nibble +
                            row nibble per slot, products scattered into the strip's LDS rows): no padding beyond the last unit of a run of columns, about s_v + 1.3 bytes per nonzero
                            on block-structured / FEM-like matrices; unset: 1 or 2, whichever puts at least 5 % fewer bytes into the streams (2 on shards whose nonzeros sit
-                           mostly in ragged CSR tiles, 1 on stencil-like shards whose units share a handful of column patterns)             TILESPMV_CSR_SPLIT */
+                           mostly in ragged CSR tiles, 1 on stencil-like shards whose units share a handful of column patterns); 3 WIDE pooled units — the same pooling with
+                           windows of 256 columns (a byte of column offset per slot: s_v + 1.75 bytes per nonzero), taken by the builder where 16-column windows leave >= 4 % of the
+                           nonzeros on the entry lists AND a unit's sixteen gathers still touch at most 3.5 lines of x on average (window-shuffled meshes)   TILESPMV_CSR_SPLIT */
     int fix_inline;     /* split tile-rows summed inside the unit kernel (1) or by k_fixup_split (0)         TILESPMV_FIX_INLINE */
     int coo_cost;       /* cost units per COO entry in the strip cutter                                      TILESPMV_COO_COST */
     int coo_heavy_min;  /* entry mode 0: strips with more entries run their list before the unit pipeline    TILESPMV_COO_HEAVY_MIN */
@@ -455,7 +457,7 @@ enum {
     TILESPMV_INFO_X_WINDOW_SLOTS = 17,    /* x-window plans: column blocks of the largest workgroup window (0 = no windows) */
     TILESPMV_INFO_X_WINDOW_SEGMENTS = 18, /* ... and of all windows together: x segments (16 values each) loaded per SpMV */
     TILESPMV_INFO_BRICK_ORDER = 19,       /* 1: the strips were regrouped into bricks of the grid (stencil-like shard) */
-    TILESPMV_INFO_DESC_BYTES = 20,        /* bytes per unit descriptor in HBM: 12, or 4 (column-pattern dictionary) */
+    TILESPMV_INFO_DESC_BYTES = 20,        /* bytes per unit descriptor in HBM: 12, or 4 (column-pattern dictionary); pooled plans 20, or 8 (pattern dictionary); wide pooled plans 28 */
     TILESPMV_INFO_NT_STREAM = 21,         /* 1: the unit kernel reads the value / entry-record streams with nontemporal loads */
     TILESPMV_INFO_PACE_SLABS = 22,        /* slab-paced entry phase: slabs of x the columns are cut into (0 = not paced) */
     TILESPMV_INFO_PACE_TEAM = 23,         /* ... workgroups per team and XCD */
@@ -466,7 +468,7 @@ enum {
     TILESPMV_INFO_SCATTERED_ENTRIES = 28, /* workgroup entry mode: list entries whose column lies more than 2,048 columns outside their group's own rows — the gathers that
                                              no neighbour shares (the chip resolves about 59 G of those per second from a table that misses the L2s: profiles/r04_gather_granule.txt) */
     TILESPMV_INFO_X_SLICE_PASSES = 29,    /* column slices pinned to XCDs: launches of the sliced entry part (0 = not used); 8 x this many slices of x */
-    TILESPMV_INFO_CSR_FORM = 30,          /* what CSR-format tiles became: 0 whole tiles (own pass), 1 ELL-style split (units + list entries), 2 pooled units */
+    TILESPMV_INFO_CSR_FORM = 30,          /* what CSR-format tiles became: 0 whole tiles (own pass), 1 ELL-style split (units + list entries), 2 pooled units, 3 wide pooled units (256-column windows) */
     TILESPMV_INFO_TIMED_CHOICES_US = 31,  /* microseconds of plan creation spent TIMING candidates (placement retry, column panels / slices, pacing); part of build_us; 0 = nothing was timed */
     TILESPMV_INFO_DEVICE_BUILD = 32,      /* 1: built by tilespmv_plan_create_from_csr (Tile_create, COUNT / EMIT / ENCODE on the device) */
     TILESPMV_INFO_TILE_CREATE_US = 33,    /* ... microseconds of its device Tile_create, the upload of the CSR arrays included (0 otherwise) */

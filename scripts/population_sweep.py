@@ -69,6 +69,15 @@ def measure(key, wl, klass, dtype, torch, api, G, build_matrix, reps=50):
                                       "x_slice_passes", "placement_tries", "dense_mode", "scattered_entries")},
            "generate_seconds": round(t_gen, 2), "tile_create_seconds": round(t_tc, 3), "plan_create_seconds": round(t_pc, 3), "timed_choices_ms": round(i["timed_choices_us"] * 1e-3, 1)}
     p.close(); api.Tile_destroy(tm)
+    # the same default plan prepared on the device (tilespmv_plan_create_from_csr: only the CSR arrays cross the bus), whole y checked the same way
+    t0 = time.time(); pd = api.Plan.from_csr(rows, n, nnz, rp, ci, v, dtype=dtype); t_dev = time.time() - t0
+    yd.fill_(-1.0)
+    pd.spmv(xd.data_ptr(), yd.data_ptr(), st); torch.cuda.synchronize()
+    idv = pd.info()
+    rec["prepared_on_device"] = {"csr_to_plan_seconds": round(t_dev, 3), "tile_create_incl_csr_upload_seconds": round(idv["tile_create_us"] * 1e-6, 3), "timed_choices_ms": round(idv["timed_choices_us"] * 1e-3, 1),
+                                 "same_form": bool(idv["csr_form"] == i["csr_form"] and idv["entry_mode"] == i["entry_mode"] and idv["num_tasks"] == i["num_tasks"]),
+                                 "check_whole_y_exact": "pass" if bool(np.array_equal(yd.cpu().numpy()[:rows].astype(np.float64), want)) else "FAIL"}
+    pd.close()
     del xd, yd
     return rec
 
@@ -82,6 +91,9 @@ def summarise(recs):
             "share_frac_ge_0.70": round(sum(f >= 0.70 for f in fr) / max(1, len(fr)), 3), "frac_min_bytes_median": med(fm),
             "share_frac_min_bytes_ge_0.60": round(sum(f >= 0.60 for f in fm) / max(1, len(fm)), 3),
             "plan_create_seconds_total": round(sum(r["plan_create_seconds"] for r in ok), 2), "timed_choices_ms_total": round(sum(r["timed_choices_ms"] for r in ok), 1),
+            "host_preparation_seconds_total": round(sum(r["plan_create_seconds"] + r["tile_create_seconds"] for r in ok), 2),
+            "device_preparation_seconds_total": round(sum(r["prepared_on_device"]["csr_to_plan_seconds"] for r in ok if "prepared_on_device" in r), 2),
+            "device_prepared_checks_failed": [k for k, r in recs.items() if r.get("prepared_on_device", {}).get("check_whole_y_exact", "pass") != "pass"],
             "below_0.70": {k: r["frac"] for k, r in recs.items() if r.get("frac", 1) < 0.70}}
 
 

@@ -300,7 +300,9 @@ void StreamBuilder::count()
         const long long best_b = ub * ((csr_form == 2 ? 20 : 12) + 16LL * sv) + eb * (sv + 5LL) + xy_b, wide_b = u3 * (28 + 16LL * sv) + e3 * (sv + 5LL) + xy_b;
         const long long moved = (e16 >= 0 ? std::min(eb, e16) : eb) - e3;   // nonzeros that leave the entry lists — measured against the 16-column windows too, chosen or not (a natural-order mesh whose
                                                                              // 16-column form narrowly missed its own bar must not get 256-column windows it has no use for)
-        const bool would_panel = (long long)K.coo_cost * e3 * 2 > 16LL * u3 + (long long)K.coo_cost * e3 && (long long)colA * sv >= (12ll << 20);
+        // (column panels exist for the classic units: a shard that would still be entry-dominated with wide windows keeps them — circuit-like shards, where wide units take 80 % of the
+        //  nonzeros, do not: 0.081 -> 0.074 ms on the 4 M-row one)
+        const bool would_panel = (long long)K.coo_cost * e3 * 2 > 16LL * u3 + (long long)K.coo_cost * e3 && 3 * e3 > 16 * u3 && (long long)colA * sv >= (12ll << 20);
         const bool take = lines3 <= POOL_WIDE_MAX_LINES && moved * 25 >= (16 * u3 + e3) && wide_b * 100 <= best_b * 103 && 16 * u3 >= e3 && !would_panel;
         if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: wide windows: %lld units + %lld entries = %.1f MB (chosen so far: %lld + %lld = %.1f MB), %.2f lines of x per pooled unit, %.1f %% of the nonzeros leave the lists -> %s\n",
                                                      u3, e3, wide_b / 1e6, ub, eb, best_b / 1e6, lines3, 100.0 * moved / std::max(1LL, 16 * u3 + e3), take ? "wide" : "kept");
