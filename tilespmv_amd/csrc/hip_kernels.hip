@@ -1679,8 +1679,8 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
 // right-hand side with ds_add (unconditionally: a unit past the task's end adds 0), and the rows of Y are stored from the slab.  The matrix streams are read once for all NVT vectors;
 // before this kernel a pooled plan ran SpMM one right-hand side at a time.
 // ------------------------------------------------------------------------------------------------
-template <int NVT, bool NTS>
-__global__ __launch_bounds__(256, MV_MIN_WAVES) void k_pool_mv(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial, const val_t *__restrict__ X, val_t *__restrict__ Y)
+template <int NVT, bool NTS, bool WIDE>
+__global__ __launch_bounds__(256, WIDE ? 5 : MV_MIN_WAVES) void k_pool_mv(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial, const val_t *__restrict__ X, val_t *__restrict__ Y)
 {
     constexpr int NV = NVT < 2 ? NVT : 2;   // vectors per lane
     constexpr int Q = NVT / NV;             // lane groups per strip
@@ -1693,7 +1693,8 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_pool_mv(DevStream S, int 
     constexpr int VS = 20;
     __shared__ lacc_t s_acc[STRIPS][SR][NVT][VS];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
-    __shared__ uint2 s_r[GROUPS_PER_BLOCK][DCHUNK];
+    typedef typename std::conditional<WIDE, uint4, uint2>::type side_t;   // per parked unit: its row nibbles (16-column pooled plans) or its 16 column-offset bytes (wide pooled plans, S.ucol: +2 KB of LDS, one workgroup fewer per CU)
+    __shared__ side_t s_r[GROUPS_PER_BLOCK][DCHUNK];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
     unsigned bid = blockIdx.x;
     {
@@ -1723,7 +1724,9 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_pool_mv(DevStream S, int 
         for (int j = 0; j < NV; j++) slab[k][q * NV + j][r] = 0;
     }
     uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
-    uint2 rcur = make_uint2(0u, 0u), rnext = rcur;
+    side_t rcur{}, rnext{};   // row nibbles — or, wide pooled plans, the 16 column-offset bytes
+    constexpr bool wide = WIDE;   // (wide pooled plans: the descriptor's nibble words are the row nibbles, S.ucol the column offsets)
+    auto side_of = [&](int i) -> side_t { if constexpr (WIDE) return S.ucol[i]; else return urw[i]; };
     val_t v[UB];
     auto load_grp = [&](int u, val_t (&out)[UB]) {
         const grp_t pv = stream_load<NTS>(ugrp + (long long)min(u, last_grp) * (16 / UNIT_GROUP));
@@ -1740,7 +1743,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_pool_mv(DevStream S, int 
             dcur.x = a.x; dcur.y = a.y; dnext.x = b.x; dnext.y = b.y;
         } else {
             dcur = load_udesc_raw(S.udesc, min(unit_begin + r, last)); dnext = load_udesc_raw(S.udesc, min(unit_begin + DCHUNK + r, last));
-            rcur = urw[min(unit_begin + r, last)]; rnext = urw[min(unit_begin + DCHUNK + r, last)];
+            rcur = side_of(min(unit_begin + r, last)); rnext = side_of(min(unit_begin + DCHUNK + r, last));
         }
         load_grp(unit_begin, v);
     }
@@ -1768,12 +1771,13 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_pool_mv(DevStream S, int 
     // ---- units
     if (have_units) {
         const uint2 *sd = reinterpret_cast<const uint2 *>(&s_d[g][0]) + (r >> 3);
-        const unsigned *sr = reinterpret_cast<const unsigned *>(&s_r[g][0]) + (r >> 3);
+        const unsigned *sr = reinterpret_cast<const unsigned *>(&s_r[g][0]) + (r >> 3);            // this lane's half of a unit's row nibbles
+        const unsigned char *sc = reinterpret_cast<const unsigned char *>(&s_r[g][0]) + r;          // wide: this lane's byte of a unit's column offsets
         if (pd) {
             const uint4 p0 = S.pdict[dcur.y], p1 = S.pdict[dnext.y];
             wnn2 = udw2[min(unit_begin + 2 * DCHUNK + r, last)];
-            dcur = make_uint4(dcur.x, p0.x, p0.y, 0u); rcur = make_uint2(p0.z, p0.w);
-            dnext = make_uint4(dnext.x, p1.x, p1.y, 0u); rnext = make_uint2(p1.z, p1.w);
+            dcur = make_uint4(dcur.x, p0.x, p0.y, 0u); dnext = make_uint4(dnext.x, p1.x, p1.y, 0u);
+            if constexpr (!WIDE) { rcur = make_uint2(p0.z, p0.w); rnext = make_uint2(p1.z, p1.w); }
         }
         s_d[g][r] = udesc_park_form(dcur); s_r[g][r] = rcur;
         wave_lds_fence();
@@ -1786,16 +1790,20 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_pool_mv(DevStream S, int 
                 chunk_end += DCHUNK;
                 if (pd) {
                     const uint4 p = S.pdict[wnn2.y];
-                    dnext = make_uint4(wnn2.x, p.x, p.y, 0u); rnext = make_uint2(p.z, p.w);
+                    dnext = make_uint4(wnn2.x, p.x, p.y, 0u);
+                    if constexpr (!WIDE) rnext = make_uint2(p.z, p.w);
                     wnn2 = udw2[min(chunk_end + DCHUNK + r, last)];
-                } else { dnext = load_udesc_raw(S.udesc, min(chunk_end + r, last)); rnext = urw[min(chunk_end + r, last)]; }
+                } else { dnext = load_udesc_raw(S.udesc, min(chunk_end + r, last)); rnext = side_of(min(chunk_end + r, last)); }
             }
             const int j0 = u - (chunk_end - DCHUNK);
             uint2 d[UB]; unsigned rw[UB]; vec_t xv[UB];
 #pragma unroll
-            for (int k = 0; k < UB; k++) { d[k] = sd[2 * (j0 + k)]; rw[k] = sr[2 * (j0 + k)]; }
+            for (int k = 0; k < UB; k++) { d[k] = sd[2 * (j0 + k)]; rw[k] = wide ? d[k].y : sr[2 * (j0 + k)]; }
 #pragma unroll
-            for (int k = 0; k < UB; k++) xv[k] = Xv[min((long long)(d[k].x & POOL_BASE_MASK) + (long long)((d[k].y >> (28 - 4 * (r & 7))) & 15u), xlast) * Q];
+            for (int k = 0; k < UB; k++) {
+                const unsigned coff = wide ? (unsigned)sc[16 * (j0 + k)] : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
+                xv[k] = Xv[min((long long)(d[k].x & POOL_BASE_MASK) + (long long)coff, xlast) * Q];
+            }
             val_t vn[UB];
             load_grp(u + UB, vn);
 #pragma unroll
@@ -1996,8 +2004,10 @@ static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense
                                              S, P.rowA, P.colA, xcd_chunk, entries_pass ? 1 : 0, slab, P.partial, X, Y)
         if (S.pooled) {   // pooled plans: their own multi-vector kernel (entries in-kernel: no entry pass, no dynamic slab)
             const dim3 grid((unsigned)((S.ntasks + strips - 1) / strips));
-            if (S.nt_stream) hipLaunchKernelGGL((k_pool_mv<NV, true>), grid, dim3(256), 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, X, Y);
-            else hipLaunchKernelGGL((k_pool_mv<NV, false>), grid, dim3(256), 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, X, Y);
+            if (S.ucol) { if (S.nt_stream) hipLaunchKernelGGL((k_pool_mv<NV, true, true>), grid, dim3(256), 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, X, Y);
+                          else hipLaunchKernelGGL((k_pool_mv<NV, false, true>), grid, dim3(256), 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, X, Y); }
+            else if (S.nt_stream) hipLaunchKernelGGL((k_pool_mv<NV, true, false>), grid, dim3(256), 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, X, Y);
+            else hipLaunchKernelGGL((k_pool_mv<NV, false, false>), grid, dim3(256), 0, st, S, P.rowA, P.colA, xcd_chunk, P.partial, X, Y);
         } else if (S.cb_bits > 0) { if (S.nt_stream) TSPMV_MV(true, true); else TSPMV_MV(true, false); }
         else { if (S.nt_stream) TSPMV_MV(false, true); else TSPMV_MV(false, false); }
 #undef TSPMV_MV

@@ -944,7 +944,7 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
     // native multi-vector kernels: unit-stream plans whose COO entries run in-tile and whose CSR tiles were split into units
     // (the defaults).  Generation-1 plans, whole-tile passes and the CSR fallback go one right-hand side at a time.
     const int mv_native = plan->mv_native;   // 1 / 0: force the multi-vector kernel / the one-at-a-time path on entry-dominated plans
-    const bool has_native = plan->kernel == TILESPMV_KERNEL_STREAM && plan->dev.ntasks == 0 && plan->dev.f_nblk == 0 && plan->st.ucol == nullptr;   // (pooled plans have k_pool_mv since round 5; wide pooled plans go one right-hand side at a time)
+    const bool has_native = plan->kernel == TILESPMV_KERNEL_STREAM && plan->dev.ntasks == 0 && plan->dev.f_nblk == 0;   // (pooled plans — 16-column, dictionary and wide — have k_pool_mv)
     // entry-dominated plans (round 3, final): the multi-vector kernel scatters a strip's entries up front (entry slab, mv_slab_rows), which beats going one right-hand side
     // at a time at every nvec (webbase stand-in 37 / 58 / 93 us against 42 / 85 / 223) and beats the separate entry pass over the merged lists (k_entries_mv; workgroup entry mode,
     // 16 strips, no x windows) from nvec 4 on (power-law 8 M: 0.254 / 0.375 / 0.678 ms against 0.198 / 0.469 / 1.364 with the pass): the pass stays for nvec 2.
