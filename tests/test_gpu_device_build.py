@@ -226,3 +226,27 @@ def test_row_block_of_a_larger_csr(torch_cuda):
     import scipy.sparse as sp
     want = sp.csr_matrix((v, ci, rp), shape=(rows, cols))[r0:r1] @ x
     assert np.allclose(yd.cpu().numpy()[:r1 - r0], want, rtol=1e-11, atol=1e-11)
+
+
+def test_device_built_plan_degenerate_inputs(torch_cuda):
+    """Empty matrix, one nonzero, fewer than 16 rows, a partial last tile-row and tile-column, an empty first / last tile-row: the device-built plan against scipy."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    cases_ = [(48, 48, [], []), (48, 48, [47], [47]), (16, 16, [0], [0]), (160, 160, [40, 41, 150], [5, 100, 159]), (1000, 999, None, None), (33, 700, None, None), (17, 17, None, None)]
+    for rows, cols, ri, cj in cases_:
+        if ri is None:
+            k = min(rows * cols // 4 + 1, 5000)
+            key = np.unique(rng.integers(0, rows * cols, k)); ri, cj = key // cols, key % cols
+        r, c, rp, ci = G.from_coo(rows, cols, np.asarray(ri, dtype=np.int64), np.asarray(cj, dtype=np.int64))
+        rows16 = (r // 16) * 16   # (the driver rule: whole tile-rows)
+        if rows16 == 0:
+            continue
+        nnz = int(rp[rows16])
+        for dtype in (np.float64, np.float32):
+            v, x = G.compat_values(max(nnz, 1), dtype)[:nnz], G.compat_x(c, dtype)
+            for knobs in (dict(), dict(csr_split=2), dict(csr_split=3), dict(entry_mode=2)):
+                plan = api.Plan.from_csr(rows16, c, nnz, rp[:rows16 + 1], ci[:nnz], v, dtype=dtype, **knobs)
+                y = _spmv(torch_cuda, plan, rows16, x)
+                plan.close()
+                want = sp.csr_matrix((v.astype(np.float64), ci[:nnz], rp[:rows16 + 1]), shape=(rows16, c)) @ x.astype(np.float64)
+                assert np.array_equal(y.astype(np.float64), want), (rows, cols, dtype, knobs)
