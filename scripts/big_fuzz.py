@@ -48,8 +48,9 @@ def knobs(rng):
     if rng.random() < 0.2: kw["placement_tries"] = 2
     if rng.random() < 0.2: kw["dense_mode"] = int(rng.choice([api.DENSE_MFMA, api.DENSE_VALU]))
     r = rng.random()      # round 5: what CSR-format tiles become — forced pooled / forced split on a third of the plans each way, the byte model's choice otherwise
-    if r < 0.3: kw["csr_split"] = 2
-    elif r < 0.45: kw["csr_split"] = 1
+    if r < 0.25: kw["csr_split"] = 2
+    elif r < 0.4: kw["csr_split"] = 1
+    elif r < 0.55: kw["csr_split"] = 3      # (second half of round 5: wide pooled units)
     if rng.random() < 0.15: kw["deterministic"] = 1
     return kw
 
@@ -75,15 +76,17 @@ def main():
                 yd = torch.full((rows + 16,), -9.0, dtype=xd.dtype, device="cuda")
                 if kw.get("placement_tries"): os.environ["TILESPMV_PLACEMENT_FORCE"] = "1"
                 infos = []
+                on_device = rng.random() < 0.4 and "placement_tries" not in kw   # (second half of round 5: the plan built by tilespmv_plan_create_from_csr — tiled matrix and streams made by kernels)
                 for a, b in zip(cuts[:-1], cuts[1:]):
-                    p = api.Plan(tm, rows, n, nnz, tilerow_begin=a, tilerow_end=b, **kw)
+                    if on_device: p = api.Plan.from_csr(rows, n, nnz, rp, ci, vals, dtype=dt, tilerow_begin=a, tilerow_end=b, **kw)
+                    else: p = api.Plan(tm, rows, n, nnz, tilerow_begin=a, tilerow_end=b, **kw)
                     p.spmv(xd.data_ptr(), yd.data_ptr()); p.spmv(xd.data_ptr(), yd.data_ptr()); torch.cuda.synchronize()
                     infos.append(p.info()); p.close(); plans += 1
                 os.environ.pop("TILESPMV_PLACEMENT_FORCE", None)
                 y = yd.cpu().numpy()
                 ok = bool(np.array_equal(y[:rows].astype(np.float64), want)) and bool((y[rows:] == -9.0).all())
                 bad += not ok
-                print("%-22s %s rows %8d nnz %9d  %s  shards %d  form %s panels %s slices %s merge %s  %s" % (name, np.dtype(dt).name, rows, nnz, "ok  " if ok else "MISMATCH", len(cuts) - 1,
+                print("%-22s %s rows %8d nnz %9d  %s  %s shards %d  form %s panels %s slices %s merge %s  %s" % (name, np.dtype(dt).name, rows, nnz, "ok  " if ok else "MISMATCH", "device-built" if on_device else "host-built  ", len(cuts) - 1,
                       [q["csr_form"] for q in infos], [q["x_panels"] for q in infos], [q["x_slice_passes"] for q in infos], [q["x_panel_merge"] for q in infos], kw), flush=True)
             api.Tile_destroy(tm)
     print("BIG FUZZ: %d matrices, %d plans, %d mismatches, %.0f s" % (nmat, plans, bad, time.time() - t0))
