@@ -119,7 +119,10 @@ struct UDesc { unsigned w0, n0, n1; };    // 12 bytes in HBM; lanes expand it to
 constexpr int POOL_KR_SHIFT = 28;         // w0 of a pooled unit: first column of the window (28 bits: the unit path already limits shards to 2^24 column blocks) | tile-row in strip << 28
 constexpr unsigned POOL_BASE_MASK = (1u << POOL_KR_SHIFT) - 1u;
 constexpr int POOL_MIN_FILL = sizeof(val_t) == 8 ? 12 : 10;   // 16 s_v + 20 bytes per unit against s_v + 5 (4 in the packed lists) per list entry
-constexpr int POOL_STRIP_ROWS = 4;        // tile-rows per strip of a pooled plan (their tile-rows are heavy; the slab of s_y is half the size: 14.5 KB of LDS per workgroup)
+#ifndef TILESPMV_POOL_STRIP_ROWS
+#define TILESPMV_POOL_STRIP_ROWS 4
+#endif
+constexpr int POOL_STRIP_ROWS = TILESPMV_POOL_STRIP_ROWS;        // tile-rows per strip of a pooled plan (their tile-rows are heavy; the slab of s_y is half the size: 14.5 KB of LDS per workgroup)
 struct URow { unsigned r0, r1; };         // row nibbles of slots 0-7 / 8-15 (slot 0 in the top nibble)
 // Wide pooled units (round 5, second half; csr_form 3): the same pooling with windows of POOL_WIDE_WINDOW columns — a slot's column offset is a byte instead of a nibble (16 bytes per unit in
 // DevStream::ucol, slot s in byte s; the descriptor's two nibble words then hold the ROW nibbles and there is no urow stream): 28 + 16 s_v bytes per unit.  For shards whose nonzeros are

@@ -1040,7 +1040,7 @@ void StreamBuilder::entries()
     n_rec = 0; n_chunk = 0; n_groups = 0;
     if (entry_mode != 0) {
         const size_t GS = entry_mode == 2 ? (size_t)wg_strips : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
-        const int slab_shift = (xwin || pooled) ? 6 : 7;   // a strip's slab of s_y: XWIN_STRIP_ROWS / POOL_STRIP_ROWS x 16 values in x-window and pooled plans, STRIP_MAX_ROWS x 16 otherwise
+        const int slab_shift = xwin ? 6 : pooled ? (POOL_STRIP_ROWS > 4 ? 7 : 6) : 7;   // a strip's slab of s_y: XWIN_STRIP_ROWS / POOL_STRIP_ROWS x 16 values in x-window and pooled plans, STRIP_MAX_ROWS x 16 otherwise
         const int dest_bits = entry_mode == 2 ? (wg_strips == 32 ? 12 : 4 + slab_shift) : 9;   // strip-in-group | row-in-strip | row (4)
         S.dest_bits = dest_bits;
         const size_t nwg = (tasks.size() + GS - 1) / GS;
