@@ -874,8 +874,11 @@ int tilespmv_plan_create_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_P
     Knobs Kd = K;
     if (Kd.kernel == TILESPMV_KERNEL_AUTO) Kd.kernel = TILESPMV_KERNEL_STREAM;
     if (Kd.coo_mode == TILESPMV_COO_AUTO) Kd.coo_mode = TILESPMV_COO_IN_TILE;
+    const double t2 = now_us();
     rc = plan_create_one(out, &H, rowA, colA, nnzA, Kd, D);
+    const double t3 = now_us();
     devtile_destroy(D);
+    if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: plan from CSR: plan build %.1f ms, tiled matrix released in %.1f ms\n", (t3 - t2) * 1e-3, (now_us() - t3) * 1e-3);
     if (rc == 0 && *out) {
         (*out)->info[TILESPMV_INFO_DEVICE_BUILD] = 1;
         (*out)->info[TILESPMV_INFO_TILE_CREATE_US] = (long long)(t1 - t0);

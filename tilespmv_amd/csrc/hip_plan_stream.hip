@@ -761,6 +761,7 @@ void StreamBuilder::encode_device()
         if (n > 0) { k.unit_begin = (int)nb; k.unit_end = (int)(nb + n); }
     }
     const double t0 = now_us();
+    const long long up0 = plan->info[TILESPMV_INFO_UPLOAD_US];   // (reserve() / upload() below count their own time: the stage's total replaces it at the end, not adds to it)
     S.udict = nullptr; S.cb_bits = 0; S.urow = nullptr; S.ucol = nullptr; S.pooled = pooled ? 1 : 0; S.pdict = nullptr; pool_dict = false;
     void *d_map = nullptr; UDesc *d_packed = nullptr; URow *d_prow = nullptr;
     auto fail = [&](const char *what, hipError_t e) { fprintf(stderr, "tilespmv: device plan build: %s: %s\n", what, hipGetErrorString(e)); (void)hipGetLastError(); rc = -3; };
@@ -825,7 +826,7 @@ void StreamBuilder::encode_device()
     for (void *q : {(void *)d_map, (void *)d_packed, (void *)d_prow, (void *)d_udesc, (void *)d_urow, (void *)d_uval, (void *)d_ucol}) if (q) (void)hipFree(q);
     d_udesc = nullptr; d_urow = nullptr; d_uval = nullptr; d_ucol = nullptr;
     S.udesc_cb = S.udesc; S.wg_win = nullptr; S.win_cb = nullptr;
-    plan->info[TILESPMV_INFO_UPLOAD_US] += (long long)(now_us() - t0);
+    plan->info[TILESPMV_INFO_UPLOAD_US] = up0 + (long long)(now_us() - t0);
 }
 
 void StreamBuilder::encode()
