@@ -369,6 +369,11 @@ int Tile_create_device(Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnz
 int tilespmv_plan_create_from_csr(tilespmv_plan **plan, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *csrRowPtrA,
                                   const int *csrColIdxA, const MAT_VAL_TYPE *csrValA, unsigned create_flags,
                                   const tilespmv_plan_options *opts);
+/* The same with the CSR arrays already in DEVICE memory (a solver that assembles on the GPU, a framework's CSR tensor): nothing crosses the bus but the few numbers the host decides on.
+ * The row pointer starts at 0; the arrays are borrowed for the duration of the call and not modified. */
+int tilespmv_plan_create_from_device_csr(tilespmv_plan **plan, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *d_csrRowPtrA,
+                                         const int *d_csrColIdxA, const MAT_VAL_TYPE *d_csrValA, unsigned create_flags,
+                                         const tilespmv_plan_options *opts);
 
 /* Values: x (and the matrix values) must be FINITE.  Zero-padded payload is multiplied by real x entries — the padding
  * slots of ELL / HYB tiles exactly as in the reference (src/tilespmv_cpu.h:173-192 walks all `width` slots), and in

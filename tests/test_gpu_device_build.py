@@ -250,3 +250,24 @@ def test_device_built_plan_degenerate_inputs(torch_cuda):
                 plan.close()
                 want = sp.csr_matrix((v.astype(np.float64), ci[:nnz], rp[:rows16 + 1]), shape=(rows16, c)) @ x.astype(np.float64)
                 assert np.array_equal(y.astype(np.float64), want), (rows, cols, dtype, knobs)
+
+
+def test_plan_from_a_device_resident_csr(torch_cuda):
+    """tilespmv_plan_create_from_device_csr: the CSR arrays are torch tensors on the GPU (what a torch CSR tensor holds): the same plan as from the host arrays, stream for stream; timing beside it."""
+    import time
+    for gen, dtype in ((G.fem_hex(20, 20, 20, 3), np.float64), (G.powerlaw(300000), np.float32), (G.laplacian5pt(600), np.float64)):
+        rows, cols, rp, ci = gen
+        rows = cases.truncated_rows(rows); nnz = int(rp[rows])
+        v, x = G.real_values(nnz, dtype), G.real_x(cols, nnz, dtype)
+        host = api.Plan.from_csr(rows, cols, nnz, rp, ci, v, dtype=dtype, deterministic=1)
+        d_rp = torch_cuda.from_numpy(np.ascontiguousarray(rp[:rows + 1], dtype=np.int32)).cuda(); d_ci = torch_cuda.from_numpy(np.ascontiguousarray(ci[:nnz], dtype=np.int32)).cuda()
+        d_v = torch_cuda.from_numpy(np.ascontiguousarray(v[:nnz])).cuda()
+        torch_cuda.cuda.synchronize()
+        dev = api.Plan.from_device_csr(rows, cols, nnz, d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr(), dtype, deterministic=1)
+        try:
+            a, b = host.stream_digests(), dev.stream_digests()
+            assert sorted(a) == sorted(b) and all(a[k] == b[k] for k in a)
+            assert np.array_equal(_spmv(torch_cuda, host, rows, x), _spmv(torch_cuda, dev, rows, x))
+            assert d_rp.cpu().numpy().tolist()[:3] == rp[:3].tolist()   # the caller's arrays are untouched
+        finally:
+            host.close(); dev.close()

@@ -86,6 +86,8 @@ def load(dtype=np.float64):
     lib.Tile_create_device.restype = C.c_int
     lib.tilespmv_plan_create_from_csr.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, _I, _I, VP, C.c_uint, C.POINTER(PlanOptions)]
     lib.tilespmv_plan_create_from_csr.restype = C.c_int
+    lib.tilespmv_plan_create_from_device_csr.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(PlanOptions)]
+    lib.tilespmv_plan_create_from_device_csr.restype = C.c_int
     lib.tilespmv_plan_stream_digests.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_longlong]
     lib.tilespmv_plan_stream_digests.restype = C.c_longlong
     lib.Tile_destroy.argtypes = [TP]
@@ -161,4 +163,4 @@ DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_c
                     "call_tilespmv_hip_multi", "tilespmv_plan_spmm", "tilespmv_plan_time_spmm", "tilespmv_plan_options_init", "tilespmv_plan_layout_digest",
                     "tilespmv_csr_save", "tilespmv_csr_load", "mmio_allinone_cached", "tilespmv_mtx_write",
                     "tilespmv_plan_time_reference_style", "tilespmv_plan_reserve_spmm", "tilespmv_plan_options_layout", "tilespmv_plan_layout_stages",
-                    "Tile_create_device", "tilespmv_plan_create_from_csr", "tilespmv_plan_stream_digests"]
+                    "Tile_create_device", "tilespmv_plan_create_from_csr", "tilespmv_plan_stream_digests", "tilespmv_plan_create_from_device_csr"]

@@ -237,6 +237,25 @@ class Plan:
         self.h = h
         return self
 
+    @classmethod
+    def from_device_csr(cls, rowA, colA, nnzA, d_rowptr, d_colidx, d_vals, dtype, cdna4=False, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, **knobs):
+        """``tilespmv_plan_create_from_device_csr``: like ``from_csr`` with the CSR arrays already in device memory — ``d_rowptr`` / ``d_colidx`` (int32) and ``d_vals`` are device
+        ADDRESSES (e.g. ``tensor.data_ptr()`` of the crow / col / values tensors of a torch CSR tensor cast to int32); borrowed for the call."""
+        dtype = np.dtype(dtype)
+        lib = _lib.load(dtype)
+        self = cls.__new__(cls)
+        self.lib = lib
+        self.rowA, self.colA, self.nnzA = rowA, colA, nnzA
+        opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, False, **knobs)
+        h = C.c_void_p()
+        rc = lib.tilespmv_plan_create_from_device_csr(C.byref(h), rowA, colA, nnzA, C.c_void_p(d_rowptr), C.c_void_p(d_colidx), C.c_void_p(d_vals), CREATE_QUIET | (CREATE_CDNA4 if cdna4 else 0), C.byref(opts))
+        if rc == -4:
+            raise NotImplementedError("tilespmv_plan_create_from_device_csr: these options have no device path")
+        if rc != 0 or not h:
+            raise RuntimeError("tilespmv_plan_create_from_device_csr failed (%d)" % rc)
+        self.h = h
+        return self
+
     def spmv(self, d_x, d_y, stream=0):
         rc = self.lib.tilespmv_plan_spmv(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream))
         if rc != 0:

@@ -840,8 +840,23 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     return 0;
 }
 
+static int plan_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *rowptr, const int *colidx, const MAT_VAL_TYPE *val, unsigned create_flags,
+                         const tilespmv_plan_options *opts, bool csr_on_device);
+
 int tilespmv_plan_create_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *rowptr, const int *colidx, const MAT_VAL_TYPE *val, unsigned create_flags,
                                   const tilespmv_plan_options *opts)
+{
+    return plan_from_csr(out, rowA, colA, nnzA, rowptr, colidx, val, create_flags, opts, false);
+}
+
+int tilespmv_plan_create_from_device_csr(tilespmv_plan **out, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *d_rowptr, const int *d_colidx, const MAT_VAL_TYPE *d_val, unsigned create_flags,
+                                         const tilespmv_plan_options *opts)
+{
+    return plan_from_csr(out, rowA, colA, nnzA, d_rowptr, d_colidx, d_val, create_flags, opts, true);
+}
+
+static int plan_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *rowptr, const int *colidx, const MAT_VAL_TYPE *val, unsigned create_flags,
+                         const tilespmv_plan_options *opts, bool csr_on_device)
 {
     *out = nullptr;
     const Knobs K = resolve_knobs(opts);
@@ -852,7 +867,7 @@ int tilespmv_plan_create_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_P
         return -4;
     const double t0 = now_us();
     DevTile *D = nullptr;
-    int rc = devtile_create(&D, rowA, colA, rowptr, colidx, val, create_flags, false);
+    int rc = devtile_create(&D, rowA, colA, rowptr, colidx, val, create_flags, false, csr_on_device);
     if (rc != 0) return rc;
     const double t1 = now_us();
     // the tile LIST on the host (what CHOOSE / CUT / the stride detection read); everything else of the tiled matrix stays where it is

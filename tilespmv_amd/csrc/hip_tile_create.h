@@ -28,7 +28,8 @@ struct DevTile {
 };
 
 // rc 0, -1 no device, -2 int32 offsets of Tile_matrix exceeded, -3 HIP error / out of device memory, -4 unsupported flags (TILESPMV_CREATE_HYB)
-int devtile_create(DevTile **out, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, const int *h_colidx, const val_t *h_val, unsigned flags, bool want_deferred);
+// csr_on_device: the three CSR arrays are DEVICE pointers already (row pointer based at 0; borrowed, not freed): no upload at all
+int devtile_create(DevTile **out, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, const int *h_colidx, const val_t *h_val, unsigned flags, bool want_deferred, bool csr_on_device = false);
 void devtile_destroy(DevTile *D);
 // every member array into freshly malloc'd host arrays (Tile_destroy frees them)
 int devtile_download(const DevTile *D, Tile_matrix *host);

@@ -258,13 +258,18 @@ inline void dfree(DevTile *D, const void *p)
 }
 inline unsigned blocks_for(long long n, int per) { return (unsigned)std::max<long long>(1, (n + per - 1) / per); }
 
-int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, const int *h_colidx, const val_t *h_val, unsigned flags, bool want_deferred)
+int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, const int *h_colidx, const val_t *h_val, unsigned flags, bool want_deferred, bool csr_on_device)
 {
     const bool verbose = getenv("TILESPMV_CREATE_VERBOSE") != nullptr, cdna4 = flags & TILESPMV_CREATE_CDNA4;
     Tile_matrix &T = D->T;
     const int tilem = (rowA + BS - 1) / BS, tilen = (colA + BS - 1) / BS;
     // the row pointer may be a slice of a larger matrix's (a row block: pointers not rebased): the block's nonzeros are [base, base + nnz) of the column / value arrays
-    const long long base = h_rowptr[0], nnz = (long long)h_rowptr[rowA] - base;
+    long long base = 0, nnz = 0;
+    if (csr_on_device) {   // (device CSR: based at 0 by contract; its last row pointer is the one number fetched)
+        int last = 0;
+        TC_TRY(hipMemcpy(&last, h_rowptr + rowA, sizeof(int), hipMemcpyDeviceToHost));
+        nnz = last;
+    } else { base = h_rowptr[0]; nnz = (long long)h_rowptr[rowA] - base; }
     std::vector<int> rebased;
     if (base != 0) {
         rebased.resize((size_t)rowA + 1);
@@ -279,10 +284,13 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     // ---- the CSR arrays cross the bus (the only large upload of the device pipeline)
     double t0 = now_ms();
     int *d_rowptr = nullptr, *d_colidx = nullptr; val_t *d_val = nullptr;
-    if (dalloc(D, &d_rowptr, (size_t)rowA + 1, false) || dalloc(D, &d_colidx, (size_t)nnz, false) || dalloc(D, &d_val, (size_t)nnz, false)) return -3;
-    TC_TRY(hipMemcpy(d_rowptr, h_rowptr, ((size_t)rowA + 1) * sizeof(int), hipMemcpyHostToDevice));
-    if (nnz) TC_TRY(hipMemcpy(d_colidx, h_colidx, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
-    if (nnz) TC_TRY(hipMemcpy(d_val, h_val, (size_t)nnz * sizeof(val_t), hipMemcpyHostToDevice));
+    if (csr_on_device) { d_rowptr = const_cast<int *>(h_rowptr); d_colidx = const_cast<int *>(h_colidx); d_val = const_cast<val_t *>(h_val); }   // (borrowed: never in D->allocs)
+    else {
+        if (dalloc(D, &d_rowptr, (size_t)rowA + 1, false) || dalloc(D, &d_colidx, (size_t)nnz, false) || dalloc(D, &d_val, (size_t)nnz, false)) return -3;
+        TC_TRY(hipMemcpy(d_rowptr, h_rowptr, ((size_t)rowA + 1) * sizeof(int), hipMemcpyHostToDevice));
+        if (nnz) TC_TRY(hipMemcpy(d_colidx, h_colidx, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+        if (nnz) TC_TRY(hipMemcpy(d_val, h_val, (size_t)nnz * sizeof(val_t), hipMemcpyHostToDevice));
+    }
     D->rowptr = d_rowptr; D->colidx = d_colidx; D->val = d_val;
     D->ms_upload = now_ms() - t0; t0 = now_ms();
 
@@ -474,14 +482,14 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
 
 }  // namespace
 
-int devtile_create(DevTile **out, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, const int *h_colidx, const val_t *h_val, unsigned flags, bool want_deferred)
+int devtile_create(DevTile **out, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, const int *h_colidx, const val_t *h_val, unsigned flags, bool want_deferred, bool csr_on_device)
 {
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); fprintf(stderr, "tilespmv: no HIP device visible — the device Tile_create has no CPU fallback (use Tile_create)\n"); return -1; }
     if (flags & TILESPMV_CREATE_HYB) { fprintf(stderr, "tilespmv: the device Tile_create does not build HYB tiles (TILESPMV_CREATE_HYB): use Tile_create_ex\n"); return -4; }
     DevTile *D = new DevTile();
-    const int rc = create_impl(D, rowA, colA, h_rowptr, h_colidx, h_val, flags, want_deferred);
+    const int rc = create_impl(D, rowA, colA, h_rowptr, h_colidx, h_val, flags, want_deferred, csr_on_device);
     if (rc != 0) { devtile_destroy(D); return rc; }
     *out = D;
     return 0;
