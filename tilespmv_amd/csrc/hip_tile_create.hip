@@ -238,9 +238,31 @@ __global__ void k_tc_unsorted_rows(int rowA, const int *__restrict__ ptr, const 
     for (int i = ptr[r] + 1; i < ptr[r + 1]; i++) if (colidx[i - 1] >= colidx[i]) { atomicAdd(count, 1); return; }
 }
 
+// Device arrays come from a few POOLS (one zeroed hipMalloc per phase of the build: the per-tile arrays, the payload arrays) instead of one hipMalloc + memset each — the build
+// makes about forty arrays, and on a busy allocator their calls, not the kernels, set the time (one box: 62 ms in the packing phase against 6 ms of kernels).  An array that
+// does not fit what is left of the current pool (or is asked for outside one) gets a hipMalloc of its own.
+struct Pool { char *at = nullptr; size_t left = 0; };
+thread_local Pool t_pool;   // (a build runs on one host thread; two builds on two threads have a pool each)
+inline size_t pool_need(size_t n, size_t elem) { return (std::max<size_t>(n, 1) * elem + 16 + 255) / 256 * 256; }
+int pool_begin(DevTile *D, size_t bytes)
+{
+    void *p = nullptr;
+    t_pool = Pool();
+    TC_TRY(hipMalloc(&p, bytes + 256));
+    D->allocs.push_back(p);
+    TC_TRY(hipMemsetAsync(p, 0, bytes + 256, 0));
+    t_pool.at = (char *)p; t_pool.left = bytes + 256;
+    return 0;
+}
+inline void pool_end() { t_pool = Pool(); }
 template <class V>
 int dalloc(DevTile *D, V **out, size_t n, bool zero)
 {
+    const size_t need = pool_need(n, sizeof(V));
+    if (t_pool.left >= need) {   // (pool memory is zeroed already)
+        *out = (V *)t_pool.at; t_pool.at += need; t_pool.left -= need;
+        return 0;
+    }
     void *p = nullptr;
     const size_t bytes = std::max<size_t>(n, 1) * sizeof(V) + 16;
     TC_TRY(hipMalloc(&p, bytes));
@@ -249,11 +271,12 @@ int dalloc(DevTile *D, V **out, size_t n, bool zero)
     *out = (V *)p;
     return 0;
 }
-inline void dfree(DevTile *D, const void *p)
+inline void dfree(DevTile *D, const void *p)   // (an array carved from a pool goes with its pool)
 {
     if (!p) return;
     auto it = std::find(D->allocs.begin(), D->allocs.end(), (void *)p);
-    if (it != D->allocs.end()) D->allocs.erase(it);
+    if (it == D->allocs.end()) return;
+    D->allocs.erase(it);
     (void)hipFree((void *)p);
 }
 inline unsigned blocks_for(long long n, int per) { return (unsigned)std::max<long long>(1, (n + per - 1) / per); }
@@ -261,6 +284,7 @@ inline unsigned blocks_for(long long n, int per) { return (unsigned)std::max<lon
 int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, const int *h_colidx, const val_t *h_val, unsigned flags, bool want_deferred, bool csr_on_device)
 {
     const bool verbose = getenv("TILESPMV_CREATE_VERBOSE") != nullptr, cdna4 = flags & TILESPMV_CREATE_CDNA4;
+    pool_end();   // (no pool left over from a build that failed on this thread)
     Tile_matrix &T = D->T;
     const int tilem = (rowA + BS - 1) / BS, tilen = (colA + BS - 1) / BS;
     // the row pointer may be a slice of a larger matrix's (a row block: pointers not rebased): the block's nonzeros are [base, base + nnz) of the column / value arrays
@@ -336,6 +360,8 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     T.tilenum = tilenum;
     if (!(flags & TILESPMV_CREATE_QUIET)) printf("\n  The number of tile = %i\n", tilenum);
     const size_t np1 = (size_t)tilenum + 1;
+    // ---- pool of the per-tile arrays: 3 + 9 + 7 arrays of tilenum (+ 1) elements
+    if (pool_begin(D, 3 * pool_need(np1, 4) + 3 * pool_need(np1, 1) + 6 * pool_need(np1, 4) + 7 * pool_need(np1, 4) + pool_need(16, 8))) return -3;
     int *d_tile_columnidx = nullptr, *d_tile_nnz = nullptr, *d_tile_bi = nullptr;
     if (dalloc(D, &d_tile_columnidx, (size_t)tilenum, true) || dalloc(D, &d_tile_nnz, np1, true) || dalloc(D, &d_tile_bi, (size_t)tilenum, true)) return -3;
     T.tile_columnidx = d_tile_columnidx; T.tile_nnz = d_tile_nnz; D->tile_bi = d_tile_bi;
@@ -400,8 +426,17 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     T.dnssize = (int)h_totals[5]; T.dnsrowsize = (int)h_totals[6]; T.dnscolsize = (int)h_totals[7]; T.coototal = (int)h_totals[11];
     const int ndenserow = (int)h_totals[8], ndensecol = (int)h_totals[9];
     D->ms_select = now_ms() - t0; t0 = now_ms();
+    pool_end();
 
-    // ---- payload arrays
+    // ---- payload arrays: one pool
+    {
+        const size_t sv = sizeof(val_t);
+        size_t bytes = pool_need((size_t)T.csrsize, sv) + pool_need((size_t)T.csrptrlen, 1) + pool_need((size_t)T.csrsize, 1) + pool_need(((size_t)T.csrsize + 1) / 2, 1) + pool_need((size_t)T.coosize, sv) +
+                       pool_need((size_t)T.coosize, 1) + pool_need((size_t)T.ellsize, sv) + pool_need((size_t)T.ellsize, 1) + pool_need(((size_t)T.ellsize + 1) / 2, 1) + pool_need(1, sv) + pool_need((size_t)tilem + 8, 1) +
+                       pool_need((size_t)T.dnssize, sv) + pool_need((size_t)T.dnsrowsize, sv) + pool_need((size_t)ndenserow, 1) + pool_need((size_t)T.dnscolsize, sv) + pool_need((size_t)ndensecol, 1);
+        if (want_deferred) bytes += pool_need((size_t)rowA + 1, 4) + pool_need((size_t)T.coototal, 4) + pool_need((size_t)T.coototal, sv) + 2 * pool_need((size_t)T.coototal, 4) + pool_need((size_t)T.coototal, sv);
+        if (pool_begin(D, bytes)) return -3;
+    }
     PackArrays P{};
     unsigned char *d_csr_idx = nullptr, *d_ell_idx = nullptr, *d_hybidx = nullptr; val_t *d_hybval = nullptr;
     if (dalloc(D, &P.Blockcsr_Val, (size_t)T.csrsize, true) || dalloc(D, &P.Blockcsr_Ptr, (size_t)T.csrptrlen, true) || dalloc(D, &P.csr_col, (size_t)T.csrsize, true) ||
@@ -425,6 +460,7 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
         P.deferredcoo_ptr = d_dptr;
         T.deferredcoo_ptr = d_dptr; T.deferredcoo_colidx = d_dcol; T.deferredcoo_val = d_dval;
     }
+    pool_end();
     if (tilenum > 0) {
         hipLaunchKernelGGL(k_tc_pack, dim3(blocks_for(tilenum, 256)), dim3(256), 0, 0, tilenum, tilem, tilen, rowA, colA, T, d_tile_bi, D->key, D->ent, d_colidx, d_val, P);
         TC_TRY(hipGetLastError());
@@ -490,6 +526,7 @@ int devtile_create(DevTile **out, int rowA, int colA, const MAT_PTR_TYPE *h_rowp
     if (flags & TILESPMV_CREATE_HYB) { fprintf(stderr, "tilespmv: the device Tile_create does not build HYB tiles (TILESPMV_CREATE_HYB): use Tile_create_ex\n"); return -4; }
     DevTile *D = new DevTile();
     const int rc = create_impl(D, rowA, colA, h_rowptr, h_colidx, h_val, flags, want_deferred, csr_on_device);
+    pool_end();
     if (rc != 0) { devtile_destroy(D); return rc; }
     *out = D;
     return 0;
