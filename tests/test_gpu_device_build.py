@@ -196,6 +196,17 @@ def test_cli_with_the_plan_built_on_the_device(torch_cuda, tmp_path):
         assert r.returncode == 0, r.stderr
         assert "Run CPU TileSpMV, errcount = 0" in r.stdout and "Check... PASS!" in r.stdout
         assert "plan from CSR: device Tile_create" in r.stderr   # the device path really ran
+    # the CLI's own switch: Tile_create_device + device-built plan, the reference's lines in order, one added line
+    env2 = dict(os.environ, TILESPMV_WARMUP="2", TILESPMV_BENCH_REPEAT="5", TILESPMV_PLAN_VERBOSE="1")
+    r = subprocess.run([os.path.join(root, "tilespmv_amd", "bin", "test_f64"), "-d", "0", os.path.join(root, "tests", "golden", "test.mtx"), "--device-build"], cwd=tmp_path, env=env2,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    pos = -1
+    for w in ["The number of tile =", "device build: Tile_matrix created on the device", "Run CPU TileSpMV, errcount = 0", "CUDA SpMV runtime", "Check... PASS!"]:
+        nxt = r.stdout.find(w, pos + 1)
+        assert nxt > pos, (w, r.stdout)
+        pos = nxt
+    assert "plan from CSR: device Tile_create" in r.stderr
     # the multi-device driver: every shard tiles ITS row block of the CSR arguments on its device (eight shards on the one device there is)
     for extra in (["--combine=none"], ["--combine=allgather"]):
         r = subprocess.run([os.path.join(root, "tilespmv_amd", "bin", "test_f64"), "-d", "0,0,0,0,0,0,0,0", os.path.join(root, "tests", "golden", "test.mtx")] + extra, cwd=tmp_path, env=env,

@@ -43,7 +43,7 @@ int main(int argc, char **argv)
         }
     if (ndev > 0) device_id = devices[0];
     int combine = TILESPMV_Y_ALLGATHER;
-    bool use_cache = false;
+    bool use_cache = false, device_build = false;   // --device-build: the tiled matrix is made by Tile_create_device and the plan(s) by tilespmv_plan_create_from_csr (preprocessing on the GPU)
     std::string cache_prefix;
     for (int a = 4; a < argc; a++) {
         if (strcmp(argv[a], "--combine=none") == 0) combine = TILESPMV_Y_SHARDED;
@@ -51,7 +51,8 @@ int main(int argc, char **argv)
         else if (strcmp(argv[a], "--combine=allreduce") == 0) combine = TILESPMV_Y_ALLREDUCE;
         else if (strcmp(argv[a], "--cache") == 0) use_cache = true;
         else if (strncmp(argv[a], "--cache=", 8) == 0) { use_cache = true; cache_prefix = argv[a] + 8; }
-        else { fprintf(stderr, "unknown option %s (expected --combine=none|allgather|allreduce or --cache[=prefix])\n", argv[a]); return 1; }
+        else if (strcmp(argv[a], "--device-build") == 0) device_build = true;
+        else { fprintf(stderr, "unknown option %s (expected --combine=none|allgather|allreduce, --cache[=prefix] or --device-build)\n", argv[a]); return 1; }
     }
     printf("device_id = %i\n", device_id);
     if (argc < 4) { fprintf(stderr, "usage: %s -d <device_id> <matrix.mtx>\n", argv[0]); return 1; }
@@ -100,8 +101,12 @@ int main(int argc, char **argv)
         printf("  cache: Tile_matrix read from %s in %4.5f sec\n", tile_cache.c_str(), ((t2.tv_sec - t1.tv_sec) * 1000.0 + (t2.tv_usec - t1.tv_usec) / 1000.0) / 1000.0);
     } else {
         gettimeofday(&t1, NULL);
-        Tile_create(matrixA, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA);
+        if (device_build) {
+            const int drc = Tile_create_device(matrixA, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, 0u);
+            if (drc != 0) { fprintf(stderr, "Tile_create_device failed (%d)\n", drc); return 2; }
+        } else Tile_create(matrixA, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA);
         gettimeofday(&t2, NULL);
+        if (device_build) printf("  device build: Tile_matrix created on the device (and copied back for the CPU check) in %4.5f sec\n", ((t2.tv_sec - t1.tv_sec) * 1000.0 + (t2.tv_usec - t1.tv_usec) / 1000.0) / 1000.0);
         if (use_cache) {
             const int src = tilespmv_matrix_save(matrixA, rowA, colA, nnzA, tile_cache.c_str());
             printf("  cache: Tile_matrix created in %4.5f sec and %s %s\n", ((t2.tv_sec - t1.tv_sec) * 1000.0 + (t2.tv_usec - t1.tv_usec) / 1000.0) / 1000.0,
@@ -127,6 +132,7 @@ int main(int argc, char **argv)
                  &blkcoostylerowidx_colstop, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, x, y, y_golden);
 
     MAT_VAL_TYPE alpha = 1.0;
+    if (device_build) setenv("TILESPMV_DEVICE_BUILD", "1", 1);   // (the driver's own switch: call_tilespmv_hip(_multi) then build their plans from the CSR arguments on the device)
     memset(y, 0, sizeof(MAT_VAL_TYPE) * rowA);
     if (ndev > 0) {
         const int mrc = call_tilespmv_hip_multi(filename, matrixA, ptroffset1, ptroffset2, rowblkblock, blkcoostylerowidx,
