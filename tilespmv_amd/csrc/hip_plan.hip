@@ -569,7 +569,9 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
                 dense_vals += 256 * nd; dense_rows += nd > 0;
             }
             const long long all_vals = span(T->blknnz, DT ? DT->T.blknnz : nullptr, t_begin, t_end);
-            dense_mode = (dense_vals * 10 >= all_vals && dense_vals >= 256 * 1024 && dense_vals >= 256 * 5 * dense_rows / 2) ? TILESPMV_DENSE_MFMA : TILESPMV_DENSE_VALU;
+            // (the chain length that pays moved from 2.5 to 4 dense tiles per tile-row in round 5: fem6_46 — 2.7 per tile-row — runs 0.183 ms with the matrix-core pass and 0.167 ms with its
+            //  dense tiles as units of the pooled kernel; band hbw 40 — 5 per tile-row — and fem12_20 keep the pass: profiles/r05_dense_mode_fem.txt)
+            dense_mode = (dense_vals * 10 >= all_vals && dense_vals >= 256 * 1024 && dense_vals >= 256 * 4 * dense_rows) ? TILESPMV_DENSE_MFMA : TILESPMV_DENSE_VALU;
         }
     }
     plan->coo_mode = coo_mode; plan->dense_mode = dense_mode;
