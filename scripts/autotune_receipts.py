@@ -10,7 +10,11 @@ out_path = sys.argv[1] if len(sys.argv) > 1 else "autotune.json"
 sys.argv = sys.argv[:1]
 import bench
 work = [("laplacian4096", "f64"), ("scircuit", "f64"), ("webbase", "f64"), ("nlpkkt160", "f32"), ("nlpkkt160", "f64"), ("lap3d256", "f64"),
-        ("band40_2000000", "f64"), ("powerlaw8000000", "f64"), ("powerlaw2000000", "f64")]
+        ("band40_2000000", "f64"), ("powerlaw8000000", "f64"), ("powerlaw2000000", "f64"),
+        # round 5: the mesh classes and the structures whose sweeps showed headroom no rule separates
+        ("fem3_68", "f64"), ("fem6_46", "f64"), ("fem3s64_68", "f64"), ("fem1_160", "f64"), ("shell4_780", "f64"), ("tet150", "f64"), ("tet150s512", "f64"), ("circuit4000000", "f64")]
+if os.environ.get("AUTOTUNE_ONLY"):
+    work = [w for w in work if w[0] in os.environ["AUTOTUNE_ONLY"].split(",")]
 res = []
 for wl, dt in work:
     dtype = np.float32 if dt == "f32" else np.float64
@@ -31,7 +35,8 @@ for wl, dt in work:
     rec.update({"workload": wl, "dtype": dt, "source": src, "default_plan_ms": round(min(t_def), 5), "autotuned_plan_ms": round(min(t_auto), 5),
                 "gain": round(min(t_def) / min(t_auto), 4)})
     res.append(rec)
-    print(wl, dt, "default %.5f ms  autotuned %.5f ms  choice %s" % (min(t_def), min(t_auto), rec["choice"]), flush=True)
+    rec["autotuned_plan_facts"] = {k: p_auto.info()[k] for k in ("csr_form", "entry_mode", "entry_ordered", "strip_cost", "wg_strips", "brick_order", "dense_mode", "num_tasks")}
+    print(wl, dt, "default %.5f ms  autotuned %.5f ms  (x %.3f)  choice %s  facts %s" % (min(t_def), min(t_auto), min(t_def) / min(t_auto), rec["choice"], rec["autotuned_plan_facts"]), flush=True)
     p_auto.close(); p_def.close(); api.Tile_destroy(tm)
     del xd, yd
 json.dump({"what": "tilespmv_plan_create with measured selection on every workload: candidates timed at plan creation, choice, and the default vs tuned plan re-timed afterwards (min of 5 x 30)", "results": res}, open(out_path, "w"), indent=1)

@@ -12,7 +12,7 @@ for wl in sys.argv[1].split(","):
     b_alg = api.algorithmic_bytes(nnz, rows, n, 8)
     ref = None
     for kw in (dict(), dict(entry_ordered=0), dict(entry_ordered=1), dict(strip_cost=800), dict(strip_cost=3200), dict(strip_cost=6400), dict(strip_cost=3200, entry_ordered=0), dict(wg_strips=32, entry_mode=2),
-               dict(wg_strips=32, entry_mode=2, strip_cost=3200), dict(nt_stream=0), dict(coo_cost=2), dict(coo_cost=8), dict(xcd_chunk=8), dict(xcd_chunk=64), dict(desc_dict=0), dict(y_store=0), dict(y_store=1)):
+               dict(wg_strips=32, entry_mode=2, strip_cost=3200), dict(nt_stream=0), dict(coo_cost=2), dict(coo_cost=8), dict(xcd_chunk=8), dict(xcd_chunk=64), dict(desc_dict=0), dict(y_store=0), dict(y_store=1), dict(entry_mode=0), dict(entry_mode=1), dict(csr_split=1), dict(csr_split=2), dict(csr_split=3), dict(dense_mode=1), dict(dense_mode=2), dict(x_window=2), dict(strip_cost=400), dict(strip_cost=1600)):
         try:
             p = api.Plan(tm, rows, n, nnz, placement_tries=1, x_panel_kb=0, **kw)
         except Exception as e:

@@ -348,6 +348,26 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
             if (w_entry == 2) c2.entry_ordered = w_ord ? 1 : 0;
             try_one(c2, "strip size");
         }
+        // round 5 (second half): the forms the byte-model rules choose between — what CSR-format tiles become, brick order, 32 strips per workgroup — as candidates on top of the
+        // winner so far (the sweeps of profiles/r05_entry_knob_sweep.txt / r05_wide_windows.txt found 5-12 % on single structures that no rule separates: a 27-point stencil
+        // that loses 8 % to the brick order its 7-point cousin needs, a KKT system that likes 32 strips with 6,400-cost strips)
+        auto with_winner = [&](Knobs c2) {
+            c2.entry_mode = best->entry_mode; c2.strip_cost = (int)best->info[TILESPMV_INFO_STRIP_COST];
+            if (best->entry_mode == 2) c2.entry_ordered = best->info[TILESPMV_INFO_ENTRY_ORDERED] ? 1 : 0;
+            return c2;
+        };
+        if (K0.csr_split < 0)
+            for (int form = 1; form <= 3; form++) {
+                if (form == (int)best->info[TILESPMV_INFO_CSR_FORM]) continue;
+                Knobs c2 = cand; c2.csr_split = form;   // (strip size and entry mode by rule: they follow the form)
+                try_one(c2, form == 1 ? "CSR tiles split" : form == 2 ? "CSR tiles pooled" : "CSR tiles pooled, wide windows");
+            }
+        if (K0.x_window < 0 && best->info[TILESPMV_INFO_BRICK_ORDER]) { Knobs c2 = with_winner(cand); c2.csr_split = (int)best->info[TILESPMV_INFO_CSR_FORM]; c2.x_window = 0; try_one(c2, "no brick order"); }
+        if (K0.wg_strips < 0 && best->entry_mode == 2 && best->wg_strips == 16 && !best->pooled) {
+            Knobs c2 = with_winner(cand); c2.wg_strips = 32; c2.x_window = 0;
+            try_one(c2, "32 strips per workgroup");
+            c2.strip_cost = 6400; try_one(c2, "32 strips per workgroup, strips of 6400");
+        }
     }
     log += "], \"xcd_maps\": [";
     // the workgroup -> XCD mapping is a launch parameter: time the alternatives on the winning plan

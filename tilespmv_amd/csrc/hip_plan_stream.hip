@@ -367,6 +367,11 @@ void StreamBuilder::choose()
             target = 800;
         }
     }
+    // pooled plans (strips of at most 4 tile-rows): light tile-rows want FULL strips — tet150: 15 units per tile-row, 0.1025 ms at 400 (1-2 rows per strip, 208 k tasks), 0.0954 at 800
+    // (4 rows, 53 k tasks) — and heavy ones want to stay whole: fem12_20's 290-unit tile-rows were cut into pieces at the 6 x 400 split threshold (0.0542 -> 0.0513 ms unsplit);
+    // fem3_68 / fem3s64 / tri2200 do not move (profiles/r05_pool_strip_cost.txt)
+    // (only where 800 still leaves >= 4 workgroups per CU: the scircuit stand-in — 172 workgroups at 800 — runs 7.6 us against 6.6-7.0 at 400)
+    if (target_in <= 0 && pooled && target < 800 && total_cost / (16LL * 800) >= 1024) target = 800;
     target = std::max(32, target);
     est_wgs = total_cost / (16LL * target) + 1;
     const int wave_coo_env = K.entry_mode;
@@ -1206,6 +1211,9 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     }
     release();
     S.ntasks = (int)tasks.size();
+    // small grids: XCD windows of 8 x 8 workgroups — with the default 8 x 32 a grid of under 256 workgroups has no full window at all and is dealt round-robin, so neighbouring strips
+    // never share an XCD's L2 (scircuit stand-in, 246 workgroups: 6.95 -> 6.55 us; webbase stand-in, 750: 13.05 -> 12.75; profiles/r05_small_grid_forms.txt)
+    if (!K.xcd_from_caller && ((long long)tasks.size() + wg_strips - 1) / wg_strips < 1024) plan->xcd_chunk = 8;
 #ifdef TILESPMV_STAMPS
     { void *sp = nullptr; const size_t nst = ((tasks.size() + 15) / 16) * 4 * 8;
       if (hipMalloc(&sp, nst * 8 + 64) == hipSuccess) { (void)hipMemset(sp, 0, nst * 8 + 64); plan->allocs.push_back(sp); } S.stamps = (unsigned long long *)sp; }
