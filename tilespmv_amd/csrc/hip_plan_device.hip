@@ -71,13 +71,37 @@ __global__ __launch_bounds__(256) void k_pd_count_tiles(const Tile_matrix T, con
     const TileCount k = tile_count(&T, t, tile_rowlen(tile_bi[t], T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form);
     tu[gid] = k.nunits; tc[gid] = k.ncoo; td[gid] = k.ndense;
 }
-__global__ __launch_bounds__(64) void k_pd_count_pool(const Tile_matrix T, int tr0, int ntr, int rowA, bool coo_in_tile, unsigned width, long long stored0, PoolEnt *__restrict__ pool, int *__restrict__ pool_u, int *__restrict__ pool_c, unsigned long long *__restrict__ stat /* [0] units, [1] lines */)
+// One WAVEFRONT per tile-row for the pooled part (round 5, second half: one thread per tile-row took 0.35 s per pass on R-MAT 21 x 16, whose hub tile-rows hold 10^4-10^5 nonzeros in
+// 10^4 tiny tiles each — and a wavefront waits for its heaviest lane).  The tile-row's tiles are laid out side by side (exclusive scan of their contributions, 64 tiles per step) and
+// filled by one lane each with the host builder's per-tile function (plan_tile_ops.h pool_one_tile): the same array pool_row makes.  The greedy window walk is sequential by nature:
+// lane 0 runs the host builder's walk over the finished array.
+__device__ __forceinline__ long long pool_row_wave(const Tile_matrix &T, int bi, int rowlen, bool coo_in_tile, PoolEnt *out, int lane)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ntr) return;
+    const int t0 = T.tile_ptr[bi], t1 = T.tile_ptr[bi + 1];
+    long long base = 0;
+    for (int tb = t0; tb < t1; tb += 64) {   // (wavefront-uniform trip count)
+        const int t = tb + lane;
+        const int cnt = t < t1 ? pool_one_tile_count(&T, t, rowlen, coo_in_tile, nullptr) : 0;
+        int incl = cnt;
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+        const int total = __shfl(incl, 63, 64);
+        if (cnt > 0) (void)pool_one_tile(&T, t, rowlen, coo_in_tile, nullptr, out + base + (incl - cnt));
+        base += total;
+    }
+    __threadfence();   // the other lanes' entries are visible to lane 0's walk
+    return base;
+}
+__global__ __launch_bounds__(256) void k_pd_count_pool(const Tile_matrix T, int tr0, int ntr, int rowA, bool coo_in_tile, unsigned width, long long stored0, PoolEnt *__restrict__ pool, int *__restrict__ pool_u, int *__restrict__ pool_c, unsigned long long *__restrict__ stat /* [0] units, [1] lines */)
+{
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= ntr) return;   // (whole wavefronts leave together)
     const int bi = tr0 + (int)i;
+    PoolEnt *scratch = pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0);
+    const long long n = pool_row_wave(T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, scratch, lane);
+    if (lane != 0) return;
     int nu, nc, nl;
-    pool_row_count(&T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, nullptr, width, pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0), &nu, &nc, &nl);
+    pool_windows_count(scratch, n, width, &nu, &nc, &nl);
     pool_u[i] = nu; pool_c[i] = nc;
     if (nu) { atomicAdd(&stat[0], (unsigned long long)nu); atomicAdd(&stat[1], (unsigned long long)nl); }
 }
@@ -134,14 +158,18 @@ __global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, cons
     // the tile that emits the last unit of an unsplit tile-row of a classic plan marks it (the kernel writes y there)
     if (csr_form < 2 && !row_split[i] && p.u > u0 && p.u == pu[i + 1]) { O.udesc[p.u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; O.udesc[p.u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
 }
-__global__ __launch_bounds__(64) void k_pd_emit_pool(const Tile_matrix T, int tr0, int ntr, int t_begin, int rowA, bool coo_in_tile, unsigned width, long long stored0, PoolEnt *__restrict__ pool, const int *__restrict__ tu,
-                                                       const int *__restrict__ tc, const int *__restrict__ pu, const int *__restrict__ pc, const unsigned char *__restrict__ row_k, const EmitOut O)
+__global__ __launch_bounds__(256) void k_pd_emit_pool(const Tile_matrix T, int tr0, int ntr, int t_begin, int rowA, bool coo_in_tile, unsigned width, long long stored0, PoolEnt *__restrict__ pool, const int *__restrict__ tu,
+                                                        const int *__restrict__ tc, const int *__restrict__ pu, const int *__restrict__ pc, const unsigned char *__restrict__ row_k, const EmitOut O)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // one wavefront per tile-row (pool_row_wave above)
+    const int lane = threadIdx.x & 63;
     if (i >= ntr) return;
     const int bi = tr0 + (int)i, a = T.tile_ptr[bi] - t_begin, b = T.tile_ptr[bi + 1] - t_begin;
+    PoolEnt *scratch = pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0);
+    const long long n = pool_row_wave(T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, scratch, lane);
+    if (lane != 0) return;
     EmitPos p{(long long)pu[i] + tu[b] - tu[a], (long long)pc[i] + tc[b] - tc[a], 0};   // behind what the tile-row's tiles emitted themselves
-    pool_row_emit(&T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, (unsigned)row_k[i], nullptr, width, pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0), O, p);
+    pool_windows_emit(scratch, n, width, (unsigned)row_k[i], O, p);
 }
 __global__ __launch_bounds__(256) void k_pd_word0(const uint4 *__restrict__ udesc, long long n, unsigned *__restrict__ out)
 {
@@ -423,7 +451,7 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &n
         PD_TRY(hipMalloc((void **)&C->pool, (size_t)std::max<long long>(1, S.stored) * sizeof(PoolEnt) + 16));
         Tmp<unsigned long long> d_stat;
         PD_TRY(d_stat.alloc(2, true));
-        hipLaunchKernelGGL(k_pd_count_pool, dim3(nblk(ntr, 64)), dim3(64), 0, 0, D->T, S.tr0, ntr, D->rowA, S.coo_in_tile, csr_form == 3 ? POOL_WIDE_WINDOW : 16u, S.stored0, C->pool, C->pool_u, C->pool_c, d_stat.p);
+        hipLaunchKernelGGL(k_pd_count_pool, dim3(nblk((long long)ntr * 64, 256)), dim3(256), 0, 0, D->T, S.tr0, ntr, D->rowA, S.coo_in_tile, csr_form == 3 ? POOL_WIDE_WINDOW : 16u, S.stored0, C->pool, C->pool_u, C->pool_c, d_stat.p);
         PD_TRY(hipGetLastError());
         unsigned long long h_stat[2] = {0, 0};
         PD_TRY(hipMemcpy(h_stat, d_stat.p, sizeof(h_stat), hipMemcpyDeviceToHost));
@@ -478,7 +506,7 @@ int dev_emit(const DevShard &S, const DevCounts &C, const std::vector<long long>
         PD_TRY(hipGetLastError());
     }
     if (C.csr_form >= 2) {
-        hipLaunchKernelGGL(k_pd_emit_pool, dim3(nblk(ntr, 64)), dim3(64), 0, 0, D->T, S.tr0, ntr, S.t_begin, D->rowA, S.coo_in_tile, C.csr_form == 3 ? POOL_WIDE_WINDOW : 16u, S.stored0, C.pool, (const int *)C.tu, (const int *)C.tc, (const int *)d_pu.p,
+        hipLaunchKernelGGL(k_pd_emit_pool, dim3(nblk((long long)ntr * 64, 256)), dim3(256), 0, 0, D->T, S.tr0, ntr, S.t_begin, D->rowA, S.coo_in_tile, C.csr_form == 3 ? POOL_WIDE_WINDOW : 16u, S.stored0, C.pool, (const int *)C.tu, (const int *)C.tc, (const int *)d_pu.p,
                            (const int *)d_pc.p, (const unsigned char *)d_rk.p, O);
         PD_TRY(hipGetLastError());
     }

@@ -86,35 +86,50 @@ TILESPMV_HD inline void pool_tile(int cb, int count, Src src, PoolEnt *out)
     for (int k = 0; k < count; k++) { unsigned r, c; val_t v; src(k, r, c, v); out[start[c]++] = PoolEnt{(unsigned)cb * 16u + c, r, v}; }
 }
 
-// Everything tile-row bi pools (hip_plan.h "pooled units"), column-major, into out (room for the tile-row's stored nonzeros); returns how many.  CSR tiles always; COO
-// tiles and HYB remainders when they run in-tile.  hyb_off: byte offset of every HYB tile in hybIdx (nullptr: the matrix has none)
+// What ONE tile contributes to its tile-row's pool, column-major, written to out[0 .. returned count): CSR tiles always; COO tiles and HYB remainders when they run in-tile.
+// hyb_off: byte offset of every HYB tile in hybIdx (nullptr: the matrix has none)
+TILESPMV_HD inline int pool_one_tile(const Tile_matrix *T, int t, int rowlen, bool coo_in_tile, const long long *hyb_off, PoolEnt *out)
+{
+    const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], cb = T->tile_columnidx[t];
+    if (fmt == TILESPMV_FMT_CSR) {
+        const int off = T->csr_offset[t];
+        const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
+        const unsigned char *idx = T->csr_compressedIdx; const val_t *val = T->Blockcsr_Val;
+        unsigned char rowof[256];   // row of entry k (a CSR tile holds fewer than 192 entries)
+        for (int r = 0; r < rowlen; r++) { const int k0 = ptr[r], k1 = (r == rowlen - 1) ? stored : ptr[r + 1]; for (int k = k0; k < k1; k++) rowof[k] = (unsigned char)r; }
+        const unsigned char *ro = rowof;
+        pool_tile(cb, stored, [=](int k, unsigned &r, unsigned &c, val_t &v) { r = ro[k]; c = (unsigned)nib_at(idx, (long long)off + k); v = val[off + k]; }, out);
+        return stored;
+    }
+    if (fmt == TILESPMV_FMT_COO && coo_in_tile) {
+        const int off = T->coo_offset[t];
+        const unsigned char *idx = T->coo_compressed_Idx; const val_t *val = T->Blockcoo_Val;
+        pool_tile(cb, stored, [=](int k, unsigned &r, unsigned &c, val_t &v) { const unsigned b = idx[off + k]; r = b >> 4; c = b & 15u; v = val[off + k]; }, out);
+        return stored;
+    }
+    if (fmt == TILESPMV_FMT_HYB && coo_in_tile && hyb_off) {
+        const int off = T->hyb_offset[t], nell = T->tilewidth[t] * rowlen;
+        const unsigned char *src = T->hybIdx + hyb_off[t]; const val_t *val = T->Blockhyb_Val;
+        pool_tile(cb, stored - nell, [=](int k, unsigned &r, unsigned &c, val_t &v) { const unsigned b = src[(nell + 1) / 2 + k]; r = b >> 4; c = b & 15u; v = val[off + nell + k]; }, out);
+        return stored - nell;
+    }
+    return 0;
+}
+// ... and how many entries that is, without writing them (the device builder lays a tile-row's tiles out side by side before it fills them)
+TILESPMV_HD inline int pool_one_tile_count(const Tile_matrix *T, int t, int rowlen, bool coo_in_tile, const long long *hyb_off)
+{
+    const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t];
+    if (fmt == TILESPMV_FMT_CSR) return stored;
+    if (fmt == TILESPMV_FMT_COO && coo_in_tile) return stored;
+    if (fmt == TILESPMV_FMT_HYB && coo_in_tile && hyb_off) return stored - T->tilewidth[t] * rowlen;
+    return 0;
+}
+
+// Everything tile-row bi pools (hip_plan.h "pooled units"), column-major, into out (room for the tile-row's stored nonzeros); returns how many: its tiles' contributions back to back
 TILESPMV_HD inline long long pool_row(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, const long long *hyb_off, PoolEnt *out)
 {
     long long n = 0;
-    for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
-        const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], cb = T->tile_columnidx[t];
-        if (fmt == TILESPMV_FMT_CSR) {
-            const int off = T->csr_offset[t];
-            const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
-            const unsigned char *idx = T->csr_compressedIdx; const val_t *val = T->Blockcsr_Val;
-            unsigned char rowof[256];   // row of entry k (a CSR tile holds fewer than 192 entries)
-            for (int r = 0; r < rowlen; r++) { const int k0 = ptr[r], k1 = (r == rowlen - 1) ? stored : ptr[r + 1]; for (int k = k0; k < k1; k++) rowof[k] = (unsigned char)r; }
-            const unsigned char *ro = rowof;
-            pool_tile(cb, stored, [=](int k, unsigned &r, unsigned &c, val_t &v) { r = ro[k]; c = (unsigned)nib_at(idx, (long long)off + k); v = val[off + k];
-            }, out + n);
-            n += stored;
-        } else if (fmt == TILESPMV_FMT_COO && coo_in_tile) {
-            const int off = T->coo_offset[t];
-            const unsigned char *idx = T->coo_compressed_Idx; const val_t *val = T->Blockcoo_Val;
-            pool_tile(cb, stored, [=](int k, unsigned &r, unsigned &c, val_t &v) { const unsigned b = idx[off + k]; r = b >> 4; c = b & 15u; v = val[off + k]; }, out + n);
-            n += stored;
-        } else if (fmt == TILESPMV_FMT_HYB && coo_in_tile && hyb_off) {
-            const int off = T->hyb_offset[t], nell = T->tilewidth[t] * rowlen;
-            const unsigned char *src = T->hybIdx + hyb_off[t]; const val_t *val = T->Blockhyb_Val;
-            pool_tile(cb, stored - nell, [=](int k, unsigned &r, unsigned &c, val_t &v) { const unsigned b = src[(nell + 1) / 2 + k]; r = b >> 4; c = b & 15u; v = val[off + nell + k]; }, out + n);
-            n += stored - nell;
-        }
-    }
+    for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) n += pool_one_tile(T, t, rowlen, coo_in_tile, hyb_off, out + n);
     return n;
 }
 
@@ -123,9 +138,8 @@ TILESPMV_HD inline long long pool_row_capacity(const Tile_matrix *T, int bi) { r
 
 // pooled part of a tile-row's counts: windows that are worth a unit, and the nonzeros of the others (list entries)
 // (nlines, optional: 16-column segments of x — 128-byte lines in fp64 — the units' gathers touch, summed over the units: what a wide window costs the texture path)
-TILESPMV_HD inline void pool_row_count(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, const long long *hyb_off, unsigned width, PoolEnt *scratch, int *nunits, int *ncoo, int *nlines = nullptr)
+TILESPMV_HD inline void pool_windows_count(const PoolEnt *scratch, long long n, unsigned width, int *nunits, int *ncoo, int *nlines)
 {
-    const long long n = pool_row(T, bi, rowlen, coo_in_tile, hyb_off, scratch);
     int nu = 0, nc = 0, nl = 0;
     constexpr unsigned LSH = 4;   // 16-column segments of x (a 128-byte line in fp64; the rule calibrated on them is kept for fp32, where wide windows lose on the same structures)
     pool_windows(n, width, [=](long long i) { return scratch[i].col; }, [&](long long b, long long e) {
@@ -137,6 +151,11 @@ TILESPMV_HD inline void pool_row_count(const Tile_matrix *T, int bi, int rowlen,
     });
     *nunits = nu; *ncoo = nc;
     if (nlines) *nlines = nl;
+}
+TILESPMV_HD inline void pool_row_count(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, const long long *hyb_off, unsigned width, PoolEnt *scratch, int *nunits, int *ncoo, int *nlines = nullptr)
+{
+    const long long n = pool_row(T, bi, rowlen, coo_in_tile, hyb_off, scratch);
+    pool_windows_count(scratch, n, width, nunits, ncoo, nlines);
 }
 
 // ---- emission
@@ -283,10 +302,9 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
 }
 
 // the pooled nonzeros of tile-row bi: windows of 16 columns -> units (slot s = s-th nonzero of the window, in row order), sparse windows -> list entries
-TILESPMV_HD inline void pool_row_emit(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, unsigned kr, const long long *hyb_off, unsigned width, PoolEnt *pool, const EmitOut &O, EmitPos &p)
+TILESPMV_HD inline void pool_windows_emit(const PoolEnt *pool, long long n, unsigned width, unsigned kr, const EmitOut &O, EmitPos &p)
 {
     const bool wide = width > 16u;
-    const long long n = pool_row(T, bi, rowlen, coo_in_tile, hyb_off, pool);
     pool_windows(n, width, [=](long long q) { return pool[q].col; }, [&](long long wb, long long we) {
         if (we - wb >= POOL_MIN_FILL) {
             const unsigned base = pool[wb].col;
@@ -320,6 +338,11 @@ TILESPMV_HD inline void pool_row_emit(const Tile_matrix *T, int bi, int rowlen, 
                 O.crow[p.c] = (unsigned char)((kr << 4) | pool[q].row); p.c++;
             }
     });
+}
+TILESPMV_HD inline void pool_row_emit(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, unsigned kr, const long long *hyb_off, unsigned width, PoolEnt *pool, const EmitOut &O, EmitPos &p)
+{
+    const long long n = pool_row(T, bi, rowlen, coo_in_tile, hyb_off, pool);
+    pool_windows_emit(pool, n, width, kr, O, p);
 }
 
 // ---- packed entry lists (hip_plan.h ERec): one list already in its final order (by column, ties in list order) -> records and per-chunk column bases.
