@@ -14,8 +14,9 @@ namespace tilespmv {
 struct DevCounts {
     int csr_form = -1;
     int *tu = nullptr, *tc = nullptr, *td = nullptr;   // units / list entries / dense tiles emitted by the tiles before tile t (pool excluded)
+    int *tp = nullptr;                                 // pooled plans: nonzeros the tiles before tile t put into the pool
     int *pool_u = nullptr, *pool_c = nullptr;          // pooled plans: units / list entries of every tile-row's pool
-    PoolEnt *pool = nullptr;                           // pooled plans: scratch, the shard's stored nonzeros
+    PoolEnt *pool = nullptr;                           // pooled plans: every tile-row's pooled nonzeros, column-major, back to back (filled by COUNT, read again by EMIT)
     void release();
 };
 

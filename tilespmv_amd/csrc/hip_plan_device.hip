@@ -63,45 +63,75 @@ __global__ __launch_bounds__(256) void k_pd_gather_ints(const int *__restrict__ 
 
 // ---- COUNT
 __global__ __launch_bounds__(256) void k_pd_count_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, int t_begin, int nt, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form,
-                                                          int *__restrict__ tu, int *__restrict__ tc, int *__restrict__ td)
+                                                          int *__restrict__ tu, int *__restrict__ tc, int *__restrict__ td, int *__restrict__ tp)
 {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nt) return;
-    const int t = t_begin + (int)gid;
-    const TileCount k = tile_count(&T, t, tile_rowlen(tile_bi[t], T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form);
+    const int t = t_begin + (int)gid, rowlen = tile_rowlen(tile_bi[t], T.tilem, rowA);
+    const TileCount k = tile_count(&T, t, rowlen, T.tilen, colA, coo_in_tile, dense_mfma, csr_form);
     tu[gid] = k.nunits; tc[gid] = k.ncoo; td[gid] = k.ndense;
+    if (csr_form >= 2) tp[gid] = pool_one_tile_count(&T, t, rowlen, coo_in_tile, nullptr);   // what the tile adds to its tile-row's pool
 }
-// One WAVEFRONT per tile-row for the pooled part (round 5, second half: one thread per tile-row took 0.35 s per pass on R-MAT 21 x 16, whose hub tile-rows hold 10^4-10^5 nonzeros in
-// 10^4 tiny tiles each — and a wavefront waits for its heaviest lane).  The tile-row's tiles are laid out side by side (exclusive scan of their contributions, 64 tiles per step) and
-// filled by one lane each with the host builder's per-tile function (plan_tile_ops.h pool_one_tile): the same array pool_row makes.  The greedy window walk is sequential by nature:
-// lane 0 runs the host builder's walk over the finished array.
-__device__ __forceinline__ long long pool_row_wave(const Tile_matrix &T, int bi, int rowlen, bool coo_in_tile, PoolEnt *out, int lane)
+// The pooled part (round 5, second half: one thread per tile-row took 0.35 s per pass on R-MAT 21 x 16, whose hub tile-rows hold 10^5 nonzeros in 10^4-10^5 tiny tiles each — and a
+// wavefront waits for its heaviest lane).  Two balanced steps instead: (1) every tile writes its contribution where the exclusive scan of the contributions (tp) puts it — the tiles of a
+// tile-row back to back, which is the array the host builder's pool_row makes — one thread per TILE with the host builder's per-tile function; (2) one WAVEFRONT per tile-row walks
+// the windows (pool_windows_wave below).
+__global__ __launch_bounds__(256) void k_pd_fill_pool(const Tile_matrix T, const int *__restrict__ tile_bi, int t_begin, int nt, int rowA, bool coo_in_tile, const int *__restrict__ tp, PoolEnt *__restrict__ pool)
 {
-    const int t0 = T.tile_ptr[bi], t1 = T.tile_ptr[bi + 1];
-    long long base = 0;
-    for (int tb = t0; tb < t1; tb += 64) {   // (wavefront-uniform trip count)
-        const int t = tb + lane;
-        const int cnt = t < t1 ? pool_one_tile_count(&T, t, rowlen, coo_in_tile, nullptr) : 0;
-        int incl = cnt;
-        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
-        const int total = __shfl(incl, 63, 64);
-        if (cnt > 0) (void)pool_one_tile(&T, t, rowlen, coo_in_tile, nullptr, out + base + (incl - cnt));
-        base += total;
-    }
-    __threadfence();   // the other lanes' entries are visible to lane 0's walk
-    return base;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nt) return;
+    if (tp[gid + 1] == tp[gid]) return;
+    const int t = t_begin + (int)gid;
+    (void)pool_one_tile(&T, t, tile_rowlen(tile_bi[t], T.tilem, rowA), coo_in_tile, nullptr, pool + tp[gid]);
 }
-__global__ __launch_bounds__(256) void k_pd_count_pool(const Tile_matrix T, int tr0, int ntr, int rowA, bool coo_in_tile, unsigned width, long long stored0, PoolEnt *__restrict__ pool, int *__restrict__ pool_u, int *__restrict__ pool_c, unsigned long long *__restrict__ stat /* [0] units, [1] lines */)
+// The window walk (plan_tile_ops.h pool_windows) by a wavefront, 64 nonzeros per step: every lane finds where a window starting at ITS nonzero would end (at most 15 look-aheads),
+// then the wavefront follows the chain of window starts through the step's 64 candidates with register reads (v_readlane: a few cycles per window, against a dependent
+// global load per nonzero when one lane walks alone — 80 ms per pass for the hub tile-rows of R-MAT 21 x 16).  f(is_start, begin, end, lane) runs on all 64 lanes
+// with the step's windows marked; windows are visited in pool order across steps, so prefix counts over (steps, lanes) number them exactly as the sequential walk does.
+template <class F>
+__device__ __forceinline__ void pool_windows_wave(const PoolEnt *s, long long n, unsigned width, int lane, F f)
+{
+    long long cur = 0;   // next window start (wavefront-uniform)
+    for (long long c0 = 0; c0 < n; c0 += 64) {
+        const long long i = c0 + lane;
+        int len = 0;
+        if (i < n) {   // first of the (at most 15) following nonzeros whose column is `width` or more above this one's: columns ascend, so a binary search finds it
+            const unsigned long long lim = (unsigned long long)s[i].col + width;
+            long long lo = i + 1, hi = i + 16 < n ? i + 16 : n;   // answer in [lo, hi]
+            while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((unsigned long long)s[mid].col < lim) lo = mid + 1; else hi = mid; }
+            len = (int)(lo - i);
+        }
+        unsigned long long starts = 0;
+        int at = __builtin_amdgcn_readfirstlane((int)(cur - c0));   // 0 .. 15: the last window of the step before may reach into this one
+        while (at < 64 && c0 + at < n) {
+            starts |= 1ull << at;
+            at += __builtin_amdgcn_readlane(len, at);
+        }
+        cur = c0 + at;
+        f((starts >> lane) & 1ull, i, i + len, lane);
+    }
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_pd_count_pool(const int *__restrict__ tile_ptr, int tr0, int ntr, int t_begin, unsigned width, const int *__restrict__ tp, const PoolEnt *__restrict__ pool, int *__restrict__ pool_u, int *__restrict__ pool_c, unsigned long long *__restrict__ stat /* [0] units, [1] lines */)
 {
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= ntr) return;   // (whole wavefronts leave together)
-    const int bi = tr0 + (int)i;
-    PoolEnt *scratch = pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0);
-    const long long n = pool_row_wave(T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, scratch, lane);
+    const int a = tile_ptr[tr0 + i] - t_begin, b = tile_ptr[tr0 + i + 1] - t_begin;
+    const PoolEnt *scratch = pool + tp[a];
+    const long long n = tp[b] - tp[a];
+    int nu = 0, nc = 0, nl = 0;
+    pool_windows_wave(scratch, n, width, lane, [&](bool start, long long b, long long e, int) {
+        if (!start) return;
+        if (e - b >= POOL_MIN_FILL) { nu++; nl += pool_window_lines(scratch, b, e); }
+        else nc += (int)(e - b);
+    });
+    nu = wave_sum(nu); nc = wave_sum(nc); nl = wave_sum(nl);
     if (lane != 0) return;
-    int nu, nc, nl;
-    pool_windows_count(scratch, n, width, &nu, &nc, &nl);
     pool_u[i] = nu; pool_c[i] = nc;
     if (nu) { atomicAdd(&stat[0], (unsigned long long)nu); atomicAdd(&stat[1], (unsigned long long)nl); }
 }
@@ -158,18 +188,28 @@ __global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, cons
     // the tile that emits the last unit of an unsplit tile-row of a classic plan marks it (the kernel writes y there)
     if (csr_form < 2 && !row_split[i] && p.u > u0 && p.u == pu[i + 1]) { O.udesc[p.u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; O.udesc[p.u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
 }
-__global__ __launch_bounds__(256) void k_pd_emit_pool(const Tile_matrix T, int tr0, int ntr, int t_begin, int rowA, bool coo_in_tile, unsigned width, long long stored0, PoolEnt *__restrict__ pool, const int *__restrict__ tu,
+__global__ __launch_bounds__(256) void k_pd_emit_pool(const int *__restrict__ tile_ptr, int tr0, int ntr, int t_begin, unsigned width, const int *__restrict__ tp, const PoolEnt *__restrict__ pool, const int *__restrict__ tu,
                                                         const int *__restrict__ tc, const int *__restrict__ pu, const int *__restrict__ pc, const unsigned char *__restrict__ row_k, const EmitOut O)
 {
-    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // one wavefront per tile-row (pool_row_wave above)
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // one wavefront per tile-row, over the pool the counting pass filled
     const int lane = threadIdx.x & 63;
     if (i >= ntr) return;
-    const int bi = tr0 + (int)i, a = T.tile_ptr[bi] - t_begin, b = T.tile_ptr[bi + 1] - t_begin;
-    PoolEnt *scratch = pool + ((long long)T.blknnz[T.tile_ptr[bi]] - stored0);
-    const long long n = pool_row_wave(T, bi, tile_rowlen(bi, T.tilem, rowA), coo_in_tile, scratch, lane);
-    if (lane != 0) return;
-    EmitPos p{(long long)pu[i] + tu[b] - tu[a], (long long)pc[i] + tc[b] - tc[a], 0};   // behind what the tile-row's tiles emitted themselves
-    pool_windows_emit(scratch, n, width, (unsigned)row_k[i], O, p);
+    const int a = tile_ptr[tr0 + i] - t_begin, b = tile_ptr[tr0 + i + 1] - t_begin;
+    const PoolEnt *scratch = pool + tp[a];
+    const long long n = tp[b] - tp[a];
+    long long u = (long long)pu[i] + tu[b] - tu[a], c = (long long)pc[i] + tc[b] - tc[a];   // behind what the tile-row's tiles emitted themselves
+    const bool wide = width > 16u;
+    const unsigned kr = (unsigned)row_k[i];
+    pool_windows_wave(scratch, n, width, lane, [&](bool start, long long wb, long long we, int ln) {
+        const bool unit = start && we - wb >= POOL_MIN_FILL;
+        const unsigned long long units = __ballot(unit);
+        const int ents = start && !unit ? (int)(we - wb) : 0;
+        int incl = ents;
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (ln >= d) incl += up; }
+        if (start) pool_window_put(scratch, wb, we, wide, kr, O, u + __popcll(units & ((1ull << ln) - 1ull)), c + (incl - ents));
+        u += __popcll(units);
+        c += __shfl(incl, 63, 64);
+    });
 }
 __global__ __launch_bounds__(256) void k_pd_word0(const uint4 *__restrict__ udesc, long long n, unsigned *__restrict__ out)
 {
@@ -400,8 +440,8 @@ namespace {
 
 void DevCounts::release()
 {
-    for (void *q : {(void *)tu, (void *)pool}) if (q) (void)hipFree(q);   // (tu heads the one block that holds tc, td, pool_u, pool_c too)
-    tu = tc = td = pool_u = pool_c = nullptr; pool = nullptr; csr_form = -1;
+    for (void *q : {(void *)tu, (void *)pool}) if (q) (void)hipFree(q);   // (tu heads the one block that holds tc, td, tp, pool_u, pool_c too)
+    tu = tc = td = tp = pool_u = pool_c = nullptr; pool = nullptr; csr_form = -1;
 }
 
 int dev_fetch_ints(const int *d_array, const long long *idx, int n, int *out)
@@ -426,32 +466,34 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &n
     C->release();
     C->csr_form = csr_form;
     nunits.assign((size_t)ntr, 0); ncoo.assign((size_t)ntr, 0); ndense.assign((size_t)ntr, 0);
-    // one allocation for the three per-tile prefix arrays (and the pooled counts): tu | tc | td | pool_u | pool_c
+    // one allocation for the per-tile prefix arrays (and the pooled counts): tu | tc | td | tp | pool_u | pool_c
     const size_t per = ((size_t)nt + 1 + 63) / 64 * 64, perr = ((size_t)std::max(ntr, 1) + 63) / 64 * 64;
     int *blockp = nullptr;
-    const size_t ints = 3 * per + (csr_form >= 2 ? 2 * perr : 0) + 16;
+    const size_t ints = 3 * per + (csr_form >= 2 ? per + 2 * perr : 0) + 16;
     PD_TRY(hipMalloc((void **)&blockp, ints * sizeof(int)));
     C->tu = blockp; C->tc = blockp + per; C->td = blockp + 2 * per;
+    if (csr_form >= 2) C->tp = blockp + 3 * per;
     PD_TRY(hipMemsetAsync(blockp, 0, ints * sizeof(int), 0));
     if (nt > 0) {
-        hipLaunchKernelGGL(k_pd_count_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, S.t_begin, nt, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, csr_form, C->tu, C->tc, C->td);
+        hipLaunchKernelGGL(k_pd_count_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, S.t_begin, nt, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, csr_form, C->tu, C->tc, C->td, C->tp);
         PD_TRY(hipGetLastError());
         size_t tmp_b = 0; void *tmp = nullptr;
         PD_TRY(rocprim::exclusive_scan(nullptr, tmp_b, C->tu, C->tu, 0, (size_t)nt + 1, rocprim::plus<int>(), (hipStream_t)0));
         PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
         hipError_t e = hipSuccess;
-        for (int *a : {C->tu, C->tc, C->td}) if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, tmp_b, a, a, 0, (size_t)nt + 1, rocprim::plus<int>(), (hipStream_t)0);   // (same stream: the scans run one after the other)
+        for (int *a : {C->tu, C->tc, C->td, C->tp}) if (a && e == hipSuccess) e = rocprim::exclusive_scan(tmp, tmp_b, a, a, 0, (size_t)nt + 1, rocprim::plus<int>(), (hipStream_t)0);   // (same stream: the scans run one after the other)
         if (e == hipSuccess) e = hipDeviceSynchronize();
         (void)hipFree(tmp);
         PD_TRY(e);
     }
     const double ms_tiles = lap_ms();
     if (csr_form >= 2 && ntr > 0) {
-        C->pool_u = blockp + 3 * per; C->pool_c = blockp + 3 * per + perr;
+        C->pool_u = blockp + 4 * per; C->pool_c = blockp + 4 * per + perr;
         PD_TRY(hipMalloc((void **)&C->pool, (size_t)std::max<long long>(1, S.stored) * sizeof(PoolEnt) + 16));
         Tmp<unsigned long long> d_stat;
         PD_TRY(d_stat.alloc(2, true));
-        hipLaunchKernelGGL(k_pd_count_pool, dim3(nblk((long long)ntr * 64, 256)), dim3(256), 0, 0, D->T, S.tr0, ntr, D->rowA, S.coo_in_tile, csr_form == 3 ? POOL_WIDE_WINDOW : 16u, S.stored0, C->pool, C->pool_u, C->pool_c, d_stat.p);
+        if (nt > 0) { hipLaunchKernelGGL(k_pd_fill_pool, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, S.t_begin, nt, D->rowA, S.coo_in_tile, (const int *)C->tp, C->pool); PD_TRY(hipGetLastError()); }
+        hipLaunchKernelGGL(k_pd_count_pool, dim3(nblk((long long)ntr * 64, 256)), dim3(256), 0, 0, (const int *)D->T.tile_ptr, S.tr0, ntr, S.t_begin, csr_form == 3 ? POOL_WIDE_WINDOW : 16u, (const int *)C->tp, (const PoolEnt *)C->pool, C->pool_u, C->pool_c, d_stat.p);
         PD_TRY(hipGetLastError());
         unsigned long long h_stat[2] = {0, 0};
         PD_TRY(hipMemcpy(h_stat, d_stat.p, sizeof(h_stat), hipMemcpyDeviceToHost));
@@ -506,7 +548,7 @@ int dev_emit(const DevShard &S, const DevCounts &C, const std::vector<long long>
         PD_TRY(hipGetLastError());
     }
     if (C.csr_form >= 2) {
-        hipLaunchKernelGGL(k_pd_emit_pool, dim3(nblk((long long)ntr * 64, 256)), dim3(256), 0, 0, D->T, S.tr0, ntr, S.t_begin, D->rowA, S.coo_in_tile, C.csr_form == 3 ? POOL_WIDE_WINDOW : 16u, S.stored0, C.pool, (const int *)C.tu, (const int *)C.tc, (const int *)d_pu.p,
+        hipLaunchKernelGGL(k_pd_emit_pool, dim3(nblk((long long)ntr * 64, 256)), dim3(256), 0, 0, (const int *)D->T.tile_ptr, S.tr0, ntr, S.t_begin, C.csr_form == 3 ? POOL_WIDE_WINDOW : 16u, (const int *)C.tp, (const PoolEnt *)C.pool, (const int *)C.tu, (const int *)C.tc, (const int *)d_pu.p,
                            (const int *)d_pc.p, (const unsigned char *)d_rk.p, O);
         PD_TRY(hipGetLastError());
     }

@@ -136,18 +136,22 @@ TILESPMV_HD inline long long pool_row(const Tile_matrix *T, int bi, int rowlen, 
 // upper bound of what pool_row writes for tile-row bi (its stored nonzeros)
 TILESPMV_HD inline long long pool_row_capacity(const Tile_matrix *T, int bi) { return (long long)T->blknnz[T->tile_ptr[bi + 1]] - T->blknnz[T->tile_ptr[bi]]; }
 
+// 16-column segments of x (a 128-byte line in fp64; the rule calibrated on them is kept for fp32, where wide windows lose on the same structures) the gathers of window [b, e) touch
+TILESPMV_HD inline int pool_window_lines(const PoolEnt *scratch, long long b, long long e)
+{
+    int nl = 0;
+    unsigned last = ~0u;
+    for (long long q = b; q < e; q++) { const unsigned l = scratch[q].col >> 4; if (l != last) { nl++; last = l; } }   // (columns ascend inside a window)
+    return nl;
+}
 // pooled part of a tile-row's counts: windows that are worth a unit, and the nonzeros of the others (list entries)
 // (nlines, optional: 16-column segments of x — 128-byte lines in fp64 — the units' gathers touch, summed over the units: what a wide window costs the texture path)
 TILESPMV_HD inline void pool_windows_count(const PoolEnt *scratch, long long n, unsigned width, int *nunits, int *ncoo, int *nlines)
 {
     int nu = 0, nc = 0, nl = 0;
-    constexpr unsigned LSH = 4;   // 16-column segments of x (a 128-byte line in fp64; the rule calibrated on them is kept for fp32, where wide windows lose on the same structures)
     pool_windows(n, width, [=](long long i) { return scratch[i].col; }, [&](long long b, long long e) {
-        if (e - b >= POOL_MIN_FILL) {
-            nu++;
-            unsigned last = ~0u;
-            for (long long q = b; q < e; q++) { const unsigned l = scratch[q].col >> LSH; if (l != last) { nl++; last = l; } }   // (columns ascend inside a window)
-        } else nc += (int)(e - b);
+        if (e - b >= POOL_MIN_FILL) { nu++; nl += pool_window_lines(scratch, b, e); }
+        else nc += (int)(e - b);
     });
     *nunits = nu; *ncoo = nc;
     if (nlines) *nlines = nl;
@@ -301,42 +305,47 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
     }
 }
 
-// the pooled nonzeros of tile-row bi: windows of 16 columns -> units (slot s = s-th nonzero of the window, in row order), sparse windows -> list entries
+// One window [wb, we) of a tile-row's pool: a unit at position u (slot s = s-th nonzero of the window, in row order) when it is full enough, list entries from position c on otherwise
+TILESPMV_HD inline void pool_window_put(const PoolEnt *pool, long long wb, long long we, bool wide, unsigned kr, const EmitOut &O, long long u, long long c)
+{
+    if (we - wb >= POOL_MIN_FILL) {
+        const unsigned base = pool[wb].col;
+        unsigned cn[2] = {0u, 0u}, rn[2] = {0u, 0u}, cbytes[4] = {0u, 0u, 0u, 0u};
+        // slots in ROW order (stable: columns ascending inside a row): the nonzeros of one row sit in neighbouring lanes, which is what the kernel's
+        // two interleaved copies of the slab rely on — neighbouring lanes add into different copies, so two nonzeros of a row never meet in one LDS atomic
+        int order[16], cnt[17];
+        for (int rr = 0; rr < 17; rr++) cnt[rr] = 0;
+        for (long long q = wb; q < we; q++) cnt[pool[q].row + 1]++;
+        for (int rr = 0; rr < 16; rr++) cnt[rr + 1] += cnt[rr];
+        for (long long q = wb; q < we; q++) order[cnt[pool[q].row]++] = (int)(q - wb);
+        for (int sl = 0; sl < (int)(we - wb); sl++) {
+            const PoolEnt &pe = pool[wb + order[sl]];
+            O.uval[u * 16 + sl] = pe.val;
+            if (wide) cbytes[sl >> 2] |= (pe.col - base) << (8 * (sl & 3));
+            else cn[sl >> 3] |= (pe.col - base) << (28 - 4 * (sl & 7));
+            rn[sl >> 3] |= pe.row << (28 - 4 * (sl & 7));
+        }
+        const unsigned w0 = base | (kr << POOL_KR_SHIFT);
+        if (wide) {   // (descriptor nibbles = row nibbles, column offsets as bytes beside it)
+            O.udesc[u] = make_uint4(w0, rn[0], w0, rn[1]);
+            O.ucol[u] = make_uint4(cbytes[0], cbytes[1], cbytes[2], cbytes[3]);
+        } else {
+            O.udesc[u] = make_uint4(w0, cn[0], w0, cn[1]);
+            O.urow[u] = make_uint2(rn[0], rn[1]);   // (empty slots: value 0, column offset 0, row 0 — they add 0 * x[base] to row 0 of the tile-row)
+        }
+    } else
+        for (long long q = wb; q < we; q++, c++) {
+            O.cval[c] = pool[q].val; O.ccol[c] = (int)pool[q].col;
+            O.crow[c] = (unsigned char)((kr << 4) | pool[q].row);
+        }
+}
+// the pooled nonzeros of tile-row bi: windows of 16 (or POOL_WIDE_WINDOW) columns -> units, sparse windows -> list entries
 TILESPMV_HD inline void pool_windows_emit(const PoolEnt *pool, long long n, unsigned width, unsigned kr, const EmitOut &O, EmitPos &p)
 {
     const bool wide = width > 16u;
     pool_windows(n, width, [=](long long q) { return pool[q].col; }, [&](long long wb, long long we) {
-        if (we - wb >= POOL_MIN_FILL) {
-            const unsigned base = pool[wb].col;
-            unsigned cn[2] = {0u, 0u}, rn[2] = {0u, 0u}, cbytes[4] = {0u, 0u, 0u, 0u};
-            // slots in ROW order (stable: columns ascending inside a row): the nonzeros of one row sit in neighbouring lanes, which is what the kernel's
-            // two interleaved copies of the slab rely on — neighbouring lanes add into different copies, so two nonzeros of a row never meet in one LDS atomic
-            int order[16], cnt[17];
-            for (int rr = 0; rr < 17; rr++) cnt[rr] = 0;
-            for (long long q = wb; q < we; q++) cnt[pool[q].row + 1]++;
-            for (int rr = 0; rr < 16; rr++) cnt[rr + 1] += cnt[rr];
-            for (long long q = wb; q < we; q++) order[cnt[pool[q].row]++] = (int)(q - wb);
-            for (int sl = 0; sl < (int)(we - wb); sl++) {
-                const PoolEnt &pe = pool[wb + order[sl]];
-                O.uval[p.u * 16 + sl] = pe.val;
-                if (wide) cbytes[sl >> 2] |= (pe.col - base) << (8 * (sl & 3));
-                else cn[sl >> 3] |= (pe.col - base) << (28 - 4 * (sl & 7));
-                rn[sl >> 3] |= pe.row << (28 - 4 * (sl & 7));
-            }
-            const unsigned w0 = base | (kr << POOL_KR_SHIFT);
-            if (wide) {   // (descriptor nibbles = row nibbles, column offsets as bytes beside it)
-                O.udesc[p.u] = make_uint4(w0, rn[0], w0, rn[1]);
-                O.ucol[p.u] = make_uint4(cbytes[0], cbytes[1], cbytes[2], cbytes[3]);
-            } else {
-                O.udesc[p.u] = make_uint4(w0, cn[0], w0, cn[1]);
-                O.urow[p.u] = make_uint2(rn[0], rn[1]);   // (empty slots: value 0, column offset 0, row 0 — they add 0 * x[base] to row 0 of the tile-row)
-            }
-            p.u++;
-        } else
-            for (long long q = wb; q < we; q++) {
-                O.cval[p.c] = pool[q].val; O.ccol[p.c] = (int)pool[q].col;
-                O.crow[p.c] = (unsigned char)((kr << 4) | pool[q].row); p.c++;
-            }
+        pool_window_put(pool, wb, we, wide, kr, O, p.u, p.c);
+        if (we - wb >= POOL_MIN_FILL) p.u++; else p.c += we - wb;
     });
 }
 TILESPMV_HD inline void pool_row_emit(const Tile_matrix *T, int bi, int rowlen, bool coo_in_tile, unsigned kr, const long long *hyb_off, unsigned width, PoolEnt *pool, const EmitOut &O, EmitPos &p)
