@@ -263,45 +263,86 @@ __global__ __launch_bounds__(256) void k_pe_keys(const STask *__restrict__ tasks
         }
     }
 }
-// one thread per group: sizes of its packed list (+ the plan fact "entries far from the group's own rows")
-__global__ __launch_bounds__(64) void k_pe_sizes(const STask *__restrict__ tasks, int ntasks, const int *__restrict__ ofs, int nwg, int GS, int dest_bits, bool count_far, const u64 *__restrict__ key,
-                                                  int *__restrict__ nrec, int *__restrict__ nchunk, unsigned long long *__restrict__ far_total)
+// The chunk walk (plan_tile_ops.h pack_chunks) by a wavefront: one chunk of ECHUNK = 64 records per step, one record per lane.  Columns ascend along a list, so the entries that
+// fit the chunk's column range are a prefix of the next 64: its length is the first zero of a ballot.  f(begin, count, base, padded) runs on all 64 lanes.
+static_assert(ECHUNK == 64, "one record of a chunk per lane");
+template <class F>
+__device__ __forceinline__ void pack_chunks_wave(const u64 *__restrict__ K, long long n, int dest_bits, int lane, F f)
 {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 span = 1ull << (32 - dest_bits);
+    long long i = 0;
+    while (i < n) {   // (wavefront-uniform)
+        const unsigned b = (unsigned)K[i];
+        const long long q = i + lane;
+        const bool in = q < n && (u64)(unsigned)K[q] - b < span;
+        const u64 out = ~__ballot(in);
+        const int cnt = out ? __ffsll((unsigned long long)out) - 1 : 64;   // >= 1: the chunk's first entry defines the base
+        f(i, cnt, b, i + cnt < n);   // interior chunks are filled up with null records
+        i += cnt;
+    }
+}
+// one wavefront per group: sizes of its packed list (+ the plan fact "entries far from the group's own rows")
+__global__ __launch_bounds__(256) void k_pe_sizes(const STask *__restrict__ tasks, int ntasks, const int *__restrict__ ofs, int nwg, int GS, int dest_bits, bool count_far, const u64 *__restrict__ key,
+                                                   int *__restrict__ nrec, int *__restrict__ nchunk, unsigned long long *__restrict__ far_total)
+{
+    const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (w >= nwg) return;
-    const int t0 = w * GS, t1 = min(ntasks, t0 + GS);
+    const int t0 = (int)w * GS, t1 = min(ntasks, t0 + GS);
     const u64 *K = key + ofs[t0];
     const long long n = ofs[t1] - ofs[t0];
     int nr = 0, nc = 0;
-    pack_chunks(n, dest_bits, [=](long long i) { return (unsigned)K[i]; }, [&](long long, unsigned) { nr++; }, [&]() { nr++; }, [&](unsigned) { nc++; });
-    nrec[w] = nr; nchunk[w] = nc;
+    pack_chunks_wave(K, n, dest_bits, lane, [&](long long, int cnt, unsigned, bool padded) { nr += padded ? ECHUNK : cnt; nc++; });
+    if (lane == 0) { nrec[w] = nr; nchunk[w] = nc; }
     if (count_far) {
-        long long own_lo = LLONG_MAX, own_hi = LLONG_MIN, far = 0;
+        long long own_lo = LLONG_MAX, own_hi = LLONG_MIN;
         for (int t = t0; t < t1; t++) { own_lo = min(own_lo, 16LL * tasks[t].row); own_hi = max(own_hi, 16LL * (tasks[t].row + max(1, tasks[t].nrows))); }
-        for (long long i = 0; i < n; i++) { const long long c = (unsigned)K[i]; far += !(c >= own_lo - 2048 && c < own_hi + 2048); }
-        if (far) atomicAdd(far_total, (unsigned long long)far);
+        int far = 0;
+        for (long long i = lane; i < n; i += 64) { const long long c = (unsigned)K[i]; far += !(c >= own_lo - 2048 && c < own_hi + 2048); }
+        far = wave_sum(far);
+        if (lane == 0 && far) atomicAdd(far_total, (unsigned long long)far);
     }
 }
-// one thread per group: its records, chunk bases and (panelled plans) panel offsets
-__global__ __launch_bounds__(64) void k_pe_write(int ntasks, const int *__restrict__ ofs, int nwg, int GS, int dest_bits, const u64 *__restrict__ key, const int *__restrict__ src, const unsigned short *__restrict__ dest_q,
-                                                  const val_t *__restrict__ cval, const int4 *__restrict__ wg, ERec *__restrict__ rec, unsigned *__restrict__ base, int NP, int panel_shift, int *__restrict__ panel_off)
+// one wavefront per group: its records, chunk bases and (panelled plans) panel offsets — panel_offsets' running maximum (plan_tile_ops.h) as a max-scan over the chunk's lanes
+__global__ __launch_bounds__(256) void k_pe_write(int ntasks, const int *__restrict__ ofs, int nwg, int GS, int dest_bits, const u64 *__restrict__ key, const int *__restrict__ src, const unsigned short *__restrict__ dest_q,
+                                                   const val_t *__restrict__ cval, const int4 *__restrict__ wg, ERec *__restrict__ rec, unsigned *__restrict__ base, int NP, int panel_shift, int *__restrict__ panel_off)
 {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (w >= nwg) return;
-    const int t0 = w * GS, t1 = min(ntasks, t0 + GS);
+    const int t0 = (int)w * GS, t1 = min(ntasks, t0 + GS);
     const u64 *K = key + ofs[t0]; const int *Q = src + ofs[t0];
     const long long n = ofs[t1] - ofs[t0];
     const int4 g = wg[w];
     ERec *R = rec + g.x; unsigned *B = base + g.z;
+    int *off = NP > 1 ? panel_off + (size_t)w * (size_t)(NP + 1) : nullptr;
     long long r = 0, c = 0;
-    pack_chunks(n, dest_bits, [=](long long i) { return (unsigned)K[i]; },
-                [&](long long i, unsigned b) { const int q = Q[i]; R[r++] = make_erec(cval[q], (((unsigned)K[i] - b) << dest_bits) | dest_q[q]); },
-                [&]() { R[r++] = make_erec((val_t)0, 0u); }, [&](unsigned b) { B[c++] = b; });
-    if (NP > 1) {
-        int *off = panel_off + (size_t)w * (size_t)(NP + 1);
-        off[0] = 0;
-        panel_offsets(R, (long long)(g.y - g.x), B, dest_bits, panel_shift, NP, off);
-        for (int q = 0; q <= NP; q++) off[q] += g.x;   // absolute record indices
+    unsigned cur = 0;   // panel of the record before (wavefront-uniform)
+    pack_chunks_wave(K, n, dest_bits, lane, [&](long long i, int cnt, unsigned b, bool padded) {
+        unsigned wv = 0; bool null_like = true;
+        const bool have = lane < cnt || padded;
+        if (lane < cnt) {
+            const int q = Q[i + lane];
+            wv = (((unsigned)K[i + lane] - b) << dest_bits) | dest_q[q];
+            const ERec e = make_erec(cval[q], wv);
+            R[r + lane] = e;
+            null_like = erec_is_null(e);
+        } else if (padded) R[r + lane] = make_erec((val_t)0, 0u);
+        if (lane == 0) B[c] = b;
+        if (off) {
+            unsigned e = have && !(null_like && lane != 0) ? (b + (wv >> dest_bits)) >> panel_shift : 0u;   // (0 leaves the running maximum alone)
+            for (int d = 1; d < 64; d <<= 1) { const unsigned up = __shfl_up(e, d, 64); if (lane >= d) e = max(e, up); }
+            const unsigned pnl = max(cur, e);
+            unsigned prev = __shfl_up(pnl, 1, 64);
+            if (lane == 0) prev = cur;
+            if (have) for (unsigned p = prev + 1; p <= pnl; p++) off[p] = g.x + (int)(r + lane);   // absolute record indices
+            cur = __shfl(pnl, 63, 64);
+        }
+        r += padded ? ECHUNK : cnt; c++;
+    });
+    if (off && lane == 0) {
+        off[0] = g.x;
+        for (unsigned p = cur + 1; p <= (unsigned)NP; p++) off[p] = g.x + (int)r;
     }
 }
 
@@ -404,7 +445,7 @@ int dev_entry_lists(const val_t *d_cval, const int *d_ccol, const unsigned char 
         PD_TRY(e);
         K = kb.current(); Q = vb.current();
     }
-    hipLaunchKernelGGL(k_pe_sizes, dim3(nblk(nwg, 64)), dim3(64), 0, 0, (const STask *)d_tasks.p, ntasks, (const int *)d_ofs.p, nwg, GS, dest_bits, count_scattered, K, d_nrec.p, d_nchunk.p, d_far.p);
+    hipLaunchKernelGGL(k_pe_sizes, dim3(nblk((long long)nwg * 64, 256)), dim3(256), 0, 0, (const STask *)d_tasks.p, ntasks, (const int *)d_ofs.p, nwg, GS, dest_bits, count_scattered, K, d_nrec.p, d_nchunk.p, d_far.p);
     PD_TRY(hipGetLastError());
     std::vector<int> nrec((size_t)nwg), nchunk((size_t)nwg);
     unsigned long long far = 0;
@@ -424,7 +465,7 @@ int dev_entry_lists(const val_t *d_cval, const int *d_ccol, const unsigned char 
     PD_TRY(hipMalloc((void **)&L->d_base, std::max<long long>(n_chunk, 1) * sizeof(unsigned) + 256));
     const int NP = x_panels;
     if (NP > 1) PD_TRY(hipMalloc((void **)&L->d_panel_off, (size_t)nwg * (size_t)(NP + 1) * sizeof(int) + 256));
-    hipLaunchKernelGGL(k_pe_write, dim3(nblk(nwg, 64)), dim3(64), 0, 0, ntasks, (const int *)d_ofs.p, nwg, GS, dest_bits, K, Q, (const unsigned short *)d_dest.p, d_cval, (const int4 *)d_wg.p, L->d_rec, L->d_base, NP,
+    hipLaunchKernelGGL(k_pe_write, dim3(nblk((long long)nwg * 64, 256)), dim3(256), 0, 0, ntasks, (const int *)d_ofs.p, nwg, GS, dest_bits, K, Q, (const unsigned short *)d_dest.p, d_cval, (const int4 *)d_wg.p, L->d_rec, L->d_base, NP,
                        panel_shift, L->d_panel_off);
     PD_TRY(hipGetLastError());
     PD_TRY(hipDeviceSynchronize());

@@ -378,6 +378,12 @@ void StreamBuilder::choose()
     entry_mode = wave_coo_env >= 0 ? std::min(2, wave_coo_env) : (!entry_heavy ? 0 : est_wgs < 768 ? 1 : 2);
     wave_coo = entry_mode != 0;
     plan->entry_mode = entry_mode;
+    if (getenv("TILESPMV_PLAN_VERBOSE")) {
+        long long rows_over16 = 0;   // tile-rows with more entries than travel with a strip's prologue
+        for (int i = 0; i < ntr; i++) rows_over16 += rc_[i].ncoo > 16;
+        fprintf(stderr, "tilespmv: choose: %d tile-rows, %lld units + %lld entries (%.1f per tile-row, %lld tile-rows with more than 16), cost %lld (%.0f per tile-row) -> strips of %d, ~%lld workgroups, entry mode %d\n",
+                ntr, NU, NC, ntr ? (double)NC / ntr : 0.0, rows_over16, total_cost, ntr ? (double)total_cost / ntr : 0.0, target, est_wgs, entry_mode);
+    }
     // strips per workgroup: 32 (512 threads) only on request and only with the workgroup entry mode — twice as many tile-rows share
     // one column-ordered list (power-law 8 M rows: 0.204 -> 0.152 distinct 128-B x lines per entry) at the same 6 waves per SIMD, but
     // it measures slower everywhere (power-law 8 M 0.1038 -> 0.1072 ms, webbase-like 13.1 -> 13.9 us, KKT fp64 equal): default 16

@@ -387,17 +387,21 @@ TILESPMV_HD inline ERec make_erec(val_t v, unsigned w)
 // Where each column panel (2^panel_shift columns) begins in a PACKED list of nrec records (bases B per chunk): off[0 .. NP], relative to the list's begin (off[0] is the
 // caller's).  Records are in column order except that the null padding of a chunk closed early repeats the chunk's first column — padding counts as part of the panel of
 // the record before it (it adds 0 * x[.] to the group's first row whichever pass executes it).
+TILESPMV_HD inline bool erec_is_null(const ERec &rr)   // all bits zero: a padding record, or an entry with value +0, offset 0 and destination 0 (which adds nothing either)
+{
+#if defined(TILESPMV_F32)
+    return rr.w == 0u && rr.v == 0u;
+#else
+    return rr.w == 0u && rr.lo == 0u && rr.hi == 0u;
+#endif
+}
 TILESPMV_HD inline void panel_offsets(const ERec *R, long long nrec, const unsigned *B, int dest_bits, int panel_shift, int NP, int *off)
 {
     unsigned cur = 0;   // panel of the previous record
     int nextp = 1;
     for (long long i = 0; i < nrec; i++) {
         const ERec &rr = R[i];
-#if defined(TILESPMV_F32)
-        const bool null_like = rr.w == 0u && rr.v == 0u;
-#else
-        const bool null_like = rr.w == 0u && rr.lo == 0u && rr.hi == 0u;
-#endif
+        const bool null_like = erec_is_null(rr);
         const unsigned here = (B[i / ECHUNK] + (rr.w >> dest_bits)) >> panel_shift;
         const unsigned pnl = null_like && i % ECHUNK != 0 ? cur : (cur > here ? cur : here);
         while (nextp <= (int)pnl) off[nextp++] = (int)i;
