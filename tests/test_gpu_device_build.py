@@ -130,6 +130,31 @@ def torch_cuda():
     return torch
 
 
+@pytest.mark.gpu
+def test_device_built_plan_hub_tile_rows(torch_cuda):
+    """Tile-rows that pool tens of thousands of nonzeros from thousands of tiny tiles (R-MAT / web-graph hubs): the device builder fills the pool by one thread per tile at scanned offsets and
+    walks the windows with one wavefront per tile-row, 64 candidates per step (windows that straddle steps, chains of one-nonzero windows, full 16-nonzero windows), and packs the entry
+    lists one 64-record chunk per step — all of it must give the host builder's streams bit for bit."""
+    rng = np.random.default_rng(77)
+    n = 60000
+    rows_of, cols_of = [], []
+    for r in (0, 1, 5, 15, 16, 40, 333, 334):            # hub rows: three in the first tile-row, one alone, two sharing tile-row 20
+        k = int(rng.integers(3000, 30000))
+        c = np.unique(np.concatenate([rng.integers(0, n, k), np.arange(2000, 2000 + 700)]))   # scattered columns + a dense run (full windows)
+        rows_of.append(np.full(len(c), r)); cols_of.append(c)
+    k = 4 * n
+    rows_of.append(rng.integers(0, n, k)); cols_of.append(rng.integers(0, n, k))                # the rest: 4 per row
+    rows_of.append(np.arange(n)); cols_of.append(np.arange(n))
+    import scipy.sparse as sp
+    A = sp.csr_matrix((np.ones(sum(len(q) for q in rows_of)), (np.concatenate(rows_of), np.concatenate(cols_of))), shape=(n, n))
+    A.sum_duplicates(); A.sort_indices()
+    rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    for knobs in (dict(csr_split=2), dict(csr_split=3), dict(csr_split=2, entry_mode=2), dict(csr_split=3, entry_mode=1), dict(entry_mode=2, x_panel_kb=1, x_panel_merge=1), dict()):
+        same_plan(torch_cuda, n, n, rp, ci, np.float64, knobs)
+    same_plan(torch_cuda, n, n, rp, ci, np.float32, dict(csr_split=3, entry_mode=2))
+    same_plan(torch_cuda, n, n, rp, ci, np.float64, dict(csr_split=2), shard=(0, 21))
+
+
 @pytest.mark.parametrize("name", sorted(cases.SMALL) + sorted(cases.MEDIUM))
 def test_device_built_plan_equals_host_built_plan(torch_cuda, name):
     rows, cols, rp, ci = (cases.SMALL.get(name) or cases.MEDIUM[name])()
