@@ -26,6 +26,7 @@ for wl in sys.argv[1].split(","):
         ms_h = ph.time(xd.data_ptr(), yh.data_ptr(), 0, 5, 20); ms_d = pd.time(xd.data_ptr(), yd.data_ptr(), 0, 5, 20)
         i = pd.info()
         hi = ph.info()
-        print("%s rep %d: host Tile_create %.3f s + plan create %.3f s = %.3f s (timed choices %.0f ms) | from_csr %.3f s (device Tile_create %.3f s incl. CSR upload; timed choices %.0f ms), from a device-resident CSR %.3f s | streams identical: %s, y identical: %s (plan-fixed summation order: %s) | SpMV %.4f / %.4f ms"
-              % (wl, rep, t_tc, t_pc, t_tc + t_pc, hi["timed_choices_us"] * 1e-3, t_dev, i["tile_create_us"] * 1e-6, i["timed_choices_us"] * 1e-3, t_dd, same, bool(torch.equal(yh, yd)), bool(hi["entry_ordered"] and i["entry_ordered"]), ms_h, ms_d), flush=True)
+        print("%s rep %d: host Tile_create %.3f s + plan create %.3f s = %.3f s (timed choices %.0f ms) | from_csr %.3f s (device Tile_create %.3f s incl. CSR upload; timed choices %.0f ms), from a device-resident CSR %.3f s | streams identical: %s, y identical: %s (plan-fixed summation order: %s, same timed launch form: %s) | SpMV %.4f / %.4f ms"
+              % (wl, rep, t_tc, t_pc, t_tc + t_pc, hi["timed_choices_us"] * 1e-3, t_dev, i["tile_create_us"] * 1e-6, i["timed_choices_us"] * 1e-3, t_dd, same, bool(torch.equal(yh, yd)), bool(hi["entry_ordered"] and i["entry_ordered"]),
+                 all(hi[k] == i[k] for k in ("x_panels", "x_panel_merge", "x_slice_passes")), ms_h, ms_d), flush=True)
         ph.close(); pd.close(); api.Tile_destroy(tm)

@@ -720,6 +720,52 @@ def test_spmv_is_capturable_into_a_hip_graph(torch_cuda):
     api.Tile_destroy(tp)
 
 
+@pytest.mark.gpu
+def test_panelled_plans_with_split_rows_sum_in_a_fixed_order(torch_cuda):
+    """A plan that says its sums are ordered (TILESPMV_INFO_ENTRY_ORDERED = 1) must give the same bits launch after launch on REAL-valued data — also when its entry lists run as column
+    panels and heavy tile-rows are split into pieces: each piece adds its panel sums to its own slot and k_fixup_split adds the slots up in slot order behind the last pass (until the
+    second half of round 5 the pieces were added into y atomically: R-MAT 22 x 8 differed between two launches of one plan).  Same for the multi-vector entry pass."""
+    from tilespmv_amd import api, generators as G
+    m, n, rp, ci = G.rmat(16, 12, 5)
+    rowA, nnz = truncated_rows(m), int(rp[truncated_rows(m)])
+    vals, x = G.real_values(nnz, np.float64), G.real_x(n, nnz, np.float64)
+    tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
+    xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda()
+    ref = None
+    import scipy.sparse as sp
+    want = sp.csr_matrix((vals[:nnz], ci[:nnz], rp[:rowA + 1]), shape=(rowA, n)) @ x
+    for kw in (dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1, strip_cost=64, split_above=200, entry_ordered=1), dict(entry_mode=2, x_panel_kb=64, x_panel_merge=2, split_above=400, entry_ordered=1),
+               dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1, strip_cost=64, split_above=200, entry_ordered=1, fix_inline=0)):
+        plan = api.Plan(tp, rowA, n, nnz, placement_tries=1, **kw)
+        info = plan.info()
+        assert info["x_panels"] > 1 and info["num_split_rows"] > 0 and info["entry_ordered"] == 1, info
+        ys = []
+        for it in range(4):
+            yd = torch_cuda.full((rowA + 16,), 7.0, dtype=xd.dtype, device="cuda")
+            plan.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()
+            ys.append(yd.cpu().numpy()[:rowA].copy())
+        for it in range(1, 4):
+            assert np.array_equal(ys[0], ys[it]), (kw, "launch", it, int(np.count_nonzero(ys[0] != ys[it])))
+        assert np.allclose(ys[0], want, rtol=1e-10, atol=1e-10 * np.abs(want).max())
+        # a second plan of the same options: the same bits
+        plan2 = api.Plan(tp, rowA, n, nnz, placement_tries=1, **kw)
+        yd = torch_cuda.zeros(rowA + 16, dtype=xd.dtype, device="cuda"); plan2.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()
+        assert np.array_equal(ys[0], yd.cpu().numpy()[:rowA]), kw
+        plan2.close(); plan.close()
+    # the multi-vector entry pass (nvec 2 on an entry-dominated plan) with split rows
+    plan = api.Plan(tp, rowA, n, nnz, placement_tries=1, entry_mode=2, strip_cost=64, split_above=200, entry_ordered=1, x_panel_kb=0)
+    assert plan.info()["num_split_rows"] > 0
+    X = np.ascontiguousarray(np.stack([x, x[::-1]], axis=1)); Xd = torch_cuda.from_numpy(X).cuda()
+    Ys = []
+    for it in range(3):
+        Yd = torch_cuda.zeros((rowA + 16, 2), dtype=Xd.dtype, device="cuda"); plan.spmm(Xd.data_ptr(), Yd.data_ptr(), 2); torch_cuda.cuda.synchronize()
+        Ys.append(Yd.cpu().numpy()[:rowA].copy())
+    assert np.array_equal(Ys[0], Ys[1]) and np.array_equal(Ys[0], Ys[2])
+    assert np.allclose(Ys[0][:, 0], want, rtol=1e-10, atol=1e-10 * np.abs(want).max())
+    plan.close()
+    api.Tile_destroy(tp)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_column_panels_bit_exact(torch_cuda, dtype):
     """Round 4: column panels of the merged entry lists — the first run of panels with the unit kernel, one k_entries_acc launch (y +=) per further run.  The oracle's y bit for bit

@@ -1109,11 +1109,13 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
 // of 16 strips, the same records and trip routine, row sums in the same LDS slabs, then y += for the strips that have entries.  Why launches: on scattered matrices with
 // a large x every gather misses the XCD's L2 and pulls a 128-byte line across the fabric (profiles/r04_pmc_*_before.json); the workgroups would have to sweep x TOGETHER
 // for the lines to be shared, and a kernel boundary is the one chip-wide synchronisation that costs microseconds instead of the polls and timetables of S6.17 — inside one
-// launch every gather of the chip falls into one panel.  The price is the read-modify-write of y per pass.  Pieces of split tile-rows add atomically (their row was written
-// by the piece that finished last in k_units).
+// launch every gather of the chip falls into one panel.  The price is the read-modify-write of y per pass.  A piece of a split tile-row adds its sums to ITS slot of the
+// partial sums (nobody else writes that slot, and the passes are launches in stream order); launch_entry_panels runs k_fixup_split over all split rows behind the last pass, which
+// adds the slots up in slot order — so a panelled plan's sums are as reproducible as the plain launch's.  (Rounds 4-5 added the pieces into y atomically: on R-MAT 22 x 8, 4,048 split
+// rows, two runs of ONE plan differed in 5 k rows' last bits while the plan's facts said "ordered" — scripts/rounds/r5b_repro_check.py.)
 // ------------------------------------------------------------------------------------------------
 template <int XCD_REMAP, bool NTS>
-__global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream S, int rowA, int xcd_chunk, int panel, const val_t *__restrict__ x, val_t *__restrict__ y)
+__global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream S, int rowA, int xcd_chunk, int panel, val_t *__restrict__ partial, const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     __shared__ lacc_t s_acc[GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
@@ -1149,8 +1151,8 @@ __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream 
     if (!side) return;
     const lacc_t *mine = s_acc + g * (STRIP_MAX_ROWS * 16);
     if (part >= 0) {
-        const long long yi = (long long)row0 * 16 + r;
-        if (yi < rowA) atomicAdd(&y[yi], (val_t)mine[r]);
+        val_t *slot = partial + (long long)part * 16 + r;
+        *slot = (val_t)((lacc_t)*slot + mine[r]);
     } else {
 #pragma unroll
         for (int k = 0; k < STRIP_MAX_ROWS; k++) {
@@ -1225,16 +1227,18 @@ hipError_t launch_entry_slices(const DevStream &S, int rowA, const val_t *x, val
     return hipGetLastError();
 }
 
-hipError_t launch_entry_panels(const DevStream &S, int rowA, int xcd_remap, int xcd_chunk, const val_t *x, val_t *y, hipStream_t st)
+hipError_t launch_entry_panels(const DevPlan &P, const DevStream &S, int xcd_remap, int xcd_chunk, const val_t *x, val_t *y, hipStream_t st)
 {
-    const int passes = (S.x_panels + S.panel_merge - 1) / S.panel_merge;
+    const int passes = (S.x_panels + S.panel_merge - 1) / S.panel_merge, rowA = P.rowA;
     for (int p = 1; p < passes; p++) {
         const dim3 grid((unsigned)S.n_groups), blk(256);
-        if (xcd_remap == 2) { if (S.nt_stream) hipLaunchKernelGGL((k_entries_acc<2, true>), grid, blk, 0, st, S, rowA, xcd_chunk, p, x, y);
-                              else hipLaunchKernelGGL((k_entries_acc<2, false>), grid, blk, 0, st, S, rowA, xcd_chunk, p, x, y); }
-        else { if (S.nt_stream) hipLaunchKernelGGL((k_entries_acc<0, true>), grid, blk, 0, st, S, rowA, xcd_chunk, p, x, y);
-               else hipLaunchKernelGGL((k_entries_acc<0, false>), grid, blk, 0, st, S, rowA, xcd_chunk, p, x, y); }
+        if (xcd_remap == 2) { if (S.nt_stream) hipLaunchKernelGGL((k_entries_acc<2, true>), grid, blk, 0, st, S, rowA, xcd_chunk, p, P.partial, x, y);
+                              else hipLaunchKernelGGL((k_entries_acc<2, false>), grid, blk, 0, st, S, rowA, xcd_chunk, p, P.partial, x, y); }
+        else { if (S.nt_stream) hipLaunchKernelGGL((k_entries_acc<0, true>), grid, blk, 0, st, S, rowA, xcd_chunk, p, P.partial, x, y);
+               else hipLaunchKernelGGL((k_entries_acc<0, false>), grid, blk, 0, st, S, rowA, xcd_chunk, p, P.partial, x, y); }
     }
+    // the split rows once more, now that their pieces' slots hold the entries of every panel (slot order: the plan's)
+    if (passes > 1 && P.nfix > 0) hipLaunchKernelGGL(k_fixup_split, dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, y);
     return hipGetLastError();
 }
 
@@ -1848,7 +1852,7 @@ __global__ __launch_bounds__(256, WIDE ? 5 : MV_MIN_WAVES) void k_pool_mv(DevStr
 // right-hand side at a time below nvec 8 (webbase-like: 40 / 83 us for nvec 2 / 4).
 // ------------------------------------------------------------------------------------------------
 template <int NVT>
-__global__ __launch_bounds__(256) void k_entries_mv(DevStream S, int rowA, const val_t *__restrict__ X, val_t *__restrict__ Y)
+__global__ __launch_bounds__(256) void k_entries_mv(DevStream S, int rowA, val_t *__restrict__ partial, const val_t *__restrict__ X, val_t *__restrict__ Y)
 {
     constexpr int NP = NVT / 2, CT = 4;
     typedef MVec<2> vec_t;
@@ -1898,12 +1902,10 @@ __global__ __launch_bounds__(256) void k_entries_mv(DevStream S, int rowA, const
         }
         __syncthreads();
         if (side) {
-            if (part >= 0) {   // piece of a split tile-row: k_fixup_split_mv has written the row; the piece's entry sums are added atomically
-                const long long yi = (long long)row0 * 16 + r;
-                if (yi < rowA) {
-                    atomicAdd(&Y[(yi * NP + p) * 2 + 0], (val_t)s_acc[g * (STRIP_MAX_ROWS * 16) + r][0]);
-                    atomicAdd(&Y[(yi * NP + p) * 2 + 1], (val_t)s_acc[g * (STRIP_MAX_ROWS * 16) + r][1]);
-                }
+            if (part >= 0) {   // piece of a split tile-row: the entry sums join the piece's own slot; k_fixup_split_mv adds the slots up afterwards, in slot order (no atomics: reproducible)
+                val_t *slot = partial + (((long long)part * 16 + r) * NP + p) * 2;
+                slot[0] = (val_t)((lacc_t)slot[0] + s_acc[g * (STRIP_MAX_ROWS * 16) + r][0]);
+                slot[1] = (val_t)((lacc_t)slot[1] + s_acc[g * (STRIP_MAX_ROWS * 16) + r][1]);
             } else {
                 for (int k = 0; k < nrows; k++) {
                     const long long yi = ((long long)row0 + k) * 16 + r;
@@ -2014,10 +2016,10 @@ static hipError_t launch_mv(const DevPlan &P, const DevStream &S, const DevDense
     }
     if (DN.nrows > 0)
         hipLaunchKernelGGL((k_dense_mfma_mv<NV>), dim3((DN.nrows + 3) / 4), dim3(256), 0, st, DN, P.rowA, P.colA, P.partial, X, Y);
-    if (P.nfix > 0)
+    if (entries_pass && !S.pooled && S.ntasks > 0)   // Y += entries (after the units and the dense pass have written Y; pieces of split rows: into their slots)
+        hipLaunchKernelGGL((k_entries_mv<NV>), dim3((unsigned)((S.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), dim3(256), 0, st, S, P.rowA, P.partial, X, Y);
+    if (P.nfix > 0)   // the split rows last: slot order
         hipLaunchKernelGGL((k_fixup_split_mv<NV>), dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, Y);
-    if (entries_pass && !S.pooled && S.ntasks > 0)   // Y += entries (after the units, the dense pass and the split-row sums have written Y)
-        hipLaunchKernelGGL((k_entries_mv<NV>), dim3((unsigned)((S.ntasks + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), dim3(256), 0, st, S, P.rowA, X, Y);
     return hipGetLastError();
 }
 
@@ -2137,7 +2139,7 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
         hipLaunchKernelGGL(k_fixup_split, dim3((Q.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, Q, y);
     }
     if (S.slice_passes > 0 && S.x_panels > 1 && S.ntasks > 0) return launch_entry_slices(S, P.rowA, x, y, st);   // the lists, by column slices pinned to XCDs
-    if (S.panel_merge > 0 && S.x_panels > S.panel_merge && S.ntasks > 0) return launch_entry_panels(S, P.rowA, xcd_remap, xcd_chunk, x, y, st);   // y += the entries of the other column panels, last: every row has been written
+    if (S.panel_merge > 0 && S.x_panels > S.panel_merge && S.ntasks > 0) return launch_entry_panels(P, S, xcd_remap, xcd_chunk, x, y, st);   // y += the entries of the other column panels, last: every row has been written
     return hipGetLastError();
 }
 
