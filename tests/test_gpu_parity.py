@@ -769,7 +769,7 @@ def test_panelled_plans_with_split_rows_sum_in_a_fixed_order(torch_cuda):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_column_panels_bit_exact(torch_cuda, dtype):
     """Round 4: column panels of the merged entry lists — the first run of panels with the unit kernel, one k_entries_acc launch (y +=) per further run.  The oracle's y bit for bit
-    with 2 ... 64 passes, ordered and unordered adds, split tile-rows (their pieces add atomically), tiny strips, both descriptor forms; repeated launches on one plan; and the
+    with 2 ... 64 passes, ordered and unordered adds, split tile-rows (their pieces add to their slots, summed behind the last pass), tiny strips, both descriptor forms; repeated launches on one plan; and the
     multi-vector product on a panelled plan (which must not take the entry pass over panel 0 alone)."""
     from oracle.oracle import CpuImpl
     from tilespmv_amd import api, generators as G
@@ -1110,7 +1110,7 @@ def test_spmm_one_at_a_time_scratch_is_reserved_and_aligned(torch_cuda, dtype):
 def test_spmm_entry_pass_on_entry_dominated_plans(torch_cuda, dtype):
     """Round 3: entry-dominated plans with the workgroup entry mode multiply their merged, column-ordered lists in a multi-vector
     pass of their own (k_entries_mv: Y += A_entries X after k_units_mv) instead of going one right-hand side at a time — also with
-    split tile-rows (pieces add atomically) and with unordered adds.  Every column == the oracle, exactly (integer data)."""
+    split tile-rows (pieces add to their slots; the split-row sums run last) and with unordered adds.  Every column == the oracle, exactly (integer data)."""
     from oracle.oracle import CpuImpl
     from tilespmv_amd import api
     O = CpuImpl("oracle", dtype)

@@ -1848,7 +1848,7 @@ __global__ __launch_bounds__(256, WIDE ? 5 : MV_MIN_WAVES) void k_pool_mv(DevStr
 // the same merged, column-ordered, packed lists k_units<.., 2> walks, two right-hand sides per pass (one 16-byte gather per entry and lane
 // in fp64), NVT / 2 passes over the workgroup's list (the list of a workgroup is ~80 KB: the later passes find it in L2).  Row sums of
 // a pass are accumulated in LDS (2,048 rows x 2 values) exactly like the single-vector kernel does, then added to Y, which k_units_mv
-// (skip_entries) has written before.  Pieces of split tile-rows add their sums atomically.  Entry-dominated plans used to run one
+// (skip_entries) has written before.  Pieces of split tile-rows add their sums to their own slot of the partial sums (k_fixup_split_mv runs behind this pass).  Entry-dominated plans used to run one
 // right-hand side at a time below nvec 8 (webbase-like: 40 / 83 us for nvec 2 / 4).
 // ------------------------------------------------------------------------------------------------
 template <int NVT>
