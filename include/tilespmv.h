@@ -456,7 +456,8 @@ enum {
     TILESPMV_INFO_BUILD_US = 11,      /* host time of the re-layout (plan build), microseconds */
     TILESPMV_INFO_UPLOAD_US = 12,     /* hipMalloc + hipMemcpy time of the plan's streams, microseconds */
     TILESPMV_INFO_ENTRY_MODE = 13,    /* COO entry lists run per strip (0), per wavefront (1), per workgroup (2) */
-    TILESPMV_INFO_ENTRY_ORDERED = 14, /* 1: the order of the additions is fixed by the plan (bit-reproducible y) */
+    TILESPMV_INFO_ENTRY_ORDERED = 14, /* 1: the order of the additions is fixed by the plan (bit-reproducible y: every launch of this plan, and every plan of the same facts, host- or device-built —
+                                         column-panel passes and split tile-rows included; tests/test_gpu_parity.py::test_panelled_plans_with_split_rows_sum_in_a_fixed_order, scripts/reproducibility_sweep.py) */
     TILESPMV_INFO_STRIP_COST = 15,    /* strip size target the plan was cut with */
     TILESPMV_INFO_WG_STRIPS = 16,     /* strips per workgroup of the unit kernel (16 or 32) */
     TILESPMV_INFO_X_WINDOW_SLOTS = 17,    /* x-window plans: column blocks of the largest workgroup window (0 = no windows) */

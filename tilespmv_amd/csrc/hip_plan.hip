@@ -309,7 +309,24 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
                  first ? "" : ", ", label, p->coo_mode, p->dense_mode, p->entry_mode, p->info[TILESPMV_INFO_ENTRY_ORDERED], p->info[TILESPMV_INFO_STRIP_COST],
                  p->info[TILESPMV_INFO_NUM_TASKS], ms);
         log += buf; first = false;
-        if (ms > 0 && (!best || ms < best_ms * 0.985)) { tilespmv_plan_destroy(best); best = p; best_ms = ms; }  // a later candidate must be clearly better
+        // a later candidate must be clearly better — and be it twice: 12 launches decide at the level of the run-to-run noise (the receipts of round 5 had four workloads where the
+        // "winner" lost 3-7 % to the default on re-measurement), so a challenger that is ahead is timed again, alternating with the holder, over 2 x 20 launches each
+        bool take = ms > 0 && (!best || ms < best_ms * 0.985);
+        double ms_c = ms;
+        if (take && best) {
+            double hold = best_ms, chal = ms;
+            for (int rep = 0; rep < 2; rep++) {
+                const double h = tilespmv_plan_time(best, dx, dy, nullptr, 2, 20), c = tilespmv_plan_time(p, dx, dy, nullptr, 2, 20);
+                if (h > 0) hold = rep ? std::min(hold, h) : h;
+                if (c > 0) chal = rep ? std::min(chal, c) : c;
+            }
+            take = chal < hold * 0.985;
+            best_ms = hold; ms_c = chal;
+            char b2[96];
+            snprintf(b2, sizeof(b2), ", {\"label\": \"confirm\", \"holder_ms\": %.5f, \"challenger_ms\": %.5f}", hold, chal);
+            log += b2;
+        }
+        if (take) { tilespmv_plan_destroy(best); best = p; best_ms = ms_c; }
         else tilespmv_plan_destroy(p);
     };
     const int coo_cands[2] = {TILESPMV_COO_IN_TILE, TILESPMV_COO_FALLBACK}, dns_cands[2] = {TILESPMV_DENSE_MFMA, TILESPMV_DENSE_VALU};
