@@ -24,15 +24,15 @@ struct DevShard { const DevTile *D; int tr0, tr1, t_begin, t_end; bool coo_in_ti
 
 // rc 0 or -3 (HIP error, reported on stderr)
 int dev_fetch_ints(const int *d_array, const long long *idx, int n, int *out);   // out[k] = d_array[idx[k]]
-int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &nunits, std::vector<int> &ncoo, std::vector<int> &ndense, long long *pool_units = nullptr, long long *pool_lines = nullptr);   // pool_*: += units made of pooled windows, 128-byte lines of x their gathers touch
+int dev_count(const DevShard &S, int csr_form, DevCounts *C, hvec<int> &counts3, long long *pool_units = nullptr, long long *pool_lines = nullptr);   // counts3: (units, list entries, dense tiles) of every tile-row; pool_*: += units made of pooled windows, 128-byte lines of x their gathers touch
 // column patterns of the first units on a sample of tiles (what the split form's dictionary would have to hold): ELL slots exactly, of a CSR tile its first unit
 int dev_pattern_sample(const DevShard &S, int step, std::vector<unsigned long long> &patterns);
 // EMIT: pu / pc / pd = first unit / list entry / dense tile of every tile-row (ntr + 1), row_k / row_split as in the host builder.  O: device destinations (zeroed by the caller;
 // urow is filled with the identity here)
-int dev_emit(const DevShard &S, const DevCounts &C, const std::vector<long long> &pu, const std::vector<long long> &pc, const std::vector<long long> &pd, const std::vector<unsigned char> &row_k,
+int dev_emit(const DevShard &S, const DevCounts &C, const hvec<long long> &pu, const hvec<long long> &pc, const hvec<long long> &pd, const std::vector<unsigned char> &row_k,
              const std::vector<unsigned char> &row_split, long long NU, const EmitOut &O);
 // word 0 of every emitted unit descriptor -> host (brick order scores the column blocks of the strips)
-int dev_fetch_word0(const uint4 *d_udesc, long long NU, std::vector<unsigned> &w0);
+int dev_fetch_word0(const uint4 *d_udesc, long long NU, hvec<unsigned> &w0);
 // ENCODE: units of task i move from [map.x, map.x + map.z) to [map.y, ..) of the packed numbering (padding units in between stay zero)
 int dev_pack_desc(const uint4 *d_udesc, const uint2 *d_urow, const uint4 *d_ucol, const int4 *d_map, int ntasks, UDesc *d_packed, URow *d_packed_row, uint4 *d_packed_col);   // d_map: device copy of the (old begin, new begin, count) triples
 // the distinct (n0, n1) patterns of NUP packed descriptors, ascending, if there are at most `cap` of them (else `over` = true); then the 4-byte form

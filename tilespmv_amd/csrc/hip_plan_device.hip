@@ -497,7 +497,7 @@ int dev_fetch_ints(const int *d_array, const long long *idx, int n, int *out)
     return 0;
 }
 
-int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &nunits, std::vector<int> &ncoo, std::vector<int> &ndense, long long *pool_units, long long *pool_lines)
+int dev_count(const DevShard &S, int csr_form, DevCounts *C, hvec<int> &counts3, long long *pool_units, long long *pool_lines)
 {
     const DevTile *D = S.D;
     const int nt = S.t_end - S.t_begin, ntr = S.tr1 - S.tr0;
@@ -506,7 +506,7 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &n
     auto lap_ms = [&]() { timeval t; gettimeofday(&t, NULL); const double ms = (t.tv_sec - tv0.tv_sec) * 1e3 + (t.tv_usec - tv0.tv_usec) * 1e-3; tv0 = t; return ms; };
     C->release();
     C->csr_form = csr_form;
-    nunits.assign((size_t)ntr, 0); ncoo.assign((size_t)ntr, 0); ndense.assign((size_t)ntr, 0);
+    counts3.resize((size_t)ntr * 3);
     // one allocation for the per-tile prefix arrays (and the pooled counts): tu | tc | td | tp | pool_u | pool_c
     const size_t per = ((size_t)nt + 1 + 63) / 64 * 64, perr = ((size_t)std::max(ntr, 1) + 63) / 64 * 64;
     int *blockp = nullptr;
@@ -547,9 +547,7 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, std::vector<int> &n
         hipLaunchKernelGGL(k_pd_row_counts, dim3(nblk(ntr, 256)), dim3(256), 0, 0, (const int *)D->T.tile_ptr, S.tr0, ntr, S.t_begin, (const int *)C->tu, (const int *)C->tc, (const int *)C->td,
                            (const int *)C->pool_u, (const int *)C->pool_c, d_out.p);
         PD_TRY(hipGetLastError());
-        std::vector<int> h((size_t)ntr * 3);
-        PD_TRY(hipMemcpy(h.data(), d_out.p, h.size() * sizeof(int), hipMemcpyDeviceToHost));
-        for (int i = 0; i < ntr; i++) { nunits[(size_t)i] = h[3 * (size_t)i]; ncoo[(size_t)i] = h[3 * (size_t)i + 1]; ndense[(size_t)i] = h[3 * (size_t)i + 2]; }
+        PD_TRY(hipMemcpy(counts3.data(), d_out.p, counts3.size() * sizeof(int), hipMemcpyDeviceToHost));
     }
     if (verbose) fprintf(stderr, "tilespmv: device count (form %d): per-tile counts + scans %.1f ms, pooled windows + per-row counts to the host %.1f ms\n", csr_form, ms_tiles, lap_ms());
     return 0;
@@ -572,13 +570,13 @@ int dev_pattern_sample(const DevShard &S, int step, std::vector<unsigned long lo
     return 0;
 }
 
-int dev_emit(const DevShard &S, const DevCounts &C, const std::vector<long long> &pu, const std::vector<long long> &pc, const std::vector<long long> &pd, const std::vector<unsigned char> &row_k,
+int dev_emit(const DevShard &S, const DevCounts &C, const hvec<long long> &pu, const hvec<long long> &pc, const hvec<long long> &pd, const std::vector<unsigned char> &row_k,
              const std::vector<unsigned char> &row_split, long long NU, const EmitOut &O)
 {
     const DevTile *D = S.D;
     const int nt = S.t_end - S.t_begin, ntr = S.tr1 - S.tr0;
     if (ntr <= 0) return 0;
-    auto narrow = [](const std::vector<long long> &v) { std::vector<int> o(v.size()); for (size_t i = 0; i < v.size(); i++) o[i] = (int)v[i]; return o; };   // (the builder refuses shards beyond 2^31 units / entries)
+    auto narrow = [](const hvec<long long> &v) { std::vector<int> o(v.size()); for (size_t i = 0; i < v.size(); i++) o[i] = (int)v[i]; return o; };   // (the builder refuses shards beyond 2^31 units / entries)
     Tmp<int> d_pu, d_pc, d_pd; Tmp<unsigned char> d_rk, d_rs;
     PD_TRY(d_pu.from(narrow(pu))); PD_TRY(d_pc.from(narrow(pc))); PD_TRY(d_pd.from(narrow(pd)));
     PD_TRY(d_rk.from(row_k)); PD_TRY(d_rs.from(row_split));
@@ -597,7 +595,7 @@ int dev_emit(const DevShard &S, const DevCounts &C, const std::vector<long long>
     return 0;
 }
 
-int dev_fetch_word0(const uint4 *d_udesc, long long NU, std::vector<unsigned> &w0)
+int dev_fetch_word0(const uint4 *d_udesc, long long NU, hvec<unsigned> &w0)
 {
     w0.assign((size_t)NU, 0u);
     if (NU <= 0) return 0;

@@ -94,7 +94,7 @@ struct StreamBuilder {
     DevShard DS{};
     DevCounts dcnt, dcnt_alt;
     uint4 *d_udesc = nullptr, *d_ucol = nullptr; uint2 *d_urow = nullptr; val_t *d_uval = nullptr;   // EMIT's unit records (scratch: ENCODE writes their final form into the plan's arena)
-    std::vector<unsigned> h_uw0;   // word 0 of every emitted unit (brick order only)
+    hvec<unsigned> h_uw0;   // word 0 of every emitted unit (brick order only)
     std::vector<FixRow> &fix; int &npartial;
     DevStream &S;
     // device mode (hip_plan_device.h; tilespmv_plan_create_from_csr): T is then a host copy of the tile LIST only (tile_ptr, tile_columnidx, Format); everything else of the
@@ -103,8 +103,8 @@ struct StreamBuilder {
     int rc = 0;
     // COUNT
     bool csr_split = true, pooled = false, wide = false; int csr_form = 1, target_in = 0, split_above_in = 0, tilem = 0, tilen = 0, ntr = 0, sv = 0;
-    std::vector<RowCount> rc_;
-    std::vector<long long> pu, pc, ph, phv, phi, pd;
+    hvec<RowCount> rc_;   // (hvec: huge-page advice on the large per-tile-row arrays, host_util.h)
+    hvec<long long> pu, pc, ph, phv, phi, pd;
     long long NU = 0, NC = 0, NH = 0, NHV = 0, NHI = 0, ND = 0;
     // CHOOSE
     bool fix_inline_on = true, entry_heavy = false, entry_dominated = false, wave_coo = false, coo_ordered = false, brick = false, xwin = false;
@@ -164,7 +164,7 @@ struct StreamBuilder {
     struct Hash {
         unsigned long long h = 1469598103934665603ull;
         void bytes(const void *p, size_t len) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < len; i++) { h ^= b[i]; h *= 1099511628211ull; } }
-        template <class V> void vec(const std::vector<V> &v) { arr(v.data(), v.size()); }
+        template <class V, class A> void vec(const std::vector<V, A> &v) { arr(v.data(), v.size()); }
         template <class V> void arr(const V *p, size_t n) { const unsigned long long cnt = n; bytes(&cnt, 8); if (n) bytes(p, n * sizeof(V)); }
         void num(long long v) { bytes(&v, 8); }
     };
@@ -199,15 +199,15 @@ void StreamBuilder::count()
         DS.stored0 = v[0]; DS.stored = (long long)v[1] - v[0];
     }
     long long pool_units_of[4] = {0, 0, 0, 0}, pool_lines_of[4] = {0, 0, 0, 0};   // per form: units made of pooled windows, 128-byte lines of x their gathers touch
-    auto count_all = [&](int form, std::vector<RowCount> &out) {
+    auto count_all = [&](int form, hvec<RowCount> &out) {
         out.assign((size_t)ntr, RowCount{0, 0, 0, 0, 0, 0, 0});
         if (DT) {   // one thread per tile (per tile-row for the pooled windows) on the device: the same per-tile functions (plan_tile_ops.h)
-            std::vector<int> nu, nc, nd;
+            hvec<int> k3;   // (units, entries, dense tiles) of every tile-row
             DevCounts &C = form == csr_form ? dcnt : dcnt_alt;
-            if (dev_count(DS, form, &C, nu, nc, nd, &pool_units_of[form], &pool_lines_of[form]) != 0) { rc = -3; return; }
+            if (dev_count(DS, form, &C, k3, &pool_units_of[form], &pool_lines_of[form]) != 0) { rc = -3; return; }
             parallel_chunks(ntr, 1 << 16, [&](int64_t b, int64_t e, int) {
                 for (int64_t i = b; i < e; i++) {
-                    RowCount c{nu[(size_t)i], nc[(size_t)i], 0, nd[(size_t)i], 0, 0, 0};
+                    RowCount c{k3[3 * (size_t)i], k3[3 * (size_t)i + 1], 0, k3[3 * (size_t)i + 2], 0, 0, 0};
                     c.cost = 16LL * c.nunits + (long long)K.coo_cost * c.ncoo + 64LL * c.ndense + 8;
                     out[(size_t)i] = c;
                 }
@@ -238,7 +238,7 @@ void StreamBuilder::count()
         csr_vals = (long long)v[1] - v[0]; all_vals = DS.stored;
     } else { csr_vals = (long long)T->csr_offset[t_end] - T->csr_offset[t_begin]; all_vals = (long long)T->blknnz[t_end] - T->blknnz[t_begin]; }
     if (K.csr_split < 0 && !classic_asked && csr_vals > 0 && csr_vals * 33 >= all_vals) {
-        std::vector<RowCount> alt;
+        hvec<RowCount> alt;
         count_all(2, alt);
         if (rc) return;
         long long u1 = 0, e1 = 0, u2 = 0, e2 = 0;
@@ -290,7 +290,7 @@ void StreamBuilder::count()
     if (K.csr_split < 0 && !classic_asked && csr_vals > 0 && csr_vals * 33 >= all_vals) {
         long long ub = 0, eb = 0;
         for (int i = 0; i < ntr; i++) { ub += rc_[i].nunits; eb += rc_[i].ncoo; }
-        std::vector<RowCount> alt;
+        hvec<RowCount> alt;
         count_all(3, alt);
         if (rc) return;
         long long u3 = 0, e3 = 0;
@@ -311,7 +311,7 @@ void StreamBuilder::count()
     }
     csr_split = csr_form != 0; pooled = csr_form >= 2; wide = csr_form == 3;
     {   // (six arrays of ntr + 1 prefixes: first touched side by side — a million tile-rows are 50 MB of fresh pages)
-        std::vector<long long> *six[6] = {&pu, &pc, &ph, &phv, &phi, &pd};
+        hvec<long long> *six[6] = {&pu, &pc, &ph, &phv, &phi, &pd};
         parallel_chunks(6, 1, [&](int64_t b, int64_t e, int) { for (int64_t q = b; q < e; q++) six[q]->assign((size_t)ntr + 1, 0); });
     }
     for (int i = 0; i < ntr; i++) pd[i + 1] = pd[i] + rc_[i].ndense;

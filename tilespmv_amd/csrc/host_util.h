@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -78,6 +79,33 @@ inline T *zalloc(size_t n)
     }
     return p;
 }
+
+// std::vector with the same advice for its storage: the plan builder's per-tile-row arrays (a million tile-rows: 40-50 MB each for the counts, 8 MB per prefix array) were first touched
+// through 4-KB page faults — 16 of the 20 ms of COUNT in the device-built plan of config 4.  hvec<T> is a std::vector whose allocations of 8 MB or more carry MADV_HUGEPAGE.
+inline void advise_huge(void *p, size_t bytes)
+{
+    static const bool thp = [] { const char *e = getenv("TILESPMV_HUGEPAGES"); return !(e && *e && atoi(e) == 0); }();
+    if (!thp || bytes < ((size_t)8 << 20)) return;
+    const uintptr_t lo = ((uintptr_t)p + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1), hi = ((uintptr_t)p + bytes) & ~(((uintptr_t)2 << 20) - 1);
+    if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+}
+template <class T>
+struct HugeAlloc {
+    using value_type = T;
+    HugeAlloc() = default;
+    template <class U> HugeAlloc(const HugeAlloc<U> &) {}
+    T *allocate(size_t n)
+    {
+        T *p = (T *)malloc((n ? n : 1) * sizeof(T));
+        if (!p) throw std::bad_alloc();
+        advise_huge(p, n * sizeof(T));
+        return p;
+    }
+    void deallocate(T *p, size_t) { free(p); }
+    template <class U> bool operator==(const HugeAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const HugeAlloc<U> &) const { return false; }
+};
+template <class T> using hvec = std::vector<T, HugeAlloc<T>>;
 
 // In-place exclusive prefix sum with 64-bit accumulation; aborts if a prefix leaves int range
 // (the reference's int products overflow silently: SURVEY.md S6).
