@@ -313,7 +313,7 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
         if (dalloc(D, &d_rowptr, (size_t)rowA + 1, false) || dalloc(D, &d_colidx, (size_t)nnz, false) || dalloc(D, &d_val, (size_t)nnz, false)) return -3;
         TC_TRY(hipMemcpy(d_rowptr, h_rowptr, ((size_t)rowA + 1) * sizeof(int), hipMemcpyHostToDevice));
         if (nnz) TC_TRY(hipMemcpy(d_colidx, h_colidx, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
-        if (nnz) TC_TRY(hipMemcpy(d_val, h_val, (size_t)nnz * sizeof(val_t), hipMemcpyHostToDevice));
+        // (the values follow while the keys are sorted: nothing before the packing reads them)
     }
     D->rowptr = d_rowptr; D->colidx = d_colidx; D->val = d_val;
     D->ms_upload = now_ms() - t0; t0 = now_ms();
@@ -331,6 +331,15 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
             TC_TRY(rocprim::radix_sort_pairs(nullptr, tmp_b, kb, vb, (size_t)nnz, 8u, (unsigned)(8 + cb_bits + bi_bits), (hipStream_t)0));
             TC_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
             hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_b, kb, vb, (size_t)nnz, 8u, (unsigned)(8 + cb_bits + bi_bits), (hipStream_t)0);
+            // the values cross the bus on a stream of their own while the sort passes run (config 4: 0.67 GB = 12 ms behind a 5-ms sort; the KKT stand-in in fp32: 17 ms behind 20)
+            if (e == hipSuccess && !csr_on_device) {
+                hipStream_t cs = nullptr;
+                if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess) {
+                    e = hipMemcpyAsync(d_val, h_val, (size_t)nnz * sizeof(val_t), hipMemcpyHostToDevice, cs);
+                    if (e == hipSuccess) e = hipStreamSynchronize(cs);
+                    (void)hipStreamDestroy(cs);
+                } else { (void)hipGetLastError(); e = hipMemcpy(d_val, h_val, (size_t)nnz * sizeof(val_t), hipMemcpyHostToDevice); }
+            }
             if (e == hipSuccess) e = hipDeviceSynchronize();
             (void)hipFree(tmp);
             TC_TRY(e);
@@ -511,7 +520,7 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     dfree(D, P.csr_col); dfree(D, P.ell_col);
     D->ms_pack = now_ms() - t0;
     if (verbose)
-        fprintf(stderr, "tilespmv: device Tile_create: upload %.1f ms, keys + sort %.1f, tile list %.1f, selection + scans %.1f, packing %.1f (%d tiles, %lld nonzeros)\n", D->ms_upload, D->ms_sort, D->ms_tiles,
+        fprintf(stderr, "tilespmv: device Tile_create: upload of the index arrays %.1f ms, keys + sort (the values cross the bus meanwhile) %.1f, tile list %.1f, selection + scans %.1f, packing %.1f (%d tiles, %lld nonzeros)\n", D->ms_upload, D->ms_sort, D->ms_tiles,
                 D->ms_select, D->ms_pack, tilenum, nnz);
     return 0;
 }
