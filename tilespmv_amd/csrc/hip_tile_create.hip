@@ -19,6 +19,7 @@
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include <sys/time.h>
+#include <thread>
 
 #include <type_traits>
 
@@ -37,6 +38,31 @@ namespace {
             return -3;                                                                                             \
         }                                                                                                          \
     } while (0)
+
+
+// the values' upload, by a helper thread on a stream of its own
+struct ValueUpload {
+    std::thread th;
+    hipError_t err = hipSuccess;
+    void start(int dev, val_t *dst, const val_t *src, size_t bytes)
+    {
+        ValueUpload *self = this;
+        th = std::thread([=] {
+            hipError_t e = hipSetDevice(dev);
+            hipStream_t cs = nullptr;
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+            if (e == hipSuccess) {
+                e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs);
+                if (e == hipSuccess) e = hipStreamSynchronize(cs);
+                (void)hipStreamDestroy(cs);
+            }
+            self->err = e;
+        });
+    }
+    hipError_t wait() { if (th.joinable()) th.join(); return err; }
+    ~ValueUpload() { if (th.joinable()) th.join(); }
+};
+
 
 inline double now_ms() { timeval t; gettimeofday(&t, NULL); return t.tv_sec * 1e3 + t.tv_usec * 1e-3; }
 inline int bits_for(int n) { int b = 1; while (b < 31 && (1ll << b) < (long long)n) b++; return b; }   // bits that hold 0 .. n - 1 (at least one)
@@ -271,13 +297,20 @@ int dalloc(DevTile *D, V **out, size_t n, bool zero)
     *out = (V *)p;
     return 0;
 }
+// hipFree waits for the whole device — also for the values' upload that runs beside the first steps of create_impl: while that is under way, memory to be released is only noted
+thread_local std::vector<void *> *t_free_later = nullptr;
+inline void free_now_or_later(void *p)
+{
+    if (!p) return;
+    if (t_free_later) t_free_later->push_back(p); else (void)hipFree(p);
+}
 inline void dfree(DevTile *D, const void *p)   // (an array carved from a pool goes with its pool)
 {
     if (!p) return;
     auto it = std::find(D->allocs.begin(), D->allocs.end(), (void *)p);
     if (it == D->allocs.end()) return;
     D->allocs.erase(it);
-    (void)hipFree((void *)p);
+    free_now_or_later((void *)p);
 }
 inline unsigned blocks_for(long long n, int per) { return (unsigned)std::max<long long>(1, (n + per - 1) / per); }
 
@@ -306,6 +339,12 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     D->cb_bits = cb_bits;
 
     // ---- the CSR arrays cross the bus (the only large upload of the device pipeline)
+    std::vector<void *> later;
+    struct Later {   // released on every way out, after the upload has been joined (members are destroyed in reverse order: `values` below goes first)
+        std::vector<void *> &v;
+        ~Later() { t_free_later = nullptr; for (void *q : v) (void)hipFree(q); v.clear(); }
+    } later_guard{later};
+    ValueUpload values;   // (joined on every way out of this function, before anybody frees d_val)
     double t0 = now_ms();
     int *d_rowptr = nullptr, *d_colidx = nullptr; val_t *d_val = nullptr;
     if (csr_on_device) { d_rowptr = const_cast<int *>(h_rowptr); d_colidx = const_cast<int *>(h_colidx); d_val = const_cast<val_t *>(h_val); }   // (borrowed: never in D->allocs)
@@ -313,7 +352,14 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
         if (dalloc(D, &d_rowptr, (size_t)rowA + 1, false) || dalloc(D, &d_colidx, (size_t)nnz, false) || dalloc(D, &d_val, (size_t)nnz, false)) return -3;
         TC_TRY(hipMemcpy(d_rowptr, h_rowptr, ((size_t)rowA + 1) * sizeof(int), hipMemcpyHostToDevice));
         if (nnz) TC_TRY(hipMemcpy(d_colidx, h_colidx, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
-        // (the values follow while the keys are sorted: nothing before the packing reads them)
+        // the values follow on a stream of their own, fed by a helper thread (a copy from pageable memory holds its caller until the last chunk is staged), while this thread sorts the
+        // keys, lists the tiles and selects their formats: nothing before the packing reads a value (config 4: 0.67 GB = 12.6 ms of bus time behind 7 ms of kernels)
+        if (nnz) {
+            int dev = 0;
+            TC_TRY(hipGetDevice(&dev));
+            values.start(dev, d_val, h_val, (size_t)nnz * sizeof(val_t));
+            t_free_later = &later;
+        }
     }
     D->rowptr = d_rowptr; D->colidx = d_colidx; D->val = d_val;
     D->ms_upload = now_ms() - t0; t0 = now_ms();
@@ -331,17 +377,8 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
             TC_TRY(rocprim::radix_sort_pairs(nullptr, tmp_b, kb, vb, (size_t)nnz, 8u, (unsigned)(8 + cb_bits + bi_bits), (hipStream_t)0));
             TC_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
             hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_b, kb, vb, (size_t)nnz, 8u, (unsigned)(8 + cb_bits + bi_bits), (hipStream_t)0);
-            // the values cross the bus on a stream of their own while the sort passes run (config 4: 0.67 GB = 12 ms behind a 5-ms sort; the KKT stand-in in fp32: 17 ms behind 20)
-            if (e == hipSuccess && !csr_on_device) {
-                hipStream_t cs = nullptr;
-                if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess) {
-                    e = hipMemcpyAsync(d_val, h_val, (size_t)nnz * sizeof(val_t), hipMemcpyHostToDevice, cs);
-                    if (e == hipSuccess) e = hipStreamSynchronize(cs);
-                    (void)hipStreamDestroy(cs);
-                } else { (void)hipGetLastError(); e = hipMemcpy(d_val, h_val, (size_t)nnz * sizeof(val_t), hipMemcpyHostToDevice); }
-            }
-            if (e == hipSuccess) e = hipDeviceSynchronize();
-            (void)hipFree(tmp);
+            if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)0)   /* (not the device: the values' upload is still under way on its own stream) */;
+            free_now_or_later(tmp);
             TC_TRY(e);
         }
         D->key = kb.current(); D->ent = vb.current();
@@ -363,7 +400,7 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
         TC_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
         hipError_t e = rocprim::run_length_encode(tmp, tmp_b, in, (unsigned)nnz, d_uniq, d_counts, d_nruns, (hipStream_t)0);
         if (e == hipSuccess) e = hipMemcpy(&tilenum, d_nruns, sizeof(int), hipMemcpyDeviceToHost);
-        (void)hipFree(tmp);
+        free_now_or_later(tmp);
         TC_TRY(e);
     }
     T.tilenum = tilenum;
@@ -383,8 +420,8 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
         TC_TRY(rocprim::exclusive_scan(nullptr, tmp_b, d_counts, d_tile_nnz, 0, np1, rocprim::plus<int>(), (hipStream_t)0));
         TC_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
         hipError_t e = rocprim::exclusive_scan(tmp, tmp_b, d_counts, d_tile_nnz, 0, np1, rocprim::plus<int>(), (hipStream_t)0);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        (void)hipFree(tmp);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)0);
+        free_now_or_later(tmp);
         TC_TRY(e);
     }
     dfree(D, d_uniq); dfree(D, d_counts); dfree(D, d_nruns);
@@ -426,8 +463,8 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
         hipError_t e = hipSuccess;
         for (int k = 0; k < NS && e == hipSuccess; k++)
             if (h_totals[k] > 0) e = rocprim::exclusive_scan(tmp, tmp_b, scans[k], scans[k], 0, np1, rocprim::plus<int>(), (hipStream_t)0);   // (an all-zero array is its own scan)
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        (void)hipFree(tmp);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)0);
+        free_now_or_later(tmp);
         TC_TRY(e);
     }
     T.csrsize = (int)h_totals[0]; T.csrptrlen = (int)h_totals[1]; T.coosize = (int)h_totals[2]; T.ellsize = (int)h_totals[3];
@@ -470,6 +507,10 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
         T.deferredcoo_ptr = d_dptr; T.deferredcoo_colidx = d_dcol; T.deferredcoo_val = d_dval;
     }
     pool_end();
+    TC_TRY(values.wait());   // the packing reads the values
+    t_free_later = nullptr;
+    for (void *q : later) (void)hipFree(q);
+    later.clear();
     if (tilenum > 0) {
         hipLaunchKernelGGL(k_tc_pack, dim3(blocks_for(tilenum, 256)), dim3(256), 0, 0, tilenum, tilem, tilen, rowA, colA, T, d_tile_bi, D->key, D->ent, d_colidx, d_val, P);
         TC_TRY(hipGetLastError());
@@ -520,7 +561,7 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     dfree(D, P.csr_col); dfree(D, P.ell_col);
     D->ms_pack = now_ms() - t0;
     if (verbose)
-        fprintf(stderr, "tilespmv: device Tile_create: upload of the index arrays %.1f ms, keys + sort (the values cross the bus meanwhile) %.1f, tile list %.1f, selection + scans %.1f, packing %.1f (%d tiles, %lld nonzeros)\n", D->ms_upload, D->ms_sort, D->ms_tiles,
+        fprintf(stderr, "tilespmv: device Tile_create: upload of the index arrays %.1f ms (the values cross the bus behind the next three steps), keys + sort %.1f, tile list %.1f, selection + scans %.1f, packing %.1f (%d tiles, %lld nonzeros)\n", D->ms_upload, D->ms_sort, D->ms_tiles,
                 D->ms_select, D->ms_pack, tilenum, nnz);
     return 0;
 }
