@@ -357,8 +357,10 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
         if (nnz) {
             int dev = 0;
             TC_TRY(hipGetDevice(&dev));
-            values.start(dev, d_val, h_val, (size_t)nnz * sizeof(val_t));
-            t_free_later = &later;
+            bool started = false;
+            try { values.start(dev, d_val, h_val, (size_t)nnz * sizeof(val_t)); started = true; } catch (...) {}   // (no thread to be had: the plain copy)
+            if (started) t_free_later = &later;
+            else TC_TRY(hipMemcpy(d_val, h_val, (size_t)nnz * sizeof(val_t), hipMemcpyHostToDevice));
         }
     }
     D->rowptr = d_rowptr; D->colidx = d_colidx; D->val = d_val;
