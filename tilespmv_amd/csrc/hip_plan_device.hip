@@ -476,9 +476,6 @@ int dev_entry_lists(const val_t *d_cval, const int *d_ccol, const unsigned char 
     return 0;
 }
 
-namespace {
-}  // namespace
-
 void DevCounts::release()
 {
     for (void *q : {(void *)tu, (void *)pool}) if (q) (void)hipFree(q);   // (tu heads the one block that holds tc, td, tp, pool_u, pool_c too)
