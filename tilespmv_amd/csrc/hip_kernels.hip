@@ -643,12 +643,12 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
-    static_assert(GPB == 16 || (GPB == 32 && ECOO == 2), "512-thread workgroups exist for the workgroup entry mode only");
+    static_assert(GPB == 16 || (GPB == 32 && ECOO == 2) || (GPB == 8 && ECOO != 2 && !XWIN && !PACE && !NTS), "512-thread workgroups exist for the workgroup entry mode only, 128-thread ones for small grids without it");
     static_assert(!XWIN || (GPB == 16 && ECOO != 1), "x windows: 256-thread workgroups, per-strip or per-workgroup entries");
     static_assert(!(XWIN && CD), "x-window plans keep 12-B descriptors (their low bits hold window slots)");
     static_assert(!(NTS && (XWIN || ECOO == 1)), "nontemporal streams: large plans only (entry mode 1 = small grids; x windows are an opt-in experiment)");
     static_assert(!PACE || (ECOO == 2 && GPB == 16 && !XWIN), "slab pacing: workgroup entry mode, 256-thread workgroups, no x windows");
-    static_assert(!POOL || (GPB == 16 && !XWIN && !PACE), "pooled plans: 256-thread workgroups, no x windows, no pacing");
+    static_assert(!POOL || ((GPB == 16 || GPB == 8) && !XWIN && !PACE), "pooled plans: 256-thread workgroups (128 on small grids), no x windows, no pacing");
     static_assert(!WIDE || (POOL && !CD), "wide windows: pooled plans, 12-B descriptors + 16 B of column offsets");
     constexpr int GROUPS_PER_BLOCK = GPB;
     constexpr int SROWS = XWIN ? XWIN_STRIP_ROWS : POOL ? POOL_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
@@ -2117,8 +2117,22 @@ hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDe
 #define TSPMV_LP(X, W, NTS) do { if (S.ucol) TSPMV_LPD(X, W, NTS, false, true); else if (S.pdict) TSPMV_LPD(X, W, NTS, true, false); else TSPMV_LPD(X, W, NTS, false, false); } while (0)
 #define TSPMV_LP1(X) do { if (entry_mode == 1) TSPMV_LP(X, 1, false); else if (entry_mode == 2) { if (S.nt_stream) TSPMV_LP(X, 2, true); else TSPMV_LP(X, 2, false); } \
         else { if (S.nt_stream) TSPMV_LP(X, 0, true); else TSPMV_LP(X, 0, false); } } while (0)
-        if (S.pooled) { if (xcd_remap == 2) TSPMV_LP1(2); else TSPMV_LP1(0); }
+        // Grids that would give fewer than half the CUs a 256-thread workgroup run 128-thread workgroups of 8 strips instead: twice the workgroups, the same strips
+        // (per-strip and per-wavefront entry modes only: the workgroup mode merges the lists of its 16 strips at plan creation)
+        static const int small_grid_workgroups = [] { const char *e = getenv("TILESPMV_SMALL_GRID_WORKGROUPS"); return e && *e ? atoi(e) : SMALL_GRID_WORKGROUPS; }();   // (0 switches the form off)
+        const bool small_grid = entry_mode != 2 && xwin_lds_bytes == 0 && !S.nt_stream && S.pace == nullptr && (S.ntasks + 15) / 16 < small_grid_workgroups;
+#define TSPMV_S8(X, W, CD, PL, WD) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, 8, false, CD, false, false, PL, WD>), dim3((unsigned)((S.ntasks + 7) / 8)), dim3(128), (size_t)lds_pad_bytes, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
+#define TSPMV_S8W(X, CD, PL, WD) do { if (entry_mode == 1) TSPMV_S8(X, 1, CD, PL, WD); else TSPMV_S8(X, 0, CD, PL, WD); } while (0)
+#define TSPMV_S8X(CD, PL, WD) do { if (xcd_remap == 2) TSPMV_S8W(2, CD, PL, WD); else TSPMV_S8W(0, CD, PL, WD); } while (0)
+        if (small_grid) {
+            if (S.pooled) { if (S.ucol) TSPMV_S8X(false, true, true); else if (S.pdict) TSPMV_S8X(true, true, false); else TSPMV_S8X(false, true, false); }
+            else if (S.cb_bits > 0) TSPMV_S8X(true, false, false); else TSPMV_S8X(false, false, false);
+        }
+        else if (S.pooled) { if (xcd_remap == 2) TSPMV_LP1(2); else TSPMV_LP1(0); }
         else if (xcd_remap == 2) TSPMV_L1(2); else TSPMV_L1(0);
+#undef TSPMV_S8X
+#undef TSPMV_S8W
+#undef TSPMV_S8
 #undef TSPMV_LP1
 #undef TSPMV_LP
 #undef TSPMV_LPD

@@ -41,6 +41,11 @@ struct ERec { unsigned v, w; };            // 8 bytes
 struct ERec { unsigned lo, hi, w; };       // 12 bytes, 4-byte aligned
 #endif
 constexpr int ECHUNK = 64;                 // records per column-base chunk
+#ifndef TILESPMV_SMALL_GRID_WORKGROUPS
+#define TILESPMV_SMALL_GRID_WORKGROUPS 128
+#endif
+constexpr int SMALL_GRID_WORKGROUPS = TILESPMV_SMALL_GRID_WORKGROUPS;   // grids with fewer 256-thread workgroups than this (half the CUs) run 128-thread workgroups of 8 strips (hip_kernels.hip launch_tiles_stream):
+                                                                    // 33-72 workgroups 6-10 % faster, 157-247 (5-pt 400^2, the scircuit stand-in) within 1.5 % either way — profiles/r05_small_grid_forms.txt
 constexpr int FB_DEST_BITS = 11;           // fallback row blocks: <= 2048 rows
 
 struct Task {
