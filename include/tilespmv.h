@@ -361,8 +361,9 @@ void tilespmv_plan_destroy(tilespmv_plan *plan);
  *
  * tilespmv_plan_create_from_csr: CSR in, resident plan out, nothing but the CSR arrays crossing the bus — the tiled matrix is built on the device and stays there, the stages of the
  * plan builder that touch every nonzero run as kernels calling the same per-tile functions as the host builder, so the plan is the one tilespmv_plan_create makes from
- * Tile_create's output (same streams, same y).  Not every option has a device path: returns -4 (and builds nothing) for autotune, the first-generation kernel, the CSR fallback
- * mode, whole CSR tiles (csr_split = 0), LDS x windows (x_window = 1), slab pacing (pace = 1) and HYB tiles — use Tile_create + tilespmv_plan_create for those.  Other return codes as above.
+ * Tile_create's output (same streams, same y).  Not every option has a device path: returns -4 (and builds nothing) for the first-generation kernel, the CSR fallback
+ * mode, whole CSR tiles (csr_split = 0), LDS x windows (x_window = 1), slab pacing (pace = 1) and HYB tiles — use Tile_create + tilespmv_plan_create for those.  autotune = 1 is served: every candidate plan is built from the one device-resident tiled
+ * matrix (the CSR-fallback candidate, which has no device path, is not among them).  Other return codes as above.
  * Peak device memory during the call: the CSR arrays + the tiled matrix + the sort's key buffers (about 40 bytes per nonzero in fp64) beside the plan. */
 int Tile_create_device(Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *csrRowPtrA,
                        const int *csrColIdxA, const MAT_VAL_TYPE *csrValA, unsigned flags);

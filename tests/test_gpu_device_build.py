@@ -210,6 +210,31 @@ def test_options_without_a_device_path_are_refused(torch_cuda):
             api.Plan.from_csr(rows, cols, len(ci), rp, ci, v, **knobs)
 
 
+def test_measured_selection_on_the_device_path(torch_cuda):
+    """autotune = 1 through tilespmv_plan_create_from_csr: the candidates are built from the one device-resident tiled matrix and timed; whatever wins, y is the oracle's (integer data: exact),
+    the plan says it was built on the device, and the log has the candidates."""
+    import json, tempfile
+    from oracle.oracle import CpuImpl
+    O = CpuImpl("oracle", np.float64)
+    for name, gen in (("powerlaw200k", cases.MEDIUM["powerlaw200k"]), ("fem", lambda: G.fem_hex(12, 12, 12, 3)), ("allfmt", cases.SMALL["allfmt"])):
+        rows, cols, rp, ci = gen()
+        rows = cases.truncated_rows(rows); nnz = int(rp[rows])
+        v, x = cases.values_for(name, len(ci), cols, np.float64)
+        want = O.spmv(O.tile_create(rows, cols, nnz, rp, ci, v), rows, cols, nnz, rp, ci, v, x)["y"]
+        log = tempfile.mktemp(suffix=".jsonl")
+        os.environ["TILESPMV_AUTOTUNE_LOG"] = log
+        try:
+            p = api.Plan.from_csr(rows, cols, nnz, rp, ci, v, autotune=True)
+        finally:
+            os.environ.pop("TILESPMV_AUTOTUNE_LOG", None)
+        assert p.info()["device_build"] == 1
+        assert np.array_equal(_spmv(torch_cuda, p, rows, x), want), name
+        p.close()
+        rec = json.loads(open(log).read().strip().splitlines()[-1])
+        assert len([c for c in rec["candidates"] if c.get("label") != "confirm"]) >= 3 and "choice" in rec, rec
+        os.remove(log)
+
+
 def test_cli_with_the_plan_built_on_the_device(torch_cuda, tmp_path):
     """`TILESPMV_DEVICE_BUILD=1 ./test -d 0 test.mtx`: call_tilespmv_hip builds its plan from the CSR arguments on the device; same lines, Check... PASS."""
     import subprocess

@@ -218,16 +218,16 @@ class Plan:
         self.h = h
 
     @classmethod
-    def from_csr(cls, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, cdna4=False, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, **knobs):
+    def from_csr(cls, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, cdna4=False, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, autotune=False, **knobs):
         """``tilespmv_plan_create_from_csr``: the tiled matrix and the plan's streams are built on the device; only the CSR arrays cross the bus.
-        Raises ``NotImplementedError`` for the options that have no device path (rc -4: autotune, first-generation kernel, CSR fallback, csr_split=0, x_window=1)."""
+        Raises ``NotImplementedError`` for the options that have no device path (rc -4: first-generation kernel, CSR fallback, csr_split=0, x_window=1).  ``autotune=True``: every candidate is built from the one device-resident tiled matrix."""
         dtype = np.dtype(dtype or np.asarray(csrValA).dtype)
         lib = _lib.load(dtype)
         rp, ci, v = _csr(lib, csrRowPtrA, csrColIdxA, csrValA)
         self = cls.__new__(cls)
         self.lib = lib
         self.rowA, self.colA, self.nnzA = rowA, colA, nnzA
-        opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, False, **knobs)
+        opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, autotune, **knobs)
         h = C.c_void_p()
         rc = lib.tilespmv_plan_create_from_csr(C.byref(h), rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int), _p(v, lib._vt), CREATE_QUIET | (CREATE_CDNA4 if cdna4 else 0), C.byref(opts))
         if rc == -4:

@@ -274,11 +274,18 @@ const char *tilespmv_plan_options_layout(void)
 // otherwise makes from byte models — COO tiles in-tile vs CSR fallback, dense tiles on the matrix cores vs as streamed
 // units, entry mode, strip size, workgroup -> XCD map — are decided by timing each candidate plan on this device.  A
 // candidate is a copy of the caller's Knobs with some fields replaced: nothing travels through the environment.
+static int plan_create_tuned(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const Knobs &Kc, const DevTile *DT);
 int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA,
                          const tilespmv_plan_options *opts)
 {
     const Knobs Kc = resolve_knobs(opts);
     if (!Kc.autotune) return plan_create_one(out, T, rowA, colA, nnzA, Kc);
+    return plan_create_tuned(out, T, rowA, colA, nnzA, Kc, nullptr);
+}
+// DT != nullptr: the candidates are built from the device-resident tiled matrix (tilespmv_plan_create_from_csr with autotune; T is then the host copy of the tile list only, and the
+// CSR-fallback candidate — which has no device path — is not among them)
+static int plan_create_tuned(tilespmv_plan **out, const Tile_matrix *T, int rowA, int colA, MAT_PTR_TYPE nnzA, const Knobs &Kc, const DevTile *DT)
+{
     // candidates are timed where they land: the placement search (up to 8 held copies of a >= 1 GB plan, each timed) runs ONCE, on the winner
     Knobs K0 = Kc;
     if (Kc.placement_tries < 0) K0.placement_tries = 1;
@@ -287,7 +294,7 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     const int tr0 = std::max(0, K0.tilerow_begin), tr1 = (K0.tilerow_end <= 0 || K0.tilerow_end > tilem) ? tilem : K0.tilerow_end;
     bool has_dense = false;
     for (int t = T->tile_ptr[tr0]; t < T->tile_ptr[tr1] && !has_dense; t++) has_dense = T->Format[t] == TILESPMV_FMT_DNS;
-    const bool has_extracted = T->new_coocount[T->tile_ptr[tr1]] > T->new_coocount[T->tile_ptr[tr0]];
+    const bool has_extracted = !DT && T->new_coocount[T->tile_ptr[tr1]] > T->new_coocount[T->tile_ptr[tr0]];
     val_t *dx = nullptr, *dy = nullptr;
     if (hipMalloc((void **)&dx, ((size_t)colA + 16) * sizeof(val_t)) != hipSuccess) return -3;
     if (hipMalloc((void **)&dy, ((size_t)rowA + 16) * sizeof(val_t)) != hipSuccess) { (void)hipFree(dx); return -3; }
@@ -302,7 +309,7 @@ int tilespmv_plan_create(tilespmv_plan **out, const Tile_matrix *T, int rowA, in
     bool first = true;
     auto try_one = [&](const Knobs &cand, const char *label) {
         tilespmv_plan *p = nullptr;
-        if (plan_create_one(&p, T, rowA, colA, nnzA, cand) != 0 || !p) return;
+        if (plan_create_one(&p, T, rowA, colA, nnzA, cand, DT) != 0 || !p) return;
         const double ms = tilespmv_plan_time(p, dx, dy, nullptr, 3, 12);
         char buf[512];
         snprintf(buf, sizeof(buf), "%s{\"label\": \"%s\", \"coo_mode\": %d, \"dense_mode\": %d, \"entry_mode\": %d, \"ordered\": %lld, \"strip_cost\": %lld, \"tasks\": %lld, \"ms\": %.5f}",
@@ -901,7 +908,7 @@ static int plan_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_PTR_TYPE n
     const Knobs K = resolve_knobs(opts);
     const int tilen = (colA + BS - 1) / BS;
     // what has no device path (include/tilespmv.h): the caller builds those plans from a host Tile_matrix
-    if (K.autotune || K.dry || (create_flags & TILESPMV_CREATE_HYB) || K.kernel == TILESPMV_KERNEL_DIRECT || tilen > (1 << UNIT_FLAG_SHIFT) || K.coo_mode == TILESPMV_COO_FALLBACK || K.csr_split == 0 ||
+    if (K.dry || (create_flags & TILESPMV_CREATE_HYB) || K.kernel == TILESPMV_KERNEL_DIRECT || tilen > (1 << UNIT_FLAG_SHIFT) || K.coo_mode == TILESPMV_COO_FALLBACK || K.csr_split == 0 ||
         K.x_window == 1 || K.pace > 0)
         return -4;
     const double t0 = now_us();
@@ -929,7 +936,7 @@ static int plan_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_PTR_TYPE n
     if (Kd.kernel == TILESPMV_KERNEL_AUTO) Kd.kernel = TILESPMV_KERNEL_STREAM;
     if (Kd.coo_mode == TILESPMV_COO_AUTO) Kd.coo_mode = TILESPMV_COO_IN_TILE;
     const double t2 = now_us();
-    rc = plan_create_one(out, &H, rowA, colA, nnzA, Kd, D);
+    rc = Kd.autotune ? plan_create_tuned(out, &H, rowA, colA, nnzA, Kd, D) : plan_create_one(out, &H, rowA, colA, nnzA, Kd, D);   // (measured selection: every candidate from the same device-resident tiled matrix)
     const double t3 = now_us();
     devtile_destroy(D);
     if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: plan from CSR: plan build %.1f ms, tiled matrix released in %.1f ms\n", (t3 - t2) * 1e-3, (now_us() - t3) * 1e-3);
