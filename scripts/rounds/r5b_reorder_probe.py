@@ -23,6 +23,19 @@ for wl in sys.argv[1].split(","):
     N = min(rows, n)
     A = sp.csr_matrix((np.ones(nnz, dtype=np.float32), ci[:nnz], rp[:rows + 1]), shape=(rows, n))[:N, :N].tocsr()
     pos = np.arange(N, dtype=np.float64)      # current position of every node
+    if os.environ.get("PROBE_RCM"):
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        t0 = time.time()
+        S = (A + A.T).tocsr()
+        perm = reverse_cuthill_mckee(S, symmetric_mode=True)
+        Ap = A[perm][:, perm].tocsr(); Ap.sort_indices()
+        t_perm = time.time() - t0
+        r2 = (N // 16) * 16
+        ms, i = timed(r2, N, Ap.indptr.astype(np.int32), Ap.indices.astype(np.int32))
+        extra_ms = 2 * 12.0 * N / 5e12 * 1e3
+        print("%-16s reverse Cuthill-McKee:    %.4f ms frac %.3f (form %d mode %d, streams %.0f MB) + ~%.4f ms for permuting x and y -> frac %.3f   [ordering + permuted CSR on the host: %.1f s]" % (
+              wl, ms, b_alg / ms * 1e-6 / 8000, i["csr_form"], i["entry_mode"], i["stream_bytes"] / 1e6, extra_ms, b_alg / (ms + extra_ms) * 1e-6 / 8000, t_perm), flush=True)
+        continue
     for sweep in range(1, 4):
         t0 = time.time()
         deg = np.maximum(1, np.diff(A.indptr))
