@@ -310,6 +310,111 @@ def device_state_under_load(run_async, sync, samples=6, gap=0.04):
     return out
 
 
+LINE_BUDGET = 4096   # bytes of the final stdout line (the driver parses the LAST line; the reference's own record is one short line: src/tilespmv_cuda.h:1139-1147)
+
+
+def compact_line(out, full_path):
+    """The ONE stdout line: the driver's contract keys, the roofline and CPU baseline of the headline, and name -> [ms, frac] for everything
+    else measured in the run.  The complete record (every plan parameter, preparation seconds, counter sources ...) goes to `full_path`."""
+    rf, cb = out["roofline"], out.get("cpu_baseline")
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out["config"]
+    line["config"] = {k: cfg[k] for k in ("workload", "source", "rows", "cols", "nnz", "partition", "y_combine", "tiles") if k in cfg}
+    line["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_min_bytes", "kernel", "kernel_ms", "algorithmic_bytes_per_launch",
+                                               "min_bytes_per_launch", "plan_stream_bytes_per_launch", "actual_traffic_gbps")}
+    line["roofline"]["traffic_from"] = (rf.get("traffic_source") or {}).get("file")
+    line["roofline"]["timing"] = "hip events, launch stream, the K timed steps"
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "seconds_per_spmv", "sample")}
+        allc = cb["format_loop_only"]["all_host_cores"]
+        line["cpu_baseline"]["all_host_cores"] = {"value": allc["value"], "cores": allc["cores"], "kind": "port"}
+        line["cpu_baseline"]["host_cpu"] = cb.get("host_cpu")
+    else:
+        line["cpu_baseline"] = None
+    line["check"] = out["check"]
+    if out.get("steady_state"):
+        line["steady_state"] = out["steady_state"]
+    line["reference_style_ms"] = out["reference_style_timing"]["ms_per_spmv"]
+    line["ranks"] = out["ranks"]; line["backend"] = out["backend"]; line["launched_by"] = out["launched_by"]
+    if out["n_gpus"] > 1:
+        line["rank_devices"] = out.get("rank_devices")
+        line["rccl_version"] = out.get("rccl_version")
+        line["per_rank_kernel_ms"] = out["per_rank_ms_per_step"]["device"]
+        line["per_rank_wall_ms"] = out["per_rank_ms_per_step"]["wall"]
+        if out.get("with_y_combine"):
+            line["with_y_combine"] = {m: ({"ms": v.get("ms_per_step"), "check": v.get("check_full_y_on_every_rank") or v.get("check_own_rows_on_every_rank")} if "error" not in v
+                                          else {"error": v["error"][:120]}) for m, v in out["with_y_combine"].items()}
+        line["prep_seconds_max"] = max((p or {}).get("total_tile_create_plus_plan", 0.0) for p in out["prep_seconds_per_rank"])
+    else:
+        line["prep_seconds"] = out["prep_seconds"].get("total_tile_create_plus_plan")
+    if "halo_bytes_per_rank" in out:
+        line["halo_bytes_per_rank"] = out["halo_bytes_per_rank"]
+    ow = out.get("other_workloads")
+    if ow:   # name -> [ms per SpMV, frac of 8 TB/s on the CSR-model bytes, whole-y check]
+        def brief(rec):
+            if "error" in rec:
+                return "error"
+            best = rec.get("default_plan") or min((rec[k] for k in ("coo_in_tile", "coo_csr_fallback") if k in rec), key=lambda r: r["ms_per_spmv"])
+            return [best["ms_per_spmv"], best["frac_of_8TBps"], best["check"]]
+        line["other_workloads"] = {k: brief(v) for k, v in ow.items()}
+    pop = out.get("population")
+    if pop:
+        line["population"] = {"error": pop["error"][:120]} if "error" in pop else {
+            "this_run": {k: pop["this_run"][k] for k in ("count", "frac_median", "frac_min", "share_frac_ge_0.70")} if "this_run" in pop else None,
+            "live": {k: [v.get("ms_per_spmv"), v.get("frac")] for k, v in pop.get("live_subset", {}).items() if isinstance(v, dict)},
+            "committed_sweep": {k: pop["committed_sweep"].get(k) for k in ("count", "frac_median", "share_frac_ge_0.70", "file")} if "committed_sweep" in pop else None}
+    line["full"] = full_path
+    txt = json.dumps(line, separators=(",", ":"))
+    for drop in ("population", "other_workloads", "steady_state", "with_y_combine"):   # never let the line outgrow what the driver reads: shed the side tables first
+        if len(txt) <= LINE_BUDGET:
+            break
+        if drop in line:
+            line[drop] = "see " + str(full_path)
+            txt = json.dumps(line, separators=(",", ":"))
+    return txt
+
+
+def write_full(out, path):
+    """The complete record beside the line; a read-only checkout must not break the run."""
+    for p in (path, os.path.join("/tmp", os.path.basename(path))):
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f, indent=1)
+                f.write("\n")
+            return p
+        except OSError:
+            continue
+    return None
+
+
+class phase:
+    """Hard limit on one phase of the run: when it expires the rank says where it was stuck on stderr and leaves with a non-zero exit code (the launcher then ends the
+    other ranks) — a first-contact hang on an 8-GPU node becomes a diagnosis instead of the driver's own timeout.  Nothing is re-executed."""
+    scale = 1.0
+    log = []
+
+    def __init__(self, name, seconds):
+        self.name, self.seconds = name, seconds * phase.scale
+
+    def _expire(self):
+        sys.stderr.write("bench.py: rank %s: phase '%s' exceeded %.0f s — giving up (exit 124)\n" % (os.environ.get("RANK", "0"), self.name, self.seconds))
+        sys.stderr.flush()
+        os._exit(124)
+
+    def __enter__(self):
+        import threading
+        self.t0 = time.time()
+        self.timer = threading.Timer(self.seconds, self._expire)
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        phase.log.append((self.name, round(time.time() - self.t0, 2)))
+        return False
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -327,7 +432,17 @@ def self_launch(args_list, n):
     env["TILESPMV_BENCH_SELF_LAUNCHED"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + args_list
-    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    limit = float(os.environ.get("TILESPMV_BENCH_JOB_TIMEOUT", "1500"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)   # a fresh child (its own process group), never an exec
+    try:
+        stdout, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)     # exactly the group started above
+        stdout, _ = proc.communicate()
+        print("bench.py: the %d ranks did not finish within %.0f s — killed" % (n, limit), file=sys.stderr)
+        return 124
+    res = subprocess.CompletedProcess(cmd, proc.returncode, stdout)
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     for l in res.stdout.splitlines():
         if not l.startswith("{"):
@@ -363,9 +478,13 @@ def main():
     ap.add_argument("--setup-launches", type=int, default=200,
                     help="untimed SpMVs issued before the steady-state measurement (the reference warms up with 200 launches, "
                          "src/tilespmv_cuda.h:1059-1082).  The plain protocol (W warm-ups, K steps, nothing else) is measured FIRST and reported beside it")
+    ap.add_argument("--full-json", default=os.path.join(ROOT, "bench_full.json"), metavar="PATH",
+                    help="the complete record (every plan parameter, preparation seconds, per-workload detail) is written here; stdout carries one compact line (< 4 KB) that names this file")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo only to rehearse the N>1 path on a single GPU")
+    ap.add_argument("--phase-timeout-scale", type=float, default=1.0, help="multiplies the hard per-phase limits (init 300 s, prepare 900 s, check 300 s, timed 300 s, each combine 300 s, extras 1500 s, cpu baseline 600 s)")
     args = ap.parse_args()
+    phase.scale = args.phase_timeout_scale
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
 
@@ -385,12 +504,31 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     dev = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
     torch.cuda.set_device(dev)
+    rccl_version = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's host driver only supports dmabuf IPC (RCCL fails with hipIpcGetMemHandle: invalid argument without it)
+        with phase("init_process_group", 300):
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+                try:
+                    rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception as e:
+                    rccl_version = "unknown (%r)" % (e,)
+                probe = torch.ones(1, device="cuda")       # first contact: one tiny all-reduce before any real work, so a fabric / IPC problem shows up here, by name
+                dist.all_reduce(probe); torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise SystemExit("bench.py: first RCCL all_reduce returned %r, expected %d" % (probe.item(), world))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+    # who runs where: every rank's device as the runtime names it (two ranks on one card, or a card seen twice, is visible in the line)
+    pr_ = torch.cuda.get_device_properties(dev)
+    my_dev = {"rank": rank, "device": dev, "name": pr_.name, "uuid": str(getattr(pr_, "uuid", "")),
+              "pci": "%04x:%02x:%02x" % (getattr(pr_, "pci_domain_id", 0), getattr(pr_, "pci_bus_id", 0), getattr(pr_, "pci_device_id", 0)), "cus": pr_.multi_processor_count}
+    rank_devices = [my_dev]
+    if world > 1:
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, my_dev)
     if args.cache:
         os.makedirs(args.cache, exist_ok=True)
 
@@ -427,7 +565,8 @@ def main():
     tile_cache = os.path.join(args.cache, "%s_%s_%s_rank%dof%d.tile_%s" % (args.workload, args.data, dname, rank, world, dname)) if args.cache else None
     # config 2 must exercise all seven tile formats: HYB is only reachable with the opt-in rule, here as in `other_workloads`
     prep_on_device = args.prep == "device" and args.workload != "scircuit"   # (config 2 needs HYB tiles: a host-only option)
-    sh = ShardedSpMV(rank, world, rows, n, rp_b, ci_b, vals_b, dtype, bounds=bounds, tile_cache=None if prep_on_device else tile_cache, hyb=(args.workload == "scircuit"), device_build=prep_on_device)
+    with phase("prepare (Tile_create + plan)", 900):
+        sh = ShardedSpMV(rank, world, rows, n, rp_b, ci_b, vals_b, dtype, bounds=bounds, tile_cache=None if prep_on_device else tile_cache, hyb=(args.workload == "scircuit"), device_build=prep_on_device)
     t_prep = time.time() - t0
     info = sh.local.info()
     stream = torch.cuda.current_stream()
@@ -508,24 +647,28 @@ def main():
         return "pass"
 
     check = "skipped"
-    if not args.no_check:
-        step("none"); torch.cuda.synchronize()
-        check = check_rows(yd[sh.r0:sh.r1].cpu().numpy(), "sharded SpMV")
-    if args.combine == "halo":
-        halo = make_halo()
+    with phase("parity check", 300):
         if not args.no_check:
-            step("halo"); torch.cuda.synchronize()
-            check_rows(halo.y_own[:halo.nloc].cpu().numpy(), "halo SpMV")
+            step("none"); torch.cuda.synchronize()
+            check = check_rows(yd[sh.r0:sh.r1].cpu().numpy(), "sharded SpMV")
+        if args.combine == "halo":
+            halo = make_halo()
+            if not args.no_check:
+                step("halo"); torch.cuda.synchronize()
+                check_rows(halo.y_own[:halo.nloc].cpu().numpy(), "halo SpMV")
 
-    # 1) the plain protocol: W warm-up steps, K timed steps, nothing else before them (what the round-end driver asks for)
-    wall0, dev_ms0 = timed(args.combine, args.steps, args.warmup)
-    # 2) steady state: `setup_launches` untimed SpMVs first (reference: 200 warm-up launches), then the same W + K
+    # the headline: the asked protocol — W warm-up steps, K timed steps, nothing else before them
+    with phase("timed steps", 300):
+        wall, dev_ms = timed(args.combine, args.steps, args.warmup)
+    main_per_rank = timed.per_rank
+    # beside it (never `value`): steady state — `setup_launches` untimed SpMVs first (reference: 200 warm-up launches, src/tilespmv_cuda.h:1059-1082), then the same W + K
+    steady = None
     if args.setup_launches > 0:
         run("none", args.setup_launches)
         sync_all()
-        wall, dev_ms = timed(args.combine, args.steps, args.warmup)
-    else:
-        wall, dev_ms = wall0, dev_ms0
+        wall_s, dev_ms_s = timed(args.combine, args.steps, args.warmup)
+        steady = {"setup_launches": args.setup_launches, "value": round(2.0 * nnz / (wall_s / args.steps) * 1e-9, 2), "ms_per_step": round(wall_s * 1e3 / args.steps, 5),
+                  "kernel_ms": round(dev_ms_s / args.steps, 5)}
     ms_per_step = wall * 1e3 / args.steps
     flops = 2.0 * nnz
     b_alg_total = api.algorithmic_bytes(nnz, rows, n, dtype.itemsize)
@@ -536,7 +679,6 @@ def main():
     b_alg_launch = api.algorithmic_bytes(sh.local_nnz, sh.local_rows, n, dtype.itemsize)
     kernel_ms = dev_ms / args.steps
     achieved = b_alg_launch / (kernel_ms * 1e-3) * 1e-9
-    main_per_rank = timed.per_rank
     # HBM traffic of one launch: PMC counters cannot be read inside this process (rocprofv3 wraps the command, and a
     # --pmc pass serialises the kernels), so the figure comes from the committed summary of scripts/profile_traffic.sh
     # for this workload/dtype — and only if that pass saw THIS plan: the summary carries a fingerprint of the plan it
@@ -606,6 +748,7 @@ def main():
         ksteps = max(5, args.steps // 10)
         for mode in ("allgather", "allreduce", "halo"):
             try:
+              with phase("y combine: " + mode, 300):
                 if mode == "halo":
                     halo = make_halo()
                 elif not args.no_check:
@@ -673,12 +816,10 @@ def main():
         prep_all = [None] * world
         dist.all_gather_object(prep_all, prep_mine)
 
-    value_plain = flops / (wall0 / args.steps) * 1e-9
     out = {
         "metric": "fp%d SpMV GFLOP/s (y = A*x, tiled format)" % (dtype.itemsize * 8), "value": round(value, 2), "unit": "GFLOP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-        "setup_launches": args.setup_launches,
-        "value_without_setup_launches": round(value_plain, 2), "ms_per_step_without_setup_launches": round(wall0 * 1e3 / args.steps, 5),
+        "steady_state": steady,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": dname,
         "data": "synthetic (reference driver data: val[i]=i%10, x[i]=i%10)" if args.data == "compat" else "synthetic (vals, x ~ U(-1,1), seed 12345; SURVEY S8(d) data mode ii)",
@@ -694,6 +835,7 @@ def main():
         "device_state_under_load": device_state,
         "check": check if check == "skipped" else ("pass: whole row block of every rank, %s" % ("exact" if args.data == "compat" else "|y - y_ref| <= %g * sum|a_ij x_j|" % (1e-12 if dtype == np.float64 else 1e-5))),
         "ranks": (dist.get_world_size() if world > 1 else 1), "devices": [int(r[0]) for r in main_per_rank], "backend": (args.backend if world > 1 else None),
+        "rank_devices": rank_devices, "rccl_version": rccl_version,
         "per_rank_ms_per_step": {"wall": [round(r[1], 5) for r in main_per_rank], "device": [round(r[2], 5) for r in main_per_rank],
                                  "min": round(min(r[1] for r in main_per_rank), 5), "max": round(max(r[1] for r in main_per_rank), 5)},
         "launched_by": "self (child torch.distributed.run)" if os.environ.get("TILESPMV_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "direct"),
@@ -728,6 +870,7 @@ def main():
             specs = [sp_ for sp_ in specs if sp_[0] in keep]
         built = {}
         t_extras = time.time()
+        ph_extras = phase("other workloads + population", 1500).__enter__()
         for key, wl, dt2, klass, also_real in specs:
             try:
                 from tilespmv_amd.tile_matrix import field_array
@@ -867,12 +1010,16 @@ def main():
             out["population"] = pop
         except Exception as e:
             out["population"] = {"error": repr(e)}
+        ph_extras.__exit__(None, None, None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(rows, n, rowptr, colidx, vals, x, dtype)
+        with phase("cpu baseline", 600):
+            out["cpu_baseline"] = cpu_baseline(rows, n, rowptr, colidx, vals, x, dtype)
     elif rank == 0:
         out["cpu_baseline"] = None
+    out["phase_seconds"] = dict(phase.log)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        full = write_full(out, args.full_json)
+        print(compact_line(out, full), flush=True)
     sh.close()
     if world > 1:
         dist.destroy_process_group()

@@ -14,19 +14,57 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
 
 
+LINE_LIMIT = 4096   # the driver parses the LAST stdout line; round 5's 30 KB line was not parsed (BENCH_r05.parsed = null)
+
+
 def _last_json(out):
+    """What the driver does: the last stdout line is the record.  It must be the only `{` line, short, and valid JSON."""
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out
+    assert out.rstrip("\n").splitlines()[-1] == lines[0]
+    assert len(lines[0]) < LINE_LIMIT, len(lines[0])
     return json.loads(lines[0])
+
+
+def _full(line):
+    """The complete record the line points to (`full`): plan parameters, preparation seconds, per-workload detail."""
+    path = line["full"] if os.path.isabs(line["full"]) else os.path.join(ROOT, line["full"])
+    with open(path) as f:
+        return json.load(f)
+
+
+def test_headline_command_line_is_short_and_complete(tmp_path):
+    """The driver's own command (`python bench.py --gpus 1 --steps 20 --warmup 5`: headline workload, every extra, population, CPU baseline) prints ONE line under 4 KB
+    that carries the contract keys, `roofline` and `cpu_baseline`; everything else sits in the sidecar."""
+    full = str(tmp_path / "full.json")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--full-json", full], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["config"]["workload"] == "laplacian4096" and d["steps"] == 20 and d["warmup"] == 5 and d["check"].startswith("pass")
+    assert abs(d["value"] - 2 * d["config"]["nnz"] / (d["ms_per_step"] * 1e-3) * 1e-9) / d["value"] < 0.02          # value IS the asked protocol
+    rf, cb = d["roofline"], d["cpu_baseline"]
+    assert rf["bound"] == "hbm" and rf["kernel_ms"] <= d["ms_per_step"] * 1.02 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert cb["kind"] == "reference" and cb["cores"] == 1 and cb["value"] > 0 and cb["all_host_cores"]["cores"] >= 1
+    assert d["steady_state"]["setup_launches"] == 200 and d["steady_state"]["value"] > 0
+    assert len(d["other_workloads"]) >= 10 and all(v != "error" and v[2] == "pass" for v in d["other_workloads"].values()), d["other_workloads"]
+    assert d["population"]["this_run"]["count"] >= 10
+    f = _full(d)
+    assert f["value"] == d["value"] and set(f["other_workloads"]) == set(d["other_workloads"]) and "prep_seconds_per_rank" in f
 
 
 def test_single_gpu_line():
     r = subprocess.run([sys.executable, "bench.py", "--workload", "laplacian512", "--steps", "10", "--warmup", "3"], cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = _last_json(r.stdout)
+    line = _last_json(r.stdout)
     for k in REQUIRED:
-        assert k in d, k
+        assert k in line, k
+    assert line["roofline"]["bound"] == "hbm" and line["cpu_baseline"]["cores"] == 1 and line["value"] > 0
+    d = _full(line)
+    assert d["value"] == line["value"] and d["ms_per_step"] == line["ms_per_step"]
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["check"].startswith("pass: whole row block")
     assert d["config"]["workload"] == "laplacian512" and "model" not in d["config"]
     rf = d["roofline"]
@@ -34,9 +72,10 @@ def test_single_gpu_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
     assert cb["sample"].startswith("the full workload") and cb["format_loop_only"]["serial_1_core"]["errcount"] == 0
-    assert d["ranks"] == 1 and d["devices"] == [0] and d["reference_style_timing"]["ms_per_spmv"] > 0 and d["setup_launches"] == 200
+    assert d["ranks"] == 1 and d["devices"] == [0] and d["reference_style_timing"]["ms_per_spmv"] > 0 and d["steady_state"]["setup_launches"] == 200
     assert {"tile_create", "plan_build", "plan_upload"} <= set(d["prep_seconds"]) and len(d["prep_seconds_per_rank"]) == 1
-    assert d["value_without_setup_launches"] > 0 and d["ms_per_step_without_setup_launches"] > 0      # the plain W + K protocol, measured first
+    assert d["steady_state"]["value"] > 0 and d["steady_state"]["ms_per_step"] > 0      # beside the headline (which is the plain W + K protocol)
+    assert len(d["rank_devices"]) == 1 and d["rank_devices"][0]["device"] == 0 and "timed steps" in d["phase_seconds"]
     assert d["config"]["generated"] == "own row block only"
     allc = cb["format_loop_only"]["all_host_cores"]
     assert allc["threads"] == allc["usable_cores"] >= 1 and allc["y_equals_csr_golden"] is True
@@ -54,7 +93,7 @@ def test_single_gpu_line_real_valued_data(tmp_path):
     for _ in range(2):
         r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        lines.append(_last_json(r.stdout))
+        lines.append(_full(_last_json(r.stdout)))
     assert "U(-1,1)" in lines[0]["data"] and "<=" in lines[0]["check"] and lines[0]["check"].startswith("pass")
     assert lines[0]["prep_seconds"]["tile_cache"] == "miss" and lines[1]["prep_seconds"]["tile_cache"] == "hit"
     assert lines[1]["check"].startswith("pass")
@@ -65,7 +104,7 @@ def test_single_gpu_line_real_valued_data(tmp_path):
         f.write("0" * 32 + "\n")
     r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    third = _last_json(r.stdout)
+    third = _full(_last_json(r.stdout))
     assert third["prep_seconds"]["tile_cache"] == "miss" and third["check"].startswith("pass")
 
 
@@ -75,7 +114,10 @@ def test_two_rank_rehearsal_over_gloo():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = _last_json(r.stdout)
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and len(line["rank_devices"]) == 2 and len(line["per_rank_kernel_ms"]) == 2
+    assert set(line["with_y_combine"]) == {"allgather", "allreduce", "halo"} and all(v["check"] == "pass" for v in line["with_y_combine"].values()), line
+    d = _full(line)
     assert d["n_gpus"] == 2 and d["check"].startswith("pass") and d["scaling"] == "strong"
     assert d["ranks"] == 2 and len(d["devices"]) == 2 and d["backend"] == "gloo" and d["launched_by"].startswith("self")
     assert len(d["per_rank_ms_per_step"]["wall"]) == 2 and d["per_rank_ms_per_step"]["max"] >= d["per_rank_ms_per_step"]["min"] > 0
@@ -91,25 +133,25 @@ def test_two_rank_halo_mode_over_gloo():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = _last_json(r.stdout)
+    d = _full(_last_json(r.stdout))
     assert d["config"]["y_combine"] == "halo" and d["halo_bytes_per_rank"] > 0 and d["check"].startswith("pass") and d["value"] > 0
 
 
-def test_one_rank_through_the_launcher_equals_the_bare_run():
+def test_one_rank_through_the_launcher_equals_the_bare_run(tmp_path):
     """The SCALE N = 1 point (driver: `python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1`) must agree with BENCH (`python bench.py`):
     same code path (no process group at world size 1), same line, same value within run-to-run noise."""
     args = ["--gpus", "1", "--steps", "100", "--warmup", "10", "--workload", "laplacian2048", "--no-cpu-baseline", "--no-extras"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    bare = subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    bare = subprocess.run([sys.executable, "bench.py"] + args + ["--full-json", str(tmp_path / "bare.json")], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert bare.returncode == 0, bare.stderr[-2000:]
     import socket
     with socket.socket() as so:      # a free port for the rendezvous (a fixed one may still be in TIME_WAIT from an earlier run)
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                               "bench.py"] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                               "bench.py"] + args + ["--full-json", str(tmp_path / "launched.json")], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert launched.returncode == 0, launched.stderr[-2000:]
-    a, b = _last_json(bare.stdout), _last_json(launched.stdout)
+    a, b = _full(_last_json(bare.stdout)), _full(_last_json(launched.stdout))
     assert a["n_gpus"] == b["n_gpus"] == 1 and a["ranks"] == b["ranks"] == 1 and a["config"] == b["config"]
     assert a["launched_by"] == "direct" and b["launched_by"] == "direct" and b["backend"] is None      # world size 1: no process group either way
     assert a["check"] == b["check"] and a["check"].startswith("pass")
@@ -128,7 +170,10 @@ def test_four_rank_rehearsal_over_gloo():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = _last_json(r.stdout)
+    line = _last_json(r.stdout)          # (< 4 KB with four ranks' devices, kernel times and the three combines in it)
+    assert line["ranks"] == 4 and [r_["device"] for r_ in line["rank_devices"]] == [0] * 4 and len({r_["uuid"] for r_ in line["rank_devices"]}) == 1
+    assert len(line["per_rank_kernel_ms"]) == 4 and all(v["check"] == "pass" for v in line["with_y_combine"].values()), line
+    d = _full(line)
     assert d["n_gpus"] == 4 and d["ranks"] == 4 and d["devices"] == [0] * 4 and d["check"].startswith("pass")
     assert len(d["prep_seconds_per_rank"]) == 4 and len(d["per_rank_ms_per_step"]["wall"]) == 4
     assert all(v["check_full_y_on_every_rank"] == "pass" for k, v in d["with_y_combine"].items() if k != "halo"), d["with_y_combine"]

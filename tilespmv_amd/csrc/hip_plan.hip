@@ -919,7 +919,8 @@ static int plan_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_PTR_TYPE n
     // the tile LIST on the host (what CHOOSE / CUT / the stride detection read); everything else of the tiled matrix stays where it is
     Tile_matrix H = D->T;
     {
-        Tile_matrix Z;   // counts stay, every pointer member is cleared (three are replaced below) memset(&Z, 0, sizeof(Z));
+        Tile_matrix Z;   // counts stay, every pointer member and the hyb sizes are cleared (three pointers are replaced below)
+        memset(&Z, 0, sizeof(Z));
         Z.tilem = H.tilem; Z.tilen = H.tilen; Z.tilenum = H.tilenum;
         Z.csrsize = H.csrsize; Z.csrptrlen = H.csrptrlen; Z.coosize = H.coosize; Z.ellsize = H.ellsize; Z.dnssize = H.dnssize; Z.dnsrowsize = H.dnsrowsize; Z.dnscolsize = H.dnscolsize; Z.coototal = H.coototal;
         H = Z;
