@@ -684,12 +684,12 @@ def main():
     # for this workload/dtype — and only if that pass saw THIS plan: the summary carries a fingerprint of the plan it
     # measured (entry mode, strip cost, tasks, stream bytes); on a mismatch traffic is null and marked stale.
     traffic, traffic_source = None, None
-    FP_KEYS = ("entry_mode", "strip_cost", "num_tasks", "stream_bytes", "x_window_slots", "desc_bytes", "nt_stream", "x_panels", "x_slice_passes")
+    FP_KEYS = ("entry_mode", "strip_cost", "num_tasks", "stream_bytes", "desc_bytes", "nt_stream", "x_panels", "x_slice_passes")
     fingerprint = {k: info[k] for k in FP_KEYS}
     tj = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, dname))
     if world == 1 and os.path.exists(tj):
         tjd = json.load(open(tj))
-        fresh = tjd.get("plan_fingerprint") == fingerprint
+        fresh = {k: (tjd.get("plan_fingerprint") or {}).get(k) for k in FP_KEYS} == fingerprint
         traffic = (tjd.get("hbm_bytes_per_spmv") or tjd.get("hbm_bytes_per_launch")) if fresh else None   # (per SpMV: a plan with dense-tile or column-panel passes is several launches)
         traffic_source = {"file": os.path.relpath(tj, ROOT), "measured": tjd.get("measured"), "kernel": tjd.get("kernel"),
                           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this command; FETCH_SIZE x2 (gfx950 correction, calibrated)",
@@ -827,7 +827,7 @@ def main():
                    "partition": "tile-row blocks, nnz-balanced, %d rank(s)" % world, "y_combine": args.combine, "backend": args.backend if world > 1 else None,
                    "tiles": getattr(sh, "tiles", None), "tasks": info["num_tasks"], "coo_mode": info["coo_mode"], "dense_mode": info["dense_mode"],
                    "entry_mode": info["entry_mode"], "sums_bit_reproducible": bool(info["entry_ordered"]), "strip_cost": info["strip_cost"],
-                   "x_window_slots": info["x_window_slots"], "x_panels": info["x_panels"], "x_panel_merge": info["x_panel_merge"], "x_slice_passes": info["x_slice_passes"], "placement_tries": info["placement_tries"],
+                   "x_panels": info["x_panels"], "x_panel_merge": info["x_panel_merge"], "x_slice_passes": info["x_slice_passes"], "placement_tries": info["placement_tries"],
                    "csr_form": info["csr_form"], "timed_choices_ms": round(info["timed_choices_us"] * 1e-3, 1)},
         "hbm_gbps_algorithmic": round(b_alg_total / (wall / args.steps) * 1e-9, 1),
         "hbm_roofline_frac": round(b_alg_total / (wall / args.steps) * 1e-9 / (HBM_PEAK_GBPS * world), 4),
@@ -964,7 +964,7 @@ def main():
                 tj2 = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (wl, "f64" if dt2 == np.float64 else "f32"))
                 if os.path.exists(tj2):   # HBM-side bytes per launch of the default plan, from the committed counter passes (not live)
                     t2 = json.load(open(tj2))
-                    fresh2 = t2.get("plan_fingerprint") == fp2
+                    fresh2 = {k: (t2.get("plan_fingerprint") or {}).get(k) for k in FP_KEYS} == fp2
                     rec["traffic"] = {"hbm_bytes_per_spmv": (t2.get("hbm_bytes_per_spmv") or t2.get("hbm_bytes_per_launch")) if fresh2 else None,
                                       "hbm_bytes_per_launch_of_the_dominant_kernel": t2.get("hbm_bytes_per_launch") if fresh2 else None, "kernel": t2.get("kernel"), "measured": t2.get("measured"),
                                       "file": os.path.relpath(tj2, ROOT), "live": False, "plan_fingerprint_matches": fresh2}

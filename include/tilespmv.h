@@ -286,8 +286,9 @@ typedef struct {
     int coo_piece;      /* entries per piece of a split tile-row                                             TILESPMV_COO_PIECE */
     int strip_even;     /* strips end on multiples of this many units                                        TILESPMV_STRIP_EVEN */
     int wg_strips;      /* workgroup entry mode: 16 (256-thread workgroups) or 32 (512 threads) strips per workgroup  TILESPMV_WG_STRIPS */
-    int x_window;       /* stencil-like shards: -1 / unset = brick task order on large 3-D shards, 0 = off, 2 = brick order wherever grid strides are
-                           found, 1 = brick order + the workgroup's x segments staged in LDS (measured slower; opt-in)          TILESPMV_X_WINDOW */
+    int x_window;       /* stencil-like shards: -1 / unset = brick task order on large 3-D shards, 0 = off, 1 / 2 = brick order wherever grid strides are
+                           found.  (Rounds 3-5: 1 also staged the workgroup's x segments in LDS; measured 25 % slower, retired in round 6 together with the
+                           slab-paced entry phase and its five `pace*` knobs)                                                 TILESPMV_X_WINDOW */
     int x_stride1;      /* ... tile-rows per grid line (0 / unset: detected from the shard)                  TILESPMV_X_STRIDE1 */
     int x_stride2;      /* ... tile-rows per grid plane (0 / unset: detected; none for 2-D problems)         TILESPMV_X_STRIDE2 */
     int mv_native;      /* tilespmv_plan_spmm: 0 one vector at a time, 1 multi-vector kernel with per-strip entries, 2 multi-vector kernel +
@@ -300,15 +301,6 @@ typedef struct {
                            are few; 0 = always the 12-B form                                                                   TILESPMV_DESC_DICT */
     int nt_stream;      /* value / entry-record / dense-tile loads: 1 nontemporal, 0 default cache policy; unset: nontemporal where one SpMV moves more
                            than 400 MB (about 1.6 x the Infinity Cache)                                                             TILESPMV_NT_STREAM */
-    int pace;           /* slab pacing of the workgroup entry mode (round 4): the workgroups one XCD holds at one time sweep x by a common timetable, so that
-                           their scattered gathers fall into the same few ~1-MB slabs, which stay in the XCD's L2; 1 = on (kept only if the calibration at plan
-                           creation finds it at least 3 % faster than the unpaced launch), 0 / unset = off: it measured slower or equal on every matrix of the
-                           round-4 sweep and stays as the counter-backed answer to "synchronise the sweeps"       TILESPMV_PACE */
-    int pace_slab_kb;   /* ... KB of x per slab (power of two; unset: 1024)                                   TILESPMV_PACE_SLAB_KB */
-    int pace_window;    /* ... slabs a wavefront may be ahead of the timetable, plus one (unset: 2)           TILESPMV_PACE_WINDOW */
-    int pace_team;      /* ... workgroups per team and XCD (unset: what the occupancy query says one XCD holds)  TILESPMV_PACE_TEAM */
-    int pace_period_us; /* ... microseconds one team's sweep over x is given (the timetable's length); unset: calibrated by timing at plan creation — and a
-                           plan that does not get faster is launched unpaced; 0: nobody waits                        TILESPMV_PACE_PERIOD_US */
     int x_panel_kb;     /* column panels (round 4): the merged entry lists of the workgroup entry mode are in column order, so the entries of a column panel (this many
                            KB of x; a power of two) are a run of a list; the plan records where the panels begin.  A panelled launch gives the unit kernel the first
                            x_panel_merge panels and every further run of x_panel_merge panels one more launch that adds its entries (y +=): the kernel boundary is the
@@ -362,7 +354,7 @@ void tilespmv_plan_destroy(tilespmv_plan *plan);
  * tilespmv_plan_create_from_csr: CSR in, resident plan out, nothing but the CSR arrays crossing the bus — the tiled matrix is built on the device and stays there, the stages of the
  * plan builder that touch every nonzero run as kernels calling the same per-tile functions as the host builder, so the plan is the one tilespmv_plan_create makes from
  * Tile_create's output (same streams, same y).  Not every option has a device path: returns -4 (and builds nothing) for the first-generation kernel, the CSR fallback
- * mode, whole CSR tiles (csr_split = 0), LDS x windows (x_window = 1), slab pacing (pace = 1) and HYB tiles — use Tile_create + tilespmv_plan_create for those.  autotune = 1 is served: every candidate plan is built from the one device-resident tiled
+ * mode, whole CSR tiles (csr_split = 0), and HYB tiles — use Tile_create + tilespmv_plan_create for those.  autotune = 1 is served: every candidate plan is built from the one device-resident tiled
  * matrix (the CSR-fallback candidate, which has no device path, is not among them).  Other return codes as above.
  * Peak device memory during the call: the CSR arrays + the tiled matrix + the sort's key buffers (about 40 bytes per nonzero in fp64) beside the plan. */
 int Tile_create_device(Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *csrRowPtrA,
@@ -461,22 +453,22 @@ enum {
                                          column-panel passes and split tile-rows included; tests/test_gpu_parity.py::test_panelled_plans_with_split_rows_sum_in_a_fixed_order, scripts/reproducibility_sweep.py) */
     TILESPMV_INFO_STRIP_COST = 15,    /* strip size target the plan was cut with */
     TILESPMV_INFO_WG_STRIPS = 16,     /* strips per workgroup of the unit kernel (16 or 32) */
-    TILESPMV_INFO_X_WINDOW_SLOTS = 17,    /* x-window plans: column blocks of the largest workgroup window (0 = no windows) */
-    TILESPMV_INFO_X_WINDOW_SEGMENTS = 18, /* ... and of all windows together: x segments (16 values each) loaded per SpMV */
+    TILESPMV_INFO_RETIRED_17 = 17,        /* always 0 (x-window plans, retired in round 6; the numbering of the facts is kept) */
+    TILESPMV_INFO_RETIRED_18 = 18,        /* always 0 */
     TILESPMV_INFO_BRICK_ORDER = 19,       /* 1: the strips were regrouped into bricks of the grid (stencil-like shard) */
     TILESPMV_INFO_DESC_BYTES = 20,        /* bytes per unit descriptor in HBM: 12, or 4 (column-pattern dictionary); pooled plans 20, or 8 (pattern dictionary); wide pooled plans 28 */
     TILESPMV_INFO_NT_STREAM = 21,         /* 1: the unit kernel reads the value / entry-record streams with nontemporal loads */
-    TILESPMV_INFO_PACE_SLABS = 22,        /* slab-paced entry phase: slabs of x the columns are cut into (0 = not paced) */
-    TILESPMV_INFO_PACE_TEAM = 23,         /* ... workgroups per team and XCD */
+    TILESPMV_INFO_RETIRED_22 = 22,        /* always 0 (slab-paced entry phase, retired in round 6) */
+    TILESPMV_INFO_RETIRED_23 = 23,        /* always 0 */
     TILESPMV_INFO_PLACEMENT_TRIES = 24,   /* arena placements timed at plan creation (large plans; 0 / 1 = the first one was kept) */
-    TILESPMV_INFO_PACE_PERIOD_US = 25,    /* ... microseconds of one team's timetable (0 = not paced) */
+    TILESPMV_INFO_RETIRED_25 = 25,        /* always 0 */
     TILESPMV_INFO_X_PANELS = 26,          /* column panels of the entry lists = launches of the entry part (1 = not panelled) */
     TILESPMV_INFO_X_PANEL_MERGE = 27,     /* recorded panels per pass of the panelled launch (0 = whole lists in the unit kernel) */
     TILESPMV_INFO_SCATTERED_ENTRIES = 28, /* workgroup entry mode: list entries whose column lies more than 2,048 columns outside their group's own rows — the gathers that
                                              no neighbour shares (the chip resolves about 59 G of those per second from a table that misses the L2s: profiles/r04_gather_granule.txt) */
     TILESPMV_INFO_X_SLICE_PASSES = 29,    /* column slices pinned to XCDs: launches of the sliced entry part (0 = not used); 8 x this many slices of x */
     TILESPMV_INFO_CSR_FORM = 30,          /* what CSR-format tiles became: 0 whole tiles (own pass), 1 ELL-style split (units + list entries), 2 pooled units, 3 wide pooled units (256-column windows) */
-    TILESPMV_INFO_TIMED_CHOICES_US = 31,  /* microseconds of plan creation spent TIMING candidates (placement retry, column panels / slices, pacing); part of build_us; 0 = nothing was timed */
+    TILESPMV_INFO_TIMED_CHOICES_US = 31,  /* microseconds of plan creation spent TIMING candidates (placement retry, column panels / slices); part of build_us; 0 = nothing was timed */
     TILESPMV_INFO_DEVICE_BUILD = 32,      /* 1: built by tilespmv_plan_create_from_csr (Tile_create, COUNT / EMIT / ENCODE on the device) */
     TILESPMV_INFO_TILE_CREATE_US = 33,    /* ... microseconds of its device Tile_create, the upload of the CSR arrays included (0 otherwise) */
     TILESPMV_INFO_COUNT = 34

@@ -25,7 +25,7 @@ lib.tilespmv_csr_load.argtypes = [C.c_char_p, I, I, I, I, C.POINTER(I), C.POINTE
 KNOBS = [dict(), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2), dict(entry_mode=2, wg_strips=32), dict(coo_mode=2), dict(kernel=1),
          dict(x_window=1, strip_cost=64), dict(x_window=2, entry_mode=2, strip_cost=100), dict(strip_cost=32, split_above=100), dict(csr_split=0),
          # round 4: slab-paced lists (local part + sentinel), column-panel offsets, both with tiny slabs / panels and split rows
-         dict(entry_mode=2, pace=1, pace_slab_kb=1, pace_period_us=10), dict(entry_mode=2, pace=1, pace_slab_kb=2, strip_cost=64, split_above=200, pace_team=3),
+         
          dict(entry_mode=2, x_panel_kb=1, x_panel_merge=1), dict(entry_mode=2, x_panel_kb=8, x_panel_merge=3, strip_cost=64, split_above=200)]
 names = list(cases.SMALL) + ["lap256", "kkt12"]
 for name in names:

@@ -23,7 +23,7 @@ def test_options_without_a_device_path_are_refused_before_any_device_call():
     rows, cols, rp, ci = G.laplacian5pt(32)
     for dtype in (np.float64, np.float32):
         v = G.compat_values(len(ci), dtype)
-        for knobs in (dict(csr_split=0), dict(kernel=api.KERNEL_DIRECT), dict(coo_mode=api.COO_FALLBACK), dict(x_window=1), dict(pace=1)):
+        for knobs in (dict(csr_split=0), dict(kernel=api.KERNEL_DIRECT), dict(coo_mode=api.COO_FALLBACK)):
             with pytest.raises(NotImplementedError):
                 api.Plan.from_csr(rows, cols, len(ci), rp, ci, v, dtype=dtype, **knobs)
     lib = _lib.load(np.float64)

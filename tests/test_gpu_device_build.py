@@ -205,7 +205,7 @@ def test_device_built_plan_matches_the_oracle(torch_cuda):
 def test_options_without_a_device_path_are_refused(torch_cuda):
     rows, cols, rp, ci = cases.SMALL["lap64"]()
     v = G.compat_values(len(ci), np.float64)
-    for knobs in (dict(csr_split=0), dict(kernel=api.KERNEL_DIRECT), dict(coo_mode=api.COO_FALLBACK), dict(x_window=1)):
+    for knobs in (dict(csr_split=0), dict(kernel=api.KERNEL_DIRECT), dict(coo_mode=api.COO_FALLBACK)):
         with pytest.raises(NotImplementedError):
             api.Plan.from_csr(rows, cols, len(ci), rp, ci, v, **knobs)
 

@@ -627,7 +627,7 @@ def test_every_plan_kind_survives_being_moved(torch_cuda, monkeypatch, dtype):
     O = CpuImpl("oracle", dtype)
     mats = {"allfmt": SMALL["allfmt"], "bandrand60k": lambda: G.band_plus_random(60000, 4, 3, 5), "kkt_like24": lambda: G.nlpkkt_like(24, target_nnz=None), "band4096_40": SMALL["band4096_40"],
             "one_long_row": SMALL["one_long_row"]}
-    knob_sets = [dict(), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, pace=1, pace_slab_kb=1, pace_period_us=5),
+    knob_sets = [dict(), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1),
                  dict(x_window=1), dict(x_window=1, entry_mode=2), dict(desc_dict=0), dict(coo_mode=api.COO_FALLBACK), dict(kernel=api.KERNEL_DIRECT), dict(csr_split=0),
                  dict(dense_mode=api.DENSE_MFMA), dict(dense_mode=api.DENSE_VALU), dict(strip_cost=64, split_above=200), dict(strip_cost=64, split_above=200, fix_inline=0),
                  dict(csr_split=2), dict(csr_split=2, entry_mode=2), dict(csr_split=2, strip_cost=64, split_above=200)]
@@ -671,7 +671,7 @@ def test_tile_row_shards_with_panels_and_pacing(torch_cuda):
     tilem = rowA // 16
     cuts = [0, tilem // 5, tilem // 2 + 3, tilem]
     xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda()
-    for kw in (dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, x_panel_kb=8, x_panel_merge=2, entry_ordered=0), dict(entry_mode=2, pace=1, pace_slab_kb=1, pace_period_us=5),
+    for kw in (dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, x_panel_kb=8, x_panel_merge=2, entry_ordered=0),
                dict(entry_mode=2, x_panel_kb=16, x_slice_passes=1), dict(entry_mode=2, x_panel_kb=8, x_slice_passes=3)):
         yd = torch_cuda.full((rowA + 16,), -7.0, dtype=xd.dtype, device="cuda")
         for a, b in zip(cuts[:-1], cuts[1:]):
@@ -699,7 +699,7 @@ def test_spmv_is_capturable_into_a_hip_graph(torch_cuda):
     want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals), rowA, n, nnz, rp, ci, vals, x)["y"]
     tp = api.Tile_create(rowA, n, nnz, rp, ci, vals)
     xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda()
-    for kw in (dict(), dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, pace=1, pace_slab_kb=1, pace_period_us=5), dict(entry_mode=2, strip_cost=64, split_above=200),
+    for kw in (dict(), dict(entry_mode=2, x_panel_kb=16, x_panel_merge=1), dict(entry_mode=2, strip_cost=64, split_above=200),
                dict(coo_mode=api.COO_FALLBACK), dict(entry_mode=1), dict(entry_mode=2, x_panel_kb=16, x_slice_passes=2)):
         plan = api.Plan(tp, rowA, n, nnz, **kw)
         yd = torch_cuda.zeros(rowA + 16, dtype=xd.dtype, device="cuda")
@@ -867,50 +867,9 @@ def test_column_slices_on_xcds_bit_exact(torch_cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_slab_paced_entry_phase_bit_exact(torch_cuda, dtype):
-    """Round 4: the workgroup entry mode with slab pacing (teams of co-resident workgroups gather from the same few slabs of x at one time; pacing is
-    speed only).  The oracle's y bit for bit — with slabs so small that the test matrices have hundreds, teams of one
-    workgroup up to more than the grid holds, leads of 0-2 slabs, ordered and unordered adds, calibrated and fixed timetables, and
-    launch after launch on one plan (the last wavefront of a team clears the team's start clock)."""
-    from oracle.oracle import CpuImpl
-    from tilespmv_amd import api, generators as G
-    O = CpuImpl("oracle", dtype)
-    mats = {"powerlaw200k": MEDIUM["powerlaw200k"], "bandrand60k": lambda: G.band_plus_random(60000, 4, 3, 5), "uniform40k": lambda: G.uniform_per_row(40000, 70001, 8, 1),
-            "allfmt": SMALL["allfmt"], "one_long_row": SMALL["one_long_row"], "empty_rows": SMALL["empty_rows"], "circuit60k": MEDIUM["circuit60k"]}
-    # a fixed timetable (pace_period_us >= 0) keeps the paced kernel whatever it costs; without one the plan calibrates by timing and may drop pacing (first set)
-    knob_sets = [dict(pace_slab_kb=1), dict(pace_slab_kb=1, pace_window=1, pace_team=1, pace_period_us=20), dict(pace_slab_kb=2, pace_window=3, pace_team=3, entry_ordered=0, pace_period_us=5),
-                 dict(pace_slab_kb=16, pace_team=192, entry_ordered=1, pace_period_us=40), dict(pace_slab_kb=1, pace_period_us=300, pace_team=2), dict(pace_slab_kb=4, nt_stream=1, desc_dict=0, pace_period_us=0),
-                 dict(pace_slab_kb=1, strip_cost=64, split_above=200, pace_period_us=15), dict(pace_slab_kb=8, xcd_remap=0, pace_team=2, strip_cost=100, pace_period_us=25)]
-    paced = 0
-    for name, gen in mats.items():
-        m, n, rp, ci = gen()
-        nnz, rowA = len(ci), truncated_rows(m)
-        vals, x = values_for(name, nnz, n, dtype)
-        want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, x)["y"]
-        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=True)
-        for kw in knob_sets:
-            y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, entry_mode=2, pace=1, **kw)
-            assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
-            paced += info["pace_slabs"] > 0
-            want_slabs = -(-n // max(256, kw["pace_slab_kb"] * 1024 // np.dtype(dtype).itemsize))
-            assert info["pace_slabs"] in (0, want_slabs), (name, kw, info["pace_slabs"])
-            if "pace_period_us" in kw and want_slabs > kw.get("pace_window", 2):
-                assert info["pace_slabs"] == want_slabs and info["pace_period_us"] == kw["pace_period_us"], (name, kw, info)
-        # one plan, many launches: counters come back to zero every time (a stale counter would only cost speed, so look at the bits AND at the time of launch 50 vs launch 1)
-        plan = api.Plan(tp, rowA, n, nnz, entry_mode=2, pace=1, pace_slab_kb=1, pace_team=4, pace_period_us=10)
-        xd = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda(); yd = torch_cuda.zeros(rowA + 16, dtype=xd.dtype, device="cuda")
-        for it in range(50):
-            yd.fill_(7.0); plan.spmv(xd.data_ptr(), yd.data_ptr()); torch_cuda.cuda.synchronize()
-            assert np.array_equal(yd.cpu().numpy()[:rowA], want), (name, "launch", it)
-        plan.close()
-        api.Tile_destroy(tp)
-    assert paced >= 30
-
-
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
-    """Round 3: packed entry records in every entry mode, 512-thread workgroups, x windows (brick task order + LDS-staged x
-    segments, strides detected from the matrix) and the resident-workgroup cap — all passed as plan options, none through the
+    """Round 3: packed entry records in every entry mode, 512-thread workgroups, brick task order (strides detected from the
+    matrix; x_window = 1 is the retired LDS-window knob and now means the same as 2) and the resident-workgroup cap — all passed as plan options, none through the
     environment — give the oracle's y bit for bit on the stencil / KKT / irregular test matrices."""
     from oracle.oracle import CpuImpl
     from tilespmv_amd import api, generators as G
@@ -926,7 +885,7 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
                  # placement retry (round 4): the plan is moved to freshly allocated blocks, every device pointer rebased, and the faster placement kept — same bits either way
                  dict(placement_tries=3), dict(placement_tries=2, entry_mode=2, strip_cost=64, split_above=200), dict(placement_tries=3, coo_mode=2), dict(placement_tries=2, x_window=1),
                  dict(placement_tries=3, dense_mode=1, csr_split=0)]
-    windowed = bricks = 0
+    bricks = 0
     desc = {4: 0, 8: 0, 12: 0, 20: 0}   # (20 / 8: pooled plans, where the byte model chooses them — 8 with their pattern dictionary)
     for name, gen in mats.items():
         m, n, rp, ci = gen()
@@ -937,28 +896,27 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
         for kw in knob_sets:
             y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, **kw)
             assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
-            if "entry_mode" in kw and not kw.get("x_window"):
+            if "entry_mode" in kw:
                 assert info["entry_mode"] == kw["entry_mode"]
             if "placement_tries" in kw:      # (the retry stops at the first placement that is clearly faster than the first one)
                 assert 2 <= info["placement_tries"] <= kw["placement_tries"], (name, kw, info["placement_tries"])
-            windowed += info["x_window_slots"] > 0
             bricks += info["brick_order"] == 1
             desc[info["desc_bytes"]] += 1
-            assert info["nt_stream"] == (1 if kw.get("nt_stream") == 1 and info["entry_mode"] != 1 and not info["x_window_slots"] else 0)   # (small test matrices: off by rule)
-            assert info["desc_bytes"] == 12 or (info["desc_bytes"] == 20 and info["csr_form"] == 2) or (kw.get("desc_dict") != 0 and info["x_window_slots"] == 0)   # (20: a pooled plan, chosen by the byte model; 8: with its pattern dictionary)
+            assert info["nt_stream"] == (1 if kw.get("nt_stream") == 1 and info["entry_mode"] != 1 else 0)   # (small test matrices: off by rule)
+            assert info["desc_bytes"] == 12 or (info["desc_bytes"] == 20 and info["csr_form"] == 2) or kw.get("desc_dict") != 0   # (20: a pooled plan, chosen by the byte model; 8: with its pattern dictionary)
             assert info["desc_bytes"] != 8 or (info["csr_form"] == 2 and kw.get("desc_dict") != 0)
             assert not (kw.get("x_window") == 0 and info["brick_order"])
-        # multi-vector product on an x-window plan: its kernel reads the column-block descriptors kept beside the slotted ones
-        plan = api.Plan(tp, rowA, n, nnz, x_window=1, entry_mode=0)
+        # multi-vector product on a brick-ordered plan
+        plan = api.Plan(tp, rowA, n, nnz, x_window=2, entry_mode=0)
         X = (np.arange(n * 4, dtype=np.int64) % 7).astype(dtype).reshape(n, 4)
         Xd = torch_cuda.from_numpy(X).cuda(); Yd = torch_cuda.zeros((rowA + 16, 4), dtype=Xd.dtype, device="cuda")
         plan.spmm(Xd.data_ptr(), Yd.data_ptr(), 4); torch_cuda.cuda.synchronize()
         for j in range(4):
             wj = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"]
-            assert np.array_equal(Yd.cpu().numpy()[:rowA, j], wj), (name, "spmm on an x-window plan", j)
+            assert np.array_equal(Yd.cpu().numpy()[:rowA, j], wj), (name, "spmm on a brick-ordered plan", j)
         plan.close()
         api.Tile_destroy(tp)
-    assert windowed >= 12 and bricks >= 20     # the stencil / KKT matrices really took the windowed kernel / the brick order
+    assert bricks >= 20     # the stencil / KKT matrices really took the brick order
     assert desc[4] >= 30 and desc[12] >= 18    # both descriptor forms ran (4 B + pattern dictionary is the default wherever the patterns are few)
 
 

@@ -89,16 +89,14 @@ def test_brick_order_is_detected_on_3d_grids_only():
 
 def test_dictionary_descriptors_where_patterns_are_few():
     """4-B unit descriptors + a dictionary of column patterns (stencils: a handful of patterns); 12 B when the knob says so,
-    when the patterns do not fit the dictionary, and on x-window plans (their descriptors hold window slots)."""
+    when the patterns do not fit the dictionary."""
     m, n, rp, ci = G.laplacian7pt(48)
     rows = cases.truncated_rows(m); nnz = int(rp[rows])
     tm = api.Tile_create(rows, n, nnz, rp, ci, G.compat_values(len(ci)))
     d4, i4 = api.plan_layout_digest(tm, rows, n, nnz)
     d12, i12 = api.plan_layout_digest(tm, rows, n, nnz, desc_dict=0)
-    _, iw = api.plan_layout_digest(tm, rows, n, nnz, x_window=1, entry_mode=0)
     assert (i4["desc_bytes"], i12["desc_bytes"]) == (4, 12) and d4 != d12
     assert i4["nt_stream"] == 0 and api.plan_layout_digest(tm, rows, n, nnz, nt_stream=1)[1]["nt_stream"] == 1    # small launch: default cache policy unless asked
-    assert iw["x_window_slots"] == 0 or iw["desc_bytes"] == 12
     assert i12["stream_bytes"] - i4["stream_bytes"] >= 8 * (nnz // 16) * 0.9      # 8 bytes per unit less to read
     api.Tile_destroy(tm)
     # an entry-dominated shard with a handful of units: the dictionary would save < 2 % of the streams and is not taken by default (desc_dict=1 asks for it anyway)

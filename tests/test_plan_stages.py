@@ -94,8 +94,8 @@ def test_brick_order_permutes_tasks_but_emits_the_same_units(mats):
     assert (il["brick_order"], ib["brick_order"]) == (0, 1)
     assert lin["count"] == brk["count"]
     assert lin["order"] != brk["order"] and lin["encode"] != brk["encode"]
-    win, iw = api.plan_layout_stages(tm, rows, n, nnz, x_window=1, entry_mode=0, **kw)
-    assert iw["x_window_slots"] > 0 and win["order"] != brk["order"]
+    one, i1 = api.plan_layout_stages(tm, rows, n, nnz, x_window=1, **kw)      # (1 was the LDS-window form, retired in round 6: it now means what 2 means)
+    assert one == brk and i1["brick_order"] == 1
 
 
 def test_dense_tiles_as_units_or_for_the_matrix_cores(mats):
@@ -119,22 +119,6 @@ def test_byte_model_follows_the_streams(mats):
     assert i0["stream_bytes"] >= 13 * int(0.8 * nnz) and i2["stream_bytes"] < i0["stream_bytes"]     # packed 12-B records against 13-B triples
 
 
-def test_slab_pacing_adds_a_sentinel_to_the_lists_and_counters_to_the_plan(mats):
-    """Pacing is a property of the entry lists (one more base word per list) and of the launch (team counters): units, strips and their order stay."""
-    tm, rows, n, nnz = mats["bandrand"]
-    off, i0 = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2)
-    on, i1 = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, pace=1, pace_slab_kb=1)
-    assert (i0["pace_slabs"], i1["pace_slabs"]) == (0, -(-n // 256)) and i1["pace_team"] == 192      # (slabs hold at least 256 columns)
-    assert _changed(off, on) == ["choose", "entries", "finish"]
-    on2, i2 = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, pace=1, pace_slab_kb=1, pace_team=7, pace_window=3, pace_period_us=50)
-    assert _changed(on, on2) in (["finish"], [])     # team size, lead and timetable length are launch facts: no list changes
-    assert i2["pace_team"] == 7
-    for kw in (dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, wg_strips=32)):    # pacing exists for 256-thread workgroup lists only
-        assert api.plan_layout_stages(tm, rows, n, nnz, pace=1, pace_slab_kb=1, **kw)[1]["pace_slabs"] == 0, kw
-    tm, rows, n, nnz = mats["allfmt"]         # 192 columns: one slab, nothing to pace
-    assert api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, pace=1, pace_slab_kb=1)[1]["pace_slabs"] == 0
-
-
 def test_column_panels_are_offsets_into_the_same_lists(mats):
     """Panels are recorded as offsets into the one column-ordered list of a group: the records do not change, and how many panels a pass takes — or whether the XCDs take them as
     column slices — is a launch fact.  (Putting a group's entries around its own rows first and letting the panels divide only the rest was tried: slower in all three forms.)"""
@@ -152,7 +136,7 @@ def test_column_panels_are_offsets_into_the_same_lists(mats):
     assert _changed(many, sl) == [] and isl["x_slice_passes"] == 2 and isl["x_panels"] == 2 and isl["x_panel_merge"] == 0 and isl["entry_ordered"] == 0
     so, iso = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, x_slice_passes=2, entry_ordered=1)
     assert iso["x_slice_passes"] == 0 and iso["entry_ordered"] == 1                # reproducible sums asked: the sliced form (atomic adds in any order) stays out
-    for kw in (dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, wg_strips=32), dict(entry_mode=2, pace=1, pace_slab_kb=1)):
+    for kw in (dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, wg_strips=32)):
         assert api.plan_layout_stages(tm, rows, n, nnz, x_panel_kb=32, x_panel_merge=1, **kw)[1]["x_panels"] == 1, kw
 
 
@@ -174,9 +158,9 @@ def test_pooled_units_are_chosen_by_the_byte_model_and_are_a_layout_of_their_own
     assert _changed(split, pooled) == ALL
     b_alg = api.algorithmic_bytes(nnz, rows, n, 8)
     assert ip["stream_bytes"] < 0.85 * b_alg            # values + 1.25 bytes per slot, fill > 0.9 even on this small mesh (boundary rows are a third of it)
-    for kw in (dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2), dict(entry_mode=2, x_panel_kb=4, x_panel_merge=1), dict(desc_dict=1), dict(x_window=1), dict(entry_mode=2, wg_strips=32), dict(entry_mode=2, pace=1, pace_slab_kb=1)):
+    for kw in (dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2), dict(entry_mode=2, x_panel_kb=4, x_panel_merge=1), dict(desc_dict=1), dict(x_window=1), dict(entry_mode=2, wg_strips=32)):
         _, i = api.plan_layout_stages(tm, rows, n, nnz, csr_split=2, **kw)
-        assert i["csr_form"] == 2 and i["desc_bytes"] == 8 and i["x_panels"] == 1 and i["x_window_slots"] == 0 and i["wg_strips"] == 16 and i["pace_slabs"] == 0, kw
+        assert i["csr_form"] == 2 and i["desc_bytes"] == 8 and i["x_panels"] == 1 and i["wg_strips"] == 16, kw
     api.Tile_destroy(tm)
     for gen, want in ((G.laplacian7pt(48), 1), (G.laplacian5pt(200), 1), (G.fem_hex(9, 9, 9, 6), 2), (G.fem_hex(14, 11, 9, 3, shuffle=16), 2)):
         tm, rows, n, nnz = _tm(gen)

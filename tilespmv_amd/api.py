@@ -220,7 +220,7 @@ class Plan:
     @classmethod
     def from_csr(cls, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, cdna4=False, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, autotune=False, **knobs):
         """``tilespmv_plan_create_from_csr``: the tiled matrix and the plan's streams are built on the device; only the CSR arrays cross the bus.
-        Raises ``NotImplementedError`` for the options that have no device path (rc -4: first-generation kernel, CSR fallback, csr_split=0, x_window=1).  ``autotune=True``: every candidate is built from the one device-resident tiled matrix."""
+        Raises ``NotImplementedError`` for the options that have no device path (rc -4: first-generation kernel, CSR fallback, csr_split=0).  ``autotune=True``: every candidate is built from the one device-resident tiled matrix."""
         dtype = np.dtype(dtype or np.asarray(csrValA).dtype)
         lib = _lib.load(dtype)
         rp, ci, v = _csr(lib, csrRowPtrA, csrColIdxA, csrValA)

@@ -492,101 +492,6 @@ __device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, con
     }
 }
 
-// ---- slab-paced form of the workgroup entry phase (k_units<.., PACE = true>; DevStream::pace, hip_plan.h).  Same records, same adds in the same order as
-// wg_entry_trips; what changes is WHEN a wavefront issues the gathers of a 64-record chunk.  Why: on the large irregular matrices every scattered x gather
-// misses the XCD's 4-MB L2 and pulls a 128-byte line across the fabric for 8 useful bytes — band + random fill, 2 M rows: 739 MB moved for a 284-MB plan;
-// uniform random, 8 M rows: 7.7 GB for 0.9 GB, both at the fabric's 7 TB/s (profiles/r04_pmc_*_before.json) — while the same gathers run 4.5x faster when
-// x fits the L2 (profiles/r04_gather_locality.txt).  The lists are in column order, so every workgroup sweeps x from left to right; if the workgroups one
-// XCD holds at one time sweep TOGETHER, the x lines they want are the same few hundred KB at any moment and stay in that L2.
-// How: the columns are cut into slabs of 2^pace_shift columns (about 1 MB of x).  The workgroups an XCD holds at one time form a team (blockIdx.x & 7 = the
-// XCD under the round-robin dispatch, (blockIdx.x >> 3) / pace_twg = the team's generation).  A workgroup's list holds its LOCAL entries first (columns
-// around its own rows: shared with the neighbouring workgroups anyway; never paced), then the remote ones in column order.  The team follows a timetable:
-// slab s opens pace_sched[s] / 2^24 of pace_period after the team's start, where pace_sched is the share of the shard's remote entries left of slab s
-// (a slot as long as the slab has work) and the team's start is the constant 100-MHz clock (s_memrealtime) at which its first wavefront finished its
-// local entries (one compare-and-swap per wavefront).  A wavefront that is ahead of the timetable sleeps until the slab of its next chunk — less
-// pace_win - 1 slabs of lead — opens; one that is behind just goes on.  No counters are polled and nobody waits for anybody: a first version that counted
-// finished wavefronts per slab spent its time in the polls (every wait is a round trip to the memory side — atomics do not execute in the L2 on this
-// part — and hundreds of wavefronts polled one line: band + random 0.107 -> 1.33 ms).  pace_period is calibrated at plan creation by timing
-// (hip_plan.hip): a plan that does not get faster is launched unpaced.  Speed only: no result depends on the clock; every wait ends when its slot opens,
-// at the latest pace_period after the team's start.
-__device__ __forceinline__ unsigned pace_clock()
-{
-    unsigned long long t;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    return (unsigned)t;
-}
-
-template <int CT, bool NTL>
-__device__ __forceinline__ void wg_entry_paced(const DevStream &S, const ERec *__restrict__ rec, const unsigned *__restrict__ base, int chunk0, int db, bool ordered,
-                                               const val_t *__restrict__ x, lacc_t *sy, int tid, int gb, int ge, int remote_from, unsigned *__restrict__ team, unsigned team_waves)
-{
-    constexpr int NT = 256;
-    const unsigned dmask = (1u << db) - 1u;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int shift = S.pace_shift, lead = S.pace_win - 1;
-    const unsigned period = S.pace_period;
-    const int nchunk = (ge - gb + 63) >> 6;              // chunks of this list; base[chunk0 + nchunk] = the list's last column (sentinel)
-    unsigned t0 = 0;                                     // the team's start on the 100-MHz clock (0 = not asked yet)
-    auto team_start = [&]() {                            // wave-uniform; first caller of the team sets the start
-        unsigned now = pace_clock() | 1u, old = 0;
-        if (lane == 0) {
-            unsigned expect = 0u;
-            __hip_atomic_compare_exchange_strong(&team[0], &expect, now, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            old = expect;                                // 0: this wavefront set it
-        }
-        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-        t0 = old ? old : now;
-    };
-    for (int e0 = gb; e0 < ge; e0 += NT * CT) {
-        ERec rr[CT]; unsigned cb[CT]; val_t xx[CT];
-#pragma unroll
-        for (int q = 0; q < CT; q++) {                   // unconditional, clamped: exact vmcnt
-            if constexpr (NTL) {
-                const unsigned *pw = reinterpret_cast<const unsigned *>(&rec[min(e0 + NT * q + tid, ge - 1)]);
-                unsigned *rw = reinterpret_cast<unsigned *>(&rr[q]);
-#pragma unroll
-                for (int z = 0; z < (int)(sizeof(ERec) / 4); z++) rw[z] = __builtin_nontemporal_load(pw + z);
-            } else rr[q] = rec[min(e0 + NT * q + tid, ge - 1)];
-            cb[q] = base[chunk0 + __builtin_amdgcn_readfirstlane(min(((e0 - gb) >> 6) + (NT / 64) * q + wave, nchunk - 1))];
-        }
-#pragma unroll
-        for (int q = 0; q < CT; q++) {
-            const int ebeg = e0 + NT * q + 64 * wave;    // this wavefront's chunk (wave-uniform)
-            if (period != 0u && ebeg < ge && ebeg >= remote_from) {
-                if (t0 == 0u) team_start();
-                const int slab = max(0, (int)(cb[q] >> shift) - lead);
-                const unsigned open_at = (unsigned)(((unsigned long long)S.pace_sched[slab] * period) >> 24);
-                unsigned el = pace_clock() - t0;         // (a stale or garbled start reads as "long ago": no wait)
-                while (el < open_at) {
-                    const unsigned left = open_at - el;                 // 10-ns ticks; s_sleep n = 64 n cycles, about 27 n ns
-                    if (left > 400u) __builtin_amdgcn_s_sleep(127); else if (left > 60u) __builtin_amdgcn_s_sleep(20); else __builtin_amdgcn_s_sleep(2);
-                    el = pace_clock() - t0;
-                }
-            }
-            xx[q] = x[(size_t)(cb[q] + (rr[q].w >> db))];
-        }
-        if (ordered) {
-            for (int w = 0; w < NT / 64; w++) {
-                if (wave == w) {
-#pragma unroll
-                    for (int q = 0; q < CT; q++)
-                        if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
-                }
-                __syncthreads();
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < CT; q++)
-                if (e0 + NT * q + tid < ge) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
-        }
-    }
-    // the last wavefront of the team to get here clears the team's start for the next launch
-    unsigned prev = 0;
-    if (lane == 0) prev = __hip_atomic_fetch_add(&team[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
-    if (prev == team_waves - 1u && lane < 2) __hip_atomic_store(&team[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // ================================================================================================
 // Very-sparse fallback: y[row] += sum_j val[j] * x[col[j]] over the extracted matrix (the reference hands it to CSR5,
 // src/tilespmv_cuda.h:1011-1029,:1080; kernels src/external/CSR5_cuda/detail/cuda/csr5_spmv_cuda.h:277-420).
@@ -624,34 +529,28 @@ hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream
 // 1 per wavefront (the four strips' lists concatenated), 2 per workgroup (merged + column-ordered list, see above).
 // GPB: strips (16-lane groups) per workgroup — 16 (256 threads) or, for the workgroup entry mode on large entry-heavy shards, 32
 // (512 threads: twice as many tile-rows share one column-ordered list, so fewer distinct x lines per entry; same waves per SIMD).
-// XWIN: x-window plans (hip_plan.h) — the workgroup's strips form a brick of the grid, the x segments (column blocks) their
-// units touch are loaded ONCE per workgroup into LDS (dynamic shared memory, sized by the plan) and the units read x from there;
-// the descriptor's low 24 bits then hold the window slot.  Strips of such plans have at most XWIN_STRIP_ROWS tile-rows.  (The window
-// leaves room for 4-5 workgroups per CU, so the workgroup-entry form is built for 4 waves per SIMD: at 6 it spills 20 bytes.)
+// (Retired in round 6, both measured slower than what replaced them: x windows staged in LDS — DESIGN S6.9 — and the slab-paced entry phase — S6.17.  The XCD remap is a run-time
+// scalar branch now (xcd_chunk > 0) instead of a template axis.)
 extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
 // CD: dictionary plans (4-B descriptors, above).  The descriptor words are loaded two chunks ahead, the pattern of a chunk is
 // gathered from the dictionary one chunk ahead (when its word has arrived), so neither hop is waited for in the unit loop.
 // NTS: value and entry-record loads are nontemporal (plans larger than the Infinity Cache, DevStream::nt_stream).
-// PACE: slab-paced workgroup entry phase (wg_entry_paced above; ECOO = 2, 256-thread workgroups, no x windows).
 // POOL: pooled plans (hip_plan.h "pooled units", round 5): a unit is up to 16 nonzeros of a tile-row inside one 16-column window of x — slot s = value, column-offset nibble, row nibble —
 // so a lane no longer owns a row: it gathers x[base + its column nibble] and adds its product to the strip's slab of s_y with ds_add (destination = tile-row in strip, its row
 // nibble); there is no register accumulator, no end-of-row handling and no "rows without units": the slab is zeroed up front, entries and units add into it, y is stored from it.
 // The row nibbles travel like the descriptors (8 bytes per unit, one coalesced lane load per chunk of 16 units, parked in LDS: + 2 KB per workgroup -> 7 workgroups per CU).
 // WIDE (with POOL; hip_plan.h "wide pooled units", csr_form 3): windows of 256 columns — a slot's column offset is a byte (16 bytes per unit in S.ucol, parked in s_c), the descriptor's nibble words hold the ROW nibbles.
-template <int UB, int XCD_REMAP, int ECOO, int GPB, bool XWIN, bool CD, bool NTS, bool PACE = false, bool POOL = false, bool WIDE = false>
-__global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_ECOO2_MIN_WAVES : ECOO2_MIN_WAVES) : POOL ? (WIDE ? 6 : POOL_MIN_WAVES) : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
+template <int UB, int ECOO, int GPB, bool CD, bool NTS, bool POOL = false, bool WIDE = false>
+__global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_ECOO2_MIN_WAVES : ECOO2_MIN_WAVES) : POOL ? (WIDE ? 6 : POOL_MIN_WAVES) : UNITS_MIN_WAVES) void k_units(DevStream S, int rowA, int colA, int xcd_chunk, val_t *__restrict__ partial,
                                                const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     static_assert(DCHUNK % UB == 0 && UB % UNIT_GROUP == 0, "a batch never straddles a descriptor chunk and is whole value groups");
-    static_assert(GPB == 16 || (GPB == 32 && ECOO == 2) || (GPB == 8 && ECOO != 2 && !XWIN && !PACE && !NTS), "512-thread workgroups exist for the workgroup entry mode only, 128-thread ones for small grids without it");
-    static_assert(!XWIN || (GPB == 16 && ECOO != 1), "x windows: 256-thread workgroups, per-strip or per-workgroup entries");
-    static_assert(!(XWIN && CD), "x-window plans keep 12-B descriptors (their low bits hold window slots)");
-    static_assert(!(NTS && (XWIN || ECOO == 1)), "nontemporal streams: large plans only (entry mode 1 = small grids; x windows are an opt-in experiment)");
-    static_assert(!PACE || (ECOO == 2 && GPB == 16 && !XWIN), "slab pacing: workgroup entry mode, 256-thread workgroups, no x windows");
-    static_assert(!POOL || ((GPB == 16 || GPB == 8) && !XWIN && !PACE), "pooled plans: 256-thread workgroups (128 on small grids), no x windows, no pacing");
+    static_assert(GPB == 16 || (GPB == 32 && ECOO == 2) || (GPB == 8 && ECOO != 2 && !NTS), "512-thread workgroups exist for the workgroup entry mode only, 128-thread ones for small grids without it");
+    static_assert(!(NTS && ECOO == 1), "nontemporal streams: large plans only (entry mode 1 = small grids)");
+    static_assert(!POOL || GPB == 16 || GPB == 8, "pooled plans: 256-thread workgroups (128 on small grids)");
     static_assert(!WIDE || (POOL && !CD), "wide windows: pooled plans, 12-B descriptors + 16 B of column offsets");
     constexpr int GROUPS_PER_BLOCK = GPB;
-    constexpr int SROWS = XWIN ? XWIN_STRIP_ROWS : POOL ? POOL_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
+    constexpr int SROWS = POOL ? POOL_STRIP_ROWS : STRIP_MAX_ROWS;   // tile-rows per strip the LDS slabs are sized for
     constexpr bool NT = NTS;  // nontemporal value loads
 #ifndef TILESPMV_NT_DESC
 #define TILESPMV_NT_DESC 0
@@ -672,14 +571,13 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
     __shared__ uint2 s_r[POOL && !WIDE ? GROUPS_PER_BLOCK : 1][POOL && !WIDE ? DCHUNK : 1];   // pooled plans: row nibbles of the parked descriptor chunk
     __shared__ uint4 s_c[WIDE ? GROUPS_PER_BLOCK : 1][WIDE ? DCHUNK : 1];                   // wide pooled plans: column-offset bytes of the parked chunk
-    val_t *s_xw = reinterpret_cast<val_t *>(s_dyn);   // [window slot][16]
     TSPMV_DIAG_UNITS_LDS_PAD
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), each
-    // with a private L2; XCD_REMAP = 2 gives every XCD runs of xcd_chunk consecutive workgroups inside
+    // with a private L2; xcd_chunk > 0 gives every XCD runs of xcd_chunk consecutive workgroups inside
     // windows of 8 x xcd_chunk (bijective for any grid size, cdna_hip_programming.md T1).  Speed only.
     unsigned bid = blockIdx.x;
-    if (XCD_REMAP == 2) {
+    if (xcd_chunk > 0) {   // (kernel argument: a scalar branch)
         const unsigned C = (unsigned)xcd_chunk, W = 8u * C, win = bid / W, off = bid % W, k = off & 7u;
         if ((win + 1) * W <= gridDim.x) bid = win * W + k * C + (off >> 3);
     }
@@ -689,7 +587,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     const bool have = task_id < S.ntasks;
     constexpr bool WCOO = ECOO == 1;
     if (ECOO == 1) { if ((long long)bid * GROUPS_PER_BLOCK + (g & ~3) >= S.ntasks) return; }  // whole wavefronts leave together (wave-cooperative entry phase)
-    else if (ECOO == 0 && !XWIN && !have) return;                                             // ECOO == 2 / XWIN: every wavefront reaches the barriers
+    else if (ECOO == 0 && !have) return;                                                      // ECOO == 2: every wavefront reaches the barriers
     int4 t0 = make_int4(0, 0, 0, 0), t1 = make_int4(0, -1, 0, 0);
     if (have) {
         t0 = reinterpret_cast<const int4 *>(S.task)[task_id * 2];
@@ -714,16 +612,6 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
     const bool have_units = unit_begin < unit_end;
     const long long xlast = (long long)colA - 1;  // row units of a partial last column block: zero payload, clamped x index
     const int ncoo = coo_end - coo_begin;
-    // ---- x window of this workgroup: wcount segments of 16 x values, lane group g loads segments g, g + 16, ...
-    int wcount = 0;
-    if constexpr (XWIN) {
-        const int2 ww = S.wg_win[bid];
-        wcount = ww.y;
-        for (int i = g; i < wcount; i += GROUPS_PER_BLOCK) {
-            const long long xi = (long long)S.win_cb[ww.x + i] * 16 + r;
-            s_xw[i * 16 + r] = x[min(xi, xlast)];
-        }
-    }
     uint4 dcur = make_uint4(0u, 0u, 0u, 0u), dnext = dcur;
     uint2 rcur = make_uint2(0u, 0u), rnext = rcur;   // POOL: row nibbles of the chunks in dcur / dnext
     const uint2 *__restrict__ urw = reinterpret_cast<const uint2 *>(S.urow);
@@ -802,8 +690,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         for (int k = 0; k < UB; k++) {
             const unsigned fl = d[k].x >> 24;
             const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
-            if (XWIN && wcount > 0) xv[k] = s_xw[(d[k].x & 0xFFFFFFu) * 16 + nib];   // workgroup-uniform: a windowed workgroup's descriptors hold slots
-            else if (TSPMV_DIAG_UNIT_GATHER_SKIP(k)) xv[k] = xv[k - 1];
+            if (TSPMV_DIAG_UNIT_GATHER_SKIP(k)) xv[k] = xv[k - 1];
             else xv[k] = x[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast)];
         }
     };
@@ -825,15 +712,7 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
         // pipelined trips on top of that (78 VGPRs at 6 x 256, no spill): 0.1050-0.1062 against 0.1031-0.1046 — slightly worse
         unit_prologue();
         TSPMV_STAMP_WAIT(2);   // prologue has arrived (the entry loads are inside the trips)
-        if constexpr (PACE) {
-            // every wavefront of every workgroup takes part (a workgroup without entries reports all slabs as finished right away)
-            const unsigned xcd = blockIdx.x & 7u, gen = (blockIdx.x >> 3) / (unsigned)S.pace_twg;
-            const unsigned on_xcd = (gridDim.x - xcd + 7u) >> 3;           // workgroups of this launch on this XCD
-            const unsigned team_wgs = min((unsigned)S.pace_twg, on_xcd - gen * (unsigned)S.pace_twg);
-            unsigned *team = S.pace + (size_t)(xcd * (unsigned)S.pace_ngen + gen) * 2u;   // {start on the 100-MHz clock, wavefronts done}
-            wg_entry_paced<WCOO_HEAVY_CT, NTS>(S, S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y, wr.x + wr.w, team, team_wgs * 4u);
-            if (wr.y > wr.x) __syncthreads();
-        } else if (wr.y > wr.x) {
+        if (wr.y > wr.x) {
             int ge = wr.y;   // column-panelled launch: this kernel takes the first panel_merge panels of the list, k_entries_acc the rest
             if (GPB == 16 && S.panel_merge > 0) ge = S.panel_off[(size_t)bid * (size_t)(S.x_panels + 1) + (size_t)min(S.x_panels, S.panel_merge)];
             if (GPB == 16 && S.slice_passes > 0) ge = wr.x;   // column slices pinned to XCDs: the whole list belongs to k_entries_xcd
@@ -965,7 +844,6 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
             acc = 0;
         }
     };
-    if constexpr (XWIN) __syncthreads();   // the workgroup's x window is complete (every wavefront of an x-window kernel gets here)
     if (have_units) {  // phase 2: units, value loads software-pipelined by one batch
         if (ECOO != 1) {  // (entry mode 1 parked the first chunk and fetched the first batch before its entry phase)
             park_first();
@@ -1114,13 +992,13 @@ __global__ __launch_bounds__(16 * GPB, (XWIN && ECOO == 2) ? 4 : ECOO == 1 ? 4 :
 // adds the slots up in slot order — so a panelled plan's sums are as reproducible as the plain launch's.  (Rounds 4-5 added the pieces into y atomically: on R-MAT 22 x 8, 4,048 split
 // rows, two runs of ONE plan differed in 5 k rows' last bits while the plan's facts said "ordered" — scripts/rounds/r5b_repro_check.py.)
 // ------------------------------------------------------------------------------------------------
-template <int XCD_REMAP, bool NTS>
+template <bool NTS>
 __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream S, int rowA, int xcd_chunk, int panel, val_t *__restrict__ partial, const val_t *__restrict__ x, val_t *__restrict__ y)
 {
     __shared__ lacc_t s_acc[GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16];
     const int tid = threadIdx.x, r = tid & 15, g = tid >> 4;
     unsigned bid = blockIdx.x;
-    if (XCD_REMAP == 2) {   // the same workgroup -> XCD windows as k_units: a group's rows of y and its x neighbourhood stay with the XCD that touched them
+    if (xcd_chunk > 0) {   // the same workgroup -> XCD windows as k_units: a group's rows of y and its x neighbourhood stay with the XCD that touched them
         const unsigned C = (unsigned)xcd_chunk, W = 8u * C, win = bid / W, off = bid % W, k = off & 7u;
         if ((win + 1) * W <= gridDim.x) bid = win * W + k * C + (off >> 3);
     }
@@ -1232,10 +1110,9 @@ hipError_t launch_entry_panels(const DevPlan &P, const DevStream &S, int xcd_rem
     const int passes = (S.x_panels + S.panel_merge - 1) / S.panel_merge, rowA = P.rowA;
     for (int p = 1; p < passes; p++) {
         const dim3 grid((unsigned)S.n_groups), blk(256);
-        if (xcd_remap == 2) { if (S.nt_stream) hipLaunchKernelGGL((k_entries_acc<2, true>), grid, blk, 0, st, S, rowA, xcd_chunk, p, P.partial, x, y);
-                              else hipLaunchKernelGGL((k_entries_acc<2, false>), grid, blk, 0, st, S, rowA, xcd_chunk, p, P.partial, x, y); }
-        else { if (S.nt_stream) hipLaunchKernelGGL((k_entries_acc<0, true>), grid, blk, 0, st, S, rowA, xcd_chunk, p, P.partial, x, y);
-               else hipLaunchKernelGGL((k_entries_acc<0, false>), grid, blk, 0, st, S, rowA, xcd_chunk, p, P.partial, x, y); }
+        const int xc = xcd_remap == 2 ? xcd_chunk : 0;   // (0 = workgroups in dispatch order)
+        if (S.nt_stream) hipLaunchKernelGGL((k_entries_acc<true>), grid, blk, 0, st, S, rowA, xc, p, P.partial, x, y);
+        else hipLaunchKernelGGL((k_entries_acc<false>), grid, blk, 0, st, S, rowA, xc, p, P.partial, x, y);
     }
     // the split rows once more, now that their pieces' slots hold the entries of every panel (slot order: the plan's)
     if (passes > 1 && P.nfix > 0) hipLaunchKernelGGL(k_fixup_split, dim3((P.nfix + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(256), 0, st, P, y);
@@ -1414,7 +1291,8 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     // the next descriptor chunk is prefetched into registers (4 VGPRs) except in the fp64 nvec 4 / 8 variants: there the
     // prefetch pushed the kernel 12 bytes into scratch at 80 VGPRs, and loading the chunk at the switch is 3.4-4.3 % faster
     // (profiles/r03_spmm.txt)
-    constexpr bool MV_PREFETCH_DESC = !(sizeof(val_t) == 8 && NVT >= 4);
+    // (round 6: the fp32 nvec 8 variant with 12-B descriptors spilled the same 12 bytes: same cure)
+    constexpr bool MV_PREFETCH_DESC = !(sizeof(val_t) == 8 && NVT >= 4) && !(sizeof(val_t) == 4 && NVT >= 8 && !CD);
     __shared__ lacc_t s_c[GROUPS_PER_BLOCK][16][NV];
     __shared__ val_t s_p[GROUPS_PER_BLOCK][16][NV];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
@@ -2088,59 +1966,38 @@ hipError_t launch_pair_values(const val_t *src, val_t *dst, const int4 *map, int
     return hipGetLastError();
 }
 
-int paced_team_workgroups(bool dict_desc, bool nt_stream, int xcd_remap, int lds_pad_bytes)
-{
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    hipError_t e;
-#define TSPMV_OCC(X, CD, NTS) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_units<TILESPMV_UB, X, 2, 16, false, CD, NTS, true>, 256, (size_t)lds_pad_bytes)
-    if (xcd_remap == 2) { if (dict_desc) { if (nt_stream) TSPMV_OCC(2, true, true); else TSPMV_OCC(2, true, false); } else { if (nt_stream) TSPMV_OCC(2, false, true); else TSPMV_OCC(2, false, false); } }
-    else { if (dict_desc) { if (nt_stream) TSPMV_OCC(0, true, true); else TSPMV_OCC(0, true, false); } else { if (nt_stream) TSPMV_OCC(0, false, true); else TSPMV_OCC(0, false, false); } }
-#undef TSPMV_OCC
-    if (e != hipSuccess || per_cu <= 0) return 0;
-    return per_cu * std::max(1, prop.multiProcessorCount / 8);   // 8 XCDs on gfx950
-}
-
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xwin_lds_bytes, int lds_pad_bytes, int xcd_remap, int xcd_chunk,
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int lds_pad_bytes, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st)
 {
     if (S.ntasks > 0) {
-#define TSPMV_L5(X, W, B, XW, CD, NTS, PC) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, B, XW, CD, NTS, PC>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)((XW ? xwin_lds_bytes : 0) + lds_pad_bytes), st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
-#define TSPMV_L4(X, W, B, XW, CD, NTS) do { if ((W) == 2 && (B) == 16 && !(XW) && S.pace != nullptr) TSPMV_L5(X, W, B, XW, CD, NTS, ((W) == 2 && (B) == 16 && !(XW))); else TSPMV_L5(X, W, B, XW, CD, NTS, false); } while (0)
-#define TSPMV_L3(X, W, B, CD) do { if (S.nt_stream) TSPMV_L4(X, W, B, false, CD, true); else TSPMV_L4(X, W, B, false, CD, false); } while (0)
-#define TSPMV_L2(X, W, B) do { if (S.cb_bits > 0) TSPMV_L3(X, W, B, true); else TSPMV_L3(X, W, B, false); } while (0)
-#define TSPMV_L1(X) do { if (xwin_lds_bytes > 0 && entry_mode == 2) TSPMV_L4(X, 2, 16, true, false, false); else if (xwin_lds_bytes > 0) TSPMV_L4(X, 0, 16, true, false, false); \
-        else if (entry_mode == 2 && wg_strips == 32) TSPMV_L2(X, 2, 32); else if (entry_mode == 2) TSPMV_L2(X, 2, 16); \
-        else if (entry_mode == 1) { if (S.cb_bits > 0) TSPMV_L4(X, 1, 16, false, true, false); else TSPMV_L4(X, 1, 16, false, false, false); } else TSPMV_L2(X, 0, 16); } while (0)
-#define TSPMV_LPD(X, W, NTS, PD, WD) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, 16, false, PD, NTS, false, true, WD>), dim3((unsigned)((S.ntasks + 15) / 16)), dim3(256), (size_t)lds_pad_bytes, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
-#define TSPMV_LP(X, W, NTS) do { if (S.ucol) TSPMV_LPD(X, W, NTS, false, true); else if (S.pdict) TSPMV_LPD(X, W, NTS, true, false); else TSPMV_LPD(X, W, NTS, false, false); } while (0)
-#define TSPMV_LP1(X) do { if (entry_mode == 1) TSPMV_LP(X, 1, false); else if (entry_mode == 2) { if (S.nt_stream) TSPMV_LP(X, 2, true); else TSPMV_LP(X, 2, false); } \
-        else { if (S.nt_stream) TSPMV_LP(X, 0, true); else TSPMV_LP(X, 0, false); } } while (0)
+        const int xc = xcd_remap == 2 ? xcd_chunk : 0;   // workgroup -> XCD windows: a kernel argument (0 = dispatch order)
+        // k_units<UB, entry mode, strips per workgroup, dictionary descriptors, nontemporal streams, pooled, wide>
+#define TSPMV_K(W, B, CD, NTS, PL, WD) hipLaunchKernelGGL((k_units<TILESPMV_UB, W, B, CD, NTS, PL, WD>), dim3((unsigned)((S.ntasks + B - 1) / B)), dim3(16 * B), (size_t)lds_pad_bytes, st, S, P.rowA, P.colA, xc, P.partial, x, y)
+#define TSPMV_NTS(W, B, CD, PL, WD) do { if (S.nt_stream) TSPMV_K(W, B, CD, true, PL, WD); else TSPMV_K(W, B, CD, false, PL, WD); } while (0)
+        // the descriptor form of the plan: classic 12-B / dictionary; pooled 20-B / pooled dictionary / wide
+#define TSPMV_FORM_(W, B, L) do { \
+            if (S.pooled) { if (S.ucol) L(W, B, false, true, true); else if (S.pdict) L(W, B, true, true, false); else L(W, B, false, true, false); } \
+            else if (S.cb_bits > 0) L(W, B, true, false, false); else L(W, B, false, false, false); } while (0)
+#define TSPMV_PLAIN(W, B, CD, PL, WD) TSPMV_K(W, B, CD, false, PL, WD)
+#define TSPMV_FORM(W, B) TSPMV_FORM_(W, B, TSPMV_NTS)          /* large plans: nontemporal streams where the plan says so */
+#define TSPMV_FORM_SMALL(W, B) TSPMV_FORM_(W, B, TSPMV_PLAIN)  /* small grids, entry mode 1: default cache policy */
         // Grids that would give fewer than half the CUs a 256-thread workgroup run 128-thread workgroups of 8 strips instead: twice the workgroups, the same strips
         // (per-strip and per-wavefront entry modes only: the workgroup mode merges the lists of its 16 strips at plan creation)
         static const int small_grid_workgroups = [] { const char *e = getenv("TILESPMV_SMALL_GRID_WORKGROUPS"); return e && *e ? atoi(e) : SMALL_GRID_WORKGROUPS; }();   // (0 switches the form off)
-        const bool small_grid = entry_mode != 2 && xwin_lds_bytes == 0 && !S.nt_stream && S.pace == nullptr && (S.ntasks + 15) / 16 < small_grid_workgroups;
-#define TSPMV_S8(X, W, CD, PL, WD) hipLaunchKernelGGL((k_units<TILESPMV_UB, X, W, 8, false, CD, false, false, PL, WD>), dim3((unsigned)((S.ntasks + 7) / 8)), dim3(128), (size_t)lds_pad_bytes, st, S, P.rowA, P.colA, xcd_chunk, P.partial, x, y)
-#define TSPMV_S8W(X, CD, PL, WD) do { if (entry_mode == 1) TSPMV_S8(X, 1, CD, PL, WD); else TSPMV_S8(X, 0, CD, PL, WD); } while (0)
-#define TSPMV_S8X(CD, PL, WD) do { if (xcd_remap == 2) TSPMV_S8W(2, CD, PL, WD); else TSPMV_S8W(0, CD, PL, WD); } while (0)
-        if (small_grid) {
-            if (S.pooled) { if (S.ucol) TSPMV_S8X(false, true, true); else if (S.pdict) TSPMV_S8X(true, true, false); else TSPMV_S8X(false, true, false); }
-            else if (S.cb_bits > 0) TSPMV_S8X(true, false, false); else TSPMV_S8X(false, false, false);
+        const bool small_grid = entry_mode != 2 && !S.nt_stream && (S.ntasks + 15) / 16 < small_grid_workgroups;
+        if (small_grid) { if (entry_mode == 1) TSPMV_FORM_SMALL(1, 8); else TSPMV_FORM_SMALL(0, 8); }
+        else if (entry_mode == 1) TSPMV_FORM_SMALL(1, 16);                                    // (entry mode 1 = small grids: never nontemporal)
+        else if (entry_mode == 2 && wg_strips == 32 && !S.pooled) {                          // 512-thread workgroups: classic / dictionary descriptors only
+            if (S.cb_bits > 0) TSPMV_NTS(2, 32, true, false, false); else TSPMV_NTS(2, 32, false, false, false);
         }
-        else if (S.pooled) { if (xcd_remap == 2) TSPMV_LP1(2); else TSPMV_LP1(0); }
-        else if (xcd_remap == 2) TSPMV_L1(2); else TSPMV_L1(0);
-#undef TSPMV_S8X
-#undef TSPMV_S8W
-#undef TSPMV_S8
-#undef TSPMV_LP1
-#undef TSPMV_LP
-#undef TSPMV_LPD
-#undef TSPMV_L1
-#undef TSPMV_L2
-#undef TSPMV_L3
-#undef TSPMV_L4
-#undef TSPMV_L5
+        else if (entry_mode == 2) TSPMV_FORM(2, 16);
+        else TSPMV_FORM(0, 16);
+#undef TSPMV_FORM_SMALL
+#undef TSPMV_FORM
+#undef TSPMV_PLAIN
+#undef TSPMV_FORM_
+#undef TSPMV_NTS
+#undef TSPMV_K
     }
     // whole-tile passes (y += ...): CSR tiles kept as tiles, dense tiles on the matrix cores; then the split-row fix-up
     hipError_t e = launch_tiles_direct(P, dense_mfma, /*accumulate=*/true, /*fixup=*/false, x, y, st);

@@ -94,8 +94,6 @@ struct DevPlan {
 constexpr int FB_ROWS = 2048;             // fallback row block: rows (= 16 x 128: the entry lists' 4 + 7 destination bits) ...
 constexpr int FB_CAP = 6144;              // ... and nonzeros (4 trips of 6 x 256)
 constexpr int STRIP_MAX_ROWS = 8;         // tile-rows per strip (3 bits of row-in-strip)
-constexpr int XWIN_STRIP_ROWS = 4;        // ... in x-window plans (the LDS the y slabs give up goes to the window)
-constexpr int XWIN_MAX_SLOTS = 224;       // column blocks (16 x values each) a workgroup's window may hold: 28 KB fp64 / 14 KB fp32
 constexpr unsigned UNIT_EOR = 1u;         // unit flag bit 0: last unit of its tile-row -> write y
 constexpr int UNIT_ROW_SHIFT = 1;         // unit flag bits 1-3: tile-row inside the strip
 constexpr unsigned UNIT_ROWUNIT = 16u;    // unit flag bit 4: "row unit" = 16 values of ONE tile row (dense-row tiles);
@@ -168,20 +166,9 @@ struct DevStream {
     const ERec *grec;
     const unsigned *gbase;                // column base per chunk of ECHUNK records, chunks counted from the list's begin
     int dest_bits;                        // 9 (wavefront lists), 11 (16 strips per workgroup) or 12 (32 strips)
-    // x-window plans (stencil-like shards): the 16 strips of a workgroup are a brick of the grid — chosen at plan time
-    // from the dominant tile-row distances of the shard — and the column blocks their units touch are loaded once per workgroup
-    // into LDS.  Descriptors of a windowed workgroup carry the window slot in their low 24 bits; a workgroup whose units touch
-    // more than XWIN_MAX_SLOTS column blocks keeps column blocks and reads x from global memory (window count 0).
-    const int2 *wg_win;                   // per workgroup: [begin, count) in win_cb
-    const int *win_cb;                    // column block of every window slot
     const uint2 *udict;                   // dictionary plans: the column patterns (nibbles of rows 0-7, of rows 8-15); udesc / udesc_cb then hold 4-B words
     int cb_bits;                          // ... column block (cb_bits) | pattern id | flags << 27;  0 = 12-B descriptors
     int nt_stream;                        // 1: value / entry-record loads are nontemporal (the plan's streams do not fit the Infinity Cache)
-    // slab pacing of the workgroup entry mode (round 4; hip_kernels.hip wg_entry_paced): the columns are cut into slabs of 2^pace_shift columns (about
-    // 1 MB of x), the workgroups one XCD holds at one time form a team, and the team sweeps the slabs by a timetable on the constant 100-MHz clock, so
-    // that its scattered gathers fall into the same few slabs — which stay in the XCD's L2 — instead of each pulling a 128-byte line across the fabric
-    // (profiles/r04_gather_locality.txt).  Lists of paced plans: the workgroup's local entries first (wg_coo.w = their record count, a multiple of 64),
-    // then the remote ones in column order, one more base word per list (its last column).  Speed only: no result depends on the clock.
     // column panels (round 4): a group's merged list is in column order, so the entries of column panel p (2^k columns, a few MB of x) are the run
     // [panel_off[group * (x_panels + 1) + p], panel_off[.. + p + 1]) of it.  A launch either walks whole lists in k_units (panel_merge = 0) or gives k_units the first
     // panel_merge panels and each further run of panel_merge panels a launch of k_entries_acc (y +=): all gathers of one pass then fall into one slice of x.
@@ -194,13 +181,7 @@ struct DevStream {
     // ever gathers from its own slice of x — which stays in its L2 — and adds the rows it touched to y atomically (sums not bit-reproducible).  0 = off
     int slice_passes;
     int slice_ct;                         // ... records per lane and trip of k_entries_xcd (4, 6 or 8: set with slice_passes from the average run length)
-    unsigned *pace;                       // per team {start clock, wavefronts done}; nullptr: no pacing
-    const unsigned *pace_sched;           // [pace_nslab + 1]: share of the shard's remote entries left of slab s, in 1 / 2^24
-    unsigned pace_period;                 // 10-ns ticks one team's sweep is given (calibrated at plan creation; 0: nobody waits)
-    int pace_shift, pace_nslab, pace_win;
-    int pace_twg;                         // workgroups per team = workgroups of this kernel one XCD holds at one time
-    int pace_ngen;                        // teams per XCD
-    const UDesc *udesc_cb;                // descriptors with column blocks for the multi-vector kernel (== udesc when there is no window)
+    const UDesc *udesc_cb;                // descriptors of the multi-vector kernel (== udesc)
     // split tile-rows whose pieces all live in the unit kernel are summed in that kernel by the piece that
     // finishes last (fixed slot order): ifix[i] describes row i, ifix_count[i] counts finished pieces
     const FixRow *ifix;

@@ -14,7 +14,7 @@
 namespace tilespmv {
 
 hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulate, bool fixup, const val_t *x, val_t *y, hipStream_t st);
-hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int xwin_lds_bytes, int lds_pad_bytes, int xcd_remap, int xcd_chunk,
+hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int lds_pad_bytes, int xcd_remap, int xcd_chunk,
                                const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_fallback(const DevPlan &P, const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_tiles_stream_mv(const DevPlan &P, const DevStream &S, const DevDense &DN, int nvec, int xcd_chunk, bool entries_pass, int slab_rows, const val_t *X, val_t *Y,
@@ -60,11 +60,6 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.mv_xcd_chunk = pick(o.mv_xcd_chunk, "TILESPMV_MV_XCD_CHUNK", -1);
     k.desc_dict = pick(o.desc_dict, "TILESPMV_DESC_DICT", -1);
     k.nt_stream = pick(o.nt_stream, "TILESPMV_NT_STREAM", -1);
-    k.pace = pick(o.pace, "TILESPMV_PACE", -1);
-    k.pace_slab_kb = pick(o.pace_slab_kb, "TILESPMV_PACE_SLAB_KB", 1024);
-    k.pace_window = std::max(1, pick(o.pace_window, "TILESPMV_PACE_WINDOW", 2));
-    k.pace_team = pick(o.pace_team, "TILESPMV_PACE_TEAM", 0);
-    k.pace_period_us = pick(o.pace_period_us, "TILESPMV_PACE_PERIOD_US", -1);
     k.placement_tries = pick(o.placement_tries, "TILESPMV_PLACEMENT_TRIES", -1);
     k.x_panel_kb = pick(o.x_panel_kb, "TILESPMV_X_PANEL_KB", -1);
     k.x_panel_merge = pick(o.x_panel_merge, "TILESPMV_X_PANEL_MERGE", -1);
@@ -74,8 +69,6 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
         if (k.placement_tries < 0) k.placement_tries = 1;
         if (k.x_panel_merge < 0) k.x_panel_merge = 0;
         if (k.x_slice_passes < 0) k.x_slice_passes = 0;
-        if (k.pace < 0) k.pace = 0;
-        if (k.pace > 0 && k.pace_period_us < 0) k.pace = 0;   // (a paced plan calibrates its timetable by timing)
         k.autotune = 0;
         k.entry_ordered = 1; k.x_slice_passes = 0;            // (column slices add rows in an order that is not fixed)
     }
@@ -104,7 +97,7 @@ static void for_each_plan_pointer(tilespmv_plan *plan, F f)
     //     re-placement left it pointing into freed blocks) — and (2) the members that are copies of, or were assigned from, an uploaded pointer
     for (const void **slot : plan->uploaded_slots) f(*slot);
     (void)D; (void)N;
-    v(D.partial); v(S.udesc_cb); v(S.ifix_count); v(S.pace);
+    v(D.partial); v(S.udesc_cb); v(S.ifix_count);
 }
 
 // Placement retry: identical plans run in one of two states 13 % apart on the KKT matrices, decided by where their blocks
@@ -263,7 +256,7 @@ const char *tilespmv_plan_options_layout(void)
         TSPMV_F(entry_mode) TSPMV_F(entry_ordered) TSPMV_F(strip_cost) TSPMV_F(split_above) TSPMV_F(split_cap) TSPMV_F(xcd_remap) TSPMV_F(xcd_chunk)
         TSPMV_F(csr_split) TSPMV_F(fix_inline) TSPMV_F(coo_cost) TSPMV_F(coo_heavy_min) TSPMV_F(coo_piece) TSPMV_F(strip_even) TSPMV_F(wg_strips)
         TSPMV_F(x_window) TSPMV_F(x_stride1) TSPMV_F(x_stride2) TSPMV_F(mv_native) TSPMV_F(mv_xcd_chunk) TSPMV_F(lds_pad) TSPMV_F(y_store)
-        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(pace) TSPMV_F(pace_slab_kb) TSPMV_F(pace_window) TSPMV_F(pace_team) TSPMV_F(pace_period_us) TSPMV_F(x_panel_kb) TSPMV_F(x_panel_merge) TSPMV_F(placement_tries) TSPMV_F(x_slice_passes) TSPMV_F(deterministic) TSPMV_F(reserved)
+        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(x_panel_kb) TSPMV_F(x_panel_merge) TSPMV_F(placement_tries) TSPMV_F(x_slice_passes) TSPMV_F(deterministic) TSPMV_F(reserved)
 #undef TSPMV_F
         return o;
     }();
@@ -413,7 +406,7 @@ static int plan_create_tuned(tilespmv_plan **out, const Tile_matrix *T, int rowA
     // cache policy of the once-read streams: the size rule (nontemporal above 400 MB per launch) switches somewhere between 340 and 500 MB; a measured selection
     // just times both (the kernels differ by a template flag only: nothing is rebuilt).  Entry mode 1 and x-window plans have no nontemporal form.
     log += "], \"stream_policy\": [";
-    if (best && best->kernel == TILESPMV_KERNEL_STREAM && K0.nt_stream < 0 && best->entry_mode != 1 && best->xwin_lds_bytes == 0) {
+    if (best && best->kernel == TILESPMV_KERNEL_STREAM && K0.nt_stream < 0 && best->entry_mode != 1) {
         const int rule = best->st.nt_stream;
         double ms2[2] = {0, 0};
         for (int k = 0; k < 2; k++) {
@@ -447,48 +440,6 @@ static int plan_create_tuned(tilespmv_plan **out, const Tile_matrix *T, int rowA
     }
     *out = best;
     return 0;
-}
-
-// Slab-paced plans (DevStream::pace): how long one team's timetable is, found by timing.  The unpaced launch first; then timetables of 0.1 ... 1.2 of
-// (unpaced time / generations of teams), the best one refined once.  Pacing is kept only when it is at least 3 % faster than the unpaced launch of the
-// same plan — otherwise the plan is launched unpaced (S.pace = nullptr) and says so in its facts.  TILESPMV_PLAN_VERBOSE prints the candidates.
-static void calibrate_pace(tilespmv_plan *plan)
-{
-    DevStream &S = plan->st;
-    const bool verbose = getenv("TILESPMV_PLAN_VERBOSE") != nullptr;
-    val_t *dx = nullptr, *dy = nullptr;
-    const size_t nx = (size_t)plan->dev.colA + 16, ny = (size_t)plan->dev.rowA + 16;
-    unsigned *const pace = S.pace;
-    auto give_up = [&]() { S.pace = nullptr; S.pace_period = 0; plan->info[TILESPMV_INFO_PACE_SLABS] = 0; plan->info[TILESPMV_INFO_PACE_PERIOD_US] = 0; };
-    if (hipMalloc((void **)&dx, nx * sizeof(val_t)) != hipSuccess) { (void)hipGetLastError(); give_up(); return; }
-    if (hipMalloc((void **)&dy, ny * sizeof(val_t)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dx); give_up(); return; }
-    {
-        std::vector<val_t> ones(nx, (val_t)1);
-        (void)hipMemcpy(dx, ones.data(), nx * sizeof(val_t), hipMemcpyHostToDevice);
-    }
-    S.pace = nullptr;
-    const double t_base = tilespmv_plan_time(plan, dx, dy, nullptr, 3, 10);
-    S.pace = pace;
-    const double grid = ((double)S.ntasks + 15) / 16, gens = std::max(1.0, grid / 8.0 / std::max(1, S.pace_twg));
-    double best = t_base, best_ticks = 0;
-    auto try_ticks = [&](double ticks) {
-        if (ticks < 100 || ticks > (double)(1u << 30)) return;
-        S.pace_period = (unsigned)ticks;
-        const double t = tilespmv_plan_time(plan, dx, dy, nullptr, 2, 8);
-        if (verbose) fprintf(stderr, "tilespmv: pace calibration: timetable %.1f us per team -> %.4f ms (unpaced %.4f)\n", ticks / 100.0, t, t_base);
-        if (t > 0 && t < best) { best = t; best_ticks = ticks; }
-    };
-    if (t_base > 0) {
-        const double unit = t_base * 1e5 / gens;     // ms -> 10-ns ticks, per generation
-        for (double f : {0.1, 0.17, 0.27, 0.4, 0.6, 0.85, 1.2}) try_ticks(unit * f);
-        if (best_ticks > 0) { const double c = best_ticks; try_ticks(c * 0.8); try_ticks(c * 1.25); }
-    }
-    (void)hipFree(dx); (void)hipFree(dy);
-    if (best_ticks > 0 && best < 0.97 * t_base) {
-        S.pace_period = (unsigned)best_ticks;
-        plan->info[TILESPMV_INFO_PACE_PERIOD_US] = (long long)(best_ticks / 100.0 + 0.5);
-    } else give_up();
-    if (verbose) fprintf(stderr, "tilespmv: pace calibration: %s (unpaced %.4f ms, best paced %.4f ms at %.1f us)\n", S.pace ? "kept" : "dropped", t_base, best, best_ticks / 100.0);
 }
 
 // Column panels (DevStream::panel_off): which launch form the entry lists get, found by timing — the plain launch (whole lists in the unit kernel), panelled launches with
@@ -876,12 +827,6 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         I[TILESPMV_INFO_ENTRY_ORDERED] = 0;
         I[TILESPMV_INFO_STREAM_BYTES] += plan->st.slice_passes * 8LL * (n_tasks * 32 + (long long)plan->st.n_groups * 16) + 2LL * sv * std::min<long long>(I[TILESPMV_INFO_SCATTERED_ENTRIES], 8LL * plan->st.slice_passes * plan->panel_rmw_rows / std::max(1, plan->st.x_panels));
     }
-    if (!K.dry && plan->pace_calibrate && plan->st.pace != nullptr) {
-        const double t0c = now_us();
-        calibrate_pace(plan);
-        I[TILESPMV_INFO_BUILD_US] += (long long)(now_us() - t0c);
-        I[TILESPMV_INFO_TIMED_CHOICES_US] += (long long)(now_us() - t0c);
-    }
     *out = plan;
     return 0;
 }
@@ -908,8 +853,7 @@ static int plan_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_PTR_TYPE n
     const Knobs K = resolve_knobs(opts);
     const int tilen = (colA + BS - 1) / BS;
     // what has no device path (include/tilespmv.h): the caller builds those plans from a host Tile_matrix
-    if (K.dry || (create_flags & TILESPMV_CREATE_HYB) || K.kernel == TILESPMV_KERNEL_DIRECT || tilen > (1 << UNIT_FLAG_SHIFT) || K.coo_mode == TILESPMV_COO_FALLBACK || K.csr_split == 0 ||
-        K.x_window == 1 || K.pace > 0)
+    if (K.dry || (create_flags & TILESPMV_CREATE_HYB) || K.kernel == TILESPMV_KERNEL_DIRECT || tilen > (1 << UNIT_FLAG_SHIFT) || K.coo_mode == TILESPMV_COO_FALLBACK || K.csr_split == 0)
         return -4;
     const double t0 = now_us();
     DevTile *D = nullptr;
@@ -980,7 +924,7 @@ int tilespmv_plan_spmv(tilespmv_plan *plan, const MAT_VAL_TYPE *d_x, MAT_VAL_TYP
 {
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = plan->dense_mode == TILESPMV_DENSE_MFMA;
-    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, plan->dn, mfma, plan->entry_mode, plan->wg_strips, plan->xwin_lds_bytes, plan->lds_pad_bytes, plan->xcd_remap, plan->xcd_chunk, d_x, d_y, st)
+    hipError_t e = plan->kernel == TILESPMV_KERNEL_STREAM ? launch_tiles_stream(plan->dev, plan->st, plan->dn, mfma, plan->entry_mode, plan->wg_strips, plan->lds_pad_bytes, plan->xcd_remap, plan->xcd_chunk, d_x, d_y, st)
                                                           : launch_tiles_direct(plan->dev, mfma, false, true, d_x, d_y, st);
     if (e != hipSuccess) return (int)e;
     return (int)launch_fallback(plan->dev, d_x, d_y, st);
@@ -1014,7 +958,7 @@ int tilespmv_plan_spmm(tilespmv_plan *plan, const MAT_VAL_TYPE *d_X, MAT_VAL_TYP
     // at a time at every nvec (webbase stand-in 37 / 58 / 93 us against 42 / 85 / 223) and beats the separate entry pass over the merged lists (k_entries_mv; workgroup entry mode,
     // 16 strips, no x windows) from nvec 4 on (power-law 8 M: 0.254 / 0.375 / 0.678 ms against 0.198 / 0.469 / 1.364 with the pass): the pass stays for nvec 2.
     // mv_native: -1 by rule, 0 one right-hand side at a time, 1 the multi-vector kernel alone, 2 the multi-vector kernel + entry pass
-    const bool can_pass = has_native && plan->entry_mode == 2 && plan->wg_strips == 16 && plan->xwin_lds_bytes == 0 && !plan->pooled;
+    const bool can_pass = has_native && plan->entry_mode == 2 && plan->wg_strips == 16 && !plan->pooled;
     const bool entries_pass = can_pass && (mv_native == 2 || (mv_native < 0 && plan->mv_by_columns && nvec < 4));
     const bool one_at_a_time = !has_native || mv_native == 0 || (mv_native < 0 && !plan->pooled && plan->mv_by_columns && !entries_pass && plan->mv_slab_rows == 0 && nvec < 8);
     if (one_at_a_time) {

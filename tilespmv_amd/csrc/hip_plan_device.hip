@@ -6,9 +6,7 @@
 #include <sys/time.h>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_run_length_encode.hpp>
-#include <rocprim/device/device_scan.hpp>
+#include "hip_prims.h"
 
 #include "hip_plan_device.h"
 
@@ -45,11 +43,11 @@ struct Tmp {
 hipError_t scan_in_place(int *a, size_t n)
 {
     size_t tmp_b = 0; void *tmp = nullptr;
-    hipError_t e = rocprim::exclusive_scan(nullptr, tmp_b, a, a, 0, n, rocprim::plus<int>(), (hipStream_t)0);
+    hipError_t e = prims::scan_int(nullptr, tmp_b, a, a, n, (hipStream_t)0);
     if (e != hipSuccess) return e;
     e = hipMalloc(&tmp, std::max<size_t>(tmp_b, 16));
     if (e != hipSuccess) return e;
-    e = rocprim::exclusive_scan(tmp, tmp_b, a, a, 0, n, rocprim::plus<int>(), (hipStream_t)0);
+    e = prims::scan_int(tmp, tmp_b, a, a, n, (hipStream_t)0);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(tmp);
     return e;
@@ -433,17 +431,16 @@ int dev_entry_lists(const val_t *d_cval, const int *d_ccol, const unsigned char 
     PD_TRY(hipGetLastError());
     const u64 *K = key_a.p; const int *Q = src_a.p;
     if (NE > 0) {
-        rocprim::double_buffer<u64> kb(key_a.p, key_b.p);
-        rocprim::double_buffer<int> vb(src_a.p, src_b.p);
+        u64 *k_cur = key_a.p, *k_alt = key_b.p; int *v_cur = src_a.p, *v_alt = src_b.p;
         int gbits = 1; while ((1ll << gbits) < nwg) gbits++;
         size_t tmp_b = 0; void *tmp = nullptr;
-        PD_TRY(rocprim::radix_sort_pairs(nullptr, tmp_b, kb, vb, (size_t)NE, 0u, (unsigned)(32 + gbits), (hipStream_t)0));
+        PD_TRY(prims::sort_pairs_u64_int(nullptr, tmp_b, k_cur, k_alt, v_cur, v_alt, (size_t)NE, 0u, (unsigned)(32 + gbits), (hipStream_t)0));
         PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
-        hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_b, kb, vb, (size_t)NE, 0u, (unsigned)(32 + gbits), (hipStream_t)0);
+        hipError_t e = prims::sort_pairs_u64_int(tmp, tmp_b, k_cur, k_alt, v_cur, v_alt, (size_t)NE, 0u, (unsigned)(32 + gbits), (hipStream_t)0);
         (void)hipDeviceSynchronize();
         (void)hipFree(tmp);
         PD_TRY(e);
-        K = kb.current(); Q = vb.current();
+        K = k_cur; Q = v_cur;
     }
     hipLaunchKernelGGL(k_pe_sizes, dim3(nblk((long long)nwg * 64, 256)), dim3(256), 0, 0, (const STask *)d_tasks.p, ntasks, (const int *)d_ofs.p, nwg, GS, dest_bits, count_scattered, K, d_nrec.p, d_nchunk.p, d_far.p);
     PD_TRY(hipGetLastError());
@@ -516,10 +513,10 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, hvec<int> &counts3,
         hipLaunchKernelGGL(k_pd_count_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, S.t_begin, nt, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, csr_form, C->tu, C->tc, C->td, C->tp);
         PD_TRY(hipGetLastError());
         size_t tmp_b = 0; void *tmp = nullptr;
-        PD_TRY(rocprim::exclusive_scan(nullptr, tmp_b, C->tu, C->tu, 0, (size_t)nt + 1, rocprim::plus<int>(), (hipStream_t)0));
+        PD_TRY(prims::scan_int(nullptr, tmp_b, C->tu, C->tu, (size_t)nt + 1, (hipStream_t)0));
         PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
         hipError_t e = hipSuccess;
-        for (int *a : {C->tu, C->tc, C->td, C->tp}) if (a && e == hipSuccess) e = rocprim::exclusive_scan(tmp, tmp_b, a, a, 0, (size_t)nt + 1, rocprim::plus<int>(), (hipStream_t)0);   // (same stream: the scans run one after the other)
+        for (int *a : {C->tu, C->tc, C->td, C->tp}) if (a && e == hipSuccess) e = prims::scan_int(tmp, tmp_b, a, a, (size_t)nt + 1, (hipStream_t)0);   // (same stream: the scans run one after the other)
         if (e == hipSuccess) e = hipDeviceSynchronize();
         (void)hipFree(tmp);
         PD_TRY(e);
@@ -621,19 +618,19 @@ int dev_dict_patterns(const UDesc *d_packed, long long NUP, size_t cap, std::vec
     PD_TRY(a.alloc((size_t)NUP, false)); PD_TRY(b.alloc((size_t)NUP, false));
     hipLaunchKernelGGL(k_pd_patterns, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, NUP, a.p);
     PD_TRY(hipGetLastError());
-    rocprim::double_buffer<u64> kb(a.p, b.p);
+    u64 *k_cur = a.p, *k_alt = b.p;
     size_t tmp_b = 0; void *tmp = nullptr;
-    PD_TRY(rocprim::radix_sort_keys(nullptr, tmp_b, kb, (size_t)NUP, 0u, 64u, (hipStream_t)0));
+    PD_TRY(prims::sort_keys_u64(nullptr, tmp_b, k_cur, k_alt, (size_t)NUP, 0u, 64u, (hipStream_t)0));
     PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
-    hipError_t e = rocprim::radix_sort_keys(tmp, tmp_b, kb, (size_t)NUP, 0u, 64u, (hipStream_t)0);
+    hipError_t e = prims::sort_keys_u64(tmp, tmp_b, k_cur, k_alt, (size_t)NUP, 0u, 64u, (hipStream_t)0);
     (void)hipDeviceSynchronize();
     (void)hipFree(tmp);
     PD_TRY(e);
     PD_TRY(uniq.alloc((size_t)NUP, false)); PD_TRY(counts.alloc((size_t)NUP, false)); PD_TRY(nruns.alloc(1, true));
     tmp_b = 0; tmp = nullptr;
-    PD_TRY(rocprim::run_length_encode(nullptr, tmp_b, kb.current(), (unsigned)NUP, uniq.p, counts.p, nruns.p, (hipStream_t)0));
+    PD_TRY(prims::rle_u64(nullptr, tmp_b, k_cur, 0u, (unsigned)NUP, uniq.p, counts.p, nruns.p, (hipStream_t)0));
     PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
-    e = rocprim::run_length_encode(tmp, tmp_b, kb.current(), (unsigned)NUP, uniq.p, counts.p, nruns.p, (hipStream_t)0);
+    e = prims::rle_u64(tmp, tmp_b, k_cur, 0u, (unsigned)NUP, uniq.p, counts.p, nruns.p, (hipStream_t)0);
     int n = 0;
     if (e == hipSuccess) e = hipMemcpy(&n, nruns.p, sizeof(int), hipMemcpyDeviceToHost);
     (void)hipFree(tmp);

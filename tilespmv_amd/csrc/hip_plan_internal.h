@@ -59,8 +59,6 @@ struct Knobs {
     int mv_native;       // -1 = by nvec
     int mv_xcd_chunk;    // -1 = the plan's XCD chunk
     int nt_stream;       // -1 by size, 0 plain, 1 nontemporal loads of the value / entry-record streams
-    int pace;            // slab pacing of the workgroup entry mode: -1 by rule, 0 off, 1 on
-    int pace_slab_kb, pace_window, pace_team, pace_period_us;   // pace_period_us < 0: calibrate at plan creation
     int x_panel_kb;      // column panels of the entry lists: KB of x per panel; 0 off, -1 by rule
     int x_panel_merge;   // ... panels per pass; 0 unpanelled launch, -1 chosen by timing
     int x_slice_passes;  // column slices pinned to XCDs: passes (8 slices each); 0 off, -1 chosen by timing beside the panelled forms
@@ -102,7 +100,6 @@ struct tilespmv_plan {
     int device = 0;
     int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
     int lds_pad_bytes = 0;              // extra (unused) dynamic LDS per workgroup of the unit kernel: caps the workgroups resident on a CU (knob lds_pad)
-    int xwin_lds_bytes = 0;             // x-window plans: dynamic LDS of the unit kernel (largest window of the plan); 0 = no windows
     int arena_flags = 0; size_t arena_skew = 0, arena_spacer = 0; bool arena_spacer_first_only = false;
     // Physical backing of large blocks (round 4; opt-in, TILESPMV_ARENA_VMM_MB = chunk size): a block larger than arena_vmm_chunk bytes is ONE virtual range
     // mapped onto separately created physical chunks of that size (hipMemAddressReserve / hipMemCreate / hipMemMap) instead of one hipMalloc.  Where a GB-sized plan lands
@@ -199,7 +196,6 @@ struct tilespmv_plan {
     bool slice_calibrate = false;       // ... and whether column slices pinned to XCDs beat them (DevStream::slice_passes)
     bool panel_calibrate = false;       // panels recorded, panels per pass still to be chosen by timing (plan_create_one)
     long long panel_rmw_rows = 0;       // rows of y the passes beyond the first read and write, at the finest panels (byte model)
-    bool pace_calibrate = false;        // slab-paced plan whose timetable length is still to be found by timing (plan_create_one)
     unsigned long long digest = 1469598103934665603ull;
     unsigned long long stage_digest[TILESPMV_STAGE_COUNT] = {0};   // layout-digest builds: one hash per stage of the unit-stream builder (hip_plan_stream.hip)
     std::vector<size_t> uploaded_bytes;          // ... and the bytes of each (tilespmv_plan_stream_digests)
@@ -382,8 +378,6 @@ inline bool pack_list(const std::vector<PEnt> &ents, int dest_bits, std::vector<
 // the value pass of the ENCODE stage on the device (hip_kernels.hip k_pair_values)
 hipError_t launch_pair_values(const val_t *src, val_t *dst, const int4 *map, int ntasks);
 
-// Workgroups of the slab-paced unit kernel one XCD holds at one time (occupancy query on the current device; hip_kernels.hip)
-int paced_team_workgroups(bool dict_desc, bool nt_stream, int xcd_remap, int lds_pad_bytes);
 
 // Second-generation layout (hip_plan_stream.hip): fills plan->st / plan->dn / the whole-tile pass of plan->dev for tile-rows [tr0, tr1).
 int build_stream(tilespmv_plan *plan, const Knobs &K, const Tile_matrix *T, int rowA, int colA, int tr0, int tr1, bool coo_in_tile,

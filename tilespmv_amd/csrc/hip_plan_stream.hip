@@ -107,12 +107,10 @@ struct StreamBuilder {
     hvec<long long> pu, pc, ph, phv, phi, pd;
     long long NU = 0, NC = 0, NH = 0, NHV = 0, NHI = 0, ND = 0;
     // CHOOSE
-    bool fix_inline_on = true, entry_heavy = false, entry_dominated = false, wave_coo = false, coo_ordered = false, brick = false, xwin = false;
+    bool fix_inline_on = true, entry_heavy = false, entry_dominated = false, wave_coo = false, coo_ordered = false, brick = false;
     long long total_cost = 0, est_wgs = 0;
     int target = 0, entry_mode = 0, wg_strips = 16, xs1 = 0, xs2 = 0, max_strip_rows = STRIP_MAX_ROWS;
     int panel_shift = 0, x_panels = 1;                          // column panels of the merged entry lists (hip_plan.h DevStream::x_panels)
-    bool pace_on = false; int pace_shift = 0, pace_nslab = 0;   // slab-paced entry phase (hip_plan.h DevStream::pace)
-    std::vector<long long> pace_hist;                           // ... remote entries per slab, whole shard (-> the teams' timetable)
     // CUT
     std::vector<STask> tasks;
     std::vector<Task> htasks;
@@ -131,10 +129,6 @@ struct StreamBuilder {
     std::vector<uint2> h_hdesc;
     // ORDER
     std::vector<uint4> h_udesc_cb;
-    std::vector<int2> h_wg_win;
-    std::vector<int> h_win_cb;
-    int xwin_slots_max = 0;
-    long long xwin_segments = 0, xwin_wgs = 0;
     // ENCODE / ENTRIES
     long long NUP = 0, n_rec = 0, n_chunk = 0, n_groups = 0, panel_rmw_rows = 0;
     bool pool_dict = false;   // pooled plan with 8-B descriptors + pattern dictionary
@@ -227,7 +221,7 @@ void StreamBuilder::count()
     if (rc) return;
     // (a caller who asks for a launch form that exists for the classic units only — column panels / slices, pacing, 512-thread workgroups, LDS x windows, a forced dictionary —
     //  gets the classic units)
-    const bool classic_asked = K.x_panel_kb > 0 || K.x_slice_passes > 0 || K.pace > 0 || K.wg_strips == 32 || K.x_window == 1 || K.desc_dict == 1;
+    const bool classic_asked = K.x_panel_kb > 0 || K.x_slice_passes > 0 || K.wg_strips == 32 || K.desc_dict == 1;
     // (nor is the second count worth its time where CSR tiles hold less than 3 % of the shard's stored values — the KKT stand-in: under 1 %; the band matrix's 5 % is worth it —: the pooled form pays 8-16 bytes more per
     //  unit on everything else and cannot come out 5 % ahead)
     long long csr_vals, all_vals;
@@ -401,36 +395,15 @@ void StreamBuilder::choose()
     // with its neighbours in the other two directions are then wanted at about the same time by one CU / one XCD, and hit in L1 /
     // L2 instead of being fetched again (nlpkkt160 stand-in: 3.07 -> 2.6-2.7 GB per launch at the fabric in fp64, 1.81 -> 1.56 GB in fp32;
     // time -2.5 ... -6 % in fp32, inside the matrix's 10 % placement spread in fp64: DESIGN.md S6.9).
-    //   x_window  -1 (default): brick order on large 3-D shards   0: off   2: brick order wherever strides are found
-    //              1: brick order + the workgroup's x segments staged once in LDS ("x windows": strips of at most XWIN_STRIP_ROWS
-    //                 tile-rows; cuts another ~0.4 GB but runs 25 % slower — profiles/r03_xwindow_and_map.txt; opt-in only)
+    //   x_window  -1 (default): brick order on large 3-D shards   0: off   1 / 2: brick order wherever strides are found
+    //   (rounds 3-5 also had 1 = the workgroup's x segments staged once in LDS: cut another ~0.4 GB but ran 25 % slower — profiles/r03_xwindow_and_map.txt; retired in round 6)
     xs1 = K.x_stride1 > 0 ? K.x_stride1 : 0; xs2 = K.x_stride2 > 0 ? K.x_stride2 : 0;
     brick = K.x_window != 0 && wg_strips == 16 && (K.x_window > 0 || est_wgs >= 2048);
     if (brick && xs1 == 0) detect_strides(T, tr0, tr1, csr_split, dense_mfma, &xs1, &xs2);
     if (xs1 < 2 || (K.x_window < 0 && xs2 == 0)) brick = false;   // (2-D grids: measured neutral on the 5-point 4096^2 case)
-    xwin = brick && K.x_window == 1 && entry_mode != 1 && !pooled;   // (the windowed kernel exists for entry modes 0 and 2, and for classic units)
     // (strips of at most 4 tile-rows in brick plans: nlpkkt160 stand-in fp64 0.418 -> 0.414 ms, fp32 0.252 -> 0.250 in one process; 2 rows: KKT 0.408 but 7-pt 256^3 +5 %)
-    max_strip_rows = xwin ? XWIN_STRIP_ROWS : pooled ? POOL_STRIP_ROWS : brick ? (K.brick_rows > 0 ? std::min(K.brick_rows, STRIP_MAX_ROWS) : 4) : STRIP_MAX_ROWS;
+    max_strip_rows = pooled ? POOL_STRIP_ROWS : brick ? (K.brick_rows > 0 ? std::min(K.brick_rows, STRIP_MAX_ROWS) : 4) : STRIP_MAX_ROWS;
     if (brick && !K.xcd_from_caller) plan->xcd_chunk = 8;   // bricks are compact: smaller XCD windows keep an XCD's resident set together
-    // ---- slab pacing of the workgroup entry mode (hip_plan.h DevStream::pace): worth it where scattered gathers miss the XCD's L2 — x clearly larger than
-    // an L2 — on shards that fill the chip (the teams are what one XCD holds at one time) with enough entries to pay for the bookkeeping
-    {
-        const long long x_bytes = (long long)colA * sv;
-        (void)x_bytes;
-        // Opt-in only (pace = 1).  Measured in round 4 (profiles/r04_slab_pacing.txt): a team keeps to a timetable only at >= 3 us per slab — every slab
-        // opens with all the team's wavefronts missing on its lines at once — and the teams of one XCD run one after the other, so no timetable beat the unpaced launch
-        // on band + random fill (2 M rows), uniform random (8 M), R-MAT (scale 22) or the power-law case; the calibration dropped every one of them.
-        pace_on = entry_mode == 2 && wg_strips == 16 && !xwin && !pooled && K.pace > 0;
-        if (pace_on) {
-            long long cols_per_slab = std::max<long long>(256, (long long)std::max(1, K.pace_slab_kb) * 1024 / sv);
-            pace_shift = 0;
-            while ((2ll << pace_shift) <= cols_per_slab) pace_shift++;
-            while ((((long long)colA - 1) >> pace_shift) + 1 > 4096) pace_shift++;          // a wavefront reports every slab it passes: keep their number bounded
-            pace_nslab = (int)((((long long)std::max(1, colA) - 1) >> pace_shift) + 1);
-            if (pace_nslab <= K.pace_window) pace_on = false;                               // everything is inside one window anyway
-        }
-        if (!pace_on) pace_shift = pace_nslab = 0;
-    }
     // ---- column panels of the entry lists (hip_plan.h DevStream::x_panels): scattered, entry-dominated shards whose x is several times an XCD's L2
     {
         const long long x_bytes = (long long)colA * sv;
@@ -438,7 +411,7 @@ void StreamBuilder::choose()
         // decided by timing (plan_create_one) — it does on uniform-random-like shards (8 M rows: 1.00 -> 0.80 ms) and does not where most entries sit near the diagonal
         const int kb = K.x_panel_kb >= 0 ? K.x_panel_kb : ((entry_dominated && x_bytes >= (12ll << 20)) ? 2048 : 0);
         x_panels = 1; panel_shift = 0;
-        if (kb > 0 && entry_mode == 2 && wg_strips == 16 && !xwin && !pooled && !pace_on && x_bytes > 1024LL * kb) {   // (the panel / slice kernels add into 8-row slabs: classic plans)
+        if (kb > 0 && entry_mode == 2 && wg_strips == 16 && !pooled && x_bytes > 1024LL * kb) {   // (the panel / slice kernels add into 8-row slabs: classic plans)
             long long cols = std::max<long long>(1024, 1024LL * kb / sv);
             while ((2ll << panel_shift) <= cols) panel_shift++;
             while ((((long long)colA - 1) >> panel_shift) + 1 > 64) panel_shift++;     // at most 64 passes
@@ -448,8 +421,8 @@ void StreamBuilder::choose()
     }
     if (hashing()) {
         Hash h;
-        h.num(pace_on); h.num(pace_shift); h.num(pace_nslab); h.num(x_panels); h.num(panel_shift);
-        for (long long v : {(long long)target, (long long)entry_mode, (long long)wg_strips, (long long)coo_ordered, (long long)xs1, (long long)xs2, (long long)brick, (long long)xwin, (long long)max_strip_rows}) h.num(v);
+        h.num(x_panels); h.num(panel_shift);
+        for (long long v : {(long long)target, (long long)entry_mode, (long long)wg_strips, (long long)coo_ordered, (long long)xs1, (long long)xs2, (long long)brick, (long long)max_strip_rows}) h.num(v);
         stage_done(TILESPMV_STAGE_CHOOSE, h);
     }
 }
@@ -638,10 +611,7 @@ void StreamBuilder::emit()
 
 void StreamBuilder::order()
 {
-    // ---- x windows: brick order of the strips, then one window of column blocks per workgroup
-    h_udesc_cb.clear();   // the descriptors with column blocks (multi-vector kernel), when windows put slots into h_udesc
-    xwin_slots_max = 0;
-    xwin_segments = 0; xwin_wgs = 0;
+    // ---- brick order of the strips
     if (brick && !tasks.empty() && DT && dev_fetch_word0(d_udesc, NU, h_uw0) != 0) { rc = -3; return; }
     if (brick && !tasks.empty()) {
         const size_t nt = tasks.size();
@@ -719,40 +689,13 @@ void StreamBuilder::order()
             for (size_t i = 0; i < nt; i++) permuted[i] = tasks[best_order[i]];
             tasks.swap(permuted);
         }
-        h_udesc_cb = h_udesc;
-        h_wg_win.assign(nwg, make_int2(0, 0));
-        std::vector<std::vector<int>> wg_blocks(nwg);
-        const bool order_only = !xwin;   // brick order alone: x is still gathered from global memory (through L1 / L2)
-        parallel_chunks(order_only ? 0 : (int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
-            for (int64_t w = b; w < e; w++) {
-                std::vector<int> &bl = wg_blocks[(size_t)w];
-                for (size_t t = 16 * (size_t)w; t < std::min(nt, 16 * (size_t)w + 16); t++) blocks_of(tasks[t], bl);
-                std::sort(bl.begin(), bl.end());
-                bl.erase(std::unique(bl.begin(), bl.end()), bl.end());
-                if (bl.size() > (size_t)XWIN_MAX_SLOTS) { bl.clear(); continue; }   // this workgroup reads x from global memory
-                for (size_t t = 16 * (size_t)w; t < std::min(nt, 16 * (size_t)w + 16); t++)
-                    for (int u = tasks[t].unit_begin; u < tasks[t].unit_end; u++) {
-                        uint4 &d = h_udesc[(size_t)u];
-                        const unsigned slot = (unsigned)(std::lower_bound(bl.begin(), bl.end(), (int)(d.x & 0xFFFFFFu)) - bl.begin());
-                        d.x = (d.x & 0xFF000000u) | slot; d.z = d.x;
-                    }
-            }
-        });
-        for (size_t w = 0; w < nwg; w++) {
-            h_wg_win[w] = make_int2((int)h_win_cb.size(), (int)wg_blocks[w].size());
-            h_win_cb.insert(h_win_cb.end(), wg_blocks[w].begin(), wg_blocks[w].end());
-            xwin_slots_max = std::max(xwin_slots_max, (int)wg_blocks[w].size());
-            xwin_segments += (long long)wg_blocks[w].size(); xwin_wgs += !wg_blocks[w].empty();
-        }
-        if (xwin_slots_max == 0) { xwin = false; h_udesc_cb.clear(); }
         if (getenv("TILESPMV_PLAN_VERBOSE"))
-            fprintf(stderr, "tilespmv: brick order: strides %d / %d tile-rows, brick %d x %d x %d strips, %.1f distinct column blocks per workgroup on the sample; x windows: %lld of %zu workgroups, %d slots at most\n",
-                    xs1, xs2, best_shape.px, best_shape.py, best_shape.pz, best_avg, xwin_wgs, nwg, xwin_slots_max);
-    } else { xwin = false; brick = false; }
+            fprintf(stderr, "tilespmv: brick order: strides %d / %d tile-rows, brick %d x %d x %d strips, %.1f distinct column blocks per workgroup on the sample\n",
+                    xs1, xs2, best_shape.px, best_shape.py, best_shape.pz, best_avg);
+    } else brick = false;
     plan->info[TILESPMV_INFO_BRICK_ORDER] = brick ? 1 : 0;
-    plan->xwin_lds_bytes = xwin ? xwin_slots_max * 16 * (int)sizeof(val_t) : 0;
     plan->size_hint = (size_t)(NU * (12 + (wide ? 16 : pooled ? 8 : 0) + 16LL * sv) + NC * (2LL * sv + 13) + NHV * sv + NHI + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);   // estimate of the plan's bytes: picks the block size of upload()
-    if (hashing()) { Hash h; h.vec(tasks); h.vec(h_wg_win); h.vec(h_win_cb); h.num(brick); h.num(xwin); stage_done(TILESPMV_STAGE_ORDER, h); }
+    if (hashing()) { Hash h; h.vec(tasks); h.num(brick); stage_done(TILESPMV_STAGE_ORDER, h); }
 }
 
 // ENCODE in device mode: the same final forms, produced from EMIT's device scratch (hip_plan_device.h)
@@ -805,7 +748,7 @@ void StreamBuilder::encode_device()
     }
     // 4-B descriptors + pattern dictionary under the host builder's conditions (below); the distinct patterns come from a sort + run-length encoding of the packed descriptors
     const bool dict_pays = K.desc_dict > 0 ? true : 8LL * NUP * 50 >= NUP * (12 + 16LL * sv) + NC * (sv + 4LL);
-    if (rc == 0 && K.desc_dict != 0 && dict_pays && !xwin && !pooled && NUP > 0) {
+    if (rc == 0 && K.desc_dict != 0 && dict_pays && !pooled && NUP > 0) {
         const int cb_bits = std::max(1, 32 - __builtin_clz((unsigned)std::max(1, T->tilen - 1)));
         const int pid_bits = std::min(DICT_MAX_BITS, 27 - cb_bits);
         if (pid_bits >= 1) {
@@ -836,7 +779,7 @@ void StreamBuilder::encode_device()
     }
     for (void *q : {(void *)d_map, (void *)d_packed, (void *)d_prow, (void *)d_udesc, (void *)d_urow, (void *)d_uval, (void *)d_ucol}) if (q) (void)hipFree(q);
     d_udesc = nullptr; d_urow = nullptr; d_uval = nullptr; d_ucol = nullptr;
-    S.udesc_cb = S.udesc; S.wg_win = nullptr; S.win_cb = nullptr;
+    S.udesc_cb = S.udesc;
     plan->info[TILESPMV_INFO_UPLOAD_US] = up0 + (long long)(now_us() - t0);
 }
 
@@ -909,7 +852,7 @@ void StreamBuilder::encode()
         // ... and only where it pays: 8 bytes per unit must be at least 2 % of the streams (an entry-dominated plan with a handful of units would only buy the dictionary
         // hop at the start of every strip: webbase-1M stand-in 13.2 -> 13.6 us); desc_dict = 1 asks for it wherever it is possible
         const bool dict_pays = K.desc_dict > 0 ? true : 8LL * NUP * 50 >= NUP * (12 + 16LL * sv) + NC * (sv + 4LL);
-        if (K.desc_dict != 0 && dict_pays && !xwin && !pooled && NUP > 0) {
+        if (K.desc_dict != 0 && dict_pays && !pooled && NUP > 0) {
             const int cb_bits = std::max(1, 32 - __builtin_clz((unsigned)std::max(1, T->tilen - 1)));
             const int pid_bits = std::min(DICT_MAX_BITS, 27 - cb_bits);
             if (pid_bits >= 1) {
@@ -1026,21 +969,6 @@ void StreamBuilder::encode()
         free_later({paired, h_uval}, (size_t)NUP * 16 * sizeof(val_t));   // (h_uval was read for the last time above)
         h_uval = nullptr;
         S.udesc_cb = S.udesc;
-        if (xwin) {   // the multi-vector kernel keeps reading x from global memory: its descriptors carry column blocks
-            std::fill(packed.begin(), packed.end(), UDesc{0u, 0u, 0u});
-            parallel_chunks((int64_t)tasks.size(), 512, [&](int64_t b, int64_t e, int) {
-                for (int64_t i = b; i < e; i++) {
-                    const STask &k = tasks[(size_t)i];   // (unit_begin already points into the packed numbering)
-                    for (long long j = 0; j < k.unit_end - k.unit_begin; j++) {
-                        const uint4 d = h_udesc_cb[(size_t)(old_begin[(size_t)i] + j)];
-                        packed[(size_t)(k.unit_begin + j)] = UDesc{d.x, d.y, d.w};
-                    }
-                }
-            });
-            rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc_cb);
-            rc |= plan->upload(h_wg_win.data(), h_wg_win.size(), &S.wg_win);
-            rc |= plan->upload(h_win_cb.data(), h_win_cb.size(), &S.win_cb);
-        } else { S.wg_win = nullptr; S.win_cb = nullptr; }
     }
     if (hashing()) { Hash h; h.num((long long)(plan->digest ^ d0)); h.num(NUP); h.num(S.cb_bits); h.num(S.pooled); if (pool_dict) h.num(8); stage_done(TILESPMV_STAGE_ENCODE, h); }   // (everything this stage produces is uploaded: the running upload digest covers it)
 }
@@ -1052,7 +980,7 @@ void StreamBuilder::entries()
     n_rec = 0; n_chunk = 0; n_groups = 0;
     if (entry_mode != 0) {
         const size_t GS = entry_mode == 2 ? (size_t)wg_strips : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
-        const int slab_shift = xwin ? 6 : pooled ? (POOL_STRIP_ROWS > 4 ? 7 : 6) : 7;   // a strip's slab of s_y: XWIN_STRIP_ROWS / POOL_STRIP_ROWS x 16 values in x-window and pooled plans, STRIP_MAX_ROWS x 16 otherwise
+        const int slab_shift = pooled ? (POOL_STRIP_ROWS > 4 ? 7 : 6) : 7;   // a strip's slab of s_y: POOL_STRIP_ROWS x 16 values in pooled plans, STRIP_MAX_ROWS x 16 otherwise
         const int dest_bits = entry_mode == 2 ? (wg_strips == 32 ? 12 : 4 + slab_shift) : 9;   // strip-in-group | row-in-strip | row (4)
         S.dest_bits = dest_bits;
         const size_t nwg = (tasks.size() + GS - 1) / GS;
@@ -1060,9 +988,6 @@ void StreamBuilder::entries()
         std::vector<std::vector<ERec>> grp_rec(nwg);
         std::vector<std::vector<unsigned>> grp_base(nwg);
         std::vector<int> h_panel_off(NP > 1 ? nwg * (NP + 1) : 0, 0);   // (relative to the list's begin here; absolute record indices below)
-        std::vector<int> wg_local(nwg, 0);      // paced lists: records of the local part (whole chunks)
-        std::mutex hist_mutex;
-        pace_hist.assign(pace_on ? (size_t)pace_nslab : 0, 0);
         std::atomic<int> bad(0);
         std::atomic<long long> scattered(0);
         DevLists dlists;   // device mode: the lists are merged, ordered and packed on the device (hip_plan_device.h: one stable sort by (group, column), then the same packing function)
@@ -1074,11 +999,10 @@ void StreamBuilder::entries()
         parallel_chunks(DT ? 0 : (int64_t)nwg, 64, [&](int64_t b, int64_t e, int) {
             std::vector<std::pair<unsigned long long, unsigned>> key;   // (column << 32 | position in strip / list order, destination)
             std::vector<int> src;
-            std::vector<PEnt> ents, local;
-            std::vector<long long> hist(pace_on ? (size_t)pace_nslab : 0, 0);
+            std::vector<PEnt> ents;
             for (int64_t w = b; w < e; w++) {
                 key.clear(); src.clear();
-                long long own_lo = LLONG_MAX, own_hi = LLONG_MIN;   // columns "around the group's own rows" (paced plans): [16 first tile-row - margin, 16 (last tile-row + 1) + margin)
+                long long own_lo = LLONG_MAX, own_hi = LLONG_MIN;   // columns "around the group's own rows": [16 first tile-row, 16 (last tile-row + 1))
                 for (size_t t = GS * (size_t)w; t < std::min(tasks.size(), GS * (size_t)w + GS); t++) {
                     own_lo = std::min<long long>(own_lo, 16LL * tasks[t].row); own_hi = std::max<long long>(own_hi, 16LL * (tasks[t].row + std::max(1, tasks[t].nrows)));
                     for (int q = tasks[t].coo_begin; q < tasks[t].coo_end; q++) {   // column-major order; ties keep strip / list order
@@ -1093,45 +1017,25 @@ void StreamBuilder::entries()
                     const int q = src[(size_t)(key[i].first & 0xFFFFFFFFull)];
                     ents[i] = PEnt{(unsigned)h_ccol[(size_t)q], key[i].second, h_cval[q]};
                 }
-                wg_local[(size_t)w] = 0;
                 if (entry_mode == 2) {   // plan fact: entries far from the group's own rows (scattered gathers)
                     long long far = 0;
                     for (const PEnt &en : ents) far += !((long long)en.col >= own_lo - 2048 && (long long)en.col < own_hi + 2048);
                     scattered.fetch_add(far, std::memory_order_relaxed);
                 }
-                if (pace_on) {
-                    // paced lists: the local entries first (columns around the group's own rows — the neighbouring workgroups want the same x lines anyway; never paced),
-                    // padded to whole chunks, then the remote entries in column order = slab order (the part the team sweeps by its timetable)
-                    constexpr long long MARGIN = 2048;
-                    local.clear();
-                    size_t nrem = 0;
-                    for (const PEnt &en : ents) {
-                        if ((long long)en.col >= own_lo - MARGIN && (long long)en.col < own_hi + MARGIN) local.push_back(en);
-                        else { ents[nrem++] = en; hist[(size_t)(en.col >> pace_shift)]++; }
-                    }
-                    ents.resize(nrem);
-                    if (!local.empty()) {
-                        if (!pack_list(local, dest_bits, grp_rec[(size_t)w], grp_base[(size_t)w], plan->dry)) bad++;
-                        if (!ents.empty()) while (grp_rec[(size_t)w].size() % ECHUNK) grp_rec[(size_t)w].push_back(make_erec((val_t)0, 0u));
-                        wg_local[(size_t)w] = (int)grp_rec[(size_t)w].size();
-                    }
-                }
                 if (!pack_list(ents, dest_bits, grp_rec[(size_t)w], grp_base[(size_t)w], plan->dry)) bad++;
-                if (pace_on) grp_base[(size_t)w].push_back(ents.empty() ? (local.empty() ? 0u : local.back().col) : ents.back().col);   // one more base word: the list's last column
                 if (NP > 1) {
                     // where each panel begins in the PACKED list: records are in column order except that the null padding of a chunk closed early repeats the chunk's first
                     // column — padding counts as part of the panel of the record before it (it adds 0 * x[.] to the group's first row whichever pass executes it)
                     panel_offsets(grp_rec[(size_t)w].data(), (long long)grp_rec[(size_t)w].size(), grp_base[(size_t)w].data(), dest_bits, panel_shift, (int)NP, &h_panel_off[(size_t)w * (NP + 1)]);
                 }
             }
-            if (pace_on) { std::lock_guard<std::mutex> lk(hist_mutex); for (size_t i2 = 0; i2 < hist.size(); i2++) pace_hist[i2] += hist[i2]; }
         });
         if (bad.load()) { fprintf(stderr, "tilespmv: internal error: %d packed entry lists do not decode to their entries\n", bad.load()); rc = -6; }
         std::vector<int4> wg((size_t)nwg);
         if (DT) { wg = dlists.wg; n_rec = dlists.n_rec; n_chunk = dlists.n_chunk; }
         else
         for (size_t w = 0; w < nwg; w++) {
-            wg[w] = make_int4((int)n_rec, (int)(n_rec + (long long)grp_rec[w].size()), (int)n_chunk, wg_local[w]);
+            wg[w] = make_int4((int)n_rec, (int)(n_rec + (long long)grp_rec[w].size()), (int)n_chunk, 0);
             if (NP > 1) for (size_t q = 0; q <= NP; q++) h_panel_off[w * (NP + 1) + q] += (int)n_rec;
             n_rec += (long long)grp_rec[w].size(); n_chunk += (long long)grp_base[w].size();
         }
@@ -1251,8 +1155,6 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     plan->info[TILESPMV_INFO_WG_STRIPS] = wg_strips;
     plan->info[TILESPMV_INFO_CSR_FORM] = csr_form;
     plan->pooled = pooled;
-    plan->info[TILESPMV_INFO_X_WINDOW_SLOTS] = xwin ? xwin_slots_max : 0;
-    plan->info[TILESPMV_INFO_X_WINDOW_SEGMENTS] = xwin ? xwin_segments : 0;
     {   // entry slab of the multi-vector kernel: shards with >= 3 entries per tile-row (strips then regularly hold more than the 16 entries that travel with the prologue)
         int used = 1;
         for (const STask &k : tasks) used = std::max(used, k.nrows);
@@ -1269,37 +1171,12 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     // 8 M 0.103 -> 0.095 — while a plan that (nearly) fits keeps the default policy, because its streams come back from the Infinity Cache on the next SpMV:
     // nontemporal loses 2 % at 340 MB (5-pt 2400^2), 15 % at 180-300 MB (power-law 3-5 M rows), 6-8 % on webbase-1M; it wins from 500 MB up (5-pt 2896^2 +4 %,
     // power-law 8 M +8 %, 5-pt 3400^2 +10 %).  Descriptors, tasks and per-strip entry lists stay on the default policy (nontemporal: config 4 0.164 -> 0.170-0.173).
-    // profiles/r03_nontemporal_streams.txt.  Entry mode 1 = small grids; x-window plans are an opt-in experiment.
+    // profiles/r03_nontemporal_streams.txt.  Entry mode 1 = small grids.
     {
         const long long launch_b = model_bytes + ((long long)colA + 16LL * ntr) * sv;
-        S.nt_stream = (entry_mode != 1 && !xwin && (K.nt_stream >= 0 ? K.nt_stream != 0 : launch_b > NT_STREAM_MIN_BYTES)) ? 1 : 0;
+        S.nt_stream = (entry_mode != 1 && (K.nt_stream >= 0 ? K.nt_stream != 0 : launch_b > NT_STREAM_MIN_BYTES)) ? 1 : 0;
     }
     plan->info[TILESPMV_INFO_NT_STREAM] = S.nt_stream;
-    // ---- slab pacing: the teams' timetable and their two words of state ({start clock, wavefronts done}; zero between launches)
-    S.pace = nullptr; S.pace_sched = nullptr; S.pace_period = 0; S.pace_shift = 0; S.pace_nslab = 0; S.pace_win = 0; S.pace_twg = 0; S.pace_ngen = 0;
-    if (pace_on && !tasks.empty()) {
-        const long long grid = ((long long)tasks.size() + 15) / 16, on_xcd0 = (grid + 7) / 8;
-        int twg = K.pace_team > 0 ? K.pace_team : (plan->dry ? 0 : paced_team_workgroups(S.cb_bits > 0, S.nt_stream != 0, plan->xcd_remap, plan->lds_pad_bytes));
-        if (twg <= 0) twg = 192;   // (6 workgroups on each of an XCD's 32 CUs: what the kernel is built for)
-        const long long ngen = (on_xcd0 + twg - 1) / twg;
-        long long total = 0;
-        for (long long v : pace_hist) total += v;
-        std::vector<unsigned> sched((size_t)pace_nslab + 1, 0u);   // slab s opens when the share of the remote entries left of it has gone by
-        long long run = 0;
-        for (int sl = 0; sl <= pace_nslab; sl++) {
-            sched[(size_t)sl] = total > 0 ? (unsigned)(((__int128)run << 24) / total) : 0u;
-            if (sl < pace_nslab) run += pace_hist[(size_t)sl];
-        }
-        std::vector<unsigned> zeros((size_t)(8 * ngen * 2), 0u);
-        const unsigned *cnt = nullptr;
-        rc |= plan->upload(sched.data(), sched.size(), &S.pace_sched);
-        rc |= plan->upload(zeros.data(), zeros.size(), &cnt);
-        S.pace = const_cast<unsigned *>(cnt);
-        S.pace_shift = pace_shift; S.pace_nslab = pace_nslab; S.pace_win = K.pace_window; S.pace_twg = twg; S.pace_ngen = (int)ngen;
-        S.pace_period = K.pace_period_us > 0 ? (unsigned)std::min<long long>(100LL * K.pace_period_us, 1LL << 30) : 0u;   // 10-ns ticks; unset: calibrated by plan_create_one
-        plan->pace_calibrate = K.pace_period_us < 0;
-        plan->info[TILESPMV_INFO_PACE_SLABS] = pace_nslab; plan->info[TILESPMV_INFO_PACE_TEAM] = twg; plan->info[TILESPMV_INFO_PACE_PERIOD_US] = S.pace_period / 100;
-    }
     if (hashing()) {
         Hash h;
         for (long long v : {model_bytes, n_tasks, (long long)S.y_streaming, (long long)S.nt_stream, (long long)S.coo_ordered, (long long)plan->mv_slab_rows, (long long)plan->mv_by_columns, (long long)S.coo_heavy_min}) h.num(v);

@@ -13,10 +13,7 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_run_length_encode.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
+#include "hip_prims.h"
 
 #include <sys/time.h>
 #include <thread>
@@ -89,7 +86,7 @@ __global__ __launch_bounds__(256) void k_tc_keys(int rowA, int tilem, const int 
     }
 }
 
-struct KeyTile { __host__ __device__ u64 operator()(u64 k) const { return k >> 8; } };   // (tile-row, column block): what names a tile
+constexpr unsigned KEY_TILE_SHIFT = 8;   // key >> 8 = (tile-row, column block): what names a tile
 
 // ---- 3. the tile list from the run-length encoded keys
 __global__ void k_tc_tiles(int tilenum, int tilem, int cb_bits, const u64 *__restrict__ uniq, int *__restrict__ tile_columnidx, int *__restrict__ tile_bi, int *__restrict__ tile_ptr)
@@ -372,19 +369,18 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     hipLaunchKernelGGL(k_tc_keys, dim3(blocks_for(tilem, 4)), dim3(256), 0, 0, rowA, tilem, d_rowptr, d_colidx, 8 + cb_bits, key_a, ent_a);
     TC_TRY(hipGetLastError());
     {
-        rocprim::double_buffer<u64> kb(key_a, key_b);
-        rocprim::double_buffer<int> vb(ent_a, ent_b);
+        u64 *k_cur = key_a, *k_alt = key_b; int *v_cur = ent_a, *v_alt = ent_b;
         size_t tmp_b = 0; void *tmp = nullptr;
         if (nnz > 0) {
-            TC_TRY(rocprim::radix_sort_pairs(nullptr, tmp_b, kb, vb, (size_t)nnz, 8u, (unsigned)(8 + cb_bits + bi_bits), (hipStream_t)0));
+            TC_TRY(prims::sort_pairs_u64_int(nullptr, tmp_b, k_cur, k_alt, v_cur, v_alt, (size_t)nnz, 8u, (unsigned)(8 + cb_bits + bi_bits), (hipStream_t)0));
             TC_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
-            hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_b, kb, vb, (size_t)nnz, 8u, (unsigned)(8 + cb_bits + bi_bits), (hipStream_t)0);
+            hipError_t e = prims::sort_pairs_u64_int(tmp, tmp_b, k_cur, k_alt, v_cur, v_alt, (size_t)nnz, 8u, (unsigned)(8 + cb_bits + bi_bits), (hipStream_t)0);
             if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)0)   /* (not the device: the values' upload is still under way on its own stream) */;
             free_now_or_later(tmp);
             TC_TRY(e);
         }
-        D->key = kb.current(); D->ent = vb.current();
-        dfree(D, kb.alternate()); dfree(D, vb.alternate());
+        D->key = k_cur; D->ent = v_cur;
+        dfree(D, k_alt); dfree(D, v_alt);
     }
     D->ms_sort = now_ms() - t0; t0 = now_ms();
 
@@ -396,11 +392,10 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     u64 *d_uniq = nullptr; int *d_counts = nullptr, *d_nruns = nullptr;
     if (nnz > 0) {
         if (dalloc(D, &d_uniq, (size_t)nnz, false) || dalloc(D, &d_counts, (size_t)nnz + 1, false) || dalloc(D, &d_nruns, 1, true)) return -3;
-        auto in = rocprim::make_transform_iterator(D->key, KeyTile());
         size_t tmp_b = 0; void *tmp = nullptr;
-        TC_TRY(rocprim::run_length_encode(nullptr, tmp_b, in, (unsigned)nnz, d_uniq, d_counts, d_nruns, (hipStream_t)0));
+        TC_TRY(prims::rle_u64(nullptr, tmp_b, D->key, KEY_TILE_SHIFT, (unsigned)nnz, d_uniq, d_counts, d_nruns, (hipStream_t)0));
         TC_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
-        hipError_t e = rocprim::run_length_encode(tmp, tmp_b, in, (unsigned)nnz, d_uniq, d_counts, d_nruns, (hipStream_t)0);
+        hipError_t e = prims::rle_u64(tmp, tmp_b, D->key, KEY_TILE_SHIFT, (unsigned)nnz, d_uniq, d_counts, d_nruns, (hipStream_t)0);
         if (e == hipSuccess) e = hipMemcpy(&tilenum, d_nruns, sizeof(int), hipMemcpyDeviceToHost);
         free_now_or_later(tmp);
         TC_TRY(e);
@@ -419,9 +414,9 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
         // tile_nnz = exclusive scan of the run lengths (np1 elements: the last one is the total)
         TC_TRY(hipMemsetAsync(d_counts + tilenum, 0, sizeof(int), 0));
         size_t tmp_b = 0; void *tmp = nullptr;
-        TC_TRY(rocprim::exclusive_scan(nullptr, tmp_b, d_counts, d_tile_nnz, 0, np1, rocprim::plus<int>(), (hipStream_t)0));
+        TC_TRY(prims::scan_int(nullptr, tmp_b, d_counts, d_tile_nnz, np1, (hipStream_t)0));
         TC_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
-        hipError_t e = rocprim::exclusive_scan(tmp, tmp_b, d_counts, d_tile_nnz, 0, np1, rocprim::plus<int>(), (hipStream_t)0);
+        hipError_t e = prims::scan_int(tmp, tmp_b, d_counts, d_tile_nnz, np1, (hipStream_t)0);
         if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)0);
         free_now_or_later(tmp);
         TC_TRY(e);
@@ -460,11 +455,11 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
         if (h_totals[k] > (unsigned long long)INT32_MAX) { fprintf(stderr, "tilespmv: %s exceeds the int32 offsets of Tile_matrix\n", names[k]); return -2; }
     {
         size_t tmp_b = 0; void *tmp = nullptr;
-        TC_TRY(rocprim::exclusive_scan(nullptr, tmp_b, scans[0], scans[0], 0, np1, rocprim::plus<int>(), (hipStream_t)0));
+        TC_TRY(prims::scan_int(nullptr, tmp_b, scans[0], scans[0], np1, (hipStream_t)0));
         TC_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
         hipError_t e = hipSuccess;
         for (int k = 0; k < NS && e == hipSuccess; k++)
-            if (h_totals[k] > 0) e = rocprim::exclusive_scan(tmp, tmp_b, scans[k], scans[k], 0, np1, rocprim::plus<int>(), (hipStream_t)0);   // (an all-zero array is its own scan)
+            if (h_totals[k] > 0) e = prims::scan_int(tmp, tmp_b, scans[k], scans[k], np1, (hipStream_t)0);   // (an all-zero array is its own scan)
         if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)0);
         free_now_or_later(tmp);
         TC_TRY(e);
@@ -523,9 +518,9 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     if (want_deferred) {
         // rows of the extracted matrix: counts -> pointers; entries: stable sort of the tile-ordered list by row = "order of appearance" inside every row (src/csr2tile.h:943-950)
         size_t tmp_b = 0; void *tmp = nullptr;
-        TC_TRY(rocprim::exclusive_scan(nullptr, tmp_b, d_dptr, d_dptr, 0, (size_t)rowA + 1, rocprim::plus<int>(), (hipStream_t)0));
+        TC_TRY(prims::scan_int(nullptr, tmp_b, d_dptr, d_dptr, (size_t)rowA + 1, (hipStream_t)0));
         TC_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
-        hipError_t e = rocprim::exclusive_scan(tmp, tmp_b, d_dptr, d_dptr, 0, (size_t)rowA + 1, rocprim::plus<int>(), (hipStream_t)0);
+        hipError_t e = prims::scan_int(tmp, tmp_b, d_dptr, d_dptr, (size_t)rowA + 1, (hipStream_t)0);
         (void)hipDeviceSynchronize();
         (void)hipFree(tmp);
         TC_TRY(e);
@@ -534,15 +529,14 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
             if (dalloc(D, &key_b2, (size_t)T.coototal, false) || dalloc(D, &pos_a, (size_t)T.coototal, false) || dalloc(D, &pos_b, (size_t)T.coototal, false)) return -3;
             hipLaunchKernelGGL(k_tc_iota, dim3(blocks_for(T.coototal, 256)), dim3(256), 0, 0, T.coototal, pos_a);
             TC_TRY(hipGetLastError());
-            rocprim::double_buffer<unsigned> kb(P.x_key, key_b2);
-            rocprim::double_buffer<int> vb(pos_a, pos_b);
+            unsigned *k_cur = P.x_key, *k_alt = key_b2; int *v_cur = pos_a, *v_alt = pos_b;
             const unsigned row_bits = (unsigned)bits_for(std::max(rowA, 2));
             tmp_b = 0; tmp = nullptr;
-            TC_TRY(rocprim::radix_sort_pairs(nullptr, tmp_b, kb, vb, (size_t)T.coototal, 0u, row_bits, (hipStream_t)0));
+            TC_TRY(prims::sort_pairs_u32_int(nullptr, tmp_b, k_cur, k_alt, v_cur, v_alt, (size_t)T.coototal, 0u, row_bits, (hipStream_t)0));
             TC_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
-            e = rocprim::radix_sort_pairs(tmp, tmp_b, kb, vb, (size_t)T.coototal, 0u, row_bits, (hipStream_t)0);
+            e = prims::sort_pairs_u32_int(tmp, tmp_b, k_cur, k_alt, v_cur, v_alt, (size_t)T.coototal, 0u, row_bits, (hipStream_t)0);
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(k_tc_deferred, dim3(blocks_for(T.coototal, 256)), dim3(256), 0, 0, T.coototal, (const int *)vb.current(), (const int *)P.x_col, (const val_t *)P.x_val, d_dcol, d_dval);
+                hipLaunchKernelGGL(k_tc_deferred, dim3(blocks_for(T.coototal, 256)), dim3(256), 0, 0, T.coototal, (const int *)v_cur, (const int *)P.x_col, (const val_t *)P.x_val, d_dcol, d_dval);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipDeviceSynchronize();
