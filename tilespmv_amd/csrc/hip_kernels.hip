@@ -37,6 +37,11 @@
 #include "hip_kernels_diag.h"
 #else
 #define TSPMV_DIAG_GATHER_X(p) (*(p))
+#define TSPMV_DIAG_TRIP_DECL
+#define TSPMV_DIAG_TRIP_RECORD(r, q, e0)
+#define TSPMV_DIAG_TRIP_GATHERS
+#define TSPMV_DIAG_TRIP_ADDS_REPLACED 0
+#define TSPMV_DIAG_TRIP_ADDS
 #define TSPMV_DIAG_UNITS_LDS_PAD
 #define TSPMV_DIAG_UNIT_GATHER_SKIP(k) false
 #define TSPMV_DIAG_POOL_ADD(dest, prod) false
@@ -355,13 +360,13 @@ typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 #define NT_Y 1  // y is written once and not re-read by this kernel: streaming (nontemporal) stores keep it from displacing x in L2 (+1-2 %; per plan: DevStream::y_streaming)
 #endif
 #ifndef WCOO_HEAVY_CT
-#define WCOO_HEAVY_CT 3  // steps per trip of the wavefront / workgroup entry phase: a lane holds 2 entries per step (round 6; rounds 3-5: 6 steps of one 12-byte record)
+#define WCOO_HEAVY_CT 6  // sub-chunks (of 64 / 256 entries) per trip of the wavefront / workgroup entry phase
 #endif
 #ifndef MV_MIN_WAVES
 #define MV_MIN_WAVES 6  // multi-vector kernel: 80 VGPRs (5 waves: 84 VGPRs, nvec 8 0.79 ms; 6: 0.74 ms; 7 spills: 1.01 ms)
 #endif
 #ifndef ECOO2_MIN_WAVES
-#define ECOO2_MIN_WAVES 5  // workgroup entry mode: 96 VGPRs (round 6: two entries per lane and step; at 6 waves = 80 VGPRs the 12-B-descriptor variants spill 20 bytes)
+#define ECOO2_MIN_WAVES 6  // workgroup entry mode: 80 VGPRs
 #endif
 #ifndef TILESPMV_UB
 #define TILESPMV_UB 4   // units per batch of the unit loop (diagnostic builds: 8 with UNITS_MIN_WAVES=6 measured below)
@@ -376,73 +381,14 @@ typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 #define POOL_MIN_WAVES 7   // pooled plans, per-strip entries: 14.5 KB of LDS per workgroup; 72 VGPRs (at 8 waves = 64 VGPRs the kernel spills 20 bytes and runs slower)
 #endif
 
-// ---- chunked entry lists (hip_plan.h EChunk).  One wavefront executes one chunk of up to ECH = 128 entries per STEP: lane L the pair of entries (L, L + h), h = ceil(count / 2).
-// estep_load issues the step's loads — the chunk's table entry through the scalar cache, ONE value load (2 values) and ONE index load (2 words) per lane; estep_decode turns the
-// index words into columns and destinations: the column of an entry is the chunk's base plus the sum of the deltas up to it, two wavefront prefix sums over the lanes.
-__device__ __forceinline__ unsigned wave_scan_incl(unsigned v)   // inclusive prefix sum over the 64 lanes (DPP: row shifts inside the 16-lane rows, then the rows' totals broadcast)
+// ---- packed entry records (hip_plan.h ERec): value + (column - chunk base) << dest_bits | destination
+__device__ __forceinline__ val_t erec_val(const ERec &r)
 {
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1  (a lane without a source inside its row adds 0)
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1 and 3
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2 and 3
-    return v;
-}
-
-struct EStep {
-    val_t va, vb;        // the values of this lane's two entries
-    unsigned m0, m1;     // raw index words (kind 0: both 16-bit words in m0; kind 1: m0, m1; kind 2: reloaded by estep_decode)
-    unsigned base, where;   // the chunk's table entry (wavefront-uniform)
-    int count;              // entries of the chunk, 1 ... ECH (wavefront-uniform)
-};
-struct EPair { unsigned ca, cb, da, db; };   // columns and destinations of the two entries
-
-// chunk = index into tab (wavefront-uniform), count = its entries; NTL: nontemporal loads (plans whose streams do not fit the Infinity Cache)
-template <bool NTL>
-__device__ __forceinline__ void estep_load(const uint4 *__restrict__ dat, const EChunk *__restrict__ tab, int chunk, int count, int lane, EStep &s)
-{
-    const EChunk ec = tab[__builtin_amdgcn_readfirstlane(chunk)];
-    s.base = ec.base; s.where = ec.where; s.count = count;
-    const int h = (count + 1) >> 1, lc = min(lane, h - 1), kind = (int)(ec.where & 3u);   // lanes beyond the chunk re-request its last pair (unconditional loads: exact vmcnt)
-    const uint4 *store = dat + (ec.where >> 2);
-    const unsigned *vw = reinterpret_cast<const unsigned *>(store) + (size_t)lc * (2 * sizeof(val_t) / 4);
-    const unsigned *mw = reinterpret_cast<const unsigned *>(store + echunk_val_units(count)) + (size_t)lc * (size_t)(1 << kind);   // (kind 0: a dword per pair — the second word read is slack)
-    unsigned v[2 * sizeof(val_t) / 4];
-    if constexpr (NTL) {   // (adjacent nontemporal dword loads become one global_load_dwordx4 / dwordx2 nt)
-#pragma unroll
-        for (int z = 0; z < (int)(2 * sizeof(val_t) / 4); z++) v[z] = __builtin_nontemporal_load(vw + z);
-        s.m0 = __builtin_nontemporal_load(mw); s.m1 = __builtin_nontemporal_load(mw + 1);
-    } else {
-#pragma unroll
-        for (int z = 0; z < (int)(2 * sizeof(val_t) / 4); z++) v[z] = vw[z];
-        s.m0 = mw[0]; s.m1 = mw[1];
-    }
 #if defined(TILESPMV_F32)
-    s.va = __uint_as_float(v[0]); s.vb = __uint_as_float(v[1]);
+    return __uint_as_float(r.v);
 #else
-    s.va = __hiloint2double((int)v[1], (int)v[0]); s.vb = __hiloint2double((int)v[3], (int)v[2]);
+    return __hiloint2double((int)r.hi, (int)r.lo);
 #endif
-}
-
-__device__ __forceinline__ EPair estep_decode(const uint4 *__restrict__ dat, const EStep &s, int db, int lane)
-{
-    const int h = (s.count + 1) >> 1, kind = (int)(s.where & 3u);
-    const unsigned dmask = (1u << db) - 1u;
-    EPair p;
-    if (kind == 2) {   // (wavefront-uniform, rare: a jump of 2^(32 - db) columns or more inside the chunk) absolute columns, 16 bytes per pair
-        const uint4 f = (dat + (s.where >> 2) + echunk_val_units(s.count))[min(lane, h - 1)];
-        p.ca = f.x; p.da = f.y; p.cb = f.z; p.db = f.w;
-        return p;
-    }
-    const unsigned wa = kind ? s.m0 : (s.m0 & 0xFFFFu), wb = kind ? s.m1 : (s.m0 >> 16);
-    p.da = wa & dmask; p.db = wb & dmask;
-    const bool in = lane < h;   // (lanes beyond the chunk hold its last pair again: they must not add to the running column)
-    const unsigned s1 = wave_scan_incl(in ? wa >> db : 0u);
-    const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)s1, __builtin_amdgcn_readfirstlane(h - 1));
-    const unsigned s2 = tot + wave_scan_incl(in ? wb >> db : 0u);
-    p.ca = s.base + s1; p.cb = s.base + s2;
-    return p;
 }
 
 // ---- wave-cooperative entry phase of k_units<.., 1>: the COO entry lists of the wavefront's four strips, merged and ordered
@@ -451,27 +397,26 @@ __device__ __forceinline__ EPair estep_decode(const uint4 *__restrict__ dat, con
 // count, not its longest strip; every load is a full 64-lane access; neighbouring lanes of a gather read the same or
 // adjacent x lines, and the four wavefronts of a workgroup sweep the columns side by side, so they find each other's lines
 // in the CU's L1.  Only this wavefront adds into its slabs: the order of the additions is fixed by the plan (bit-
-// reproducible).  CT chunks (CT x 128 entries) per trip: every load of a trip, then its gathers, then the adds.
+// reproducible).  CT x 64 entries per trip: every record load of a trip (one 12-/8-byte lane load each; the chunk's column
+// base comes through the scalar cache), then its gathers, then the adds.
 template <int CT>
 __device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t *__restrict__ x, lacc_t *swave, int lane, int gb, int ge, int chunk0, int cfirst)
 {
-    const int db = S.dest_bits, nchunk = (ge - gb + ECH - 1) / ECH;
-    for (int c0 = cfirst; c0 < nchunk; c0 += CT) {
-        EStep st[CT]; EPair pr[CT]; val_t xa[CT], xb[CT];
-#pragma unroll
-        for (int q = 0; q < CT; q++) { const int c = min(c0 + q, nchunk - 1); estep_load<false>(S.gdat, S.gtab, chunk0 + c, min(ECH, ge - gb - c * ECH), lane, st[q]); }
-#pragma unroll
-        for (int q = 0; q < CT; q++) { pr[q] = estep_decode(S.gdat, st[q], db, lane); xa[q] = x[(size_t)pr[q].ca]; xb[q] = x[(size_t)pr[q].cb]; }
+    const int db = S.dest_bits;
+    const unsigned dmask = (1u << db) - 1u;
+    const int clast = chunk0 + ((ge - 1 - gb) >> 6);
+    for (int e0 = gb + 64 * cfirst; e0 < ge; e0 += 64 * CT) {
+        ERec rr[CT]; unsigned cb[CT]; val_t xx[CT];
 #pragma unroll
         for (int q = 0; q < CT; q++) {
-            const int h = (st[q].count + 1) >> 1;
-            if (c0 + q < nchunk && lane < h) atomicAdd(&swave[pr[q].da], (lacc_t)(st[q].va * xa[q]));
+            rr[q] = S.grec[min(e0 + 64 * q + lane, ge - 1)];
+            cb[q] = S.gbase[__builtin_amdgcn_readfirstlane(min(chunk0 + ((e0 - gb) >> 6) + q, clast))];
         }
 #pragma unroll
-        for (int q = 0; q < CT; q++) {
-            const int h = (st[q].count + 1) >> 1;
-            if (c0 + q < nchunk && lane + h < st[q].count) atomicAdd(&swave[pr[q].db], (lacc_t)(st[q].vb * xb[q]));
-        }
+        for (int q = 0; q < CT; q++) xx[q] = x[(size_t)(cb[q] + (rr[q].w >> db))];
+#pragma unroll
+        for (int q = 0; q < CT; q++)
+            if (e0 + 64 * q + lane < ge) atomicAdd(&swave[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
     }
 }
 
@@ -479,51 +424,71 @@ __device__ __forceinline__ void wave_entry_trips(const DevStream &S, const val_t
 // 32 strips, merged and ordered by column at plan time, walked by all NT lanes.  Neighbouring lanes of a gather then read
 // the same or adjacent x lines: on power-law matrices the number of distinct x lines per batch drops from 0.48 per entry (one
 // strip at a time) to 0.15 (64 tile-rows at a time), and the CU's L1 -> L2 request rate is what bounds those matrices.
-// NTL: the chunk storage is read with nontemporal loads (plans whose streams do not fit the Infinity Cache: the once-read stream
+#ifndef WG_TRIP_PIPE
+#define WG_TRIP_PIPE 0   // 1: the next trip's records are requested behind the current trip's gathers.  Measured (profiles/r03_entry_ablations.txt): power-law 8 M 0.1039 -> 0.1065 ms, KKT fp64 0.427 -> 0.435, webbase 13.1 -> 12.9 us at 4 x 256 per trip; 6 x 256 spills.  Off.
+#endif
+// NTL: the records are read with nontemporal loads (plans whose streams do not fit the Infinity Cache: the once-read stream
 // then does not displace x in the L2s; DevStream::nt_stream).
 __device__ __forceinline__ val_t gather_x(const val_t *p) { return TSPMV_DIAG_GATHER_X(p); }   // (diagnostic builds probe other cache policies here: hip_kernels_diag.h)
 
-// The list = entries [gb, gl) of the shard's entry numbering, its chunks from tab[chunk0] on; [gs, ge) = the entries to execute (column panels and slices execute a run that
-// begins and ends inside the list, even inside a chunk: the chunk is decoded whole, the entries outside the run are masked).  CT steps per trip: NT / 64 x CT chunks.
 template <int CT, int NT, bool NTL>
-__device__ __forceinline__ void wg_entry_trips(const uint4 *__restrict__ dat, const EChunk *__restrict__ tab, int chunk0, int db, bool ordered,
-                                               const val_t *__restrict__ x, lacc_t *sy, int tid, int gb, int gl, int ge, int gs = -1)
+__device__ __forceinline__ void wg_entry_trips(const ERec *__restrict__ rec, const unsigned *__restrict__ base, int chunk0, int db, bool ordered,
+                                               const val_t *__restrict__ x, lacc_t *sy, int tid, int gb, int ge, int gs = -1)
 {
+    // [gs, ge) = the records to execute; gb = the list's begin, which chunk numbers count from (column panels execute a run that starts inside the list, even inside a chunk)
     if (gs < 0) gs = gb;
-    if (ge <= gs) return;
-    constexpr int NW = NT / 64;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (wavefront-uniform by construction: tell the compiler, so that chunk numbers and counts live in scalar registers)
-    const int c_first = (gs - gb) / ECH, c_end = (ge - 1 - gb) / ECH + 1;   // chunks that hold entries of the run
-    for (int c0 = c_first; c0 < c_end; c0 += NW * CT) {
-        EStep st[CT]; EPair pr[CT]; val_t xa[CT], xb[CT];
+    const int e_first = gb + ((gs - gb) & ~63);
+    const unsigned dmask = (1u << db) - 1u;
+    const int wave = tid >> 6;
+    const int clast = chunk0 + ((ge - 1 - gb) >> 6);
+    TSPMV_DIAG_TRIP_DECL
+    ERec rr[CT]; unsigned cb[CT];
+    auto load_trip = [&](int e0, ERec (&r)[CT], unsigned (&c)[CT]) {   // unconditional, clamped: exact vmcnt
 #pragma unroll
-        for (int q = 0; q < CT; q++) {   // unconditional, clamped: exact vmcnt
-            const int c = min(c0 + NW * q + wave, c_end - 1);
-            estep_load<NTL>(dat, tab, chunk0 + c, min(ECH, gl - gb - c * ECH), lane, st[q]);
+        for (int q = 0; q < CT; q++) {
+            if constexpr (NTL) {   // (the adjacent nontemporal dword loads become one global_load_dwordx3 / dwordx2 nt)
+                const unsigned *pw = reinterpret_cast<const unsigned *>(&rec[min(e0 + NT * q + tid, ge - 1)]);
+                unsigned *rw = reinterpret_cast<unsigned *>(&r[q]);
+#pragma unroll
+                for (int z = 0; z < (int)(sizeof(ERec) / 4); z++) rw[z] = __builtin_nontemporal_load(pw + z);
+            } else r[q] = rec[min(e0 + NT * q + tid, ge - 1)];
+            c[q] = base[__builtin_amdgcn_readfirstlane(min(chunk0 + ((e0 - gb) >> 6) + (NT / 64) * q + wave, clast))];   // a wavefront's 64 records are one chunk
+            TSPMV_DIAG_TRIP_RECORD(r, q, e0)
         }
+    };
+    if (e_first < ge) load_trip(e_first, rr, cb);
+    for (int e0 = e_first; e0 < ge; e0 += NT * CT) {
+        val_t xx[CT];
+        if (!WG_TRIP_PIPE && e0 > e_first) load_trip(e0, rr, cb);
 #pragma unroll
-        for (int q = 0; q < CT; q++) { pr[q] = estep_decode(dat, st[q], db, lane); xa[q] = gather_x(&x[(size_t)pr[q].ca]); xb[q] = gather_x(&x[(size_t)pr[q].cb]); }
-        auto adds = [&]() {
-#pragma unroll
-            for (int q = 0; q < CT; q++) {
-                const int c = c0 + NW * q + wave, h = (st[q].count + 1) >> 1, ea = gb + c * ECH + lane;
-                if (c < c_end && lane < h && ea >= gs && ea < ge) atomicAdd(&sy[pr[q].da], (lacc_t)(st[q].va * xa[q]));
-            }
-#pragma unroll
-            for (int q = 0; q < CT; q++) {
-                const int c = c0 + NW * q + wave, h = (st[q].count + 1) >> 1, eb = gb + c * ECH + h + lane;
-                if (c < c_end && lane + h < st[q].count && eb >= gs && eb < ge) atomicAdd(&sy[pr[q].db], (lacc_t)(st[q].vb * xb[q]));
-            }
-        };
-        if (ordered) {
+        for (int q = 0; q < CT; q++) xx[q] = gather_x(&x[(size_t)(cb[q] + (rr[q].w >> db))]);
+        TSPMV_DIAG_TRIP_GATHERS
+        // the next trip's records go in flight behind this trip's gathers (loads return in issue order: the gathers are waited
+        // for with the prefetch still outstanding); the last trip re-requests its own (clamped) records, which costs nothing
+        ERec rn[CT]; unsigned cn[CT];
+        if (WG_TRIP_PIPE) load_trip(min(e0 + NT * CT, gb + (ge - 1 - gb) / (NT * CT) * (NT * CT)), rn, cn);
+        if constexpr (TSPMV_DIAG_TRIP_ADDS_REPLACED) { TSPMV_DIAG_TRIP_ADDS }
+        else if (ordered) {
             // the wavefronts add in turn: the order of the additions into one y element is then fixed by the plan (entry
             // order inside a wavefront instruction, instruction order inside a wavefront, wavefront 0..NT/64-1 inside a trip), not
             // by timing, and two launches give the same bits (the reference's atomicAdd, src/tilespmv_cuda.h:784-790, does not)
-            for (int w = 0; w < NW; w++) {
-                if (wave == w) adds();
+            for (int w = 0; w < NT / 64; w++) {
+                if (wave == w) {
+#pragma unroll
+                    for (int q = 0; q < CT; q++)
+                        if (e0 + NT * q + tid < ge && e0 + NT * q + tid >= gs) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
+                }
                 __syncthreads();
             }
-        } else adds();
+        } else {
+#pragma unroll
+            for (int q = 0; q < CT; q++)
+                if (e0 + NT * q + tid < ge && e0 + NT * q + tid >= gs) atomicAdd(&sy[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
+        }
+        if (WG_TRIP_PIPE) {
+#pragma unroll
+            for (int q = 0; q < CT; q++) { rr[q] = rn[q]; cb[q] = cn[q]; }
+        }
     }
 }
 
@@ -543,7 +508,7 @@ __global__ __launch_bounds__(256) void k_fallback_entries(DevPlan P, const val_t
     const int nrows = b.y < 0 ? 1 : b.y;
     for (int i = tid; i < nrows; i += 256) s_acc[i] = 0;
     __syncthreads();
-    wg_entry_trips<3, 256, false>(P.f_dat, P.f_tab, b.w, FB_DEST_BITS, P.f_ordered != 0, x, s_acc, tid, 0, b.z, b.z);   // (b.z entries, chunks from b.w on)
+    wg_entry_trips<6, 256, false>(P.f_rec, P.f_base, b.z >> 6, FB_DEST_BITS, P.f_ordered != 0, x, s_acc, tid, b.z, b.w);   // a block's list starts on a chunk boundary
     __syncthreads();
     if (b.y < 0) {
         if (tid == 0) atomicAdd(&y[(long long)P.f_row0 + b.x], (val_t)s_acc[0]);
@@ -751,7 +716,7 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
             int ge = wr.y;   // column-panelled launch: this kernel takes the first panel_merge panels of the list, k_entries_acc the rest
             if (GPB == 16 && S.panel_merge > 0) ge = S.panel_off[(size_t)bid * (size_t)(S.x_panels + 1) + (size_t)min(S.x_panels, S.panel_merge)];
             if (GPB == 16 && S.slice_passes > 0) ge = wr.x;   // column slices pinned to XCDs: the whole list belongs to k_entries_xcd
-            wg_entry_trips<WCOO_HEAVY_CT, 16 * GPB, NTS>(S.gdat, S.gtab, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, wr.y, ge);
+            wg_entry_trips<WCOO_HEAVY_CT, 16 * GPB, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, &s_y[0][0][0], tid, wr.x, ge);
             __syncthreads();
         }
         TSPMV_STAMP_WAIT(3);   // entry phase done
@@ -760,19 +725,23 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
         // round trips, so everything that can be in flight together is: task -> {unit prologue, entry loads} -> {x gathers
         // of the first unit batch, x gathers of the entries} -> adds -> unit loop.  Registers are not a constraint here
         // (4 waves/SIMD asked of the allocator).
-        constexpr int CT = 3;   // steps (chunks of 128 entries) whose loads travel with the unit prologue
+        constexpr int CT = 6;
         const int lane = tid & 63;
         const int4 wr = S.wg_coo[(long long)bid * (GROUPS_PER_BLOCK / 4) + (g >> 2)];  // this wavefront's merged list
         const int tot = wr.y - wr.x;
         lacc_t *swave = &s_y[g & ~3][0][0];  // the wavefront's four slabs of STRIP_MAX_ROWS x 16 values
         TSPMV_STAMP_WAIT(1);   // task and list range have arrived
         unit_prologue();
-        EStep est[CT];
-        const int db = S.dest_bits, nchunk = (tot + ECH - 1) / ECH;
+        ERec rr[CT]; unsigned cbase[CT]; val_t xx[CT];
+        const int db = S.dest_bits;
         if (tot > 0) {
             if (side) for (int k = 0; k < nrows; k++) s_y[g][k][r] = 0;
+            const int clast = wr.z + ((tot - 1) >> 6);
 #pragma unroll
-            for (int q = 0; q < CT; q++) { const int c = min(q, nchunk - 1); estep_load<false>(S.gdat, S.gtab, wr.z + c, min(ECH, tot - c * ECH), lane, est[q]); }
+            for (int q = 0; q < CT; q++) {
+                rr[q] = S.grec[min(wr.x + 64 * q + lane, wr.y - 1)];
+                cbase[q] = S.gbase[__builtin_amdgcn_readfirstlane(min(wr.z + q, clast))];
+            }
         }
         if (have_units) {  // waits for the descriptor chunk only (older than the entry loads)
             park_first();
@@ -781,16 +750,13 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
         } else if (tot > 0) wave_lds_fence();
         TSPMV_STAMP_WAIT(2);   // prologue + entry loads (and the first unit batch's gathers) have arrived
         if (tot > 0) {
-            EPair pr[CT]; val_t xa[CT], xb[CT];
+            const unsigned dmask = (1u << db) - 1u;
 #pragma unroll
-            for (int q = 0; q < CT; q++) { pr[q] = estep_decode(S.gdat, est[q], db, lane); xa[q] = x[(size_t)pr[q].ca]; xb[q] = x[(size_t)pr[q].cb]; }
-#pragma unroll
-            for (int q = 0; q < CT; q++)
-                if (q < nchunk && lane < ((est[q].count + 1) >> 1)) atomicAdd(&swave[pr[q].da], (lacc_t)(est[q].va * xa[q]));
+            for (int q = 0; q < CT; q++) xx[q] = x[(size_t)(cbase[q] + (rr[q].w >> db))];
 #pragma unroll
             for (int q = 0; q < CT; q++)
-                if (q < nchunk && lane + ((est[q].count + 1) >> 1) < est[q].count) atomicAdd(&swave[pr[q].db], (lacc_t)(est[q].vb * xb[q]));
-            if (nchunk > CT) wave_entry_trips<CT>(S, x, swave, lane, wr.x, wr.y, wr.z, CT);
+                if (wr.x + 64 * q + lane < wr.y) atomicAdd(&swave[rr[q].w & dmask], (lacc_t)(erec_val(rr[q]) * xx[q]));
+            if (tot > 64 * CT) wave_entry_trips<CT>(S, x, swave, lane, wr.x, wr.y, wr.z, CT);
             wave_lds_fence();
         }
         TSPMV_STAMP_WAIT(3);   // entry phase done
@@ -1058,7 +1024,7 @@ __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream 
     }
     for (int i = tid; i < GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16; i += 256) s_acc[i] = 0;
     __syncthreads();
-    wg_entry_trips<WCOO_HEAVY_CT, 256, NTS>(S.gdat, S.gtab, wr.z, S.dest_bits, S.coo_ordered != 0, x, s_acc, tid, wr.x, wr.y, ge, gs);
+    wg_entry_trips<WCOO_HEAVY_CT, 256, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, S.coo_ordered != 0, x, s_acc, tid, wr.x, ge, gs);
     __syncthreads();
     if (!side) return;
     const lacc_t *mine = s_acc + g * (STRIP_MAX_ROWS * 16);
@@ -1103,7 +1069,7 @@ __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_xcd(DevStream 
     const int row0 = t1.x, part = t1.y, nrows = t1.w;
     if (TSPMV_DIAG_XCD_ZERO) for (int i = tid; i < GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16; i += 256) s_acc[i] = 0;
     __syncthreads();
-    if (TSPMV_DIAG_XCD_TRIP) wg_entry_trips<CT, 256, NTS>(S.gdat, S.gtab, wr.z, S.dest_bits, false, x, s_acc, tid, wr.x, wr.y, ge, gs);
+    if (TSPMV_DIAG_XCD_TRIP) wg_entry_trips<CT, 256, NTS>(S.grec, S.gbase, wr.z, S.dest_bits, false, x, s_acc, tid, wr.x, ge, gs);
     __syncthreads();
     TSPMV_DIAG_XCD_SKIP_ADDS
     if (!side) return;
@@ -1129,13 +1095,12 @@ hipError_t launch_entry_slices(const DevStream &S, int rowA, const val_t *x, val
     // (uniform random 4 M rows, 1,536 records per run: CT 6 0.2815 ms, CT 8 0.2563; 8 M rows in two passes, 768 per run: CT 4 0.700, CT 6 0.706, CT 8 0.716)
     const int ct = S.slice_ct;
     for (int p = 0; p < S.slice_passes; p++) {
-        // (template argument: steps per trip — a lane holds two entries per step)
-        if (ct == 8) { if (S.nt_stream) hipLaunchKernelGGL((k_entries_xcd<true, 4>), grid, blk, 0, st, S, rowA, p, x, y);
-                       else hipLaunchKernelGGL((k_entries_xcd<false, 4>), grid, blk, 0, st, S, rowA, p, x, y); }
-        else if (ct == 4) { if (S.nt_stream) hipLaunchKernelGGL((k_entries_xcd<true, 2>), grid, blk, 0, st, S, rowA, p, x, y);
-                            else hipLaunchKernelGGL((k_entries_xcd<false, 2>), grid, blk, 0, st, S, rowA, p, x, y); }
-        else { if (S.nt_stream) hipLaunchKernelGGL((k_entries_xcd<true, 3>), grid, blk, 0, st, S, rowA, p, x, y);
-               else hipLaunchKernelGGL((k_entries_xcd<false, 3>), grid, blk, 0, st, S, rowA, p, x, y); }
+        if (ct == 8) { if (S.nt_stream) hipLaunchKernelGGL((k_entries_xcd<true, 8>), grid, blk, 0, st, S, rowA, p, x, y);
+                       else hipLaunchKernelGGL((k_entries_xcd<false, 8>), grid, blk, 0, st, S, rowA, p, x, y); }
+        else if (ct == 4) { if (S.nt_stream) hipLaunchKernelGGL((k_entries_xcd<true, 4>), grid, blk, 0, st, S, rowA, p, x, y);
+                            else hipLaunchKernelGGL((k_entries_xcd<false, 4>), grid, blk, 0, st, S, rowA, p, x, y); }
+        else { if (S.nt_stream) hipLaunchKernelGGL((k_entries_xcd<true, 6>), grid, blk, 0, st, S, rowA, p, x, y);
+               else hipLaunchKernelGGL((k_entries_xcd<false, 6>), grid, blk, 0, st, S, rowA, p, x, y); }
     }
     return hipGetLastError();
 }
@@ -1767,10 +1732,10 @@ __global__ __launch_bounds__(256, WIDE ? 5 : MV_MIN_WAVES) void k_pool_mv(DevStr
 template <int NVT>
 __global__ __launch_bounds__(256) void k_entries_mv(DevStream S, int rowA, val_t *__restrict__ partial, const val_t *__restrict__ X, val_t *__restrict__ Y)
 {
-    constexpr int NP = NVT / 2, CT = 2;   // steps per trip: 4 wavefronts x 2 chunks x 128 entries
+    constexpr int NP = NVT / 2, CT = 4;
     typedef MVec<2> vec_t;
     __shared__ lacc_t s_acc[GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16][2];
-    const int tid = threadIdx.x, r = tid & 15, g = tid >> 4, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tid = threadIdx.x, r = tid & 15, g = tid >> 4, wave = tid >> 6;
     const unsigned bid = blockIdx.x;
     const int4 wr = S.wg_coo[bid];
     if (wr.y <= wr.x) return;   // workgroup-uniform
@@ -1783,36 +1748,31 @@ __global__ __launch_bounds__(256) void k_entries_mv(DevStream S, int rowA, val_t
     const bool side = t0.w > t0.z;
     const int row0 = t1.x, part = t1.y, nrows = t1.w;
     const int db = S.dest_bits, gb = wr.x, ge = wr.y;
-    const int nchunk = (ge - gb + ECH - 1) / ECH;
+    const unsigned dmask = (1u << db) - 1u;
+    const int clast = wr.z + ((ge - 1 - gb) >> 6);
     const bool ordered = S.coo_ordered != 0;
     const vec_t *__restrict__ X2 = reinterpret_cast<const vec_t *>(X);
     vec_t *__restrict__ Y2 = reinterpret_cast<vec_t *>(Y);
     for (int p = 0; p < NP; p++) {
         for (int i = tid; i < GROUPS_PER_BLOCK * STRIP_MAX_ROWS * 16; i += 256) { s_acc[i][0] = 0; s_acc[i][1] = 0; }
         __syncthreads();
-        for (int c0 = 0; c0 < nchunk; c0 += 4 * CT) {
-            EStep st[CT]; EPair pr[CT]; vec_t xa[CT], xb[CT];
+        for (int e0 = gb; e0 < ge; e0 += 256 * CT) {
+            ERec rr[CT]; unsigned cb[CT]; vec_t xx[CT];
 #pragma unroll
-            for (int q = 0; q < CT; q++) { const int c = min(c0 + 4 * q + wave, nchunk - 1); estep_load<false>(S.gdat, S.gtab, wr.z + c, min(ECH, ge - gb - c * ECH), lane, st[q]); }
+            for (int q = 0; q < CT; q++) {
+                rr[q] = S.grec[min(e0 + 256 * q + tid, ge - 1)];
+                cb[q] = S.gbase[__builtin_amdgcn_readfirstlane(min(wr.z + ((e0 - gb) >> 6) + 4 * q + wave, clast))];
+            }
 #pragma unroll
-            for (int q = 0; q < CT; q++) { pr[q] = estep_decode(S.gdat, st[q], db, lane); xa[q] = X2[(size_t)pr[q].ca * NP + p]; xb[q] = X2[(size_t)pr[q].cb * NP + p]; }
+            for (int q = 0; q < CT; q++) xx[q] = X2[(size_t)(cb[q] + (rr[q].w >> db)) * NP + p];
             auto adds = [&]() {
 #pragma unroll
-                for (int q = 0; q < CT; q++) {
-                    const int h = (st[q].count + 1) >> 1;
-                    if (c0 + 4 * q + wave < nchunk && lane < h) {
-                        atomicAdd(&s_acc[pr[q].da][0], (lacc_t)(st[q].va * xa[q].v[0]));
-                        atomicAdd(&s_acc[pr[q].da][1], (lacc_t)(st[q].va * xa[q].v[1]));
+                for (int q = 0; q < CT; q++)
+                    if (e0 + 256 * q + tid < ge) {
+                        const val_t v = erec_val(rr[q]);
+                        atomicAdd(&s_acc[rr[q].w & dmask][0], (lacc_t)(v * xx[q].v[0]));
+                        atomicAdd(&s_acc[rr[q].w & dmask][1], (lacc_t)(v * xx[q].v[1]));
                     }
-                }
-#pragma unroll
-                for (int q = 0; q < CT; q++) {
-                    const int h = (st[q].count + 1) >> 1;
-                    if (c0 + 4 * q + wave < nchunk && lane + h < st[q].count) {
-                        atomicAdd(&s_acc[pr[q].db][0], (lacc_t)(st[q].vb * xb[q].v[0]));
-                        atomicAdd(&s_acc[pr[q].db][1], (lacc_t)(st[q].vb * xb[q].v[1]));
-                    }
-                }
             };
             if (ordered) {   // wavefronts add in turn: plan-fixed order of the additions, as in k_units<.., 2>
                 for (int w = 0; w < 4; w++) { if (wave == w) adds(); __syncthreads(); }

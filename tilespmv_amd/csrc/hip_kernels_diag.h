@@ -14,7 +14,30 @@
 #define TSPMV_DIAG_GATHER_X(p) (*(p))
 #endif
 
-// (round 6: the per-trip ablations of the 12-byte record — TILESPMV_ABL 1 / 2 / 5, profiles/r03_entry_ablations.txt — went with that record)
+// ---- wg_entry_trips: TILESPMV_ABL 1 no LDS adds, 2 contiguous instead of gathered x, 5 one extra 2-byte stream load per entry
+#ifdef TILESPMV_ABL
+#define TSPMV_DIAG_TRIP_DECL val_t abl_acc = 0;
+#else
+#define TSPMV_DIAG_TRIP_DECL
+#endif
+#if defined(TILESPMV_ABL) && TILESPMV_ABL == 5
+#define TSPMV_DIAG_TRIP_RECORD(r, q, e0) r[q].w += reinterpret_cast<const unsigned short *>(base)[min(e0 + NT * q + tid, ge - 1)] & 1u;
+#else
+#define TSPMV_DIAG_TRIP_RECORD(r, q, e0)
+#endif
+#if defined(TILESPMV_ABL) && TILESPMV_ABL == 2
+#define TSPMV_DIAG_TRIP_GATHERS _Pragma("unroll") for (int q = 0; q < CT; q++) xx[q] = x[(e0 + NT * q + tid) & 0xFFFFF];
+#else
+#define TSPMV_DIAG_TRIP_GATHERS
+#endif
+#if defined(TILESPMV_ABL) && TILESPMV_ABL == 1
+#define TSPMV_DIAG_TRIP_ADDS_REPLACED 1
+#define TSPMV_DIAG_TRIP_ADDS _Pragma("unroll") for (int q = 0; q < CT; q++) abl_acc += erec_val(rr[q]) * xx[q] + (val_t)(rr[q].w & dmask); \
+        if (e0 + NT * CT >= ge) atomicAdd(&sy[tid], (lacc_t)abl_acc);
+#else
+#define TSPMV_DIAG_TRIP_ADDS_REPLACED 0
+#define TSPMV_DIAG_TRIP_ADDS
+#endif
 
 // ---- k_units: extra LDS per workgroup (what fewer resident workgroups cost); TILESPMV_ABL 7: a unit whose column block equals the previous unit's skips its gather
 #ifdef TILESPMV_ABL_LDS_PAD

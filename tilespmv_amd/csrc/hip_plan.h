@@ -26,44 +26,21 @@ constexpr unsigned DESC_EOR = 8u;         // last tile of its tile-row
 constexpr int DESC_P1_SHIFT = 4;          // 8 bits: CSR nnz | COO count | ELL/HYB width | #dense rows/cols
 constexpr int DESC_P2_SHIFT = 12;         // 8 bits: HYB remainder count
 
-// ---- packed entry lists (merged, column-ordered entry lists of the wavefront / workgroup entry modes and of the fallback), round 6: chunked, structure-of-arrays,
-// 10 bytes per entry in fp64 (6 in fp32) where the columns of a list lie close together, 12 (8) where they do not.
-// The reference's COO tile costs s_v + 1 bytes per entry (src/csr2tile.h:452-484, index byte :975-980) plus 18 bytes of per-tile metadata; rounds 3-5 stored one 12-byte
-// record per entry (value + (column - chunk base) << dest_bits | destination) and ran the entry-heavy matrices at the fabric's rate — only fewer bytes could move them.
-// A list of n entries (column order, ties in list order) is cut into chunks of ECH = 128 consecutive entries (the last one shorter); a wavefront executes one chunk per
-// step, lane L the PAIR of entries (L, L + h), h = ceil(count / 2), so that each of the step's two gathers / LDS adds covers a run of consecutive entries:
-//   chunk table   EChunk per chunk (8 B, read through the scalar cache): column of the chunk's first entry; where the chunk's storage begins (16-byte units from the
-//                 stream's begin) << 2 | kind
-//   storage       h value pairs (2 s_v bytes each: one 16-byte lane load in fp64), rounded up to 16 bytes; then h pairs of index words, rounded up to 16 bytes:
-//                 word = (column - column of the entry before it in the list's chunk) << dest_bits | destination row of the group   (first entry of a chunk: delta 0)
-//                 kind 0: 16-bit words (every delta of the chunk < 2^(16 - dest_bits): 32 columns at 11 destination bits) — one dword per lane
-//                 kind 1: 32-bit words (every delta < 2^(32 - dest_bits))                                                      — two dwords per lane
-//                 kind 2: (absolute column, destination) as two 32-bit words per entry (a jump of >= 2^(32 - dest_bits) columns inside the chunk)
-// The lanes rebuild the columns with two wavefront prefix sums of the deltas (DPP row shifts: a dozen VALU instructions per 128 entries).  Per step and lane: ONE value
-// load and ONE index load for two entries — the same vector-memory instructions per entry as the 12-byte record had (what round 3's ablations showed to matter as much as
-// the bytes, profiles/r03_entry_ablations.txt).  Every list keeps its entry count (no padding records), so record indices — column-panel offsets, slices — are entry indices.
-struct EChunk { unsigned base, where; };   // where = storage offset in 16-byte units << 2 | kind
-constexpr int ECH = 128;                   // entries per chunk = two per lane of a wavefront
-// ---- chunked entry lists (hip_plan.h EChunk): the pieces the host builder (hip_plan_internal.h pack_list), the device builder (hip_plan_device.hip) and the kernels share
-TILESPMV_HD inline int echunk_kind(unsigned max_delta, int dest_bits)   // the narrowest index word that holds every column delta of a chunk
-{
-    return max_delta < (1u << (16 - dest_bits)) ? 0 : max_delta < (1u << (32 - dest_bits)) ? 1 : 2;
-}
-TILESPMV_HD inline unsigned echunk_val_units(int count) { return (unsigned)((((count + 1) >> 1) * 2 * (int)sizeof(val_t) + 15) >> 4); }   // 16-byte units of the value pairs
-TILESPMV_HD inline unsigned echunk_units(int count, int kind) { return echunk_val_units(count) + (unsigned)((((count + 1) >> 1) * (4 << kind) + 15) >> 4); }
-// Entry i of a chunk of `count` entries sits in pair i % h, half i / h (h = ceil(count / 2)): lane L executes entries L and L + h
-TILESPMV_HD inline int echunk_slot(int i, int count) { const int h = (count + 1) >> 1; return 2 * (i % h) + i / h; }
-// Writes entry i's value and index word into a chunk's storage (zeroed beforehand; `store` points at the chunk's first 16-byte unit)
-TILESPMV_HD inline void echunk_put(unsigned char *store, int count, int kind, int i, val_t v, unsigned col, unsigned delta, unsigned dest, int dest_bits)
-{
-    const int slot = echunk_slot(i, count);
-    __builtin_memcpy(store + (size_t)slot * sizeof(val_t), &v, sizeof(val_t));
-    unsigned char *m = store + (size_t)echunk_val_units(count) * 16;
-    if (kind == 0) { const unsigned short w = (unsigned short)((delta << dest_bits) | dest); __builtin_memcpy(m + (size_t)slot * 2, &w, 2); }
-    else if (kind == 1) { const unsigned w = (delta << dest_bits) | dest; __builtin_memcpy(m + (size_t)slot * 4, &w, 4); }
-    else { const unsigned w[2] = {col, dest}; __builtin_memcpy(m + (size_t)slot * 8, w, 8); }
-}
-
+// ---- packed entry record (merged, column-ordered entry lists of the wavefront / workgroup entry modes and of the fallback):
+// value + one index word = (column - chunk base) << dest_bits | destination row of the group.  One lane load per entry
+// (global_load_dwordx3 in fp64, dwordx2 in fp32) instead of three stream loads (value, column, row byte): 12 B instead of
+// 13 B per entry in fp64, 8 instead of 9 in fp32, and — what the ablations of round 3 showed to matter as much as the
+// bytes — one vector-memory instruction per 64 entries instead of three (profiles/r03_entry_ablations.txt).  The column
+// base is one 32-bit word per chunk of 64 consecutive records of a list (a wavefront's share of one sub-trip), fetched
+// with a scalar load.  A chunk whose columns span more than 2^(32 - dest_bits) is cut short and padded with null records
+// (value 0, offset 0, destination 0).  Columns are full 32-bit numbers again (the round-2 lists kept the strip in the
+// column word's top four bits, which limited them to matrices of < 2^28 columns).
+#if defined(TILESPMV_F32)
+struct ERec { unsigned v, w; };            // 8 bytes
+#else
+struct ERec { unsigned lo, hi, w; };       // 12 bytes, 4-byte aligned
+#endif
+constexpr int ECHUNK = 64;                 // records per column-base chunk
 #ifndef TILESPMV_SMALL_GRID_WORKGROUPS
 #define TILESPMV_SMALL_GRID_WORKGROUPS 128
 #endif
@@ -95,10 +72,10 @@ struct DevPlan {
     int nfix_late;
     // very-sparse fallback (the extracted matrix of the shard's rows, deferredcoo_*): row blocks of <= FB_ROWS rows and
     // <= FB_CAP nonzeros, one workgroup each, the block's nonzeros ordered by column and stored as packed entry records
-    // (chunked lists above; destination = row-in-block, FB_DEST_BITS bits); every block is a list of its own
-    const int4 *f_blk;      // per block: first local row, #rows (-1: one piece of a single row longer than FB_CAP -> atomic add), entry count, first chunk in f_tab
-    const uint4 *f_dat;     // chunk storage
-    const EChunk *f_tab;    // chunk table
+    // (ERec below; destination = row-in-block, FB_DEST_BITS bits); a block's list starts on a chunk boundary
+    const int4 *f_blk;      // per block: first local row, #rows (-1: one piece of a single row longer than FB_CAP -> atomic add), [begin, end) in f_rec
+    const ERec *f_rec;
+    const unsigned *f_base; // column base per 64-record chunk (chunk of record i = i >> 6)
     int f_nblk;
     int f_ordered;          // wavefronts add in turn (bit-reproducible sums)
     int f_row0;             // first global row of the shard
@@ -183,11 +160,11 @@ struct DevStream {
     int coo_ordered;                      // workgroup entry mode: wavefronts add in turn (bit-reproducible sums)
     int y_streaming;                      // y stores carry the nontemporal hint (plans whose y is a real share of the traffic) or are plain
     // entry modes 1 / 2 (k_units<.., 1 | 2>): the entries of the 4 strips of one wavefront / the 16 or 32 strips of one
-    // workgroup, merged and ordered by column, so that the lanes of one gather share x lines; chunked lists (EChunk above),
+    // workgroup, merged and ordered by column, so that the lanes of one gather share x lines; packed records (ERec),
     // destination = strip-in-group << 7 | row-in-strip << 4 | row = the index into the group's slabs of s_y
-    const int4 *wg_coo;                   // per group (wavefront or workgroup): [begin, end) = its entries in the shard-wide entry numbering, first chunk in gtab, 0
-    const uint4 *gdat;                    // chunk storage of every list (16-byte units; 16 bytes of slack behind the last chunk)
-    const EChunk *gtab;                   // chunk table: the chunks of a list are consecutive, ECH entries each (the last one shorter)
+    const int4 *wg_coo;                   // per group (wavefront or workgroup): [begin, end) in grec, first chunk in gbase, 0
+    const ERec *grec;
+    const unsigned *gbase;                // column base per chunk of ECHUNK records, chunks counted from the list's begin
     int dest_bits;                        // 9 (wavefront lists), 11 (16 strips per workgroup) or 12 (32 strips)
     const uint2 *udict;                   // dictionary plans: the column patterns (nibbles of rows 0-7, of rows 8-15); udesc / udesc_cb then hold 4-B words
     int cb_bits;                          // ... column block (cb_bits) | pattern id | flags << 27;  0 = 12-B descriptors

@@ -701,8 +701,8 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     std::vector<int4> f_blk;
     long long f_nnz = 0;
     const int row0 = tr0 * 16, rows = (int)shard_rows;
-    std::vector<uint4> f_dat;     // chunked lists (hip_plan.h EChunk), one per block
-    std::vector<EChunk> f_tab;
+    std::vector<ERec> f_rec;
+    std::vector<unsigned> f_base;
     if (!coo_in_tile && extracted > 0) {
         const int *P0 = T->deferredcoo_ptr + row0;
         const int base = P0[0];
@@ -710,7 +710,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         // block size: FB_CAP nonzeros when there is enough work for ~3 workgroups per CU, smaller blocks (down to one trip) otherwise
         const int cap = (int)std::max<long long>(1536, std::min<long long>(FB_CAP, f_nnz / (3 * 256)));
         int r = 0;
-        while (r < rows) {   // .z / .w: source range in the extracted matrix for now; entry count and first chunk after packing
+        while (r < rows) {   // .z / .w: source range in the extracted matrix for now, record range after packing
             const int nr = P0[r + 1] - P0[r];
             if (nr == 0) { r++; continue; }   // runs of empty rows are not covered at all
             if (nr > FB_CAP) {
@@ -724,9 +724,8 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
             f_blk.push_back(make_int4(r, e - r, P0[r] - base, P0[e] - base));
             r = e;
         }
-        std::vector<std::vector<uint4>> blk_dat(f_blk.size());
-        std::vector<std::vector<EChunk>> blk_tab(f_blk.size());
-        std::vector<int> blk_n(f_blk.size(), 0);
+        std::vector<std::vector<ERec>> blk_rec(f_blk.size());
+        std::vector<std::vector<unsigned>> blk_base(f_blk.size());
         std::atomic<int> bad(0);
         parallel_chunks((int64_t)f_blk.size(), 16, [&](int64_t b0, int64_t b1, int) {
             std::vector<std::pair<unsigned long long, int>> key;
@@ -747,30 +746,23 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
                     const int q = k.z + (int)(key[i].first & 0xFFFFFFFFull);
                     ents[i] = PEnt{(unsigned)T->deferredcoo_colidx[base + q], (unsigned)key[i].second, T->deferredcoo_val[base + q]};
                 }
-                if (!pack_list(ents, FB_DEST_BITS, blk_tab[(size_t)b], blk_dat[(size_t)b], K.dry)) bad++;
-                blk_n[(size_t)b] = (int)ents.size();
+                if (!pack_list(ents, FB_DEST_BITS, blk_rec[(size_t)b], blk_base[(size_t)b], K.dry)) bad++;
             }
         });
         if (bad.load()) { fprintf(stderr, "tilespmv: internal error: %d packed fallback lists do not decode to their entries\n", bad.load()); rc = -6; }
-        long long units = 0, chunks = 0;
-        std::vector<long long> blk_at(f_blk.size(), 0);
+        long long at = 0;   // every block's list starts on a chunk boundary: chunk of record i = i >> 6
         for (size_t b = 0; b < f_blk.size(); b++) {
-            f_blk[b].z = blk_n[b]; f_blk[b].w = (int)chunks;
-            blk_at[b] = units;
-            units += (long long)blk_dat[b].size(); chunks += (long long)blk_tab[b].size();
+            f_blk[b].z = (int)at; f_blk[b].w = (int)(at + (long long)blk_rec[b].size());
+            at = (at + (long long)blk_rec[b].size() + ECHUNK - 1) / ECHUNK * ECHUNK;
+            if (at > INT32_MAX - ECHUNK) { fprintf(stderr, "tilespmv: shard too large for 32-bit entry ids\n"); rc = -2; break; }
         }
-        if (units >= (1LL << 30) || chunks > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for the 30-bit storage offsets of the fallback lists\n"); rc = -2; }
         if (rc == 0) {
-            f_dat.assign((size_t)units + 1, make_uint4(0u, 0u, 0u, 0u));   // (+ 16 bytes of slack: a lane's index load is two dwords wide)
-            f_tab.resize((size_t)chunks);
+            f_rec.assign((size_t)at, make_erec((val_t)0, 0u));
+            f_base.assign((size_t)(at / ECHUNK), 0u);
             parallel_chunks((int64_t)f_blk.size(), 64, [&](int64_t b0, int64_t b1, int) {
                 for (int64_t b = b0; b < b1; b++) {
-                    if (!blk_dat[(size_t)b].empty()) memcpy(&f_dat[(size_t)blk_at[(size_t)b]], blk_dat[(size_t)b].data(), blk_dat[(size_t)b].size() * sizeof(uint4));
-                    for (size_t c = 0; c < blk_tab[(size_t)b].size(); c++) {
-                        EChunk ec = blk_tab[(size_t)b][c];
-                        ec.where += (unsigned)(blk_at[(size_t)b] << 2);
-                        f_tab[(size_t)f_blk[(size_t)b].w + c] = ec;
-                    }
+                    if (!blk_rec[(size_t)b].empty()) memcpy(&f_rec[(size_t)f_blk[(size_t)b].z], blk_rec[(size_t)b].data(), blk_rec[(size_t)b].size() * sizeof(ERec));
+                    if (!blk_base[(size_t)b].empty()) memcpy(&f_base[(size_t)(f_blk[(size_t)b].z / ECHUNK)], blk_base[(size_t)b].data(), blk_base[(size_t)b].size() * sizeof(unsigned));
                 }
             });
         }
@@ -785,8 +777,8 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
         else { plan->allocs.push_back(p); plan->arena_blocks.push_back({p, (size_t)npartial * 16 * sizeof(val_t) * TILESPMV_MAX_NVEC}); D.partial = (val_t *)p; }
     }
     if (!f_blk.empty()) {
-        rc |= plan->upload(f_dat.data(), f_dat.size(), &D.f_dat);
-        rc |= plan->upload(f_tab.data(), f_tab.size(), &D.f_tab);
+        rc |= plan->upload(f_rec.data(), f_rec.size(), &D.f_rec);
+        rc |= plan->upload(f_base.data(), f_base.size(), &D.f_base);
         rc |= plan->upload(f_blk.data(), f_blk.size(), &D.f_blk);
         D.f_nblk = (int)f_blk.size();
         // taking turns costs latency on small grids and nothing on large ones (as in the unit kernel's workgroup entry mode)
@@ -809,7 +801,7 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     I[TILESPMV_INFO_BUILD_US] = (long long)(now_us() - t_create0) - I[TILESPMV_INFO_UPLOAD_US];
     // bytes one SpMV has to move at least: the three streams + tasks + x once + y once (+ fallback)
     I[TILESPMV_INFO_STREAM_BYTES] = model_bytes + (long long)colA * sv + (long long)rows * sv +
-                                    (f_nnz ? (long long)f_dat.size() * 16 + (long long)f_tab.size() * (long long)sizeof(EChunk) + 2LL * sv * rows + (long long)f_blk.size() * 16 : 0);   // the fallback re-reads and re-writes its rows of y
+                                    (f_nnz ? (long long)f_rec.size() * (long long)sizeof(ERec) + (long long)f_base.size() * 4 + 2LL * sv * rows + (long long)f_blk.size() * 16 : 0);   // the fallback re-reads and re-writes its rows of y
     if (!K.dry) {
         const int tries = K.placement_tries >= 0 ? K.placement_tries : (I[TILESPMV_INFO_DEVICE_BYTES] >= (1ll << 30) ? 8 : 1);
         const double t0p = now_us();

@@ -43,13 +43,13 @@ int dev_pool_dict(const UDesc *d_packed, const URow *d_packed_row, long long NUP
 int dev_pool_compact(const UDesc *d_packed, const URow *d_packed_row, long long NUP, const uint4 *d_dict, int ndict, uint2 *d_out);
 
 // ENTRIES (entry modes 1 / 2): the lists of every group of GS consecutive tasks merged, ordered by column (ties keep task / list order: ONE stable radix sort by
-// (group, column) of the entries laid out group by group) and packed into chunks (hip_plan.h EChunk; plan_tile_ops.h echunk_* are shared with the host builder) — two passes of one
-// wavefront per group: storage sizes, then chunk tables and storage.  d_cval / d_ccol / d_crow: EMIT's list entries (device); tasks: host copy, coo ranges in EMIT's numbering.
+// (group, column) of the entries laid out group by group) and packed (plan_tile_ops.h pack_chunks, the host builder's function) — two passes of one thread per group:
+// sizes, then records.  d_cval / d_ccol / d_crow: EMIT's list entries (device); tasks: host copy, coo ranges in EMIT's numbering.
 struct DevLists {
-    std::vector<int4> wg;           // per group: [entry begin, end), first chunk, 0 (host copy: the caller uploads it)
-    long long n_rec = 0, n_chunk = 0, n_units = 0, scattered = 0;   // entries, chunks, 16-byte storage units
-    uint4 *d_dat = nullptr; EChunk *d_tab = nullptr;     // scratch until the caller has copied them into the plan
-    int *d_panel_off = nullptr;      // x_panels > 1: (x_panels + 1) absolute entry offsets per group
+    std::vector<int4> wg;           // per group: [record begin, end), first chunk, 0 (host copy: the caller uploads it)
+    long long n_rec = 0, n_chunk = 0, scattered = 0;
+    ERec *d_rec = nullptr; unsigned *d_base = nullptr;   // scratch until place() has copied them into the plan
+    int *d_panel_off = nullptr;      // x_panels > 1: (x_panels + 1) absolute record offsets per group
     std::vector<int> panel_off;      // ... host copy
     void release();
     ~DevLists() { release(); }

@@ -261,19 +261,27 @@ __global__ __launch_bounds__(256) void k_pe_keys(const STask *__restrict__ tasks
         }
     }
 }
-// The chunked lists (hip_plan.h EChunk; host twin: hip_plan_internal.h pack_list) by one wavefront per group.  K = the group's sorted keys (column in the low 32 bits), n entries.
-// Kind of the chunk that begins at entry c0 (count entries): the largest column step between neighbours inside it, as a wavefront maximum.
-__device__ __forceinline__ int echunk_kind_wave(const u64 *__restrict__ K, long long c0, int count, int dest_bits, int lane)
+// The chunk walk (plan_tile_ops.h pack_chunks) by a wavefront: one chunk of ECHUNK = 64 records per step, one record per lane.  Columns ascend along a list, so the entries that
+// fit the chunk's column range are a prefix of the next 64: its length is the first zero of a ballot.  f(begin, count, base, padded) runs on all 64 lanes.
+static_assert(ECHUNK == 64, "one record of a chunk per lane");
+template <class F>
+__device__ __forceinline__ void pack_chunks_wave(const u64 *__restrict__ K, long long n, int dest_bits, int lane, F f)
 {
-    unsigned maxd = 0;
-    for (int i = lane; i < count; i += 64)
-        if (i > 0) maxd = max(maxd, (unsigned)K[c0 + i] - (unsigned)K[c0 + i - 1]);
-    for (int d = 32; d >= 1; d >>= 1) maxd = max(maxd, (unsigned)__shfl_xor((int)maxd, d, 64));
-    return echunk_kind(maxd, dest_bits);
+    const u64 span = 1ull << (32 - dest_bits);
+    long long i = 0;
+    while (i < n) {   // (wavefront-uniform)
+        const unsigned b = (unsigned)K[i];
+        const long long q = i + lane;
+        const bool in = q < n && (u64)(unsigned)K[q] - b < span;
+        const u64 out = ~__ballot(in);
+        const int cnt = out ? __ffsll((unsigned long long)out) - 1 : 64;   // >= 1: the chunk's first entry defines the base
+        f(i, cnt, b, i + cnt < n);   // interior chunks are filled up with null records
+        i += cnt;
+    }
 }
-// sizes: 16-byte storage units of every group's list (+ the plan fact "entries far from the group's own rows")
+// one wavefront per group: sizes of its packed list (+ the plan fact "entries far from the group's own rows")
 __global__ __launch_bounds__(256) void k_pe_sizes(const STask *__restrict__ tasks, int ntasks, const int *__restrict__ ofs, int nwg, int GS, int dest_bits, bool count_far, const u64 *__restrict__ key,
-                                                   int *__restrict__ nunits, unsigned long long *__restrict__ far_total)
+                                                   int *__restrict__ nrec, int *__restrict__ nchunk, unsigned long long *__restrict__ far_total)
 {
     const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -281,12 +289,9 @@ __global__ __launch_bounds__(256) void k_pe_sizes(const STask *__restrict__ task
     const int t0 = (int)w * GS, t1 = min(ntasks, t0 + GS);
     const u64 *K = key + ofs[t0];
     const long long n = ofs[t1] - ofs[t0];
-    long long units = 0;
-    for (long long c0 = 0; c0 < n; c0 += ECH) {   // (wavefront-uniform)
-        const int count = (int)min((long long)ECH, n - c0);
-        units += echunk_units(count, echunk_kind_wave(K, c0, count, dest_bits, lane));
-    }
-    if (lane == 0) nunits[w] = (int)min(units, (long long)INT32_MAX);
+    int nr = 0, nc = 0;
+    pack_chunks_wave(K, n, dest_bits, lane, [&](long long, int cnt, unsigned, bool padded) { nr += padded ? ECHUNK : cnt; nc++; });
+    if (lane == 0) { nrec[w] = nr; nchunk[w] = nc; }
     if (count_far) {
         long long own_lo = LLONG_MAX, own_hi = LLONG_MIN;
         for (int t = t0; t < t1; t++) { own_lo = min(own_lo, 16LL * tasks[t].row); own_hi = max(own_hi, 16LL * (tasks[t].row + max(1, tasks[t].nrows))); }
@@ -296,10 +301,9 @@ __global__ __launch_bounds__(256) void k_pe_sizes(const STask *__restrict__ task
         if (lane == 0 && far) atomicAdd(far_total, (unsigned long long)far);
     }
 }
-// one wavefront per group: its chunk table, chunk storage (zeroed by the caller) and (panelled plans) panel offsets — a list is in column order, so panel p begins at the first entry
-// whose column lies in panel p or beyond
+// one wavefront per group: its records, chunk bases and (panelled plans) panel offsets — panel_offsets' running maximum (plan_tile_ops.h) as a max-scan over the chunk's lanes
 __global__ __launch_bounds__(256) void k_pe_write(int ntasks, const int *__restrict__ ofs, int nwg, int GS, int dest_bits, const u64 *__restrict__ key, const int *__restrict__ src, const unsigned short *__restrict__ dest_q,
-                                                   const val_t *__restrict__ cval, const int4 *__restrict__ wg, const long long *__restrict__ grp_at, uint4 *__restrict__ dat, EChunk *__restrict__ tab, int NP, int panel_shift, int *__restrict__ panel_off)
+                                                   const val_t *__restrict__ cval, const int4 *__restrict__ wg, ERec *__restrict__ rec, unsigned *__restrict__ base, int NP, int panel_shift, int *__restrict__ panel_off)
 {
     const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -308,31 +312,35 @@ __global__ __launch_bounds__(256) void k_pe_write(int ntasks, const int *__restr
     const u64 *K = key + ofs[t0]; const int *Q = src + ofs[t0];
     const long long n = ofs[t1] - ofs[t0];
     const int4 g = wg[w];
-    long long at = grp_at[w];
-    EChunk *B = tab + g.z;
-    for (long long c0 = 0, c = 0; c0 < n; c0 += ECH, c++) {   // (wavefront-uniform)
-        const int count = (int)min((long long)ECH, n - c0);
-        const int kind = echunk_kind_wave(K, c0, count, dest_bits, lane);
-        unsigned char *store = reinterpret_cast<unsigned char *>(dat + at);
-        for (int i = lane; i < count; i += 64) {
-            const int q = Q[c0 + i];
-            const unsigned col = (unsigned)K[c0 + i];
-            echunk_put(store, count, kind, i, cval[q], col, i ? col - (unsigned)K[c0 + i - 1] : 0u, (unsigned)dest_q[q], dest_bits);
+    ERec *R = rec + g.x; unsigned *B = base + g.z;
+    int *off = NP > 1 ? panel_off + (size_t)w * (size_t)(NP + 1) : nullptr;
+    long long r = 0, c = 0;
+    unsigned cur = 0;   // panel of the record before (wavefront-uniform)
+    pack_chunks_wave(K, n, dest_bits, lane, [&](long long i, int cnt, unsigned b, bool padded) {
+        unsigned wv = 0; bool null_like = true;
+        const bool have = lane < cnt || padded;
+        if (lane < cnt) {
+            const int q = Q[i + lane];
+            wv = (((unsigned)K[i + lane] - b) << dest_bits) | dest_q[q];
+            const ERec e = make_erec(cval[q], wv);
+            R[r + lane] = e;
+            null_like = erec_is_null(e);
+        } else if (padded) R[r + lane] = make_erec((val_t)0, 0u);
+        if (lane == 0) B[c] = b;
+        if (off) {
+            unsigned e = have && !(null_like && lane != 0) ? (b + (wv >> dest_bits)) >> panel_shift : 0u;   // (0 leaves the running maximum alone)
+            for (int d = 1; d < 64; d <<= 1) { const unsigned up = __shfl_up(e, d, 64); if (lane >= d) e = max(e, up); }
+            const unsigned pnl = max(cur, e);
+            unsigned prev = __shfl_up(pnl, 1, 64);
+            if (lane == 0) prev = cur;
+            if (have) for (unsigned p = prev + 1; p <= pnl; p++) off[p] = g.x + (int)(r + lane);   // absolute record indices
+            cur = __shfl(pnl, 63, 64);
         }
-        if (lane == 0) B[c] = EChunk{(unsigned)K[c0], (unsigned)(at << 2) | (unsigned)kind};
-        at += echunk_units(count, kind);
-    }
-    if (NP > 1) {
-        int *off = panel_off + (size_t)w * (size_t)(NP + 1);   // absolute entry indices
-        for (long long i = lane; i < n; i += 64) {
-            const int pnl = min(NP, (int)((unsigned)K[i] >> panel_shift)), prev = i ? min(NP, (int)((unsigned)K[i - 1] >> panel_shift)) : 0;
-            for (int p = prev + 1; p <= pnl; p++) off[p] = g.x + (int)i;
-        }
-        if (lane == 0) {
-            off[0] = g.x;
-            const int last = n ? min(NP, (int)((unsigned)K[n - 1] >> panel_shift)) : 0;
-            for (int p = last + 1; p <= NP; p++) off[p] = g.x + (int)n;
-        }
+        r += padded ? ECHUNK : cnt; c++;
+    });
+    if (off && lane == 0) {
+        off[0] = g.x;
+        for (unsigned p = cur + 1; p <= (unsigned)NP; p++) off[p] = g.x + (int)r;
     }
 }
 
@@ -402,23 +410,23 @@ __global__ __launch_bounds__(256) void k_pd_pool_compact(const UDesc *__restrict
 
 void DevLists::release()
 {
-    for (void *q : {(void *)d_dat, (void *)d_tab, (void *)d_panel_off}) if (q) (void)hipFree(q);
-    d_dat = nullptr; d_tab = nullptr; d_panel_off = nullptr;
+    for (void *q : {(void *)d_rec, (void *)d_base, (void *)d_panel_off}) if (q) (void)hipFree(q);
+    d_rec = nullptr; d_base = nullptr; d_panel_off = nullptr;
 }
 
 int dev_entry_lists(const val_t *d_cval, const int *d_ccol, const unsigned char *d_crow, long long NC, const std::vector<STask> &tasks, int GS, int slab_shift, int dest_bits, bool count_scattered,
                     int x_panels, int panel_shift, DevLists *L)
 {
     const int ntasks = (int)tasks.size(), nwg = (ntasks + GS - 1) / GS;
-    L->release(); L->wg.assign((size_t)nwg, make_int4(0, 0, 0, 0)); L->n_rec = L->n_chunk = L->n_units = L->scattered = 0; L->panel_off.clear();
+    L->release(); L->wg.assign((size_t)nwg, make_int4(0, 0, 0, 0)); L->n_rec = L->n_chunk = L->scattered = 0; L->panel_off.clear();
     if (nwg == 0) return 0;
     std::vector<int> ofs((size_t)ntasks + 1, 0);   // entries in front of task t, tasks in their final order
     { long long run = 0; for (int t = 0; t < ntasks; t++) { ofs[(size_t)t] = (int)run; run += tasks[(size_t)t].coo_end - tasks[(size_t)t].coo_begin; } ofs[(size_t)ntasks] = (int)run; if (run > NC) return -3; }
     const long long NE = ofs[(size_t)ntasks];
-    Tmp<STask> d_tasks; Tmp<int> d_ofs, src_a, src_b, d_nunits; Tmp<long long> d_grp_at; Tmp<u64> key_a, key_b; Tmp<unsigned short> d_dest; Tmp<unsigned long long> d_far; Tmp<int4> d_wg;
+    Tmp<STask> d_tasks; Tmp<int> d_ofs, src_a, src_b, d_nrec, d_nchunk; Tmp<u64> key_a, key_b; Tmp<unsigned short> d_dest; Tmp<unsigned long long> d_far; Tmp<int4> d_wg;
     PD_TRY(d_tasks.from(tasks)); PD_TRY(d_ofs.from(ofs));
     PD_TRY(key_a.alloc((size_t)NE, false)); PD_TRY(key_b.alloc((size_t)NE, false)); PD_TRY(src_a.alloc((size_t)NE, false)); PD_TRY(src_b.alloc((size_t)NE, false));
-    PD_TRY(d_dest.alloc((size_t)NC, true)); PD_TRY(d_nunits.alloc((size_t)nwg, true)); PD_TRY(d_far.alloc(1, true));
+    PD_TRY(d_dest.alloc((size_t)NC, true)); PD_TRY(d_nrec.alloc((size_t)nwg, true)); PD_TRY(d_nchunk.alloc((size_t)nwg, true)); PD_TRY(d_far.alloc(1, true));
     hipLaunchKernelGGL(k_pe_keys, dim3((unsigned)std::min(ntasks, 1 << 20)), dim3(256), 0, 0, (const STask *)d_tasks.p, ntasks, (const int *)d_ofs.p, GS, slab_shift, d_ccol, d_crow, key_a.p, src_a.p, d_dest.p);
     PD_TRY(hipGetLastError());
     const u64 *K = key_a.p; const int *Q = src_a.p;
@@ -434,31 +442,28 @@ int dev_entry_lists(const val_t *d_cval, const int *d_ccol, const unsigned char 
         PD_TRY(e);
         K = k_cur; Q = v_cur;
     }
-    hipLaunchKernelGGL(k_pe_sizes, dim3(nblk((long long)nwg * 64, 256)), dim3(256), 0, 0, (const STask *)d_tasks.p, ntasks, (const int *)d_ofs.p, nwg, GS, dest_bits, count_scattered, K, d_nunits.p, d_far.p);
+    hipLaunchKernelGGL(k_pe_sizes, dim3(nblk((long long)nwg * 64, 256)), dim3(256), 0, 0, (const STask *)d_tasks.p, ntasks, (const int *)d_ofs.p, nwg, GS, dest_bits, count_scattered, K, d_nrec.p, d_nchunk.p, d_far.p);
     PD_TRY(hipGetLastError());
-    std::vector<int> nunits((size_t)nwg);
+    std::vector<int> nrec((size_t)nwg), nchunk((size_t)nwg);
     unsigned long long far = 0;
-    PD_TRY(hipMemcpy(nunits.data(), d_nunits.p, (size_t)nwg * sizeof(int), hipMemcpyDeviceToHost));
+    PD_TRY(hipMemcpy(nrec.data(), d_nrec.p, (size_t)nwg * sizeof(int), hipMemcpyDeviceToHost));
+    PD_TRY(hipMemcpy(nchunk.data(), d_nchunk.p, (size_t)nwg * sizeof(int), hipMemcpyDeviceToHost));
     PD_TRY(hipMemcpy(&far, d_far.p, sizeof(far), hipMemcpyDeviceToHost));
     L->scattered = (long long)far;
-    long long n_rec = 0, n_chunk = 0, n_units = 0;
-    std::vector<long long> grp_at((size_t)nwg, 0);
-    for (int w = 0; w < nwg; w++) {   // a list keeps its entry count: entries and chunks are known from the tasks, the storage from the pass above
-        const long long n = ofs[(size_t)std::min(ntasks, (w + 1) * GS)] - ofs[(size_t)w * GS];
-        L->wg[(size_t)w] = make_int4((int)n_rec, (int)(n_rec + n), (int)n_chunk, 0);
-        grp_at[(size_t)w] = n_units;
-        n_rec += n; n_chunk += (n + ECH - 1) / ECH; n_units += nunits[(size_t)w];
+    long long n_rec = 0, n_chunk = 0;
+    for (int w = 0; w < nwg; w++) {
+        L->wg[(size_t)w] = make_int4((int)n_rec, (int)(n_rec + nrec[(size_t)w]), (int)n_chunk, 0);
+        n_rec += nrec[(size_t)w]; n_chunk += nchunk[(size_t)w];
     }
-    L->n_rec = n_rec; L->n_chunk = n_chunk; L->n_units = n_units;
-    if (n_rec > INT32_MAX || n_units >= (1LL << 30)) return 0;   // (the caller reports it, like the host builder)
-    PD_TRY(d_wg.from(L->wg)); PD_TRY(d_grp_at.from(grp_at));
-    PD_TRY(hipMalloc((void **)&L->d_dat, (size_t)(std::max<long long>(n_units, 1) + 1) * sizeof(uint4) + 256));
-    PD_TRY(hipMemset(L->d_dat, 0, (size_t)(std::max<long long>(n_units, 1) + 1) * sizeof(uint4)));
-    PD_TRY(hipMalloc((void **)&L->d_tab, std::max<long long>(n_chunk, 1) * sizeof(EChunk) + 256));
+    L->n_rec = n_rec; L->n_chunk = n_chunk;
+    if (n_rec > INT32_MAX) return 0;   // (the caller reports it, like the host builder)
+    PD_TRY(d_wg.from(L->wg));
+    PD_TRY(hipMalloc((void **)&L->d_rec, std::max<long long>(n_rec, 1) * sizeof(ERec) + 256));
+    PD_TRY(hipMalloc((void **)&L->d_base, std::max<long long>(n_chunk, 1) * sizeof(unsigned) + 256));
     const int NP = x_panels;
     if (NP > 1) PD_TRY(hipMalloc((void **)&L->d_panel_off, (size_t)nwg * (size_t)(NP + 1) * sizeof(int) + 256));
-    hipLaunchKernelGGL(k_pe_write, dim3(nblk((long long)nwg * 64, 256)), dim3(256), 0, 0, ntasks, (const int *)d_ofs.p, nwg, GS, dest_bits, K, Q, (const unsigned short *)d_dest.p, d_cval, (const int4 *)d_wg.p,
-                       (const long long *)d_grp_at.p, L->d_dat, L->d_tab, NP, panel_shift, L->d_panel_off);
+    hipLaunchKernelGGL(k_pe_write, dim3(nblk((long long)nwg * 64, 256)), dim3(256), 0, 0, ntasks, (const int *)d_ofs.p, nwg, GS, dest_bits, K, Q, (const unsigned short *)d_dest.p, d_cval, (const int4 *)d_wg.p, L->d_rec, L->d_base, NP,
+                       panel_shift, L->d_panel_off);
     PD_TRY(hipGetLastError());
     PD_TRY(hipDeviceSynchronize());
     if (NP > 1) {

@@ -344,61 +344,35 @@ inline void repack_tile(const Tile_matrix *T, int t, const Emit &e, int rowlen, 
 // One entry of a merged list before packing.
 struct PEnt { unsigned col, dest; val_t val; };
 
-// Packs one list (entries already in their final order: by column, ties in list order) into chunks (hip_plan.h EChunk): appends the list's chunk table entries to `tab` and
-// its storage to `dat`; `where` counts 16-byte units from dat's begin (the caller rebases it when lists are concatenated).  Returns false if the packed list does not decode
-// back to the input (checked in layout-digest builds) or a storage offset does not fit its 30 bits.
-inline bool pack_list(const std::vector<PEnt> &ents, int dest_bits, std::vector<EChunk> &tab, std::vector<uint4> &dat, bool verify)
+// Packs one list (entries already in their final order: by column, ties in list order) into records and per-chunk column
+// bases (hip_plan.h ERec).  Chunk k of the list = its records [64k, 64k + 64); base = column of the chunk's first entry;
+// an entry whose column is 2^(32 - dest_bits) or more above the base closes the chunk, which is filled up with null
+// records (value 0, offset 0, destination 0: adds 0 * x[base] to the group's first row).  Returns false if the packed list
+// does not decode back to the input (checked in layout-digest builds).
+inline bool pack_list(const std::vector<PEnt> &ents, int dest_bits, std::vector<ERec> &rec, std::vector<unsigned> &base, bool verify)
 {
-    const size_t n = ents.size(), tab0 = tab.size();
-    for (size_t c0 = 0; c0 < n; c0 += ECH) {
-        const int count = (int)std::min<size_t>(ECH, n - c0);
-        unsigned maxd = 0;
-        for (int i = 1; i < count; i++) maxd = std::max(maxd, ents[c0 + i].col - ents[c0 + i - 1].col);
-        const int kind = echunk_kind(maxd, dest_bits);
-        const size_t at = dat.size();
-        if (at >= ((size_t)1 << 30)) return false;
-        dat.resize(at + echunk_units(count, kind), make_uint4(0u, 0u, 0u, 0u));
-        unsigned char *store = reinterpret_cast<unsigned char *>(&dat[at]);
-        for (int i = 0; i < count; i++) {
-            const PEnt &e = ents[c0 + i];
-            echunk_put(store, count, kind, i, e.val, e.col, i ? e.col - ents[c0 + i - 1].col : 0u, e.dest, dest_bits);
-        }
-        tab.push_back(EChunk{ents[c0].col, (unsigned)(at << 2) | (unsigned)kind});
-    }
+    const size_t rec0 = rec.size(), base0 = base.size();
+    pack_chunks((long long)ents.size(), dest_bits, [&](long long i) { return ents[(size_t)i].col; },
+                [&](long long i, unsigned b) { rec.push_back(make_erec(ents[(size_t)i].val, ((ents[(size_t)i].col - b) << dest_bits) | ents[(size_t)i].dest)); },
+                [&]() { rec.push_back(make_erec((val_t)0, 0u)); }, [&](unsigned b) { base.push_back(b); });   // (plan_tile_ops.h: shared with the device builder)
     if (!verify) return true;
-    if (tab.size() - tab0 != (n + ECH - 1) / ECH) return false;
-    for (size_t j = 0; j < n; j++) {   // decode the way the kernels do: pair slots, running column
-        const size_t c = j / ECH; const int i = (int)(j % ECH), count = (int)std::min<size_t>(ECH, n - c * ECH);
-        const EChunk ec = tab[tab0 + c];
-        const int kind = (int)(ec.where & 3u), slot = echunk_slot(i, count);
-        const unsigned char *store = reinterpret_cast<const unsigned char *>(&dat[ec.where >> 2]), *m = store + (size_t)echunk_val_units(count) * 16;
-        val_t v; memcpy(&v, store + (size_t)slot * sizeof(val_t), sizeof(val_t));
-        unsigned col, dest;
-        if (kind == 2) { unsigned w[2]; memcpy(w, m + (size_t)slot * 8, 8); col = w[0]; dest = w[1]; }
-        else {
-            col = ec.base;
-            for (int k = 0; k <= i; k++) {
-                const int sk = echunk_slot(k, count);
-                unsigned w; if (kind == 0) { unsigned short h; memcpy(&h, m + (size_t)sk * 2, 2); w = h; } else memcpy(&w, m + (size_t)sk * 4, 4);
-                col += w >> dest_bits; dest = w & ((1u << dest_bits) - 1u);
-            }
-        }
+    size_t j = 0;
+    for (size_t q = rec0; q < rec.size(); q++) {
+        const ERec &r = rec[q];
+        const unsigned bq = base[base0 + (q - rec0) / ECHUNK];
+        val_t v;
+#if defined(TILESPMV_F32)
+        memcpy(&v, &r.v, 4);
+#else
+        unsigned bb[2] = {r.lo, r.hi}; memcpy(&v, bb, 8);
+#endif
+        if (r.w == 0u && v == (val_t)0 && (j >= ents.size() || ents[j].col != bq || ents[j].dest != 0u || ents[j].val != (val_t)0)) continue;   // null padding
+        if (j >= ents.size()) return false;
+        const unsigned col = bq + (r.w >> dest_bits), dest = r.w & ((1u << dest_bits) - 1u);
         if (col != ents[j].col || dest != ents[j].dest || memcmp(&v, &ents[j].val, sizeof(val_t)) != 0) return false;
+        j++;
     }
-    return true;
-}
-
-// Where each column panel (2^panel_shift columns) begins in a list of n entries in column order: off[0 .. NP] = entry indices relative to the list's begin
-template <class ColAt>
-inline void panel_offsets(long long n, ColAt col, int panel_shift, int NP, int *off)
-{
-    int nextp = 0;
-    for (long long i = 0; i < n; i++) {
-        const int pnl = (int)(col(i) >> panel_shift);
-        while (nextp <= pnl && nextp <= NP) off[nextp++] = (int)i;
-    }
-    while (nextp <= NP) off[nextp++] = (int)n;
-    off[0] = 0;
+    return j == ents.size() && base.size() - base0 == (rec.size() - rec0 + ECHUNK - 1) / ECHUNK;
 }
 
 // the value pass of the ENCODE stage on the device (hip_kernels.hip k_pair_values)

@@ -130,7 +130,7 @@ struct StreamBuilder {
     // ORDER
     std::vector<uint4> h_udesc_cb;
     // ENCODE / ENTRIES
-    long long NUP = 0, n_rec = 0, n_chunk = 0, n_units = 0, n_groups = 0, panel_rmw_rows = 0;   // entry lists: entries, chunks, 16-byte storage units
+    long long NUP = 0, n_rec = 0, n_chunk = 0, n_groups = 0, panel_rmw_rows = 0;
     bool pool_dict = false;   // pooled plan with 8-B descriptors + pattern dictionary
     long long desc_bytes() const { return S.cb_bits > 0 ? 4 : wide ? 28 : pooled ? (pool_dict ? 8 : 20) : 12; }
     std::vector<long long> old_begin;
@@ -976,8 +976,8 @@ void StreamBuilder::encode()
 void StreamBuilder::entries()
 {
     const unsigned long long d0 = plan->digest;
-    S.wg_coo = nullptr; S.gdat = nullptr; S.gtab = nullptr; S.dest_bits = 11;
-    n_rec = 0; n_chunk = 0; n_units = 0; n_groups = 0;
+    S.wg_coo = nullptr; S.grec = nullptr; S.gbase = nullptr; S.dest_bits = 11;
+    n_rec = 0; n_chunk = 0; n_groups = 0;
     if (entry_mode != 0) {
         const size_t GS = entry_mode == 2 ? (size_t)wg_strips : 4;   // tasks whose lists are merged: one workgroup's or one wavefront's
         const int slab_shift = pooled ? (POOL_STRIP_ROWS > 4 ? 7 : 6) : 7;   // a strip's slab of s_y: POOL_STRIP_ROWS x 16 values in pooled plans, STRIP_MAX_ROWS x 16 otherwise
@@ -985,10 +985,9 @@ void StreamBuilder::entries()
         S.dest_bits = dest_bits;
         const size_t nwg = (tasks.size() + GS - 1) / GS;
         const size_t NP = (size_t)x_panels;          // column panels: a group's list stays ONE column-ordered list; panel p is the run [panel_off[p], panel_off[p + 1]) of it
-        std::vector<std::vector<uint4>> grp_dat(nwg);      // chunk storage and chunk table of every group's list (hip_plan.h EChunk)
-        std::vector<std::vector<EChunk>> grp_tab(nwg);
-        std::vector<int> grp_n(nwg, 0);                     // entries of every group's list
-        std::vector<int> h_panel_off(NP > 1 ? nwg * (NP + 1) : 0, 0);   // (relative to the list's begin here; absolute entry indices below)
+        std::vector<std::vector<ERec>> grp_rec(nwg);
+        std::vector<std::vector<unsigned>> grp_base(nwg);
+        std::vector<int> h_panel_off(NP > 1 ? nwg * (NP + 1) : 0, 0);   // (relative to the list's begin here; absolute record indices below)
         std::atomic<int> bad(0);
         std::atomic<long long> scattered(0);
         DevLists dlists;   // device mode: the lists are merged, ordered and packed on the device (hip_plan_device.h: one stable sort by (group, column), then the same packing function)
@@ -1023,34 +1022,31 @@ void StreamBuilder::entries()
                     for (const PEnt &en : ents) far += !((long long)en.col >= own_lo - 2048 && (long long)en.col < own_hi + 2048);
                     scattered.fetch_add(far, std::memory_order_relaxed);
                 }
-                if (!pack_list(ents, dest_bits, grp_tab[(size_t)w], grp_dat[(size_t)w], plan->dry)) bad++;
-                grp_n[(size_t)w] = (int)ents.size();
-                if (NP > 1) panel_offsets((long long)ents.size(), [&](long long i) { return ents[(size_t)i].col; }, panel_shift, (int)NP, &h_panel_off[(size_t)w * (NP + 1)]);   // the list is in column order: a panel is a run of it
+                if (!pack_list(ents, dest_bits, grp_rec[(size_t)w], grp_base[(size_t)w], plan->dry)) bad++;
+                if (NP > 1) {
+                    // where each panel begins in the PACKED list: records are in column order except that the null padding of a chunk closed early repeats the chunk's first
+                    // column — padding counts as part of the panel of the record before it (it adds 0 * x[.] to the group's first row whichever pass executes it)
+                    panel_offsets(grp_rec[(size_t)w].data(), (long long)grp_rec[(size_t)w].size(), grp_base[(size_t)w].data(), dest_bits, panel_shift, (int)NP, &h_panel_off[(size_t)w * (NP + 1)]);
+                }
             }
         });
         if (bad.load()) { fprintf(stderr, "tilespmv: internal error: %d packed entry lists do not decode to their entries\n", bad.load()); rc = -6; }
         std::vector<int4> wg((size_t)nwg);
-        std::vector<long long> grp_at(DT ? 0 : nwg, 0);   // first storage unit of every group's list
-        if (DT) { wg = dlists.wg; n_rec = dlists.n_rec; n_chunk = dlists.n_chunk; n_units = dlists.n_units; }
+        if (DT) { wg = dlists.wg; n_rec = dlists.n_rec; n_chunk = dlists.n_chunk; }
         else
         for (size_t w = 0; w < nwg; w++) {
-            wg[w] = make_int4((int)n_rec, (int)(n_rec + grp_n[w]), (int)n_chunk, 0);
+            wg[w] = make_int4((int)n_rec, (int)(n_rec + (long long)grp_rec[w].size()), (int)n_chunk, 0);
             if (NP > 1) for (size_t q = 0; q <= NP; q++) h_panel_off[w * (NP + 1) + q] += (int)n_rec;
-            grp_at[w] = n_units;
-            n_rec += grp_n[w]; n_chunk += (long long)grp_tab[w].size(); n_units += (long long)grp_dat[w].size();
+            n_rec += (long long)grp_rec[w].size(); n_chunk += (long long)grp_base[w].size();
         }
-        if (n_rec > INT32_MAX || n_units >= (1LL << 30)) { fprintf(stderr, "tilespmv: shard too large for 32-bit entry ids / 30-bit storage offsets of the entry lists\n"); rc = -2; n_rec = 0; n_units = 0; n_chunk = 0; }
-        std::vector<uint4> g_dat(DT || rc ? 0 : (size_t)n_units + 1, make_uint4(0u, 0u, 0u, 0u));   // (+ 16 bytes of slack: a lane's index load is two dwords wide)
-        std::vector<EChunk> g_tab(DT || rc ? 0 : (size_t)n_chunk);
+        if (n_rec > INT32_MAX) { fprintf(stderr, "tilespmv: shard too large for 32-bit entry ids\n"); rc = -2; n_rec = 0; }
+        std::vector<ERec> g_rec(DT ? 0 : (size_t)n_rec);
+        std::vector<unsigned> g_base(DT ? 0 : (size_t)n_chunk);
         if (rc == 0 && !DT)
             parallel_chunks((int64_t)nwg, 256, [&](int64_t b, int64_t e, int) {
                 for (int64_t w = b; w < e; w++) {
-                    if (!grp_dat[(size_t)w].empty()) memcpy(&g_dat[(size_t)grp_at[(size_t)w]], grp_dat[(size_t)w].data(), grp_dat[(size_t)w].size() * sizeof(uint4));
-                    for (size_t c = 0; c < grp_tab[(size_t)w].size(); c++) {
-                        EChunk ec = grp_tab[(size_t)w][c];
-                        ec.where += (unsigned)(grp_at[(size_t)w] << 2);      // (the kind bits stay)
-                        g_tab[(size_t)wg[(size_t)w].z + c] = ec;
-                    }
+                    if (!grp_rec[(size_t)w].empty()) memcpy(&g_rec[(size_t)wg[(size_t)w].x], grp_rec[(size_t)w].data(), grp_rec[(size_t)w].size() * sizeof(ERec));
+                    if (!grp_base[(size_t)w].empty()) memcpy(&g_base[(size_t)wg[(size_t)w].z], grp_base[(size_t)w].data(), grp_base[(size_t)w].size() * sizeof(unsigned));
                 }
             });
         n_groups = (long long)nwg;
@@ -1070,16 +1066,16 @@ void StreamBuilder::entries()
         }
         rc |= plan->upload(wg.data(), wg.size(), &S.wg_coo);
         if (DT) {   // records and bases are on the device already: into the plan's arena
-            rc |= plan->reserve((size_t)n_units + 1, &S.gdat);
-            rc |= plan->reserve((size_t)n_chunk, &S.gtab);
+            rc |= plan->reserve((size_t)n_rec, &S.grec);
+            rc |= plan->reserve((size_t)n_chunk, &S.gbase);
             hipError_t e = hipSuccess;
-            if (rc == 0 && n_units > 0) e = hipMemcpy(const_cast<uint4 *>(S.gdat), dlists.d_dat, (size_t)n_units * sizeof(uint4), hipMemcpyDeviceToDevice);
-            if (rc == 0 && e == hipSuccess && n_chunk > 0) e = hipMemcpy(const_cast<EChunk *>(S.gtab), dlists.d_tab, (size_t)n_chunk * sizeof(EChunk), hipMemcpyDeviceToDevice);
+            if (rc == 0 && n_rec > 0) e = hipMemcpy(const_cast<ERec *>(S.grec), dlists.d_rec, (size_t)n_rec * sizeof(ERec), hipMemcpyDeviceToDevice);
+            if (rc == 0 && e == hipSuccess && n_chunk > 0) e = hipMemcpy(const_cast<unsigned *>(S.gbase), dlists.d_base, (size_t)n_chunk * sizeof(unsigned), hipMemcpyDeviceToDevice);
             if (e != hipSuccess) { fprintf(stderr, "tilespmv: device plan build: entry lists into the plan: %s\n", hipGetErrorString(e)); (void)hipGetLastError(); rc = -3; }
             dlists.release();
         } else {
-            rc |= plan->upload(g_dat.data(), g_dat.size(), &S.gdat);
-            rc |= plan->upload(g_tab.data(), g_tab.size(), &S.gtab);
+            rc |= plan->upload(g_rec.data(), g_rec.size(), &S.grec);
+            rc |= plan->upload(g_base.data(), g_base.size(), &S.gbase);
         }
         S.panel_off = nullptr;
         if (NP > 1) rc |= plan->upload(h_panel_off.data(), h_panel_off.size(), &S.panel_off);
@@ -1096,7 +1092,7 @@ void StreamBuilder::entries()
     plan->slice_calibrate = slices_allowed && K.x_slice_passes < 0 && K.x_panel_merge < 0;   // (a caller who fixes the panels per pass has chosen the form)
     plan->panel_rmw_rows = panel_rmw_rows;
     plan->info[TILESPMV_INFO_X_PANELS] = S.panel_merge > 0 ? (x_panels + S.panel_merge - 1) / S.panel_merge : 1;   // launches of the entry part
-    if (hashing()) { Hash h; h.num((long long)(plan->digest ^ d0)); h.num(n_rec); h.num(n_chunk); h.num(n_units); h.num(n_groups); h.num(S.dest_bits); h.num(x_panels); stage_done(TILESPMV_STAGE_ENTRIES, h); }
+    if (hashing()) { Hash h; h.num((long long)(plan->digest ^ d0)); h.num(n_rec); h.num(n_chunk); h.num(n_groups); h.num(S.dest_bits); h.num(x_panels); stage_done(TILESPMV_STAGE_ENTRIES, h); }
 }
 
 void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
@@ -1167,7 +1163,7 @@ void StreamBuilder::finish(long long &n_tasks, long long &model_bytes)
     }
     plan->mv_by_columns = entry_dominated && target >= 800;   // (small strips hold few entries each: scircuit-like 18 / 22 / 32 us native against 22 / 41 / 78 us)
     n_tasks = (long long)tasks.size();
-    model_bytes = NUP * (desc_bytes() + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_units * 16 + n_chunk * (long long)sizeof(EChunk) + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
+    model_bytes = NUP * (desc_bytes() + 16LL * sv) + (entry_mode == 0 ? NC * (sv + 5LL) : n_rec * (long long)sizeof(ERec) + n_chunk * 4 + n_groups * 16) + NH * 8 + NHV * sv + NHI + n_tasks * (long long)sizeof(STask) +
                   (long long)htasks.size() * ((long long)sizeof(Task) + 32LL * sv) +  // whole-tile passes re-read and re-write their rows of y
                   ND * (4 + 256LL * sv) + (long long)drows.size() * (16 + 32LL * sv);
     // The once-read streams (values, entry records) are loaded nontemporally when the launch moves clearly more than the Infinity Cache holds: they then do

@@ -354,4 +354,60 @@ TILESPMV_HD inline void pool_row_emit(const Tile_matrix *T, int bi, int rowlen, 
     pool_windows_emit(pool, n, width, kr, O, p);
 }
 
+// ---- packed entry lists (hip_plan.h ERec): one list already in its final order (by column, ties in list order) -> records and per-chunk column bases.
+// Chunk k of the list = its records [64k, 64k + 64); base = column of the chunk's first entry; an entry whose column is 2^(32 - dest_bits) or more above the base closes the
+// chunk, which is filled up with null records (value 0, offset 0, destination 0: adds 0 * x[base] to the group's first row).  col(i): column of entry i;
+// rec(i, base): entry i becomes the next record; pad(): a null record; chunk(base): a chunk begins.
+template <class ColAt, class Rec, class Pad, class Chunk>
+TILESPMV_HD inline void pack_chunks(long long n, int dest_bits, ColAt col, Rec rec, Pad pad, Chunk chunk)
+{
+    const unsigned long long span = 1ull << (32 - dest_bits);
+    long long i = 0;
+    while (i < n) {
+        const unsigned b = col(i);
+        chunk(b);
+        int k = 0;
+        while (i < n && k < ECHUNK && (unsigned long long)col(i) - b < span) { rec(i, b); i++; k++; }
+        if (i < n) for (; k < ECHUNK; k++) pad();   // interior chunks are always full
+    }
+}
+
+TILESPMV_HD inline ERec make_erec(val_t v, unsigned w)
+{
+    ERec r;
+#if defined(TILESPMV_F32)
+    __builtin_memcpy(&r.v, &v, 4);
+#else
+    unsigned b[2]; __builtin_memcpy(b, &v, 8); r.lo = b[0]; r.hi = b[1];
+#endif
+    r.w = w;
+    return r;
+}
+
+// Where each column panel (2^panel_shift columns) begins in a PACKED list of nrec records (bases B per chunk): off[0 .. NP], relative to the list's begin (off[0] is the
+// caller's).  Records are in column order except that the null padding of a chunk closed early repeats the chunk's first column — padding counts as part of the panel of
+// the record before it (it adds 0 * x[.] to the group's first row whichever pass executes it).
+TILESPMV_HD inline bool erec_is_null(const ERec &rr)   // all bits zero: a padding record, or an entry with value +0, offset 0 and destination 0 (which adds nothing either)
+{
+#if defined(TILESPMV_F32)
+    return rr.w == 0u && rr.v == 0u;
+#else
+    return rr.w == 0u && rr.lo == 0u && rr.hi == 0u;
+#endif
+}
+TILESPMV_HD inline void panel_offsets(const ERec *R, long long nrec, const unsigned *B, int dest_bits, int panel_shift, int NP, int *off)
+{
+    unsigned cur = 0;   // panel of the previous record
+    int nextp = 1;
+    for (long long i = 0; i < nrec; i++) {
+        const ERec &rr = R[i];
+        const bool null_like = erec_is_null(rr);
+        const unsigned here = (B[i / ECHUNK] + (rr.w >> dest_bits)) >> panel_shift;
+        const unsigned pnl = null_like && i % ECHUNK != 0 ? cur : (cur > here ? cur : here);
+        while (nextp <= (int)pnl) off[nextp++] = (int)i;
+        cur = pnl;
+    }
+    while (nextp <= NP) off[nextp++] = (int)nrec;
+}
+
 }  // namespace tilespmv
