@@ -363,9 +363,12 @@ def compact_line(out, full_path):
             "this_run": {k: pop["this_run"][k] for k in ("count", "frac_median", "frac_min", "share_frac_ge_0.70")} if "this_run" in pop else None,
             "live": {k: [v.get("ms_per_spmv"), v.get("frac")] for k, v in pop.get("live_subset", {}).items() if isinstance(v, dict)},
             "committed_sweep": {k: pop["committed_sweep"].get(k) for k in ("count", "frac_median", "share_frac_ge_0.70", "file")} if "committed_sweep" in pop else None}
+    ro = out.get("reorder")
+    if ro and "workloads" in ro:   # name -> [frac natural numbering, frac after RCM (kernel only), frac amortised over 10 products]
+        line["reorder"] = {k: ("error" if "error" in v else [v["natural"]["frac"], v["rcm"]["frac"], v["amortised_over_K_products"]["10"]["frac"]]) for k, v in ro["workloads"].items()}
     line["full"] = full_path
     txt = json.dumps(line, separators=(",", ":"))
-    for drop in ("population", "other_workloads", "steady_state", "with_y_combine"):   # never let the line outgrow what the driver reads: shed the side tables first
+    for drop in ("reorder", "population", "other_workloads", "steady_state", "with_y_combine"):   # never let the line outgrow what the driver reads: shed the side tables first
         if len(txt) <= LINE_BUDGET:
             break
         if drop in line:
@@ -1010,6 +1013,22 @@ def main():
             out["population"] = pop
         except Exception as e:
             out["population"] = {"error": repr(e)}
+        # ---- permuted-numbering plans (round 6; include/tilespmv.h): the window-shuffled meshes in their natural numbering and after reverse Cuthill-McKee — kernel only, and
+        # amortised over K products between the two vector permutations (a solver permutes x once at entry and y once at exit: tilespmv_amd/halo.py HaloSpMV(reorder=True) / cg)
+        try:
+            import reorder_bench as RB
+            out["reorder"] = {"what": "default plan of A against the default plan of P A P^T (P: reverse Cuthill-McKee on the symmetrised pattern, host); frac = B_alg / t / 8 TB/s; "
+                                      "amortised_over_K_products adds (permute x + un-permute y) / K", "workloads": {}}
+            t_ro = time.time()
+            for wl in RB.WORKLOADS:
+                try:
+                    out["reorder"]["workloads"][wl] = RB.measure(wl, torch, api, G, build_matrix, reps=30)
+                except Exception as e:
+                    out["reorder"]["workloads"][wl] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+            out["reorder"]["seconds"] = round(time.time() - t_ro, 1)
+        except Exception as e:
+            out["reorder"] = {"error": repr(e)}
         ph_extras.__exit__(None, None, None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         with phase("cpu baseline", 600):

@@ -497,6 +497,19 @@ void tilespmv_partition_tilerows(const Tile_matrix *matrix, int nparts, int *bou
 
 /* Library facts. */
 int tilespmv_sizeof_value(void);    /* 8 or 4 */
+
+/* ---- Permuted-numbering plans (new, round 6; no reference counterpart: the reference multiplies in the numbering of its file, src/main.cu:59-110).
+ * For callers that STAY in the permuted numbering — a solver: x is permuted once at entry, K products run on plan-ordered vectors, y is un-permuted once at exit
+ * (tilespmv_amd/halo.py HaloSpMV(reorder=True) / cg).  Around ONE product the two permutations cost what the better numbering saves (profiles/r05_rcm_probe.txt).
+ *   tilespmv_reorder_rcm   reverse Cuthill-McKee on the symmetrised pattern of the leading n x n block (host, deterministic; perm[new] = old)
+ *   tilespmv_csr_permute   B = P A P^T; columns >= n (a rank's halo columns) stay; the entries of a row keep their order; val / out_val may be NULL
+ *   tilespmv_permute_vector  device: scatter = 0: out[i] = in[perm[i]] (into plan order), scatter = 1: out[perm[i]] = in[i] (back); asynchronous on `stream`
+ * The plan of B is created like any other (Tile_create + tilespmv_plan_create, or tilespmv_plan_create_from_csr). */
+int tilespmv_reorder_rcm(int n, const MAT_PTR_TYPE *csrRowPtr, const int *csrColIdx, int *perm /* [n] */);
+int tilespmv_csr_permute(int n, const MAT_PTR_TYPE *csrRowPtr, const int *csrColIdx, const MAT_VAL_TYPE *csrVal, const int *perm,
+                         MAT_PTR_TYPE *outRowPtr /* [n + 1] */, int *outColIdx, MAT_VAL_TYPE *outVal);
+long long tilespmv_csr_bandwidth(int n, const MAT_PTR_TYPE *csrRowPtr, const int *csrColIdx);   /* max |i - j| over the leading n x n block */
+int tilespmv_permute_vector(const MAT_VAL_TYPE *d_in, MAT_VAL_TYPE *d_out, const int *d_perm, long long n, int scatter, void *stream);   /* hipError_t value */
 const char *tilespmv_version(void);
 int tilespmv_device_count(void);    /* 0 when no HIP device is visible */
 

@@ -23,6 +23,8 @@ def _matrix(name):
         return G.laplacian5pt(48)            # 2304 rows
     if name == "band2048_40":
         return G.band(2048, 40)
+    if name == "tri48s":                     # 2-D triangulation, nodes numbered in shuffled windows of 256 (2304 rows): what reordering is for
+        return G.tri_mesh(48, 48, shuffle=256)
     if name == "powerlaw8k":
         m, n, rp, ci = G.powerlaw(8000)
         assert m == n
@@ -47,19 +49,21 @@ def _worker(rank, world, port, name, what, out):
     m, n, rp, ci = _matrix(name)
     dtype = np.float64
     mk = lambda r, c, a, b, v: _OracleLocal(r, c, a, b, v, np.dtype(dtype))  # noqa: E731
-    if what == "matvec":
+    reorder = what.endswith("_rcm")
+    if what.startswith("matvec"):
         vals, x = G.compat_values(len(ci), dtype), G.compat_x(n, dtype)
-        A = HaloSpMV(rank, world, n, rp, ci, vals, dtype, make_local=mk, device="cpu")
+        A = HaloSpMV(rank, world, n, rp, ci, vals, dtype, make_local=mk, device="cpu", reorder=reorder)
         y = A.new_vector(-3.0)
+        xin = A.to_plan_order(torch.from_numpy(np.concatenate([x[A.r0:A.r1], np.zeros(16)])))   # (a copy when the operator is not reordered)
         for _ in range(2):   # second call: stale halo values must be overwritten, not accumulated
-            A.matvec(torch.from_numpy(x[A.r0:A.r1].copy()), y)
-        res = y[:A.nloc].numpy().copy()
-        meta = (A.nhalo, sum(A.send_splits), len(A.blocks))
+            A.matvec(xin, y)
+        res = A.from_plan_order(y)[:A.nloc].numpy().copy()
+        meta = (A.nhalo, sum(A.send_splits), len(A.blocks)) + ((A.bandwidth[0], A.bandwidth[1]) if reorder else (0, 0))
     else:
         vals = _spd_values(n, rp, ci)
         rng = np.random.default_rng(7)
         bfull = rng.uniform(-1, 1, n)
-        A = HaloSpMV(rank, world, n, rp, ci, vals, dtype, make_local=mk, device="cpu")
+        A = HaloSpMV(rank, world, n, rp, ci, vals, dtype, make_local=mk, device="cpu", reorder=reorder)
         b = A.new_vector(); b[:A.nloc] = torch.from_numpy(bfull[A.r0:A.r1].copy())
         x, it, rel = cg(A, b, tol=1e-11, maxiter=400)
         res = x[:A.nloc].numpy().copy()
@@ -112,6 +116,35 @@ def test_halo_cg_converges_to_scipy_solution(tmp_path, world):
     assert np.linalg.norm(x - xs) <= 1e-8 * np.linalg.norm(xs)
     meta = np.load(out + ".meta.npy")
     assert (meta[:, 0] == meta[0, 0]).all() and meta[0, 0] < 400 and (meta[:, 1] <= 1e-11).all()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_reordered_halo_operator_is_the_same_product_in_another_numbering(tmp_path, world):
+    """HaloSpMV(reorder=True): every rank renumbers its own block by reverse Cuthill-McKee (rows, own columns, and what its neighbours fetch from it), vectors live in that
+    numbering; permuted in at entry and out at exit the product is the 1-process result bit for bit on integer data — and the rank's band really got narrower."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import generators as G
+    out = str(tmp_path / "y.npy")
+    mp.spawn(_worker, args=(world, _port(("rcm", world)), "tri48s", "matvec_rcm", out), nprocs=world, join=True)
+    m, n, rp, ci = _matrix("tri48s")
+    vals, x = G.compat_values(len(ci)), G.compat_x(n)
+    assert np.array_equal(np.load(out), CpuImpl("oracle").csr_spmv(n, rp, ci, vals, x))
+    meta = np.load(out + ".meta.npy")
+    assert (meta[:, 4] < 0.7 * meta[:, 3]).all(), meta          # bandwidth of the own block: after < before
+    assert meta[:, 0].sum() == meta[:, 1].sum()
+
+
+def test_cg_on_a_reordered_operator_permutes_once_at_entry_and_exit(tmp_path):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    out = str(tmp_path / "x.npy")
+    mp.spawn(_worker, args=(2, _port(("cg_rcm", 2)), "tri48s", "cg_rcm", out), nprocs=2, join=True)
+    m, n, rp, ci = _matrix("tri48s")
+    A = sp.csr_matrix((_spd_values(n, rp, ci), ci, rp), shape=(n, n))
+    b = np.random.default_rng(7).uniform(-1, 1, n)
+    xs = spla.spsolve(A.tocsc(), b)
+    x = np.load(out)
+    assert np.linalg.norm(x - xs) <= 1e-8 * np.linalg.norm(xs)
 
 
 def test_halo_single_rank_is_plain_spmv():

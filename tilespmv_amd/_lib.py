@@ -143,6 +143,14 @@ def load(dtype=np.float64):
     lib.mmio_allinone_cached.restype = C.c_int
     lib.tilespmv_mtx_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, _I, _I, VP]
     lib.tilespmv_mtx_write.restype = C.c_int
+    lib.tilespmv_reorder_rcm.argtypes = [C.c_int, _I, _I, _I]
+    lib.tilespmv_reorder_rcm.restype = C.c_int
+    lib.tilespmv_csr_permute.argtypes = [C.c_int, _I, _I, VP, _I, _I, _I, VP]
+    lib.tilespmv_csr_permute.restype = C.c_int
+    lib.tilespmv_csr_bandwidth.argtypes = [C.c_int, _I, _I]
+    lib.tilespmv_csr_bandwidth.restype = C.c_longlong
+    lib.tilespmv_permute_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
+    lib.tilespmv_permute_vector.restype = C.c_int
     lib.tilespmv_device_count.restype = C.c_int
     lib.tilespmv_plan_options_layout.restype = C.c_char_p
     lib.tilespmv_version.restype = C.c_char_p
@@ -163,4 +171,5 @@ DECLARED_SYMBOLS = ["Tile_create", "Tile_create_ex", "Tile_destroy", "tilespmv_c
                     "call_tilespmv_hip_multi", "tilespmv_plan_spmm", "tilespmv_plan_time_spmm", "tilespmv_plan_options_init", "tilespmv_plan_layout_digest",
                     "tilespmv_csr_save", "tilespmv_csr_load", "mmio_allinone_cached", "tilespmv_mtx_write",
                     "tilespmv_plan_time_reference_style", "tilespmv_plan_reserve_spmm", "tilespmv_plan_options_layout", "tilespmv_plan_layout_stages",
-                    "Tile_create_device", "tilespmv_plan_create_from_csr", "tilespmv_plan_stream_digests", "tilespmv_plan_create_from_device_csr"]
+                    "Tile_create_device", "tilespmv_plan_create_from_csr", "tilespmv_plan_stream_digests", "tilespmv_plan_create_from_device_csr",
+                    "tilespmv_reorder_rcm", "tilespmv_csr_permute", "tilespmv_csr_bandwidth", "tilespmv_permute_vector"]

@@ -177,6 +177,44 @@ def partition_tilerows(tm, nparts):
     return b
 
 
+def reorder_rcm(n, rowptr, colidx, dtype=np.float64):
+    """Reverse Cuthill-McKee on the symmetrised pattern of the leading n x n block (host; tilespmv_reorder_rcm): ``perm[new] = old``."""
+    lib = _lib.load(dtype)
+    rp, ci = np.ascontiguousarray(rowptr, dtype=np.int32), np.ascontiguousarray(colidx, dtype=np.int32)
+    perm = np.zeros(max(n, 1), dtype=np.int32)
+    rc = lib.tilespmv_reorder_rcm(n, _p(rp, C.c_int), _p(ci, C.c_int), _p(perm, C.c_int))
+    if rc != 0:
+        raise RuntimeError("tilespmv_reorder_rcm failed (%d)" % rc)
+    return perm[:n]
+
+
+def csr_permute(n, rowptr, colidx, vals, perm, dtype=None):
+    """``B = P A P^T`` for ``perm[new] = old`` (tilespmv_csr_permute): rows and the columns < n are renumbered, columns >= n (halo) stay, entries of a row keep their order."""
+    dtype = np.dtype(dtype if dtype is not None else np.asarray(vals).dtype)
+    lib = _lib.load(dtype)
+    rp, ci, v = _csr(lib, rowptr, colidx, vals)
+    pm = np.ascontiguousarray(perm, dtype=np.int32)
+    nnz = int(rp[n])
+    orp, oci, ov = np.zeros(n + 1, dtype=np.int32), np.zeros(max(nnz, 1), dtype=np.int32), np.zeros(max(nnz, 1), dtype=dtype)
+    rc = lib.tilespmv_csr_permute(n, _p(rp, C.c_int), _p(ci, C.c_int), _p(v, lib._vt), _p(pm, C.c_int), _p(orp, C.c_int), _p(oci, C.c_int), _p(ov, lib._vt))
+    if rc != 0:
+        raise ValueError("tilespmv_csr_permute: perm is not a permutation of 0 .. n - 1 (%d)" % rc)
+    return orp, oci[:nnz], ov[:nnz]
+
+
+def csr_bandwidth(n, rowptr, colidx, dtype=np.float64):
+    lib = _lib.load(dtype)
+    rp, ci = np.ascontiguousarray(rowptr, dtype=np.int32), np.ascontiguousarray(colidx, dtype=np.int32)
+    return int(lib.tilespmv_csr_bandwidth(n, _p(rp, C.c_int), _p(ci, C.c_int)))
+
+
+def permute_vector(d_in, d_out, d_perm, n, scatter=False, stream=0, dtype=np.float64):
+    """Device vectors between the caller's numbering and a reordered plan's: gather ``out[i] = in[perm[i]]`` (into plan order) or scatter ``out[perm[i]] = in[i]`` (back)."""
+    rc = _lib.load(dtype).tilespmv_permute_vector(d_in, d_out, d_perm, n, 1 if scatter else 0, stream)
+    if rc != 0:
+        raise RuntimeError("tilespmv_permute_vector failed (hipError %d)" % rc)
+
+
 def plan_layout_digest(tm, rowA, colA, nnzA, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, **knobs):
     """Host-only build of the plan layout (no GPU needed): returns (FNV-1a-64 digest of every stream, plan facts)."""
     opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, False, **knobs)

@@ -1930,6 +1930,21 @@ __global__ __launch_bounds__(256) void k_columns_to_rows(const val_t *__restrict
     if (i >= rows) return;
     for (int j = 0; j < nvec; j++) Y[(row0 + i) * nvec + j] = YT[j * ld + i];
 }
+// Vectors between the caller's numbering and a reordered plan's (host_reorder.cpp: perm[new] = old): gather out[i] = in[perm[i]] (x into plan order), scatter out[perm[i]] = in[i]
+// (y back).  16 bytes of perm and of the contiguous side per 4 lanes: the scattered side is what it costs (one 128-byte line per element at worst).
+__global__ __launch_bounds__(256) void k_permute_vector(const val_t *__restrict__ in, val_t *__restrict__ out, const int *__restrict__ perm, long long n, int scatter)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long p = perm[i];
+    if (scatter) out[p] = in[i]; else out[i] = in[p];
+}
+hipError_t launch_permute_vector(const val_t *in, val_t *out, const int *perm, long long n, int scatter, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_permute_vector, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, perm, n, scatter);
+    return hipGetLastError();
+}
+
 hipError_t launch_rows_to_columns(const val_t *X, int nvec, long long n, long long ld, val_t *XT, hipStream_t st)
 {
     if (n > 0) hipLaunchKernelGGL(k_rows_to_columns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, nvec, n, ld, XT);

@@ -12,6 +12,7 @@
 #include "hip_plan_device.h"
 
 namespace tilespmv {
+hipError_t launch_permute_vector(const val_t *in, val_t *out, const int *perm, long long n, int scatter, hipStream_t st);   // hip_kernels.hip
 
 hipError_t launch_tiles_direct(const DevPlan &P, bool dense_mfma, bool accumulate, bool fixup, const val_t *x, val_t *y, hipStream_t st);
 hipError_t launch_tiles_stream(const DevPlan &P, const DevStream &S, const DevDense &DN, bool dense_mfma, int entry_mode, int wg_strips, int lds_pad_bytes, int xcd_remap, int xcd_chunk,
@@ -210,6 +211,12 @@ int tilespmv_device_count(void)
 }
 
 int tilespmv_sizeof_value(void) { return (int)sizeof(val_t); }
+
+int tilespmv_permute_vector(const MAT_VAL_TYPE *d_in, MAT_VAL_TYPE *d_out, const int *d_perm, long long n, int scatter, void *stream)
+{
+    if (n < 0 || (n > 0 && (!d_in || !d_out || !d_perm)) || d_in == d_out) return (int)hipErrorInvalidValue;
+    return (int)tilespmv::launch_permute_vector(d_in, d_out, d_perm, n, scatter, (hipStream_t)stream);
+}
 const char *tilespmv_version(void) { return "tilespmv-mi355x 0.1 (gfx950)"; }
 
 void tilespmv_partition_tilerows(const Tile_matrix *T, int nparts, int *bounds)

@@ -17,6 +17,11 @@ any other matrix.  One exchange = pack (index_select) -> ``all_to_all_single`` (
 splits are zero for a stencil) straight into the halo part of ``x_ext``.  Rows are split into up to three
 contiguous blocks — leading rows that touch the halo, the interior run that does not, trailing rows that
 do — so the interior block multiplies while the halo is in flight.
+
+``reorder=True`` (round 6): the rank's own block is renumbered by reverse Cuthill-McKee on its symmetrised pattern (``tilespmv_reorder_rcm``) before it is tiled — rows and own
+columns alike, halo columns stay — and every vector of the operator lives in that numbering (``x_own``, ``new_vector``, ``matvec``, ``dot``): a solver permutes its right-hand side
+once at entry (``to_plan_order``) and its solution once at exit (``from_plan_order``); ``cg`` does both.  On meshes numbered in shuffled windows the kernel runs 16-25 % faster in
+the better numbering (profiles/r06_reorder.txt); around ONE product the two permutations would take that back, which is why this lives here and not in the drop-in path.
 """
 import numpy as np
 
@@ -32,7 +37,7 @@ class HaloSpMV:
     """
 
     def __init__(self, rank, world, n, rowptr, colidx, vals, dtype=np.float64, make_local=None, device="cuda",
-                 overlap=True, group=None, bounds=None, **plan_kw):
+                 overlap=True, group=None, bounds=None, reorder=False, **plan_kw):
         import torch
         import torch.distributed as dist
         from . import api
@@ -74,6 +79,21 @@ class HaloSpMV:
         self.send_splits = [int(g.size) for g in give]
         give_all = np.concatenate(give) if give else np.zeros(0, dtype=np.int64)
         assert give_all.size == 0 or (give_all.min() >= 0 and give_all.max() < self.nloc)
+        # ---- permuted numbering of the own block (perm[new] = old): rows, own columns and what the neighbours fetch from me
+        self.perm = None
+        self.perm_dev = None
+        self.bandwidth = None
+        if reorder and self.nloc > 0:
+            rp32, ci32 = np.ascontiguousarray(rp, dtype=np.int32), np.ascontiguousarray(new_ci, dtype=np.int32)
+            perm = api.reorder_rcm(self.nloc, rp32, ci32, dtype=self.dtype)
+            before = api.csr_bandwidth(self.nloc, rp32, ci32, dtype=self.dtype)
+            rp, new_ci, v = api.csr_permute(self.nloc, rp32, ci32, v, perm, dtype=self.dtype)
+            self.bandwidth = (before, api.csr_bandwidth(self.nloc, rp, new_ci, dtype=self.dtype))
+            inv = np.empty(self.nloc, dtype=np.int64); inv[perm] = np.arange(self.nloc, dtype=np.int64)
+            give_all = inv[give_all]
+            own = new_ci < self.nloc
+            self.perm = perm
+            self.perm_dev = torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int32)).to(self.device)
         self.give_idx = torch.from_numpy(give_all).to(self.device)
         self.send_buf = torch.zeros(max(1, give_all.size), dtype=self.tdtype, device=self.device)
         self.x_ext = torch.zeros(self.nloc + self.nhalo + 16, dtype=self.tdtype, device=self.device)
@@ -124,6 +144,28 @@ class HaloSpMV:
         """A local vector with the 16-element tail the kernels may write."""
         import torch
         return torch.full((self.nloc + 16,), fill, dtype=self.tdtype, device=self.device)
+
+    def _permuted(self, v, scatter):
+        import torch
+        from . import api
+        out = self.new_vector()
+        if self.perm is None:
+            out[:self.nloc].copy_(v[:self.nloc])
+        elif self.device.type == "cuda":
+            api.permute_vector(v.data_ptr(), out.data_ptr(), self.perm_dev.data_ptr(), self.nloc, scatter=scatter, stream=self._stream(), dtype=self.dtype)
+        elif scatter:
+            out[:self.nloc].index_copy_(0, self.perm_dev.long(), v[:self.nloc])
+        else:
+            torch.index_select(v[:self.nloc], 0, self.perm_dev.long(), out=out[:self.nloc])
+        return out
+
+    def to_plan_order(self, v):
+        """The rank's slice of a vector in the caller's numbering -> the operator's (a new vector; a copy when the operator is not reordered)."""
+        return self._permuted(v, scatter=False)
+
+    def from_plan_order(self, v):
+        """... and back."""
+        return self._permuted(v, scatter=True)
 
     def _stream(self):
         import torch
@@ -192,13 +234,19 @@ class HaloSpMV:
         self.blocks = []
 
 
-def cg(A, b, x0=None, tol=1e-10, maxiter=1000, check_every=8):
+def cg(A, b, x0=None, tol=1e-10, maxiter=1000, check_every=8, plan_order=False):
     """Conjugate gradients on a ``HaloSpMV`` operator (symmetric positive definite A).
 
     All vectors are the rank's slices (``A.new_vector()`` shaped); scalars stay on the device, so the host
     synchronises only every ``check_every`` iterations for the convergence test.  Returns (x, iterations,
-    relative residual)."""
+    relative residual).  On a reordered operator (``HaloSpMV(reorder=True)``) ``b`` / ``x0`` are permuted into the
+    operator's numbering once here and the solution back once at the end, unless ``plan_order`` says they already
+    are (and the result shall stay) in it."""
     import torch
+    permute = getattr(A, "perm", None) is not None and not plan_order
+    if permute:
+        b = A.to_plan_order(b)
+        x0 = None if x0 is None else A.to_plan_order(x0)
     x = A.new_vector() if x0 is None else x0.clone()
     r = A.new_vector(); Ap = A.new_vector()
     n = A.nloc
@@ -226,4 +274,6 @@ def cg(A, b, x0=None, tol=1e-10, maxiter=1000, check_every=8):
         if it % check_every == 0 or it == maxiter:
             rel = (float(rr) / bnorm2) ** 0.5
     rel = (float(rr) / bnorm2) ** 0.5
+    if permute:
+        x = A.from_plan_order(x)
     return x, it, rel
