@@ -567,7 +567,7 @@ def main():
     t0 = time.time()
     tile_cache = os.path.join(args.cache, "%s_%s_%s_rank%dof%d.tile_%s" % (args.workload, args.data, dname, rank, world, dname)) if args.cache else None
     # config 2 must exercise all seven tile formats: HYB is only reachable with the opt-in rule, here as in `other_workloads`
-    prep_on_device = args.prep == "device" and args.workload != "scircuit"   # (config 2 needs HYB tiles: a host-only option)
+    prep_on_device = args.prep == "device"
     with phase("prepare (Tile_create + plan)", 900):
         sh = ShardedSpMV(rank, world, rows, n, rp_b, ci_b, vals_b, dtype, bounds=bounds, tile_cache=None if prep_on_device else tile_cache, hyb=(args.workload == "scircuit"), device_build=prep_on_device)
     t_prep = time.time() - t0
@@ -790,16 +790,16 @@ def main():
     # per-rank preprocessing seconds (every rank prepares only its own block)
     prep_mine = dict({"generate": round(t_gen, 3), "process_warm_up_seconds": round(t_warm_process, 3), "total_tile_create_plus_plan": round(t_prep, 3)}, **{k: (round(v, 3) if isinstance(v, float) else v) for k, v in sh.seconds.items()})
     # the other way of preparing the same plan, timed beside it: its streams must be the measured plan's, byte for byte (per-stream digests read back from the device)
-    if args.workload != "scircuit" and not args.no_extras:
+    if not args.no_extras:
         try:
             t0 = time.time()
             if prep_on_device:
-                tm_o = api.Tile_create(len(rp_b) - 1, n, int(rp_b[-1]), rp_b, ci_b, vals_b, dtype=dtype)
+                tm_o = api.Tile_create(len(rp_b) - 1, n, int(rp_b[-1]), rp_b, ci_b, vals_b, dtype=dtype, hyb=(args.workload == "scircuit"))
                 t_tc_o = time.time() - t0
                 other = api.Plan(tm_o, len(rp_b) - 1, n, int(rp_b[-1]))
                 api.Tile_destroy(tm_o)
             else:
-                other = api.Plan.from_csr(len(rp_b) - 1, n, int(rp_b[-1]), rp_b, ci_b, vals_b, dtype=dtype)
+                other = api.Plan.from_csr(len(rp_b) - 1, n, int(rp_b[-1]), rp_b, ci_b, vals_b, dtype=dtype, hyb=(args.workload == "scircuit"))
                 t_tc_o = other.info()["tile_create_us"] * 1e-6
             t_o = time.time() - t0
             a, b = sh.local.stream_digests(), other.stream_digests()
@@ -903,10 +903,10 @@ def main():
                 xd2 = torch.from_numpy(x2).cuda()
                 modes = (("coo_in_tile", api.COO_IN_TILE), ("coo_csr_fallback", api.COO_FALLBACK)) if small else (("default_plan", api.COO_AUTO),)
                 rec["tile_create_seconds"] = round(t_tc, 3)
-                if wl != "scircuit":   # (its HYB tiles are a host-only option)
+                if True:   # (config 2's HYB tiles included: built on the device since round 6)
                     # the same default plan prepared on the device (tilespmv_plan_create_from_csr: only the CSR arrays cross the bus), whole y checked like the host-built plan's
                     t_dv = time.time()
-                    pdv = api.Plan.from_csr(r2, n2, nz2, rp2, ci2, v2, dtype=dt2)
+                    pdv = api.Plan.from_csr(r2, n2, nz2, rp2, ci2, v2, dtype=dt2, hyb=(wl == "scircuit"))
                     t_dv = time.time() - t_dv
                     ydv = torch.zeros(r2 + 16, dtype=td2, device="cuda")
                     pdv.spmv(xd2.data_ptr(), ydv.data_ptr(), stream.cuda_stream); torch.cuda.synchronize()

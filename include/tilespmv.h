@@ -348,13 +348,14 @@ void tilespmv_plan_destroy(tilespmv_plan *plan);
 /* Preprocessing on the device (new; SURVEY.md S8 f1 "device-side"; replaces the reference's Tile_create + upload, src/csr2tile.h:629-1020 + src/tilespmv_cuda.h:828-1057, end to end).
  *
  * Tile_create_device: the host Tile_create computed by kernels — the CSR arrays go up, every member array of the Tile_matrix comes back, byte for byte what Tile_create /
- * Tile_create_ex builds (flags: TILESPMV_CREATE_QUIET, TILESPMV_CREATE_CDNA4; TILESPMV_CREATE_HYB is a host-only option).  Returns 0, -1 no HIP device (there is no CPU
- * fallback behind this entry point: call Tile_create), -2 an offset leaves the int32 range of Tile_matrix, -3 HIP error / out of device memory, -4 unsupported flag.
+ * Tile_create_ex builds (flags: TILESPMV_CREATE_QUIET, TILESPMV_CREATE_CDNA4, and since round 6 TILESPMV_CREATE_HYB — width search src/csr2tile.h:279-306, pack :505-548, index bytes
+ * :984-1008 as per-tile device code).  Returns 0, -1 no HIP device (there is no CPU fallback behind this entry point: call Tile_create), -2 an offset leaves the int32 range
+ * of Tile_matrix, -3 HIP error / out of device memory.
  *
  * tilespmv_plan_create_from_csr: CSR in, resident plan out, nothing but the CSR arrays crossing the bus — the tiled matrix is built on the device and stays there, the stages of the
  * plan builder that touch every nonzero run as kernels calling the same per-tile functions as the host builder, so the plan is the one tilespmv_plan_create makes from
  * Tile_create's output (same streams, same y).  Not every option has a device path: returns -4 (and builds nothing) for the first-generation kernel, the CSR fallback
- * mode, whole CSR tiles (csr_split = 0), and HYB tiles — use Tile_create + tilespmv_plan_create for those.  autotune = 1 is served: every candidate plan is built from the one device-resident tiled
+ * mode and whole CSR tiles (csr_split = 0) — use Tile_create + tilespmv_plan_create for those (HYB tiles, TILESPMV_CREATE_HYB in `create_flags`, are served since round 6).  autotune = 1 is served: every candidate plan is built from the one device-resident tiled
  * matrix (the CSR-fallback candidate, which has no device path, is not among them).  Other return codes as above.
  * Peak device memory during the call: the CSR arrays + the tiled matrix + the sort's key buffers (about 40 bytes per nonzero in fp64) beside the plan. */
 int Tile_create_device(Tile_matrix *matrix, int rowA, int colA, MAT_PTR_TYPE nnzA, const MAT_PTR_TYPE *csrRowPtrA,

@@ -19,11 +19,11 @@ from tilespmv_amd.tile_matrix import to_dict  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def same_tile_matrix(rows, cols, rp, ci, dtype, cdna4=False, real=False):
+def same_tile_matrix(rows, cols, rp, ci, dtype, cdna4=False, real=False, hyb=False):
     nnz = int(rp[rows])
     v = G.real_values(nnz, dtype) if real else G.compat_values(nnz, dtype)
-    host = api.Tile_create(rows, cols, nnz, rp, ci, v, dtype=dtype, cdna4=cdna4)
-    dev = api.Tile_create_device(rows, cols, nnz, rp, ci, v, dtype=dtype, cdna4=cdna4)
+    host = api.Tile_create(rows, cols, nnz, rp, ci, v, dtype=dtype, cdna4=cdna4, hyb=hyb)
+    dev = api.Tile_create_device(rows, cols, nnz, rp, ci, v, dtype=dtype, cdna4=cdna4, hyb=hyb)
     try:
         h, d = to_dict(host, rows), to_dict(dev, rows)
         bad = []
@@ -39,18 +39,33 @@ def same_tile_matrix(rows, cols, rp, ci, dtype, cdna4=False, real=False):
         api.Tile_destroy(host); api.Tile_destroy(dev)
 
 
+@pytest.mark.parametrize("hyb", [False, True])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("name", sorted(cases.SMALL) + sorted(cases.MEDIUM))
-def test_device_tile_create_equals_host(name, dtype):
+def test_device_tile_create_equals_host(name, dtype, hyb):
+    """hyb = True: the reference's dormant HYB rule switched on (TILESPMV_CREATE_HYB; width search src/csr2tile.h:279-306, pack :505-548, index bytes :984-1008) — since round 6
+    built on the device too, byte for byte the host's Tile_matrix (hybsize / hybellsize / hybcoosize, Blockhyb_Val, hybIdx, the remainders in deferredcoo_*)."""
     rows, cols, rp, ci = (cases.SMALL.get(name) or cases.MEDIUM[name])()
-    assert same_tile_matrix(rows, cols, rp, ci, dtype) == []
+    assert same_tile_matrix(rows, cols, rp, ci, dtype, hyb=hyb) == []
+
+
+def test_device_tile_create_builds_hyb_tiles_where_the_rule_selects_them():
+    """The HYB cases are not vacuous: the all-formats matrix and the circuit-like stand-in of config 2 really get HYB tiles from both builders."""
+    for rows, cols, rp, ci in (cases.SMALL["allfmt"](), G.retarget_nnz(*G.circuit_like(20000, seed=1), target_nnz=112000, seed=1)):
+        rows = cases.truncated_rows(rows); nnz = int(rp[rows])
+        v = G.compat_values(nnz, np.float64)
+        dev = api.Tile_create_device(rows, cols, nnz, rp, ci, v, hyb=True)
+        d = to_dict(dev, rows)
+        assert int(np.count_nonzero(d["Format"] == 3)) > 0 and d["hybsize"] > 0 and d["hybsize"] == d["hybellsize"] + d["hybcoosize"]
+        api.Tile_destroy(dev)
+        assert same_tile_matrix(rows, cols, rp, ci, np.float64, hyb=True) == []
 
 
 def test_device_tile_create_random_ingredients():
     """60 matrices from the fuzz generator's ingredients (every format, long rows, empty tile-rows, odd column counts; half of them with unsorted columns)."""
     for seed in range(60):
         rows, cols, rp, ci = random_matrix(1000 + seed)
-        bad = same_tile_matrix(rows, cols, rp, ci, np.float64 if seed % 3 else np.float32, cdna4=seed % 5 == 0, real=seed % 2 == 0)
+        bad = same_tile_matrix(rows, cols, rp, ci, np.float64 if seed % 3 else np.float32, cdna4=seed % 5 == 0, real=seed % 2 == 0, hyb=seed % 4 == 1)
         assert bad == [], "seed %d: %s" % (1000 + seed, bad)
 
 
@@ -94,7 +109,7 @@ def _spmv(torch, plan, rows, x):
     return y[:rows]
 
 
-def same_plan(torch, rows, cols, rp, ci, dtype, knobs, cdna4=False, shard=None):
+def same_plan(torch, rows, cols, rp, ci, dtype, knobs, cdna4=False, shard=None, hyb=False):
     """Host-built and device-built plan of one matrix and one option set: the same streams (per-stream digests read back from the device), the same facts, the same bits of y."""
     nnz = int(rp[rows])
     v, x = G.real_values(nnz, dtype), G.real_x(cols, nnz, dtype)
@@ -102,9 +117,9 @@ def same_plan(torch, rows, cols, rp, ci, dtype, knobs, cdna4=False, shard=None):
     kw.setdefault("placement_tries", 1)
     if shard:
         kw["tilerow_begin"], kw["tilerow_end"] = shard
-    tm = api.Tile_create(rows, cols, nnz, rp, ci, v, dtype=dtype, cdna4=cdna4)
+    tm = api.Tile_create(rows, cols, nnz, rp, ci, v, dtype=dtype, cdna4=cdna4, hyb=hyb)
     host = api.Plan(tm, rows, cols, nnz, **kw)
-    dev = api.Plan.from_csr(rows, cols, nnz, rp, ci, v, dtype=dtype, cdna4=cdna4, **kw)
+    dev = api.Plan.from_csr(rows, cols, nnz, rp, ci, v, dtype=dtype, cdna4=cdna4, hyb=hyb, **kw)
     try:
         hi, di = host.info(), dev.info()
         assert di["device_build"] == 1 and hi["device_build"] == 0
@@ -180,7 +195,28 @@ def test_device_built_plan_random_ingredients(torch_cuda):
     for seed in range(40):
         rows, cols, rp, ci = random_matrix(2000 + seed)
         knobs = KNOB_SETS[seed % len(KNOB_SETS)]
-        same_plan(torch_cuda, rows, cols, rp, ci, np.float64 if seed % 2 else np.float32, knobs, cdna4=seed % 7 == 0)
+        same_plan(torch_cuda, rows, cols, rp, ci, np.float64 if seed % 2 else np.float32, knobs, cdna4=seed % 7 == 0, hyb=seed % 3 == 1)
+
+
+def test_device_built_plan_with_hyb_tiles(torch_cuda):
+    """Config 2's requirement (all seven formats) through tilespmv_plan_create_from_csr: with TILESPMV_CREATE_HYB the device-built plan has the host-built plan's streams, facts and y —
+    split, pooled and wide forms, per-strip / per-wavefront / per-workgroup entry lists (HYB remainders go where COO entries go)."""
+    from oracle.oracle import CpuImpl
+    mats = [cases.SMALL["allfmt"](), G.retarget_nnz(*G.circuit_like(60000, seed=1), target_nnz=336000, seed=1)]
+    for rows, cols, rp, ci in mats:
+        rows = cases.truncated_rows(rows)
+        for i, knobs in enumerate([dict(), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2), dict(csr_split=1), dict(csr_split=2), dict(csr_split=3), dict(deterministic=1, strip_cost=64, split_above=200)]):
+            same_plan(torch_cuda, rows, cols, rp, ci, np.float64 if i % 2 == 0 else np.float32, knobs, hyb=True)
+    # ... and the result is the oracle's (HYB oracle = the reference's headers with the dormant branch re-enabled, oracle/Makefile), bit for bit on integer data
+    rows, cols, rp, ci = mats[1]
+    rows = cases.truncated_rows(rows); nnz = int(rp[rows])
+    for dtype in (np.float64, np.float32):
+        O = CpuImpl("oracle", dtype)
+        v, x = G.compat_values(nnz, dtype), G.compat_x(cols, dtype)
+        want = O.spmv(O.tile_create(rows, cols, nnz, rp, ci, v, hyb=True), rows, cols, nnz, rp, ci, v, x)["y"]
+        p = api.Plan.from_csr(rows, cols, nnz, rp, ci, v, dtype=dtype, hyb=True)
+        assert np.array_equal(_spmv(torch_cuda, p, rows, x), want)
+        p.close()
 
 
 def test_device_built_plan_matches_the_oracle(torch_cuda):

@@ -51,14 +51,14 @@ def Tile_create(rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, h
     return tm
 
 
-def Tile_create_device(rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, quiet=True, cdna4=False):
-    """``Tile_create`` computed on the GPU (hip_tile_create.hip): the CSR arrays go up, the tiled matrix comes back, byte for byte what ``Tile_create`` builds.
-    No CPU fallback: raises when no device is visible (rc -1); HYB tiles are a host-only option."""
+def Tile_create_device(rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, quiet=True, cdna4=False, hyb=False):
+    """``Tile_create`` computed on the GPU (hip_tile_create.hip): the CSR arrays go up, the tiled matrix comes back, byte for byte what ``Tile_create`` builds
+    (``hyb=True``: with the reference's dormant HYB rule switched on, as ``Tile_create(hyb=True)``).  No CPU fallback: raises when no device is visible (rc -1)."""
     dtype = np.dtype(dtype or np.asarray(csrValA).dtype)
     lib = _lib.load(dtype)
     rp, ci, v = _csr(lib, csrRowPtrA, csrColIdxA, csrValA)
     tm = lib._TM()
-    flags = (CREATE_QUIET if quiet else 0) | (CREATE_CDNA4 if cdna4 else 0)
+    flags = (CREATE_QUIET if quiet else 0) | (CREATE_CDNA4 if cdna4 else 0) | (CREATE_HYB if hyb else 0)
     rc = lib.Tile_create_device(C.byref(tm), rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int), _p(v, lib._vt), flags)
     if rc != 0:
         raise RuntimeError("Tile_create_device failed (%d): no usable HIP device / extension, or offsets beyond int32" % rc)
@@ -256,7 +256,7 @@ class Plan:
         self.h = h
 
     @classmethod
-    def from_csr(cls, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, cdna4=False, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, autotune=False, **knobs):
+    def from_csr(cls, rowA, colA, nnzA, csrRowPtrA, csrColIdxA, csrValA, dtype=None, cdna4=False, hyb=False, coo_mode=COO_AUTO, dense_mode=DENSE_AUTO, kernel=0, tilerow_begin=0, tilerow_end=0, autotune=False, **knobs):
         """``tilespmv_plan_create_from_csr``: the tiled matrix and the plan's streams are built on the device; only the CSR arrays cross the bus.
         Raises ``NotImplementedError`` for the options that have no device path (rc -4: first-generation kernel, CSR fallback, csr_split=0).  ``autotune=True``: every candidate is built from the one device-resident tiled matrix."""
         dtype = np.dtype(dtype or np.asarray(csrValA).dtype)
@@ -267,7 +267,7 @@ class Plan:
         self.rowA, self.colA, self.nnzA = rowA, colA, nnzA
         opts = _lib.PlanOptions(coo_mode, dense_mode, kernel, tilerow_begin, tilerow_end, autotune, **knobs)
         h = C.c_void_p()
-        rc = lib.tilespmv_plan_create_from_csr(C.byref(h), rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int), _p(v, lib._vt), CREATE_QUIET | (CREATE_CDNA4 if cdna4 else 0), C.byref(opts))
+        rc = lib.tilespmv_plan_create_from_csr(C.byref(h), rowA, colA, nnzA, _p(rp, C.c_int), _p(ci, C.c_int), _p(v, lib._vt), CREATE_QUIET | (CREATE_CDNA4 if cdna4 else 0) | (CREATE_HYB if hyb else 0), C.byref(opts))
         if rc == -4:
             raise NotImplementedError("tilespmv_plan_create_from_csr: these options have no device path")
         if rc != 0 or not h:

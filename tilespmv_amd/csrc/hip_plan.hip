@@ -579,8 +579,8 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     plan->coo_mode = coo_mode; plan->dense_mode = dense_mode;
 
     // ---- HYB tiles address hybIdx by a running byte offset (reference ptroffset2, src/tilespmv_cpu.h:195-196)
-    std::vector<long long> hyb_off;
-    if (T->hybsize > 0) {
+    std::vector<long long> hyb_off;   // (device mode: the builder's kernels take DevTile::hyb_off; the host never decodes a tile there)
+    if (T->hybsize > 0 && !DT) {
         hyb_off.assign((size_t)T->tilenum, 0);
         long long at = 0;
         for (int bi = 0; bi < tilem; bi++) {
@@ -860,7 +860,7 @@ static int plan_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_PTR_TYPE n
     const Knobs K = resolve_knobs(opts);
     const int tilen = (colA + BS - 1) / BS;
     // what has no device path (include/tilespmv.h): the caller builds those plans from a host Tile_matrix
-    if (K.dry || (create_flags & TILESPMV_CREATE_HYB) || K.kernel == TILESPMV_KERNEL_DIRECT || tilen > (1 << UNIT_FLAG_SHIFT) || K.coo_mode == TILESPMV_COO_FALLBACK || K.csr_split == 0)
+    if (K.dry || K.kernel == TILESPMV_KERNEL_DIRECT || tilen > (1 << UNIT_FLAG_SHIFT) || K.coo_mode == TILESPMV_COO_FALLBACK || K.csr_split == 0)
         return -4;
     const double t0 = now_us();
     DevTile *D = nullptr;
@@ -873,7 +873,7 @@ static int plan_from_csr(tilespmv_plan **out, int rowA, int colA, MAT_PTR_TYPE n
         Tile_matrix Z;   // counts stay, every pointer member and the hyb sizes are cleared (three pointers are replaced below)
         memset(&Z, 0, sizeof(Z));
         Z.tilem = H.tilem; Z.tilen = H.tilen; Z.tilenum = H.tilenum;
-        Z.csrsize = H.csrsize; Z.csrptrlen = H.csrptrlen; Z.coosize = H.coosize; Z.ellsize = H.ellsize; Z.dnssize = H.dnssize; Z.dnsrowsize = H.dnsrowsize; Z.dnscolsize = H.dnscolsize; Z.coototal = H.coototal;
+        Z.csrsize = H.csrsize; Z.csrptrlen = H.csrptrlen; Z.coosize = H.coosize; Z.ellsize = H.ellsize; Z.hybsize = H.hybsize; Z.hybellsize = H.hybellsize; Z.hybcoosize = H.hybcoosize; Z.dnssize = H.dnssize; Z.dnsrowsize = H.dnsrowsize; Z.dnscolsize = H.dnscolsize; Z.coototal = H.coototal;
         H = Z;
     }
     std::vector<int> h_tile_ptr((size_t)H.tilem + 1, 0), h_tile_col((size_t)std::max(1, H.tilenum), 0);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_pd_gather_ints(const int *__restrict__ 
 }
 
 // ---- COUNT
-__global__ __launch_bounds__(256) void k_pd_count_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, int t_begin, int nt, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form,
+__global__ __launch_bounds__(256) void k_pd_count_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, const long long *__restrict__ hyb_off, int t_begin, int nt, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form,
                                                           int *__restrict__ tu, int *__restrict__ tc, int *__restrict__ td, int *__restrict__ tp)
 {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,19 +68,19 @@ __global__ __launch_bounds__(256) void k_pd_count_tiles(const Tile_matrix T, con
     const int t = t_begin + (int)gid, rowlen = tile_rowlen(tile_bi[t], T.tilem, rowA);
     const TileCount k = tile_count(&T, t, rowlen, T.tilen, colA, coo_in_tile, dense_mfma, csr_form);
     tu[gid] = k.nunits; tc[gid] = k.ncoo; td[gid] = k.ndense;
-    if (csr_form >= 2) tp[gid] = pool_one_tile_count(&T, t, rowlen, coo_in_tile, nullptr);   // what the tile adds to its tile-row's pool
+    if (csr_form >= 2) tp[gid] = pool_one_tile_count(&T, t, rowlen, coo_in_tile, hyb_off);   // what the tile adds to its tile-row's pool
 }
 // The pooled part (round 5, second half: one thread per tile-row took 0.35 s per pass on R-MAT 21 x 16, whose hub tile-rows hold 10^5 nonzeros in 10^4-10^5 tiny tiles each — and a
 // wavefront waits for its heaviest lane).  Two balanced steps instead: (1) every tile writes its contribution where the exclusive scan of the contributions (tp) puts it — the tiles of a
 // tile-row back to back, which is the array the host builder's pool_row makes — one thread per TILE with the host builder's per-tile function; (2) one WAVEFRONT per tile-row walks
 // the windows (pool_windows_wave below).
-__global__ __launch_bounds__(256) void k_pd_fill_pool(const Tile_matrix T, const int *__restrict__ tile_bi, int t_begin, int nt, int rowA, bool coo_in_tile, const int *__restrict__ tp, PoolEnt *__restrict__ pool)
+__global__ __launch_bounds__(256) void k_pd_fill_pool(const Tile_matrix T, const int *__restrict__ tile_bi, const long long *__restrict__ hyb_off, int t_begin, int nt, int rowA, bool coo_in_tile, const int *__restrict__ tp, PoolEnt *__restrict__ pool)
 {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nt) return;
     if (tp[gid + 1] == tp[gid]) return;
     const int t = t_begin + (int)gid;
-    (void)pool_one_tile(&T, t, tile_rowlen(tile_bi[t], T.tilem, rowA), coo_in_tile, nullptr, pool + tp[gid]);
+    (void)pool_one_tile(&T, t, tile_rowlen(tile_bi[t], T.tilem, rowA), coo_in_tile, hyb_off, pool + tp[gid]);
 }
 // The window walk (plan_tile_ops.h pool_windows) by a wavefront, 64 nonzeros per step: every lane finds where a window starting at ITS nonzero would end (at most 15 look-aheads),
 // then the wavefront follows the chain of window starts through the step's 64 candidates with register reads (v_readlane: a few cycles per window, against a dependent
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_pd_fill_urow(uint2 *__restrict__ urow, 
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) urow[i] = make_uint2(0x01234567u, 0x89ABCDEFu);   // (units that keep one row per lane: identity)
 }
-__global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, int t_begin, int nt, int tr0, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form,
+__global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, const long long *__restrict__ hyb_off, int t_begin, int nt, int tr0, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form,
                                                          const int *__restrict__ tu, const int *__restrict__ tc, const int *__restrict__ td, const int *__restrict__ pu, const int *__restrict__ pc,
                                                          const int *__restrict__ pd, const unsigned char *__restrict__ row_k, const unsigned char *__restrict__ row_split, const EmitOut O)
 {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, cons
     const int t = t_begin + (int)gid, bi = tile_bi[t], i = bi - tr0, a = T.tile_ptr[bi] - t_begin;
     EmitPos p{(long long)pu[i] + tu[gid] - tu[a], (long long)pc[i] + tc[gid] - tc[a], (long long)pd[i] + td[gid] - td[a]};
     const long long u0 = p.u;
-    tile_emit(&T, t, tile_rowlen(bi, T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form, (unsigned)row_k[i], nullptr, O, p);
+    tile_emit(&T, t, tile_rowlen(bi, T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form, (unsigned)row_k[i], hyb_off, O, p);
     // the tile that emits the last unit of an unsplit tile-row of a classic plan marks it (the kernel writes y there)
     if (csr_form < 2 && !row_split[i] && p.u > u0 && p.u == pu[i + 1]) { O.udesc[p.u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; O.udesc[p.u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
 }
@@ -510,7 +510,7 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, hvec<int> &counts3,
     if (csr_form >= 2) C->tp = blockp + 3 * per;
     PD_TRY(hipMemsetAsync(blockp, 0, ints * sizeof(int), 0));
     if (nt > 0) {
-        hipLaunchKernelGGL(k_pd_count_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, S.t_begin, nt, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, csr_form, C->tu, C->tc, C->td, C->tp);
+        hipLaunchKernelGGL(k_pd_count_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, D->hyb_off, S.t_begin, nt, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, csr_form, C->tu, C->tc, C->td, C->tp);
         PD_TRY(hipGetLastError());
         size_t tmp_b = 0; void *tmp = nullptr;
         PD_TRY(prims::scan_int(nullptr, tmp_b, C->tu, C->tu, (size_t)nt + 1, (hipStream_t)0));
@@ -527,7 +527,7 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, hvec<int> &counts3,
         PD_TRY(hipMalloc((void **)&C->pool, (size_t)std::max<long long>(1, S.stored) * sizeof(PoolEnt) + 16));
         Tmp<unsigned long long> d_stat;
         PD_TRY(d_stat.alloc(2, true));
-        if (nt > 0) { hipLaunchKernelGGL(k_pd_fill_pool, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, S.t_begin, nt, D->rowA, S.coo_in_tile, (const int *)C->tp, C->pool); PD_TRY(hipGetLastError()); }
+        if (nt > 0) { hipLaunchKernelGGL(k_pd_fill_pool, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, D->hyb_off, S.t_begin, nt, D->rowA, S.coo_in_tile, (const int *)C->tp, C->pool); PD_TRY(hipGetLastError()); }
         hipLaunchKernelGGL(k_pd_count_pool, dim3(nblk((long long)ntr * 64, 256)), dim3(256), 0, 0, (const int *)D->T.tile_ptr, S.tr0, ntr, S.t_begin, csr_form == 3 ? POOL_WIDE_WINDOW : 16u, (const int *)C->tp, (const PoolEnt *)C->pool, C->pool_u, C->pool_c, d_stat.p);
         PD_TRY(hipGetLastError());
         unsigned long long h_stat[2] = {0, 0};
@@ -576,7 +576,7 @@ int dev_emit(const DevShard &S, const DevCounts &C, const hvec<long long> &pu, c
     PD_TRY(d_rk.from(row_k)); PD_TRY(d_rs.from(row_split));
     if (O.urow && NU > 0) { hipLaunchKernelGGL(k_pd_fill_urow, dim3(nblk(NU, 256)), dim3(256), 0, 0, O.urow, NU); PD_TRY(hipGetLastError()); }
     if (nt > 0) {
-        hipLaunchKernelGGL(k_pd_emit_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, S.t_begin, nt, S.tr0, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, C.csr_form, (const int *)C.tu,
+        hipLaunchKernelGGL(k_pd_emit_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, D->hyb_off, S.t_begin, nt, S.tr0, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, C.csr_form, (const int *)C.tu,
                            (const int *)C.tc, (const int *)C.td, (const int *)d_pu.p, (const int *)d_pc.p, (const int *)d_pd.p, (const unsigned char *)d_rk.p, (const unsigned char *)d_rs.p, O);
         PD_TRY(hipGetLastError());
     }

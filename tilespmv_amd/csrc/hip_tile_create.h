@@ -20,6 +20,8 @@ struct DevTile {
     const unsigned long long *key = nullptr;   // per nonzero, tile order: tile-row << (8 + cb_bits) | column block << 8 | local row << 4 | local column
     const int *ent = nullptr;              // per nonzero, tile order: its position in the CSR arrays
     const int *tile_bi = nullptr;          // per tile: its tile-row
+    const long long *hyb_off = nullptr;    // the same as 64-bit offsets (nullptr: the matrix has no HYB tile): what plan_tile_ops.h's per-tile functions take
+    const int *hyb_byte_off = nullptr;     // per tile (+ 1): first byte of a HYB tile in hybIdx (the running offset the reference calls ptroffset2, src/tilespmv_cpu.h:195-196)
     int cb_bits = 0;
     bool have_deferred = false;            // deferredcoo_* built (Tile_create_device) or skipped (plans never read them in the in-tile COO mode)
     int unsorted_rows = 0;                 // rows of the extracted matrix whose columns do not increase (the host sorts those after the download, like the reference)
@@ -27,7 +29,7 @@ struct DevTile {
     double ms_upload = 0, ms_sort = 0, ms_tiles = 0, ms_select = 0, ms_pack = 0;
 };
 
-// rc 0, -1 no device, -2 int32 offsets of Tile_matrix exceeded, -3 HIP error / out of device memory, -4 unsupported flags (TILESPMV_CREATE_HYB)
+// rc 0, -1 no device, -2 int32 offsets of Tile_matrix exceeded, -3 HIP error / out of device memory
 // csr_on_device: the three CSR arrays are DEVICE pointers already (row pointer based at 0; borrowed, not freed): no upload at all
 int devtile_create(DevTile **out, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, const int *h_colidx, const val_t *h_val, unsigned flags, bool want_deferred, bool csr_on_device = false);
 void devtile_destroy(DevTile *D);

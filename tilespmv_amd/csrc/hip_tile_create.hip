@@ -9,7 +9,8 @@
 //   4. one thread per tile: row counts from the keys, the shared selection rule (tile_select.h), sizes -> thirteen exclusive scans;
 //   5. one thread per tile packs its payload (values gathered from the CSR array through the sorted positions); nibble streams packed by a second kernel (two tiles may
 //      share a byte); the extracted very-sparse matrix (deferredcoo_*) by one more stable sort by row.
-// HYB tiles (TILESPMV_CREATE_HYB, dormant in the shipped reference) are not built here: the flag is refused and the caller uses the host path.
+// HYB tiles (TILESPMV_CREATE_HYB, dormant in the shipped reference: SURVEY S1; width search src/csr2tile.h:279-306 = tile_select.h, pack :505-548, index bytes :984-1008) are built
+// too (round 6): a tile's index bytes are tile-byte-aligned, so the thread that packs the tile writes them itself, at a byte offset that is one more scan.
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -105,10 +106,11 @@ struct TileArrays {   // the per-tile arrays of Tile_matrix (device)
     char *Format; int *blknnz; unsigned char *blknnznnz; int *dnsrowptr, *dnscolptr; char *tilewidth;
     int *csrptr_offset, *hyb_coocount, *new_coocount;
     int *fmt_offset[7];   // csr, coo, ell, hyb, dns, dnsrow, dnscol (TILESPMV_FMT_* order)
+    int *hyb_bytes;       // HYB tiles: bytes of the tile in hybIdx (scanned into the tile's byte offset)
 };
 
 // ---- 4. selection: one thread per tile
-__global__ __launch_bounds__(256) void k_tc_select(int tilenum, int tilem, int tilen, int rowA, int colA, bool cdna4, const int *__restrict__ tile_nnz, const int *__restrict__ tile_bi,
+__global__ __launch_bounds__(256) void k_tc_select(int tilenum, int tilem, int tilen, int rowA, int colA, bool allow_hyb, bool cdna4, const int *__restrict__ tile_nnz, const int *__restrict__ tile_bi,
                                                      const int *__restrict__ tile_columnidx, const u64 *__restrict__ key, TileArrays A)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_tc_select(int tilenum, int tilem, int t
         if (r < 8) c0 = (c0 & ~m) | ((c0 + one) & m); else c1 = (c1 & ~m) | ((c1 + one) & m);
     }
     const u64 *kp = key + e0;
-    const Choice c = select_format(n, rowlen, collen, [c0, c1](int r) { return (int)(((r < 8 ? c0 : c1) >> (8 * (r & 7))) & 255ull); }, [kp](int k) { return (int)(kp[k] & 255ull); }, false, cdna4);
+    const Choice c = select_format(n, rowlen, collen, [c0, c1](int r) { return (int)(((r < 8 ? c0 : c1) >> (8 * (r & 7))) & 255ull); }, [kp](int k) { return (int)(kp[k] & 255ull); }, allow_hyb, cdna4);
     A.Format[t] = (char)c.fmt;
     A.blknnz[t] = c.stored;
     A.blknnznnz[t] = (unsigned char)c.stored;
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(256) void k_tc_select(int tilenum, int tilem, int t
     A.hyb_coocount[t] = c.hybcoo; A.new_coocount[t] = c.extracted;
     A.csrptr_offset[t] = c.csrptr;
     A.fmt_offset[c.fmt][t] = c.stored;
+    if (c.fmt == TILESPMV_FMT_HYB) A.hyb_bytes[t] = (c.width * rowlen + 1) / 2 + c.hybcoo;   // ELL part in nibbles (rounded up to a byte), then one byte per remainder entry
 }
 
 // totals of K int arrays of n elements each, in 64 bits (the scans below are done in int: a total that fits proves every prefix does, the counts are non-negative)
@@ -151,6 +154,7 @@ struct PackArrays {
     val_t *Blockell_Val; unsigned char *ell_col;
     val_t *Blockdense_Val, *Blockdenserow_Val, *Blockdensecol_Val;
     char *denserowid, *densecolid;
+    val_t *Blockhyb_Val; unsigned char *hybIdx; const int *hyb_byte_off;   // HYB: values, index bytes, every tile's byte offset in hybIdx
     unsigned *x_key; int *x_col; val_t *x_val;   // extracted entries in tile order: global row, column, value (nullptr: not wanted)
     int *deferredcoo_ptr;                          // per-row counts (atomics), scanned afterwards
 };
@@ -204,6 +208,32 @@ __global__ __launch_bounds__(256) void k_tc_pack(int tilenum, int tilem, int til
         }
         break;
     }
+    case TILESPMV_FMT_HYB: {   // ELL part of width w (slot-major, zero padded) + the entries beyond it in row order (src/csr2tile.h:505-548); index bytes :984-1008
+        const int off = T.hyb_offset[t], xo = T.new_coocount[t], w = T.tilewidth[t], nell = w * rowlen;
+        unsigned char *ib = P.hybIdx + P.hyb_byte_off[t];   // this tile's bytes (nobody else's: the stream is tile-byte-aligned)
+        int spill = 0;
+        for (int k = 0; k < n; k++) {
+            const int rc = (int)(kp[k] & 255ull), r = rc >> 4;
+            if (r != rcur) { rcur = r; rstart = k; }
+            const int sl = k - rstart;
+            const val_t v = vals[src[k]];
+            if (sl < w) {
+                const int q = sl * rowlen + r;
+                P.Blockhyb_Val[off + q] = v;
+                ib[q >> 1] = (unsigned char)(ib[q >> 1] | ((q & 1) ? (rc & 15) : ((rc & 15) << 4)));   // nibble at position q of the tile's own stream: high nibble first
+            } else {
+                P.Blockhyb_Val[off + nell + spill] = v;
+                ib[(nell + 1) / 2 + spill] = (unsigned char)rc;   // (row << 4) | column
+                if (P.x_key) {
+                    const unsigned row = (unsigned)bi * 16u + (unsigned)r;
+                    P.x_key[xo + spill] = row; P.x_col[xo + spill] = colidx[src[k]]; P.x_val[xo + spill] = v;
+                    atomicAdd(&P.deferredcoo_ptr[row], 1);
+                }
+                spill++;
+            }
+        }
+        break;
+    }
     case TILESPMV_FMT_DNS: {
         const int off = T.dns_offset[t];
         for (int k = 0; k < n; k++) { const int rc = (int)(kp[k] & 255ull); P.Blockdense_Val[off + (rc & 15) * rowlen + (rc >> 4)] = vals[src[k]]; }
@@ -248,6 +278,11 @@ __global__ void k_tc_deferred(int n, const int *__restrict__ pos, const int *__r
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     colidx[i] = x_col[pos[i]]; val[i] = x_val[pos[i]];
+}
+__global__ void k_tc_widen(long long n, const int *__restrict__ a, long long *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i];
 }
 __global__ void k_tc_iota(int n, int *__restrict__ a)
 {
@@ -313,7 +348,7 @@ inline unsigned blocks_for(long long n, int per) { return (unsigned)std::max<lon
 
 int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, const int *h_colidx, const val_t *h_val, unsigned flags, bool want_deferred, bool csr_on_device)
 {
-    const bool verbose = getenv("TILESPMV_CREATE_VERBOSE") != nullptr, cdna4 = flags & TILESPMV_CREATE_CDNA4;
+    const bool verbose = getenv("TILESPMV_CREATE_VERBOSE") != nullptr, cdna4 = flags & TILESPMV_CREATE_CDNA4, allow_hyb = flags & TILESPMV_CREATE_HYB;
     pool_end();   // (no pool left over from a build that failed on this thread)
     Tile_matrix &T = D->T;
     const int tilem = (rowA + BS - 1) / BS, tilen = (colA + BS - 1) / BS;
@@ -429,7 +464,7 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     int *off7[7];
     if (dalloc(D, &A.Format, (size_t)tilenum, true) || dalloc(D, &A.blknnz, np1, true) || dalloc(D, &A.blknnznnz, np1, true) || dalloc(D, &A.dnsrowptr, np1, true) ||
         dalloc(D, &A.dnscolptr, np1, true) || dalloc(D, &A.tilewidth, (size_t)tilenum, true) || dalloc(D, &A.csrptr_offset, np1, true) || dalloc(D, &A.hyb_coocount, np1, true) ||
-        dalloc(D, &A.new_coocount, np1, true))
+        dalloc(D, &A.new_coocount, np1, true) || dalloc(D, &A.hyb_bytes, np1, true))
         return -3;
     for (int f = 0; f < 7; f++) { if (dalloc(D, &off7[f], np1, true)) return -3; A.fmt_offset[f] = off7[f]; }
     T.Format = A.Format; T.blknnz = A.blknnz; T.blknnznnz = A.blknnznnz; T.dnsrowptr = A.dnsrowptr; T.dnscolptr = A.dnscolptr; T.tilewidth = A.tilewidth;
@@ -437,13 +472,13 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     T.csr_offset = off7[TILESPMV_FMT_CSR]; T.coo_offset = off7[TILESPMV_FMT_COO]; T.ell_offset = off7[TILESPMV_FMT_ELL]; T.hyb_offset = off7[TILESPMV_FMT_HYB];
     T.dns_offset = off7[TILESPMV_FMT_DNS]; T.dnsrow_offset = off7[TILESPMV_FMT_DNSROW]; T.dnscol_offset = off7[TILESPMV_FMT_DNSCOL];
     if (tilenum > 0) {
-        hipLaunchKernelGGL(k_tc_select, dim3(blocks_for(tilenum, 256)), dim3(256), 0, 0, tilenum, tilem, tilen, rowA, colA, cdna4, d_tile_nnz, d_tile_bi, d_tile_columnidx, D->key, A);
+        hipLaunchKernelGGL(k_tc_select, dim3(blocks_for(tilenum, 256)), dim3(256), 0, 0, tilenum, tilem, tilen, rowA, colA, allow_hyb, cdna4, d_tile_nnz, d_tile_bi, d_tile_columnidx, D->key, A);
         TC_TRY(hipGetLastError());
     }
     ScanSet S{};
-    int *scans[] = {T.csr_offset, T.csrptr_offset, T.coo_offset, T.ell_offset, T.hyb_offset, T.dns_offset, T.dnsrow_offset, T.dnscol_offset, T.dnsrowptr, T.dnscolptr, T.hyb_coocount, T.new_coocount, T.blknnz};
-    static const char *names[] = {"csr_offset", "csrptr_offset", "coo_offset", "ell_offset", "hyb_offset", "dns_offset", "dnsrow_offset", "dnscol_offset", "dnsrowptr", "dnscolptr", "hyb_coocount", "new_coocount", "blknnz"};
-    constexpr int NS = 13;
+    int *scans[] = {T.csr_offset, T.csrptr_offset, T.coo_offset, T.ell_offset, T.hyb_offset, T.dns_offset, T.dnsrow_offset, T.dnscol_offset, T.dnsrowptr, T.dnscolptr, T.hyb_coocount, T.new_coocount, T.blknnz, A.hyb_bytes};
+    static const char *names[] = {"csr_offset", "csrptr_offset", "coo_offset", "ell_offset", "hyb_offset", "dns_offset", "dnsrow_offset", "dnscol_offset", "dnsrowptr", "dnscolptr", "hyb_coocount", "new_coocount", "blknnz", "hybIdx bytes"};
+    constexpr int NS = 14;
     for (int k = 0; k < NS; k++) S.a[k] = scans[k];
     unsigned long long *d_totals = nullptr, h_totals[NS] = {0};
     if (dalloc(D, &d_totals, NS, true)) return -3;
@@ -465,7 +500,15 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
         TC_TRY(e);
     }
     T.csrsize = (int)h_totals[0]; T.csrptrlen = (int)h_totals[1]; T.coosize = (int)h_totals[2]; T.ellsize = (int)h_totals[3];
-    T.hybsize = 0; T.hybellsize = 0; T.hybcoosize = 0;
+    T.hybsize = (int)h_totals[4]; T.hybcoosize = (int)h_totals[10]; T.hybellsize = T.hybsize - T.hybcoosize;   // (a HYB tile stores its ELL part + its remainder)
+    D->hyb_byte_off = A.hyb_bytes;   // (scanned: per tile its first byte in hybIdx)
+    if (T.hybsize > 0) {             // ... and as the 64-bit offsets the plan builders' per-tile functions take (plan_tile_ops.h hyb_off)
+        long long *d_off64 = nullptr;
+        if (dalloc(D, &d_off64, np1, true)) return -3;
+        hipLaunchKernelGGL(k_tc_widen, dim3(blocks_for((long long)np1, 256)), dim3(256), 0, 0, (long long)np1, (const int *)A.hyb_bytes, d_off64);
+        TC_TRY(hipGetLastError());
+        D->hyb_off = d_off64;
+    }
     T.dnssize = (int)h_totals[5]; T.dnsrowsize = (int)h_totals[6]; T.dnscolsize = (int)h_totals[7]; T.coototal = (int)h_totals[11];
     const int ndenserow = (int)h_totals[8], ndensecol = (int)h_totals[9];
     D->ms_select = now_ms() - t0; t0 = now_ms();
@@ -475,7 +518,7 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     {
         const size_t sv = sizeof(val_t);
         size_t bytes = pool_need((size_t)T.csrsize, sv) + pool_need((size_t)T.csrptrlen, 1) + pool_need((size_t)T.csrsize, 1) + pool_need(((size_t)T.csrsize + 1) / 2, 1) + pool_need((size_t)T.coosize, sv) +
-                       pool_need((size_t)T.coosize, 1) + pool_need((size_t)T.ellsize, sv) + pool_need((size_t)T.ellsize, 1) + pool_need(((size_t)T.ellsize + 1) / 2, 1) + pool_need(1, sv) + pool_need((size_t)tilem + 8, 1) +
+                       pool_need((size_t)T.coosize, 1) + pool_need((size_t)T.ellsize, sv) + pool_need((size_t)T.ellsize, 1) + pool_need(((size_t)T.ellsize + 1) / 2, 1) + pool_need((size_t)T.hybsize + 1, sv) + pool_need(((size_t)T.hybellsize + 1) / 2 + (size_t)T.hybcoosize + (size_t)tilem + 8, 1) +
                        pool_need((size_t)T.dnssize, sv) + pool_need((size_t)T.dnsrowsize, sv) + pool_need((size_t)ndenserow, 1) + pool_need((size_t)T.dnscolsize, sv) + pool_need((size_t)ndensecol, 1);
         if (want_deferred) bytes += pool_need((size_t)rowA + 1, 4) + pool_need((size_t)T.coototal, 4) + pool_need((size_t)T.coototal, sv) + 2 * pool_need((size_t)T.coototal, 4) + pool_need((size_t)T.coototal, sv);
         if (pool_begin(D, bytes)) return -3;
@@ -485,7 +528,7 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     if (dalloc(D, &P.Blockcsr_Val, (size_t)T.csrsize, true) || dalloc(D, &P.Blockcsr_Ptr, (size_t)T.csrptrlen, true) || dalloc(D, &P.csr_col, (size_t)T.csrsize, true) ||
         dalloc(D, &d_csr_idx, ((size_t)T.csrsize + 1) / 2, true) || dalloc(D, &P.Blockcoo_Val, (size_t)T.coosize, true) || dalloc(D, &P.coo_compressed_Idx, (size_t)T.coosize, true) ||
         dalloc(D, &P.Blockell_Val, (size_t)T.ellsize, true) || dalloc(D, &P.ell_col, (size_t)T.ellsize, true) || dalloc(D, &d_ell_idx, ((size_t)T.ellsize + 1) / 2, true) ||
-        dalloc(D, &d_hybval, 1, true) || dalloc(D, &d_hybidx, (size_t)tilem + 8, true) || dalloc(D, &P.Blockdense_Val, (size_t)T.dnssize, true) ||
+        dalloc(D, &d_hybval, (size_t)T.hybsize + 1, true) || dalloc(D, &d_hybidx, ((size_t)T.hybellsize + 1) / 2 + (size_t)T.hybcoosize + (size_t)tilem + 8, true) || dalloc(D, &P.Blockdense_Val, (size_t)T.dnssize, true) ||
         dalloc(D, &P.Blockdenserow_Val, (size_t)T.dnsrowsize, true) || dalloc(D, &P.denserowid, (size_t)ndenserow, true) || dalloc(D, &P.Blockdensecol_Val, (size_t)T.dnscolsize, true) ||
         dalloc(D, &P.densecolid, (size_t)ndensecol, true))
         return -3;
@@ -493,6 +536,7 @@ int create_impl(DevTile *D, int rowA, int colA, const MAT_PTR_TYPE *h_rowptr, co
     T.Blockcoo_Val = P.Blockcoo_Val; T.coo_compressed_Idx = P.coo_compressed_Idx;
     T.Blockell_Val = P.Blockell_Val; T.ell_compressedIdx = d_ell_idx;
     T.Blockhyb_Val = d_hybval; T.hybIdx = d_hybidx;
+    P.Blockhyb_Val = d_hybval; P.hybIdx = d_hybidx; P.hyb_byte_off = A.hyb_bytes;
     T.Blockdense_Val = P.Blockdense_Val; T.Blockdenserow_Val = P.Blockdenserow_Val; T.denserowid = P.denserowid;
     T.Blockdensecol_Val = P.Blockdensecol_Val; T.densecolid = P.densecolid;
     int *d_dptr = nullptr, *d_dcol = nullptr; val_t *d_dval = nullptr;
@@ -569,7 +613,6 @@ int devtile_create(DevTile **out, int rowA, int colA, const MAT_PTR_TYPE *h_rowp
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); fprintf(stderr, "tilespmv: no HIP device visible — the device Tile_create has no CPU fallback (use Tile_create)\n"); return -1; }
-    if (flags & TILESPMV_CREATE_HYB) { fprintf(stderr, "tilespmv: the device Tile_create does not build HYB tiles (TILESPMV_CREATE_HYB): use Tile_create_ex\n"); return -4; }
     DevTile *D = new DevTile();
     const int rc = create_impl(D, rowA, colA, h_rowptr, h_colidx, h_val, flags, want_deferred, csr_on_device);
     pool_end();
@@ -592,7 +635,7 @@ int devtile_download(const DevTile *D, Tile_matrix *H)
     const Tile_matrix &T = D->T;
     memset(H, 0, sizeof(*H));
     H->tilem = T.tilem; H->tilen = T.tilen; H->tilenum = T.tilenum;
-    H->csrsize = T.csrsize; H->csrptrlen = T.csrptrlen; H->coosize = T.coosize; H->ellsize = T.ellsize; H->hybsize = 0; H->hybellsize = 0; H->hybcoosize = 0;
+    H->csrsize = T.csrsize; H->csrptrlen = T.csrptrlen; H->coosize = T.coosize; H->ellsize = T.ellsize; H->hybsize = T.hybsize; H->hybellsize = T.hybellsize; H->hybcoosize = T.hybcoosize;
     H->dnssize = T.dnssize; H->dnsrowsize = T.dnsrowsize; H->dnscolsize = T.dnscolsize; H->coototal = T.coototal;
     const size_t tn = (size_t)T.tilenum, np1 = tn + 1;
     int rc = 0;
@@ -627,8 +670,8 @@ int devtile_download(const DevTile *D, Tile_matrix *H)
     get(&H->coo_compressed_Idx, T.coo_compressed_Idx, (size_t)T.coosize);
     get(&H->Blockell_Val, T.Blockell_Val, (size_t)T.ellsize);
     get(&H->ell_compressedIdx, T.ell_compressedIdx, ((size_t)T.ellsize + 1) / 2);
-    H->Blockhyb_Val = zalloc<val_t>(0);
-    H->hybIdx = zalloc<unsigned char>((size_t)T.tilem + 8);
+    get(&H->Blockhyb_Val, T.Blockhyb_Val, (size_t)T.hybellsize + (size_t)T.hybcoosize);
+    get(&H->hybIdx, T.hybIdx, ((size_t)T.hybellsize + 1) / 2 + (size_t)T.hybcoosize + (size_t)T.tilem + 8);
     get(&H->Blockdense_Val, T.Blockdense_Val, (size_t)T.dnssize);
     get(&H->Blockdenserow_Val, T.Blockdenserow_Val, (size_t)T.dnsrowsize);
     int ndr = 0, ndc = 0;

@@ -87,7 +87,8 @@ class ShardedSpMV:
             import time
             t0 = time.perf_counter()
             self.tm, self.tile_cache = None, None
-            self.local = api.Plan.from_csr(self.local_rows, cols, self.local_nnz, rp, ci, v, dtype=self.dtype, **plan_kw)
+            self.tile_cache = "unused (device build)" if tile_cache is not None else None
+            self.local = api.Plan.from_csr(self.local_rows, cols, self.local_nnz, rp, ci, v, dtype=self.dtype, hyb=hyb, **plan_kw)
             t1 = time.perf_counter()
             info = self.local.info()
             self.tiles = int(info["tiles"])
