@@ -26,7 +26,7 @@ struct DevShard { const DevTile *D; int tr0, tr1, t_begin, t_end; bool coo_in_ti
 int dev_fetch_ints(const int *d_array, const long long *idx, int n, int *out);   // out[k] = d_array[idx[k]]
 int dev_count(const DevShard &S, int csr_form, DevCounts *C, hvec<int> &counts3, long long *pool_units = nullptr, long long *pool_lines = nullptr);   // counts3: (units, list entries, dense tiles) of every tile-row; pool_*: += units made of pooled windows, 128-byte lines of x their gathers touch
 // column patterns of the first units on a sample of tiles (what the split form's dictionary would have to hold): ELL slots exactly, of a CSR tile its first unit
-int dev_pattern_sample(const DevShard &S, int step, std::vector<unsigned long long> &patterns);
+int dev_pattern_sample(const DevShard &S, int step, int last_first_tile, int last_rowlen, std::vector<unsigned long long> &patterns);
 // EMIT: pu / pc / pd = first unit / list entry / dense tile of every tile-row (ntr + 1), row_k / row_split as in the host builder.  O: device destinations (zeroed by the caller;
 // urow is filled with the identity here)
 int dev_emit(const DevShard &S, const DevCounts &C, const hvec<long long> &pu, const hvec<long long> &pc, const hvec<long long> &pd, const std::vector<unsigned char> &row_k,

@@ -144,23 +144,23 @@ __global__ __launch_bounds__(256) void k_pd_row_counts(const int *__restrict__ t
     out[3 * i + 2] = td[b] - td[a];
 }
 
-// the sample of hip_plan_stream.hip StreamBuilder::count(), literally (it reads 16 rows of every sampled tile: a sample, not a count)
-__global__ __launch_bounds__(256) void k_pd_pattern_sample(const Tile_matrix T, int t_begin, int t_end, int step, int nsample, u64 *__restrict__ pats, int *__restrict__ npat)
+// the sample of hip_plan_stream.hip StreamBuilder::count(), literally (tiles from last_first_tile on belong to the last tile-row, of last_rowlen rows)
+__global__ __launch_bounds__(256) void k_pd_pattern_sample(const Tile_matrix T, int t_begin, int t_end, int step, int nsample, int last_first_tile, int last_rowlen, u64 *__restrict__ pats, int *__restrict__ npat)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsample) return;
     const int t = t_begin + s * step;
     int n = 0;
     if (t < t_end) {
-        const int fmt = T.Format[t];
+        const int fmt = T.Format[t], rl = t >= last_first_tile ? last_rowlen : 16;
         if (fmt == TILESPMV_FMT_ELL) {
             const int off = T.ell_offset[t], w = T.tilewidth[t];
-            for (int sl = 0; sl < w; sl++) { u64 nibs = 0; for (int r = 0; r < 16; r++) nibs |= (u64)nib_at(T.ell_compressedIdx, (long long)off + sl * 16 + r) << (60 - 4 * r); pats[(size_t)s * 16 + n++] = nibs; }
+            for (int sl = 0; sl < w; sl++) { u64 nibs = 0; for (int r = 0; r < rl; r++) nibs |= (u64)nib_at(T.ell_compressedIdx, (long long)off + sl * rl + r) << (60 - 4 * r); pats[(size_t)s * 16 + n++] = nibs; }
         } else if (fmt == TILESPMV_FMT_CSR) {
             const int off = T.csr_offset[t], stored = T.blknnz[t + 1] - T.blknnz[t];
             const unsigned char *ptr = T.Blockcsr_Ptr + T.csrptr_offset[t];
             u64 nibs = 0;
-            for (int r = 0; r < 16; r++) { const int k0 = ptr[r], k1 = r == 15 ? stored : ptr[r + 1]; if (k1 > k0) nibs |= (u64)nib_at(T.csr_compressedIdx, (long long)off + k0) << (60 - 4 * r); }
+            for (int r = 0; r < rl; r++) { const int k0 = ptr[r], k1 = r == rl - 1 ? stored : ptr[r + 1]; if (k1 > k0) nibs |= (u64)nib_at(T.csr_compressedIdx, (long long)off + k0) << (60 - 4 * r); }
             pats[(size_t)s * 16 + n++] = nibs;
         }
     }
@@ -547,7 +547,7 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, hvec<int> &counts3,
     return 0;
 }
 
-int dev_pattern_sample(const DevShard &S, int step, std::vector<unsigned long long> &patterns)
+int dev_pattern_sample(const DevShard &S, int step, int last_first_tile, int last_rowlen, std::vector<unsigned long long> &patterns)
 {
     patterns.clear();
     const int nt = S.t_end - S.t_begin;
@@ -555,7 +555,7 @@ int dev_pattern_sample(const DevShard &S, int step, std::vector<unsigned long lo
     const int nsample = (nt + step - 1) / step;
     Tmp<u64> d_p; Tmp<int> d_n;
     PD_TRY(d_p.alloc((size_t)nsample * 16, false)); PD_TRY(d_n.alloc((size_t)nsample, true));
-    hipLaunchKernelGGL(k_pd_pattern_sample, dim3(nblk(nsample, 256)), dim3(256), 0, 0, S.D->T, S.t_begin, S.t_end, step, nsample, d_p.p, d_n.p);
+    hipLaunchKernelGGL(k_pd_pattern_sample, dim3(nblk(nsample, 256)), dim3(256), 0, 0, S.D->T, S.t_begin, S.t_end, step, nsample, last_first_tile, last_rowlen, d_p.p, d_n.p);
     PD_TRY(hipGetLastError());
     std::vector<u64> hp((size_t)nsample * 16); std::vector<int> hn((size_t)nsample);
     PD_TRY(hipMemcpy(hp.data(), d_p.p, hp.size() * sizeof(u64), hipMemcpyDeviceToHost));

@@ -245,21 +245,24 @@ void StreamBuilder::count()
         else {
             std::unordered_set<unsigned long long> pats;
             const int nt = t_end - t_begin, step = std::max(1, nt / 16384);
+            // tiles of a partial last tile-row have fewer than 16 rows: their row pointer advances by rowlen and their ELL slots are rowlen apart (the sample read 16)
+            const int last_rowlen = tile_rowlen(tilem - 1, tilem, rowA), last_first_tile = tilem > 0 ? T->tile_ptr[tilem - 1] : 0;
             if (DT) {   // the same sample, taken by a kernel
                 std::vector<unsigned long long> got;
-                if (dev_pattern_sample(DS, step, got) != 0) { rc = -3; return; }
+                if (dev_pattern_sample(DS, step, last_first_tile, last_rowlen, got) != 0) { rc = -3; return; }
                 pats.insert(got.begin(), got.end());
             } else
             for (int t = t_begin; t < t_end && pats.size() <= ((size_t)1 << DICT_MAX_BITS); t += step) {
                 const int fmt = T->Format[t];
+                const int rl = t >= last_first_tile ? last_rowlen : 16;
                 if (fmt == TILESPMV_FMT_ELL) {
                     const int off = T->ell_offset[t], w = T->tilewidth[t];
-                    for (int sl = 0; sl < w; sl++) { unsigned long long nibs = 0; for (int r = 0; r < 16; r++) nibs |= (unsigned long long)nib(T->ell_compressedIdx, (long long)off + sl * 16 + r) << (60 - 4 * r); pats.insert(nibs); }
+                    for (int sl = 0; sl < w; sl++) { unsigned long long nibs = 0; for (int r = 0; r < rl; r++) nibs |= (unsigned long long)nib(T->ell_compressedIdx, (long long)off + sl * rl + r) << (60 - 4 * r); pats.insert(nibs); }
                 } else if (fmt == TILESPMV_FMT_CSR) {
                     const int off = T->csr_offset[t], stored = T->blknnz[t + 1] - T->blknnz[t];
                     const unsigned char *ptr = T->Blockcsr_Ptr + T->csrptr_offset[t];
                     unsigned long long nibs = 0;
-                    for (int r = 0; r < 16; r++) { const int k0 = ptr[r], k1 = r == 15 ? stored : ptr[r + 1]; if (k1 > k0) nibs |= (unsigned long long)nib(T->csr_compressedIdx, (long long)off + k0) << (60 - 4 * r); }
+                    for (int r = 0; r < rl; r++) { const int k0 = ptr[r], k1 = r == rl - 1 ? stored : ptr[r + 1]; if (k1 > k0) nibs |= (unsigned long long)nib(T->csr_compressedIdx, (long long)off + k0) << (60 - 4 * r); }
                     pats.insert(nibs);
                 }
             }

@@ -25,7 +25,8 @@ struct DevTile {
     int cb_bits = 0;
     bool have_deferred = false;            // deferredcoo_* built (Tile_create_device) or skipped (plans never read them in the in-tile COO mode)
     int unsorted_rows = 0;                 // rows of the extracted matrix whose columns do not increase (the host sorts those after the download, like the reference)
-    std::vector<void *> allocs;            // everything above
+    std::vector<void *> allocs;            // arrays with a hipMalloc of their own
+    std::vector<void *> pools;             // pool blocks (several arrays carved from each): freed only by devtile_destroy
     double ms_upload = 0, ms_sort = 0, ms_tiles = 0, ms_select = 0, ms_pack = 0;
 };
 

@@ -307,7 +307,7 @@ int pool_begin(DevTile *D, size_t bytes)
     void *p = nullptr;
     t_pool = Pool();
     TC_TRY(hipMalloc(&p, bytes + 256));
-    D->allocs.push_back(p);
+    D->pools.push_back(p);   // (its own list: dfree never looks here — the first array carved from a pool has the pool's address, and freeing IT must not free the pool)
     TC_TRY(hipMemsetAsync(p, 0, bytes + 256, 0));
     t_pool.at = (char *)p; t_pool.left = bytes + 256;
     return 0;
@@ -336,7 +336,7 @@ inline void free_now_or_later(void *p)
     if (!p) return;
     if (t_free_later) t_free_later->push_back(p); else (void)hipFree(p);
 }
-inline void dfree(DevTile *D, const void *p)   // (an array carved from a pool goes with its pool)
+inline void dfree(DevTile *D, const void *p)   // (an array carved from a pool is not in D->allocs: it goes with its pool, at devtile_destroy)
 {
     if (!p) return;
     auto it = std::find(D->allocs.begin(), D->allocs.end(), (void *)p);
@@ -625,6 +625,7 @@ void devtile_destroy(DevTile *D)
 {
     if (!D) return;
     for (void *p : D->allocs) (void)hipFree(p);
+    for (void *p : D->pools) (void)hipFree(p);
     delete D;
 }
 

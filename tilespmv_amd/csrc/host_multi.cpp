@@ -11,6 +11,7 @@
 #include <sys/time.h>
 
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -143,7 +144,13 @@ static void run_multi(std::vector<Shard> &S, Rccl &rccl, std::vector<void *> &co
         int rc_dev = -4;
         if (s.tr1 > s.tr0 && env_int("TILESPMV_DEVICE_BUILD", 0) != 0 && matrix->hybsize == 0 && csrRowPtrA && csrColIdxA && csrValA) {
             rc_dev = tilespmv_plan_create_from_csr(&s.plan, (int)s.rows, colA, csrRowPtrA[s.row0 + s.rows] - csrRowPtrA[s.row0], csrRowPtrA + s.row0, csrColIdxA, csrValA, TILESPMV_CREATE_QUIET, nullptr);
-            if (rc_dev == 0) s.y_local = true;
+            if (rc_dev == 0) {
+                s.y_local = true;
+                // the block must be the block of `matrix` (the CPU check and the report use the matrix): same tile count, as call_tilespmv_hip checks for the whole matrix
+                long long info[TILESPMV_INFO_COUNT];
+                tilespmv_plan_info(s.plan, info);
+                if (info[TILESPMV_INFO_TILES] != (long long)matrix->tile_ptr[s.tr1] - matrix->tile_ptr[s.tr0]) { e.what = "the CSR arguments do not describe the rows of `matrix` (tile count of a shard differs)"; e.code = -6; return; }
+            }
             else if (rc_dev != -4) { e.what = "tilespmv_plan_create_from_csr"; e.code = rc_dev; return; }
         }
         if (s.tr1 > s.tr0 && rc_dev == -4) CKT(tilespmv_plan_create(&s.plan, matrix, rowA, colA, nnzA, &o));
@@ -157,8 +164,12 @@ static void run_multi(std::vector<Shard> &S, Rccl &rccl, std::vector<void *> &co
         for (int g = 0; g < ngpus; g++) setup(g);
     } else {
         std::vector<std::thread> th;
-        for (int g = 0; g < ngpus; g++) th.emplace_back(setup, g);
+        int started = 0;
+        try {
+            for (; started < ngpus; started++) th.emplace_back(setup, started);
+        } catch (const std::system_error &) { }   // (no more threads to be had: what was started is joined, the rest set up here, one after another)
         for (auto &t : th) t.join();
+        for (int g = started; g < ngpus; g++) setup(g);
     }
     for (int g = 0; g < ngpus; g++) if (err[(size_t)g].what) die(err[(size_t)g].what, err[(size_t)g].code);
     // peer access for the gather (a no-op between shards that share a device)
