@@ -547,7 +547,7 @@ def main():
     t_gen = time.time() - t0
 
     # What a process pays ONCE, whatever it prepares first: the code objects of the preparation kernels, HIP's large-copy path (the first hipMemcpy of hundreds of MB from pageable memory takes
-    # 150-280 ms in a fresh process, the same copy 19 ms afterwards — scripts/rounds/r5b_upload_first_touch2.py), the host thread pool.  A small matrix goes through both preparation paths here,
+    # 150-280 ms in a fresh process, the same copy 19 ms afterwards — scripts/archive/rounds/r5b_upload_first_touch2.py), the host thread pool.  A small matrix goes through both preparation paths here,
     # untimed, so that `prep_seconds` below is what preparing THIS matrix costs a running process; the one-time part is reported as `process_warm_up_seconds`.
     t0 = time.time()
     if not args.no_prep_warm_up:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 evidence run on the GPU box: tests, smoke, default bench, other workloads, profiles.  usage: scripts/rounds/r2_final.sh <tag>
+# Round-2 evidence run on the GPU box: tests, smoke, default bench, other workloads, profiles.  usage: scripts/archive/rounds/r2_final.sh <tag>
 tag=${1:-r02}
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp

@@ -4,7 +4,7 @@ set -o pipefail
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r4first
 python -m pytest tests -m gpu -x -q > gpurun_out/r4first/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r4first/pytest_gpu.log
-timeout -k 10 500 python scripts/rounds/r4_gather_locality.py 4000000 8 > gpurun_out/r4first/locality.txt 2>&1; echo "locality rc=$?"; cat gpurun_out/r4first/locality.txt
+timeout -k 10 500 python scripts/archive/rounds/r4_gather_locality.py 4000000 8 > gpurun_out/r4first/locality.txt 2>&1; echo "locality rc=$?"; cat gpurun_out/r4first/locality.txt
 for wl in bandrand4x3_2000000 uniform8_8000000; do
   timeout -k 10 300 python bench.py --workload $wl --steps 50 --warmup 10 --no-cpu-baseline --no-extras > gpurun_out/r4first/bench_$wl.json 2> gpurun_out/r4first/bench_$wl.err; echo "bench $wl rc=$?"
   python -c "import json;d=json.load(open('gpurun_out/r4first/bench_$wl.json'));print(d['ms_per_step'], d['roofline']['frac'], d['config']['entry_mode'], d['config']['strip_cost'], d['config']['tasks'], d['roofline']['plan_stream_bytes_per_launch'])"

@@ -1,7 +1,7 @@
 """Round 4: how much of the irregular class's time is the x gather's cache level?  Same rows, same entries per row, same plan
 shape; only the number of COLUMNS (= the size of x the gathers spread over) changes: x that fits an XCD's 4-MB L2 (<= 256 k
 columns in fp64) ... x of 64 MB.  B_alg barely moves (x is a few per cent of it), so the time difference is the gathers.
-python scripts/rounds/r4_gather_locality.py [rows] [per_row]"""
+python scripts/archive/rounds/r4_gather_locality.py [rows] [per_row]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -8,4 +8,4 @@ python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "
 ( time timeout -k 10 900 python bench.py --steps 20 --warmup 5 > $out/bench_driver_args.json 2> $out/bench_driver_args.err ) 2> $out/bench_driver_args.time; echo "bench rc=$?"; tail -3 $out/bench_driver_args.time
 ( time timeout -k 10 900 python bench.py > $out/bench_default_args.json 2> $out/bench_default_args.err ) 2> $out/bench_default_args.time; echo "bench default rc=$?"
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --data real --no-extras --no-cpu-baseline > $out/bench_real.json 2> $out/bench_real.err; echo "bench real rc=$?"
-scripts/rounds/r4_final.sh > $out/final.log 2>&1; grep "^{\|calls" $out/final.log | cut -c1-200
+scripts/archive/rounds/r4_final.sh > $out/final.log 2>&1; grep "^{\|calls" $out/final.log | cut -c1-200

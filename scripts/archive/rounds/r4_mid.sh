@@ -5,9 +5,9 @@ set -o pipefail
 export TMPDIR=/tmp
 out=gpurun_out/r4mid; mkdir -p $out
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest.log
-timeout -k 10 600 python scripts/rounds/r4_placement.py nlpkkt160 10 > $out/placement_kkt_f64.txt 2>&1; echo "placement rc=$?"; grep -v amdgpu.ids $out/placement_kkt_f64.txt
-timeout -k 10 600 python scripts/rounds/r4_placement.py nlpkkt160 f32 10 > $out/placement_kkt_f32.txt 2>&1; grep -v amdgpu.ids $out/placement_kkt_f32.txt
-timeout -k 10 300 python scripts/rounds/r4_placement.py laplacian4096 6 > $out/placement_lap.txt 2>&1; grep -v amdgpu.ids $out/placement_lap.txt
+timeout -k 10 600 python scripts/archive/rounds/r4_placement.py nlpkkt160 10 > $out/placement_kkt_f64.txt 2>&1; echo "placement rc=$?"; grep -v amdgpu.ids $out/placement_kkt_f64.txt
+timeout -k 10 600 python scripts/archive/rounds/r4_placement.py nlpkkt160 f32 10 > $out/placement_kkt_f32.txt 2>&1; grep -v amdgpu.ids $out/placement_kkt_f32.txt
+timeout -k 10 300 python scripts/archive/rounds/r4_placement.py laplacian4096 6 > $out/placement_lap.txt 2>&1; grep -v amdgpu.ids $out/placement_lap.txt
 for a in "laplacian4096 f64" "laplacian4096 f32" "nlpkkt160 f32" "nlpkkt160 f64"; do timeout -k 10 300 python scripts/spmm_bench.py $a 1,2,4,8 2>/dev/null | grep "^{" > $out/spmm_$(echo $a | tr ' ' '_').json; cat $out/spmm_$(echo $a | tr ' ' '_').json | cut -c1-600; done
 for a in "laplacian4096 f32" "nlpkkt160 f32"; do TILESPMV_LIB_VARIANT=_nd timeout -k 10 300 python scripts/spmm_bench.py $a 8 2>/dev/null | grep "^{" > $out/spmm_nd_$(echo $a | tr ' ' '_').json; echo "no deferred store:"; cat $out/spmm_nd_$(echo $a | tr ' ' '_').json | cut -c1-400; done
 ( time timeout -k 10 900 python bench.py --steps 20 --warmup 5 > $out/bench_default.json 2> $out/bench_default.err ) 2> $out/bench_default.time; echo "bench rc=$?"; tail -3 $out/bench_default.time

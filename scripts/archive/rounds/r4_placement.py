@@ -1,6 +1,6 @@
 """Round 4, VERDICT item 5: the placement lottery of the KKT matrices.  N plans of one Tile_matrix built one after the other in ONE process (all alive at the
 same time, as round 3's probe had them), each timed; once without the placement retry (placement_tries=1) and once with the default (3 for plans >= 1 GB).
-python scripts/rounds/r4_placement.py [workload] [f32] [N]"""
+python scripts/archive/rounds/r4_placement.py [workload] [f32] [N]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,5 +1,5 @@
 """Placement retry policies on the KKT stand-in (fp64): N plans per setting in ONE process (three alive at a time), up to T placements each; what the retry kept, and after how many tries.
-python scripts/rounds/r4_placement_far.py   (FAR_SETTINGS="A=1,B=2;C=3" FAR_PLANS=6 FAR_TRIES=12)"""
+python scripts/archive/rounds/r4_placement_far.py   (FAR_SETTINGS="A=1,B=2;C=3" FAR_PLANS=6 FAR_TRIES=12)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

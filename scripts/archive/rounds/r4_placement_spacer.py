@@ -1,5 +1,5 @@
 """Does WHERE a plan's blocks land decide its state?  One Tile_matrix, plans built one after the other (each destroyed before the next), with an unused allocation of S MB in front of
-every arena block (TILESPMV_ARENA_SPACER_MB) and with different block sizes (TILESPMV_ARENA_MB): python scripts/rounds/r4_placement_spacer.py [workload] [f32]"""
+every arena block (TILESPMV_ARENA_SPACER_MB) and with different block sizes (TILESPMV_ARENA_MB): python scripts/archive/rounds/r4_placement_spacer.py [workload] [f32]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

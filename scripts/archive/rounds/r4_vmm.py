@@ -1,6 +1,6 @@
 """Round 4: does the physical chunking of a large plan's blocks decide its placement state?  Plans of one Tile_matrix, built one after the other in ONE process
 (three alive at a time), placement retry off; the blocks either plain hipMalloc or one virtual range mapped onto separately created physical chunks of 64 / 256 / 1024 MB
-(experiment knob TILESPMV_ARENA_VMM_MB).  python scripts/rounds/r4_vmm.py [workload] [f32] [N]"""
+(experiment knob TILESPMV_ARENA_VMM_MB).  python scripts/archive/rounds/r4_vmm.py [workload] [f32] [N]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

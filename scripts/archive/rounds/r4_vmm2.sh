@@ -8,6 +8,6 @@ timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "sur
 for wl in "nlpkkt160 10" "band40_2000000 6" "nlpkkt160 f32 6"; do
   for mb in 0 64; do
     echo "== $wl  TILESPMV_ARENA_VMM_MB=$mb"
-    TILESPMV_ARENA_VMM_MB=$mb timeout -k 10 500 python scripts/rounds/r4_placement.py $wl 2>&1 | grep -v amdgpu.ids | cut -c1-220
+    TILESPMV_ARENA_VMM_MB=$mb timeout -k 10 500 python scripts/archive/rounds/r4_placement.py $wl 2>&1 | grep -v amdgpu.ids | cut -c1-220
   done
 done

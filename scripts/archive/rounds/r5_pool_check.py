@@ -1,5 +1,5 @@
 """Round 5: pooled units (csr_split = 2) — whole-y exact check against scipy on small matrices in every entry mode, then timing of the FEM class split vs pooled.
-python scripts/rounds/r5_pool_check.py [check|time|all]"""
+python scripts/archive/rounds/r5_pool_check.py [check|time|all]"""
 import os, sys, time
 import numpy as np, scipy.sparse as sp, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,4 +1,4 @@
-"""Round 5: default-plan times of a few workloads, fp64 and fp32 (python scripts/rounds/r5_quick_time.py wl,wl [f64|f32|both])."""
+"""Round 5: default-plan times of a few workloads, fp64 and fp32 (python scripts/archive/rounds/r5_quick_time.py wl,wl [f64|f32|both])."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

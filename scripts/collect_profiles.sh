@@ -1,5 +1,5 @@
 #!/bin/bash
-# copies the judged summaries of scripts/rounds/r4_final.sh (gpurun_out/prof_<round>_<workload>_<dtype>/) into profiles/ under that round's names: scripts/collect_profiles.sh [r04]
+# copies the judged summaries of scripts/archive/rounds/r4_final.sh (gpurun_out/prof_<round>_<workload>_<dtype>/) into profiles/ under that round's names: scripts/collect_profiles.sh [r04]
 r=${1:-r04}
 for d in gpurun_out/prof_${r}_*; do
   [ -d "$d" ] || continue

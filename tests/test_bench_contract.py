@@ -164,7 +164,7 @@ def test_one_rank_through_the_launcher_equals_the_bare_run(tmp_path):
 
 def test_four_rank_rehearsal_over_gloo():
     """More than two ranks through the driver's command shape, all on device 0 over gloo (the GPU box lets 6 processes of one job use its card at once: this test process +
-    4 ranks stay below that; scripts/rounds/r4_rehearsal.sh runs 6 ranks bare): the plumbing of an 8-rank run — per-rank generation and preprocessing with a share of the host cores
+    4 ranks stay below that; scripts/archive/rounds/r4_rehearsal.sh runs 6 ranks bare): the plumbing of an 8-rank run — per-rank generation and preprocessing with a share of the host cores
     each, the three y combines with the neighbours' rows checked, max-over-ranks timing — before there is an 8-GPU node."""
     cmd = [sys.executable, "bench.py", "--gpus", "4", "--steps", "10", "--warmup", "3", "--backend", "gloo", "--workload", "laplacian1024"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}

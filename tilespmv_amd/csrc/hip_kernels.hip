@@ -990,7 +990,7 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
 // launch every gather of the chip falls into one panel.  The price is the read-modify-write of y per pass.  A piece of a split tile-row adds its sums to ITS slot of the
 // partial sums (nobody else writes that slot, and the passes are launches in stream order); launch_entry_panels runs k_fixup_split over all split rows behind the last pass, which
 // adds the slots up in slot order — so a panelled plan's sums are as reproducible as the plain launch's.  (Rounds 4-5 added the pieces into y atomically: on R-MAT 22 x 8, 4,048 split
-// rows, two runs of ONE plan differed in 5 k rows' last bits while the plan's facts said "ordered" — scripts/rounds/r5b_repro_check.py.)
+// rows, two runs of ONE plan differed in 5 k rows' last bits while the plan's facts said "ordered" — scripts/archive/rounds/r5b_repro_check.py.)
 // ------------------------------------------------------------------------------------------------
 template <bool NTS>
 __global__ __launch_bounds__(256, ECOO2_MIN_WAVES) void k_entries_acc(DevStream S, int rowA, int xcd_chunk, int panel, val_t *__restrict__ partial, const val_t *__restrict__ x, val_t *__restrict__ y)

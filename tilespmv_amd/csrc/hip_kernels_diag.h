@@ -1,6 +1,6 @@
 // hip_kernels_diag.h — TIMING-ONLY diagnostics of hip_kernels.hip.  Included only with -DTILESPMV_DIAG (make VARIANT=_name EXTRA_DEFS=...: the product libraries
 // never contain any of this).  Most of these variants return WRONG rows by construction — they exist to price one part of a kernel (scripts/ablate_entries.sh,
-// scripts/rounds/r4_slices*.sh, scripts/rounds/r5_pool_abl.sh, scripts/stamps_probe.py, scripts/rounds/r4_gather_policy.sh).  Every macro names the locals of the function it is used in.
+// scripts/archive/rounds/r4_slices*.sh, scripts/archive/rounds/r5_pool_abl.sh, scripts/stamps_probe.py, scripts/archive/rounds/r4_gather_policy.sh).  Every macro names the locals of the function it is used in.
 #pragma once
 
 // ---- cache policy of the scattered x gathers of the workgroup entry phase: TILESPMV_GATHER_POLICY 0 default, 1 nontemporal, 2 agent scope (sc1), 3 system scope (sc0 sc1)

@@ -270,7 +270,7 @@ void StreamBuilder::count()
         }
         const long long xy_b = ((long long)colA + 16LL * ntr) * sv;   // x once, y once: part of what either form moves
         const long long split_b = u1 * (desc_split + 16LL * sv) + e1 * (sv + 5LL) + xy_b, pooled_b = u2 * (20 + 16LL * sv) + e2 * (sv + 5LL) + xy_b;
-        // Calibrated on the population (scripts/rounds/r5_form_study.py, profiles/r05_form_study.txt): the pooled kernel's time follows its bytes with about 8 % on top of the
+        // Calibrated on the population (scripts/archive/rounds/r5_form_study.py, profiles/r05_form_study.txt): the pooled kernel's time follows its bytes with about 8 % on top of the
         // classic kernel's at equal bytes, so it is taken where one SpMV moves at least 5 % fewer bytes — and only where units carry the shard (an entry-dominated shard
         // lives in its entry lists) and the shard would not get column panels (scattered entries over an x of >= 12 MB: the panel / slice launches exist for the
         // classic kernel; band + random fill loses 23 % without them)

@@ -68,7 +68,7 @@ inline T *zalloc(size_t n)
     if (!p) { fprintf(stderr, "tilespmv: out of host memory (%zu x %zu bytes)\n", n, sizeof(T)); exit(2); }
     // Large arrays: ask for transparent huge pages (round 5; what numpy does for its own large arrays).  A calloc of this size is a fresh anonymous mapping that is zeroed page
     // by page at first touch: the per-tile arrays of config 4's Tile_matrix (1.5 GB) and the plan builder's staging arrays cost 4-KB page faults by the hundred thousand — on the
-    // GPU box's host 2/3 of Tile_create's time and 1/3 of plan creation's (config 4: 0.26 -> 0.08-0.14 s and 0.31 -> 0.19 s, scripts/rounds/r5_hugepages.sh); with THP in
+    // GPU box's host 2/3 of Tile_create's time and 1/3 of plan creation's (config 4: 0.26 -> 0.08-0.14 s and 0.31 -> 0.19 s, scripts/archive/rounds/r5_hugepages.sh); with THP in
     // "madvise" mode (this image) the advice turns them into 2-MB faults.  Still plain malloc memory: the caller frees it with free() as the reference's API requires.
     // TILESPMV_HUGEPAGES=0 switches the advice off (a host whose memory is too fragmented to have huge pages at hand compacts synchronously inside such a fault).
     static const bool thp = [] { const char *e = getenv("TILESPMV_HUGEPAGES"); return !(e && *e && atoi(e) == 0); }();
