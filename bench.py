@@ -319,9 +319,9 @@ def compact_line(out, full_path):
     rf, cb = out["roofline"], out.get("cpu_baseline")
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     cfg = out["config"]
-    line["config"] = {k: cfg[k] for k in ("workload", "source", "rows", "cols", "nnz", "partition", "y_combine", "tiles") if k in cfg}
+    line["config"] = {k: cfg[k] for k in ("workload", "source", "rows", "cols", "nnz", "partition", "y_combine", "tiles", "x_panel_merge", "x_slice_passes") if k in cfg}
     line["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_min_bytes", "kernel", "kernel_ms", "algorithmic_bytes_per_launch",
-                                               "min_bytes_per_launch", "plan_stream_bytes_per_launch", "actual_traffic_gbps")}
+                                               "min_bytes_per_launch", "plan_stream_bytes_per_launch", "actual_traffic_gbps", "plan_fingerprint")}   # (plan_fingerprint: what scripts/traffic_json.py ties a counter pass to)
     line["roofline"]["traffic_from"] = (rf.get("traffic_source") or {}).get("file")
     line["roofline"]["timing"] = "hip events, launch stream, the K timed steps"
     if cb:
