@@ -624,9 +624,8 @@ def test_inline_fixup_of_split_rows_is_stable_across_launches(torch_cuda, monkey
 def test_every_plan_kind_survives_being_moved(torch_cuda, monkeypatch, dtype):
     """The placement retry moves a plan to freshly allocated blocks and rebases its device pointers; a pointer it misses dangles once the old blocks are freed (round 4: the
     column-panel offsets did, and the GPU suite aborted in the one run in which the timing happened to keep a moved placement).  TILESPMV_PLACEMENT_FORCE=1 keeps the LAST
-    placement always: every plan kind — panels, pacing, x windows, dictionary / 12-B descriptors, CSR fallback, first-generation kernel, whole CSR tiles, dense tiles on the
-    matrix cores, split rows — is moved twice and must still give the oracle's y, SpMM included; half of them with their blocks as virtual ranges over
-    separately created physical chunks (hipMemCreate / hipMemMap: opt-in, TILESPMV_ARENA_VMM_MB — off by default)."""
+    placement always: every plan kind — panels, brick order, dictionary / 12-B descriptors, CSR fallback, first-generation kernel, whole CSR tiles, dense tiles on the
+    matrix cores, split rows, pooled units — is moved twice and must still give the oracle's y, SpMM included."""
     from oracle.oracle import CpuImpl
     from tilespmv_amd import api, generators as G
     monkeypatch.setenv("TILESPMV_PLACEMENT_FORCE", "1")
@@ -644,13 +643,9 @@ def test_every_plan_kind_survives_being_moved(torch_cuda, monkeypatch, dtype):
         want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, x)["y"]
         tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=True)
         for i, kw in enumerate(knob_sets):
-            # every other set with blocks of more than 1 MB as virtual ranges over separately created physical chunks (the large-plan default at 64 MB): allocated, moved, freed
-            if i % 2: monkeypatch.setenv("TILESPMV_ARENA_VMM_MB", "1")
-            else: monkeypatch.delenv("TILESPMV_ARENA_VMM_MB", raising=False)
             y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, placement_tries=3, **kw)
             assert info["placement_tries"] == 3, (name, kw)
             assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
-        monkeypatch.setenv("TILESPMV_ARENA_VMM_MB", "1")
         plan = api.Plan(tp, rowA, n, nnz, placement_tries=2)
         X = (np.arange(n * 4, dtype=np.int64) % 5).astype(dtype).reshape(n, 4)
         Xd = torch_cuda.from_numpy(X).cuda(); Yd = torch_cuda.zeros((rowA + 16, 4), dtype=Xd.dtype, device="cuda")
@@ -659,13 +654,12 @@ def test_every_plan_kind_survives_being_moved(torch_cuda, monkeypatch, dtype):
             wj = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=True), rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"]
             assert np.array_equal(Yd.cpu().numpy()[:rowA, j], wj), (name, "spmm on a moved plan", j)
         plan.close()
-        monkeypatch.delenv("TILESPMV_ARENA_VMM_MB", raising=False)
         api.Tile_destroy(tp)
 
 
-def test_tile_row_shards_with_panels_and_pacing(torch_cuda):
-    """Tile-row shards (what one rank of a multi-GPU run owns) of a panelled / paced plan write exactly their rows of the full-length y: three shards with uneven cuts, columns not a
-    multiple of 16, panelled, paced and sliced (column slices on XCDs: atomic adds into the shard's rows only) launches; the union is the oracle's y and nothing outside a shard's rows is touched."""
+def test_tile_row_shards_with_panels_and_slices(torch_cuda):
+    """Tile-row shards (what one rank of a multi-GPU run owns) of a panelled / sliced plan write exactly their rows of the full-length y: three shards with uneven cuts, columns not a
+    multiple of 16, panelled and sliced (column slices on XCDs: atomic adds into the shard's rows only) launches; the union is the oracle's y and nothing outside a shard's rows is touched."""
     from oracle.oracle import CpuImpl
     from tilespmv_amd import api, generators as G
     O = CpuImpl("oracle", np.float64)

@@ -237,7 +237,6 @@ void tilespmv_plan_destroy(tilespmv_plan *plan)
 {
     if (!plan) return;
     for (void *p : plan->allocs) (void)hipFree(p);
-    plan->vmm_free_all();
     delete plan;
 }
 
@@ -518,7 +517,6 @@ static int plan_create_one(tilespmv_plan **out, const Tile_matrix *T, int rowA, 
     if (const char *as = getenv("TILESPMV_ARENA_SKEW")) plan->arena_skew = (size_t)std::max(0ll, atoll(as)) / 256 * 256;
     if (const char *sp = getenv("TILESPMV_ARENA_SPACER_MB")) plan->arena_spacer = (size_t)std::max(0ll, atoll(sp)) << 20;
     plan->arena_spacer_first_only = env_int("TILESPMV_ARENA_SPACER_FIRST", 0) != 0;
-    if (const char *av = getenv("TILESPMV_ARENA_VMM_MB")) plan->arena_vmm_chunk = (size_t)std::max(0, atoi(av)) << 20;
     if (const char *ab = getenv("TILESPMV_ARENA_MB")) plan->arena_block = (size_t)std::max(0, atoi(ab)) << 20;   // (experiment knob; 0 = one hipMalloc per stream)
     if (!K.dry && hipGetDevice(&plan->device) != hipSuccess) { fprintf(stderr, "tilespmv: hipGetDevice failed\n"); delete plan; return -1; }
 

@@ -101,67 +101,15 @@ struct tilespmv_plan {
     int wg_strips = 16;                 // strips per workgroup of the unit kernel (32 only with the workgroup entry mode)
     int lds_pad_bytes = 0;              // extra (unused) dynamic LDS per workgroup of the unit kernel: caps the workgroups resident on a CU (knob lds_pad)
     int arena_flags = 0; size_t arena_skew = 0, arena_spacer = 0; bool arena_spacer_first_only = false;
-    // Physical backing of large blocks (round 4; opt-in, TILESPMV_ARENA_VMM_MB = chunk size): a block larger than arena_vmm_chunk bytes is ONE virtual range
-    // mapped onto separately created physical chunks of that size (hipMemAddressReserve / hipMemCreate / hipMemMap) instead of one hipMalloc.  Where a GB-sized plan lands
-    // decides between states up to 13 % apart on the KKT matrices; chunks of 16-64 MB come from elsewhere in the card's memory and changed the state for the better in two of
-    // four sessions, not at all in the other two (profiles/r04_placement_retry.txt) — hence not the default.  Falls back to hipMalloc when the driver refuses any step.
-    struct VmmRange { void *ptr; size_t size; std::vector<hipMemGenericAllocationHandle_t> handles; };
-    std::vector<VmmRange> vmm;
-    size_t arena_vmm_chunk = 0;   // off by default (TILESPMV_ARENA_VMM_MB): it helped in two of four sessions and changed nothing in the others
-    void vmm_release(VmmRange &R)
-    {
-        // The physical chunks go back; the virtual range stays reserved for the life of the process, on purpose: on this driver (ROCm 7.2) a range that is freed and handed
-        // out again by the next hipMemAddressReserve can still translate to the OLD physical pages — scripts/micro/vmm_probe.hip: 54 of 60 reservations got the same address back
-        // and 1.8 M of 3.6 M copied words read back wrong; with the ranges kept, none.  (That is what made small test plans with chunked blocks give wrong rows and fault.)
-        // Address space is the only cost: 47 bits hold tens of thousands of multi-GB plans.
-        if (R.ptr) { (void)hipMemUnmap(R.ptr, R.size); }
-        for (auto h : R.handles) (void)hipMemRelease(h);
-        R.ptr = nullptr; R.handles.clear();
-    }
-    int vmm_alloc(void **out, size_t bytes)
-    {
-        hipMemAllocationProp prop{};
-        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
-        size_t gran = 0;
-        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) { (void)hipGetLastError(); return -1; }
-        const size_t chunk = (arena_vmm_chunk + gran - 1) / gran * gran, total = (bytes + gran - 1) / gran * gran;
-        void *base = nullptr;
-        if (hipMemAddressReserve(&base, total, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
-        VmmRange R{base, total, {}};
-        bool ok = true;
-        size_t mapped = 0;
-        for (size_t off = 0; off < total && ok; off += chunk) {
-            const size_t sz = std::min(chunk, total - off);
-            hipMemGenericAllocationHandle_t h;
-            if (hipMemCreate(&h, sz, &prop, 0) != hipSuccess) { ok = false; break; }
-            R.handles.push_back(h);
-            if (hipMemMap((char *)base + off, sz, 0, h, 0) != hipSuccess) { ok = false; break; }
-            mapped = off + sz;
-        }
-        hipMemAccessDesc acc{};
-        acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
-        if (ok && hipMemSetAccess(base, total, &acc, 1) != hipSuccess) ok = false;
-        if (!ok) {   // undo what was done; the caller falls back to hipMalloc
-            (void)hipGetLastError();
-            if (mapped) (void)hipMemUnmap(base, mapped);
-            for (auto h : R.handles) (void)hipMemRelease(h);
-            return -1;   // (the reserved range is not freed: see vmm_release)
-        }
-        vmm.push_back(R);
-        *out = base;
-        return 0;
-    }
-    // a block of the arena (or a candidate placement of one): chunked physical backing when large, hipMalloc otherwise; the plan owns it until block_free / destroy
+    // (Round 4's opt-in chunked physical backing of large blocks — hipMemAddressReserve / hipMemCreate / hipMemMap, TILESPMV_ARENA_VMM_MB — changed the placement state for the better in two of
+    // four sessions and had to keep its virtual ranges reserved for the life of the process because of stale translations on re-reserved ranges (LABBOOK S6.19, scripts/micro/vmm_probe.hip): retired in round 6.)
+    // a block of the arena (or a candidate placement of one); the plan owns it until block_free / destroy
     int block_alloc(void **out, size_t bytes, bool quiet = false)
     {
         // A block starts out as zeros, explicitly: the kernels read a little past the end of some streams (a strip's last descriptor chunk, masked tail lanes — the 256 bytes of
         // slack behind every stream are there for that) and what they find must decode to "nothing" (unit 0, offset 0).  hipMalloc happens to hand out zeroed memory;
-        // hipMemCreate does not (found the hard way: stale descriptors behind the last strip sent a value prefetch to a wild address).
+        // other allocators do not (found the hard way: stale descriptors behind the last strip sent a value prefetch to a wild address).
         *out = nullptr;
-        if (arena_vmm_chunk && bytes > arena_vmm_chunk && vmm_alloc(out, bytes) == 0) {
-            if (hipMemset(*out, 0, bytes) == hipSuccess) return 0;
-            (void)hipGetLastError(); block_free(*out); *out = nullptr;
-        }
         hipError_t e = arena_flags ? hipExtMallocWithFlags(out, bytes, (unsigned)arena_flags) : hipMalloc(out, bytes);   // experiment knob TILESPMV_ARENA_FLAGS (4 = physically contiguous)
         if (e == hipSuccess) e = hipMemset(*out, 0, bytes);
         if (e != hipSuccess) {
@@ -178,16 +126,9 @@ struct tilespmv_plan {
     }
     void block_free(void *p)
     {
-        for (size_t i = 0; i < vmm.size(); i++)
-            if (vmm[i].ptr == p) { vmm_release(vmm[i]); vmm.erase(vmm.begin() + (long)i); return; }
         (void)hipFree(p);
         auto it = std::find(allocs.begin(), allocs.end(), p);
         if (it != allocs.end()) allocs.erase(it);
-    }
-    void vmm_free_all()
-    {
-        for (VmmRange &R : vmm) vmm_release(R);
-        vmm.clear();
     }
     size_t arena_used = 0;              // bytes handed out by upload() so far
     char *arena_at = nullptr; size_t arena_left = 0, arena_block = (size_t)256 << 20, arena_next = (size_t)1 << 20, size_hint = 0;   // bump allocator of upload(); size_hint = the builder's estimate of the plan's bytes
