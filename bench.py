@@ -982,12 +982,12 @@ def main():
         built.clear()
         out["other_workloads_seconds"] = round(time.time() - t_extras, 1)
         # ---- the population (round 5): the committed sweep of 26 generated structures >= 10 M nnz in the class mix of the reference's >= 10 M-nnz matrices
-        # (scripts/population_sweep.py -> profiles/r05_population.json: its summary is quoted here), and six of them measured LIVE in this run with the same routine
+        # (scripts/population_sweep.py -> profiles/r06_population.json: its summary is quoted here), and six of them measured LIVE in this run with the same routine
         try:
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             import population_sweep as PS
             pop = {"what": "default plans over a population of generated structures (reference's method is a sweep: src/external/CSR5_cuda/bench0.sh:1-14); frac = B_alg / t / 8 TB/s"}
-            pj = os.path.join(ROOT, "profiles", "r05_population.json")
+            pj = os.path.join(ROOT, "profiles", "r06_population.json")
             if os.path.exists(pj):
                 pjd = json.load(open(pj))
                 pop["committed_sweep"] = dict(pjd["summary"], file=os.path.relpath(pj, ROOT), measured=pjd.get("measured"), live=False)

@@ -99,7 +99,7 @@ def summarise(recs):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_population.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_population.json"))
     ap.add_argument("--only", default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     a = ap.parse_args()
