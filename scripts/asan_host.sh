@@ -5,7 +5,7 @@ set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=/tmp/tilespmv_asan; mkdir -p $out
 cd $root/tilespmv_amd/csrc
-for f in host_tile_create host_tilespmv_cpu host_mmio host_matrix_io; do
+for f in host_tile_create host_tilespmv_cpu host_mmio host_matrix_io host_reorder; do
   g++ -O1 -g -fPIC -std=c++17 -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -DMAT_VAL_TYPE=double -c $f.cpp -o $out/$f.o
 done
 # the plan layout builder, host-only (plain g++; libamdhip64 only satisfies the linker: tilespmv_plan_layout_digest makes no HIP call)

@@ -110,4 +110,22 @@ for f in ('trunc', 'short', 'junk'):
     mm, nn_, zz, ss = C.c_int(), C.c_int(), C.c_int(), C.c_int(); rpp, cii = I(), I(); vv = D()
     rc = lib.mmio_allinone(C.byref(mm), C.byref(nn_), C.byref(zz), C.byref(ss), C.byref(rpp), C.byref(cii), C.byref(vv), ('/tmp/tilespmv_asan/%s.mtx' % f).encode())
     print(f, rc, flush=True)
+# round 6: reverse Cuthill-McKee + CSR permutation (host_reorder.cpp) — meshes, a graph with hubs, isolated rows, a rectangular [own | halo] block, bad permutations
+lib.tilespmv_reorder_rcm.argtypes = [C.c_int, I, I, I]
+lib.tilespmv_csr_permute.argtypes = [C.c_int, I, I, D, I, I, I, D]
+lib.tilespmv_csr_bandwidth.argtypes = [C.c_int, I, I]; lib.tilespmv_csr_bandwidth.restype = C.c_longlong
+for gen in (lambda: G.tri_mesh(40, 40, shuffle=128), lambda: G.tet_mesh(10, shuffle=64), lambda: G.powerlaw(4000, seed=2), lambda: G.laplacian5pt(3)):
+    m, n, rp, ci = gen()
+    k = min(m, n)
+    rp = np.ascontiguousarray(rp[:k + 1], dtype=np.int32); ci = np.ascontiguousarray(ci[:int(rp[k])], dtype=np.int32)   # (columns >= k: the halo part of a rank's index space)
+    v = np.arange(len(ci), dtype=np.float64)
+    perm = np.zeros(max(k, 1), dtype=np.int32)
+    assert lib.tilespmv_reorder_rcm(k, p(rp, C.c_int), p(ci, C.c_int), p(perm, C.c_int)) == 0 and sorted(perm[:k].tolist()) == list(range(k))
+    orp, oci, ov = np.zeros(k + 1, dtype=np.int32), np.zeros(max(len(ci), 1), dtype=np.int32), np.zeros(max(len(ci), 1))
+    assert lib.tilespmv_csr_permute(k, p(rp, C.c_int), p(ci, C.c_int), p(v, C.c_double), p(perm, C.c_int), p(orp, C.c_int), p(oci, C.c_int), p(ov, C.c_double)) == 0
+    assert int(orp[k]) == len(ci) and lib.tilespmv_csr_bandwidth(k, p(orp, C.c_int), p(oci, C.c_int)) >= 0
+    bad = perm.copy(); bad[0] = bad[-1]
+    assert k < 2 or lib.tilespmv_csr_permute(k, p(rp, C.c_int), p(ci, C.c_int), p(v, C.c_double), p(bad, C.c_int), p(orp, C.c_int), p(oci, C.c_int), p(ov, C.c_double)) != 0
+assert lib.tilespmv_reorder_rcm(0, None, None, None) == 0
+print("reorder ok", flush=True)
 print("DONE")
