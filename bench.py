@@ -12,6 +12,7 @@ Workloads (synthetic stand-ins unless $TILESPMV_MATRIX_DIR/<name>.mtx exists; SU
                  the >= 10 M-nnz fp64 case the roofline target is quoted on, fits one GPU)
   scircuit       circuit-like, 170,998 rows, 958,936 nnz (config 2)   webbase   power-law, 1,000,005 rows, 3,105,536 nnz (config 3)
   nlpkkt160      KKT-like, 8,345,600 rows, 229,518,112 nnz, fp32 by default (config 5)
+  path/to/A.mtx  any Matrix Market file (e.g. a SuiteSparse download), through the product's reader
 Multi-GPU: contiguous nnz-balanced tile-row blocks, one rank per GPU, x replicated, y left
 sharded (the SpMV needs no collective: SURVEY.md §8e) => "scaling": "strong" on the fixed matrix;
 --combine allgather|allreduce adds the RCCL y combine to every step, --combine halo runs the sharded-x form
@@ -38,6 +39,13 @@ SCATTERED_GATHER_CEILING = 59.4e9  # scattered 8-byte gathers per second this ch
 
 def build_matrix(name, cache_dir=None):
     from tilespmv_amd import api, generators as G
+    if name.endswith(".mtx"):   # any Matrix Market file (a SuiteSparse download): --workload path/to/A.mtx — parsed by the product's reader (file order, symmetric entries mirrored: src/mmio_highlevel.h:593-759), cached when --cache is given
+        if not os.path.exists(name):
+            raise SystemExit("bench.py: no such file: " + name)
+        cache = os.path.join(cache_dir, os.path.basename(name)[:-4] + ".csr_f64") if cache_dir else None
+        r = api.mmio_allinone(name, cache=cache)
+        how = "" if cache is None else (" (CSR cache hit)" if r.get("from_cache") == 1 else " (parsed; CSR cache written)")
+        return r["m"], r["n"], r["rowptr"], r["colidx"], "file:" + os.path.basename(name) + how
     d = os.environ.get("TILESPMV_MATRIX_DIR")
     real = {"laplacian4096": None, "scircuit": "scircuit", "webbase": "webbase-1M", "nlpkkt160": "nlpkkt160"}.get(name)
     if d and real and os.path.exists(os.path.join(d, real + ".mtx")):

@@ -374,6 +374,35 @@ def test_matrix_dir_hook_with_a_generated_file(torch_cuda, tmp_path, monkeypatch
     test_real_matrix_files_through_cli_and_plan(torch_cuda, tmp_path)
 
 
+def test_bench_takes_any_mtx_file(torch_cuda, tmp_path):
+    """`bench.py --workload path/to/A.mtx` (a SuiteSparse download, round 6): the file goes through the product's reader (symmetric banner: entries mirrored), the CSR cache, Tile_create,
+    the plan and the whole-y check; the line names the file.  Written here: a symmetric pattern file (lower triangle only) and a general real file."""
+    import json, subprocess, sys
+    import scipy.sparse as sp
+    from tilespmv_amd import generators as G
+    m, n, rp, ci = G.tri_mesh(120, 120, shuffle=64)
+    A = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(m, n))
+    L = sp.tril(A).tocoo()
+    sym = tmp_path / "mesh_sym.mtx"
+    with open(sym, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate pattern symmetric\n")
+        f.write("%d %d %d\n" % (m, n, L.nnz))
+        for i, j in zip(L.row, L.col):
+            f.write("%d %d\n" % (i + 1, j + 1))
+    gen = tmp_path / "circuit_gen.mtx"
+    m2, n2, rp2, ci2 = G.circuit_like(6000, seed=5)
+    G.write_mtx(str(gen), m2, n2, rp2, ci2)
+    for path, rows, nnz in ((sym, m, A.nnz), (gen, m2, len(ci2))):
+        for rep in range(2):     # second run: CSR cache hit
+            r = subprocess.run([sys.executable, "bench.py", "--workload", str(path), "--steps", "10", "--warmup", "3", "--no-extras", "--no-cpu-baseline", "--cache", str(tmp_path / "cache"),
+                                "--full-json", str(tmp_path / "full.json")], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            assert line["config"]["source"].startswith("file:" + path.name) and line["check"].startswith("pass") and line["value"] > 0
+            assert ("cache hit" in line["config"]["source"]) == (rep == 1)
+            assert line["config"]["nnz"] == int(sp.csr_matrix((np.ones(nnz), (ci if path == sym else ci2), (rp if path == sym else rp2)), shape=(rows, rows))[: (rows // 16) * 16].nnz)
+
+
 def test_auto_rules_pick_what_was_measured(torch_cuda):
     """The AUTO choices that round 2's sweep over unseen matrices corrected stay put: with the unit-stream
     kernel COO entries always run in-tile (also on uniform random matrices, where the old byte model chose the fallback); the
