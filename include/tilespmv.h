@@ -503,7 +503,8 @@ int tilespmv_sizeof_value(void);    /* 8 or 4 */
  * For callers that STAY in the permuted numbering — a solver: x is permuted once at entry, K products run on plan-ordered vectors, y is un-permuted once at exit
  * (tilespmv_amd/halo.py HaloSpMV(reorder=True) / cg).  Around ONE product the two permutations cost what the better numbering saves (profiles/r05_rcm_probe.txt).
  *   tilespmv_reorder_rcm   reverse Cuthill-McKee on the symmetrised pattern of the leading n x n block (host, deterministic; perm[new] = old)
- *   tilespmv_csr_permute   B = P A P^T; columns >= n (a rank's halo columns) stay; the entries of a row keep their order; val / out_val may be NULL
+ *   tilespmv_csr_permute   B = P A P^T; columns >= n (a rank's halo columns) stay; every row of B comes out in ascending column order (the reference's dense-row / dense-col
+ *                          tiles assume that: src/csr2tile.h:586,600-605); val / out_val may be NULL
  *   tilespmv_permute_vector  device: scatter = 0: out[i] = in[perm[i]] (into plan order), scatter = 1: out[perm[i]] = in[i] (back); asynchronous on `stream`
  * The plan of B is created like any other (Tile_create + tilespmv_plan_create, or tilespmv_plan_create_from_csr). */
 int tilespmv_reorder_rcm(int n, const MAT_PTR_TYPE *csrRowPtr, const int *csrColIdx, int *perm /* [n] */);

@@ -26,7 +26,8 @@ def _square(gen):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("name,gen", [("tri300s1024", lambda: G.tri_mesh(300, 300, shuffle=1024)), ("tet40s256", lambda: G.tet_mesh(40, shuffle=256)),
-                                      ("fem3s64_16", lambda: G.fem_hex(16, 16, 16, 3, shuffle=64)), ("bandrand40k", lambda: G.band_plus_random(40000, 4, 3, 5))])
+                                      ("fem3s64_16", lambda: G.fem_hex(16, 16, 16, 3, shuffle=64)), ("bandrand40k", lambda: G.band_plus_random(40000, 4, 3, 5)),
+                                      ("fem6s16_12 (dense-row / dense-col tiles)", lambda: G.fem_hex(12, 12, 12, 6, shuffle=16))])
 def test_plan_of_the_permuted_matrix_bit_exact(torch_cuda, name, gen, dtype):
     from oracle.oracle import CpuImpl
     torch = torch_cuda

@@ -43,7 +43,7 @@ def _blocks():
     return A.shape[0], A.shape[1], A.indptr.astype(np.int32), A.indices.astype(np.int32)
 
 
-def test_permute_keeps_halo_columns_and_entry_order_and_refuses_non_permutations():
+def test_permute_keeps_halo_columns_sorts_rows_and_refuses_non_permutations():
     # a rank's [own | halo] index space: 4 own rows / columns, halo columns 4 .. 6
     rp = np.array([0, 3, 5, 7, 9], dtype=np.int32)
     ci = np.array([2, 0, 5, 1, 6, 3, 2, 4, 0], dtype=np.int32)
@@ -52,10 +52,35 @@ def test_permute_keeps_halo_columns_and_entry_order_and_refuses_non_permutations
     brp, bci, bv = api.csr_permute(4, rp, ci, v, perm)
     inv = np.argsort(perm)
     assert brp.tolist() == [0, 2, 5, 7, 9]
-    assert bci.tolist() == [int(inv[3]), int(inv[2]), int(inv[2]), int(inv[0]), 5, 4, int(inv[0]), int(inv[1]), 6]   # rows 2, 0, 3, 1; columns < 4 mapped, halo columns kept, order kept
-    assert bv.tolist() == [6, 7, 1, 2, 3, 8, 9, 4, 5]
+    # rows 2, 0, 3, 1 of A; columns < 4 mapped through inv, halo columns (>= 4) kept; every row ascending by new column, values with their entries
+    want = [sorted([(int(inv[3]), 6.0), (int(inv[2]), 7.0)]), sorted([(int(inv[2]), 1.0), (int(inv[0]), 2.0), (5, 3.0)]), sorted([(4, 8.0), (int(inv[0]), 9.0)]), sorted([(int(inv[1]), 4.0), (6, 5.0)])]
+    assert bci.tolist() == [c for row in want for c, _ in row] and bv.tolist() == [v for row in want for _, v in row]
     with pytest.raises(ValueError):
         api.csr_permute(4, rp, ci, v, np.array([0, 0, 1, 2], dtype=np.int32))
+
+
+def test_permuted_rows_ascend_so_that_dense_row_and_dense_col_tiles_stay_valid():
+    """A 6-dof hex mesh is full of dense-row / dense-col tiles, whose packing takes the columns of a row to ascend (src/csr2tile.h:586,600-605 vs src/tilespmv_cpu.h:246,262).
+    A first version of tilespmv_csr_permute kept A's entry order mapped through the permutation: the reference's own CPU tile path then returned 4,221 wrong rows on
+    fem6s16_40.  Rows of B ascend; the tile path on B is exact."""
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd.tile_matrix import to_dict
+    m, n, rp, ci = G.fem_hex(9, 9, 9, 6, shuffle=16)
+    rows = (m // 16) * 16
+    A = sp.csr_matrix((np.ones(int(rp[rows])), ci[:int(rp[rows])], rp[:rows + 1]), shape=(rows, n))[:, :rows].tocsr()
+    rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    vals, x = G.compat_values(len(ci)), G.compat_x(rows)
+    perm = api.reorder_rcm(rows, rp, ci)
+    brp, bci, bv = api.csr_permute(rows, rp, ci, vals, perm)
+    assert all(np.all(np.diff(bci[brp[i]:brp[i + 1]]) > 0) for i in range(rows))
+    O = CpuImpl("oracle")
+    y = O.csr_spmv(rows, rp, ci, vals, x)
+    tm = api.Tile_create(rows, rows, len(bci), brp, bci, bv)
+    fmt = np.bincount(to_dict(tm, rows)["Format"], minlength=7)
+    assert fmt[5] > 0 and fmt[6] > 0            # dense-row and dense-col tiles are there
+    r = api.tilespmv_cpu(tm, rows, rows, len(bci), brp, bci, bv, np.ascontiguousarray(x[perm]), O.csr_spmv(rows, brp, bci, bv, np.ascontiguousarray(x[perm])))
+    api.Tile_destroy(tm)
+    assert r["errcount"] == 0 and np.array_equal(r["y"][:rows], y[perm])
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

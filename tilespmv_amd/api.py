@@ -189,7 +189,7 @@ def reorder_rcm(n, rowptr, colidx, dtype=np.float64):
 
 
 def csr_permute(n, rowptr, colidx, vals, perm, dtype=None):
-    """``B = P A P^T`` for ``perm[new] = old`` (tilespmv_csr_permute): rows and the columns < n are renumbered, columns >= n (halo) stay, entries of a row keep their order."""
+    """``B = P A P^T`` for ``perm[new] = old`` (tilespmv_csr_permute): rows and the columns < n are renumbered, columns >= n (halo) stay, every row comes out in ascending column order."""
     dtype = np.dtype(dtype if dtype is not None else np.asarray(vals).dtype)
     lib = _lib.load(dtype)
     rp, ci, v = _csr(lib, rowptr, colidx, vals)
