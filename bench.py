@@ -496,6 +496,7 @@ def main():
     ap.add_argument("--phase-timeout-scale", type=float, default=1.0, help="multiplies the hard per-phase limits (init 300 s, prepare 900 s, check 300 s, timed 300 s, each combine 300 s, extras 1500 s, cpu baseline 600 s)")
     args = ap.parse_args()
     phase.scale = args.phase_timeout_scale
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before anything touches the GPU: this pool's host driver only supports dmabuf IPC (RCCL fails with hipIpcGetMemHandle: invalid argument without it)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
 
@@ -518,7 +519,6 @@ def main():
     rccl_version = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's host driver only supports dmabuf IPC (RCCL fails with hipIpcGetMemHandle: invalid argument without it)
         with phase("init_process_group", 300):
             if args.backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
