@@ -298,7 +298,9 @@ typedef struct {
     int y_store;        /* y stores: 1 streaming (nontemporal), 0 plain; unset: streaming where y is >= 5 % of the launch's bytes  TILESPMV_Y_STORE */
     int desc_dict;      /* unit descriptors: unset = 4 B per unit + a dictionary of column patterns where the shard's units use few distinct
                            patterns AND the 8 bytes per unit are >= 2 % of the streams (stencil-like shards); 1 = wherever the patterns
-                           are few; 0 = always the 12-B form                                                                   TILESPMV_DESC_DICT */
+                           are few; 0 = always the 12-B form.  Pooled plans (csr_split 2): any value but 0 = pattern dictionary where the patterns are few, as ONE
+                           4-byte word per unit where window base, pattern id and tile-row fit it (round 6), else as 8-byte pairs; 2 = always pairs;
+                           0 = the 20-byte form                                                                                 TILESPMV_DESC_DICT */
     int nt_stream;      /* value / entry-record / dense-tile loads: 1 nontemporal, 0 default cache policy; unset: nontemporal where one SpMV moves more
                            than 400 MB (about 1.6 x the Infinity Cache)                                                             TILESPMV_NT_STREAM */
     int x_panel_kb;     /* column panels (round 4): the merged entry lists of the workgroup entry mode are in column order, so the entries of a column panel (this many

@@ -183,7 +183,7 @@ def test_fem_class_default_plans_full_size(torch_cuda, workload, dtype):
         plan = api.Plan(tp, rowA, n, nnz, **kw)
         info = plan.info()
         # natural-order meshes: 16-column pooled units, a few dozen patterns -> 8-byte descriptors + dictionary; the window-shuffled one: wide pooled units (256-column windows, 28-byte descriptors)
-        assert (info["csr_form"], info["desc_bytes"]) == ((3, 28) if workload == "fem3s64_68" else (2, 8)), (workload, info)
+        assert (info["csr_form"], info["desc_bytes"]) == ((3, 28) if workload == "fem3s64_68" else (2, 4)), (workload, info)
         if dtype == np.float64 and workload != "fem3s64_68":
             assert info["stream_bytes"] <= 0.82 * api.algorithmic_bytes(nnz, rowA, n, 8), (workload, info["stream_bytes"])
         ys = []

@@ -94,7 +94,7 @@ def test_device_tile_create_large_classes():
 KNOB_SETS = [dict(), dict(deterministic=1), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2), dict(csr_split=1), dict(csr_split=2), dict(csr_split=2, entry_mode=2),
              dict(dense_mode=1), dict(dense_mode=2), dict(strip_cost=64, split_above=200), dict(csr_split=2, strip_cost=64, split_above=128, dense_mode=1), dict(x_window=2), dict(desc_dict=0),
              dict(desc_dict=1), dict(x_panel_kb=1, x_panel_merge=1, entry_mode=2), dict(wg_strips=32, entry_mode=2), dict(csr_split=3), dict(csr_split=3, entry_mode=2),
-             dict(csr_split=3, strip_cost=64, split_above=128, dense_mode=1), dict(csr_split=2, desc_dict=0)]
+             dict(csr_split=3, strip_cost=64, split_above=128, dense_mode=1), dict(csr_split=2, desc_dict=0), dict(csr_split=2, desc_dict=2)]
 FACTS = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel", "num_tasks", "num_split_rows", "entry_mode", "entry_ordered", "strip_cost", "wg_strips", "brick_order",
          "desc_bytes", "nt_stream", "x_panels", "scattered_entries", "csr_form"]
 

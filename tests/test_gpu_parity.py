@@ -904,7 +904,7 @@ def test_plan_knobs_through_options_bit_exact(torch_cuda, dtype):
             desc[info["desc_bytes"]] += 1
             assert info["nt_stream"] == (1 if kw.get("nt_stream") == 1 and info["entry_mode"] != 1 else 0)   # (small test matrices: off by rule)
             assert info["desc_bytes"] == 12 or (info["desc_bytes"] == 20 and info["csr_form"] == 2) or kw.get("desc_dict") != 0   # (20: a pooled plan, chosen by the byte model; 8: with its pattern dictionary)
-            assert info["desc_bytes"] != 8 or (info["csr_form"] == 2 and kw.get("desc_dict") != 0)
+            assert info["desc_bytes"] not in (4, 8) or kw.get("desc_dict") != 0   # (pooled plans with the dictionary: 4-byte words, round 6)
             assert not (kw.get("x_window") == 0 and info["brick_order"])
         # multi-vector product on a brick-ordered plan
         plan = api.Plan(tp, rowA, n, nnz, x_window=2, entry_mode=0)
@@ -1110,7 +1110,7 @@ def test_pooled_units_bit_exact(torch_cuda, dtype):
     mats = {"fem3_12": lambda: G.fem_hex(12, 12, 12, 3), "fem3s_14": lambda: G.fem_hex(14, 11, 9, 3, shuffle=16), "fem6_9": lambda: G.fem_hex(9, 9, 9, 6), "fem2_odd": lambda: G.fem_hex(13, 7, 5, 2),
             "allfmt": SMALL["allfmt"], "allfmt_pad5": SMALL["allfmt_pad5"], "kkt12": MEDIUM["kkt12"], "band4096_40": SMALL["band4096_40"], "powerlaw20k": SMALL["powerlaw20k"],
             "one_long_row": SMALL["one_long_row"], "empty_rows": SMALL["empty_rows"], "rand500x700": SMALL["rand500x700"]}
-    knob_sets = [dict(), dict(desc_dict=0), dict(desc_dict=0, entry_mode=2), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, entry_ordered=1), dict(entry_mode=2, entry_ordered=0), dict(strip_cost=64, split_above=200),
+    knob_sets = [dict(), dict(desc_dict=0), dict(desc_dict=0, entry_mode=2), dict(desc_dict=2), dict(desc_dict=2, entry_mode=2), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, entry_ordered=1), dict(entry_mode=2, entry_ordered=0), dict(strip_cost=64, split_above=200),
                  dict(entry_mode=2, strip_cost=100, split_above=300, split_cap=300), dict(entry_mode=0, fix_inline=0, split_above=150, strip_cost=50), dict(dense_mode=api.DENSE_MFMA),
                  dict(dense_mode=api.DENSE_VALU), dict(coo_mode=api.COO_FALLBACK), dict(xcd_remap=0, nt_stream=1), dict(entry_mode=2, nt_stream=1), dict(x_window=2), dict(lds_pad=8192)]
     for name, gen in mats.items():
@@ -1122,7 +1122,7 @@ def test_pooled_units_bit_exact(torch_cuda, dtype):
         tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=hyb)
         for kw in knob_sets:
             y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, csr_split=2, **kw)
-            assert info["csr_form"] == 2 and info["desc_bytes"] in ((20,) if kw.get("desc_dict") == 0 else (8, 20)), (name, kw)   # (8: the shard's units use few enough patterns for the dictionary)
+            assert info["csr_form"] == 2 and info["desc_bytes"] in ((20,) if kw.get("desc_dict") == 0 else (8, 20) if kw.get("desc_dict") == 2 else (4, 20)), (name, kw)   # (4: few enough patterns for the dictionary, one word per unit; 8: as pairs)
             assert np.array_equal(y, want), (name, kw, int(np.count_nonzero(y != want)))
             # wide pooled units (windows of 256 columns, one byte of column offset per slot): the same bar
             y, info = _gpu_y(torch_cuda, tp, rowA, n, nnz, x, csr_split=3, **kw)
@@ -1150,7 +1150,7 @@ def test_pooled_units_bit_exact(torch_cuda, dtype):
         # dense tiles on the matrix cores (k_dense_mfma_mv adds into Y afterwards), and one right-hand side at a time (mv_native = 0) as the cross-check
         X = (np.arange(n * 8, dtype=np.int64) % 5).astype(dtype).reshape(n, 8)
         wcols = [O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals, hyb=hyb), rowA, n, nnz, rp, ci, vals, np.ascontiguousarray(X[:, j]))["y"] for j in range(8)]
-        for kw in (dict(), dict(strip_cost=64, split_above=200), dict(dense_mode=api.DENSE_MFMA, entry_mode=2), dict(mv_native=0), dict(csr_split=3), dict(csr_split=3, strip_cost=64, split_above=200)):   # (wide pooled plans: one right-hand side at a time)
+        for kw in (dict(), dict(desc_dict=2), dict(strip_cost=64, split_above=200), dict(dense_mode=api.DENSE_MFMA, entry_mode=2), dict(mv_native=0), dict(csr_split=3), dict(csr_split=3, strip_cost=64, split_above=200)):   # (wide pooled plans: one right-hand side at a time)
             plan = api.Plan(tp, rowA, n, nnz, **dict(dict(csr_split=2), **kw))
             for nv in (2, 4, 8):
                 Xd = torch_cuda.from_numpy(np.ascontiguousarray(X[:, :nv])).cuda(); Yd = torch_cuda.full((rowA + 16, nv), -4.0, dtype=Xd.dtype, device="cuda")

@@ -143,8 +143,8 @@ def test_column_panels_are_offsets_into_the_same_lists(mats):
 def test_pooled_units_are_chosen_by_the_byte_model_and_are_a_layout_of_their_own():
     """Round 5: CSR-format tiles as pooled units (csr_split = 2).  Unset, the form is the one that puts fewer bytes into the streams: pooled on a block-structured (FEM-like) shard whose
     nonzeros sit in ragged CSR tiles, the ELL-style split on stencil-like shards whose units share a few column patterns (4-byte dictionary descriptors).  The form is decided in the
-    count stage, so every later stage follows; pooled plans have 20-byte descriptors — or 8-byte ones + a dictionary of 16-byte patterns where the shard's units use at most 1,024 of
-    them (natural-order meshes: a few dozen) —, 4-row strips and no column panels."""
+    count stage, so every later stage follows; pooled plans have 20-byte descriptors — or a dictionary of 16-byte patterns where the shard's units use at most 1,024 of them (natural-order meshes: a few dozen), with one 4-byte
+    word per unit (round 6; 8-byte pairs where base, id and tile-row do not fit a word, or with desc_dict = 2) —, 4-row strips and no column panels."""
     tm, rows, n, nnz = _tm(G.fem_hex(12, 12, 12, 3))
     auto, ia = api.plan_layout_stages(tm, rows, n, nnz)
     split, is_ = api.plan_layout_stages(tm, rows, n, nnz, csr_split=1)
@@ -152,7 +152,9 @@ def test_pooled_units_are_chosen_by_the_byte_model_and_are_a_layout_of_their_own
     whole, iw = api.plan_layout_stages(tm, rows, n, nnz, csr_split=0)
     assert (ia["csr_form"], is_["csr_form"], ip["csr_form"], iw["csr_form"]) == (2, 1, 2, 0)
     assert auto == pooled and {k: v for k, v in ia.items() if not k.endswith("_us")} == {k: v for k, v in ip.items() if not k.endswith("_us")}
-    assert ip["stream_bytes"] < 0.93 * is_["stream_bytes"] and ip["desc_bytes"] == 8
+    assert ip["stream_bytes"] < 0.93 * is_["stream_bytes"] and ip["desc_bytes"] == 4
+    pairs, ipair = api.plan_layout_stages(tm, rows, n, nnz, csr_split=2, desc_dict=2)
+    assert ipair["desc_bytes"] == 8 and ipair["stream_bytes"] > ip["stream_bytes"] and set(_changed(pairs, pooled)) <= {"encode", "entries", "finish"} and "encode" in _changed(pairs, pooled)   # (the same units, another encoding)
     nodict, ind = api.plan_layout_stages(tm, rows, n, nnz, csr_split=2, desc_dict=0)
     assert ind["desc_bytes"] == 20 and set(_changed(nodict, pooled)) <= {"encode", "entries", "finish"} and "encode" in _changed(nodict, pooled) and ind["stream_bytes"] > ip["stream_bytes"]   # the dictionary is an encoding of the same units (the entries stage hashes its uploads on top of the running digest)
     assert _changed(split, pooled) == ALL
@@ -160,7 +162,7 @@ def test_pooled_units_are_chosen_by_the_byte_model_and_are_a_layout_of_their_own
     assert ip["stream_bytes"] < 0.85 * b_alg            # values + 1.25 bytes per slot, fill > 0.9 even on this small mesh (boundary rows are a third of it)
     for kw in (dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2), dict(entry_mode=2, x_panel_kb=4, x_panel_merge=1), dict(desc_dict=1), dict(x_window=1), dict(entry_mode=2, wg_strips=32)):
         _, i = api.plan_layout_stages(tm, rows, n, nnz, csr_split=2, **kw)
-        assert i["csr_form"] == 2 and i["desc_bytes"] == 8 and i["x_panels"] == 1 and i["wg_strips"] == 16, kw
+        assert i["csr_form"] == 2 and i["desc_bytes"] == 4 and i["x_panels"] == 1 and i["wg_strips"] == 16, kw
     api.Tile_destroy(tm)
     for gen, want in ((G.laplacian7pt(48), 1), (G.laplacian5pt(200), 1), (G.fem_hex(9, 9, 9, 6), 2), (G.fem_hex(14, 11, 9, 3, shuffle=16), 2)):
         tm, rows, n, nnz = _tm(gen)

@@ -337,6 +337,17 @@ __device__ __forceinline__ uint4 udesc_park_form(const uint4 raw) { return make_
 // flags << 27 — and the unit's column pattern (the two nibble words) in a small dictionary that stays in the vector L1.
 // A lane expands its unit's descriptor to the 16-B LDS form when the chunk is parked.
 __device__ __forceinline__ uint2 udict_of(const DevStream &S, unsigned w) { return S.udict[(w << 5) >> (5 + S.cb_bits)]; }
+// pooled dictionary plans: descriptor of unit i as (word 0 = window base | tile-row in strip << POOL_KR_SHIFT, pattern id) — from the 8-byte pair, or (S.cb_bits = b > 0) from the
+// 4-byte word base | id << b | tile-row << 30 (hip_plan.h)
+__device__ __forceinline__ uint2 pool_desc(const DevStream &S, int i)
+{
+    const int b = S.cb_bits;
+    if (b > 0) {
+        const unsigned a = reinterpret_cast<const unsigned *>(S.udesc)[i];
+        return make_uint2((a & ((1u << b) - 1u)) | ((a >> POOL_WORD_KR_SHIFT) << POOL_KR_SHIFT), (a << (32 - POOL_WORD_KR_SHIFT)) >> (32 - POOL_WORD_KR_SHIFT + b));
+    }
+    return reinterpret_cast<const uint2 *>(S.udesc)[i];
+}
 __device__ __forceinline__ uint4 udesc_expand(const DevStream &S, unsigned w, uint2 pat)
 {
     const unsigned w0 = (w & ((1u << S.cb_bits) - 1u)) | ((w >> 27) << UNIT_FLAG_SHIFT);
@@ -620,14 +631,13 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
     const unsigned *__restrict__ udw = reinterpret_cast<const unsigned *>(S.udesc);
     // POOL + CD (pooled dictionary plans, round 5): a unit's descriptor in HBM is 8 bytes — word 0 (window base | tile-row in strip) and the id of its 16-byte pattern (the 16 column
     // nibbles and the 16 row nibbles) in S.pdict, which stays in the vector L1 / L2: natural-order meshes use a few dozen patterns (fem3_68: 54).  Same staging as the classic
-    // dictionary: words two chunks ahead, the pattern gathered one chunk ahead, so neither hop is waited for in the unit loop.
+    // dictionary: words two chunks ahead, the pattern gathered one chunk ahead, so neither hop is waited for in the unit loop.  Round 6: 4-byte words where everything fits one (pool_desc).
     uint2 wnn2 = make_uint2(0u, 0u);
-    const uint2 *__restrict__ udw2 = reinterpret_cast<const uint2 *>(S.udesc);
     val_t v[UB];
     auto unit_prologue = [&]() {  // descriptor chunks 0 and 1, first value batch: in flight across the entry phase
         if (have_units) {
             if constexpr (CD && POOL) {   // pooled dictionary plans: 8-byte descriptors (word 0, pattern id)
-                const uint2 a = udw2[min(unit_begin + r, last)], b = udw2[min(unit_begin + DCHUNK + r, last)];
+                const uint2 a = pool_desc(S, min(unit_begin + r, last)), b = pool_desc(S, min(unit_begin + DCHUNK + r, last));
                 dcur.x = a.x; dcur.y = a.y; dnext.x = b.x; dnext.y = b.y;
             } else if constexpr (CD) {
                 dcur.x = stream_load<NT_DESC>(udw + min(unit_begin + r, last));
@@ -657,7 +667,7 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
     auto park_first = [&]() {   // chunk 0 into LDS (CD: the patterns of chunks 0 and 1 are gathered here, the word of chunk 2 loaded)
         if constexpr (CD && POOL) {
             const uint4 p0 = S.pdict[dcur.y], p1 = S.pdict[dnext.y];
-            wnn2 = udw2[min(unit_begin + 2 * DCHUNK + r, last)];
+            wnn2 = pool_desc(S, min(unit_begin + 2 * DCHUNK + r, last));
             s_d[g][r] = make_uint4(dcur.x, p0.x, dcur.x, p0.y); s_r[g][r] = make_uint2(p0.z, p0.w);
             dnext = make_uint4(dnext.x, p1.x, 0u, p1.y); rnext = make_uint2(p1.z, p1.w);
         } else if constexpr (CD) {
@@ -863,7 +873,7 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
                 if constexpr (CD && POOL) {
                     const uint4 p = S.pdict[wnn2.y];   // (its words were loaded a chunk ago)
                     dnext = make_uint4(wnn2.x, p.x, 0u, p.y); rnext = make_uint2(p.z, p.w);
-                    wnn2 = udw2[min(chunk_end + DCHUNK + r, last)];
+                    wnn2 = pool_desc(S, min(chunk_end + DCHUNK + r, last));
                 } else if constexpr (CD) {
                     const uint2 p = udict_of(S, wnn);   // (its word was loaded a chunk ago)
                     dnext = make_uint4(wnn, p.x, 0u, p.y);
@@ -1616,12 +1626,11 @@ __global__ __launch_bounds__(256, WIDE ? 5 : MV_MIN_WAVES) void k_pool_mv(DevStr
         for (int k = 0; k < UNIT_GROUP; k++) out[k] = pv[k];
     };
     // pooled dictionary plans (S.pdict): 8-byte descriptors (word 0, pattern id); the pattern — column and row nibbles — is gathered one chunk after its id was loaded
-    const uint2 *__restrict__ udw2 = reinterpret_cast<const uint2 *>(S.udesc);
     const bool pd = S.pdict != nullptr;
     uint2 wnn2 = make_uint2(0u, 0u);
     if (have_units) {   // descriptor chunks 0 and 1, first value group: in flight across the entry phase
         if (pd) {
-            const uint2 a = udw2[min(unit_begin + r, last)], b = udw2[min(unit_begin + DCHUNK + r, last)];
+            const uint2 a = pool_desc(S, min(unit_begin + r, last)), b = pool_desc(S, min(unit_begin + DCHUNK + r, last));
             dcur.x = a.x; dcur.y = a.y; dnext.x = b.x; dnext.y = b.y;
         } else {
             dcur = load_udesc_raw(S.udesc, min(unit_begin + r, last)); dnext = load_udesc_raw(S.udesc, min(unit_begin + DCHUNK + r, last));
@@ -1657,7 +1666,7 @@ __global__ __launch_bounds__(256, WIDE ? 5 : MV_MIN_WAVES) void k_pool_mv(DevStr
         const unsigned char *sc = reinterpret_cast<const unsigned char *>(&s_r[g][0]) + r;          // wide: this lane's byte of a unit's column offsets
         if (pd) {
             const uint4 p0 = S.pdict[dcur.y], p1 = S.pdict[dnext.y];
-            wnn2 = udw2[min(unit_begin + 2 * DCHUNK + r, last)];
+            wnn2 = pool_desc(S, min(unit_begin + 2 * DCHUNK + r, last));
             dcur = make_uint4(dcur.x, p0.x, p0.y, 0u); dnext = make_uint4(dnext.x, p1.x, p1.y, 0u);
             if constexpr (!WIDE) { rcur = make_uint2(p0.z, p0.w); rnext = make_uint2(p1.z, p1.w); }
         }
@@ -1674,7 +1683,7 @@ __global__ __launch_bounds__(256, WIDE ? 5 : MV_MIN_WAVES) void k_pool_mv(DevStr
                     const uint4 p = S.pdict[wnn2.y];
                     dnext = make_uint4(wnn2.x, p.x, p.y, 0u);
                     if constexpr (!WIDE) rnext = make_uint2(p.z, p.w);
-                    wnn2 = udw2[min(chunk_end + DCHUNK + r, last)];
+                    wnn2 = pool_desc(S, min(chunk_end + DCHUNK + r, last));
                 } else { dnext = load_udesc_raw(S.udesc, min(chunk_end + r, last)); rnext = side_of(min(chunk_end + r, last)); }
             }
             const int j0 = u - (chunk_end - DCHUNK);

@@ -119,8 +119,17 @@ struct UDesc { unsigned w0, n0, n1; };    // 12 bytes in HBM; lanes expand it to
 // meshes use a few dozen: 54 on the 27-point hex mesh x 3 unknowns, 31 on the tetrahedral mesh — a unit's descriptor in HBM is 8 bytes (w0, pattern id) and the patterns sit in
 // DevStream::pdict, which stays in the vector L1 / L2: 136 instead of 148 bytes per unit (streams -8 %, time -2 ... -5 %: profiles/r05_pool_dictionary_ab.txt).  desc_dict = 0 keeps the
 // 20-byte form; window-shuffled meshes (10^5 patterns) keep it by themselves.
+// Round 6: where window base, pattern id and tile-row fit one word — base < 2^b with b = 30 - (bits of the largest id), i.e. up to 2^24 columns with 64 patterns, 2^20 with 1024 — the
+// descriptor is that 4-byte word: base | id << b | tile-row in strip << 30 (DevStream::cb_bits = b; 0 = the 8-byte pairs): 132 bytes per unit.  desc_dict = 2 keeps the 8-byte pairs.
 constexpr int POOL_KR_SHIFT = 28;         // w0 of a pooled unit: first column of the window (28 bits: the unit path already limits shards to 2^24 column blocks) | tile-row in strip << 28
 constexpr unsigned POOL_BASE_MASK = (1u << POOL_KR_SHIFT) - 1u;
+constexpr int POOL_WORD_KR_SHIFT = 30;    // 4-byte pooled dictionary descriptors: tile-row in strip in the top two bits
+__host__ __device__ inline int pool_word_base_bits(int npatterns)   // bits left for the window base once the ids of `npatterns` patterns and the tile-row are in the word
+{
+    int ib = 1;
+    while ((1 << ib) < npatterns) ib++;
+    return POOL_WORD_KR_SHIFT - ib;
+}
 constexpr int POOL_MIN_FILL = sizeof(val_t) == 8 ? 12 : 10;   // 16 s_v + 20 bytes per unit against s_v + 5 (4 in the packed lists) per list entry
 #ifndef TILESPMV_POOL_STRIP_ROWS
 #define TILESPMV_POOL_STRIP_ROWS 4
@@ -148,7 +157,7 @@ struct DevStream {
     const UDesc *udesc;                   // per unit, 12 B: column block | flags << 24, column nibbles of rows 0-7, of rows 8-15 (dictionary plans: 4-B words, see cb_bits)
     const URow *urow;                     // pooled plans: the row nibbles of every unit (nullptr otherwise, and in pooled dictionary plans)
     const uint4 *ucol;                    // wide pooled plans (csr_form 3): the column-offset bytes of every unit (nullptr otherwise)
-    const uint4 *pdict;                   // pooled dictionary plans: udesc holds 8-byte (word 0, pattern id) pairs, pdict[id] = column nibbles 0-7, 8-15, row nibbles 0-7, 8-15 (nullptr: none)
+    const uint4 *pdict;                   // pooled dictionary plans: udesc holds 8-byte (word 0, pattern id) pairs — or, cb_bits > 0, 4-byte words —, pdict[id] = column nibbles 0-7, 8-15, row nibbles 0-7, 8-15 (nullptr: none)
     int pooled;                           // 1: every unit is a pooled unit (above)
     const val_t *uval;                    // 16 values per unit, stored in groups of UNIT_GROUP units of one task, interleaved per row
     const val_t *cval;                    // COO entry list: value, global column, (row-in-strip << 4) | row
@@ -167,7 +176,7 @@ struct DevStream {
     const unsigned *gbase;                // column base per chunk of ECHUNK records, chunks counted from the list's begin
     int dest_bits;                        // 9 (wavefront lists), 11 (16 strips per workgroup) or 12 (32 strips)
     const uint2 *udict;                   // dictionary plans: the column patterns (nibbles of rows 0-7, of rows 8-15); udesc / udesc_cb then hold 4-B words
-    int cb_bits;                          // ... column block (cb_bits) | pattern id | flags << 27;  0 = 12-B descriptors
+    int cb_bits;                          // ... column block (cb_bits) | pattern id | flags << 27;  0 = 12-B descriptors.  Pooled dictionary plans: bits of the window base in the 4-byte word, 0 = 8-byte pairs
     int nt_stream;                        // 1: value / entry-record loads are nontemporal (the plan's streams do not fit the Infinity Cache)
     // column panels (round 4): a group's merged list is in column order, so the entries of column panel p (2^k columns, a few MB of x) are the run
     // [panel_off[group * (x_panels + 1) + p], panel_off[.. + p + 1]) of it.  A launch either walks whole lists in k_units (panel_merge = 0) or gives k_units the first

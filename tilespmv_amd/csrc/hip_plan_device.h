@@ -40,7 +40,7 @@ int dev_dict_patterns(const UDesc *d_packed, long long NUP, size_t cap, std::vec
 int dev_compact_desc(const UDesc *d_packed, long long NUP, const uint2 *d_dict, int ndict, int cb_bits, unsigned *d_compact);
 // pooled dictionary plans: the distinct 16-byte patterns (n0, n1, r0, r1) of the packed units, ascending, if at most `cap` (else over); then the 8-byte (word 0, pattern id) form
 int dev_pool_dict(const UDesc *d_packed, const URow *d_packed_row, long long NUP, size_t cap, std::vector<uint4> &sorted_patterns, bool *over);
-int dev_pool_compact(const UDesc *d_packed, const URow *d_packed_row, long long NUP, const uint4 *d_dict, int ndict, uint2 *d_out);
+int dev_pool_compact(const UDesc *d_packed, const URow *d_packed_row, long long NUP, const uint4 *d_dict, int ndict, int word_bits, void *d_out);   // word_bits > 0: 4-byte words (hip_plan.h), else 8-byte pairs
 
 // ENTRIES (entry modes 1 / 2): the lists of every group of GS consecutive tasks merged, ordered by column (ties keep task / list order: ONE stable radix sort by
 // (group, column) of the entries laid out group by group) and packed (plan_tile_ops.h pack_chunks, the host builder's function) — two passes of one thread per group:

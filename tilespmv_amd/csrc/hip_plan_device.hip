@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void k_pd_pool_verify(const UDesc *__restrict_
     }
     count_over[1] = 1;   // (not found: cannot happen after a complete insert pass; treated like a mismatch)
 }
-__global__ __launch_bounds__(256) void k_pd_pool_compact(const UDesc *__restrict__ packed, const URow *__restrict__ prow, long long n, const uint4 *__restrict__ dict, int ndict, uint2 *__restrict__ out)
+__global__ __launch_bounds__(256) void k_pd_pool_compact(const UDesc *__restrict__ packed, const URow *__restrict__ prow, long long n, const uint4 *__restrict__ dict, int ndict, int word_bits, void *__restrict__ out)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -404,7 +404,9 @@ __global__ __launch_bounds__(256) void k_pd_pool_compact(const UDesc *__restrict
         for (int k = 0; k < 4; k++) { if (e[k] != q[k]) { less = e[k] < q[k]; break; } }
         if (less) lo = mid + 1; else hi = mid;
     }
-    out[i] = make_uint2(packed[i].w0, (unsigned)lo);
+    const unsigned w0 = packed[i].w0;
+    if (word_bits > 0) reinterpret_cast<unsigned *>(out)[i] = (w0 & POOL_BASE_MASK) | ((unsigned)lo << word_bits) | ((w0 >> POOL_KR_SHIFT) << POOL_WORD_KR_SHIFT);   // (hip_plan.h: 4-byte pooled descriptors)
+    else reinterpret_cast<uint2 *>(out)[i] = make_uint2(w0, (unsigned)lo);
 }
 }  // namespace
 
@@ -669,10 +671,10 @@ int dev_pool_dict(const UDesc *d_packed, const URow *d_packed_row, long long NUP
     return 0;
 }
 
-int dev_pool_compact(const UDesc *d_packed, const URow *d_packed_row, long long NUP, const uint4 *d_dict, int ndict, uint2 *d_out)
+int dev_pool_compact(const UDesc *d_packed, const URow *d_packed_row, long long NUP, const uint4 *d_dict, int ndict, int word_bits, void *d_out)
 {
     if (NUP <= 0) return 0;
-    hipLaunchKernelGGL(k_pd_pool_compact, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, d_packed_row, NUP, d_dict, ndict, d_out);
+    hipLaunchKernelGGL(k_pd_pool_compact, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, d_packed_row, NUP, d_dict, ndict, word_bits, d_out);
     PD_TRY(hipGetLastError());
     PD_TRY(hipDeviceSynchronize());
     return 0;

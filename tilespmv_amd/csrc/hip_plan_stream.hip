@@ -740,9 +740,13 @@ void StreamBuilder::encode_device()
         if (dev_pool_dict(d_packed, d_prow, NUP, (size_t)1 << DICT_MAX_BITS, pats, &over) != 0) rc = -3;
         else if (!over) {
             rc |= plan->upload(pats.data(), pats.size(), &S.pdict);
-            rc |= plan->reserve((size_t)NUP, reinterpret_cast<const uint2 **>(&S.udesc));
-            if (rc == 0 && dev_pool_compact(d_packed, d_prow, NUP, S.pdict, (int)pats.size(), reinterpret_cast<uint2 *>(const_cast<UDesc *>(S.udesc))) != 0) rc = -3;
+            const int bb = pool_word_base_bits((int)pats.size());   // (4-byte words under the host builder's rule)
+            const bool word = K.desc_dict != 2 && POOL_STRIP_ROWS <= 4 && bb >= 4 && (long long)T->tilen * 16 <= (1ll << bb);
+            if (word) rc |= plan->reserve((size_t)NUP, reinterpret_cast<const unsigned **>(&S.udesc));
+            else rc |= plan->reserve((size_t)NUP, reinterpret_cast<const uint2 **>(&S.udesc));
+            if (rc == 0 && dev_pool_compact(d_packed, d_prow, NUP, S.pdict, (int)pats.size(), word ? bb : 0, const_cast<UDesc *>(S.udesc)) != 0) rc = -3;
             pool_dict = true;
+            if (word) S.cb_bits = bb;
         }
     }
     if (rc == 0 && pooled && !wide && !pool_dict) {
@@ -899,6 +903,7 @@ void StreamBuilder::encode()
         S.pdict = nullptr; pool_dict = false;
         std::vector<uint4> pdict;
         std::vector<uint2> compact2;
+        std::vector<unsigned> compact1;
         if (pooled && !wide && K.desc_dict != 0 && NUP > 0) {
             typedef std::array<unsigned, 4> Pat;
             const size_t cap = (size_t)1 << DICT_MAX_BITS;
@@ -933,11 +938,24 @@ void StreamBuilder::encode()
                     }
                 });
                 pool_dict = true;
+                // round 6: one 4-byte word per unit where window base, pattern id and tile-row fit it (hip_plan.h; desc_dict = 2 keeps the pairs)
+                const int bb = pool_word_base_bits((int)all.size());
+                if (K.desc_dict != 2 && POOL_STRIP_ROWS <= 4 && bb >= 4 && (long long)T->tilen * 16 <= (1ll << bb)) {
+                    compact1.resize((size_t)NUP);
+                    parallel_chunks((int64_t)NUP, 1 << 16, [&](int64_t b, int64_t e, int) {
+                        for (int64_t u = b; u < e; u++) {
+                            const uint2 c = compact2[(size_t)u];
+                            compact1[(size_t)u] = (c.x & POOL_BASE_MASK) | (c.y << bb) | ((c.x >> POOL_KR_SHIFT) << POOL_WORD_KR_SHIFT);
+                        }
+                    });
+                    S.cb_bits = bb;
+                }
             }
         }
         S.urow = nullptr; S.ucol = nullptr; S.pooled = pooled ? 1 : 0;
         if (pool_dict) {
-            rc |= plan->upload(compact2.data(), compact2.size(), reinterpret_cast<const uint2 **>(&S.udesc));
+            if (S.cb_bits > 0) rc |= plan->upload(compact1.data(), compact1.size(), reinterpret_cast<const unsigned **>(&S.udesc));
+            else rc |= plan->upload(compact2.data(), compact2.size(), reinterpret_cast<const uint2 **>(&S.udesc));
             rc |= plan->upload(pdict.data(), pdict.size(), &S.pdict);
         } else if (S.cb_bits > 0) {
             rc |= plan->upload(compact.data(), compact.size(), reinterpret_cast<const unsigned **>(&S.udesc));
