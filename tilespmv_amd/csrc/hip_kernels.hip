@@ -44,6 +44,7 @@
 #define TSPMV_DIAG_TRIP_ADDS
 #define TSPMV_DIAG_UNITS_LDS_PAD
 #define TSPMV_DIAG_UNIT_GATHER_SKIP(k) false
+#define TSPMV_DIAG_UNIT_X(i) (i)
 #define TSPMV_DIAG_POOL_ADD(dest, prod) false
 #define TSPMV_DIAG_POOL_X(load, d) (load)
 #define TSPMV_DIAG_XCD_ZERO 1
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
             const unsigned fl = d[k].x >> 24;
             const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
             if (TSPMV_DIAG_UNIT_GATHER_SKIP(k)) xv[k] = xv[k - 1];
-            else xv[k] = x[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast)];
+            else xv[k] = x[TSPMV_DIAG_UNIT_X(min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast))];
         }
     };
 

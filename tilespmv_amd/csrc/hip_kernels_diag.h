@@ -52,6 +52,13 @@
 #define TSPMV_DIAG_UNIT_GATHER_SKIP(k) false
 #endif
 
+// TILESPMV_ABL 8 (round 6): the classic units' x gathers all fall into the first 256 elements of x (what the launch fetches apart from x: FETCH_SIZE of this build against the product's);
+#if defined(TILESPMV_ABL) && TILESPMV_ABL == 8
+#define TSPMV_DIAG_UNIT_X(i) ((i) & 255)
+#else
+#define TSPMV_DIAG_UNIT_X(i) (i)
+#endif
+
 // ---- pooled units (round 5): TILESPMV_POOL_ABL 1 plain LDS store instead of the atomic add, 2 atomic add to a lane-private address (no two lanes of a unit share one), 3 no LDS operation at all
 #if defined(TILESPMV_POOL_ABL) && TILESPMV_POOL_ABL == 1
 #define TSPMV_DIAG_POOL_ADD(dest, prod) (((&s_y[g][0][0])[dest] = (lacc_t)(prod)), true)
