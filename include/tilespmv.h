@@ -329,6 +329,9 @@ typedef struct {
                            that the caller left unset are switched off (as if 1 / 0 / 0 / 0 / 0) and entry_ordered is 1: two plans of the same matrix then have the same layout,
                            the same launch form and give bit-identical y on any data, run after run and rank after rank (the reference's own timing loop never changes the
                            result either, src/tilespmv_cuda.h:1112-1137).  0 / unset: the defaults described above                       TILESPMV_DETERMINISTIC */
+    int absorb;         /* round 6: list entries of a COO tile that sit within a few columns of a neighbouring ELL tile (the corner entries of a band / stencil) move into
+                           that tile's padding slots — the unit's 16-column window of x is shifted by -4 .. 3 columns — instead of going to the strip's entry list:
+                           unset / 1 = where it applies (classic unit plans), 0 = never                                                    TILESPMV_ABSORB */
     int reserved[1];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
@@ -456,7 +459,8 @@ enum {
                                          column-panel passes and split tile-rows included; tests/test_gpu_parity.py::test_panelled_plans_with_split_rows_sum_in_a_fixed_order, scripts/reproducibility_sweep.py) */
     TILESPMV_INFO_STRIP_COST = 15,    /* strip size target the plan was cut with */
     TILESPMV_INFO_WG_STRIPS = 16,     /* strips per workgroup of the unit kernel (16 or 32) */
-    TILESPMV_INFO_RETIRED_17 = 17,        /* always 0 (x-window plans, retired in round 6; the numbering of the facts is kept) */
+    TILESPMV_INFO_LIST_ENTRIES = 17,      /* nonzeros on the strips' entry lists (COO tiles, HYB / CSR-tile remainders) after the ones that fit the padding of a neighbouring ELL unit moved there
+                                             (tilespmv_plan_options.absorb); unit-stream plans, 0 otherwise.  (Until round 6: a retired fact that was always 0) */
     TILESPMV_INFO_RETIRED_18 = 18,        /* always 0 */
     TILESPMV_INFO_BRICK_ORDER = 19,       /* 1: the strips were regrouped into bricks of the grid (stencil-like shard) */
     TILESPMV_INFO_DESC_BYTES = 20,        /* bytes per unit descriptor in HBM: 12, or 4 (column-pattern dictionary); pooled plans 20, or 8 (pattern dictionary); wide pooled plans 28 */

@@ -6,6 +6,7 @@ for v in $3; do
   export TILESPMV_LIB_VARIANT=$v
   out=$GRAFT_REPO_ROOT/gpurun_out/fetch_ab_${wl}${v}; mkdir -p $out
   for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $out/pmc_$c
     (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-check --workload $wl --dtype $dt --no-cpu-baseline --no-extras > /dev/null 2> $out/$c.err) || echo "$c failed"
     python3 - $out/pmc_$c $c "$v" <<'P'
 import sys, glob, csv

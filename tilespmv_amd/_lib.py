@@ -18,13 +18,13 @@ _CACHE = {}
 
 INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel",
               "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us", "entry_mode", "entry_ordered", "strip_cost",
-              "wg_strips", "retired_17", "retired_18", "brick_order", "desc_bytes", "nt_stream", "retired_22", "retired_23", "placement_tries", "retired_25", "x_panels", "x_panel_merge", "scattered_entries", "x_slice_passes", "csr_form", "timed_choices_us", "device_build", "tile_create_us"]
+              "wg_strips", "list_entries", "retired_18", "brick_order", "desc_bytes", "nt_stream", "retired_22", "retired_23", "placement_tries", "retired_25", "x_panels", "x_panel_merge", "scattered_entries", "x_slice_passes", "csr_form", "timed_choices_us", "device_build", "tile_create_us"]
 
 
 KNOB_DEFAULT = -1
 # tuning knobs of tilespmv_plan_options (include/tilespmv.h), in struct order after `autotune`
 KNOB_NAMES = ["entry_mode", "entry_ordered", "strip_cost", "split_above", "split_cap", "xcd_remap", "xcd_chunk", "csr_split", "fix_inline",
-              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "x_stride1", "x_stride2", "mv_native", "mv_xcd_chunk", "lds_pad", "y_store", "desc_dict", "nt_stream", "x_panel_kb", "x_panel_merge", "placement_tries", "x_slice_passes", "deterministic"]
+              "coo_cost", "coo_heavy_min", "coo_piece", "strip_even", "wg_strips", "x_window", "x_stride1", "x_stride2", "mv_native", "mv_xcd_chunk", "lds_pad", "y_store", "desc_dict", "nt_stream", "x_panel_kb", "x_panel_merge", "placement_tries", "x_slice_passes", "deterministic", "absorb"]
 
 
 class PlanOptions(C.Structure):

@@ -45,6 +45,8 @@
 #define TSPMV_DIAG_UNITS_LDS_PAD
 #define TSPMV_DIAG_UNIT_GATHER_SKIP(k) false
 #define TSPMV_DIAG_UNIT_X(i) (i)
+#define TSPMV_DIAG_COO0_ON true
+#define TSPMV_DIAG_COO0_X(c) (c)
 #define TSPMV_DIAG_POOL_ADD(dest, prod) false
 #define TSPMV_DIAG_POOL_X(load, d) (load)
 #define TSPMV_DIAG_XCD_ZERO 1
@@ -337,7 +339,7 @@ __device__ __forceinline__ uint4 udesc_park_form(const uint4 raw) { return make_
 // Dictionary plans (DevStream::cb_bits > 0; hip_plan.hip): 4 B per unit in HBM — column block | pattern id << cb_bits |
 // flags << 27 — and the unit's column pattern (the two nibble words) in a small dictionary that stays in the vector L1.
 // A lane expands its unit's descriptor to the 16-B LDS form when the chunk is parked.
-__device__ __forceinline__ uint2 udict_of(const DevStream &S, unsigned w) { return S.udict[(w << 5) >> (5 + S.cb_bits)]; }
+__device__ __forceinline__ uint4 udict_of(const DevStream &S, unsigned w) { return S.udict[(w << 5) >> (5 + S.cb_bits)]; }   // (nibbles of rows 0-7, of rows 8-15, window shift << 29, 0)
 // pooled dictionary plans: descriptor of unit i as (word 0 = window base | tile-row in strip << POOL_KR_SHIFT, pattern id) — from the 8-byte pair, or (S.cb_bits = b > 0) from the
 // 4-byte word base | id << b | tile-row << 30 (hip_plan.h)
 __device__ __forceinline__ uint2 pool_desc(const DevStream &S, int i)
@@ -349,11 +351,13 @@ __device__ __forceinline__ uint2 pool_desc(const DevStream &S, int i)
     }
     return reinterpret_cast<const uint2 *>(S.udesc)[i];
 }
-__device__ __forceinline__ uint4 udesc_expand(const DevStream &S, unsigned w, uint2 pat)
+__device__ __forceinline__ uint4 udesc_expand(const DevStream &S, unsigned w, uint4 pat)
 {
-    const unsigned w0 = (w & ((1u << S.cb_bits) - 1u)) | ((w >> 27) << UNIT_FLAG_SHIFT);
+    const unsigned w0 = (w & ((1u << S.cb_bits) - 1u)) | ((w >> 27) << UNIT_FLAG_SHIFT) | pat.z;   // (pat.z: the pattern's window shift, already at UNIT_SHIFT_SHIFT)
     return make_uint4(w0, pat.x, w0, pat.y);
 }
+// first column of a classic unit's window of x: column block * 16, moved by the signed shift of a unit that took list entries (hip_plan.h UNIT_SHIFT_SHIFT)
+__device__ __forceinline__ long long unit_x_base(unsigned w0) { return (long long)(w0 & 0xFFFFFFu) * 16 + ((int)w0 >> UNIT_SHIFT_SHIFT); }
 
 // Descriptor word layout in LDS (16 B per unit, two identical-purpose halves so that a lane reads 8 B; HBM holds the
 // 12-B form without the duplicate word, UDesc):
@@ -672,9 +676,9 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
             s_d[g][r] = make_uint4(dcur.x, p0.x, dcur.x, p0.y); s_r[g][r] = make_uint2(p0.z, p0.w);
             dnext = make_uint4(dnext.x, p1.x, 0u, p1.y); rnext = make_uint2(p1.z, p1.w);
         } else if constexpr (CD) {
-            const uint2 p0 = udict_of(S, dcur.x), p1 = udict_of(S, dnext.x);
+            const uint4 p0 = udict_of(S, dcur.x), p1 = udict_of(S, dnext.x);
             wnn = stream_load<NT_DESC>(udw + min(unit_begin + 2 * DCHUNK + r, last));
-            dnext.y = p1.x; dnext.w = p1.y;
+            dnext.y = p1.x; dnext.z = p1.z; dnext.w = p1.y;
             s_d[g][r] = udesc_expand(S, dcur.x, p0);
         } else s_d[g][r] = udesc_park_form(dcur);
         if constexpr (WIDE) s_c[g][r] = ccur;
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
             const unsigned fl = d[k].x >> 24;
             const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
             if (TSPMV_DIAG_UNIT_GATHER_SKIP(k)) xv[k] = xv[k - 1];
-            else xv[k] = x[TSPMV_DIAG_UNIT_X(min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast))];
+            else xv[k] = x[TSPMV_DIAG_UNIT_X(min(unit_x_base(d[k].x) + nib, xlast))];
         }
     };
 
@@ -799,11 +803,11 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
         wave_lds_fence();
     }
     unsigned rb0 = 0; int cc0 = 0; val_t cv0 = 0;
-    const bool coo0 = side && !coo_heavy && (coo_begin + r < coo_end);
+    const bool coo0 = TSPMV_DIAG_COO0_ON && side && !coo_heavy && (coo_begin + r < coo_end);
     if (coo0) { rb0 = stream_load<NT_COO0>(S.crow + coo_begin + r); cc0 = stream_load<NT_COO0>(S.ccol + coo_begin + r); cv0 = stream_load<NT_COO0>(S.cval + coo_begin + r); }
     unit_prologue();
     if (side && !coo_heavy) {  // up to coo_heavy_min entries: 16 with the prologue loads, the rest 4 x 16 per trip
-        if (coo0) atomicAdd(&s_y[g][rb0 >> 4][rb0 & 15u], (lacc_t)(cv0 * x[cc0]));
+        if (coo0) atomicAdd(&s_y[g][rb0 >> 4][rb0 & 15u], (lacc_t)(cv0 * x[TSPMV_DIAG_COO0_X(cc0)]));
         for (int e0 = coo_begin + 16; e0 < coo_end; e0 += 64) {
             unsigned rb[4]; int cc[4]; val_t cv[4], xx[4];
 #pragma unroll
@@ -865,7 +869,7 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
             if (u == chunk_end) {  // next descriptor chunk: already in registers, fetch the one after it
                 wave_lds_fence();
                 if constexpr (CD && POOL) { s_d[g][r] = make_uint4(dnext.x, dnext.y, dnext.x, dnext.w); s_r[g][r] = rnext; }
-                else if constexpr (CD) s_d[g][r] = udesc_expand(S, dnext.x, make_uint2(dnext.y, dnext.w));
+                else if constexpr (CD) s_d[g][r] = udesc_expand(S, dnext.x, make_uint4(dnext.y, dnext.w, dnext.z, 0u));
                 else s_d[g][r] = udesc_park_form(dnext);
                 if constexpr (WIDE) { s_c[g][r] = cnext; cnext = S.ucol[min(chunk_end + DCHUNK + r, last)]; }
                 else if constexpr (POOL && !CD) { s_r[g][r] = rnext; rnext = urw[min(chunk_end + DCHUNK + r, last)]; }
@@ -876,8 +880,8 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
                     dnext = make_uint4(wnn2.x, p.x, 0u, p.y); rnext = make_uint2(p.z, p.w);
                     wnn2 = pool_desc(S, min(chunk_end + DCHUNK + r, last));
                 } else if constexpr (CD) {
-                    const uint2 p = udict_of(S, wnn);   // (its word was loaded a chunk ago)
-                    dnext = make_uint4(wnn, p.x, 0u, p.y);
+                    const uint4 p = udict_of(S, wnn);   // (its word was loaded a chunk ago)
+                    dnext = make_uint4(wnn, p.x, p.z, p.y);
                     wnn = stream_load<NT_DESC>(udw + min(chunk_end + DCHUNK + r, last));
                 } else dnext = load_udesc_raw(S.udesc, min(chunk_end + r, last));
             }
@@ -1521,7 +1525,7 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
             for (int k = 0; k < UB; k++) {
                 const unsigned fl = d[k].x >> 24;
                 const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
-                xv[k] = Xv[min((long long)(d[k].x & 0xFFFFFFu) * 16 + nib, xlast) * Q];
+                xv[k] = Xv[min(unit_x_base(d[k].x) + nib, xlast) * Q];
             }
             val_t vn[UB];
             load_grp(u + UB, vn);

@@ -58,6 +58,17 @@
 #else
 #define TSPMV_DIAG_UNIT_X(i) (i)
 #endif
+// TILESPMV_ABL 9: the short per-strip entry lists (entry mode 0, up to 16 entries with the prologue) gather inside the first 2 KB of x; 10: they are skipped altogether
+#if defined(TILESPMV_ABL) && TILESPMV_ABL == 9
+#define TSPMV_DIAG_COO0_X(c) ((c) & 255)
+#else
+#define TSPMV_DIAG_COO0_X(c) (c)
+#endif
+#if defined(TILESPMV_ABL) && TILESPMV_ABL == 10
+#define TSPMV_DIAG_COO0_ON false
+#else
+#define TSPMV_DIAG_COO0_ON true
+#endif
 
 // ---- pooled units (round 5): TILESPMV_POOL_ABL 1 plain LDS store instead of the atomic add, 2 atomic add to a lane-private address (no two lanes of a unit share one), 3 no LDS operation at all
 #if defined(TILESPMV_POOL_ABL) && TILESPMV_POOL_ABL == 1

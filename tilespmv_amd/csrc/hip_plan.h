@@ -98,6 +98,8 @@ constexpr unsigned UNIT_EOR = 1u;         // unit flag bit 0: last unit of its t
 constexpr int UNIT_ROW_SHIFT = 1;         // unit flag bits 1-3: tile-row inside the strip
 constexpr unsigned UNIT_ROWUNIT = 16u;    // unit flag bit 4: "row unit" = 16 values of ONE tile row (dense-row tiles);
                                           //   lane = column, word 1/3 hold the target row, result needs a 16-lane reduction
+constexpr int UNIT_SHIFT_SHIFT = 29;      // unit flag bits 5-7 (word 0 bits 29-31): signed window shift of a unit that took list entries (plan_tile_ops.h "absorbed list entries"):
+constexpr int ABSORB_SHIFT_MIN = -4, ABSORB_SHIFT_MAX = 3;   //   x index = column block * 16 + shift + nibble.  Dictionary plans keep the shift with the pattern (DevStream::udict)
 constexpr int UNIT_GROUP = 16 / (int)sizeof(val_t);  // units whose values share one 16-byte lane load (2 in fp64, 4 in fp32)
 constexpr long long NT_STREAM_MIN_BYTES = 400ll << 20;   // launches that move more than this (about 1.6 x the 256 MB Infinity Cache) read their once-read streams nontemporally
 constexpr int DICT_MAX_BITS = 10;         // dictionary plans: at most 1024 column patterns (8 KB: stays in the vector L1)
@@ -175,7 +177,7 @@ struct DevStream {
     const ERec *grec;
     const unsigned *gbase;                // column base per chunk of ECHUNK records, chunks counted from the list's begin
     int dest_bits;                        // 9 (wavefront lists), 11 (16 strips per workgroup) or 12 (32 strips)
-    const uint2 *udict;                   // dictionary plans: the column patterns (nibbles of rows 0-7, of rows 8-15); udesc / udesc_cb then hold 4-B words
+    const uint4 *udict;                   // dictionary plans: the column patterns (nibbles of rows 0-7, of rows 8-15, window shift << UNIT_SHIFT_SHIFT, 0), ordered by (shift, nibbles); udesc / udesc_cb then hold 4-B words
     int cb_bits;                          // ... column block (cb_bits) | pattern id | flags << 27;  0 = 12-B descriptors.  Pooled dictionary plans: bits of the window base in the 4-byte word, 0 = 8-byte pairs
     int nt_stream;                        // 1: value / entry-record loads are nontemporal (the plan's streams do not fit the Infinity Cache)
     // column panels (round 4): a group's merged list is in column order, so the entries of column panel p (2^k columns, a few MB of x) are the run

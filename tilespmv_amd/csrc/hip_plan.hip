@@ -65,6 +65,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.x_panel_kb = pick(o.x_panel_kb, "TILESPMV_X_PANEL_KB", -1);
     k.x_panel_merge = pick(o.x_panel_merge, "TILESPMV_X_PANEL_MERGE", -1);
     k.x_slice_passes = pick(o.x_slice_passes, "TILESPMV_X_SLICE_PASSES", -1);
+    k.absorb = pick(o.absorb, "TILESPMV_ABSORB", -1) != 0 ? 1 : 0;
     k.deterministic = pick(o.deterministic, "TILESPMV_DETERMINISTIC", 0) > 0 ? 1 : 0;
     if (k.deterministic) {   // no stopwatch, no unordered sum: whatever the caller left unset among the timed choices is switched off
         if (k.placement_tries < 0) k.placement_tries = 1;
@@ -262,7 +263,7 @@ const char *tilespmv_plan_options_layout(void)
         TSPMV_F(entry_mode) TSPMV_F(entry_ordered) TSPMV_F(strip_cost) TSPMV_F(split_above) TSPMV_F(split_cap) TSPMV_F(xcd_remap) TSPMV_F(xcd_chunk)
         TSPMV_F(csr_split) TSPMV_F(fix_inline) TSPMV_F(coo_cost) TSPMV_F(coo_heavy_min) TSPMV_F(coo_piece) TSPMV_F(strip_even) TSPMV_F(wg_strips)
         TSPMV_F(x_window) TSPMV_F(x_stride1) TSPMV_F(x_stride2) TSPMV_F(mv_native) TSPMV_F(mv_xcd_chunk) TSPMV_F(lds_pad) TSPMV_F(y_store)
-        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(x_panel_kb) TSPMV_F(x_panel_merge) TSPMV_F(placement_tries) TSPMV_F(x_slice_passes) TSPMV_F(deterministic) TSPMV_F(reserved)
+        TSPMV_F(desc_dict) TSPMV_F(nt_stream) TSPMV_F(x_panel_kb) TSPMV_F(x_panel_merge) TSPMV_F(placement_tries) TSPMV_F(x_slice_passes) TSPMV_F(deterministic) TSPMV_F(absorb) TSPMV_F(reserved)
 #undef TSPMV_F
         return o;
     }();

@@ -20,7 +20,7 @@ struct DevCounts {
     void release();
 };
 
-struct DevShard { const DevTile *D; int tr0, tr1, t_begin, t_end; bool coo_in_tile, dense_mfma; long long stored0, stored; };   // stored: blknnz[t_end] - blknnz[t_begin]
+struct DevShard { const DevTile *D; int tr0, tr1, t_begin, t_end; bool coo_in_tile, dense_mfma; long long stored0, stored; bool absorb = false; };   // absorb: plan_tile_ops.h "absorbed list entries"   // stored: blknnz[t_end] - blknnz[t_begin]
 
 // rc 0 or -3 (HIP error, reported on stderr)
 int dev_fetch_ints(const int *d_array, const long long *idx, int n, int *out);   // out[k] = d_array[idx[k]]
@@ -36,8 +36,9 @@ int dev_fetch_word0(const uint4 *d_udesc, long long NU, hvec<unsigned> &w0);
 // ENCODE: units of task i move from [map.x, map.x + map.z) to [map.y, ..) of the packed numbering (padding units in between stay zero)
 int dev_pack_desc(const uint4 *d_udesc, const uint2 *d_urow, const uint4 *d_ucol, const int4 *d_map, int ntasks, UDesc *d_packed, URow *d_packed_row, uint4 *d_packed_col);   // d_map: device copy of the (old begin, new begin, count) triples
 // the distinct (n0, n1) patterns of NUP packed descriptors, ascending, if there are at most `cap` of them (else `over` = true); then the 4-byte form
-int dev_dict_patterns(const UDesc *d_packed, long long NUP, size_t cap, std::vector<unsigned long long> &sorted_patterns, bool *over);
-int dev_compact_desc(const UDesc *d_packed, long long NUP, const uint2 *d_dict, int ndict, int cb_bits, unsigned *d_compact);
+struct DictRanges { int off[9]; };   // dictionary entries of shift code c (word 0 >> UNIT_SHIFT_SHIFT): [off[c], off[c + 1])
+int dev_dict_patterns(const UDesc *d_packed, long long NUP, size_t cap, std::vector<uint4> &dict, DictRanges *ranges, bool *over);   // distinct (shift code, nibbles) patterns in ascending order, as dictionary entries
+int dev_compact_desc(const UDesc *d_packed, long long NUP, const uint4 *d_dict, DictRanges ranges, int cb_bits, unsigned *d_compact);
 // pooled dictionary plans: the distinct 16-byte patterns (n0, n1, r0, r1) of the packed units, ascending, if at most `cap` (else over); then the 8-byte (word 0, pattern id) form
 int dev_pool_dict(const UDesc *d_packed, const URow *d_packed_row, long long NUP, size_t cap, std::vector<uint4> &sorted_patterns, bool *over);
 int dev_pool_compact(const UDesc *d_packed, const URow *d_packed_row, long long NUP, const uint4 *d_dict, int ndict, int word_bits, void *d_out);   // word_bits > 0: 4-byte words (hip_plan.h), else 8-byte pairs

@@ -60,13 +60,13 @@ __global__ __launch_bounds__(256) void k_pd_gather_ints(const int *__restrict__ 
 }
 
 // ---- COUNT
-__global__ __launch_bounds__(256) void k_pd_count_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, const long long *__restrict__ hyb_off, int t_begin, int nt, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form,
+__global__ __launch_bounds__(256) void k_pd_count_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, const long long *__restrict__ hyb_off, int t_begin, int nt, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, bool absorb,
                                                           int *__restrict__ tu, int *__restrict__ tc, int *__restrict__ td, int *__restrict__ tp)
 {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nt) return;
-    const int t = t_begin + (int)gid, rowlen = tile_rowlen(tile_bi[t], T.tilem, rowA);
-    const TileCount k = tile_count(&T, t, rowlen, T.tilen, colA, coo_in_tile, dense_mfma, csr_form);
+    const int t = t_begin + (int)gid, bi = tile_bi[t], rowlen = tile_rowlen(bi, T.tilem, rowA);
+    const TileCount k = tile_count(&T, t, rowlen, T.tilen, colA, coo_in_tile, dense_mfma, csr_form, absorb, T.tile_ptr[bi], T.tile_ptr[bi + 1]);
     tu[gid] = k.nunits; tc[gid] = k.ncoo; td[gid] = k.ndense;
     if (csr_form >= 2) tp[gid] = pool_one_tile_count(&T, t, rowlen, coo_in_tile, hyb_off);   // what the tile adds to its tile-row's pool
 }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_pd_fill_urow(uint2 *__restrict__ urow, 
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) urow[i] = make_uint2(0x01234567u, 0x89ABCDEFu);   // (units that keep one row per lane: identity)
 }
-__global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, const long long *__restrict__ hyb_off, int t_begin, int nt, int tr0, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form,
+__global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, const long long *__restrict__ hyb_off, int t_begin, int nt, int tr0, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, bool absorb,
                                                          const int *__restrict__ tu, const int *__restrict__ tc, const int *__restrict__ td, const int *__restrict__ pu, const int *__restrict__ pc,
                                                          const int *__restrict__ pd, const unsigned char *__restrict__ row_k, const unsigned char *__restrict__ row_split, const EmitOut O)
 {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, cons
     const int t = t_begin + (int)gid, bi = tile_bi[t], i = bi - tr0, a = T.tile_ptr[bi] - t_begin;
     EmitPos p{(long long)pu[i] + tu[gid] - tu[a], (long long)pc[i] + tc[gid] - tc[a], (long long)pd[i] + td[gid] - td[a]};
     const long long u0 = p.u;
-    tile_emit(&T, t, tile_rowlen(bi, T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form, (unsigned)row_k[i], hyb_off, O, p);
+    tile_emit(&T, t, tile_rowlen(bi, T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form, (unsigned)row_k[i], hyb_off, O, p, absorb, T.tile_ptr[bi], T.tile_ptr[bi + 1]);
     // the tile that emits the last unit of an unsplit tile-row of a classic plan marks it (the kernel writes y there)
     if (csr_form < 2 && !row_split[i] && p.u > u0 && p.u == pu[i + 1]) { O.udesc[p.u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; O.udesc[p.u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
 }
@@ -229,19 +229,34 @@ __global__ __launch_bounds__(256) void k_pd_pack_desc(const uint4 *__restrict__ 
         }
     }
 }
-__global__ __launch_bounds__(256) void k_pd_patterns(const UDesc *__restrict__ packed, long long n, u64 *__restrict__ out)
+// the nibble patterns of the units whose shift code (word 0 >> UNIT_SHIFT_SHIFT: units that took list entries, plan_tile_ops.h) is `code`, appended to out in any order (they are sorted next);
+// all_same: every unit has that code (plans without such units: code 0) -> position i, no counter
+__global__ __launch_bounds__(256) void k_pd_patterns(const UDesc *__restrict__ packed, long long n, unsigned code, bool all_same, u64 *__restrict__ out, unsigned long long *__restrict__ count)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = ((u64)packed[i].n0 << 32) | packed[i].n1;
+    if (i >= n) return;
+    const UDesc d = packed[i];
+    if (all_same) { out[i] = ((u64)d.n0 << 32) | d.n1; return; }
+    if ((d.w0 >> UNIT_SHIFT_SHIFT) == code) out[atomicAdd(count, 1ull)] = ((u64)d.n0 << 32) | d.n1;
 }
-__global__ __launch_bounds__(256) void k_pd_compact(const UDesc *__restrict__ packed, long long n, const uint2 *__restrict__ dict, int ndict, int cb_bits, unsigned *__restrict__ compact)
+__global__ __launch_bounds__(256) void k_pd_shift_hist(const UDesc *__restrict__ packed, long long n, unsigned long long *__restrict__ hist)
+{
+    __shared__ unsigned h[8];
+    if (threadIdx.x < 8) h[threadIdx.x] = 0u;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) atomicAdd(&h[packed[i].w0 >> UNIT_SHIFT_SHIFT], 1u);
+    __syncthreads();
+    if (threadIdx.x < 8 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_pd_compact(const UDesc *__restrict__ packed, long long n, const uint4 *__restrict__ dict, DictRanges ranges, int cb_bits, unsigned *__restrict__ compact)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const UDesc d = packed[i];
     const u64 key = ((u64)d.n0 << 32) | d.n1;
-    int lo = 0, hi = ndict;   // lower bound in the ascending dictionary
-    while (lo < hi) { const int mid = (lo + hi) >> 1; const uint2 q = dict[mid]; if ((((u64)q.x << 32) | q.y) < key) lo = mid + 1; else hi = mid; }
+    const unsigned code = d.w0 >> UNIT_SHIFT_SHIFT;
+    int lo = ranges.off[code], hi = ranges.off[code + 1];   // lower bound among the entries of the unit's shift code (ascending nibbles)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; const uint4 q = dict[mid]; if ((((u64)q.x << 32) | q.y) < key) lo = mid + 1; else hi = mid; }
     compact[i] = (d.w0 & ((1u << cb_bits) - 1u)) | ((unsigned)lo << cb_bits) | ((d.w0 >> UNIT_FLAG_SHIFT) << 27);
 }
 
@@ -512,7 +527,7 @@ int dev_count(const DevShard &S, int csr_form, DevCounts *C, hvec<int> &counts3,
     if (csr_form >= 2) C->tp = blockp + 3 * per;
     PD_TRY(hipMemsetAsync(blockp, 0, ints * sizeof(int), 0));
     if (nt > 0) {
-        hipLaunchKernelGGL(k_pd_count_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, D->hyb_off, S.t_begin, nt, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, csr_form, C->tu, C->tc, C->td, C->tp);
+        hipLaunchKernelGGL(k_pd_count_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, D->hyb_off, S.t_begin, nt, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, csr_form, S.absorb && csr_form < 2, C->tu, C->tc, C->td, C->tp);
         PD_TRY(hipGetLastError());
         size_t tmp_b = 0; void *tmp = nullptr;
         PD_TRY(prims::scan_int(nullptr, tmp_b, C->tu, C->tu, (size_t)nt + 1, (hipStream_t)0));
@@ -578,7 +593,7 @@ int dev_emit(const DevShard &S, const DevCounts &C, const hvec<long long> &pu, c
     PD_TRY(d_rk.from(row_k)); PD_TRY(d_rs.from(row_split));
     if (O.urow && NU > 0) { hipLaunchKernelGGL(k_pd_fill_urow, dim3(nblk(NU, 256)), dim3(256), 0, 0, O.urow, NU); PD_TRY(hipGetLastError()); }
     if (nt > 0) {
-        hipLaunchKernelGGL(k_pd_emit_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, D->hyb_off, S.t_begin, nt, S.tr0, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, C.csr_form, (const int *)C.tu,
+        hipLaunchKernelGGL(k_pd_emit_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, D->hyb_off, S.t_begin, nt, S.tr0, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, C.csr_form, S.absorb && C.csr_form < 2, (const int *)C.tu,
                            (const int *)C.tc, (const int *)C.td, (const int *)d_pu.p, (const int *)d_pc.p, (const int *)d_pd.p, (const unsigned char *)d_rk.p, (const unsigned char *)d_rs.p, O);
         PD_TRY(hipGetLastError());
     }
@@ -612,34 +627,52 @@ int dev_pack_desc(const uint4 *d_udesc, const uint2 *d_urow, const uint4 *d_ucol
     return 0;
 }
 
-int dev_dict_patterns(const UDesc *d_packed, long long NUP, size_t cap, std::vector<unsigned long long> &sorted_patterns, bool *over)
+int dev_dict_patterns(const UDesc *d_packed, long long NUP, size_t cap, std::vector<uint4> &dict, DictRanges *ranges, bool *over)
 {
-    sorted_patterns.clear(); *over = false;
+    dict.clear(); *over = false;
+    for (int c = 0; c < 9; c++) ranges->off[c] = 0;
     if (NUP <= 0) return 0;
+    // how many units carry each shift code: one sort + run-length pass per code that occurs (plans without absorbed entries: code 0 only, the whole array as before)
+    Tmp<unsigned long long> hist;
+    PD_TRY(hist.alloc(9, true));
+    hipLaunchKernelGGL(k_pd_shift_hist, dim3((unsigned)std::min<long long>(nblk(NUP, 256), 4096)), dim3(256), 0, 0, d_packed, NUP, hist.p);
+    PD_TRY(hipGetLastError());
+    unsigned long long h[9];
+    PD_TRY(hipMemcpy(h, hist.p, sizeof(h), hipMemcpyDeviceToHost));
     Tmp<u64> a, b, uniq; Tmp<int> counts, nruns;
     PD_TRY(a.alloc((size_t)NUP, false)); PD_TRY(b.alloc((size_t)NUP, false));
-    hipLaunchKernelGGL(k_pd_patterns, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, NUP, a.p);
-    PD_TRY(hipGetLastError());
-    u64 *k_cur = a.p, *k_alt = b.p;
-    size_t tmp_b = 0; void *tmp = nullptr;
-    PD_TRY(prims::sort_keys_u64(nullptr, tmp_b, k_cur, k_alt, (size_t)NUP, 0u, 64u, (hipStream_t)0));
-    PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
-    hipError_t e = prims::sort_keys_u64(tmp, tmp_b, k_cur, k_alt, (size_t)NUP, 0u, 64u, (hipStream_t)0);
-    (void)hipDeviceSynchronize();
-    (void)hipFree(tmp);
-    PD_TRY(e);
     PD_TRY(uniq.alloc((size_t)NUP, false)); PD_TRY(counts.alloc((size_t)NUP, false)); PD_TRY(nruns.alloc(1, true));
-    tmp_b = 0; tmp = nullptr;
-    PD_TRY(prims::rle_u64(nullptr, tmp_b, k_cur, 0u, (unsigned)NUP, uniq.p, counts.p, nruns.p, (hipStream_t)0));
-    PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
-    e = prims::rle_u64(tmp, tmp_b, k_cur, 0u, (unsigned)NUP, uniq.p, counts.p, nruns.p, (hipStream_t)0);
-    int n = 0;
-    if (e == hipSuccess) e = hipMemcpy(&n, nruns.p, sizeof(int), hipMemcpyDeviceToHost);
-    (void)hipFree(tmp);
-    PD_TRY(e);
-    if ((size_t)n > cap) { *over = true; return 0; }
-    sorted_patterns.resize((size_t)n);
-    PD_TRY(hipMemcpy(sorted_patterns.data(), uniq.p, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+    std::vector<u64> got;
+    for (unsigned code = 0; code < 8; code++) {
+        ranges->off[code] = (int)dict.size();
+        const long long nc = (long long)h[code];
+        if (nc == 0) continue;
+        PD_TRY(hipMemset(hist.p + 8, 0, sizeof(unsigned long long)));
+        hipLaunchKernelGGL(k_pd_patterns, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, NUP, code, nc == NUP, a.p, hist.p + 8);
+        PD_TRY(hipGetLastError());
+        u64 *k_cur = a.p, *k_alt = b.p;
+        size_t tmp_b = 0; void *tmp = nullptr;
+        PD_TRY(prims::sort_keys_u64(nullptr, tmp_b, k_cur, k_alt, (size_t)nc, 0u, 64u, (hipStream_t)0));
+        PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
+        hipError_t e = prims::sort_keys_u64(tmp, tmp_b, k_cur, k_alt, (size_t)nc, 0u, 64u, (hipStream_t)0);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(tmp);
+        PD_TRY(e);
+        PD_TRY(hipMemset(nruns.p, 0, sizeof(int)));
+        tmp_b = 0; tmp = nullptr;
+        PD_TRY(prims::rle_u64(nullptr, tmp_b, k_cur, 0u, (unsigned)nc, uniq.p, counts.p, nruns.p, (hipStream_t)0));
+        PD_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_b, 16)));
+        e = prims::rle_u64(tmp, tmp_b, k_cur, 0u, (unsigned)nc, uniq.p, counts.p, nruns.p, (hipStream_t)0);
+        int n = 0;
+        if (e == hipSuccess) e = hipMemcpy(&n, nruns.p, sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        PD_TRY(e);
+        if (dict.size() + (size_t)n > cap) { *over = true; dict.clear(); return 0; }
+        got.resize((size_t)n);
+        PD_TRY(hipMemcpy(got.data(), uniq.p, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+        for (u64 k : got) dict.push_back(make_uint4((unsigned)(k >> 32), (unsigned)(k & 0xffffffffull), code << UNIT_SHIFT_SHIFT, 0u));
+    }
+    ranges->off[8] = (int)dict.size();
     return 0;
 }
 
@@ -680,10 +713,10 @@ int dev_pool_compact(const UDesc *d_packed, const URow *d_packed_row, long long 
     return 0;
 }
 
-int dev_compact_desc(const UDesc *d_packed, long long NUP, const uint2 *d_dict, int ndict, int cb_bits, unsigned *d_compact)
+int dev_compact_desc(const UDesc *d_packed, long long NUP, const uint4 *d_dict, DictRanges ranges, int cb_bits, unsigned *d_compact)
 {
     if (NUP <= 0) return 0;
-    hipLaunchKernelGGL(k_pd_compact, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, NUP, d_dict, ndict, cb_bits, d_compact);
+    hipLaunchKernelGGL(k_pd_compact, dim3(nblk(NUP, 256)), dim3(256), 0, 0, d_packed, NUP, d_dict, ranges, cb_bits, d_compact);
     PD_TRY(hipGetLastError());
     PD_TRY(hipDeviceSynchronize());
     return 0;

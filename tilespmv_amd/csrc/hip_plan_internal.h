@@ -64,6 +64,7 @@ struct Knobs {
     int x_slice_passes;  // column slices pinned to XCDs: passes (8 slices each); 0 off, -1 chosen by timing beside the panelled forms
     int placement_tries; // large plans: arena placements timed at plan creation (-1 by size, 0 / 1 off, n)
     int deterministic;   // 1: nothing is chosen by timing, every sum in a plan-fixed order (tilespmv_plan_options.deterministic)
+    int absorb;          // 1 (default): list entries next to an ELL tile go into its padding slots (plan_tile_ops.h "absorbed list entries"); 0 = never
     int desc_dict;       // 0 = always 12-B unit descriptors; -1 = 4-B descriptors + pattern dictionary where the shard allows and it pays; 1 = wherever it allows; 2 = like 1 (pooled plans: 8-byte pairs instead of 4-byte words)
     bool xcd_from_caller, entry_from_caller, strip_from_caller;   // the autotuner leaves alone what the caller pinned
     bool dry;            // tilespmv_plan_layout_digest: build the layout on the host only, hash instead of upload

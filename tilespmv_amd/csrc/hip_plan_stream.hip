@@ -15,11 +15,11 @@ namespace {
 struct RowCount { int nunits, ncoo, nheavy, ndense; long long hval, hidx; long long cost; };
 
 // One tile-row's counts: the sum of its tiles' (plan_tile_ops.h tile_count) plus, in pooled plans, its pool's windows.  `scratch`: room for the tile-row's stored nonzeros (pooled plans)
-inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, int coo_cost, const long long *hyb_off, std::vector<PoolEnt> &scratch, long long *pool_stat = nullptr)
+inline RowCount count_row(const Tile_matrix *T, int bi, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, bool absorb, int coo_cost, const long long *hyb_off, std::vector<PoolEnt> &scratch, long long *pool_stat = nullptr)
 {
     RowCount c{0, 0, 0, 0, 0, 0, 0};
     for (int t = T->tile_ptr[bi]; t < T->tile_ptr[bi + 1]; t++) {
-        const TileCount k = tile_count(T, t, rowlen, tilen, colA, coo_in_tile, dense_mfma, csr_form);
+        const TileCount k = tile_count(T, t, rowlen, tilen, colA, coo_in_tile, dense_mfma, csr_form, absorb && csr_form < 2, T->tile_ptr[bi], T->tile_ptr[bi + 1]);
         c.nunits += k.nunits; c.ncoo += k.ncoo; c.nheavy += k.nheavy; c.ndense += k.ndense; c.hval += k.hval; c.hidx += k.hidx;
     }
     if (csr_form >= 2) {
@@ -102,7 +102,7 @@ struct StreamBuilder {
     const DevTile *DT = nullptr;
     int rc = 0;
     // COUNT
-    bool csr_split = true, pooled = false, wide = false; int csr_form = 1, target_in = 0, split_above_in = 0, tilem = 0, tilen = 0, ntr = 0, sv = 0;
+    bool csr_split = true, pooled = false, wide = false, absorb = false; int csr_form = 1, target_in = 0, split_above_in = 0, tilem = 0, tilen = 0, ntr = 0, sv = 0;
     hvec<RowCount> rc_;   // (hvec: huge-page advice on the large per-tile-row arrays, host_util.h)
     hvec<long long> pu, pc, ph, phv, phi, pd;
     long long NU = 0, NC = 0, NH = 0, NHV = 0, NHI = 0, ND = 0;
@@ -185,9 +185,10 @@ void StreamBuilder::count()
     // 5 % smaller than the split form's WITH 4-byte dictionary descriptors (whether the dictionary applies is only known once the units exist: the split form gets the benefit
     // of the doubt, so stencil-like shards with a few CSR tiles — KKT, unaligned grids — keep their 4-byte descriptors).
     csr_form = K.csr_split < 0 ? 1 : std::min(K.csr_split, 3);
+    absorb = K.absorb != 0 && coo_in_tile;   // (classic forms only: the per-tile functions ignore it in pooled plans)
     const int t_begin = T->tile_ptr[tr0], t_end = T->tile_ptr[tr1];
     if (DT) {
-        DS = DevShard{DT, tr0, tr1, t_begin, t_end, coo_in_tile, dense_mfma, 0, 0};
+        DS = DevShard{DT, tr0, tr1, t_begin, t_end, coo_in_tile, dense_mfma, 0, 0, absorb};
         const long long idx[2] = {t_begin, t_end}; int v[2] = {0, 0};
         if (dev_fetch_ints(DT->T.blknnz, idx, 2, v) != 0) { rc = -3; return; }
         DS.stored0 = v[0]; DS.stored = (long long)v[1] - v[0];
@@ -212,7 +213,7 @@ void StreamBuilder::count()
         parallel_chunks(ntr, 1024, [&](int64_t b, int64_t e, int) {
             std::vector<PoolEnt> scratch;
             long long st[2] = {0, 0};
-            for (int64_t i = b; i < e; i++) out[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, form, K.coo_cost, hyb_ptr(), scratch, st);
+            for (int64_t i = b; i < e; i++) out[i] = count_row(T, tr0 + (int)i, tile_rowlen(tr0 + (int)i, tilem, rowA), tilen, colA, coo_in_tile, dense_mfma, form, absorb, K.coo_cost, hyb_ptr(), scratch, st);
             std::lock_guard<std::mutex> lk(stat_mutex);
             pool_units_of[form & 3] += st[0]; pool_lines_of[form & 3] += st[1];
         });
@@ -594,7 +595,7 @@ void StreamBuilder::emit()
                     repack_tile(T, t, em, rowlen, tile_collen(cb, tilen, colA), 0, h_hval + hv, h_hidx + hi);
                     h_hdesc[(size_t)h] = make_uint2((unsigned)cb, (unsigned)em.fmt | ((unsigned)em.p1 << DESC_P1_SHIFT));
                     h++; hv += em.nv; hi += em.ni;
-                } else tile_emit(T, t, rowlen, tilen, colA, coo_in_tile, dense_mfma, csr_form, kr, hyb_ptr(), O, pos);   // (plan_tile_ops.h: shared with the device builder)
+                } else tile_emit(T, t, rowlen, tilen, colA, coo_in_tile, dense_mfma, csr_form, kr, hyb_ptr(), O, pos, absorb && csr_form < 2, T->tile_ptr[bi], T->tile_ptr[bi + 1]);   // (plan_tile_ops.h: shared with the device builder)
             }
             if (pooled) {   // the pooled nonzeros of the tile-row: windows of 16 columns -> units, sparse windows -> list entries
                 pool.resize((size_t)std::max<long long>(1, pool_row_capacity(T, bi)));
@@ -685,8 +686,9 @@ void StreamBuilder::order()
                 avgs[(size_t)si] = wgs ? (double)slots / (double)wgs : 1e30;
             }
         });
+        static const int forced_shape = [] { const char *e = getenv("TILESPMV_BRICK_SHAPE"); return e && *e ? atoi(e) : -1; }();   // (experiment knob, environment only: index into the shape list)
         for (int si = 0; si < nshapes; si++)
-            if (avgs[(size_t)si] < best_avg * 0.98) { best_avg = avgs[(size_t)si]; best_order.swap(orders[(size_t)si]); best_shape = shapes[si]; }
+            if (forced_shape >= 0 && forced_shape < nshapes ? si == forced_shape : avgs[(size_t)si] < best_avg * 0.98) { best_avg = avgs[(size_t)si]; best_order.swap(orders[(size_t)si]); best_shape = shapes[si]; }
         {
             std::vector<STask> permuted(nt);
             for (size_t i = 0; i < nt; i++) permuted[i] = tasks[best_order[i]];
@@ -697,6 +699,7 @@ void StreamBuilder::order()
                     xs1, xs2, best_shape.px, best_shape.py, best_shape.pz, best_avg);
     } else brick = false;
     plan->info[TILESPMV_INFO_BRICK_ORDER] = brick ? 1 : 0;
+    plan->info[TILESPMV_INFO_LIST_ENTRIES] = NC;
     plan->size_hint = (size_t)(NU * (12 + (wide ? 16 : pooled ? 8 : 0) + 16LL * sv) + NC * (2LL * sv + 13) + NHV * sv + NHI + ND * (4 + 256LL * sv) + (long long)tasks.size() * 40);   // estimate of the plan's bytes: picks the block size of upload()
     if (hashing()) { Hash h; h.vec(tasks); h.num(brick); stage_done(TILESPMV_STAGE_ORDER, h); }
 }
@@ -759,15 +762,14 @@ void StreamBuilder::encode_device()
         const int cb_bits = std::max(1, 32 - __builtin_clz((unsigned)std::max(1, T->tilen - 1)));
         const int pid_bits = std::min(DICT_MAX_BITS, 27 - cb_bits);
         if (pid_bits >= 1) {
-            std::vector<unsigned long long> all;
+            std::vector<uint4> dict;   // (the host builder's order: shift code, then nibbles)
+            DictRanges ranges;
             bool over = false;
-            if (dev_dict_patterns(d_packed, NUP, (size_t)1 << pid_bits, all, &over) != 0) rc = -3;
+            if (dev_dict_patterns(d_packed, NUP, (size_t)1 << pid_bits, dict, &ranges, &over) != 0) rc = -3;
             else if (!over) {
-                std::vector<uint2> dict(all.size());
-                for (size_t i = 0; i < all.size(); i++) dict[i] = make_uint2((unsigned)(all[i] >> 32), (unsigned)(all[i] & 0xffffffffull));
                 rc |= plan->upload(dict.data(), dict.size(), &S.udict);
                 rc |= plan->reserve((size_t)NUP, reinterpret_cast<const unsigned **>(&S.udesc));
-                if (rc == 0 && dev_compact_desc(d_packed, NUP, S.udict, (int)dict.size(), cb_bits, reinterpret_cast<unsigned *>(const_cast<UDesc *>(S.udesc))) != 0) rc = -3;
+                if (rc == 0 && dev_compact_desc(d_packed, NUP, S.udict, ranges, cb_bits, reinterpret_cast<unsigned *>(const_cast<UDesc *>(S.udesc))) != 0) rc = -3;
                 S.cb_bits = cb_bits;
             }
         }
@@ -854,7 +856,7 @@ void StreamBuilder::encode()
         // 5- and 7-point grids, 36 in the KKT stand-in): column block | pattern id << cb_bits | flags << 27, the patterns (the
         // two nibble words) in a dictionary the kernels gather from.  Not for x-window plans (their descriptors hold slots).
         S.udict = nullptr; S.cb_bits = 0;
-        std::vector<uint2> dict;
+        std::vector<uint4> dict;   // (nibbles of rows 0-7, of rows 8-15, window shift << UNIT_SHIFT_SHIFT, 0), ascending (shift code, nibbles)
         std::vector<unsigned> compact;
         // ... and only where it pays: 8 bytes per unit must be at least 2 % of the streams (an entry-dominated plan with a handful of units would only buy the dictionary
         // hop at the start of every strip: webbase-1M stand-in 13.2 -> 13.6 us); desc_dict = 1 asks for it wherever it is possible
@@ -864,31 +866,35 @@ void StreamBuilder::encode()
             const int pid_bits = std::min(DICT_MAX_BITS, 27 - cb_bits);
             if (pid_bits >= 1) {
                 const size_t cap = (size_t)1 << pid_bits;
-                std::vector<std::unordered_set<unsigned long long>> local((size_t)host_threads());
+                // a pattern = the unit's window shift (units that took list entries: plan_tile_ops.h; code = word 0 >> UNIT_SHIFT_SHIFT) and its 16 column nibbles
+                typedef std::pair<unsigned, unsigned long long> Pat;
+                std::vector<std::array<std::unordered_set<unsigned long long>, 8>> local((size_t)host_threads());
                 std::atomic<int> over(0);
                 parallel_chunks((int64_t)NUP, 1 << 16, [&](int64_t b, int64_t e, int th) {
                     if (over.load(std::memory_order_relaxed)) return;
-                    std::unordered_set<unsigned long long> &L = local[(size_t)th];
+                    auto &L = local[(size_t)th];
+                    size_t have = 0;
+                    for (auto &q : L) have += q.size();
                     for (int64_t u = b; u < e; u++) {
-                        L.insert(((unsigned long long)packed[(size_t)u].n0 << 32) | packed[(size_t)u].n1);
-                        if (L.size() > cap) { over.store(1); return; }
+                        if (L[packed[(size_t)u].w0 >> UNIT_SHIFT_SHIFT].insert(((unsigned long long)packed[(size_t)u].n0 << 32) | packed[(size_t)u].n1).second) have++;
+                        if (have > cap) { over.store(1); return; }
                     }
                 });
-                std::vector<unsigned long long> all;
+                std::vector<Pat> all;
                 if (!over.load()) {
-                    for (auto &L : local) all.insert(all.end(), L.begin(), L.end());
+                    for (auto &L : local) for (unsigned sc = 0; sc < 8; sc++) for (unsigned long long k : L[sc]) all.push_back(Pat(sc, k));
                     std::sort(all.begin(), all.end());
                     all.erase(std::unique(all.begin(), all.end()), all.end());
                 }
                 if (!over.load() && all.size() <= cap) {
                     dict.resize(all.size());
-                    for (size_t i = 0; i < all.size(); i++) dict[i] = make_uint2((unsigned)(all[i] >> 32), (unsigned)(all[i] & 0xffffffffull));
+                    for (size_t i = 0; i < all.size(); i++) dict[i] = make_uint4((unsigned)(all[i].second >> 32), (unsigned)(all[i].second & 0xffffffffull), all[i].first << UNIT_SHIFT_SHIFT, 0u);
                     compact.resize((size_t)NUP);
                     const unsigned cbmask = (1u << cb_bits) - 1u;
                     parallel_chunks((int64_t)NUP, 1 << 16, [&](int64_t b, int64_t e, int) {
                         for (int64_t u = b; u < e; u++) {
                             const UDesc &d = packed[(size_t)u];
-                            const unsigned long long key = ((unsigned long long)d.n0 << 32) | d.n1;
+                            const Pat key(d.w0 >> UNIT_SHIFT_SHIFT, ((unsigned long long)d.n0 << 32) | d.n1);
                             const unsigned pid = (unsigned)(std::lower_bound(all.begin(), all.end(), key) - all.begin());
                             compact[(size_t)u] = (d.w0 & cbmask) | (pid << cb_bits) | ((d.w0 >> UNIT_FLAG_SHIFT) << 27);
                         }

@@ -28,11 +28,120 @@ TILESPMV_HD inline int csr_split_width(const unsigned char *ptr, int rowlen, int
     return best_w;
 }
 
+// ---- absorbed list entries (round 6; classic plans).  A COO tile next to an ELL tile of the same tile-row often holds the corner entries of a band that leaves the ELL tile by one column
+// (stencils: row 15 -> first column of the next block, row 0 -> last column of the previous one), and the ELL tile's units have padding in exactly those rows.  Such an entry moves
+// into the padding slot: the unit's 16-column window of x then starts `shift` columns beside its block (x index = block * 16 + shift + nibble, shift in [-4, 3], kept in flag bits 5-7 of
+// the descriptor's word 0), the entry leaves the strip's list.  On the 5-point 4096^2 grid every list entry goes that way: no entry phase, and the lines of x the lists touched long
+// before / after the units needed them are fetched once (profiles/r06_config4_x_refetch.txt).  The rule is a pure function of the ELL tile and its two neighbours, evaluated by
+// whoever needs it (the ELL tile's emission, the COO tiles' counts and emission), so host and device builders agree by construction.
+constexpr int ABSORB_MAX = 24;                               // entries one ELL tile takes at most
+constexpr signed char ABSORB_EMPTY = -128;
+struct AbsorbPlan {
+    int n;                                                   // entries taken
+    unsigned char src[ABSORB_MAX], q[ABSORB_MAX];            // from the left (0) / right (1) neighbour, its q-th entry
+    signed char col[16][16];                                 // [unit][row]: column relative to the ELL tile's first column (-4 .. 18), ABSORB_EMPTY = padding
+    unsigned char from[16][16];                              // [unit][row]: where the slot's value comes from: 0 .. 15 = that ELL slot of the same row, 0x80 | k = taken entry k
+    signed char shift[16], lo[16];                           // per unit: window shift; lowest relative column among its slots (what padding slots point at)
+    unsigned short touched;                                  // bit s: unit s differs from the ELL tile's own slot s
+};
+// A taken entry joins its row at its sorted place (a row's slots hold ascending columns, as the ELL pack leaves them): an entry from the left neighbour goes first and moves the row's
+// own entries one slot up — into the padding every row shorter than the tile's width has at its end —, one from the right neighbour goes behind them.  It is taken if afterwards every
+// unit's columns still fit a 16-column window that starts at most 4 columns before / 3 after the block.  (5-point grid: row 0 gains column -1, row 15 column 16, and the three
+// units of the diagonal tile become the three diagonals r - 1, r, r + 1 with shifts -1, 0, +1 and the identity pattern.)
+TILESPMV_HD inline void ell_absorb_plan(const Tile_matrix *T, int e, int t_lo, int t_hi, int rowlen, AbsorbPlan *A)
+{
+    A->n = 0; A->touched = 0;
+    for (int s = 0; s < 16; s++) { A->shift[s] = 0; A->lo[s] = 0; }
+    if (T->Format[e] != TILESPMV_FMT_ELL) return;
+    const int w = T->tilewidth[e], off = T->ell_offset[e], cb = T->tile_columnidx[e];
+    if (w <= 0 || w > 16) return;
+    bool any = false;
+    for (int side = 0; side < 2; side++) {
+        const int tn = e + (side ? 1 : -1);
+        if (tn >= t_lo && tn < t_hi && T->Format[tn] == TILESPMV_FMT_COO && T->tile_columnidx[tn] == cb + (side ? 1 : -1)) any = true;
+    }
+    if (!any) return;
+    // a row's own entries are its first len slots (the ELL pack is left-justified, src/csr2tile.h:452-484); padding = value 0 AND column nibble 0 behind the last slot that is not
+    // (an entry of A with value 0 keeps its slot: the compat data val[i] = i % 10 is one tenth zeros)
+    for (int r = 0; r < 16; r++) {
+        int len = 0;
+        if (r < rowlen)
+            for (int s = 0; s < w; s++)
+                if (T->Blockell_Val[off + s * rowlen + r] != (val_t)0 || nib_at(T->ell_compressedIdx, (long long)off + s * rowlen + r) != 0) len = s + 1;
+        for (int s = 0; s < w; s++) {
+            A->col[s][r] = s < len ? (signed char)nib_at(T->ell_compressedIdx, (long long)off + s * rowlen + r) : ABSORB_EMPTY;
+            A->from[s][r] = (unsigned char)s;
+        }
+    }
+    for (int side = 0; side < 2 && A->n < ABSORB_MAX; side++) {
+        const int tn = e + (side ? 1 : -1);
+        if (tn < t_lo || tn >= t_hi || T->Format[tn] != TILESPMV_FMT_COO || T->tile_columnidx[tn] != cb + (side ? 1 : -1)) continue;
+        const int stored = T->blknnz[tn + 1] - T->blknnz[tn], coff = T->coo_offset[tn];
+        for (int q = 0; q < stored && q < 256 && A->n < ABSORB_MAX; q++) {
+            const unsigned b = T->coo_compressed_Idx[coff + q];
+            const int r = (int)(b >> 4), c = side ? 16 + (int)(b & 15u) : (int)(b & 15u) - 16;
+            if (c < ABSORB_SHIFT_MIN || c > 15 + ABSORB_SHIFT_MAX || r >= rowlen) continue;
+            // the row's slots in order, the new entry at its sorted place
+            signed char ncol[16]; unsigned char nfrom[16];
+            int len = 0; bool placed = false;
+            for (int s = 0; s < w; s++) {
+                if (A->col[s][r] == ABSORB_EMPTY) continue;
+                if (!placed && c < (int)A->col[s][r]) { ncol[len] = (signed char)c; nfrom[len] = (unsigned char)(0x80 | A->n); len++; placed = true; }
+                if (len < 16) { ncol[len] = A->col[s][r]; nfrom[len] = A->from[s][r]; len++; }
+            }
+            if (!placed) { if (len < 16) { ncol[len] = (signed char)c; nfrom[len] = (unsigned char)(0x80 | A->n); len++; placed = true; } }
+            if (!placed || len > w) continue;   // (no padding left in this row)
+            // would every unit still fit its window?
+            bool fits = true;
+            for (int s = 0; s < w && fits; s++) {
+                int lo = 99, hi = -99;
+                for (int rr = 0; rr < 16; rr++) {
+                    const int v = rr == r ? (s < len ? (int)ncol[s] : (int)ABSORB_EMPTY) : (int)A->col[s][rr];
+                    if (v == (int)ABSORB_EMPTY) continue;
+                    lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+                }
+                if (hi >= lo && (hi - lo > 15 || lo < ABSORB_SHIFT_MIN || hi > 15 + ABSORB_SHIFT_MAX)) fits = false;
+            }
+            if (!fits) continue;
+            for (int s = 0; s < w; s++) {
+                const signed char v = s < len ? ncol[s] : ABSORB_EMPTY;
+                const unsigned char f = s < len ? nfrom[s] : (unsigned char)s;
+                if (v != A->col[s][r] || f != A->from[s][r]) A->touched |= (unsigned short)(1u << s);
+                A->col[s][r] = v; A->from[s][r] = f;
+            }
+            A->src[A->n] = (unsigned char)side; A->q[A->n] = (unsigned char)q; A->n++;
+        }
+    }
+    for (int s = 0; s < w; s++) {
+        int lo = 99, hi = -99;
+        for (int r = 0; r < 16; r++) { const int v = A->col[s][r]; if (v == (int)ABSORB_EMPTY) continue; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        A->shift[s] = (signed char)(hi < lo ? 0 : lo < 0 ? lo : hi > 15 ? hi - 15 : 0);
+        A->lo[s] = (signed char)(hi < lo ? 0 : lo);
+    }
+}
+// which entries of COO tile t its ELL neighbours take: taken[q] = 1; returns how many
+TILESPMV_HD inline int coo_absorbed(const Tile_matrix *T, int t, int t_lo, int t_hi, int rowlen, unsigned char *taken)
+{
+    const int stored = T->blknnz[t + 1] - T->blknnz[t];
+    if (taken) for (int q = 0; q < stored && q < 256; q++) taken[q] = 0;
+    int n = 0;
+    for (int side = 0; side < 2; side++) {   // side 0: this tile is the LEFT neighbour of ELL tile t + 1; side 1: the RIGHT neighbour of ELL tile t - 1
+        const int e = t + (side ? -1 : 1);
+        if (e < t_lo || e >= t_hi || T->Format[e] != TILESPMV_FMT_ELL || T->tile_columnidx[e] != T->tile_columnidx[t] + (side ? -1 : 1)) continue;
+        AbsorbPlan A;
+        ell_absorb_plan(T, e, t_lo, t_hi, rowlen, &A);
+        for (int k = 0; k < A.n; k++)
+            if (A.src[k] == (unsigned char)side) { n++; if (taken) taken[A.q[k]] = 1; }
+    }
+    return n;
+}
+
 // What one tile adds to its tile-row's counts.  csr_form: 0 CSR tiles stay whole tiles (their own pass), 1 ELL-style split (w units + list entries), 2 pooled units, 3 wide pooled units
 // (windows of POOL_WIDE_WINDOW columns, one byte of column offset per slot: hip_plan.h)
 // (the pooled nonzeros — CSR tiles, in-tile COO tiles, HYB remainders — are counted per tile-row by pool_row_count, not here).
 struct TileCount { int nunits, ncoo, nheavy, ndense, hval, hidx; };
-TILESPMV_HD inline TileCount tile_count(const Tile_matrix *T, int t, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form)
+// absorb: list entries of COO tiles move into the padding of neighbouring ELL units where they fit (above); [t_lo, t_hi) = the tiles of t's tile-row
+TILESPMV_HD inline TileCount tile_count(const Tile_matrix *T, int t, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, bool absorb = false, int t_lo = 0, int t_hi = 0)
 {
     TileCount c{0, 0, 0, 0, 0, 0};
     const bool pooled = csr_form >= 2;
@@ -45,7 +154,7 @@ TILESPMV_HD inline TileCount tile_count(const Tile_matrix *T, int t, int rowlen,
         if (dense_mfma) c.ndense = 1;
         else c.nunits = tile_collen(T->tile_columnidx[t], tilen, colA);
         break;
-    case TILESPMV_FMT_COO: if (coo_in_tile && !pooled) c.ncoo = stored; break;
+    case TILESPMV_FMT_COO: if (coo_in_tile && !pooled) c.ncoo = stored - (absorb ? coo_absorbed(T, t, t_lo, t_hi, rowlen, nullptr) : 0); break;
     case TILESPMV_FMT_CSR:
         if (pooled) break;
         if (csr_form == 1) { int rem; c.nunits = csr_split_width(T->Blockcsr_Ptr + T->csrptr_offset[t], rowlen, stored, &rem); c.ncoo = rem; }
@@ -196,7 +305,7 @@ TILESPMV_HD inline void put_unit(const EmitOut &O, EmitPos &p, int csr_form, uns
 // Everything one tile emits EXCEPT whole ("heavy") CSR tiles (csr_form 0: host only, hip_plan_stream.hip) and the pooled nonzeros (pool_row_emit).
 // kr = the tile-row's place in its strip; the caller sets the end-of-row flag on the row's last unit afterwards (classic plans).
 TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, unsigned kr, const long long *hyb_off,
-                                  const EmitOut &O, EmitPos &p)
+                                  const EmitOut &O, EmitPos &p, bool absorb = false, int t_lo = 0, int t_hi = 0)
 {
     const bool pooled = csr_form >= 2;
     const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
@@ -204,10 +313,34 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
     switch (fmt) {
     case TILESPMV_FMT_ELL: {
         const int off = T->ell_offset[t];
+        AbsorbPlan A;
+        A.n = 0; A.touched = 0;
+        if (absorb && !pooled) ell_absorb_plan(T, t, t_lo, t_hi, rowlen, &A);
         for (int s = 0; s < w; s++) {
             unsigned long long nibs = 0;
-            for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib_at(T->ell_compressedIdx, (long long)off + s * rowlen + r) << (60 - 4 * r);
-            put_unit(O, p, csr_form, kr, cb, T->Blockell_Val + off + s * rowlen, rowlen, nibs);
+            if (!((A.touched >> s) & 1u)) {
+                for (int r = 0; r < rowlen; r++) nibs |= (unsigned long long)nib_at(T->ell_compressedIdx, (long long)off + s * rowlen + r) << (60 - 4 * r);
+                put_unit(O, p, csr_form, kr, cb, T->Blockell_Val + off + s * rowlen, rowlen, nibs);
+                continue;
+            }
+            // a unit the rule above changed: its window starts `shift` columns beside the block; padding slots point at the window's lowest used column
+            const int sh = A.shift[s], pad = A.lo[s] - sh;
+            val_t vals[16];
+            for (int r = 0; r < 16; r++) {
+                int nb = pad; val_t v = 0;
+                if (A.col[s][r] != ABSORB_EMPTY) {
+                    nb = (int)A.col[s][r] - sh;
+                    const unsigned f = A.from[s][r];
+                    if (f & 0x80u) { const int k = (int)(f & 0x7Fu), tn = t + (A.src[k] ? 1 : -1); v = T->Blockcoo_Val[T->coo_offset[tn] + A.q[k]]; }
+                    else v = T->Blockell_Val[off + (int)f * rowlen + r];
+                }
+                vals[r] = v;
+                nibs |= (unsigned long long)(nb & 15) << (60 - 4 * r);
+            }
+            const long long u = p.u;
+            put_unit(O, p, csr_form, kr, cb, vals, 16, nibs);
+            const unsigned shbits = ((unsigned)sh & 7u) << UNIT_SHIFT_SHIFT;
+            O.udesc[u].x |= shbits; O.udesc[u].z |= shbits;
         }
         break;
     }
@@ -236,7 +369,10 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
     case TILESPMV_FMT_COO:
         if (coo_in_tile && !pooled) {
             const int off = T->coo_offset[t];
+            unsigned char taken[256];
+            const int ntaken = absorb ? coo_absorbed(T, t, t_lo, t_hi, rowlen, taken) : 0;
             for (int q = 0; q < stored; q++) {
+                if (ntaken && q < 256 && taken[q]) continue;   // (in a padding slot of a neighbouring ELL unit)
                 const unsigned char rcb = T->coo_compressed_Idx[off + q];
                 O.cval[p.c] = T->Blockcoo_Val[off + q]; O.ccol[p.c] = cb * 16 + (rcb & 15);
                 O.crow[p.c] = (unsigned char)((kr << 4) | (rcb >> 4)); p.c++;
