@@ -211,3 +211,25 @@ def test_deterministic_switch_turns_every_timed_choice_off(mats):
     assert isl["x_slice_passes"] == 0 and isl["entry_ordered"] == 1      # the switch wins over knobs that would make the sums meet in any order
     pm, ipm = api.plan_layout_stages(tm, rows, n, nnz, entry_mode=2, x_panel_kb=32, x_panel_merge=2, deterministic=1)
     assert ipm["x_panel_merge"] == 2                                      # a FIXED panelled form times nothing and adds in a fixed order: allowed
+
+
+def test_absorbed_entries_are_decided_in_the_count_stage(mats):
+    """Round 6: the corner entries of a stencil's COO tiles move into the padding of the neighbouring ELL units (tilespmv_plan_options.absorb, csrc/plan_tile_ops.h).  The rule is a
+    per-tile function used by COUNT (fewer list entries) and EMIT (shifted units) alike, so every stage from the first one on sees it; on the aligned 7-point grid no list entry is left,
+    the streams shrink, and the descriptor form (4-byte words + dictionary, now keyed by shift and nibbles) stays what it was.  Off: the plan of round 5, stage for stage."""
+    tm, rows, n, nnz = mats["lap3d"]
+    on, ion = api.plan_layout_stages(tm, rows, n, nnz)
+    off, ioff = api.plan_layout_stages(tm, rows, n, nnz, absorb=0)
+    dflt, idf = api.plan_layout_stages(tm, rows, n, nnz, absorb=1)
+    assert on == dflt and ion["list_entries"] == idf["list_entries"]
+    assert "count" in _changed(on, off) and "emit" in _changed(on, off) and "encode" in _changed(on, off)
+    assert ioff["list_entries"] > 0 and ion["list_entries"] == 0 and ion["stream_bytes"] < ioff["stream_bytes"]
+    assert (ion["desc_bytes"], ioff["desc_bytes"]) == (4, 4)
+    # nothing to absorb where COO tiles go to the CSR fallback, or in a matrix without ELL tiles next to COO tiles
+    a, ia = api.plan_layout_stages(tm, rows, n, nnz, coo_mode=api.COO_FALLBACK)
+    b, ib = api.plan_layout_stages(tm, rows, n, nnz, coo_mode=api.COO_FALLBACK, absorb=0)
+    assert a == b and ia["list_entries"] == ib["list_entries"]
+    tm2, rows2, n2, nnz2 = mats["band40"]
+    a, _ = api.plan_layout_stages(tm2, rows2, n2, nnz2)
+    b, _ = api.plan_layout_stages(tm2, rows2, n2, nnz2, absorb=0)
+    assert a == b

@@ -362,7 +362,7 @@ __device__ __forceinline__ long long unit_x_base(unsigned w0) { return (long lon
 // Descriptor word layout in LDS (16 B per unit, two identical-purpose halves so that a lane reads 8 B; HBM holds the
 // 12-B form without the duplicate word, UDesc):
 //   word 0 / word 2 : column block (24 bits) | flags << 24   (flag bit 0 = end of tile-row, bits 1-3 = row in strip,
-//                     bit 4 = row unit)
+//                     bit 4 = row unit, bits 5-7 = signed shift of the unit's window of x: a unit that took list entries, plan_tile_ops.h)
 //   word 1          : column nibbles of rows 0-7  (row 0 in the top nibble)   [row unit: target row]
 //   word 3          : column nibbles of rows 8-15
 // Descriptors reach the lanes through LDS: one coalesced 16-B-per-lane load brings the descriptors of 16

@@ -105,7 +105,7 @@ constexpr long long NT_STREAM_MIN_BYTES = 400ll << 20;   // launches that move m
 constexpr int DICT_MAX_BITS = 10;         // dictionary plans: at most 1024 column patterns (8 KB: stays in the vector L1)
 constexpr int UNIT_FLAG_SHIFT = 24;       // flags live above the 24-bit column block in words 0 and 2
 
-struct UDesc { unsigned w0, n0, n1; };    // 12 bytes in HBM; lanes expand it to (w0, n0, w0, n1) in LDS so that a lane reads one 8-B half
+struct UDesc { unsigned w0, n0, n1; };    // 12 bytes in HBM (w0 = column block | flags << 24: end of row, row in strip, row unit, window shift; n0 / n1 = column nibbles of rows 0-7 / 8-15); lanes expand it to (w0, n0, w0, n1) in LDS so that a lane reads one 8-B half
 
 // ---- pooled units (round 5; the execution form of CSR-format tiles on block-structured / FEM-like shards, where > 90 % of the nonzeros sit in ragged CSR tiles:
 // reference pack src/csr2tile.h:429-451, GPU routine src/tilespmv_cuda.h:531-561).  The nonzeros of a tile-row's CSR tiles, COO tiles and HYB remainders are POOLED in
