@@ -32,7 +32,17 @@ def _mats():
         keep = (c >= 0) & (c < n) & ~((np.tile(np.arange(3), n) == 0) & (r % 7 == 3))
         return G.from_coo(n, n, r[keep], c[keep])
 
-    return {"lap5_128": lambda: G.laplacian5pt(128), "lap5_100": lambda: G.laplacian5pt(100), "lap7_24": lambda: G.laplacian7pt(24),
+    def ell16_full_row():   # an ELL tile of width 16 with one full row (no padding there) between two COO tiles whose entries want in: a first version dropped the full row's last entry
+        ri, cj = [], []
+        for r in range(16):
+            cols = range(16, 32) if r == 6 else [16 + (r + j) % 16 for j in range(11)]
+            ri += [r] * len(cols); cj += list(cols)
+        for r in (3, 5, 6, 7, 10, 14): ri.append(r); cj.append(15)       # left neighbour, last column
+        for r in (2, 6, 9, 13): ri.append(r); cj.append(32)              # right neighbour, first column
+        for r in range(16, 32): ri.append(r); cj.append(r)
+        return G.from_coo(32, 64, ri, cj)
+
+    return {"ell16_full_row": ell16_full_row, "lap5_128": lambda: G.laplacian5pt(128), "lap5_100": lambda: G.laplacian5pt(100), "lap7_24": lambda: G.laplacian7pt(24),
             "band1": lambda: G.band(2000, 1), "band2": lambda: G.band(2000, 2), "band3_cols1003": lambda: G.band(1000, 3, ncols=1003), "band5": lambda: G.band(1500, 5),
             "two_bands": two_bands, "holes": holes, "kkt12": MEDIUM["kkt12"], "allfmt": SMALL["allfmt"], "allfmt_pad5": SMALL["allfmt_pad5"], "rand500x700": SMALL["rand500x700"]}
 

@@ -82,15 +82,17 @@ TILESPMV_HD inline void ell_absorb_plan(const Tile_matrix *T, int e, int t_lo, i
             const int r = (int)(b >> 4), c = side ? 16 + (int)(b & 15u) : (int)(b & 15u) - 16;
             if (c < ABSORB_SHIFT_MIN || c > 15 + ABSORB_SHIFT_MAX || r >= rowlen) continue;
             // the row's slots in order, the new entry at its sorted place
+            int have = 0;
+            for (int s = 0; s < w; s++) have += A->col[s][r] != ABSORB_EMPTY;
+            if (have + 1 > w) continue;   // (no padding left in this row)
             signed char ncol[16]; unsigned char nfrom[16];
             int len = 0; bool placed = false;
             for (int s = 0; s < w; s++) {
                 if (A->col[s][r] == ABSORB_EMPTY) continue;
                 if (!placed && c < (int)A->col[s][r]) { ncol[len] = (signed char)c; nfrom[len] = (unsigned char)(0x80 | A->n); len++; placed = true; }
-                if (len < 16) { ncol[len] = A->col[s][r]; nfrom[len] = A->from[s][r]; len++; }
+                ncol[len] = A->col[s][r]; nfrom[len] = A->from[s][r]; len++;
             }
-            if (!placed) { if (len < 16) { ncol[len] = (signed char)c; nfrom[len] = (unsigned char)(0x80 | A->n); len++; placed = true; } }
-            if (!placed || len > w) continue;   // (no padding left in this row)
+            if (!placed) { ncol[len] = (signed char)c; nfrom[len] = (unsigned char)(0x80 | A->n); len++; }
             // would every unit still fit its window?
             bool fits = true;
             for (int s = 0; s < w && fits; s++) {
