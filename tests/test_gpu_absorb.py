@@ -130,3 +130,57 @@ def test_absorbed_entries_change_no_bit(dtype):
         assert np.array_equal(y1, y2), (name, "not reproducible")
         assert (np.abs(y1.astype(np.float64) - wr) <= TOL[np.dtype(dtype)] * bound + 1e-300).all(), (name, "real values")
     assert absorbed_somewhere > 0
+
+
+def _random_neighbours(seed):
+    """Tile-rows of ELL-like tiles (random width 1 .. 16, rows within a fifth of it, some rows full) with sparse tiles beside them whose few entries hug the shared boundary."""
+    from tilespmv_amd import generators as G
+    rng = np.random.default_rng(seed)
+    ntr, nbc = int(rng.integers(2, 6)), int(rng.integers(6, 14))
+    ri, cj = [], []
+    for tr in range(ntr):
+        b = 0
+        while b < nbc:
+            kind = rng.integers(0, 3)
+            if kind == 0:   # ELL-like tile
+                w = int(rng.integers(1, 17))
+                for r in range(16):
+                    ln = w if rng.random() < 0.4 else max(1, w - int(rng.integers(0, max(1, w // 5) + 1)))
+                    cols = np.sort(rng.choice(16, size=ln, replace=False))
+                    ri += [tr * 16 + r] * ln; cj += (b * 16 + cols).tolist()
+            elif kind == 1:   # sparse tile near a boundary
+                for _ in range(int(rng.integers(1, 9))):
+                    c = int(rng.choice([0, 1, 2, 3, 12, 13, 14, 15, int(rng.integers(0, 16))]))
+                    ri.append(tr * 16 + int(rng.integers(0, 16))); cj.append(b * 16 + c)
+            b += 1
+    ri.append(ntr * 16 - 1); cj.append(nbc * 16 - 1)
+    return G.from_coo(ntr * 16, nbc * 16 - int(rng.integers(0, 9)), np.array(ri), np.minimum(np.array(cj), nbc * 16 - 10))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_absorbed_entries_random_neighbourhoods(dtype):
+    """300 random arrangements of ELL tiles and sparse neighbours (the class in which scripts/big_fuzz.py found the one bug of the first version): default plans, the 12-byte
+    descriptor form and the workgroup entry mode, host- and device-built, against the oracle bit for bit; a good share of the candidates must actually move."""
+    import torch
+    from oracle.oracle import CpuImpl
+    from tilespmv_amd import api
+    O = CpuImpl("oracle", dtype)
+    moved = 0
+    for seed in range(300):
+        m, n, rp, ci = _random_neighbours(seed)
+        nnz, rowA = len(ci), truncated_rows(m)
+        vals, x = values_for("rand", nnz, n, dtype)
+        want = O.spmv(O.tile_create(rowA, n, nnz, rp, ci, vals), rowA, n, nnz, rp, ci, vals, x)["y"]
+        tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype)
+        for kw in (dict(), dict(desc_dict=0), dict(entry_mode=2), dict(csr_split=0), dict(strip_cost=32, split_above=64)):
+            plan = api.Plan(tp, rowA, n, nnz, **kw)
+            y = _run(torch, plan, x, rowA)
+            i1 = plan.info(); plan.close()
+            assert np.array_equal(y, want), (seed, kw, int(np.count_nonzero(y != want)))
+            if not kw:
+                p0 = api.Plan(tp, rowA, n, nnz, absorb=0); moved += p0.info()["list_entries"] - i1["list_entries"]; p0.close()
+        dev = api.Plan.from_csr(rowA, n, nnz, rp, ci, vals, dtype=dtype)
+        assert np.array_equal(_run(torch, dev, x, rowA), want), (seed, "device-built")
+        dev.close()
+        api.Tile_destroy(tp)
+    assert moved > 300
