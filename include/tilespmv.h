@@ -330,8 +330,9 @@ typedef struct {
                            the same launch form and give bit-identical y on any data, run after run and rank after rank (the reference's own timing loop never changes the
                            result either, src/tilespmv_cuda.h:1112-1137).  0 / unset: the defaults described above                       TILESPMV_DETERMINISTIC */
     int absorb;         /* round 6: list entries of a COO tile that sit within a few columns of a neighbouring ELL tile (the corner entries of a band / stencil) move into
-                           that tile's padding slots — the unit's 16-column window of x is shifted by -4 .. 3 columns — instead of going to the strip's entry list:
-                           unset / 1 = where it applies (classic unit plans), 0 = never                                                    TILESPMV_ABSORB */
+                           that tile's padding slots — the unit's 16-column window of x is shifted by -3 .. 3 columns — instead of going to the strip's entry list; and a
+                           unit whose columns are the previous unit's moved one to the right (consecutive diagonals of a band tile) takes that unit's x one lane up
+                           instead of gathering.  unset / 1 = both, where they apply (classic unit plans); 2 = absorbed entries only; 0 = neither                                                    TILESPMV_ABSORB */
     int reserved[1];    /* must be TILESPMV_KNOB_DEFAULT or 0 */
 } tilespmv_plan_options;
 void tilespmv_plan_options_init(tilespmv_plan_options *opts);
@@ -461,7 +462,8 @@ enum {
     TILESPMV_INFO_WG_STRIPS = 16,     /* strips per workgroup of the unit kernel (16 or 32) */
     TILESPMV_INFO_LIST_ENTRIES = 17,      /* nonzeros on the strips' entry lists (COO tiles, HYB / CSR-tile remainders) after the ones that fit the padding of a neighbouring ELL unit moved there
                                              (tilespmv_plan_options.absorb); unit-stream plans, 0 otherwise.  (Until round 6: a retired fact that was always 0) */
-    TILESPMV_INFO_RETIRED_18 = 18,        /* always 0 */
+    TILESPMV_INFO_DERIVED_UNITS = 18,     /* classic unit plans: units that take their x from the previous unit, one lane up, instead of gathering (the consecutive diagonals of a band /
+                                             stencil tile: csrc/plan_tile_ops.h; tilespmv_plan_options.absorb = 2 switches them off).  (Until round 6: a retired fact that was always 0) */
     TILESPMV_INFO_BRICK_ORDER = 19,       /* 1: the strips were regrouped into bricks of the grid (stencil-like shard) */
     TILESPMV_INFO_DESC_BYTES = 20,        /* bytes per unit descriptor in HBM: 12, or 4 (column-pattern dictionary); pooled plans 20, or 8 (pattern dictionary); wide pooled plans 28 */
     TILESPMV_INFO_NT_STREAM = 21,         /* 1: the unit kernel reads the value / entry-record streams with nontemporal loads */

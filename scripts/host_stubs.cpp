@@ -28,6 +28,7 @@ int dev_pattern_sample(const DevShard &, int, int, int, std::vector<unsigned lon
 int dev_emit(const DevShard &, const DevCounts &, const hvec<long long> &, const hvec<long long> &, const hvec<long long> &, const std::vector<unsigned char> &, const std::vector<unsigned char> &, long long, const EmitOut &) { return -3; }
 int dev_fetch_word0(const uint4 *, long long, hvec<unsigned> &) { return -3; }
 int dev_pack_desc(const uint4 *, const uint2 *, const uint4 *, const int4 *, int, UDesc *, URow *, uint4 *) { return -3; }
+int dev_shift_histogram(const UDesc *, long long, unsigned long long *) { return -3; }
 int dev_dict_patterns(const UDesc *, long long, size_t, std::vector<uint4> &, DictRanges *, bool *) { return -3; }
 int dev_compact_desc(const UDesc *, long long, const uint4 *, DictRanges, int, unsigned *) { return -3; }
 int dev_pool_dict(const UDesc *, const URow *, long long, size_t, std::vector<uint4> &, bool *) { return -3; }

@@ -1,8 +1,10 @@
-"""Round 6: list entries absorbed into the padding of neighbouring ELL units (tilespmv_plan_options.absorb; csrc/plan_tile_ops.h "absorbed list entries").
+"""Round 6: list entries absorbed into the padding of neighbouring ELL units, and units that take their x from the previous unit instead of gathering
+(tilespmv_plan_options.absorb; csrc/plan_tile_ops.h "absorbed list entries" / "DERIVED units").
 
 The corner entries of a band / stencil — row 15 -> first column of the next block, row 0 -> last column of the previous one — sit in COO tiles of their own in the reference's
 format (src/csr2tile.h:143-325 picks COO for tiles that sparse) and went to the strips' entry lists; the plan now moves the ones that fit into the padding slots of the ELL tile
-next door and shifts that unit's window of x by -4 .. 3 columns.  Nothing of the result may change: whole y against the oracle bit for bit on the reference's compat data, in
+next door and shifts that unit's window of x by -3 .. 3 columns.  In a band the units of a tile are consecutive diagonals: unit s is unit s - 1 one column further right, so it takes
+the x its predecessor gathered, one lane up (a DPP row rotation), and only lane 15 loads.  Nothing of the result may change: whole y against the oracle bit for bit on the reference's compat data, in
 both value types, host- and device-built plans with the same facts, every entry mode, split rows, shards, SpMM; real-valued data inside the stated tolerance and the same bits twice.
 """
 import numpy as np
@@ -65,7 +67,7 @@ def test_absorbed_entries_change_no_bit(dtype):
     O = CpuImpl("oracle", dtype)
     knob_sets = [dict(), dict(desc_dict=0), dict(entry_mode=0), dict(entry_mode=1), dict(entry_mode=2, entry_ordered=1), dict(entry_mode=2, entry_ordered=0), dict(strip_cost=64, split_above=200),
                  dict(csr_split=0), dict(x_window=2), dict(coo_mode=api.COO_FALLBACK), dict(dense_mode=api.DENSE_VALU), dict(nt_stream=1), dict(xcd_remap=0)]
-    absorbed_somewhere = 0
+    absorbed_somewhere = derived_somewhere = 0
     for name, gen in _mats().items():
         m, n, rp, ci = gen()
         nnz, rowA = len(ci), truncated_rows(m)
@@ -75,13 +77,17 @@ def test_absorbed_entries_change_no_bit(dtype):
         tp = api.Tile_create(rowA, n, nnz, rp, ci, vals, dtype=dtype, hyb=hyb)
         for kw in knob_sets:
             facts = {}
-            for absorb in (0, 1):
+            for absorb in (0, 1, 2):   # off; on, with derived units (the default); on, every unit gathering
                 plan = api.Plan(tp, rowA, n, nnz, absorb=absorb, **kw)
                 y = _run(torch, plan, x, rowA)
                 facts[absorb] = plan.info()
                 plan.close()
                 assert np.array_equal(y, want), (name, kw, absorb, int(np.count_nonzero(y != want)))
-            assert facts[1]["list_entries"] <= facts[0]["list_entries"], (name, kw)
+            assert facts[1]["list_entries"] <= facts[0]["list_entries"] and facts[2]["list_entries"] == facts[1]["list_entries"], (name, kw)
+            assert facts[0]["derived_units"] == 0 and facts[2]["derived_units"] == 0, (name, kw)
+            derived_somewhere += facts[1]["derived_units"]
+            if name in ("lap5_128", "band1") and kw.get("csr_split") != 0 and not kw.get("split_above") and kw.get("coo_mode") != api.COO_FALLBACK:
+                assert facts[1]["derived_units"] > 0, (name, kw)   # consecutive diagonals: every unit but the first of a tile takes its x from its predecessor
             if kw.get("coo_mode") == api.COO_FALLBACK:
                 assert facts[1]["list_entries"] == facts[0]["list_entries"]        # (COO tiles go to the CSR fallback: nothing to absorb)
             absorbed_somewhere += facts[0]["list_entries"] - facts[1]["list_entries"]
@@ -129,7 +135,7 @@ def test_absorbed_entries_change_no_bit(dtype):
         p.close(); api.Tile_destroy(tr)
         assert np.array_equal(y1, y2), (name, "not reproducible")
         assert (np.abs(y1.astype(np.float64) - wr) <= TOL[np.dtype(dtype)] * bound + 1e-300).all(), (name, "real values")
-    assert absorbed_somewhere > 0
+    assert absorbed_somewhere > 0 and derived_somewhere > 0
 
 
 def _random_neighbours(seed):

@@ -222,6 +222,9 @@ def test_absorbed_entries_are_decided_in_the_count_stage(mats):
     off, ioff = api.plan_layout_stages(tm, rows, n, nnz, absorb=0)
     dflt, idf = api.plan_layout_stages(tm, rows, n, nnz, absorb=1)
     assert on == dflt and ion["list_entries"] == idf["list_entries"]
+    gather, ig = api.plan_layout_stages(tm, rows, n, nnz, absorb=2)   # absorbed entries, but no derived units: the same counts and cuts, other descriptors
+    assert ion["derived_units"] > 0 and ig["derived_units"] == 0 and ioff["derived_units"] == 0 and ig["list_entries"] == ion["list_entries"]
+    assert _changed(on, gather) == ["emit", "encode", "finish"] or _changed(on, gather) == ["emit", "encode"], _changed(on, gather)
     assert "count" in _changed(on, off) and "emit" in _changed(on, off) and "encode" in _changed(on, off)
     assert ioff["list_entries"] > 0 and ion["list_entries"] == 0 and ion["stream_bytes"] < ioff["stream_bytes"]
     assert (ion["desc_bytes"], ioff["desc_bytes"]) == (4, 4)

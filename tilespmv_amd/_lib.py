@@ -18,7 +18,7 @@ _CACHE = {}
 
 INFO_NAMES = ["device_bytes", "stream_bytes", "nnz", "rows", "tiles", "coo_mode", "dense_mode", "kernel",
               "num_tasks", "num_split_rows", "fallback_nnz", "build_us", "upload_us", "entry_mode", "entry_ordered", "strip_cost",
-              "wg_strips", "list_entries", "retired_18", "brick_order", "desc_bytes", "nt_stream", "retired_22", "retired_23", "placement_tries", "retired_25", "x_panels", "x_panel_merge", "scattered_entries", "x_slice_passes", "csr_form", "timed_choices_us", "device_build", "tile_create_us"]
+              "wg_strips", "list_entries", "derived_units", "brick_order", "desc_bytes", "nt_stream", "retired_22", "retired_23", "placement_tries", "retired_25", "x_panels", "x_panel_merge", "scattered_entries", "x_slice_passes", "csr_form", "timed_choices_us", "device_build", "tile_create_us"]
 
 
 KNOB_DEFAULT = -1

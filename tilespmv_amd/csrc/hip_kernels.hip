@@ -356,6 +356,14 @@ __device__ __forceinline__ uint4 udesc_expand(const DevStream &S, unsigned w, ui
     const unsigned w0 = (w & ((1u << S.cb_bits) - 1u)) | ((w >> 27) << UNIT_FLAG_SHIFT) | pat.z;   // (pat.z: the pattern's window shift, already at UNIT_SHIFT_SHIFT)
     return make_uint4(w0, pat.x, w0, pat.y);
 }
+// DERIVED units (hip_plan.h UNIT_DERIVED_CODE, plan_tile_ops.h): lanes 0-14 of the strip use the x the previous unit used one lane up (DPP row rotation: a DPP row is one strip),
+// lane 15 the value it loaded itself; every other unit uses what it gathered.  `prev` = the x the previous unit of this strip used.
+template <class X>
+__device__ __forceinline__ X unit_x_use(X gathered, X prev, unsigned w0, int r)
+{
+    const X up = dpp_mov<0x12F>(prev);   // row_ror:15 = lane i reads lane i + 1
+    return ((w0 >> UNIT_SHIFT_SHIFT) == UNIT_DERIVED_CODE && r != 15) ? up : gathered;
+}
 // first column of a classic unit's window of x: column block * 16, moved by the signed shift of a unit that took list entries (hip_plan.h UNIT_SHIFT_SHIFT)
 __device__ __forceinline__ long long unit_x_base(unsigned w0) { return (long long)(w0 & 0xFFFFFFu) * 16 + ((int)w0 >> UNIT_SHIFT_SHIFT); }
 
@@ -706,6 +714,7 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
             const unsigned fl = d[k].x >> 24;
             const unsigned nib = (fl & UNIT_ROWUNIT) ? (unsigned)r : (d[k].y >> (28 - 4 * (r & 7))) & 15u;
             if (TSPMV_DIAG_UNIT_GATHER_SKIP(k)) xv[k] = xv[k - 1];
+            else if ((d[k].x >> UNIT_SHIFT_SHIFT) == UNIT_DERIVED_CODE && r != 15) xv[k] = 0;   // derived unit: only lane 15 loads (unit_x_use gives the others the previous unit's x)
             else xv[k] = x[TSPMV_DIAG_UNIT_X(min(unit_x_base(d[k].x) + nib, xlast))];
         }
     };
@@ -865,6 +874,7 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
             wave_lds_fence();
         }
         int chunk_end = unit_begin + DCHUNK;  // first unit NOT described by the chunk in LDS
+        val_t xprev = 0;   // classic plans: the x the previous unit used (derived units, unit_x_use)
         for (int u = unit_begin; u < unit_end; u += UB) {
             if (u == chunk_end) {  // next descriptor chunk: already in registers, fetch the one after it
                 wave_lds_fence();
@@ -900,7 +910,11 @@ __global__ __launch_bounds__(16 * GPB, ECOO == 1 ? 4 : ECOO == 2 ? (POOL ? POOL_
                     // unconditional adds (a unit past the task's end adds 0 to a row of this strip's slab: its descriptor is the clamped load of the task's last unit): with the add
                     // under a branch the compiler sinks the unit's gather into the branch and waits for it with vmcnt(0) — every unit then pays a full memory round trip
                     retire((u + k < unit_end) ? v[k] * xv[k] : (val_t)0, d[k].x >> 24, rw[k]);
-                } else if (u + k < unit_end) retire(v[k] * xv[k], d[k].x >> 24, d[k].y);
+                } else {
+                    const val_t xu = unit_x_use(xv[k], xprev, d[k].x, r);
+                    xprev = xu;
+                    if (u + k < unit_end) retire(v[k] * xu, d[k].x >> 24, d[k].y);
+                }
             }
 #pragma unroll
             for (int k = 0; k < UB; k++) v[k] = vn[k];
@@ -1306,8 +1320,8 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
     // the next descriptor chunk is prefetched into registers (4 VGPRs) except in the fp64 nvec 4 / 8 variants: there the
     // prefetch pushed the kernel 12 bytes into scratch at 80 VGPRs, and loading the chunk at the switch is 3.4-4.3 % faster
     // (profiles/r03_spmm.txt)
-    // (round 6: the fp32 nvec 8 variant with 12-B descriptors spilled the same 12 bytes: same cure)
-    constexpr bool MV_PREFETCH_DESC = !(sizeof(val_t) == 8 && NVT >= 4) && !(sizeof(val_t) == 4 && NVT >= 8 && !CD);
+    // (round 6: the fp32 nvec 8 variant with 12-B descriptors spilled the same 12 bytes: same cure; with the derived units' carried x also the fp32 nvec 4 one)
+    constexpr bool MV_PREFETCH_DESC = !(sizeof(val_t) == 8 && NVT >= 4) && !(sizeof(val_t) == 4 && NVT >= 4 && !CD);
     __shared__ lacc_t s_c[GROUPS_PER_BLOCK][16][NV];
     __shared__ val_t s_p[GROUPS_PER_BLOCK][16][NV];
     __shared__ uint4 s_d[GROUPS_PER_BLOCK][DCHUNK];
@@ -1504,6 +1518,9 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
         else s_d[g][r] = dcur;
         wave_lds_fence();
         int chunk_end = unit_begin + DCHUNK;
+        val_t xprev[NV];   // the x the previous unit used (derived units, unit_x_use)
+#pragma unroll
+        for (int j = 0; j < NV; j++) xprev[j] = 0;
         for (int u = unit_begin; u < unit_end; u += UB) {
             if (u == chunk_end) {
                 wave_lds_fence();
@@ -1543,7 +1560,11 @@ __global__ __launch_bounds__(256, MV_MIN_WAVES) void k_units_mv(DevStream S, int
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < NV; j++) acc[j] += v[k] * xv[k].v[j];
+                    for (int j = 0; j < NV; j++) {   // (derived units: the previous unit's x one lane up, unit_x_use)
+                        const val_t xu = unit_x_use(xv[k].v[j], xprev[j], d[k].x, r);
+                        xprev[j] = xu;
+                        acc[j] += v[k] * xu;
+                    }
                 }
                 if (fl & UNIT_EOR) {
                     const int kr = (int)((fl >> UNIT_ROW_SHIFT) & 7u);

@@ -99,7 +99,8 @@ constexpr int UNIT_ROW_SHIFT = 1;         // unit flag bits 1-3: tile-row inside
 constexpr unsigned UNIT_ROWUNIT = 16u;    // unit flag bit 4: "row unit" = 16 values of ONE tile row (dense-row tiles);
                                           //   lane = column, word 1/3 hold the target row, result needs a 16-lane reduction
 constexpr int UNIT_SHIFT_SHIFT = 29;      // unit flag bits 5-7 (word 0 bits 29-31): signed window shift of a unit that took list entries (plan_tile_ops.h "absorbed list entries"):
-constexpr int ABSORB_SHIFT_MIN = -4, ABSORB_SHIFT_MAX = 3;   //   x index = column block * 16 + shift + nibble.  Dictionary plans keep the shift with the pattern (DevStream::udict)
+constexpr int ABSORB_SHIFT_MIN = -3, ABSORB_SHIFT_MAX = 3;   //   x index = column block * 16 + shift + nibble.  Dictionary plans keep the shift with the pattern (DevStream::udict)
+constexpr unsigned UNIT_DERIVED_CODE = 4u;                   //   shift code -4: a DERIVED unit — lanes 0-14 take the previous unit's x one lane up, lane 15 loads (plan_tile_ops.h)
 constexpr int UNIT_GROUP = 16 / (int)sizeof(val_t);  // units whose values share one 16-byte lane load (2 in fp64, 4 in fp32)
 constexpr long long NT_STREAM_MIN_BYTES = 400ll << 20;   // launches that move more than this (about 1.6 x the 256 MB Infinity Cache) read their once-read streams nontemporally
 constexpr int DICT_MAX_BITS = 10;         // dictionary plans: at most 1024 column patterns (8 KB: stays in the vector L1)

@@ -65,7 +65,7 @@ static Knobs resolve_knobs(const tilespmv_plan_options *opts)
     k.x_panel_kb = pick(o.x_panel_kb, "TILESPMV_X_PANEL_KB", -1);
     k.x_panel_merge = pick(o.x_panel_merge, "TILESPMV_X_PANEL_MERGE", -1);
     k.x_slice_passes = pick(o.x_slice_passes, "TILESPMV_X_SLICE_PASSES", -1);
-    k.absorb = pick(o.absorb, "TILESPMV_ABSORB", -1) != 0 ? 1 : 0;
+    k.absorb = pick(o.absorb, "TILESPMV_ABSORB", -1); if (k.absorb < 0 || k.absorb > 2) k.absorb = 1;
     k.deterministic = pick(o.deterministic, "TILESPMV_DETERMINISTIC", 0) > 0 ? 1 : 0;
     if (k.deterministic) {   // no stopwatch, no unordered sum: whatever the caller left unset among the timed choices is switched off
         if (k.placement_tries < 0) k.placement_tries = 1;

@@ -20,7 +20,7 @@ struct DevCounts {
     void release();
 };
 
-struct DevShard { const DevTile *D; int tr0, tr1, t_begin, t_end; bool coo_in_tile, dense_mfma; long long stored0, stored; bool absorb = false; };   // absorb: plan_tile_ops.h "absorbed list entries"   // stored: blknnz[t_end] - blknnz[t_begin]
+struct DevShard { const DevTile *D; int tr0, tr1, t_begin, t_end; bool coo_in_tile, dense_mfma; long long stored0, stored; bool absorb = false, derive = false; };   // absorb: plan_tile_ops.h "absorbed list entries"   // stored: blknnz[t_end] - blknnz[t_begin]
 
 // rc 0 or -3 (HIP error, reported on stderr)
 int dev_fetch_ints(const int *d_array, const long long *idx, int n, int *out);   // out[k] = d_array[idx[k]]
@@ -36,6 +36,7 @@ int dev_fetch_word0(const uint4 *d_udesc, long long NU, hvec<unsigned> &w0);
 // ENCODE: units of task i move from [map.x, map.x + map.z) to [map.y, ..) of the packed numbering (padding units in between stay zero)
 int dev_pack_desc(const uint4 *d_udesc, const uint2 *d_urow, const uint4 *d_ucol, const int4 *d_map, int ntasks, UDesc *d_packed, URow *d_packed_row, uint4 *d_packed_col);   // d_map: device copy of the (old begin, new begin, count) triples
 // the distinct (n0, n1) patterns of NUP packed descriptors, ascending, if there are at most `cap` of them (else `over` = true); then the 4-byte form
+int dev_shift_histogram(const UDesc *d_packed, long long NUP, unsigned long long hist[8]);   // units per shift code (word 0 >> UNIT_SHIFT_SHIFT)
 struct DictRanges { int off[9]; };   // dictionary entries of shift code c (word 0 >> UNIT_SHIFT_SHIFT): [off[c], off[c + 1])
 int dev_dict_patterns(const UDesc *d_packed, long long NUP, size_t cap, std::vector<uint4> &dict, DictRanges *ranges, bool *over);   // distinct (shift code, nibbles) patterns in ascending order, as dictionary entries
 int dev_compact_desc(const UDesc *d_packed, long long NUP, const uint4 *d_dict, DictRanges ranges, int cb_bits, unsigned *d_compact);

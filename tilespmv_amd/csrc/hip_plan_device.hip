@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_pd_fill_urow(uint2 *__restrict__ urow, 
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) urow[i] = make_uint2(0x01234567u, 0x89ABCDEFu);   // (units that keep one row per lane: identity)
 }
-__global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, const long long *__restrict__ hyb_off, int t_begin, int nt, int tr0, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, bool absorb,
+__global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, const int *__restrict__ tile_bi, const long long *__restrict__ hyb_off, int t_begin, int nt, int tr0, int rowA, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, bool absorb, bool derive,
                                                          const int *__restrict__ tu, const int *__restrict__ tc, const int *__restrict__ td, const int *__restrict__ pu, const int *__restrict__ pc,
                                                          const int *__restrict__ pd, const unsigned char *__restrict__ row_k, const unsigned char *__restrict__ row_split, const EmitOut O)
 {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_pd_emit_tiles(const Tile_matrix T, cons
     const int t = t_begin + (int)gid, bi = tile_bi[t], i = bi - tr0, a = T.tile_ptr[bi] - t_begin;
     EmitPos p{(long long)pu[i] + tu[gid] - tu[a], (long long)pc[i] + tc[gid] - tc[a], (long long)pd[i] + td[gid] - td[a]};
     const long long u0 = p.u;
-    tile_emit(&T, t, tile_rowlen(bi, T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form, (unsigned)row_k[i], hyb_off, O, p, absorb, T.tile_ptr[bi], T.tile_ptr[bi + 1]);
+    tile_emit(&T, t, tile_rowlen(bi, T.tilem, rowA), T.tilen, colA, coo_in_tile, dense_mfma, csr_form, (unsigned)row_k[i], hyb_off, O, p, absorb, T.tile_ptr[bi], T.tile_ptr[bi + 1], derive && !row_split[i]);
     // the tile that emits the last unit of an unsplit tile-row of a classic plan marks it (the kernel writes y there)
     if (csr_form < 2 && !row_split[i] && p.u > u0 && p.u == pu[i + 1]) { O.udesc[p.u - 1].x |= UNIT_EOR << UNIT_FLAG_SHIFT; O.udesc[p.u - 1].z |= UNIT_EOR << UNIT_FLAG_SHIFT; }
 }
@@ -593,7 +593,7 @@ int dev_emit(const DevShard &S, const DevCounts &C, const hvec<long long> &pu, c
     PD_TRY(d_rk.from(row_k)); PD_TRY(d_rs.from(row_split));
     if (O.urow && NU > 0) { hipLaunchKernelGGL(k_pd_fill_urow, dim3(nblk(NU, 256)), dim3(256), 0, 0, O.urow, NU); PD_TRY(hipGetLastError()); }
     if (nt > 0) {
-        hipLaunchKernelGGL(k_pd_emit_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, D->hyb_off, S.t_begin, nt, S.tr0, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, C.csr_form, S.absorb && C.csr_form < 2, (const int *)C.tu,
+        hipLaunchKernelGGL(k_pd_emit_tiles, dim3(nblk(nt, 256)), dim3(256), 0, 0, D->T, D->tile_bi, D->hyb_off, S.t_begin, nt, S.tr0, D->rowA, D->colA, S.coo_in_tile, S.dense_mfma, C.csr_form, S.absorb && C.csr_form < 2, S.derive && C.csr_form < 2, (const int *)C.tu,
                            (const int *)C.tc, (const int *)C.td, (const int *)d_pu.p, (const int *)d_pc.p, (const int *)d_pd.p, (const unsigned char *)d_rk.p, (const unsigned char *)d_rs.p, O);
         PD_TRY(hipGetLastError());
     }
@@ -624,6 +624,18 @@ int dev_pack_desc(const uint4 *d_udesc, const uint2 *d_urow, const uint4 *d_ucol
     hipLaunchKernelGGL(k_pd_pack_desc, dim3((unsigned)std::min(ntasks, 1 << 20)), dim3(256), 0, 0, d_udesc, d_urow, d_ucol, d_map, ntasks, d_packed, d_packed_row, d_packed_col);
     PD_TRY(hipGetLastError());
     PD_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+int dev_shift_histogram(const UDesc *d_packed, long long NUP, unsigned long long hist[8])
+{
+    for (int c = 0; c < 8; c++) hist[c] = 0;
+    if (NUP <= 0) return 0;
+    Tmp<unsigned long long> h;
+    PD_TRY(h.alloc(8, true));
+    hipLaunchKernelGGL(k_pd_shift_hist, dim3((unsigned)std::min<long long>(nblk(NUP, 256), 4096)), dim3(256), 0, 0, d_packed, NUP, h.p);
+    PD_TRY(hipGetLastError());
+    PD_TRY(hipMemcpy(hist, h.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -102,7 +102,7 @@ struct StreamBuilder {
     const DevTile *DT = nullptr;
     int rc = 0;
     // COUNT
-    bool csr_split = true, pooled = false, wide = false, absorb = false; int csr_form = 1, target_in = 0, split_above_in = 0, tilem = 0, tilen = 0, ntr = 0, sv = 0;
+    bool csr_split = true, pooled = false, wide = false, absorb = false, derive = false; int csr_form = 1, target_in = 0, split_above_in = 0, tilem = 0, tilen = 0, ntr = 0, sv = 0;
     hvec<RowCount> rc_;   // (hvec: huge-page advice on the large per-tile-row arrays, host_util.h)
     hvec<long long> pu, pc, ph, phv, phi, pd;
     long long NU = 0, NC = 0, NH = 0, NHV = 0, NHI = 0, ND = 0;
@@ -186,9 +186,10 @@ void StreamBuilder::count()
     // of the doubt, so stencil-like shards with a few CSR tiles — KKT, unaligned grids — keep their 4-byte descriptors).
     csr_form = K.csr_split < 0 ? 1 : std::min(K.csr_split, 3);
     absorb = K.absorb != 0 && coo_in_tile;   // (classic forms only: the per-tile functions ignore it in pooled plans)
+    derive = absorb && K.absorb != 2;        // derived units (plan_tile_ops.h): absorb = 2 keeps every unit gathering
     const int t_begin = T->tile_ptr[tr0], t_end = T->tile_ptr[tr1];
     if (DT) {
-        DS = DevShard{DT, tr0, tr1, t_begin, t_end, coo_in_tile, dense_mfma, 0, 0, absorb};
+        DS = DevShard{DT, tr0, tr1, t_begin, t_end, coo_in_tile, dense_mfma, 0, 0, absorb, derive};
         const long long idx[2] = {t_begin, t_end}; int v[2] = {0, 0};
         if (dev_fetch_ints(DT->T.blknnz, idx, 2, v) != 0) { rc = -3; return; }
         DS.stored0 = v[0]; DS.stored = (long long)v[1] - v[0];
@@ -595,7 +596,7 @@ void StreamBuilder::emit()
                     repack_tile(T, t, em, rowlen, tile_collen(cb, tilen, colA), 0, h_hval + hv, h_hidx + hi);
                     h_hdesc[(size_t)h] = make_uint2((unsigned)cb, (unsigned)em.fmt | ((unsigned)em.p1 << DESC_P1_SHIFT));
                     h++; hv += em.nv; hi += em.ni;
-                } else tile_emit(T, t, rowlen, tilen, colA, coo_in_tile, dense_mfma, csr_form, kr, hyb_ptr(), O, pos, absorb && csr_form < 2, T->tile_ptr[bi], T->tile_ptr[bi + 1]);   // (plan_tile_ops.h: shared with the device builder)
+                } else tile_emit(T, t, rowlen, tilen, colA, coo_in_tile, dense_mfma, csr_form, kr, hyb_ptr(), O, pos, absorb && csr_form < 2, T->tile_ptr[bi], T->tile_ptr[bi + 1], derive && csr_form < 2 && !row_split[i]);   // (plan_tile_ops.h: shared with the device builder)
             }
             if (pooled) {   // the pooled nonzeros of the tile-row: windows of 16 columns -> units, sparse windows -> list entries
                 pool.resize((size_t)std::max<long long>(1, pool_row_capacity(T, bi)));
@@ -779,6 +780,7 @@ void StreamBuilder::encode_device()
         if (rc == 0 && NUP > 0 && (e = hipMemcpy(const_cast<UDesc *>(S.udesc), d_packed, (size_t)NUP * sizeof(UDesc), hipMemcpyDeviceToDevice)) != hipSuccess) fail("descriptor copy", e);
     }
     plan->info[TILESPMV_INFO_DESC_BYTES] = desc_bytes();
+    if (rc == 0 && !pooled) { unsigned long long hist[8]; if (dev_shift_histogram(d_packed, NUP, hist) != 0) rc = -3; else plan->info[TILESPMV_INFO_DERIVED_UNITS] = (long long)hist[UNIT_DERIVED_CODE]; }
     // the value pass (as in host mode: k_pair_values), its source already on the device
     rc |= plan->reserve((size_t)NUP * 16, &S.uval);
     if (rc == 0) {
@@ -968,6 +970,7 @@ void StreamBuilder::encode()
             rc |= plan->upload(dict.data(), dict.size(), &S.udict);
         } else rc |= plan->upload(packed.data(), (size_t)NUP, &S.udesc);
         plan->info[TILESPMV_INFO_DESC_BYTES] = desc_bytes();
+        if (!pooled) { long long nder = 0; for (long long u = 0; u < NUP; u++) nder += (packed[(size_t)u].w0 >> UNIT_SHIFT_SHIFT) == UNIT_DERIVED_CODE; plan->info[TILESPMV_INFO_DERIVED_UNITS] = nder; }
         if (pooled && !wide && !pool_dict) rc |= plan->upload(packed_row.data(), (size_t)NUP, &S.urow);
         if (wide) rc |= plan->upload(packed_col.data(), (size_t)NUP, &S.ucol);
         if (on_device) {

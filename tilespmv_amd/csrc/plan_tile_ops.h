@@ -43,14 +43,21 @@ struct AbsorbPlan {
     unsigned char from[16][16];                              // [unit][row]: where the slot's value comes from: 0 .. 15 = that ELL slot of the same row, 0x80 | k = taken entry k
     signed char shift[16], lo[16];                           // per unit: window shift; lowest relative column among its slots (what padding slots point at)
     unsigned short touched;                                  // bit s: unit s differs from the ELL tile's own slot s
+    unsigned short derived;                                  // bit s: unit s takes its x from unit s - 1, one lane up (below); dcb / dnib: what its descriptor then holds
+    int dcb[16]; unsigned char dnib[16];
 };
 // A taken entry joins its row at its sorted place (a row's slots hold ascending columns, as the ELL pack leaves them): an entry from the left neighbour goes first and moves the row's
 // own entries one slot up — into the padding every row shorter than the tile's width has at its end —, one from the right neighbour goes behind them.  It is taken if afterwards every
 // unit's columns still fit a 16-column window that starts at most 4 columns before / 3 after the block.  (5-point grid: row 0 gains column -1, row 15 column 16, and the three
 // units of the diagonal tile become the three diagonals r - 1, r, r + 1 with shifts -1, 0, +1 and the identity pattern.)
-TILESPMV_HD inline void ell_absorb_plan(const Tile_matrix *T, int e, int t_lo, int t_hi, int rowlen, AbsorbPlan *A)
+// DERIVED units (round 6, second step): in a band the slots of a row hold consecutive columns, so unit s is unit s - 1 moved one column to the right — lane r of unit s needs the x that
+// lane r + 1 of unit s - 1 has just gathered.  Where that holds for every real slot of lanes 0 .. 14 (the slot one lane up in the previous unit is real and has the same column), unit s
+// does not gather: the kernel rotates the previous unit's x by one lane (DPP) and only lane 15 reads x — the unit's descriptor holds lane 15's column for all sixteen lanes (one address
+// per strip instead of sixteen) and the shift code UNIT_DERIVED_CODE.  5-point grid: the diagonal tile's three units cost one gather and two single-address loads
+// (timing-only probe: -5.5 % on config 4 with a quarter of the derivable units left out, profiles/r06_absorb_ab.txt).
+TILESPMV_HD inline void ell_absorb_plan(const Tile_matrix *T, int e, int t_lo, int t_hi, int rowlen, AbsorbPlan *A, bool derive = false, int tilen = 0)
 {
-    A->n = 0; A->touched = 0;
+    A->n = 0; A->touched = 0; A->derived = 0;
     for (int s = 0; s < 16; s++) { A->shift[s] = 0; A->lo[s] = 0; }
     if (T->Format[e] != TILESPMV_FMT_ELL) return;
     const int w = T->tilewidth[e], off = T->ell_offset[e], cb = T->tile_columnidx[e];
@@ -60,7 +67,7 @@ TILESPMV_HD inline void ell_absorb_plan(const Tile_matrix *T, int e, int t_lo, i
         const int tn = e + (side ? 1 : -1);
         if (tn >= t_lo && tn < t_hi && T->Format[tn] == TILESPMV_FMT_COO && T->tile_columnidx[tn] == cb + (side ? 1 : -1)) any = true;
     }
-    if (!any) return;
+    if (!any && !derive) return;
     // a row's own entries are its first len slots (the ELL pack is left-justified, src/csr2tile.h:452-484); padding = value 0 AND column nibble 0 behind the last slot that is not
     // (an entry of A with value 0 keeps its slot: the compat data val[i] = i % 10 is one tenth zeros)
     for (int r = 0; r < 16; r++) {
@@ -73,7 +80,7 @@ TILESPMV_HD inline void ell_absorb_plan(const Tile_matrix *T, int e, int t_lo, i
             A->from[s][r] = (unsigned char)s;
         }
     }
-    for (int side = 0; side < 2 && A->n < ABSORB_MAX; side++) {
+    for (int side = 0; any && side < 2 && A->n < ABSORB_MAX; side++) {
         const int tn = e + (side ? 1 : -1);
         if (tn < t_lo || tn >= t_hi || T->Format[tn] != TILESPMV_FMT_COO || T->tile_columnidx[tn] != cb + (side ? 1 : -1)) continue;
         const int stored = T->blknnz[tn + 1] - T->blknnz[tn], coff = T->coo_offset[tn];
@@ -119,6 +126,18 @@ TILESPMV_HD inline void ell_absorb_plan(const Tile_matrix *T, int e, int t_lo, i
         for (int r = 0; r < 16; r++) { const int v = A->col[s][r]; if (v == (int)ABSORB_EMPTY) continue; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
         A->shift[s] = (signed char)(hi < lo ? 0 : lo < 0 ? lo : hi > 15 ? hi - 15 : 0);
         A->lo[s] = (signed char)(hi < lo ? 0 : lo);
+    }
+    if (!derive) return;
+    for (int s = 1; s < w; s++) {
+        bool ok = true; int real = 0;
+        for (int r = 0; r < 15 && ok; r++)
+            if (A->col[s][r] != ABSORB_EMPTY) { real++; if (A->col[s - 1][r + 1] != A->col[s][r]) ok = false; }
+        if (!ok || real == 0) continue;
+        // lane 15's column, written so that the descriptor's arithmetic (block * 16 + shift code's -4 + nibble) gives it back
+        const long long a = (long long)cb * 16 + (A->col[s][15] != ABSORB_EMPTY ? (int)A->col[s][15] : 0) + 4;
+        if (a < 4 || (a >> 4) > (long long)tilen - 1) continue;
+        A->derived |= (unsigned short)(1u << s); A->touched |= (unsigned short)(1u << s);
+        A->dcb[s] = (int)(a >> 4); A->dnib[s] = (unsigned char)(a & 15);
     }
 }
 // which entries of COO tile t its ELL neighbours take: taken[q] = 1; returns how many
@@ -307,7 +326,7 @@ TILESPMV_HD inline void put_unit(const EmitOut &O, EmitPos &p, int csr_form, uns
 // Everything one tile emits EXCEPT whole ("heavy") CSR tiles (csr_form 0: host only, hip_plan_stream.hip) and the pooled nonzeros (pool_row_emit).
 // kr = the tile-row's place in its strip; the caller sets the end-of-row flag on the row's last unit afterwards (classic plans).
 TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, unsigned kr, const long long *hyb_off,
-                                  const EmitOut &O, EmitPos &p, bool absorb = false, int t_lo = 0, int t_hi = 0)
+                                  const EmitOut &O, EmitPos &p, bool absorb = false, int t_lo = 0, int t_hi = 0, bool derive = false)
 {
     const bool pooled = csr_form >= 2;
     const int fmt = T->Format[t], stored = T->blknnz[t + 1] - T->blknnz[t], w = T->tilewidth[t];
@@ -316,8 +335,8 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
     case TILESPMV_FMT_ELL: {
         const int off = T->ell_offset[t];
         AbsorbPlan A;
-        A.n = 0; A.touched = 0;
-        if (absorb && !pooled) ell_absorb_plan(T, t, t_lo, t_hi, rowlen, &A);
+        A.n = 0; A.touched = 0; A.derived = 0;
+        if (absorb && !pooled) ell_absorb_plan(T, t, t_lo, t_hi, rowlen, &A, derive, tilen);
         for (int s = 0; s < w; s++) {
             unsigned long long nibs = 0;
             if (!((A.touched >> s) & 1u)) {
@@ -326,12 +345,13 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
                 continue;
             }
             // a unit the rule above changed: its window starts `shift` columns beside the block; padding slots point at the window's lowest used column
-            const int sh = A.shift[s], pad = A.lo[s] - sh;
+            const bool der = (A.derived >> s) & 1u;
+            const int sh = der ? 0 : A.shift[s], pad = der ? (int)A.dnib[s] : A.lo[s] - sh;
             val_t vals[16];
             for (int r = 0; r < 16; r++) {
                 int nb = pad; val_t v = 0;
                 if (A.col[s][r] != ABSORB_EMPTY) {
-                    nb = (int)A.col[s][r] - sh;
+                    nb = der ? (int)A.dnib[s] : (int)A.col[s][r] - sh;
                     const unsigned f = A.from[s][r];
                     if (f & 0x80u) { const int k = (int)(f & 0x7Fu), tn = t + (A.src[k] ? 1 : -1); v = T->Blockcoo_Val[T->coo_offset[tn] + A.q[k]]; }
                     else v = T->Blockell_Val[off + (int)f * rowlen + r];
@@ -340,8 +360,8 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
                 nibs |= (unsigned long long)(nb & 15) << (60 - 4 * r);
             }
             const long long u = p.u;
-            put_unit(O, p, csr_form, kr, cb, vals, 16, nibs);
-            const unsigned shbits = ((unsigned)sh & 7u) << UNIT_SHIFT_SHIFT;
+            put_unit(O, p, csr_form, kr, der ? A.dcb[s] : cb, vals, 16, nibs);
+            const unsigned shbits = (der ? UNIT_DERIVED_CODE : ((unsigned)sh & 7u)) << UNIT_SHIFT_SHIFT;
             O.udesc[u].x |= shbits; O.udesc[u].z |= shbits;
         }
         break;
