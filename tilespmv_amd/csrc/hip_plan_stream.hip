@@ -233,7 +233,13 @@ void StreamBuilder::count()
         if (dev_fetch_ints(DT->T.csr_offset, idx, 2, v) != 0) { rc = -3; return; }
         csr_vals = (long long)v[1] - v[0]; all_vals = DS.stored;
     } else { csr_vals = (long long)T->csr_offset[t_end] - T->csr_offset[t_begin]; all_vals = (long long)T->blknnz[t_end] - T->blknnz[t_begin]; }
-    if (K.csr_split < 0 && !classic_asked && csr_vals > 0 && csr_vals * 33 >= all_vals) {
+    // (round 6: ... or where the classic form leaves a tenth of the shard on entry lists — stencils on grids whose lines are not a multiple of 16 long: their off-diagonals cross the
+    //  tile boundaries at a different row in every tile-row, the pieces are COO tiles of 1-12 entries, and a pooled unit's window starts at any column: 7-point 250^3 0.2505 -> 0.2235 ms,
+    //  5-point 4090^2 0.1835 -> 0.1756; irregular shards are counted too and keep the classic form by the same byte rule)
+    long long e_classic = 0;
+    for (int i = 0; i < ntr; i++) e_classic += rc_[i].ncoo;
+    const bool consider_pooled = K.csr_split < 0 && !classic_asked && ((csr_vals > 0 && csr_vals * 33 >= all_vals) || (coo_in_tile && e_classic * 10 >= all_vals));
+    if (consider_pooled) {
         hvec<RowCount> alt;
         count_all(2, alt);
         if (rc) return;
@@ -277,16 +283,23 @@ void StreamBuilder::count()
         // lives in its entry lists) and the shard would not get column panels (scattered entries over an x of >= 12 MB: the panel / slice launches exist for the
         // classic kernel; band + random fill loses 23 % without them)
         const bool would_panel = (long long)K.coo_cost * e2 * 2 > 16LL * u2 + (long long)K.coo_cost * e2 && (long long)colA * sv >= (12ll << 20);
-        if (pooled_b * 100 <= split_b * 95 && 16 * u2 >= e2 && !would_panel) { rc_.swap(alt); csr_form = 2; std::swap(dcnt, dcnt_alt); dcnt.csr_form = 2; }
+        bool take = pooled_b * 100 <= split_b * 95 && 16 * u2 >= e2 && !would_panel;
+        // the second way in (round 6): a regular shard (its split form would get the dictionary) a tenth of which sat on entry lists, and the pooled windows take at least half of those
+        // entries off the lists — stencils on grids whose lines are not a multiple of 16 long.  There the classic kernel's time does not follow its bytes (its entry phase is the slow part):
+        // any byte saving will do, with the pooled units priced at the 4-byte dictionary words such shards get.  (Irregular shards fail the half: power-law 28.8 -> 25.6 M entries, road
+        // network 20.3 -> 13.6 M, and are 8-23 % slower pooled.)
+        const long long pooled_reg_b = u2 * (4 + 16LL * sv) + e2 * (sv + 5LL) + xy_b;
+        const bool take_regular = !take && coo_in_tile && e_classic * 10 >= all_vals && desc_split == 4 && e2 * 2 <= e1 && pooled_reg_b <= split_b && 16 * u2 >= e2 && !would_panel;
+        if (take || take_regular) { rc_.swap(alt); csr_form = 2; std::swap(dcnt, dcnt_alt); dcnt.csr_form = 2; }
         dcnt_alt.release();
         if (getenv("TILESPMV_PLAN_VERBOSE")) fprintf(stderr, "tilespmv: CSR tiles: split form (%d-byte descriptors) %lld units + %lld entries = %.1f MB, pooled form %lld units + %lld entries = %.1f MB -> %s\n",
-                                                     desc_split, u1, e1, split_b / 1e6, u2, e2, pooled_b / 1e6, csr_form == 2 ? "pooled" : "split");
+                                                     desc_split, u1, e1, split_b / 1e6, u2, e2, pooled_b / 1e6, csr_form == 2 ? (take ? "pooled" : "pooled (regular shard, entries halved)") : "split");
     }
     // ---- wide pooled units (hip_plan.h; csr_form 3): windows of 256 columns take what 16-column windows leave on the entry lists — where the nonzeros are dense enough inside those
     // windows that a unit's 16 gathers still touch few lines of x (window-shuffled FEM / shell meshes: 1.5-3 lines per unit) it wins 5-20 %; where every slot sits on a line of its own
     // (tetrahedral / 2-D meshes shuffled over thousands of nodes, web graphs) the column-ordered entry lists of a whole workgroup share lines better and the wide form loses up to 30 %
     // (profiles/r05_wide_windows.txt).  Counted whenever the 16-column pooled form was, taken by the rule below.
-    if (K.csr_split < 0 && !classic_asked && csr_vals > 0 && csr_vals * 33 >= all_vals) {
+    if (consider_pooled) {
         long long ub = 0, eb = 0;
         for (int i = 0; i < ntr; i++) { ub += rc_[i].nunits; eb += rc_[i].ncoo; }
         hvec<RowCount> alt;
