@@ -44,7 +44,9 @@ def _mats():
         for r in range(16, 32): ri.append(r); cj.append(r)
         return G.from_coo(32, 64, ri, cj)
 
-    return {"ell16_full_row": ell16_full_row, "lap5_128": lambda: G.laplacian5pt(128), "lap5_100": lambda: G.laplacian5pt(100), "lap7_24": lambda: G.laplacian7pt(24),
+    # (lap5_130 / lap7_34: grid lines two columns longer than a multiple of 16 — the off-diagonals' pieces are one-entry-per-row CSR tiles with a two-entry sparse tile beside them:
+    #  CSR tiles host absorbed entries too)
+    return {"ell16_full_row": ell16_full_row, "lap5_130": lambda: G.laplacian5pt(130), "lap7_34": lambda: G.laplacian7pt(34), "lap5_128": lambda: G.laplacian5pt(128), "lap5_100": lambda: G.laplacian5pt(100), "lap7_24": lambda: G.laplacian7pt(24),
             "band1": lambda: G.band(2000, 1), "band2": lambda: G.band(2000, 2), "band3_cols1003": lambda: G.band(1000, 3, ncols=1003), "band5": lambda: G.band(1500, 5),
             "two_bands": two_bands, "holes": holes, "kkt12": MEDIUM["kkt12"], "allfmt": SMALL["allfmt"], "allfmt_pad5": SMALL["allfmt_pad5"], "rand500x700": SMALL["rand500x700"]}
 
@@ -83,14 +85,18 @@ def test_absorbed_entries_change_no_bit(dtype):
                 facts[absorb] = plan.info()
                 plan.close()
                 assert np.array_equal(y, want), (name, kw, absorb, int(np.count_nonzero(y != want)))
-            assert facts[1]["list_entries"] <= facts[0]["list_entries"] and facts[2]["list_entries"] == facts[1]["list_entries"], (name, kw)
+            if facts[0]["csr_form"] == facts[1]["csr_form"]:   # (the form rule looks at what is left on the lists: with fewer entries a shard can keep the classic form that it would otherwise trade for pooled units)
+                assert facts[1]["list_entries"] <= facts[0]["list_entries"], (name, kw)
+            assert facts[2]["list_entries"] == facts[1]["list_entries"], (name, kw)
             assert facts[0]["derived_units"] == 0 and facts[2]["derived_units"] == 0, (name, kw)
             derived_somewhere += facts[1]["derived_units"]
             if name in ("lap5_128", "band1") and kw.get("csr_split") != 0 and not kw.get("split_above") and kw.get("coo_mode") != api.COO_FALLBACK:
                 assert facts[1]["derived_units"] > 0, (name, kw)   # consecutive diagonals: every unit but the first of a tile takes its x from its predecessor
             if kw.get("coo_mode") == api.COO_FALLBACK:
                 assert facts[1]["list_entries"] == facts[0]["list_entries"]        # (COO tiles go to the CSR fallback: nothing to absorb)
-            absorbed_somewhere += facts[0]["list_entries"] - facts[1]["list_entries"]
+            absorbed_somewhere += max(0, facts[0]["list_entries"] - facts[1]["list_entries"])
+            if name == "lap5_130" and not kw:
+                assert facts[1]["list_entries"] * 20 < facts[0]["list_entries"], (facts[0]["list_entries"], facts[1]["list_entries"])   # the pieces of the off-diagonals go into the CSR tiles' units
             if name in ("lap5_128", "band1") and not kw:
                 assert facts[0]["list_entries"] > 0 and facts[1]["list_entries"] == 0, (name, facts[0]["list_entries"], facts[1]["list_entries"])   # every corner entry fits
                 assert facts[1]["stream_bytes"] < facts[0]["stream_bytes"]

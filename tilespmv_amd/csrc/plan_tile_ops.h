@@ -45,7 +45,14 @@ struct AbsorbPlan {
     unsigned short touched;                                  // bit s: unit s differs from the ELL tile's own slot s
     unsigned short derived;                                  // bit s: unit s takes its x from unit s - 1, one lane up (below); dcb / dnib: what its descriptor then holds
     int dcb[16]; unsigned char dnib[16];
+    int w;                                                   // units of the host tile (ELL: its width; CSR tile: its split width)
 };
+// value of the host tile's own slot `f` of row r (AbsorbPlan::from < 16)
+TILESPMV_HD inline val_t absorb_own_value(const Tile_matrix *T, int e, int rowlen, int f, int r)
+{
+    if (T->Format[e] == TILESPMV_FMT_CSR) return T->Blockcsr_Val[T->csr_offset[e] + (T->Blockcsr_Ptr + T->csrptr_offset[e])[r] + f];
+    return T->Blockell_Val[T->ell_offset[e] + f * rowlen + r];
+}
 // A taken entry joins its row at its sorted place (a row's slots hold ascending columns, as the ELL pack leaves them): an entry from the left neighbour goes first and moves the row's
 // own entries one slot up — into the padding every row shorter than the tile's width has at its end —, one from the right neighbour goes behind them.  It is taken if afterwards every
 // unit's columns still fit a 16-column window that starts at most 4 columns before / 3 after the block.  (5-point grid: row 0 gains column -1, row 15 column 16, and the three
@@ -55,13 +62,21 @@ struct AbsorbPlan {
 // does not gather: the kernel rotates the previous unit's x by one lane (DPP) and only lane 15 reads x — the unit's descriptor holds lane 15's column for all sixteen lanes (one address
 // per strip instead of sixteen) and the shift code UNIT_DERIVED_CODE.  5-point grid: the diagonal tile's three units cost one gather and two single-address loads
 // (timing-only probe: -5.5 % on config 4 with a quarter of the derivable units left out, profiles/r06_absorb_ab.txt).
-TILESPMV_HD inline void ell_absorb_plan(const Tile_matrix *T, int e, int t_lo, int t_hi, int rowlen, AbsorbPlan *A, bool derive = false, int tilen = 0)
+// The tile whose units take part: an ELL tile (its slots), or — csr_split, the ELL-style split of CSR tiles — a CSR tile (the first w entries of every row; what lies beyond w stays on the
+// list as before).  A one-entry-per-row piece of an off-diagonal that a grid line two or three columns longer than a multiple of 16 leaves in a tile of its own is such a CSR tile.
+TILESPMV_HD inline bool absorb_host_tile(const Tile_matrix *T, int e, bool csr_split) { return T->Format[e] == TILESPMV_FMT_ELL || (csr_split && T->Format[e] == TILESPMV_FMT_CSR); }
+TILESPMV_HD inline void ell_absorb_plan(const Tile_matrix *T, int e, int t_lo, int t_hi, int rowlen, AbsorbPlan *A, bool derive = false, int tilen = 0, bool csr_split = false)
 {
-    A->n = 0; A->touched = 0; A->derived = 0;
+    A->n = 0; A->touched = 0; A->derived = 0; A->w = 0;
     for (int s = 0; s < 16; s++) { A->shift[s] = 0; A->lo[s] = 0; }
-    if (T->Format[e] != TILESPMV_FMT_ELL) return;
-    const int w = T->tilewidth[e], off = T->ell_offset[e], cb = T->tile_columnidx[e];
+    if (!absorb_host_tile(T, e, csr_split)) return;
+    const bool is_csr = T->Format[e] == TILESPMV_FMT_CSR;
+    const int cb = T->tile_columnidx[e], off = is_csr ? T->csr_offset[e] : T->ell_offset[e], stored_e = T->blknnz[e + 1] - T->blknnz[e];
+    const unsigned char *cptr = is_csr ? T->Blockcsr_Ptr + T->csrptr_offset[e] : nullptr;
+    int w;
+    if (is_csr) { int rem; w = csr_split_width(cptr, rowlen, stored_e, &rem); } else w = T->tilewidth[e];
     if (w <= 0 || w > 16) return;
+    A->w = w;
     bool any = false;
     for (int side = 0; side < 2; side++) {
         const int tn = e + (side ? 1 : -1);
@@ -71,12 +86,15 @@ TILESPMV_HD inline void ell_absorb_plan(const Tile_matrix *T, int e, int t_lo, i
     // a row's own entries are its first len slots (the ELL pack is left-justified, src/csr2tile.h:452-484); padding = value 0 AND column nibble 0 behind the last slot that is not
     // (an entry of A with value 0 keeps its slot: the compat data val[i] = i % 10 is one tenth zeros)
     for (int r = 0; r < 16; r++) {
-        int len = 0;
-        if (r < rowlen)
-            for (int s = 0; s < w; s++)
-                if (T->Blockell_Val[off + s * rowlen + r] != (val_t)0 || nib_at(T->ell_compressedIdx, (long long)off + s * rowlen + r) != 0) len = s + 1;
+        int len = 0, k0 = 0;
+        if (r < rowlen) {
+            if (is_csr) { k0 = cptr[r]; const int k1 = r == rowlen - 1 ? stored_e : cptr[r + 1]; len = k1 - k0 < w ? k1 - k0 : w; }
+            else
+                for (int s = 0; s < w; s++)
+                    if (T->Blockell_Val[off + s * rowlen + r] != (val_t)0 || nib_at(T->ell_compressedIdx, (long long)off + s * rowlen + r) != 0) len = s + 1;
+        }
         for (int s = 0; s < w; s++) {
-            A->col[s][r] = s < len ? (signed char)nib_at(T->ell_compressedIdx, (long long)off + s * rowlen + r) : ABSORB_EMPTY;
+            A->col[s][r] = s >= len ? ABSORB_EMPTY : (signed char)(is_csr ? nib_at(T->csr_compressedIdx, (long long)off + k0 + s) : nib_at(T->ell_compressedIdx, (long long)off + s * rowlen + r));
             A->from[s][r] = (unsigned char)s;
         }
     }
@@ -141,16 +159,16 @@ TILESPMV_HD inline void ell_absorb_plan(const Tile_matrix *T, int e, int t_lo, i
     }
 }
 // which entries of COO tile t its ELL neighbours take: taken[q] = 1; returns how many
-TILESPMV_HD inline int coo_absorbed(const Tile_matrix *T, int t, int t_lo, int t_hi, int rowlen, unsigned char *taken)
+TILESPMV_HD inline int coo_absorbed(const Tile_matrix *T, int t, int t_lo, int t_hi, int rowlen, unsigned char *taken, bool csr_split = false)
 {
     const int stored = T->blknnz[t + 1] - T->blknnz[t];
     if (taken) for (int q = 0; q < stored && q < 256; q++) taken[q] = 0;
     int n = 0;
     for (int side = 0; side < 2; side++) {   // side 0: this tile is the LEFT neighbour of ELL tile t + 1; side 1: the RIGHT neighbour of ELL tile t - 1
         const int e = t + (side ? -1 : 1);
-        if (e < t_lo || e >= t_hi || T->Format[e] != TILESPMV_FMT_ELL || T->tile_columnidx[e] != T->tile_columnidx[t] + (side ? -1 : 1)) continue;
+        if (e < t_lo || e >= t_hi || !absorb_host_tile(T, e, csr_split) || T->tile_columnidx[e] != T->tile_columnidx[t] + (side ? -1 : 1)) continue;
         AbsorbPlan A;
-        ell_absorb_plan(T, e, t_lo, t_hi, rowlen, &A);
+        ell_absorb_plan(T, e, t_lo, t_hi, rowlen, &A, false, 0, csr_split);
         for (int k = 0; k < A.n; k++)
             if (A.src[k] == (unsigned char)side) { n++; if (taken) taken[A.q[k]] = 1; }
     }
@@ -175,7 +193,7 @@ TILESPMV_HD inline TileCount tile_count(const Tile_matrix *T, int t, int rowlen,
         if (dense_mfma) c.ndense = 1;
         else c.nunits = tile_collen(T->tile_columnidx[t], tilen, colA);
         break;
-    case TILESPMV_FMT_COO: if (coo_in_tile && !pooled) c.ncoo = stored - (absorb ? coo_absorbed(T, t, t_lo, t_hi, rowlen, nullptr) : 0); break;
+    case TILESPMV_FMT_COO: if (coo_in_tile && !pooled) c.ncoo = stored - (absorb ? coo_absorbed(T, t, t_lo, t_hi, rowlen, nullptr, csr_form == 1) : 0); break;
     case TILESPMV_FMT_CSR:
         if (pooled) break;
         if (csr_form == 1) { int rem; c.nunits = csr_split_width(T->Blockcsr_Ptr + T->csrptr_offset[t], rowlen, stored, &rem); c.ncoo = rem; }
@@ -323,6 +341,31 @@ TILESPMV_HD inline void put_unit(const EmitOut &O, EmitPos &p, int csr_form, uns
     p.u++;
 }
 
+// Unit s of host tile t as the absorb plan left it (a unit that took entries, whose row slots moved, or that is derived): written at unit index u
+TILESPMV_HD inline void emit_touched_unit(const Tile_matrix *T, int t, int rowlen, const AbsorbPlan &A, int s, int cb, unsigned kr, int csr_form, const EmitOut &O, long long u)
+{
+    // its window starts `shift` columns beside the block; padding slots point at the window's lowest used column (derived units: every lane holds lane 15's column)
+    const bool der = (A.derived >> s) & 1u;
+    const int sh = der ? 0 : A.shift[s], pad = der ? (int)A.dnib[s] : A.lo[s] - sh;
+    unsigned long long nibs = 0;
+    val_t vals[16];
+    for (int r = 0; r < 16; r++) {
+        int nb = pad; val_t v = 0;
+        if (A.col[s][r] != ABSORB_EMPTY) {
+            nb = der ? (int)A.dnib[s] : (int)A.col[s][r] - sh;
+            const unsigned f = A.from[s][r];
+            if (f & 0x80u) { const int k = (int)(f & 0x7Fu), tn = t + (A.src[k] ? 1 : -1); v = T->Blockcoo_Val[T->coo_offset[tn] + A.q[k]]; }
+            else v = absorb_own_value(T, t, rowlen, (int)f, r);
+        }
+        vals[r] = v;
+        nibs |= (unsigned long long)(nb & 15) << (60 - 4 * r);
+    }
+    EmitPos q{u, 0, 0};
+    put_unit(O, q, csr_form, kr, der ? A.dcb[s] : cb, vals, 16, nibs);
+    const unsigned shbits = (der ? UNIT_DERIVED_CODE : ((unsigned)sh & 7u)) << UNIT_SHIFT_SHIFT;
+    O.udesc[u].x |= shbits; O.udesc[u].z |= shbits;
+}
+
 // Everything one tile emits EXCEPT whole ("heavy") CSR tiles (csr_form 0: host only, hip_plan_stream.hip) and the pooled nonzeros (pool_row_emit).
 // kr = the tile-row's place in its strip; the caller sets the end-of-row flag on the row's last unit afterwards (classic plans).
 TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int tilen, int colA, bool coo_in_tile, bool dense_mfma, int csr_form, unsigned kr, const long long *hyb_off,
@@ -336,7 +379,7 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
         const int off = T->ell_offset[t];
         AbsorbPlan A;
         A.n = 0; A.touched = 0; A.derived = 0;
-        if (absorb && !pooled) ell_absorb_plan(T, t, t_lo, t_hi, rowlen, &A, derive, tilen);
+        if (absorb && !pooled) ell_absorb_plan(T, t, t_lo, t_hi, rowlen, &A, derive, tilen, csr_form == 1);
         for (int s = 0; s < w; s++) {
             unsigned long long nibs = 0;
             if (!((A.touched >> s) & 1u)) {
@@ -344,25 +387,8 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
                 put_unit(O, p, csr_form, kr, cb, T->Blockell_Val + off + s * rowlen, rowlen, nibs);
                 continue;
             }
-            // a unit the rule above changed: its window starts `shift` columns beside the block; padding slots point at the window's lowest used column
-            const bool der = (A.derived >> s) & 1u;
-            const int sh = der ? 0 : A.shift[s], pad = der ? (int)A.dnib[s] : A.lo[s] - sh;
-            val_t vals[16];
-            for (int r = 0; r < 16; r++) {
-                int nb = pad; val_t v = 0;
-                if (A.col[s][r] != ABSORB_EMPTY) {
-                    nb = der ? (int)A.dnib[s] : (int)A.col[s][r] - sh;
-                    const unsigned f = A.from[s][r];
-                    if (f & 0x80u) { const int k = (int)(f & 0x7Fu), tn = t + (A.src[k] ? 1 : -1); v = T->Blockcoo_Val[T->coo_offset[tn] + A.q[k]]; }
-                    else v = T->Blockell_Val[off + (int)f * rowlen + r];
-                }
-                vals[r] = v;
-                nibs |= (unsigned long long)(nb & 15) << (60 - 4 * r);
-            }
-            const long long u = p.u;
-            put_unit(O, p, csr_form, kr, der ? A.dcb[s] : cb, vals, 16, nibs);
-            const unsigned shbits = (der ? UNIT_DERIVED_CODE : ((unsigned)sh & 7u)) << UNIT_SHIFT_SHIFT;
-            O.udesc[u].x |= shbits; O.udesc[u].z |= shbits;
+            emit_touched_unit(T, t, rowlen, A, s, cb, kr, csr_form, O, p.u);
+            p.u++;
         }
         break;
     }
@@ -392,7 +418,7 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
         if (coo_in_tile && !pooled) {
             const int off = T->coo_offset[t];
             unsigned char taken[256];
-            const int ntaken = absorb ? coo_absorbed(T, t, t_lo, t_hi, rowlen, taken) : 0;
+            const int ntaken = absorb ? coo_absorbed(T, t, t_lo, t_hi, rowlen, taken, csr_form == 1) : 0;
             for (int q = 0; q < stored; q++) {
                 if (ntaken && q < 256 && taken[q]) continue;   // (in a padding slot of a neighbouring ELL unit)
                 const unsigned char rcb = T->coo_compressed_Idx[off + q];
@@ -457,6 +483,12 @@ TILESPMV_HD inline void tile_emit(const Tile_matrix *T, int t, int rowlen, int t
                         O.crow[p.c] = (unsigned char)((kr << 4) | r); p.c++;
                     }
                 }
+            }
+            if (absorb && ws > 0) {   // the units this tile's neighbours' entries went into, and derived units, rewritten (plan_tile_ops.h "absorbed list entries": CSR tiles host them too)
+                AbsorbPlan A;
+                ell_absorb_plan(T, t, t_lo, t_hi, rowlen, &A, derive, tilen, true);
+                for (int sidx = 0; sidx < ws && sidx < A.w; sidx++)
+                    if ((A.touched >> sidx) & 1u) emit_touched_unit(T, t, rowlen, A, sidx, cb, kr, csr_form, O, u0 + sidx);
             }
         }
         break;
