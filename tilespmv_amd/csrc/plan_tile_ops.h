@@ -30,7 +30,7 @@ TILESPMV_HD inline int csr_split_width(const unsigned char *ptr, int rowlen, int
 
 // ---- absorbed list entries (round 6; classic plans).  A COO tile next to an ELL tile of the same tile-row often holds the corner entries of a band that leaves the ELL tile by one column
 // (stencils: row 15 -> first column of the next block, row 0 -> last column of the previous one), and the ELL tile's units have padding in exactly those rows.  Such an entry moves
-// into the padding slot: the unit's 16-column window of x then starts `shift` columns beside its block (x index = block * 16 + shift + nibble, shift in [-4, 3], kept in flag bits 5-7 of
+// into the padding slot: the unit's 16-column window of x then starts `shift` columns beside its block (x index = block * 16 + shift + nibble, shift in [-3, 3], kept in flag bits 5-7 of
 // the descriptor's word 0), the entry leaves the strip's list.  On the 5-point 4096^2 grid every list entry goes that way: no entry phase, and the lines of x the lists touched long
 // before / after the units needed them are fetched once (profiles/r06_config4_x_refetch.txt).  The rule is a pure function of the ELL tile and its two neighbours, evaluated by
 // whoever needs it (the ELL tile's emission, the COO tiles' counts and emission), so host and device builders agree by construction.
@@ -39,7 +39,7 @@ constexpr signed char ABSORB_EMPTY = -128;
 struct AbsorbPlan {
     int n;                                                   // entries taken
     unsigned char src[ABSORB_MAX], q[ABSORB_MAX];            // from the left (0) / right (1) neighbour, its q-th entry
-    signed char col[16][16];                                 // [unit][row]: column relative to the ELL tile's first column (-4 .. 18), ABSORB_EMPTY = padding
+    signed char col[16][16];                                 // [unit][row]: column relative to the host tile's first column (-3 .. 18), ABSORB_EMPTY = padding
     unsigned char from[16][16];                              // [unit][row]: where the slot's value comes from: 0 .. 15 = that ELL slot of the same row, 0x80 | k = taken entry k
     signed char shift[16], lo[16];                           // per unit: window shift; lowest relative column among its slots (what padding slots point at)
     unsigned short touched;                                  // bit s: unit s differs from the ELL tile's own slot s
@@ -55,13 +55,13 @@ TILESPMV_HD inline val_t absorb_own_value(const Tile_matrix *T, int e, int rowle
 }
 // A taken entry joins its row at its sorted place (a row's slots hold ascending columns, as the ELL pack leaves them): an entry from the left neighbour goes first and moves the row's
 // own entries one slot up — into the padding every row shorter than the tile's width has at its end —, one from the right neighbour goes behind them.  It is taken if afterwards every
-// unit's columns still fit a 16-column window that starts at most 4 columns before / 3 after the block.  (5-point grid: row 0 gains column -1, row 15 column 16, and the three
+// unit's columns still fit a 16-column window that starts at most 3 columns before / after the block.  (5-point grid: row 0 gains column -1, row 15 column 16, and the three
 // units of the diagonal tile become the three diagonals r - 1, r, r + 1 with shifts -1, 0, +1 and the identity pattern.)
 // DERIVED units (round 6, second step): in a band the slots of a row hold consecutive columns, so unit s is unit s - 1 moved one column to the right — lane r of unit s needs the x that
 // lane r + 1 of unit s - 1 has just gathered.  Where that holds for every real slot of lanes 0 .. 14 (the slot one lane up in the previous unit is real and has the same column), unit s
-// does not gather: the kernel rotates the previous unit's x by one lane (DPP) and only lane 15 reads x — the unit's descriptor holds lane 15's column for all sixteen lanes (one address
-// per strip instead of sixteen) and the shift code UNIT_DERIVED_CODE.  5-point grid: the diagonal tile's three units cost one gather and two single-address loads
-// (timing-only probe: -5.5 % on config 4 with a quarter of the derivable units left out, profiles/r06_absorb_ab.txt).
+// does not gather: the kernel rotates the previous unit's x by one lane (DPP) and only lane 15 reads x (the other lanes are masked off: the descriptor holds lane 15's column in every
+// nibble, under the shift code UNIT_DERIVED_CODE).  5-point grid: the diagonal tile's three units cost one gather and two one-lane loads
+// (measured -1.5 % on config 4; a timing-only probe without the one-lane loads had shown -5.5 %: profiles/r06_absorb_ab.txt).
 // The tile whose units take part: an ELL tile (its slots), or — csr_split, the ELL-style split of CSR tiles — a CSR tile (the first w entries of every row; what lies beyond w stays on the
 // list as before).  A one-entry-per-row piece of an off-diagonal that a grid line two or three columns longer than a multiple of 16 leaves in a tile of its own is such a CSR tile.
 TILESPMV_HD inline bool absorb_host_tile(const Tile_matrix *T, int e, bool csr_split) { return T->Format[e] == TILESPMV_FMT_ELL || (csr_split && T->Format[e] == TILESPMV_FMT_CSR); }
